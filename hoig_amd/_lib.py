@@ -1,0 +1,113 @@
+"""ctypes binding of libhoig_hip.so (the C ABI declared in include/hoig_kernels.h).
+
+There is NO fallback: if the shared library is missing, or a symbol the header
+declares is absent, importing this module raises.  Every product op in
+``hoig_amd.ops`` goes through here.
+"""
+import ctypes
+import os
+import re
+import subprocess
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, 'csrc', '_build', 'libhoig_hip.so')
+HEADER_PATH = os.path.join(os.path.dirname(_HERE), 'include', 'hoig_kernels.h')
+
+OK, EINVAL, ELAUNCH, EUNSUPPORTED = 0, -1, -2, -3
+ACT_NONE, ACT_RELU, ACT_LRELU, ACT_TANH, ACT_SIGMOID = 0, 1, 2, 3, 4
+PREC_F32, PREC_BF16X3, PREC_BF16 = 0, 1, 2
+LOSS_L1, LOSS_MSE, LOSS_BCE = 0, 1, 2
+_ERR = {EINVAL: 'invalid argument', ELAUNCH: 'kernel launch failed', EUNSUPPORTED: 'unsupported shape'}
+
+
+class HoigKernelError(RuntimeError):
+    pass
+
+
+class ConvDesc(ctypes.Structure):
+    _fields_ = [(n, ctypes.c_int32) for n in ('B', 'Hi', 'Wi', 'Ci', 'Ho', 'Wo', 'Co', 'R', 'S', 'stride', 'pad',
+                                              'transposed', 'act')] + \
+               [('slope', ctypes.c_float), ('precision', ctypes.c_int32)]
+
+
+def build(verbose=False):
+    """Compile every HIP source for gfx950 into hoig_amd/csrc/_build/libhoig_hip.so."""
+    script = os.path.join(_HERE, 'csrc', 'build.sh')
+    out = subprocess.run(['bash', script], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
+    if verbose or out.returncode != 0:
+        print(out.stdout)
+    if out.returncode != 0:
+        raise RuntimeError('hipcc build of libhoig_hip.so failed')
+    return LIB_PATH
+
+
+def declared_symbols():
+    """Entry points the header declares (used by the CPU test that checks the library exports all of them)."""
+    text = open(HEADER_PATH).read()
+    return sorted(set(re.findall(r'\b(hoig_[a-z0-9_]+)\s*\(', text)) - {'hoig_stream_t'})
+
+
+_vp, _i, _i64, _f = ctypes.c_void_p, ctypes.c_int, ctypes.c_int64, ctypes.c_float
+_SIGS = {
+    'hoig_conv2d_fwd': [ctypes.POINTER(ConvDesc), _vp, _vp, _vp, _vp, _vp],
+    'hoig_conv2d_bwd_data': [ctypes.POINTER(ConvDesc), _vp, _vp, _vp, _vp],
+    'hoig_conv2d_bwd_weight': [ctypes.POINTER(ConvDesc), _vp, _vp, _vp, _vp, _vp],
+    'hoig_inorm_stats': [_vp, _i, _i, _i, _f, _vp, _vp, _vp, _vp],
+    'hoig_inorm_apply': [_vp, _vp, _vp, _i, _vp, _vp, _i, _f, _vp, _vp, _i, _i, _i, _vp],
+    'hoig_inorm_bwd': [_vp, _vp, _vp, _i, _vp, _vp, _vp, _i, _f, _vp, _vp, _vp, _i, _i, _i, _vp, _vp],
+    'hoig_local_attn_fwd': [_vp] * 10 + [_i] * 5 + [_vp],
+    'hoig_local_attn_bwd': [_vp] * 15 + [_i] * 5 + [_vp],
+    'hoig_block_extractor_forward': [_vp, _vp, _vp] + [_i] * 7 + [_vp],
+    'hoig_block_extractor_backward': [_vp] * 5 + [_i] * 7 + [_vp],
+    'hoig_local_attn_reshape_forward': [_vp, _vp] + [_i] * 4 + [_vp],
+    'hoig_local_attn_reshape_backward': [_vp, _vp] + [_i] * 4 + [_vp],
+    'hoig_grid_sample_fwd': [_vp, _vp, _vp] + [_i] * 6 + [_vp],
+    'hoig_grid_sample_bwd': [_vp, _vp, _vp] + [_i] * 6 + [_vp],
+    'hoig_resize_bilinear_ac': [_vp, _vp] + [_i] * 6 + [_vp],
+    'hoig_resize_nearest': [_vp, _vp] + [_i] * 6 + [_vp],
+    'hoig_attn_flow': [_vp, _vp, _i, _i, _vp],
+    'hoig_maxpool2_fwd': [_vp, _vp] + [_i] * 4 + [_vp],
+    'hoig_maxpool2_bwd': [_vp, _vp, _vp, _vp] + [_i] * 4 + [_vp],
+    'hoig_nchw_to_nhwc': [_vp, _vp] + [_i] * 4 + [_vp],
+    'hoig_nhwc_to_nchw': [_vp, _vp] + [_i] * 4 + [_vp],
+    'hoig_copy_channels': [_vp, _vp, _i64, _i, _i, _i, _i, _i, _i, _vp],
+    'hoig_add': [_vp, _vp, _vp, _i64, _vp],
+    'hoig_act_bwd': [_vp, _vp, _vp, _i, _f, _i64, _vp],
+    'hoig_colsum_accum': [_vp, _vp, _i64, _i, _vp],
+    'hoig_compose_fwd': [_vp] * 6 + [_i64, _i, _vp],
+    'hoig_compose_bwd': [_vp] * 11 + [_i64, _i, _vp],
+    'hoig_loss_fwd_bwd': [_i, _vp, _vp, _f, _f, _vp, _vp, _i64, _vp],
+    'hoig_tv_fwd_bwd': [_vp, _f, _f, _vp, _vp, _i, _i, _i, _vp],
+    'hoig_sum': [_vp, _vp, _i64, _vp],
+    'hoig_adam_step': [_vp, _vp, _vp, _vp, _i64, _f, _f, _f, _f, _i, _f, _vp],
+    'hoig_tensor2im_u8': [_vp, _vp] + [_i] * 6 + [_vp],
+}
+
+
+def _load():
+    if not os.path.exists(LIB_PATH):
+        raise ImportError(
+            'hoig_amd: %s not found. The HIP extension is mandatory (no CPU / eager fallback exists); build it with '
+            '`python -c "import __graft_entry__ as g; g.build()"` or `bash hoig_amd/csrc/build.sh`.' % LIB_PATH)
+    lib = ctypes.CDLL(LIB_PATH)
+    for name, args in _SIGS.items():
+        fn = getattr(lib, name)          # AttributeError here = header/library mismatch: fail loudly
+        fn.argtypes = args
+        fn.restype = ctypes.c_int
+    lib.hoig_inorm_workspace_bytes.argtypes = [_i, _i, _i]
+    lib.hoig_inorm_workspace_bytes.restype = ctypes.c_int64
+    lib.hoig_version.argtypes = []
+    lib.hoig_version.restype = ctypes.c_char_p
+    return lib
+
+
+lib = _load()
+
+
+def check(rc, what):
+    if rc != 0:
+        raise HoigKernelError('%s failed: %s (code %d)' % (what, _ERR.get(rc, 'unknown'), rc))
+
+
+def call(name, *args):
+    check(getattr(lib, name)(*args), name)

@@ -1,0 +1,17 @@
+#!/bin/bash
+# Builds libhoig_hip.so (gfx950 code objects) in-tree: hoig_amd/csrc/_build/libhoig_hip.so
+set -e
+cd "$(dirname "$0")"
+mkdir -p _build
+HIPCC=${HIPCC:-/opt/rocm/bin/hipcc}
+FLAGS="-O3 -std=c++17 --offload-arch=gfx950 -fPIC -I../../include -I. -Wno-unused-result"
+pids=()
+for f in conv_igemm conv_igemm_bf16 norm attn sample pointwise; do
+  if [ ! -f _build/$f.o ] || [ $f.hip -nt _build/$f.o ] || [ common.h -nt _build/$f.o ] || [ ../../include/hoig_kernels.h -nt _build/$f.o ]; then
+    $HIPCC $FLAGS -c $f.hip -o _build/$f.o &
+    pids+=($!)
+  fi
+done
+for p in "${pids[@]}"; do wait $p; done
+$HIPCC --offload-arch=gfx950 -shared -fPIC -o _build/libhoig_hip.so _build/*.o
+echo built _build/libhoig_hip.so

@@ -1,0 +1,283 @@
+// Instance normalisation over NHWC fp32 (HBM-bound streaming kernels, 16-B accesses per lane).
+//   reference: nn.InstanceNorm2d (eps 1e-5, biased variance, no running stats) at generator.py:16-22,101-120,154-208,
+//   spade.py:13 (param-free, then SPADE modulate spade.py:36), discriminator.py:37,45 via base_network.py:31.
+// stats  : per (b,c) shifted sums over H*W split across workgroups -> workspace -> fixed-order finalise (deterministic)
+// apply  : y = act((x-mean)*rstd*scale+shift) (+ residual)       scale/shift = 1/0 | weight/bias[c] | 1+gamma/beta
+// bwd    : dx = rstd*(g' - mean(g') - xhat*mean(g'*xhat)),  g' = dy*act'(y)*scale ; affine / SPADE parameter grads
+#include "common.h"
+
+namespace {
+
+constexpr int NT = 256;
+
+__host__ __device__ inline int inorm_chunks(int HW) {
+    int n = (HW + 63) / 64;
+    if (n > 128) n = 128;
+    if (n < 1) n = 1;
+    return n;
+}
+
+// partial[b][chunk][0/1][c] = sum (v - pivot), sum (v - pivot)^2 over the chunk's rows; pivot = x[b][0][c]
+// MODE_BWD: v = g' (sum) and g'*xhat (second sum), no pivot.
+template <bool BWD>
+__global__ __launch_bounds__(NT) void inorm_partial_kernel(const float *__restrict__ x, const float *__restrict__ mean,
+                                                           const float *__restrict__ rstd, int mode,
+                                                           const float *__restrict__ p0, const float *__restrict__ y,
+                                                           const float *__restrict__ dy, int act, float slope, int HW,
+                                                           int C, int nchunks, float *__restrict__ partial) {
+    const int b = blockIdx.y, chunk = blockIdx.x;
+    const int CV = C >> 2;                 // float4 columns
+    const int rows_per = (HW + nchunks - 1) / nchunks;
+    const int r0 = chunk * rows_per, r1 = min(HW, r0 + rows_per);
+    const int lanes_per_row = CV < NT ? CV : NT;
+    const int row_lanes = NT / lanes_per_row;
+    const int cv0 = threadIdx.x % lanes_per_row, rl = threadIdx.x / lanes_per_row;
+    extern __shared__ float red[];         // [row_lanes][2][C]
+    for (int cv = cv0; cv < CV; cv += lanes_per_row) {
+        const int c = cv * 4;
+        float4 s1 = make_float4(0, 0, 0, 0), s2 = make_float4(0, 0, 0, 0);
+        float4 pv = make_float4(0, 0, 0, 0), mu = pv, rs = pv, sc = make_float4(1, 1, 1, 1);
+        if (!BWD) {
+            pv = *reinterpret_cast<const float4 *>(x + (size_t)b * HW * C + c);
+        } else {
+            mu = *reinterpret_cast<const float4 *>(mean + (size_t)b * C + c);
+            rs = *reinterpret_cast<const float4 *>(rstd + (size_t)b * C + c);
+        }
+        for (int r = r0 + rl; r < r1; r += row_lanes) {
+            const size_t off = ((size_t)b * HW + r) * C + c;
+            const float4 v = *reinterpret_cast<const float4 *>(x + off);
+            if (!BWD) {
+                const float dx = v.x - pv.x, dy_ = v.y - pv.y, dz = v.z - pv.z, dw = v.w - pv.w;
+                s1.x += dx; s1.y += dy_; s1.z += dz; s1.w += dw;
+                s2.x += dx * dx; s2.y += dy_ * dy_; s2.z += dz * dz; s2.w += dw * dw;
+            } else {
+                float4 g = *reinterpret_cast<const float4 *>(dy + off);
+                if (act != HOIG_ACT_NONE) {
+                    const float4 yy = *reinterpret_cast<const float4 *>(y + off);
+                    g.x *= hoig_act_grad_from_y(yy.x, act, slope);
+                    g.y *= hoig_act_grad_from_y(yy.y, act, slope);
+                    g.z *= hoig_act_grad_from_y(yy.z, act, slope);
+                    g.w *= hoig_act_grad_from_y(yy.w, act, slope);
+                }
+                if (mode == 2) {
+                    const float4 ga = *reinterpret_cast<const float4 *>(p0 + off);
+                    g.x *= 1.f + ga.x; g.y *= 1.f + ga.y; g.z *= 1.f + ga.z; g.w *= 1.f + ga.w;
+                }
+                const float hx = (v.x - mu.x) * rs.x, hy = (v.y - mu.y) * rs.y, hz = (v.z - mu.z) * rs.z,
+                            hw = (v.w - mu.w) * rs.w;
+                s1.x += g.x; s1.y += g.y; s1.z += g.z; s1.w += g.w;
+                s2.x += g.x * hx; s2.y += g.y * hy; s2.z += g.z * hz; s2.w += g.w * hw;
+            }
+        }
+        (void)sc;
+        float *r_ = red + (size_t)rl * 2 * C;
+        *reinterpret_cast<float4 *>(r_ + c) = s1;
+        *reinterpret_cast<float4 *>(r_ + C + c) = s2;
+    }
+    __syncthreads();
+    float *out = partial + ((size_t)b * nchunks + chunk) * 2 * C;
+    for (int i = threadIdx.x; i < 2 * C; i += NT) {
+        float s = 0.f;
+        for (int k = 0; k < row_lanes; ++k) s += red[(size_t)k * 2 * C + i];
+        out[i] = s;
+    }
+}
+
+__global__ void inorm_finalize_kernel(const float *__restrict__ x, const float *__restrict__ partial, int HW, int C,
+                                      int nchunks, float eps, float *__restrict__ mean, float *__restrict__ rstd,
+                                      int total) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= total) return;
+    const int b = i / C, c = i - b * C;
+    float s1 = 0.f, s2 = 0.f;
+    for (int k = 0; k < nchunks; ++k) {
+        const float *p = partial + ((size_t)b * nchunks + k) * 2 * C;
+        s1 += p[c];
+        s2 += p[C + c];
+    }
+    const float inv = 1.f / (float)HW;
+    const float d = s1 * inv;
+    float var = s2 * inv - d * d;
+    var = var > 0.f ? var : 0.f;
+    mean[i] = x[(size_t)b * HW * C + c] + d;
+    rstd[i] = 1.f / sqrtf(var + eps);
+}
+
+// sums[b][0/1][c] for the backward; affine grads accumulate atomically
+__global__ void inorm_bwd_finalize_kernel(const float *__restrict__ partial, int C, int nchunks, int mode,
+                                          float *__restrict__ sums, float *__restrict__ dweight,
+                                          float *__restrict__ dbias, int total) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= total) return;
+    const int b = i / C, c = i - b * C;
+    float s1 = 0.f, s2 = 0.f;
+    for (int k = 0; k < nchunks; ++k) {
+        const float *p = partial + ((size_t)b * nchunks + k) * 2 * C;
+        s1 += p[c];
+        s2 += p[C + c];
+    }
+    sums[(size_t)b * 2 * C + c] = s1;
+    sums[(size_t)b * 2 * C + C + c] = s2;
+    if (mode == 1) {
+        if (dbias) atomicAdd(&dbias[c], s1);
+        if (dweight) atomicAdd(&dweight[c], s2);
+    }
+}
+
+__global__ __launch_bounds__(NT) void inorm_apply_kernel(const float *__restrict__ x, const float *__restrict__ mean,
+                                                         const float *__restrict__ rstd, int mode,
+                                                         const float *__restrict__ p0, const float *__restrict__ p1,
+                                                         int act, float slope, const float *__restrict__ residual,
+                                                         float *__restrict__ y, int HW, int C, int64_t n4) {
+    const int CV = C >> 2;
+    for (int64_t i = (int64_t)blockIdx.x * NT + threadIdx.x; i < n4; i += (int64_t)gridDim.x * NT) {
+        const int cv = (int)(i % CV);
+        const int64_t pix = i / CV;
+        const int b = (int)(pix / HW);
+        const int c = cv * 4;
+        const float4 v = reinterpret_cast<const float4 *>(x)[i];
+        const float4 mu = *reinterpret_cast<const float4 *>(mean + (size_t)b * C + c);
+        const float4 rs = *reinterpret_cast<const float4 *>(rstd + (size_t)b * C + c);
+        float4 sc = make_float4(1, 1, 1, 1), sh = make_float4(0, 0, 0, 0);
+        if (mode == 1) {
+            sc = *reinterpret_cast<const float4 *>(p0 + c);
+            sh = *reinterpret_cast<const float4 *>(p1 + c);
+        } else if (mode == 2) {
+            sc = reinterpret_cast<const float4 *>(p0)[i];
+            sh = reinterpret_cast<const float4 *>(p1)[i];
+            sc.x += 1.f; sc.y += 1.f; sc.z += 1.f; sc.w += 1.f;
+        }
+        float4 o;
+        o.x = hoig_act((v.x - mu.x) * rs.x * sc.x + sh.x, act, slope);
+        o.y = hoig_act((v.y - mu.y) * rs.y * sc.y + sh.y, act, slope);
+        o.z = hoig_act((v.z - mu.z) * rs.z * sc.z + sh.z, act, slope);
+        o.w = hoig_act((v.w - mu.w) * rs.w * sc.w + sh.w, act, slope);
+        if (residual) {
+            const float4 r = reinterpret_cast<const float4 *>(residual)[i];
+            o.x += r.x; o.y += r.y; o.z += r.z; o.w += r.w;
+        }
+        reinterpret_cast<float4 *>(y)[i] = o;
+    }
+}
+
+__global__ __launch_bounds__(NT) void inorm_bwd_apply_kernel(const float *__restrict__ x, const float *__restrict__ mean,
+                                                             const float *__restrict__ rstd, int mode,
+                                                             const float *__restrict__ p0, const float *__restrict__ y,
+                                                             const float *__restrict__ dy, int act, float slope,
+                                                             const float *__restrict__ sums, float *__restrict__ dx,
+                                                             float *__restrict__ dp0, float *__restrict__ dp1, int HW,
+                                                             int C, int64_t n4) {
+    const int CV = C >> 2;
+    const float inv = 1.f / (float)HW;
+    for (int64_t i = (int64_t)blockIdx.x * NT + threadIdx.x; i < n4; i += (int64_t)gridDim.x * NT) {
+        const int cv = (int)(i % CV);
+        const int64_t pix = i / CV;
+        const int b = (int)(pix / HW);
+        const int c = cv * 4;
+        const float4 v = reinterpret_cast<const float4 *>(x)[i];
+        float4 g = reinterpret_cast<const float4 *>(dy)[i];
+        if (act != HOIG_ACT_NONE) {
+            const float4 yy = reinterpret_cast<const float4 *>(y)[i];
+            g.x *= hoig_act_grad_from_y(yy.x, act, slope);
+            g.y *= hoig_act_grad_from_y(yy.y, act, slope);
+            g.z *= hoig_act_grad_from_y(yy.z, act, slope);
+            g.w *= hoig_act_grad_from_y(yy.w, act, slope);
+        }
+        const float4 mu = *reinterpret_cast<const float4 *>(mean + (size_t)b * C + c);
+        const float4 rs = *reinterpret_cast<const float4 *>(rstd + (size_t)b * C + c);
+        float4 h;
+        h.x = (v.x - mu.x) * rs.x; h.y = (v.y - mu.y) * rs.y; h.z = (v.z - mu.z) * rs.z; h.w = (v.w - mu.w) * rs.w;
+        float4 s1 = *reinterpret_cast<const float4 *>(sums + (size_t)b * 2 * C + c);
+        float4 s2 = *reinterpret_cast<const float4 *>(sums + (size_t)b * 2 * C + C + c);
+        float4 sc = make_float4(1, 1, 1, 1);
+        if (mode == 1) {
+            sc = *reinterpret_cast<const float4 *>(p0 + c);
+            s1.x *= sc.x; s1.y *= sc.y; s1.z *= sc.z; s1.w *= sc.w;
+            s2.x *= sc.x; s2.y *= sc.y; s2.z *= sc.z; s2.w *= sc.w;
+        } else if (mode == 2) {
+            const float4 ga = reinterpret_cast<const float4 *>(p0)[i];
+            sc = make_float4(1.f + ga.x, 1.f + ga.y, 1.f + ga.z, 1.f + ga.w);
+            reinterpret_cast<float4 *>(dp0)[i] = make_float4(g.x * h.x, g.y * h.y, g.z * h.z, g.w * h.w);
+            reinterpret_cast<float4 *>(dp1)[i] = g;
+        }
+        float4 o;
+        o.x = rs.x * (g.x * sc.x - s1.x * inv - h.x * s2.x * inv);
+        o.y = rs.y * (g.y * sc.y - s1.y * inv - h.y * s2.y * inv);
+        o.z = rs.z * (g.z * sc.z - s1.z * inv - h.z * s2.z * inv);
+        o.w = rs.w * (g.w * sc.w - s1.w * inv - h.w * s2.w * inv);
+        reinterpret_cast<float4 *>(dx)[i] = o;
+    }
+}
+
+bool shape_ok(int B, int HW, int C) {
+    if (B <= 0 || HW <= 0 || C <= 0 || (C & 3)) return false;
+    const int CV = C / 4;
+    if (CV < NT && (NT % CV) != 0) return false;
+    return true;
+}
+
+size_t red_bytes(int C) {
+    const int CV = C / 4;
+    const int lanes_per_row = CV < NT ? CV : NT;
+    return (size_t)(NT / lanes_per_row) * 2 * C * sizeof(float);
+}
+
+}  // namespace
+
+extern "C" int64_t hoig_inorm_workspace_bytes(int B, int HW, int C) {
+    return (int64_t)B * (inorm_chunks(HW) + 1) * 2 * C * (int64_t)sizeof(float);
+}
+
+extern "C" int hoig_inorm_stats(const float *x, int B, int HW, int C, float eps, float *mean, float *rstd,
+                                void *workspace, hoig_stream_t stream) {
+    if (!x || !mean || !rstd || !workspace) return HOIG_EINVAL;
+    if (!shape_ok(B, HW, C)) return HOIG_EUNSUPPORTED;
+    hipStream_t st = (hipStream_t)stream;
+    const int nch = inorm_chunks(HW);
+    float *partial = (float *)workspace;
+    inorm_partial_kernel<false><<<dim3(nch, B), NT, red_bytes(C), st>>>(x, nullptr, nullptr, 0, nullptr, nullptr,
+                                                                        nullptr, 0, 0.f, HW, C, nch, partial);
+    HOIG_LAUNCH_CHECK();
+    const int total = B * C;
+    inorm_finalize_kernel<<<(total + 255) / 256, 256, 0, st>>>(x, partial, HW, C, nch, eps, mean, rstd, total);
+    HOIG_LAUNCH_CHECK();
+    return HOIG_OK;
+}
+
+extern "C" int hoig_inorm_apply(const float *x, const float *mean, const float *rstd, int mode, const float *p0,
+                                const float *p1, int act, float slope, const float *residual, float *y, int B, int HW,
+                                int C, hoig_stream_t stream) {
+    if (!x || !mean || !rstd || !y || mode < 0 || mode > 2) return HOIG_EINVAL;
+    if (mode != 0 && (!p0 || !p1)) return HOIG_EINVAL;
+    if (C & 3) return HOIG_EUNSUPPORTED;
+    const int64_t n4 = (int64_t)B * HW * C / 4;
+    inorm_apply_kernel<<<hoig_stream_grid(n4, NT), NT, 0, (hipStream_t)stream>>>(x, mean, rstd, mode, p0, p1, act, slope,
+                                                                               residual, y, HW, C, n4);
+    HOIG_LAUNCH_CHECK();
+    return HOIG_OK;
+}
+
+extern "C" int hoig_inorm_bwd(const float *x, const float *mean, const float *rstd, int mode, const float *p0,
+                              const float *y, const float *dy, int act, float slope, float *dx, float *dp0, float *dp1,
+                              int B, int HW, int C, void *workspace, hoig_stream_t stream) {
+    if (!x || !mean || !rstd || !dy || !dx || !workspace || mode < 0 || mode > 2) return HOIG_EINVAL;
+    if (act != HOIG_ACT_NONE && !y) return HOIG_EINVAL;
+    if (mode != 0 && !p0) return HOIG_EINVAL;
+    if (mode == 2 && (!dp0 || !dp1)) return HOIG_EINVAL;
+    if (!shape_ok(B, HW, C)) return HOIG_EUNSUPPORTED;
+    hipStream_t st = (hipStream_t)stream;
+    const int nch = inorm_chunks(HW);
+    float *partial = (float *)workspace;
+    float *sums = partial + (size_t)B * nch * 2 * C;
+    inorm_partial_kernel<true><<<dim3(nch, B), NT, red_bytes(C), st>>>(x, mean, rstd, mode, p0, y, dy, act, slope, HW, C,
+                                                                       nch, partial);
+    HOIG_LAUNCH_CHECK();
+    const int total = B * C;
+    inorm_bwd_finalize_kernel<<<(total + 255) / 256, 256, 0, st>>>(partial, C, nch, mode, sums, dp0, dp1, total);
+    HOIG_LAUNCH_CHECK();
+    const int64_t n4 = (int64_t)B * HW * C / 4;
+    inorm_bwd_apply_kernel<<<hoig_stream_grid(n4, NT), NT, 0, st>>>(x, mean, rstd, mode, p0, y, dy, act, slope, sums, dx,
+                                                                   dp0, dp1, HW, C, n4);
+    HOIG_LAUNCH_CHECK();
+    return HOIG_OK;
+}

@@ -1,0 +1,417 @@
+// HBM-bound pointwise / reduction kernels of the HOGAN step: layout conversion, channel concat, bias gradients,
+// alpha compositing (trainer.py:400-401), the loss terms of trainer.py:436-481, VGG max-pooling, fused Adam
+// (trainer.py:275-278,425-434) and the eval.py uint8 output stage (utils/util.py:249-264).
+#include "common.h"
+
+namespace {
+constexpr int NT = 256;
+
+__device__ __forceinline__ float block_sum(float v) {
+    __shared__ float part[NT / 64];
+    v = hoig_wave_sum(v);
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    __syncthreads();
+    if (lane == 0) part[w] = v;
+    __syncthreads();
+    float s = 0.f;
+#pragma unroll
+    for (int i = 0; i < NT / 64; ++i) s += part[i];
+    return s;
+}
+
+// ---- layout: 32x32 LDS-tiled transpose between [C][HW] and [HW][C] planes of one image
+__global__ void transpose_kernel(const float *__restrict__ x, float *__restrict__ y, int rows, int cols) {
+    // x: [batch][rows][cols] -> y: [batch][cols][rows]
+    __shared__ float t[32][33];
+    const size_t base = (size_t)blockIdx.z * rows * cols;
+    const int c0 = blockIdx.x * 32, r0 = blockIdx.y * 32;
+    for (int i = threadIdx.y; i < 32; i += blockDim.y) {
+        const int r = r0 + i, c = c0 + threadIdx.x;
+        t[i][threadIdx.x] = (r < rows && c < cols) ? x[base + (size_t)r * cols + c] : 0.f;
+    }
+    __syncthreads();
+    for (int i = threadIdx.y; i < 32; i += blockDim.y) {
+        const int c = c0 + i, r = r0 + threadIdx.x;
+        if (r < rows && c < cols) y[base + (size_t)c * rows + r] = t[threadIdx.x][i];
+    }
+}
+
+__global__ void copy_channels_kernel(const float *__restrict__ x, float *__restrict__ y, int64_t npix, int Cx, int x_off,
+                                     int Cy, int y_off, int Cc, int accumulate) {
+    const int64_t n = npix * Cc;
+    for (int64_t i = (int64_t)blockIdx.x * NT + threadIdx.x; i < n; i += (int64_t)gridDim.x * NT) {
+        const int64_t p = i / Cc;
+        const int c = (int)(i - p * Cc);
+        const float v = x[p * Cx + x_off + c];
+        float *dst = y + p * Cy + y_off + c;
+        *dst = accumulate ? *dst + v : v;
+    }
+}
+
+__global__ void add_kernel(const float *__restrict__ a, const float *__restrict__ b, float *__restrict__ y, int64_t n) {
+    const int64_t n4 = n >> 2;
+    for (int64_t i = (int64_t)blockIdx.x * NT + threadIdx.x; i < n4; i += (int64_t)gridDim.x * NT) {
+        const float4 u = reinterpret_cast<const float4 *>(a)[i], v = reinterpret_cast<const float4 *>(b)[i];
+        reinterpret_cast<float4 *>(y)[i] = make_float4(u.x + v.x, u.y + v.y, u.z + v.z, u.w + v.w);
+    }
+    for (int64_t i = (n4 << 2) + (int64_t)blockIdx.x * NT + threadIdx.x; i < n; i += (int64_t)gridDim.x * NT)
+        y[i] = a[i] + b[i];
+}
+
+__global__ void act_bwd_kernel(const float *__restrict__ y, const float *__restrict__ dy, float *__restrict__ dx,
+                               int act, float slope, int64_t n) {
+    for (int64_t i = (int64_t)blockIdx.x * NT + threadIdx.x; i < n; i += (int64_t)gridDim.x * NT)
+        dx[i] = dy[i] * hoig_act_grad_from_y(y[i], act, slope);
+}
+
+// out[c] += sum_rows x[row][c]; one workgroup per row slab, lanes along channels (coalesced), LDS combine, one
+// atomic per (workgroup, channel)
+__global__ __launch_bounds__(NT) void colsum_kernel(const float *__restrict__ x, float *__restrict__ out, int64_t rows,
+                                                    int C, int64_t rows_per_block) {
+    const int64_t r0 = (int64_t)blockIdx.x * rows_per_block;
+    const int64_t r1 = r0 + rows_per_block < rows ? r0 + rows_per_block : rows;
+    const int lanes = C < NT ? C : NT;
+    const int rl_n = NT / lanes;
+    const int c0 = threadIdx.x % lanes, rl = threadIdx.x / lanes;
+    extern __shared__ float red[];
+    if (threadIdx.x < lanes * rl_n) {
+        for (int c = c0; c < C; c += lanes) {
+            float s = 0.f;
+            for (int64_t r = r0 + rl; r < r1; r += rl_n) s += x[r * C + c];
+            red[rl * C + c] = s;
+        }
+    }
+    __syncthreads();
+    for (int c = threadIdx.x; c < C; c += NT) {
+        float s = 0.f;
+        for (int k = 0; k < rl_n; ++k) s += red[k * C + c];
+        atomicAdd(&out[c], s);
+    }
+}
+
+__global__ void compose_fwd_kernel(const float *__restrict__ bg, const float *__restrict__ obj,
+                                   const float *__restrict__ hand, const float *__restrict__ mbg,
+                                   const float *__restrict__ mh, float *__restrict__ img, int64_t npix, int C) {
+    const int64_t n = npix * C;
+    for (int64_t i = (int64_t)blockIdx.x * NT + threadIdx.x; i < n; i += (int64_t)gridDim.x * NT) {
+        const int64_t p = i / C;
+        const float a = mbg[p], h = mh[p];
+        img[i] = a * bg[i] + (1.f - a) * (obj[i] * h + hand[i] * (1.f - h));
+    }
+}
+
+__global__ void compose_bwd_kernel(const float *__restrict__ bg, const float *__restrict__ obj,
+                                   const float *__restrict__ hand, const float *__restrict__ mbg,
+                                   const float *__restrict__ mh, const float *__restrict__ dimg, float *__restrict__ dbg,
+                                   float *__restrict__ dobj, float *__restrict__ dhand, float *__restrict__ dmbg,
+                                   float *__restrict__ dmh, int64_t npix, int C) {
+    for (int64_t p = (int64_t)blockIdx.x * NT + threadIdx.x; p < npix; p += (int64_t)gridDim.x * NT) {
+        const float a = mbg[p], h = mh[p];
+        float da = 0.f, dh = 0.f;
+        for (int c = 0; c < C; ++c) {
+            const int64_t i = p * C + c;
+            const float g = dimg[i];
+            const float fg = obj[i] * h + hand[i] * (1.f - h);
+            dbg[i] = g * a;
+            dobj[i] = g * (1.f - a) * h;
+            dhand[i] = g * (1.f - a) * (1.f - h);
+            da += g * (bg[i] - fg);
+            dh += g * (1.f - a) * (obj[i] - hand[i]);
+        }
+        dmbg[p] = da;
+        dmh[p] = dh;
+    }
+}
+
+__global__ __launch_bounds__(NT) void loss_kernel(int kind, const float *__restrict__ pred,
+                                                  const float *__restrict__ target, float tconst, float gscale,
+                                                  float *__restrict__ out, float *__restrict__ dpred, int64_t n) {
+    float acc = 0.f;
+    for (int64_t i = (int64_t)blockIdx.x * NT + threadIdx.x; i < n; i += (int64_t)gridDim.x * NT) {
+        const float p = pred[i], t = target ? target[i] : tconst;
+        float l, g;
+        if (kind == HOIG_LOSS_L1) {
+            const float d = p - t;
+            l = fabsf(d);
+            g = d > 0.f ? 1.f : (d < 0.f ? -1.f : 0.f);
+        } else if (kind == HOIG_LOSS_MSE) {
+            const float d = p - t;
+            l = d * d;
+            g = 2.f * d;
+        } else {  // BCE with torch's clamps: log >= -100 (forward), denominator >= 1e-12 (backward)
+            const float lp = fmaxf(logf(p), -100.f), lq = fmaxf(logf(1.f - p), -100.f);
+            l = -(t * lp + (1.f - t) * lq);
+            g = (p - t) / fmaxf((1.f - p) * p, 1e-12f);
+        }
+        acc += l;
+        if (dpred) dpred[i] = g * gscale;
+    }
+    const float s = block_sum(acc);
+    if (threadIdx.x == 0) atomicAdd(out, s);
+}
+
+__global__ __launch_bounds__(NT) void tv_kernel(const float *__restrict__ m, float gx, float gy, float *__restrict__ out,
+                                                float *__restrict__ dm, int B, int H, int W) {
+    const int64_t n = (int64_t)B * H * W;
+    float ax = 0.f, ay = 0.f;
+    for (int64_t i = (int64_t)blockIdx.x * NT + threadIdx.x; i < n; i += (int64_t)gridDim.x * NT) {
+        const int x = (int)(i % W), y = (int)((i / W) % H);
+        const float v = m[i];
+        float g = 0.f;
+        if (x + 1 < W) {
+            const float d = v - m[i + 1];
+            ax += fabsf(d);
+            g += gx * (d > 0.f ? 1.f : (d < 0.f ? -1.f : 0.f));
+        }
+        if (x > 0) {
+            const float d = m[i - 1] - v;
+            g -= gx * (d > 0.f ? 1.f : (d < 0.f ? -1.f : 0.f));
+        }
+        if (y + 1 < H) {
+            const float d = v - m[i + W];
+            ay += fabsf(d);
+            g += gy * (d > 0.f ? 1.f : (d < 0.f ? -1.f : 0.f));
+        }
+        if (y > 0) {
+            const float d = m[i - W] - v;
+            g -= gy * (d > 0.f ? 1.f : (d < 0.f ? -1.f : 0.f));
+        }
+        if (dm) dm[i] = g;
+    }
+    const float sx = block_sum(ax);
+    const float sy = block_sum(ay);
+    if (threadIdx.x == 0) {
+        atomicAdd(&out[0], sx);
+        atomicAdd(&out[1], sy);
+    }
+}
+
+__global__ __launch_bounds__(NT) void sum_kernel(const float *__restrict__ x, float *__restrict__ out, int64_t n) {
+    float acc = 0.f;
+    for (int64_t i = (int64_t)blockIdx.x * NT + threadIdx.x; i < n; i += (int64_t)gridDim.x * NT) acc += x[i];
+    const float s = block_sum(acc);
+    if (threadIdx.x == 0) atomicAdd(out, s);
+}
+
+__global__ void maxpool_fwd_kernel(const float *__restrict__ x, float *__restrict__ y, int B, int H, int W, int C) {
+    const int Ho = H / 2, Wo = W / 2;
+    const int64_t n = (int64_t)B * Ho * Wo * C;
+    for (int64_t i = (int64_t)blockIdx.x * NT + threadIdx.x; i < n; i += (int64_t)gridDim.x * NT) {
+        const int c = (int)(i % C);
+        int64_t p = i / C;
+        const int wo = (int)(p % Wo);
+        p /= Wo;
+        const int ho = (int)(p % Ho), b = (int)(p / Ho);
+        const float *s = x + (((size_t)b * H + 2 * ho) * W + 2 * wo) * C + c;
+        const float a = s[0], bb = s[C], cc = s[(size_t)W * C], d = s[(size_t)W * C + C];
+        y[i] = fmaxf(fmaxf(a, bb), fmaxf(cc, d));
+    }
+}
+
+__global__ void maxpool_bwd_kernel(const float *__restrict__ x, const float *__restrict__ dy, float *__restrict__ dx,
+                                   int B, int H, int W, int C) {
+    const int Ho = H / 2, Wo = W / 2;
+    const int64_t n = (int64_t)B * Ho * Wo * C;
+    for (int64_t i = (int64_t)blockIdx.x * NT + threadIdx.x; i < n; i += (int64_t)gridDim.x * NT) {
+        const int c = (int)(i % C);
+        int64_t p = i / C;
+        const int wo = (int)(p % Wo);
+        p /= Wo;
+        const int ho = (int)(p % Ho), b = (int)(p / Ho);
+        const size_t o = (((size_t)b * H + 2 * ho) * W + 2 * wo) * C + c;
+        const size_t offs[4] = {0, (size_t)C, (size_t)W * C, (size_t)W * C + C};
+        int best = 0;
+        float bv = x[o];
+#pragma unroll
+        for (int k = 1; k < 4; ++k) {   // first maximum in scan order wins, as ATen's CPU kernel does
+            const float v = x[o + offs[k]];
+            if (v > bv) { bv = v; best = k; }
+        }
+        const float g = dy[i];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) dx[o + offs[k]] = (k == best) ? g : 0.f;
+    }
+}
+
+// torch.optim.Adam single-tensor update (no amsgrad, no weight decay), op order as ATen applies it:
+//   m.lerp_(g, 1-b1); v = v*b2 + (1-b2)*g*g; denom = sqrt(v)/sqrt(bc2) + eps; p -= (lr/bc1) * m/denom
+__global__ __launch_bounds__(NT) void adam_kernel(float *__restrict__ p, const float *__restrict__ g, float *__restrict__ m,
+                                                  float *__restrict__ v, int64_t n, float step_size, float b1, float b2,
+                                                  float eps, float bc2_sqrt, float gscale) {
+    const int64_t n4 = n >> 2;
+    for (int64_t i = (int64_t)blockIdx.x * NT + threadIdx.x; i < n4; i += (int64_t)gridDim.x * NT) {
+        float4 pp = reinterpret_cast<float4 *>(p)[i];
+        const float4 gg = reinterpret_cast<const float4 *>(g)[i];
+        float4 mm = reinterpret_cast<float4 *>(m)[i], vv = reinterpret_cast<float4 *>(v)[i];
+        float *pe = &pp.x, *me = &mm.x, *ve = &vv.x;
+        const float *ge = &gg.x;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const float gk = ge[k] * gscale;
+            me[k] = me[k] + (gk - me[k]) * (1.f - b1);
+            ve[k] = ve[k] * b2 + (1.f - b2) * gk * gk;
+            const float denom = sqrtf(ve[k]) / bc2_sqrt + eps;
+            pe[k] = pe[k] - step_size * (me[k] / denom);
+        }
+        reinterpret_cast<float4 *>(p)[i] = pp;
+        reinterpret_cast<float4 *>(m)[i] = mm;
+        reinterpret_cast<float4 *>(v)[i] = vv;
+    }
+    for (int64_t i = (n4 << 2) + (int64_t)blockIdx.x * NT + threadIdx.x; i < n; i += (int64_t)gridDim.x * NT) {
+        const float gk = g[i] * gscale;
+        const float mk = m[i] + (gk - m[i]) * (1.f - b1);
+        const float vk = v[i] * b2 + (1.f - b2) * gk * gk;
+        m[i] = mk;
+        v[i] = vk;
+        p[i] = p[i] - step_size * (mk / (sqrtf(vk) / bc2_sqrt + eps));
+    }
+}
+
+__global__ void tensor2im_kernel(const float *__restrict__ x, uint8_t *__restrict__ out, int B, int H, int W, int C,
+                                 int ncol, int nrw, int unnorm) {
+    // out: [C][nrw*H][ncol*W] uint8 ; x NHWC
+    const int64_t n = (int64_t)B * H * W * C;
+    for (int64_t i = (int64_t)blockIdx.x * NT + threadIdx.x; i < n; i += (int64_t)gridDim.x * NT) {
+        const int c = (int)(i % C);
+        int64_t p = i / C;
+        const int w = (int)(p % W);
+        p /= W;
+        const int h = (int)(p % H), b = (int)(p / H);
+        float v = x[i];
+        if (unnorm) { v += 1.0f; v /= 2.0f; }
+        v *= 255.0f;
+        const int gr = b / ncol, gc = b % ncol;
+        // numpy astype(uint8) of a float: C-style truncation, wrap on out-of-range (values here are in range)
+        const int iv = (int)v;
+        out[((size_t)c * (nrw * H) + gr * H + h) * ((size_t)ncol * W) + gc * W + w] = (uint8_t)(iv & 0xFF);
+    }
+}
+
+}  // namespace
+
+#define ST ((hipStream_t)stream)
+
+extern "C" int hoig_nchw_to_nhwc(const float *x, float *y, int B, int C, int H, int W, hoig_stream_t stream) {
+    if (!x || !y) return HOIG_EINVAL;
+    const int HW = H * W;  // x: [B][C][HW] -> y: [B][HW][C]
+    transpose_kernel<<<dim3((HW + 31) / 32, (C + 31) / 32, B), dim3(32, 8), 0, ST>>>(x, y, C, HW);
+    HOIG_LAUNCH_CHECK();
+    return HOIG_OK;
+}
+extern "C" int hoig_nhwc_to_nchw(const float *x, float *y, int B, int C, int H, int W, hoig_stream_t stream) {
+    if (!x || !y) return HOIG_EINVAL;
+    const int HW = H * W;  // x: [B][HW][C] -> y: [B][C][HW]
+    transpose_kernel<<<dim3((C + 31) / 32, (HW + 31) / 32, B), dim3(32, 8), 0, ST>>>(x, y, HW, C);
+    HOIG_LAUNCH_CHECK();
+    return HOIG_OK;
+}
+extern "C" int hoig_copy_channels(const float *x, float *y, int64_t npix, int Cx, int x_off, int Cy, int y_off, int Cc,
+                                  int accumulate, hoig_stream_t stream) {
+    if (!x || !y || x_off + Cc > Cx || y_off + Cc > Cy) return HOIG_EINVAL;
+    copy_channels_kernel<<<hoig_stream_grid(npix * Cc, NT), NT, 0, ST>>>(x, y, npix, Cx, x_off, Cy, y_off, Cc, accumulate);
+    HOIG_LAUNCH_CHECK();
+    return HOIG_OK;
+}
+extern "C" int hoig_add(const float *a, const float *b, float *y, int64_t n, hoig_stream_t stream) {
+    if (!a || !b || !y) return HOIG_EINVAL;
+    add_kernel<<<hoig_stream_grid(n / 4 + 1, NT), NT, 0, ST>>>(a, b, y, n);
+    HOIG_LAUNCH_CHECK();
+    return HOIG_OK;
+}
+extern "C" int hoig_act_bwd(const float *y, const float *dy, float *dx, int act, float slope, int64_t n,
+                            hoig_stream_t stream) {
+    if (!y || !dy || !dx) return HOIG_EINVAL;
+    act_bwd_kernel<<<hoig_stream_grid(n, NT), NT, 0, ST>>>(y, dy, dx, act, slope, n);
+    HOIG_LAUNCH_CHECK();
+    return HOIG_OK;
+}
+extern "C" int hoig_colsum_accum(const float *x, float *out, int64_t rows, int C, hoig_stream_t stream) {
+    if (!x || !out || C <= 0) return HOIG_EINVAL;
+    int64_t nblk = hoig_cdiv(rows, 64);
+    if (nblk > 1024) nblk = 1024;
+    const int64_t rpb = hoig_cdiv(rows, nblk);
+    nblk = hoig_cdiv(rows, rpb);
+    const int lanes = C < NT ? C : NT;
+    const size_t shm = (size_t)(NT / lanes) * C * sizeof(float);
+    colsum_kernel<<<(int)nblk, NT, shm, ST>>>(x, out, rows, C, rpb);
+    HOIG_LAUNCH_CHECK();
+    return HOIG_OK;
+}
+extern "C" int hoig_compose_fwd(const float *bg, const float *obj, const float *hand, const float *mbg, const float *mh,
+                                float *img, int64_t npix, int C, hoig_stream_t stream) {
+    if (!bg || !obj || !hand || !mbg || !mh || !img) return HOIG_EINVAL;
+    compose_fwd_kernel<<<hoig_stream_grid(npix * C, NT), NT, 0, ST>>>(bg, obj, hand, mbg, mh, img, npix, C);
+    HOIG_LAUNCH_CHECK();
+    return HOIG_OK;
+}
+extern "C" int hoig_compose_bwd(const float *bg, const float *obj, const float *hand, const float *mbg, const float *mh,
+                                const float *dimg, float *dbg, float *dobj, float *dhand, float *dmbg, float *dmh,
+                                int64_t npix, int C, hoig_stream_t stream) {
+    if (!bg || !obj || !hand || !mbg || !mh || !dimg || !dbg || !dobj || !dhand || !dmbg || !dmh) return HOIG_EINVAL;
+    compose_bwd_kernel<<<hoig_stream_grid(npix, NT), NT, 0, ST>>>(bg, obj, hand, mbg, mh, dimg, dbg, dobj, dhand, dmbg,
+                                                                 dmh, npix, C);
+    HOIG_LAUNCH_CHECK();
+    return HOIG_OK;
+}
+extern "C" int hoig_loss_fwd_bwd(int kind, const float *pred, const float *target, float target_const, float gscale,
+                                 float *out, float *dpred, int64_t n, hoig_stream_t stream) {
+    if (!pred || !out || kind < 0 || kind > 2) return HOIG_EINVAL;
+    int g = hoig_stream_grid(n, NT);
+    if (g > 512) g = 512;
+    loss_kernel<<<g, NT, 0, ST>>>(kind, pred, target, target_const, gscale, out, dpred, n);
+    HOIG_LAUNCH_CHECK();
+    return HOIG_OK;
+}
+extern "C" int hoig_tv_fwd_bwd(const float *m, float gx, float gy, float *out, float *dm, int B, int H, int W,
+                               hoig_stream_t stream) {
+    if (!m || !out) return HOIG_EINVAL;
+    int g = hoig_stream_grid((int64_t)B * H * W, NT);
+    if (g > 512) g = 512;
+    tv_kernel<<<g, NT, 0, ST>>>(m, gx, gy, out, dm, B, H, W);
+    HOIG_LAUNCH_CHECK();
+    return HOIG_OK;
+}
+extern "C" int hoig_sum(const float *x, float *out, int64_t n, hoig_stream_t stream) {
+    if (!x || !out) return HOIG_EINVAL;
+    int g = hoig_stream_grid(n, NT);
+    if (g > 512) g = 512;
+    sum_kernel<<<g, NT, 0, ST>>>(x, out, n);
+    HOIG_LAUNCH_CHECK();
+    return HOIG_OK;
+}
+extern "C" int hoig_maxpool2_fwd(const float *x, float *y, int B, int H, int W, int C, hoig_stream_t stream) {
+    if (!x || !y || (H & 1) || (W & 1)) return HOIG_EINVAL;
+    maxpool_fwd_kernel<<<hoig_stream_grid((int64_t)B * H * W * C / 4, NT), NT, 0, ST>>>(x, y, B, H, W, C);
+    HOIG_LAUNCH_CHECK();
+    return HOIG_OK;
+}
+extern "C" int hoig_maxpool2_bwd(const float *x, const float *y, const float *dy, float *dx, int B, int H, int W, int C,
+                                 hoig_stream_t stream) {
+    (void)y;
+    if (!x || !dy || !dx || (H & 1) || (W & 1)) return HOIG_EINVAL;
+    maxpool_bwd_kernel<<<hoig_stream_grid((int64_t)B * H * W * C / 4, NT), NT, 0, ST>>>(x, dy, dx, B, H, W, C);
+    HOIG_LAUNCH_CHECK();
+    return HOIG_OK;
+}
+extern "C" int hoig_adam_step(float *param, const float *grad, float *exp_avg, float *exp_avg_sq, int64_t n, float lr,
+                              float beta1, float beta2, float eps, int step, float grad_scale, hoig_stream_t stream) {
+    if (!param || !grad || !exp_avg || !exp_avg_sq || step < 1) return HOIG_EINVAL;
+    const double bc1 = 1.0 - pow((double)beta1, step), bc2 = 1.0 - pow((double)beta2, step);
+    const float step_size = (float)((double)lr / bc1);
+    const float bc2_sqrt = (float)sqrt(bc2);
+    adam_kernel<<<hoig_stream_grid(n / 4 + 1, NT), NT, 0, ST>>>(param, grad, exp_avg, exp_avg_sq, n, step_size, beta1,
+                                                               beta2, eps, bc2_sqrt, grad_scale);
+    HOIG_LAUNCH_CHECK();
+    return HOIG_OK;
+}
+extern "C" int hoig_tensor2im_u8(const float *x, uint8_t *out, int B, int H, int W, int C, int nrow, int unnormalize,
+                                 hoig_stream_t stream) {
+    if (!x || !out || nrow <= 0) return HOIG_EINVAL;
+    const int ncol = nrow < B ? nrow : B;   // torchvision.utils.make_grid: xmaps = min(nrow, B)
+    const int nrw = (B + ncol - 1) / ncol;
+    tensor2im_kernel<<<hoig_stream_grid((int64_t)B * H * W * C, NT), NT, 0, ST>>>(x, out, B, H, W, C, ncol, nrw,
+                                                                                 unnormalize);
+    HOIG_LAUNCH_CHECK();
+    return HOIG_OK;
+}
+extern "C" const char *hoig_version(void) { return "hoig-hip 0.1 (gfx950)"; }

@@ -1,0 +1,206 @@
+"""HOGAN generator on the HIP operators (NHWC, fp32 activations in HBM).
+
+Mirrors the reference's ``Generator`` interface (models/networks/generator.py:318-491): same constructor
+arguments, ``forward`` signature, ``init_weights`` and parameter names; the computation is a functional
+pass over a flat parameter store, every operator a hand-written gfx950 kernel (hoig_amd/ops.py).
+"""
+import torch
+
+from ... import ops
+from ..._lib import ACT_NONE, ACT_RELU, ACT_TANH, ACT_SIGMOID
+from ...nn import ParamTree
+from .schema import GeneratorConfig, generator_schema
+
+
+def to_nhwc(t):
+    """NCHW-shaped CUDA tensor -> contiguous NHWC tensor (free when `t` already is a channels-last view)."""
+    if t is None:
+        return None
+    v = t.permute(0, 2, 3, 1)
+    if v.is_contiguous():
+        return v
+    return ops.nchw_to_nhwc(t)
+
+
+def as_nchw(t):
+    """NHWC tensor presented with the reference's NCHW shape (a view, no copy)."""
+    return t.permute(0, 3, 1, 2)
+
+
+class Generator(ParamTree):
+    def __init__(self, bg_dim, img_dim, obj_dim, img_cond_dim=0, obj_cond_dim=0, conv_dim=64, repeat_num=6,
+                 gen_name='generator_spade_attn', device=None):
+        self.cfg = GeneratorConfig(gen_name, bg_dim, img_dim, obj_dim, img_cond_dim, obj_cond_dim, conv_dim, repeat_num)
+        sch = generator_schema(self.cfg)
+        device = device if device is not None else torch.device('cuda', torch.cuda.current_device())
+        super().__init__(sch.shapes, device, sch.transposed)
+        self._name = 'generator'
+        self._seg_cache = {}
+
+    @property
+    def name(self):
+        return self._name
+
+    # ---- building blocks -------------------------------------------------------------------
+    def _conv(self, x, name, stride=1, pad=1, act=ACT_NONE):
+        return ops.conv2d(x, self.P[name + '.weight'], self.P.get(name + '.bias'), stride, pad, act)
+
+    def _convT(self, x, name):
+        return ops.conv_transpose2d(x, self.P[name + '.weight'])
+
+    def _in(self, x, name, act=ACT_NONE, residual=None):
+        return ops.instance_norm(x, self.P[name + '.weight'], self.P[name + '.bias'], act=act, residual=residual)
+
+    def _seg_at(self, seg, h, w):
+        key = (id(seg), h, w)
+        if key not in self._seg_cache:
+            self._seg_cache[key] = ops.resize_nearest(seg, h, w)          # spade.py:30
+        return self._seg_cache[key]
+
+    def _spade(self, x, seg, name, act):
+        """spade.py:25-38 (+ the ReLU that always follows it, generator.py:66-67,88)."""
+        s = self._seg_at(seg, x.shape[1], x.shape[2])
+        actv = self._conv(s, name + '.mlp_shared.0', act=ACT_RELU)
+        gamma = self._conv(actv, name + '.mlp_gamma')
+        beta = self._conv(actv, name + '.mlp_beta')
+        return ops.spade_norm(x, gamma, beta, act=act)
+
+    def _conv_in_relu(self, x, name, stride=1, pad=1, transposed=False):
+        h = self._convT(x, name + '.0') if transposed else self._conv(x, name + '.0', stride, pad)
+        return self._in(h, name + '.1', act=ACT_RELU)
+
+    def _resblock(self, x, name):                                          # generator.py:9-32
+        h = self._in(self._conv(x, name + '.main.0'), name + '.main.1', act=ACT_RELU)
+        return self._in(self._conv(h, name + '.main.3'), name + '.main.4', residual=x)
+
+    def _spade_resblock(self, x, seg, name):                               # generator.py:63-71
+        dx = self._conv(self._spade(x, seg, name + '.norm_0', ACT_RELU), name + '.conv_0')
+        dx = self._conv(self._spade(dx, seg, name + '.norm_1', ACT_RELU), name + '.conv_1')
+        return ops.add(x, dx)
+
+    def _spade_block(self, x, seg, name, down):                            # generator.py:74-90
+        h = self._conv(x, name + '.conv', stride=2) if down else self._convT(x, name + '.conv')
+        return self._spade(h, seg, name + '.norm', ACT_RELU)
+
+    def _bg_net(self, x):                                                  # generator.py:93-135
+        c, p = self.cfg, 'bg_model.model'
+        x = self._in(self._conv(x, p + '.0', pad=3), p + '.1', act=ACT_RELU)
+        idx = 3
+        for _ in range(c.n_down):
+            x = self._in(self._conv(x, p + '.%d' % idx, stride=2), p + '.%d' % (idx + 1), act=ACT_RELU)
+            idx += 3
+        for _ in range(c.repeat_num):
+            x = self._resblock(x, p + '.%d' % idx)
+            idx += 1
+        for _ in range(c.n_down):
+            x = self._in(self._convT(x, p + '.%d' % idx), p + '.%d' % (idx + 1), act=ACT_RELU)
+            idx += 3
+        return self._conv(x, p + '.%d' % idx, pad=3, act=ACT_TANH)
+
+    def _enc_level(self, x, seg, p, i):
+        if self.cfg.spade_layers[0]:
+            return self._spade_block(x, seg, p + '.encoders.%d' % i, True)
+        return self._conv_in_relu(x, p + '.encoders.%d' % i, stride=2)
+
+    def _resnet(self, x, seg, p, i):
+        c = self.cfg
+        if (c.spade_layers[1] if i < c.repeat_num // 2 else c.spade_layers[2]):
+            return self._spade_resblock(x, seg, p + '.resnets.%d' % i)
+        return self._resblock(x, p + '.resnets.%d' % i)
+
+    def _decode(self, x, enc, seg, p):                                     # generator.py:298-309
+        nd = self.cfg.n_down
+        for i in range(nd):
+            if self.cfg.spade_layers[3]:
+                x = self._spade_block(x, seg, p + '.decoders.%d' % i, False)
+            else:
+                x = self._conv_in_relu(x, p + '.decoders.%d' % i, transposed=True)
+            x = ops.cat_channels([enc[nd - 1 - i], x])
+            x = self._conv_in_relu(x, p + '.skippers.%d' % i)
+        return x
+
+    def _unet(self, x, seg, p):                                            # generator.py:261-283
+        e = self._conv_in_relu(x, p + '.encoders.0', pad=3)
+        enc = [e]
+        for i in range(1, self.cfg.n_down + 1):
+            e = self._enc_level(e, seg, p, i)
+            enc.append(e)
+        for i in range(self.cfg.repeat_num):
+            e = self._resnet(e, seg, p, i)
+        return self._decode(e, enc, seg, p)
+
+    # ---- feature warping (generator.py:466-491) ------------------------------------------------
+    def _tscale(self, T, h):
+        key = ('T', id(T), h)
+        if key not in self._seg_cache:
+            self._seg_cache[key] = ops.resize_bilinear_ac(T, h, h)         # resize_trans: size=(h, h)
+        return self._seg_cache[key]
+
+    def _transform(self, x, T, layer, y=None):
+        h = x.shape[1]
+        ts = self._tscale(T, h)
+        if layer in self.cfg.attn_layers:
+            key = ('F', id(T), h)
+            if key not in self._seg_cache:
+                self._seg_cache[key] = ops.attn_flow(ts)
+            p = 'attn_%d.fully_connect_layer' % layer
+            return ops.local_attention(x, y, self._seg_cache[key], self.P[p + '.0.weight'], self.P[p + '.0.bias'],
+                                       self.P[p + '.2.weight'], self.P[p + '.2.bias'])
+        return ops.grid_sample(x, ts)
+
+    # ---- public forward: reference signature (generator.py:347-376), NCHW in / NCHW-shaped out ---
+    def forward(self, bg_inputs, src_obj_inputs, tsf_obj_inputs, src_hand_inputs, tsf_hand_inputs, T,
+                src_obj_conds=None, src_hand_conds=None, tsf_obj_conds=None, tsf_hand_conds=None,
+                src_armask=None, tsf_armask=None):
+        if src_obj_conds is None or src_hand_conds is None or tsf_obj_conds is None or tsf_hand_conds is None:
+            raise NotImplementedError('Generator.forward without conds (use_spade=False) is unreachable in the reference: '
+                                      'Trainer.forward passes arguments in an order that mismatches obj_dim/img_dim '
+                                      '(trainer.py:395-398 vs :263-264)')
+        outs = self.forward_nhwc(to_nhwc(bg_inputs), to_nhwc(src_obj_inputs), to_nhwc(tsf_obj_inputs),
+                                 to_nhwc(src_hand_inputs), to_nhwc(tsf_hand_inputs), T.contiguous(),
+                                 to_nhwc(src_obj_conds), to_nhwc(src_hand_conds), to_nhwc(tsf_obj_conds),
+                                 to_nhwc(tsf_hand_conds), to_nhwc(src_armask), to_nhwc(tsf_armask))
+        return tuple(as_nchw(o) for o in outs)
+
+    def forward_nhwc(self, bg, src_obj, tsf_obj, src_hand, tsf_hand, T, src_obj_c, src_hand_c, tsf_obj_c, tsf_hand_c,
+                     src_armask=None, tsf_armask=None):
+        c = self.cfg
+        self._seg_cache = {}
+        src_bg_in = [bg, src_hand_c] + ([src_armask] if src_armask is not None else [])
+        tsf_bg_in = [bg, tsf_hand_c] + ([tsf_armask] if tsf_armask is not None else [])
+        src_img_bg = self._bg_net(ops.cat_channels(src_bg_in))
+        tsf_img_bg = self._bg_net(ops.cat_channels(tsf_bg_in))
+
+        # infer_front (generator.py:379-464)
+        sx = self._conv_in_relu(src_hand, 'src_model.encoders.0', pad=3)
+        tx = self._conv_in_relu(tsf_hand, 'tsf_model.encoders.0', pad=3)
+        s_enc, t_enc = [sx], [tx]
+        for i in range(1, c.n_down + 1):
+            sx = self._enc_level(sx, src_hand_c, 'src_model', i)
+            tx = self._enc_level(tx, tsf_hand_c, 'tsf_model', i)
+            tx = ops.add(tx, self._transform(sx, T, i, y=tx))
+            s_enc.append(sx)
+            t_enc.append(tx)
+        for i in range(c.repeat_num):
+            sx = self._resnet(sx, src_hand_c, 'src_model', i)
+            tx = self._resnet(tx, tsf_hand_c, 'tsf_model', i)
+            tx = ops.add(tx, self._transform(sx, T, i + c.n_down + 1, y=tx))
+
+        sy = self._unet(src_obj, src_obj_c, 'obj_model')
+        ty = self._unet(tsf_obj, tsf_obj_c, 'obj_model')
+        sx = self._decode(sx, s_enc, src_hand_c, 'src_model')
+        tx = self._decode(tx, t_enc, tsf_hand_c, 'tsf_model')
+
+        def regress(x, y, p):                                              # generator.py:311-315
+            img = self._conv(x, p + '.img_reg.0', pad=3, act=ACT_TANH)
+            mh = self._conv(x, p + '.attetion_reg_hand.0', pad=3, act=ACT_SIGMOID)
+            mb = self._conv(ops.cat_channels([x, y]), p + '.attetion_reg_bg.0', pad=3, act=ACT_SIGMOID)
+            return img, mh, mb
+
+        src_hand_o, src_mask_hand, src_mask_bg = regress(sx, sy, 'src_model')
+        tsf_hand_o, tsf_mask_hand, tsf_mask_bg = regress(tx, ty, 'tsf_model')
+        src_obj_o = self._conv(sy, 'obj_model.img_reg.0', pad=3, act=ACT_TANH)
+        tsf_obj_o = self._conv(ty, 'obj_model.img_reg.0', pad=3, act=ACT_TANH)
+        self._seg_cache = {}
+        return (src_img_bg, tsf_img_bg, src_obj_o, src_hand_o, src_mask_bg, src_mask_hand,
+                tsf_obj_o, tsf_hand_o, tsf_mask_bg, tsf_mask_hand)

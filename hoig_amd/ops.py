@@ -1,0 +1,543 @@
+"""Autograd-visible operators of the HOGAN path; every one is a call into libhoig_hip.so.
+
+Tensors are fp32 CUDA tensors in NHWC ("channels-last") layout, contiguous.
+Convolution weights keep the reference's LOGICAL shapes -- Conv2d (Co,Ci,R,S),
+ConvTranspose2d (Ci,Co,R,S) -- over PACKED storage [Co][R][S][Ci] (see
+``hoig_amd.nn``).  Parameters that live in a flat buffer (``_hoig_flat``) get
+their weight gradients accumulated in place by the kernels; for ordinary
+tensors the gradient is returned through autograd.
+"""
+import ctypes
+import os
+
+import torch
+from torch.autograd import Function
+
+from . import _lib as L
+from ._lib import call, ConvDesc
+
+_PREC = {'f32': L.PREC_F32, 'bf16x3': L.PREC_BF16X3, 'bf16': L.PREC_BF16}
+precision = _PREC[os.environ.get('HOIG_PRECISION', 'f32')]
+
+
+def set_precision(name):
+    global precision
+    precision = _PREC[name]
+
+
+def _st():
+    return torch.cuda.current_stream().cuda_stream
+
+
+def _p(t):
+    return None if t is None else t.data_ptr()
+
+
+def _chk(t, name='tensor'):
+    if t is None:
+        return
+    if not t.is_cuda:
+        raise NotImplementedError('%s: hoig_amd ops run on the HIP device only (no CPU path), as the reference ops '
+                                  'do (block_extractor.py:23-24)' % name)
+    if t.dtype != torch.float32:
+        raise TypeError('%s must be float32' % name)
+
+
+def packed_strides(shape, transposed):
+    """Strides of a logical conv weight over packed [Co][R][S][Ci] storage."""
+    if transposed:
+        ci, co, r, s = shape
+        return (1, r * s * ci, s * ci, ci)
+    co, ci, r, s = shape
+    return (r * s * ci, 1, s * ci, ci)
+
+
+def pack_weight(w, transposed=False):
+    """Return `w` (logical NCHW-style conv weight) re-laid over packed storage."""
+    out = torch.empty_strided(tuple(w.shape), packed_strides(w.shape, transposed), dtype=w.dtype, device=w.device)
+    out.copy_(w)
+    return out
+
+
+def _grad_target(p):
+    """(buffer to accumulate into, returned-through-autograd?)"""
+    if getattr(p, '_hoig_flat', False):
+        if p.grad is None:
+            raise RuntimeError('flat parameter without a gradient view')
+        return p.grad, False
+    if p.dim() == 4:
+        g = torch.empty_strided(tuple(p.shape), p.stride(), dtype=p.dtype, device=p.device).zero_()
+    else:
+        g = torch.zeros_like(p)
+    return g, True
+
+
+# ------------------------------------------------------------------------------------------------- conv
+class _Conv(Function):
+    @staticmethod
+    def forward(ctx, x, w, b, stride, pad, transposed, act, slope, out_hw, prec):
+        _chk(x, 'x'); _chk(w, 'w'); _chk(b, 'bias')
+        assert x.is_contiguous() and x.dim() == 4
+        B, Hi, Wi, Ci = x.shape
+        if transposed:
+            ci_w, Co, R, S = w.shape
+        else:
+            Co, ci_w, R, S = w.shape
+        assert ci_w == Ci, 'channel mismatch %d vs %d' % (ci_w, Ci)
+        assert tuple(w.stride()) == packed_strides(w.shape, transposed), 'conv weight is not in packed layout'
+        if out_hw is None:
+            if transposed:
+                raise ValueError('out_hw required for transposed conv')
+            out_hw = ((Hi + 2 * pad - R) // stride + 1, (Wi + 2 * pad - S) // stride + 1)
+        Ho, Wo = out_hw
+        y = torch.empty((B, Ho, Wo, Co), dtype=x.dtype, device=x.device)
+        d = ConvDesc(B, Hi, Wi, Ci, Ho, Wo, Co, R, S, stride, pad, 1 if transposed else 0, act, slope, prec)
+        call('hoig_conv2d_fwd', ctypes.byref(d), _p(x), _p(w), _p(b), _p(y), _st())
+        ctx.d = d
+        ctx.has_bias = b is not None
+        ctx.save_for_backward(x, w, b, y if act != L.ACT_NONE else None)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, w, b, y = ctx.saved_tensors
+        d = ctx.d
+        dy = dy.contiguous()
+        if d.act != L.ACT_NONE:
+            g = torch.empty_like(dy)
+            call('hoig_act_bwd', _p(y), _p(dy), _p(g), d.act, d.slope, dy.numel(), _st())
+        else:
+            g = dy
+        dw_ret = db_ret = None
+        if ctx.needs_input_grad[1]:
+            dw, ret_w = _grad_target(w)
+            db = None
+            if ctx.has_bias and ctx.needs_input_grad[2]:
+                db, ret_b = _grad_target(b)
+                db_ret = db if ret_b else None
+            call('hoig_conv2d_bwd_weight', ctypes.byref(d), _p(x), _p(g), _p(dw), _p(db), _st())
+            dw_ret = dw if ret_w else None
+        dx = None
+        if ctx.needs_input_grad[0]:
+            dx = torch.empty_like(x)
+            call('hoig_conv2d_bwd_data', ctypes.byref(d), _p(g), _p(w), _p(dx), _st())
+        return dx, dw_ret, db_ret, None, None, None, None, None, None, None
+
+
+def conv2d(x, w, b=None, stride=1, pad=0, act=L.ACT_NONE, slope=0.0, prec=None):
+    return _Conv.apply(x, w, b, stride, pad, False, act, slope, None, precision if prec is None else prec)
+
+
+def conv_transpose2d(x, w, stride=2, pad=1, output_padding=1, prec=None):
+    """nn.ConvTranspose2d(k, stride, padding, output_padding, bias=False) (generator.py:118,201)."""
+    B, Hi, Wi, _ = x.shape
+    R, S = w.shape[2], w.shape[3]
+    out_hw = ((Hi - 1) * stride - 2 * pad + R + output_padding, (Wi - 1) * stride - 2 * pad + S + output_padding)
+    return _Conv.apply(x, w, None, stride, pad, True, L.ACT_NONE, 0.0, out_hw, precision if prec is None else prec)
+
+
+# ------------------------------------------------------------------------------------------------- instance norm
+class _INorm(Function):
+    @staticmethod
+    def forward(ctx, x, p0, p1, mode, act, slope, residual, eps):
+        _chk(x, 'x')
+        assert x.is_contiguous()
+        B, H, W, C = x.shape
+        HW = H * W
+        ws = torch.empty(L.lib.hoig_inorm_workspace_bytes(B, HW, C) // 4, dtype=torch.float32, device=x.device)
+        mean = torch.empty(B * C, dtype=torch.float32, device=x.device)
+        rstd = torch.empty_like(mean)
+        call('hoig_inorm_stats', _p(x), B, HW, C, eps, _p(mean), _p(rstd), _p(ws), _st())
+        y = torch.empty_like(x)
+        if act != L.ACT_NONE and residual is not None:
+            raise ValueError('activation + residual in one instance-norm epilogue is not defined')
+        call('hoig_inorm_apply', _p(x), _p(mean), _p(rstd), mode, _p(p0), _p(p1), act, slope, _p(residual), _p(y),
+             B, HW, C, _st())
+        ctx.cfg = (mode, act, slope, B, HW, C, residual is not None)
+        ctx.save_for_backward(x, mean, rstd, p0, p1, y if act != L.ACT_NONE else None)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, mean, rstd, p0, p1, y = ctx.saved_tensors
+        mode, act, slope, B, HW, C, has_res = ctx.cfg
+        dy = dy.contiguous()
+        ws = torch.empty(L.lib.hoig_inorm_workspace_bytes(B, HW, C) // 4, dtype=torch.float32, device=x.device)
+        dx = torch.empty_like(x)
+        dp0 = dp1 = r0 = r1 = None
+        if mode == 1:
+            dp0, ret0 = _grad_target(p0)
+            dp1, ret1 = _grad_target(p1)
+            r0, r1 = (dp0 if ret0 else None), (dp1 if ret1 else None)
+        elif mode == 2:
+            dp0, dp1 = torch.empty_like(x), torch.empty_like(x)
+            r0, r1 = dp0, dp1
+        call('hoig_inorm_bwd', _p(x), _p(mean), _p(rstd), mode, _p(p0), _p(y), _p(dy), act, slope, _p(dx), _p(dp0),
+             _p(dp1), B, HW, C, _p(ws), _st())
+        return dx, r0, r1, None, None, None, (dy if has_res else None), None
+
+
+def instance_norm(x, weight=None, bias=None, act=L.ACT_NONE, slope=0.0, residual=None, eps=1e-5):
+    mode = 1 if weight is not None else 0
+    return _INorm.apply(x, weight, bias, mode, act, slope, residual, eps)
+
+
+def spade_norm(x, gamma, beta, act=L.ACT_NONE, slope=0.0, eps=1e-5):
+    """IN(x) * (1 + gamma) + beta (spade.py:36), optionally followed by an activation."""
+    return _INorm.apply(x, gamma, beta, 2, act, slope, None, eps)
+
+
+# ------------------------------------------------------------------------------------------------- small ops
+class _Add(Function):
+    @staticmethod
+    def forward(ctx, a, b):
+        _chk(a); _chk(b)
+        assert a.shape == b.shape and a.is_contiguous() and b.is_contiguous()
+        y = torch.empty_like(a)
+        call('hoig_add', _p(a), _p(b), _p(y), a.numel(), _st())
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        return dy, dy
+
+
+def add(a, b):
+    return _Add.apply(a, b)
+
+
+def _copy_channels(x, y, x_off, y_off, n, accumulate=False):
+    npix = x.numel() // x.shape[-1]
+    call('hoig_copy_channels', _p(x), _p(y), npix, x.shape[-1], x_off, y.shape[-1], y_off, n, 1 if accumulate else 0,
+         _st())
+
+
+class _Cat(Function):
+    @staticmethod
+    def forward(ctx, *xs):
+        for t in xs:
+            _chk(t)
+            assert t.is_contiguous()
+        cs = [t.shape[-1] for t in xs]
+        y = torch.empty(xs[0].shape[:-1] + (sum(cs),), dtype=xs[0].dtype, device=xs[0].device)
+        off = 0
+        for t, c in zip(xs, cs):
+            _copy_channels(t, y, 0, off, c)
+            off += c
+        ctx.cs = cs
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        dy = dy.contiguous()
+        outs, off = [], 0
+        for i, c in enumerate(ctx.cs):
+            if ctx.needs_input_grad[i]:
+                g = torch.empty(dy.shape[:-1] + (c,), dtype=dy.dtype, device=dy.device)
+                _copy_channels(dy, g, off, 0, c)
+                outs.append(g)
+            else:
+                outs.append(None)
+            off += c
+        return tuple(outs)
+
+
+def cat_channels(xs):
+    return _Cat.apply(*xs)
+
+
+def slice_channels(x, a, b):
+    """x[..., a:b] as a new contiguous NHWC tensor (inputs only; no gradient)."""
+    y = torch.empty(x.shape[:-1] + (b - a,), dtype=x.dtype, device=x.device)
+    _copy_channels(x, y, a, 0, b - a)
+    return y
+
+
+def nchw_to_nhwc(x):
+    _chk(x)
+    x = x.contiguous()
+    B, C, H, W = x.shape
+    y = torch.empty((B, H, W, C), dtype=x.dtype, device=x.device)
+    call('hoig_nchw_to_nhwc', _p(x), _p(y), B, C, H, W, _st())
+    return y
+
+
+def nhwc_to_nchw(x):
+    _chk(x)
+    x = x.contiguous()
+    B, H, W, C = x.shape
+    y = torch.empty((B, C, H, W), dtype=x.dtype, device=x.device)
+    call('hoig_nhwc_to_nchw', _p(x), _p(y), B, C, H, W, _st())
+    return y
+
+
+class _MaxPool(Function):
+    @staticmethod
+    def forward(ctx, x):
+        _chk(x)
+        B, H, W, C = x.shape
+        y = torch.empty((B, H // 2, W // 2, C), dtype=x.dtype, device=x.device)
+        call('hoig_maxpool2_fwd', _p(x), _p(y), B, H, W, C, _st())
+        ctx.save_for_backward(x)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, = ctx.saved_tensors
+        B, H, W, C = x.shape
+        dx = torch.empty_like(x)
+        call('hoig_maxpool2_bwd', _p(x), None, _p(dy.contiguous()), _p(dx), B, H, W, C, _st())
+        return dx
+
+
+def maxpool2(x):
+    return _MaxPool.apply(x)
+
+
+# ------------------------------------------------------------------------------------------------- sampling
+def resize_bilinear_ac(x, ho, wo):
+    B, Hi, Wi, C = x.shape
+    y = torch.empty((B, ho, wo, C), dtype=x.dtype, device=x.device)
+    call('hoig_resize_bilinear_ac', _p(x.contiguous()), _p(y), B, Hi, Wi, C, ho, wo, _st())
+    return y
+
+
+def resize_nearest(x, ho, wo):
+    B, Hi, Wi, C = x.shape
+    if (Hi, Wi) == (ho, wo):
+        return x
+    y = torch.empty((B, ho, wo, C), dtype=x.dtype, device=x.device)
+    call('hoig_resize_nearest', _p(x.contiguous()), _p(y), B, Hi, Wi, C, ho, wo, _st())
+    return y
+
+
+def attn_flow(tscale):
+    B, h = tscale.shape[0], tscale.shape[1]
+    flow = torch.empty((B, 2, h, h), dtype=tscale.dtype, device=tscale.device)
+    call('hoig_attn_flow', _p(tscale.contiguous()), _p(flow), B, h, _st())
+    return flow
+
+
+class _GridSample(Function):
+    @staticmethod
+    def forward(ctx, x, grid):
+        _chk(x); _chk(grid)
+        B, H, W, C = x.shape
+        Ho, Wo = grid.shape[1], grid.shape[2]
+        y = torch.empty((B, Ho, Wo, C), dtype=x.dtype, device=x.device)
+        call('hoig_grid_sample_fwd', _p(x), _p(grid), _p(y), B, H, W, C, Ho, Wo, _st())
+        ctx.save_for_backward(grid)
+        ctx.shape = (B, H, W, C, Ho, Wo)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        grid, = ctx.saved_tensors
+        B, H, W, C, Ho, Wo = ctx.shape
+        dx = torch.zeros((B, H, W, C), dtype=dy.dtype, device=dy.device)
+        call('hoig_grid_sample_bwd', _p(grid), _p(dy.contiguous()), _p(dx), B, H, W, C, Ho, Wo, _st())
+        return dx, None
+
+
+def grid_sample(x, grid):
+    return _GridSample.apply(x, grid.contiguous())
+
+
+class _LocalAttn(Function):
+    @staticmethod
+    def forward(ctx, source, target, flow, w1, b1, w2, b2, prec):
+        for t in (source, target, flow, w1, b1, w2, b2):
+            _chk(t)
+        B, H, W, C = source.shape
+        assert tuple(w1.shape) == (128, 2 * C, 5, 5) and tuple(w1.stride()) == packed_strides(w1.shape, False)
+        M = B * H * W
+        hidden = torch.empty((M, 128), dtype=source.dtype, device=source.device)
+        attn = torch.empty((M, 25), dtype=source.dtype, device=source.device)
+        out = torch.empty_like(source)
+        call('hoig_local_attn_fwd', _p(source), _p(target), _p(flow), _p(w1), _p(b1), _p(w2), _p(b2), _p(hidden),
+             _p(attn), _p(out), B, H, W, C, prec, _st())
+        ctx.save_for_backward(source, target, flow, w1, b1, w2, b2, hidden, attn)
+        ctx.prec = prec
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        source, target, flow, w1, b1, w2, b2, hidden, attn = ctx.saved_tensors
+        B, H, W, C = source.shape
+        dsrc = torch.zeros_like(source)
+        dtgt = torch.zeros_like(target)
+        dhid = torch.empty_like(hidden)
+        gs = [_grad_target(p) for p in (w1, b1, w2, b2)]
+        call('hoig_local_attn_bwd', _p(source), _p(target), _p(flow), _p(w1), _p(w2), _p(hidden), _p(attn),
+             _p(dout.contiguous()), _p(dsrc), _p(dtgt), _p(gs[0][0]), _p(gs[1][0]), _p(gs[2][0]), _p(gs[3][0]),
+             _p(dhid), B, H, W, C, ctx.prec, _st())
+        rets = [g if r else None for g, r in gs]
+        return dsrc, dtgt, None, rets[0], rets[1], rets[2], rets[3], None
+
+
+def local_attention(source, target, flow, w1, b1, w2, b2, prec=None):
+    return _LocalAttn.apply(source, target, flow.contiguous(), w1, b1, w2, b2, precision if prec is None else prec)
+
+
+# stand-alone equivalents of the reference's two extension modules (NCHW, caller-visible semantics of
+# block_extractor.py:5-54 / local_attn_reshape.py:5-46)
+class _BlockExtractor(Function):
+    @staticmethod
+    def forward(ctx, source, flow, k):
+        _chk(source); _chk(flow)
+        assert source.is_contiguous() and flow.is_contiguous() and flow.shape[1] == 2
+        B, C, Hs, Ws = source.shape
+        Hf, Wf = flow.shape[2], flow.shape[3]
+        out = source.new_zeros((B, C, k * Hf, k * Wf))
+        call('hoig_block_extractor_forward', _p(source), _p(flow), _p(out), B, C, Hs, Ws, Hf, Wf, k, _st())
+        ctx.save_for_backward(source, flow)
+        ctx.k = k
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        source, flow = ctx.saved_tensors
+        B, C, Hs, Ws = source.shape
+        Hf, Wf = flow.shape[2], flow.shape[3]
+        gs, gf = torch.zeros_like(source), torch.zeros_like(flow)
+        call('hoig_block_extractor_backward', _p(source), _p(flow), _p(g.contiguous()), _p(gs), _p(gf), B, C, Hs, Ws,
+             Hf, Wf, ctx.k, _st())
+        return gs, gf, None
+
+
+def block_extractor(source, flow, kernel_size):
+    return _BlockExtractor.apply(source.contiguous(), flow.contiguous(), kernel_size)
+
+
+class _LocalAttnReshape(Function):
+    @staticmethod
+    def forward(ctx, x, k):
+        _chk(x)
+        B, C, Hs, Ws = x.shape
+        assert C == k * k
+        out = x.new_zeros((B, 1, k * Hs, k * Ws))
+        call('hoig_local_attn_reshape_forward', _p(x), _p(out), B, Hs, Ws, k, _st())
+        ctx.cfg = (B, Hs, Ws, k)
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        B, Hs, Ws, k = ctx.cfg
+        gi = g.new_zeros((B, k * k, Hs, Ws))
+        call('hoig_local_attn_reshape_backward', _p(g.contiguous()), _p(gi), B, Hs, Ws, k, _st())
+        return gi, None
+
+
+def local_attn_reshape(x, kernel_size):
+    return _LocalAttnReshape.apply(x.contiguous(), kernel_size)
+
+
+# ------------------------------------------------------------------------------------------------- compose / losses
+class _Compose(Function):
+    @staticmethod
+    def forward(ctx, bg, obj, hand, mbg, mh):
+        for t in (bg, obj, hand, mbg, mh):
+            _chk(t)
+        C = bg.shape[-1]
+        npix = bg.numel() // C
+        img = torch.empty_like(bg)
+        call('hoig_compose_fwd', _p(bg), _p(obj), _p(hand), _p(mbg), _p(mh), _p(img), npix, C, _st())
+        ctx.save_for_backward(bg, obj, hand, mbg, mh)
+        return img
+
+    @staticmethod
+    def backward(ctx, dimg):
+        bg, obj, hand, mbg, mh = ctx.saved_tensors
+        C = bg.shape[-1]
+        npix = bg.numel() // C
+        dbg, dobj, dhand = torch.empty_like(bg), torch.empty_like(obj), torch.empty_like(hand)
+        dmbg, dmh = torch.empty_like(mbg), torch.empty_like(mh)
+        call('hoig_compose_bwd', _p(bg), _p(obj), _p(hand), _p(mbg), _p(mh), _p(dimg.contiguous()), _p(dbg), _p(dobj),
+             _p(dhand), _p(dmbg), _p(dmh), npix, C, _st())
+        return dbg, dobj, dhand, dmbg, dmh
+
+
+def compose(bg, obj, hand, mbg, mh):
+    """mbg*bg + (1-mbg)*(obj*mh + hand*(1-mh))  (trainer.py:400-401)."""
+    return _Compose.apply(bg, obj, hand, mbg, mh)
+
+
+class _MeanLoss(Function):
+    """scale * mean(loss(pred, target)); the kernel produces the sum and the pre-scaled gradient in one pass."""
+
+    @staticmethod
+    def forward(ctx, pred, target, kind, tconst, scale):
+        _chk(pred); _chk(target)
+        pred = pred.contiguous()
+        n = pred.numel()
+        out = torch.zeros(1, dtype=torch.float32, device=pred.device)
+        need = pred.requires_grad
+        dpred = torch.empty_like(pred) if need else None
+        call('hoig_loss_fwd_bwd', kind, _p(pred), _p(target), tconst, scale / n, _p(out), _p(dpred), n, _st())
+        ctx.save_for_backward(dpred)
+        return out[0] * (scale / n)
+
+    @staticmethod
+    def backward(ctx, g):
+        dpred, = ctx.saved_tensors
+        return (dpred * g if dpred is not None else None), None, None, None, None
+
+
+def l1_loss(pred, target, scale=1.0):
+    return _MeanLoss.apply(pred, target.contiguous(), L.LOSS_L1, 0.0, scale)
+
+
+def mse_loss(pred, target, scale=1.0):
+    return _MeanLoss.apply(pred, target.contiguous(), L.LOSS_MSE, 0.0, scale)
+
+
+def bce_loss(pred, target, scale=1.0):
+    return _MeanLoss.apply(pred, target.contiguous(), L.LOSS_BCE, 0.0, scale)
+
+
+def lsgan_loss(pred, target_value, scale=1.0):
+    """mean((x - y)^2) * scale with a constant target (trainer.py:476-477)."""
+    return _MeanLoss.apply(pred, None, L.LOSS_MSE, float(target_value), scale)
+
+
+class _TV(Function):
+    """Trainer._compute_loss_smooth (trainer.py:479-481) on a single-channel NHWC map."""
+
+    @staticmethod
+    def forward(ctx, m, scale):
+        _chk(m)
+        m = m.contiguous()
+        B, H, W, C = m.shape
+        assert C == 1
+        out = torch.zeros(2, dtype=torch.float32, device=m.device)
+        nx, ny = B * H * (W - 1), B * (H - 1) * W
+        need = m.requires_grad
+        dm = torch.empty_like(m) if need else None
+        call('hoig_tv_fwd_bwd', _p(m), scale / nx, scale / ny, _p(out), _p(dm), B, H, W, _st())
+        ctx.save_for_backward(dm)
+        return out[0] * (scale / nx) + out[1] * (scale / ny)
+
+    @staticmethod
+    def backward(ctx, g):
+        dm, = ctx.saved_tensors
+        return (dm * g if dm is not None else None), None
+
+
+def tv_loss(m, scale=1.0):
+    return _TV.apply(m, scale)
+
+
+def mean(x):
+    out = torch.zeros(1, dtype=torch.float32, device=x.device)
+    call('hoig_sum', _p(x.contiguous()), _p(out), x.numel(), _st())
+    return out[0] / x.numel()
+
+
+def tensor2im_u8(x_nhwc, nrow, unnormalize=True):
+    """utils/util.py:249-264 for a batch grid: uint8 CHW of make_grid(nrow, padding=0)."""
+    B, H, W, C = x_nhwc.shape
+    ncol = min(nrow, B)
+    nrw = (B + ncol - 1) // ncol
+    out = torch.empty((C, nrw * H, ncol * W), dtype=torch.uint8, device=x_nhwc.device)
+    call('hoig_tensor2im_u8', _p(x_nhwc.contiguous()), _p(out), B, H, W, C, nrow, 1 if unnormalize else 0, _st())
+    return out

@@ -1,0 +1,186 @@
+/* hoig_kernels.h -- C ABI of libhoig_hip.so: the hand-written gfx950 (CDNA4)
+ * kernels behind the HOGAN generator/discriminator hot path.
+ *
+ * Boundary conventions (they mirror what the reference's own native layer does,
+ * thirdparty/block_extractor/block_extractor_cuda.cc:5-33 and
+ * thirdparty/local_attn_reshape/local_attn_reshape_cuda.cc:5-29, wrapped by
+ * block_extractor.py:5-54 / local_attn_reshape.py:5-46):
+ *   - plain device pointers + sizes, no torch types;
+ *   - the CALLER owns and allocates every buffer (outputs, workspaces);
+ *   - work is enqueued on the given hipStream_t, never synchronises, no
+ *     allocation inside (graph-capturable);
+ *   - return 0 on success, a negative HOIG_E* code on a rejected argument or a
+ *     failed launch (the reference returns `int 1` and never checks).
+ * Differences from the reference ops, by design: activations are NHWC fp32
+ * ("channels-last"), conv weights are packed [Cout][kh][kw][Cin] for Conv2d AND
+ * ConvTranspose2d (the host keeps the reference's logical NCHW shapes as views
+ * of that storage, hoig_amd/nn.py), gradients of weights ACCUMULATE into the
+ * caller's (zeroed) flat gradient buffer.
+ *
+ * Reference call sites each family replaces are cited per function
+ * (paths relative to /root/reference/HOIG_HOv3).
+ */
+#ifndef HOIG_KERNELS_H
+#define HOIG_KERNELS_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef void *hoig_stream_t; /* hipStream_t */
+
+enum { HOIG_OK = 0, HOIG_EINVAL = -1, HOIG_ELAUNCH = -2, HOIG_EUNSUPPORTED = -3 };
+
+/* epilogue activations */
+enum { HOIG_ACT_NONE = 0, HOIG_ACT_RELU = 1, HOIG_ACT_LRELU = 2, HOIG_ACT_TANH = 3, HOIG_ACT_SIGMOID = 4 };
+
+/* arithmetic of the MFMA contraction (accumulation is always fp32):
+ *   F32    v_mfma_f32_32x32x2_f32, exact fp32 products (parity mode)
+ *   BF16X3 operands split hi+lo bf16, 3 x v_mfma_f32_32x32x16_bf16 (~2^-16 rel.)
+ *   BF16   one v_mfma_f32_32x32x16_bf16 per k-step (~2^-8 rel. per operand) */
+enum { HOIG_PREC_F32 = 0, HOIG_PREC_BF16X3 = 1, HOIG_PREC_BF16 = 2 };
+
+/* One convolution problem.  NHWC activations, weights [Co][R][S][Ci].
+ * transposed=0: y = conv2d(x, w, stride, pad)            x:[B,Hi,Wi,Ci] y:[B,Ho,Wo,Co]
+ * transposed=1: y = conv_transpose2d(x, w, stride, pad)  (output_padding implied by Ho,Wo)
+ * Replaces the cuDNN convolutions reached from generator.py:15-235,
+ * spade.py:18-22, discriminator.py:29-49, extract_attn.py:18-20, vgg19.py:56. */
+typedef struct hoig_conv_desc {
+    int32_t B, Hi, Wi, Ci;
+    int32_t Ho, Wo, Co;
+    int32_t R, S;
+    int32_t stride, pad;
+    int32_t transposed;
+    int32_t act;       /* forward epilogue: HOIG_ACT_* applied after +bias */
+    float slope;       /* LeakyReLU slope */
+    int32_t precision; /* HOIG_PREC_* */
+} hoig_conv_desc;
+
+int hoig_conv2d_fwd(const hoig_conv_desc *d, const float *x, const float *w, const float *bias /*nullable*/,
+                    float *y, hoig_stream_t stream);
+/* dx = d(loss)/dx given dy (dy already carries the activation derivative) */
+int hoig_conv2d_bwd_data(const hoig_conv_desc *d, const float *dy, const float *w, float *dx, hoig_stream_t stream);
+/* dw += ..., dbias += ... (atomic accumulation into caller-zeroed buffers; dbias nullable) */
+int hoig_conv2d_bwd_weight(const hoig_conv_desc *d, const float *x, const float *dy, float *dw, float *dbias,
+                           hoig_stream_t stream);
+
+/* ---- instance norm (generator.py:16-22,101-120,154-208; spade.py:13; discriminator.py:37,45 via
+ *      base_network.py:31): per-(b,c) mean / biased variance over H*W, eps 1e-5, no running stats. ---- */
+/* stats: mean[b*C+c], rstd[b*C+c].  workspace: >= hoig_inorm_workspace_bytes(B,HW,C) bytes. */
+int64_t hoig_inorm_workspace_bytes(int B, int HW, int C);
+int hoig_inorm_stats(const float *x, int B, int HW, int C, float eps, float *mean, float *rstd, void *workspace,
+                     hoig_stream_t stream);
+/* y = act( (x-mean)*rstd * scale + shift ) + residual
+ *   mode 0: scale=1, shift=0 (param-free)           mode 1: scale=weight[c], shift=bias[c] (affine)
+ *   mode 2: scale=1+gamma[b,hw,c], shift=beta[b,hw,c] (SPADE, spade.py:36) */
+int hoig_inorm_apply(const float *x, const float *mean, const float *rstd, int mode, const float *p0, const float *p1,
+                     int act, float slope, const float *residual /*nullable*/, float *y, int B, int HW, int C,
+                     hoig_stream_t stream);
+/* backward of hoig_inorm_apply(+stats).  dy is d/d(y) ; y is the forward output (for the activation mask; pass
+ * the pre-residual activation output, or NULL when act==NONE).
+ * Outputs: dx; mode 1: dweight[c] += , dbias[c] += ; mode 2: dgamma, dbeta (same shape as x, overwritten).
+ * workspace >= hoig_inorm_workspace_bytes. */
+int hoig_inorm_bwd(const float *x, const float *mean, const float *rstd, int mode, const float *p0, const float *y,
+                   const float *dy, int act, float slope, float *dx, float *dp0, float *dp1, int B, int HW, int C,
+                   void *workspace, hoig_stream_t stream);
+
+/* ---- local attention warping: ExtractorAttn (extract_attn.py:23-29) = K1 block extraction of source
+ *      (with flow) and target (zero flow) + conv k5/s5 + LeakyReLU(0.01) + conv1x1 + softmax(25) + K3 reshape +
+ *      weighted 5x5 average, WITHOUT materialising the 25x tensors.
+ *      source/target: [B,H,W,C] NHWC; flow: [B,2,H,W] (ch0 = x, ch1 = y, PIXEL units as K1 reads them,
+ *      block_extractor_kernel.cu:62-67); w1: [128][5][5][2C] packed (first C = target, next C = source);
+ *      b1[128]; w2[25][128]; b2[25].
+ *      hidden: [B*H*W,128] pre-activation (saved for backward); attn: [B*H*W,25] softmax; out: [B,H,W,C]. ---- */
+int hoig_local_attn_fwd(const float *source, const float *target, const float *flow, const float *w1, const float *b1,
+                        const float *w2, const float *b2, float *hidden, float *attn, float *out, int B, int H, int W,
+                        int C, int precision, hoig_stream_t stream);
+/* backward: dsource, dtarget overwritten ([B,H,W,C], caller zero-fills), dw1/db1/dw2/db2 accumulate.
+ * dhidden: scratch [B*H*W,128]. The flow carries no gradient on the path (it is data: generator.py:481-488). */
+int hoig_local_attn_bwd(const float *source, const float *target, const float *flow, const float *w1, const float *w2,
+                        const float *hidden, const float *attn, const float *dout, float *dsource, float *dtarget,
+                        float *dw1, float *db1, float *dw2, float *db2, float *dhidden, int B, int H, int W, int C,
+                        int precision, hoig_stream_t stream);
+
+/* Stand-alone drop-ins for the reference's two pybind ops, same argument meaning, contiguous NCHW fp32,
+ * caller zero-fills outputs: block_extractor_cuda.forward/backward (block_extractor_cuda.cc:5-33) and
+ * local_attn_reshape_cuda.forward/backward (local_attn_reshape_cuda.cc:5-29). */
+int hoig_block_extractor_forward(const float *source, const float *flow, float *output, int B, int C, int Hs, int Ws,
+                                 int Hf, int Wf, int kernel_size, hoig_stream_t stream);
+int hoig_block_extractor_backward(const float *source, const float *flow, const float *grad_output, float *grad_source,
+                                  float *grad_flow, int B, int C, int Hs, int Ws, int Hf, int Wf, int kernel_size,
+                                  hoig_stream_t stream);
+int hoig_local_attn_reshape_forward(const float *inputs, float *output, int B, int Hs, int Ws, int kernel_size,
+                                    hoig_stream_t stream);
+int hoig_local_attn_reshape_backward(const float *grad_output, float *grad_inputs, int B, int Hs, int Ws,
+                                     int kernel_size, hoig_stream_t stream);
+
+/* ---- sampling (generator.py:466-478; spade.py:30) ---- */
+/* F.grid_sample(x, grid) bilinear / zeros / align_corners=False. x:[B,H,W,C] NHWC, grid:[B,Ho,Wo,2], y:[B,Ho,Wo,C] */
+int hoig_grid_sample_fwd(const float *x, const float *grid, float *y, int B, int H, int W, int C, int Ho, int Wo,
+                         hoig_stream_t stream);
+/* dx accumulates (caller zero-fills) */
+int hoig_grid_sample_bwd(const float *grid, const float *dy, float *dx, int B, int H, int W, int C, int Ho, int Wo,
+                         hoig_stream_t stream);
+/* F.interpolate(bilinear, align_corners=True) on NHWC [B,Hi,Wi,C] -> [B,Ho,Wo,C] */
+int hoig_resize_bilinear_ac(const float *x, float *y, int B, int Hi, int Wi, int C, int Ho, int Wo,
+                            hoig_stream_t stream);
+/* F.interpolate(nearest) NHWC */
+int hoig_resize_nearest(const float *x, float *y, int B, int Hi, int Wi, int C, int Ho, int Wo, hoig_stream_t stream);
+/* attention flow of generator.py:484-488: flow[b,ch,y,x] = Tscale[b,y,x,ch] - idt ; idt ch0 = -1+2*y/h (the ROW
+ * coordinate, 'ij' meshgrid quirk), ch1 = -1+2*x/h.  tscale:[B,h,h,2] -> flow:[B,2,h,h] */
+int hoig_attn_flow(const float *tscale, float *flow, int B, int h, hoig_stream_t stream);
+
+/* ---- pooling for the VGG19 feature path (vgg19.py:56; MaxPool2d(2,2)) NHWC ---- */
+int hoig_maxpool2_fwd(const float *x, float *y, int B, int H, int W, int C, hoig_stream_t stream);
+int hoig_maxpool2_bwd(const float *x, const float *y, const float *dy, float *dx, int B, int H, int W, int C,
+                      hoig_stream_t stream);
+
+/* ---- pointwise / layout ---- */
+int hoig_nchw_to_nhwc(const float *x, float *y, int B, int C, int H, int W, hoig_stream_t stream);
+int hoig_nhwc_to_nchw(const float *x, float *y, int B, int C, int H, int W, hoig_stream_t stream);
+/* y[:, c_off : c_off+Cx] = x  for NHWC tensors with Cy channels (channel concat building block) */
+int hoig_copy_channels(const float *x, float *y, int64_t npix, int Cx, int x_off, int Cy, int y_off, int Ccopy,
+                       int accumulate, hoig_stream_t stream);
+/* y = a + b (n elements) ; y = act_bwd: dx = dy * act'(y) */
+int hoig_add(const float *a, const float *b, float *y, int64_t n, hoig_stream_t stream);
+int hoig_act_bwd(const float *y, const float *dy, float *dx, int act, float slope, int64_t n, hoig_stream_t stream);
+/* column sums: out[c] += sum_rows x[row][c]  (bias gradients) */
+int hoig_colsum_accum(const float *x, float *out, int64_t rows, int C, hoig_stream_t stream);
+
+/* alpha compositing of trainer.py:400-401 : img = mbg*bg + (1-mbg)*(obj*mh + hand*(1-mh)); NHWC, masks 1 channel */
+int hoig_compose_fwd(const float *bg, const float *obj, const float *hand, const float *mbg, const float *mh, float *img,
+                     int64_t npix, int C, hoig_stream_t stream);
+int hoig_compose_bwd(const float *bg, const float *obj, const float *hand, const float *mbg, const float *mh,
+                     const float *dimg, float *dbg, float *dobj, float *dhand, float *dmbg, float *dmh, int64_t npix,
+                     int C, hoig_stream_t stream);
+
+/* ---- losses (trainer.py:436-481): each writes sum-reductions into out[] (caller-zeroed, fp32 atomics of
+ *      per-block partials) and, when dpred != NULL, the gradient of (scale * mean-loss) w.r.t. pred. ---- */
+enum { HOIG_LOSS_L1 = 0, HOIG_LOSS_MSE = 1, HOIG_LOSS_BCE = 2 };
+/* out[0] += sum loss(pred, target) ; dpred = gscale * dloss/dpred (gscale already includes 1/n and lambda).
+ * target_const used when target == NULL (LSGAN targets 0/+1/-1, trainer.py:439,467-468). */
+int hoig_loss_fwd_bwd(int kind, const float *pred, const float *target, float target_const, float gscale, float *out,
+                      float *dpred, int64_t n, hoig_stream_t stream);
+/* TV-L1 smoothness trainer.py:479-481 on [B,H,W] single-channel maps: out[0] += sum|dx|, out[1] += sum|dy| ;
+ * dm (overwritten) = gx * d(sum|dx|) + gy * d(sum|dy|) */
+int hoig_tv_fwd_bwd(const float *m, float gx, float gy, float *out, float *dm, int B, int H, int W, hoig_stream_t stream);
+/* out[0] += sum x */
+int hoig_sum(const float *x, float *out, int64_t n, hoig_stream_t stream);
+
+/* ---- fused Adam over one flat parameter buffer (torch.optim.Adam defaults of trainer.py:275-278:
+ *      no weight decay, no amsgrad): step is the 1-based step count after increment ---- */
+int hoig_adam_step(float *param, const float *grad, float *exp_avg, float *exp_avg_sq, int64_t n, float lr, float beta1,
+                   float beta2, float eps, int step, float grad_scale, hoig_stream_t stream);
+
+/* eval.py output stage (utils/util.py:249-264): uint8 = (x+1)/2*255 truncated, NHWC fp32 -> CHW uint8 grid tile */
+int hoig_tensor2im_u8(const float *x, uint8_t *out, int B, int H, int W, int C, int nrow, int unnormalize,
+                      hoig_stream_t stream);
+
+const char *hoig_version(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

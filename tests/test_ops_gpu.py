@@ -1,0 +1,308 @@
+"""GPU parity of every C-ABI operator family against the fp32 CPU oracle arithmetic (torch ATen ops are the
+reference's own arithmetic; K1-K4 / attention against oracle/hogan_oracle.py).  Tolerances: fp32-exact MFMA mode
+1e-4 relative (summation order differs), far inside the 1e-3 north_star bound."""
+import pytest
+import torch
+import torch.nn.functional as F
+
+from gpu_util import nhwc_cuda, nchw_cpu, rel_err
+
+pytestmark = pytest.mark.gpu
+TOL = 1e-4
+
+
+def _ops():
+    from hoig_amd import ops
+    return ops
+
+
+CONV_CASES = [
+    # B, Ci, Co, H, k, stride, pad, bias
+    (2, 64, 64, 16, 3, 1, 1, False),
+    (2, 128, 256, 16, 3, 2, 1, False),
+    (1, 512, 512, 8, 3, 1, 1, True),
+    (2, 3, 64, 32, 7, 1, 3, False),
+    (2, 8, 64, 16, 7, 1, 3, False),
+    (2, 12, 128, 16, 3, 1, 1, True),
+    (2, 64, 3, 32, 7, 1, 3, False),
+    (2, 128, 1, 16, 7, 1, 3, False),
+    (2, 19, 64, 32, 4, 2, 1, True),
+    (2, 64, 128, 16, 4, 2, 1, True),
+    (2, 256, 256, 9, 4, 1, 1, True),
+    (2, 256, 1, 8, 4, 1, 1, True),
+    (3, 96, 160, 10, 3, 1, 1, True),
+    (2, 128, 25, 8, 1, 1, 0, True),
+]
+
+
+@pytest.mark.parametrize('B,Ci,Co,H,k,stride,pad,bias', CONV_CASES)
+def test_conv2d_fwd_bwd(B, Ci, Co, H, k, stride, pad, bias):
+    ops = _ops()
+    g = torch.Generator().manual_seed(1)
+    x = torch.randn(B, Ci, H, H, generator=g)
+    w = torch.randn(Co, Ci, k, k, generator=g) * 0.1
+    b = torch.randn(Co, generator=g) if bias else None
+    xr, wr = x.clone().requires_grad_(True), w.clone().requires_grad_(True)
+    br = b.clone().requires_grad_(True) if bias else None
+    yr = F.conv2d(xr, wr, br, stride=stride, padding=pad)
+    gy = torch.randn(yr.shape, generator=g)
+    yr.backward(gy)
+
+    xd = nhwc_cuda(x).requires_grad_(True)
+    wd = ops.pack_weight(w.cuda()).requires_grad_(True)
+    bd = b.cuda().requires_grad_(True) if bias else None
+    y = ops.conv2d(xd, wd, bd, stride, pad)
+    y.backward(nhwc_cuda(gy))
+    torch.cuda.synchronize()
+    assert rel_err(nchw_cpu(y), yr) < TOL
+    assert rel_err(nchw_cpu(xd.grad), xr.grad) < TOL
+    assert rel_err(wd.grad, wr.grad) < TOL
+    if bias:
+        assert rel_err(bd.grad, br.grad) < TOL
+
+
+@pytest.mark.parametrize('B,Ci,Co,H', [(2, 64, 32, 8), (1, 512, 256, 4), (2, 128, 64, 16), (3, 32, 32, 6)])
+def test_conv_transpose2d_fwd_bwd(B, Ci, Co, H):
+    ops = _ops()
+    g = torch.Generator().manual_seed(2)
+    x = torch.randn(B, Ci, H, H, generator=g)
+    w = torch.randn(Ci, Co, 3, 3, generator=g) * 0.1
+    xr, wr = x.clone().requires_grad_(True), w.clone().requires_grad_(True)
+    yr = F.conv_transpose2d(xr, wr, None, stride=2, padding=1, output_padding=1)
+    gy = torch.randn(yr.shape, generator=g)
+    yr.backward(gy)
+    xd = nhwc_cuda(x).requires_grad_(True)
+    wd = ops.pack_weight(w.cuda(), transposed=True).requires_grad_(True)
+    y = ops.conv_transpose2d(xd, wd)
+    y.backward(nhwc_cuda(gy))
+    assert rel_err(nchw_cpu(y), yr) < TOL
+    assert rel_err(nchw_cpu(xd.grad), xr.grad) < TOL
+    assert rel_err(wd.grad, wr.grad) < TOL
+
+
+@pytest.mark.parametrize('act', ['relu', 'lrelu', 'tanh', 'sigmoid'])
+def test_conv_epilogue_activations(act):
+    ops = _ops()
+    from hoig_amd import _lib as L
+    code = dict(relu=L.ACT_RELU, lrelu=L.ACT_LRELU, tanh=L.ACT_TANH, sigmoid=L.ACT_SIGMOID)[act]
+    fn = dict(relu=F.relu, lrelu=lambda t: F.leaky_relu(t, 0.2), tanh=torch.tanh, sigmoid=torch.sigmoid)[act]
+    g = torch.Generator().manual_seed(3)
+    x = torch.randn(2, 32, 8, 8, generator=g)
+    w = torch.randn(32, 32, 3, 3, generator=g) * 0.1
+    b = torch.randn(32, generator=g)
+    xr, wr = x.clone().requires_grad_(True), w.clone().requires_grad_(True)
+    yr = fn(F.conv2d(xr, wr, b, padding=1))
+    gy = torch.randn(yr.shape, generator=g)
+    yr.backward(gy)
+    xd = nhwc_cuda(x).requires_grad_(True)
+    wd = ops.pack_weight(w.cuda()).requires_grad_(True)
+    y = ops.conv2d(xd, wd, b.cuda(), 1, 1, code, 0.2)
+    y.backward(nhwc_cuda(gy))
+    assert rel_err(nchw_cpu(y), yr) < TOL
+    assert rel_err(nchw_cpu(xd.grad), xr.grad) < TOL
+    assert rel_err(wd.grad, wr.grad) < TOL
+
+
+@pytest.mark.parametrize('mode', ['plain', 'affine', 'spade'])
+@pytest.mark.parametrize('B,C,H,W', [(2, 64, 16, 16), (2, 512, 8, 8), (3, 128, 15, 15), (1, 256, 14, 14)])
+def test_instance_norm(mode, B, C, H, W):
+    ops = _ops()
+    from hoig_amd import _lib as L
+    g = torch.Generator().manual_seed(4)
+    x = torch.randn(B, C, H, W, generator=g) * 2 + 3          # non-zero mean stresses the variance computation
+    xr = x.clone().requires_grad_(True)
+    xd = nhwc_cuda(x).requires_grad_(True)
+    if mode == 'plain':
+        yr = F.leaky_relu(F.instance_norm(xr, eps=1e-5), 0.2)
+        y = ops.instance_norm(xd, act=L.ACT_LRELU, slope=0.2)
+        extra = []
+    elif mode == 'affine':
+        w, b = torch.randn(C, generator=g), torch.randn(C, generator=g)
+        wr, br = w.clone().requires_grad_(True), b.clone().requires_grad_(True)
+        res = torch.randn(B, C, H, W, generator=g)
+        yr = res + F.instance_norm(xr, weight=wr, bias=br, eps=1e-5)
+        wd, bd = w.cuda().requires_grad_(True), b.cuda().requires_grad_(True)
+        y = ops.instance_norm(xd, wd, bd, residual=nhwc_cuda(res))
+        extra = [(wd, wr), (bd, br)]
+    else:
+        ga, be = torch.randn(B, C, H, W, generator=g), torch.randn(B, C, H, W, generator=g)
+        gar, ber = ga.clone().requires_grad_(True), be.clone().requires_grad_(True)
+        yr = F.relu(F.instance_norm(xr, eps=1e-5) * (1 + gar) + ber)
+        gad, bed = nhwc_cuda(ga).requires_grad_(True), nhwc_cuda(be).requires_grad_(True)
+        y = ops.spade_norm(xd, gad, bed, act=L.ACT_RELU)
+        extra = [(gad, gar), (bed, ber)]
+    gy = torch.randn(yr.shape, generator=g)
+    yr.backward(gy)
+    y.backward(nhwc_cuda(gy))
+    assert rel_err(nchw_cpu(y), yr) < TOL
+    assert rel_err(nchw_cpu(xd.grad), xr.grad) < 5 * TOL
+    for d, r in extra:
+        dg = nchw_cpu(d.grad) if d.grad.dim() == 4 else d.grad
+        assert rel_err(dg, r.grad) < 5 * TOL
+
+
+@pytest.mark.parametrize('B,C,h', [(2, 128, 8), (1, 256, 6), (2, 512, 4)])
+def test_local_attention_vs_oracle(B, C, h):
+    """Fused attention (fc1 MFMA + pixel kernel) against the oracle's materialising restatement of
+    extract_attn.py:23-29, forward and all gradients."""
+    ops = _ops()
+    from oracle import hogan_oracle as O
+    g = torch.Generator().manual_seed(5)
+    src = torch.randn(B, C, h, h, generator=g)
+    tgt = torch.randn(B, C, h, h, generator=g)
+    flow = torch.randn(B, 2, h, h, generator=g) * 1.5
+    flow[0, :, 0, 0] = -40.0                                  # far out of range: exercises the border clamp
+    sd = {'a.fully_connect_layer.0.weight': torch.randn(128, 2 * C, 5, 5, generator=g) * 0.02,
+          'a.fully_connect_layer.0.bias': torch.randn(128, generator=g) * 0.1,
+          'a.fully_connect_layer.2.weight': torch.randn(25, 128, 1, 1, generator=g) * 0.3,
+          'a.fully_connect_layer.2.bias': torch.randn(25, generator=g) * 0.1}
+    ref = {k: v.clone().requires_grad_(True) for k, v in sd.items()}
+    sr, tr = src.clone().requires_grad_(True), tgt.clone().requires_grad_(True)
+    yr = O.extractor_attn(sr, tr, flow, ref, 'a')
+    gy = torch.randn(yr.shape, generator=g)
+    yr.backward(gy)
+
+    sdv, tdv = nhwc_cuda(src).requires_grad_(True), nhwc_cuda(tgt).requires_grad_(True)
+    w1 = ops.pack_weight(sd['a.fully_connect_layer.0.weight'].cuda()).requires_grad_(True)
+    b1 = sd['a.fully_connect_layer.0.bias'].cuda().requires_grad_(True)
+    w2 = ops.pack_weight(sd['a.fully_connect_layer.2.weight'].cuda()).requires_grad_(True)
+    b2 = sd['a.fully_connect_layer.2.bias'].cuda().requires_grad_(True)
+    y = ops.local_attention(sdv, tdv, flow.cuda(), w1, b1, w2, b2)
+    y.backward(nhwc_cuda(gy))
+    assert rel_err(nchw_cpu(y), yr) < TOL
+    assert rel_err(nchw_cpu(sdv.grad), sr.grad) < 5 * TOL
+    assert rel_err(nchw_cpu(tdv.grad), tr.grad) < 5 * TOL
+    assert rel_err(w1.grad, ref['a.fully_connect_layer.0.weight'].grad) < 5 * TOL
+    assert rel_err(b1.grad, ref['a.fully_connect_layer.0.bias'].grad) < 5 * TOL
+    assert rel_err(w2.grad, ref['a.fully_connect_layer.2.weight'].grad) < 5 * TOL
+    assert rel_err(b2.grad, ref['a.fully_connect_layer.2.bias'].grad) < 5 * TOL
+
+
+def test_block_extractor_and_reshape_dropins():
+    """The NCHW drop-ins for block_extractor_cuda / local_attn_reshape_cuda against the oracle (K1-K4), incl. the
+    reference's own known-answer read-out (test_local_attn_reshape.py:29-43)."""
+    ops = _ops()
+    from oracle import hogan_oracle as O
+    g = torch.Generator().manual_seed(6)
+    src = torch.rand(4, 6, 14, 10, generator=g)
+    flow = torch.rand(4, 2, 14, 10, generator=g) * 1.8      # the recipe of test_block_extractor.py:74-75
+    sr, fr = src.clone().requires_grad_(True), flow.clone().requires_grad_(True)
+    yr = O.block_extract(sr, fr, 3)
+    gy = torch.randn(yr.shape, generator=g)
+    yr.backward(gy)
+    sd, fd = src.cuda().requires_grad_(True), flow.cuda().requires_grad_(True)
+    y = ops.block_extractor(sd, fd, 3)
+    y.backward(gy.cuda())
+    assert rel_err(y, yr) < 1e-6
+    assert rel_err(sd.grad, sr.grad) < 1e-5
+    assert rel_err(fd.grad, fr.grad) < 1e-4
+    inp = torch.arange(9.0).view(1, 9, 1, 1).repeat(2, 1, 10, 10)
+    out = ops.local_attn_reshape(inp.cuda().requires_grad_(True), 3)
+    assert out[0, 0, :3, :3].cpu().tolist() == [[0, 1, 2], [3, 4, 5], [6, 7, 8]]
+    assert torch.equal(out.cpu(), O.local_attn_reshape(inp, 3))
+    gg = torch.randn(out.shape)
+    xin = inp.cuda().requires_grad_(True)
+    ops.local_attn_reshape(xin, 3).backward(gg.cuda())
+    xr = inp.clone().requires_grad_(True)
+    O.local_attn_reshape(xr, 3).backward(gg)
+    assert torch.equal(xin.grad.cpu(), xr.grad)
+
+
+def test_sampling_ops():
+    ops = _ops()
+    g = torch.Generator().manual_seed(7)
+    x = torch.randn(2, 32, 16, 16, generator=g)
+    grid = torch.rand(2, 16, 16, 2, generator=g) * 2.4 - 1.2
+    grid[0, :4] = -2.0                                        # the -2 sentinel of utils/nmr.py:884
+    xr = x.clone().requires_grad_(True)
+    yr = F.grid_sample(xr, grid, mode='bilinear', padding_mode='zeros', align_corners=False)
+    gy = torch.randn(yr.shape, generator=g)
+    yr.backward(gy)
+    xd = nhwc_cuda(x).requires_grad_(True)
+    y = ops.grid_sample(xd, grid.cuda())
+    y.backward(nhwc_cuda(gy))
+    assert rel_err(nchw_cpu(y), yr) < 1e-5
+    assert rel_err(nchw_cpu(xd.grad), xr.grad) < 1e-5
+    T = torch.rand(2, 64, 64, 2, generator=g) * 2 - 1
+    for h in (32, 16, 8):
+        tr = F.interpolate(T.permute(0, 3, 1, 2), size=(h, h), mode='bilinear', align_corners=True).permute(0, 2, 3, 1)
+        td = ops.resize_bilinear_ac(T.cuda(), h, h)
+        assert rel_err(td, tr) < 2e-5
+        from oracle import hogan_oracle as O
+        assert rel_err(ops.attn_flow(td), O.attn_flow(T, h)) < 2e-5
+    seg = torch.randn(2, 12, 64, 64, generator=g)
+    for h in (32, 16, 8):
+        sr = F.interpolate(seg, size=(h, h), mode='nearest')
+        assert torch.equal(nchw_cpu(ops.resize_nearest(nhwc_cuda(seg), h, h)), sr)
+
+
+def test_pointwise_and_losses():
+    ops = _ops()
+    g = torch.Generator().manual_seed(8)
+    B, H, W = 2, 16, 16
+    bg, obj, hand = [torch.randn(B, 3, H, W, generator=g) for _ in range(3)]
+    mbg, mh = [torch.rand(B, 1, H, W, generator=g) for _ in range(2)]
+    refs = [t.clone().requires_grad_(True) for t in (bg, obj, hand, mbg, mh)]
+    r = refs
+    img_r = r[3] * r[0] + (1 - r[3]) * (r[1] * r[4] + r[2] * (1 - r[4]))
+    devs = [nhwc_cuda(t).requires_grad_(True) for t in (bg, obj, hand, mbg, mh)]
+    img = ops.compose(*devs)
+    real = torch.rand(B, 3, H, W, generator=g) * 2 - 1
+    tgt_m = (torch.rand(B, 1, H, W, generator=g) > 0.5).float()
+    loss_r = F.l1_loss(img_r, real) * 10 + F.binary_cross_entropy(r[3], tgt_m) * 1.0 + F.mse_loss(r[4], tgt_m) * 0.5 \
+        + torch.mean((r[4] - 1) ** 2) * 2.0 \
+        + ((r[3][:, :, :, :-1] - r[3][:, :, :, 1:]).abs().mean() + (r[3][:, :, :-1] - r[3][:, :, 1:]).abs().mean()) * 3.0
+    loss_r.backward()
+    loss = ops.l1_loss(img, nhwc_cuda(real), 10.0) + ops.bce_loss(devs[3], nhwc_cuda(tgt_m), 1.0) \
+        + ops.mse_loss(devs[4], nhwc_cuda(tgt_m), 0.5) + ops.lsgan_loss(devs[4], 1.0, 2.0) + ops.tv_loss(devs[3], 3.0)
+    loss.backward()
+    assert abs(loss.item() - loss_r.item()) < 1e-4 * abs(loss_r.item())
+    assert rel_err(nchw_cpu(img), img_r) < 1e-6
+    for d, rr in zip(devs, refs):
+        assert rel_err(nchw_cpu(d.grad), rr.grad) < 1e-4
+    x = torch.randn(2, 8, 6, 6, generator=g)
+    assert abs(ops.mean(nhwc_cuda(x)).item() - x.mean().item()) < 1e-6
+    # maxpool
+    xr = x.clone().requires_grad_(True)
+    yr = F.max_pool2d(xr, 2, 2)
+    gy = torch.randn(yr.shape, generator=g)
+    yr.backward(gy)
+    xd = nhwc_cuda(x).requires_grad_(True)
+    y = ops.maxpool2(xd)
+    y.backward(nhwc_cuda(gy))
+    assert torch.equal(nchw_cpu(y), yr) and torch.equal(nchw_cpu(xd.grad), xr.grad)
+    # layout + cat
+    assert torch.equal(ops.nhwc_to_nchw(ops.nchw_to_nhwc(x.cuda())).cpu(), x)
+    a, b = torch.randn(2, 5, 4, 4, generator=g), torch.randn(2, 7, 4, 4, generator=g)
+    c = ops.cat_channels([nhwc_cuda(a), nhwc_cuda(b)])
+    assert torch.equal(nchw_cpu(c), torch.cat([a, b], 1))
+
+
+def test_fused_adam_matches_torch():
+    from hoig_amd.nn import ParamTree, FusedAdam
+    shapes = {'a.weight': (8, 4, 3, 3), 'a.bias': (8,), 'b.weight': (5,), 'b.bias': (5,)}
+    tree = ParamTree(shapes, torch.device('cuda'))
+    g = torch.Generator().manual_seed(9)
+    ref = {k: torch.randn(v, generator=g) for k, v in shapes.items()}
+    tree.load_state_dict(ref)
+    params = [v.clone().requires_grad_(True) for v in ref.values()]
+    opt_r = torch.optim.Adam(params, lr=2e-4, betas=(0.5, 0.999))
+    opt = FusedAdam(tree, lr=2e-4, betas=(0.5, 0.999))
+    for step in range(3):
+        grads = [torch.randn(p.shape, generator=g) for p in params]
+        for p, gr in zip(params, grads):
+            p.grad = gr.clone()
+        opt_r.step()
+        with torch.no_grad():
+            for p, gr in zip(tree.P.values(), grads):
+                p.grad.copy_(gr.cuda())
+        opt.step()
+    sd = tree.state_dict()
+    for k, p in zip(shapes, params):
+        assert rel_err(sd[k], p) < 1e-6
+    osd, osr = opt.state_dict(), opt_r.state_dict()
+    assert set(osd['state'].keys()) == set(osr['state'].keys())
+    for i in osr['state']:
+        assert rel_err(osd['state'][i]['exp_avg'], osr['state'][i]['exp_avg']) < 1e-6
+        assert rel_err(osd['state'][i]['exp_avg_sq'], osr['state'][i]['exp_avg_sq']) < 1e-6
+        assert float(osd['state'][i]['step']) == float(osr['state'][i]['step'])
