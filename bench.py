@@ -1,0 +1,145 @@
+#!/usr/bin/env python
+"""bench.py -- HOGAN G+D training-step throughput on synthetic 256x256 hand-object-pose tensors.
+
+  python bench.py --gpus N --steps K --warmup W            (N>1: launched by torch.distributed.run, one rank per GPU)
+
+A "step" is one ``Trainer.optimize_parameters()`` (forward, G loss, backward, Adam(G), D loss, backward, Adam(D);
+under DDP also the RCCL gradient exchange) on a per-GPU batch of 8 pairs (BASELINE.json configs[1]; weak scaling:
+configs[2] is the same per-GPU batch on 8 GPUs).  Inputs are resident in HBM before the timed region.
+Prints ONE JSON line on rank 0.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import torch
+import torch.distributed as dist
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, 'tests'))
+
+GFLOP_PER_PAIR_TRAIN_256 = 2555.2      # BASELINE.md §2 / SURVEY.md §8d (3*G + 3*VGG + 9*D), generator_spade_attn
+PEAK = {'f32': 157.3, 'bf16x3': 2500.0, 'bf16': 2500.0}          # TFLOP/s dense MFMA, MI355X_MICROARCH.md
+
+
+def dominant_kernel_roofline(batch, side, precision, iters=20):
+    """The dominant kernel of the step is the 3x3 stride-1 512->512 convolution at side/8 (72 of ~260 conv calls of a
+    forward, 44% of G's MACs).  Time that kernel alone with HIP events on the launch stream."""
+    from hoig_amd import ops
+    h = side // 8
+    x = torch.randn(batch, h, h, 512, device='cuda')
+    w = ops.pack_weight(torch.randn(512, 512, 3, 3, device='cuda') * 0.02)
+    for _ in range(3):
+        ops.conv2d(x, w, None, 1, 1)
+    s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    torch.cuda.synchronize()
+    s.record()
+    for _ in range(iters):
+        ops.conv2d(x, w, None, 1, 1)
+    e.record()
+    torch.cuda.synchronize()
+    ms = s.elapsed_time(e) / iters
+    flops = 2.0 * batch * h * h * 512 * 512 * 9            # algorithmic: 2*M*N*K, M=B*h*h, N=512, K=9*512
+    achieved = flops / (ms * 1e-3) / 1e12
+    return dict(bound='mfma', kernel='igemm_f32_kernel (conv3x3 s1 512->512 @%dx%d, B=%d)' % (h, h, batch),
+                achieved=round(achieved, 2), peak=PEAK[precision], unit='TFLOP/s',
+                frac=round(achieved / PEAK[precision], 4), traffic=None, avg_launch_ms=round(ms, 4),
+                algorithmic_flop_per_launch=flops)
+
+
+def cpu_baseline():
+    """The oracle (a port: the reference's algorithm in fp32 torch-CPU, pinned bit-exact to the reference in the build
+    container) timed on this box's host cores on a BOUNDED sample: one full G+D step at 256x256, batch 1."""
+    from common import oracle_trainer
+    torch.set_num_threads(max(1, os.cpu_count() or 1))
+    warm = oracle_trainer('generator_spade_attn', 1, 64)
+    warm.optimize_parameters()
+    ot = oracle_trainer('generator_spade_attn', 1, 256)
+    t0 = time.time()
+    ot.optimize_parameters()
+    dt = time.time() - t0
+    return dict(value=round(1.0 / dt, 4), unit='images/s', cores=torch.get_num_threads(), kind='port',
+                sample='1 full G+D step (optimize_parameters), 256x256, batch 1, fp32, after a 64x64 warm-up step; '
+                       '%.1f s' % dt)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--gpus', type=int, default=1)
+    ap.add_argument('--steps', type=int, default=10)
+    ap.add_argument('--warmup', type=int, default=3)
+    ap.add_argument('--batch', type=int, default=8, help='pairs per GPU')
+    ap.add_argument('--side', type=int, default=256)
+    ap.add_argument('--gen_name', default='generator_spade_attn')
+    ap.add_argument('--precision', default=os.environ.get('HOIG_PRECISION', 'f32'))
+    ap.add_argument('--no-cpu-baseline', action='store_true')
+    args = ap.parse_args()
+
+    rank = int(os.environ.get('RANK', 0))
+    local_rank = int(os.environ.get('LOCAL_RANK', 0))
+    world = int(os.environ.get('WORLD_SIZE', 1))
+    ddp = world > 1
+    torch.cuda.set_device(local_rank)
+    if ddp:
+        os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+        dist.init_process_group(backend='nccl', device_id=torch.device('cuda', local_rank))
+
+    from hoig_amd import ops, synthetic
+    from hoig_amd.models import ModelsFactory
+    from common import opt_namespace
+    ops.set_precision(args.precision)
+
+    opt = opt_namespace(gen_name=args.gen_name, local_rank=local_rank, image_size=args.side)
+    torch.manual_seed(8)
+    model = ModelsFactory.get_by_name('trainer', opt, use_ddp=ddp)
+    model.set_train()
+    model.set_input(synthetic.make_inputs(args.batch, args.side, seed=8 + rank))
+    torch.cuda.synchronize()
+
+    def barrier():
+        if ddp:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        model.optimize_parameters()
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        model.optimize_parameters()
+    barrier()
+    dt = time.perf_counter() - t0
+    if ddp:
+        t = torch.tensor([dt], device='cuda', dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+    errors = model.get_current_errors()
+
+    if rank == 0:
+        ms = dt / args.steps * 1e3
+        value = world * args.batch * args.steps / dt
+        roof = dominant_kernel_roofline(args.batch, args.side, args.precision)
+        out = {
+            'metric': 'HOGAN train images/sec at %dx%d' % (args.side, args.side),
+            'value': round(value, 3), 'unit': 'images/s', 'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
+            'ms_per_step': round(ms, 3), 'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
+            'dtype': args.precision, 'data': 'synthetic',
+            'config': {'workload': '%dx%d HO3Dv3-shaped synthetic, batch %d per GPU, G+D full step (%s, VGG19 '
+                                   'surrogate weights)' % (args.side, args.side, args.batch, args.gen_name),
+                       'global_batch': world * args.batch, 'parallelism': 'dp%d' % world},
+            'step_tflops': round(GFLOP_PER_PAIR_TRAIN_256 * (args.side / 256.0) ** 2 * value / 1e3, 2),
+            'roofline': roof,
+            'losses_finite': all(v == v and abs(v) != float('inf') for v in errors.values()),
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            out['cpu_baseline'] = cpu_baseline()
+        print(json.dumps(out))
+    if ddp:
+        dist.destroy_process_group()
+
+
+if __name__ == '__main__':
+    main()

@@ -236,8 +236,8 @@ __global__ void maxpool_bwd_kernel(const float *__restrict__ x, const float *__r
 // torch.optim.Adam single-tensor update (no amsgrad, no weight decay), op order as ATen applies it:
 //   m.lerp_(g, 1-b1); v = v*b2 + (1-b2)*g*g; denom = sqrt(v)/sqrt(bc2) + eps; p -= (lr/bc1) * m/denom
 __global__ __launch_bounds__(NT) void adam_kernel(float *__restrict__ p, const float *__restrict__ g, float *__restrict__ m,
-                                                  float *__restrict__ v, int64_t n, float step_size, float b1, float b2,
-                                                  float eps, float bc2_sqrt, float gscale) {
+                                                  float *__restrict__ v, int64_t n, float step_size, float omb1, float b2,
+                                                  float omb2, float eps, float bc2_sqrt, float gscale) {
     const int64_t n4 = n >> 2;
     for (int64_t i = (int64_t)blockIdx.x * NT + threadIdx.x; i < n4; i += (int64_t)gridDim.x * NT) {
         float4 pp = reinterpret_cast<float4 *>(p)[i];
@@ -248,8 +248,8 @@ __global__ __launch_bounds__(NT) void adam_kernel(float *__restrict__ p, const f
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
             const float gk = ge[k] * gscale;
-            me[k] = me[k] + (gk - me[k]) * (1.f - b1);
-            ve[k] = ve[k] * b2 + (1.f - b2) * gk * gk;
+            me[k] = me[k] + (gk - me[k]) * omb1;
+            ve[k] = ve[k] * b2 + omb2 * (gk * gk);
             const float denom = sqrtf(ve[k]) / bc2_sqrt + eps;
             pe[k] = pe[k] - step_size * (me[k] / denom);
         }
@@ -259,8 +259,8 @@ __global__ __launch_bounds__(NT) void adam_kernel(float *__restrict__ p, const f
     }
     for (int64_t i = (n4 << 2) + (int64_t)blockIdx.x * NT + threadIdx.x; i < n; i += (int64_t)gridDim.x * NT) {
         const float gk = g[i] * gscale;
-        const float mk = m[i] + (gk - m[i]) * (1.f - b1);
-        const float vk = v[i] * b2 + (1.f - b2) * gk * gk;
+        const float mk = m[i] + (gk - m[i]) * omb1;
+        const float vk = v[i] * b2 + omb2 * (gk * gk);
         m[i] = mk;
         v[i] = vk;
         p[i] = p[i] - step_size * (mk / (sqrtf(vk) / bc2_sqrt + eps));
@@ -399,8 +399,10 @@ extern "C" int hoig_adam_step(float *param, const float *grad, float *exp_avg, f
     const double bc1 = 1.0 - pow((double)beta1, step), bc2 = 1.0 - pow((double)beta2, step);
     const float step_size = (float)((double)lr / bc1);
     const float bc2_sqrt = (float)sqrt(bc2);
-    adam_kernel<<<hoig_stream_grid(n / 4 + 1, NT), NT, 0, ST>>>(param, grad, exp_avg, exp_avg_sq, n, step_size, beta1,
-                                                               beta2, eps, bc2_sqrt, grad_scale);
+    // 1-beta evaluated in double like torch does (python floats), then rounded once
+    adam_kernel<<<hoig_stream_grid(n / 4 + 1, NT), NT, 0, ST>>>(param, grad, exp_avg, exp_avg_sq, n, step_size,
+                                                               (float)(1.0 - (double)beta1), beta2,
+                                                               (float)(1.0 - (double)beta2), eps, bc2_sqrt, grad_scale);
     HOIG_LAUNCH_CHECK();
     return HOIG_OK;
 }

@@ -1,0 +1,387 @@
+"""``Trainer`` -- the HOGAN model object the reference drivers (train.py, train_ddp.py, eval.py) talk to.
+
+Same public surface as the reference's ``class Trainer(BaseModel)`` (models/trainer.py:188-591): ``set_input /
+set_train / set_eval / forward / optimize_parameters / _optimize_G / _optimize_D / get_current_errors /
+get_current_scalars / get_current_visuals / save / load / update_learning_rate``; ``HOGANModel``, ``backward_G`` and
+``backward_D`` are aliases for the names BASELINE.json's north_star uses.  Underneath everything is new: NHWC fp32
+tensors in HBM, every operator a hand-written gfx950 kernel (hoig_amd/ops.py), one flat buffer per network, fused
+Adam, RCCL gradient exchange overlapped with the D step (hoig_amd/ddp.py).
+
+Out of scope here: ``HandRecoveryFlow`` (MANO + neural renderer input preparation,
+trainer.py:14-185).  ``set_input`` therefore accepts the tensors that stage produces (the a2 surface) -- a dict
+with the keys of ``hoig_amd.synthetic.make_inputs`` -- and raises for raw dataloader batches.
+"""
+import math
+from collections import OrderedDict
+
+import numpy as np
+import torch
+import torch.distributed as dist
+
+from .. import ops
+from ..ddp import FlatDDP
+from ..nn import FusedAdam
+from .base_model import BaseModel
+from .networks import NetworksFactory
+from .networks.generator import to_nhwc, as_nchw
+from .networks.vgg19 import Vgg19, VGGLoss
+
+PREPARED_KEYS = ['input_G_bg', 'input_G_src_obj', 'input_G_tsf_obj', 'input_G_src_hand', 'input_G_tsf_hand', 'T',
+                 'real_src', 'real_tsf', 'bg_mask', 'hand_mask']
+
+
+def _labelcolormap(n):
+    """utils/util.py:22-44 (non-cityscapes branch)."""
+    cmap = np.zeros((n, 3), dtype=np.uint8)
+    for i in range(n):
+        r = g = b = 0
+        ident = i + 1
+        for j in range(7):
+            bits = [(ident >> y) & 1 for y in range(7, -1, -1)]
+            r ^= bits[-1] << (7 - j)
+            g ^= bits[-2] << (7 - j)
+            b ^= bits[-3] << (7 - j)
+            ident >>= 3
+        cmap[i] = (r & 0xFF, g & 0xFF, b & 0xFF)
+    return cmap
+
+
+class Trainer(BaseModel):
+    def __init__(self, opt, use_ddp=False):
+        super(Trainer, self).__init__(opt, use_ddp)
+        self._name = 'Trainer'
+        if not torch.cuda.is_available():
+            raise RuntimeError('hoig_amd.Trainer needs an MI355X: the product path has no CPU fallback')
+        if use_ddp:
+            self.device = torch.device('cuda:{}'.format(opt.local_rank))
+        else:
+            self.device = torch.device('cuda', torch.cuda.current_device())
+        torch.cuda.set_device(self.device)
+        self._dexycb = 'dex' in str(getattr(opt, 'dataset_mode', 'hov3')).lower()
+        self._world = dist.get_world_size() if (use_ddp and dist.is_initialized()) else 1
+        self._side = torch.cuda.Stream(device=self.device) if self._world > 1 else None
+        self._g_ready = None
+
+        self._init_create_networks(use_ddp=use_ddp)
+        if self._is_train:
+            self._init_train_vars()
+            self._init_losses(use_ddp=use_ddp)
+
+        if self._opt.load_path != 'None' and self._opt.load_path is not None:
+            self._load_params(self._G, self._opt.load_path, need_module=False)
+        elif not self._is_train or self._opt.load_epoch > 0:
+            self.load()
+
+        self._cmap = _labelcolormap(16)
+        self._init_prefetch_inputs()
+
+    # ------------------------------------------------------------------ construction (trainer.py:217-322)
+    def _init_create_networks(self, use_ddp=False):
+        self._hdr = None          # HandRecoveryFlow: out of scope (needs MANO assets + neural_renderer)
+        self._G = self._create_generator()
+        self._G.init_weights()
+        if use_ddp:
+            self._G = FlatDDP(self._G)
+        self._D = self._create_discriminator()
+        self._D.init_weights()
+        if use_ddp:
+            self._D = FlatDDP(self._D)
+
+    def _create_generator(self):
+        if not self._opt.use_spade:
+            raise NotImplementedError('use_spade=False is unreachable in the reference (argument order / channel '
+                                      'mismatch at trainer.py:395-398); pass --use_spade as every script does')
+        bg_dim, cond = (13, 9) if self._dexycb else (8, 3)     # HOIG_DexYCB/models/trainer.py:263-264 / HOv3 :260-261
+        return NetworksFactory.get_by_name(self._opt.gen_name, bg_dim=bg_dim, img_dim=3, obj_dim=3, img_cond_dim=cond,
+                                           obj_cond_dim=12, repeat_num=self._opt.repeat_num,
+                                           conv_dim=getattr(self._opt, 'conv_dim', 64))
+
+    def _create_discriminator(self):
+        return NetworksFactory.get_by_name('discriminator_patch_gan', input_nc=24 if self._dexycb else 19,
+                                           norm_type=self._opt.norm_type, ndf=64, n_layers=4, use_sigmoid=False)
+
+    @staticmethod
+    def _net(x):
+        return x.module if isinstance(x, FlatDDP) else x
+
+    def _init_train_vars(self):
+        self._current_lr_G = self._opt.lr_G
+        self._current_lr_D = self._opt.lr_D
+        self._optimizer_G = FusedAdam(self._net(self._G), lr=self._current_lr_G,
+                                      betas=(self._opt.G_adam_b1, self._opt.G_adam_b2))
+        self._optimizer_D = FusedAdam(self._net(self._D), lr=self._current_lr_D,
+                                      betas=(self._opt.D_adam_b1, self._opt.D_adam_b2))
+
+    def _init_prefetch_inputs(self):
+        self._real_src = self._real_tsf = self._bg_mask = self._hand_mask = None
+        self._input_G_bg = self._input_G_src_obj = self._input_G_tsf_obj = None
+        self._input_G_src_hand = self._input_G_tsf_hand = self._T = None
+        self._armask_src = self._armask_tsf = None
+
+    def _init_losses(self, use_ddp=False):
+        vgg_net = Vgg19()
+        vgg_path = getattr(self._opt, 'vgg_weights', None)
+        if vgg_path:
+            vgg_net.load_torchvision_features(torch.load(vgg_path, map_location='cpu'))
+        if self._opt.use_vgg:
+            self._crt_tsf = VGGLoss(vgg=vgg_net)
+        z = lambda: torch.zeros((), device=self.device)
+        self._loss_g_rec, self._loss_g_tsf, self._loss_g_adv = z(), z(), z()
+        self._loss_g_smooth, self._loss_g_mask, self._loss_g_mask_smooth = z(), z(), z()
+        self._d_real, self._d_fake = z(), z()
+
+    # ------------------------------------------------------------------ inputs
+    def set_input(self, input):
+        if all(k in input for k in PREPARED_KEYS):
+            return self.set_prepared_input(input)
+        raise NotImplementedError(
+            'Trainer.set_input: raw dataloader batches need HandRecoveryFlow (MANO + neural renderer, '
+            'trainer.py:324-362), which is outside the accelerated path; pass the prepared tensors %s' % PREPARED_KEYS)
+
+    def set_prepared_input(self, inp):
+        """Stage the a2 attributes (what trainer.py:346-362 assigns).  NCHW tensors (T: B,S,S,2), CPU or device."""
+        dev = self.device
+        with torch.no_grad():
+            t = {k: v.to(dev, non_blocking=True).float() for k, v in inp.items() if torch.is_tensor(v)}
+            n = self._n = {}
+            for k in ['input_G_bg', 'input_G_src_obj', 'input_G_tsf_obj', 'input_G_src_hand', 'input_G_tsf_hand',
+                      'real_src', 'real_tsf', 'bg_mask', 'hand_mask', 'armask_src', 'armask_tsf']:
+                if k in t:
+                    n[k] = to_nhwc(t[k])
+            n['T'] = t['T'].contiguous()
+            if self._dexycb:
+                n.pop('armask_src', None)
+                n.pop('armask_tsf', None)
+            elif 'armask_src' not in n:
+                raise KeyError('HOv3 inputs need armask_src / armask_tsf (trainer.py:329-337)')
+            for side in ('src', 'tsf'):
+                for part in ('obj', 'hand'):
+                    full = n['input_G_%s_%s' % (side, part)]
+                    n['%s_%s_rgb' % (side, part)] = ops.slice_channels(full, 0, 3)            # trainer.py:377-385
+                    n['%s_%s_cond' % (side, part)] = ops.slice_channels(full, 3, full.shape[-1])
+            cond = [n['tsf_obj_cond'], n['tsf_hand_cond']] + ([n['armask_tsf']] if 'armask_tsf' in n else [])
+            n['tsf_cond'] = ops.cat_channels(cond)                                            # trainer.py:437,460
+            # reference-named NCHW views
+            self._input_G_bg = as_nchw(n['input_G_bg'])
+            self._input_G_src_obj, self._input_G_tsf_obj = as_nchw(n['input_G_src_obj']), as_nchw(n['input_G_tsf_obj'])
+            self._input_G_src_hand = as_nchw(n['input_G_src_hand'])
+            self._input_G_tsf_hand = as_nchw(n['input_G_tsf_hand'])
+            self._T = n['T']
+            self._real_src, self._real_tsf = as_nchw(n['real_src']), as_nchw(n['real_tsf'])
+            self._bg_mask, self._hand_mask = as_nchw(n['bg_mask']), as_nchw(n['hand_mask'])
+            if 'armask_src' in n:
+                self._armask_src, self._armask_tsf = as_nchw(n['armask_src']), as_nchw(n['armask_tsf'])
+
+    def set_train(self):
+        self._G.train()
+        self._D.train()
+        self._is_train = True
+
+    def set_eval(self):
+        self._G.eval()
+        self._is_train = False
+
+    # ------------------------------------------------------------------ forward (trainer.py:373-415)
+    def _wait_g(self):
+        if self._g_ready is not None:
+            torch.cuda.current_stream().wait_event(self._g_ready)
+            self._g_ready = None
+
+    def forward(self, keep_data_for_visuals=False, return_estimates=False):
+        self._wait_g()
+        n = self._n
+        outs = self._G.forward_nhwc(n['input_G_bg'], n['src_obj_rgb'], n['tsf_obj_rgb'], n['src_hand_rgb'],
+                                    n['tsf_hand_rgb'], n['T'], n['src_obj_cond'], n['src_hand_cond'],
+                                    n['tsf_obj_cond'], n['tsf_hand_cond'], n.get('armask_src'), n.get('armask_tsf'))
+        (src_bg, tsf_bg, src_obj, src_hand, src_mbg, src_mh, tsf_obj, tsf_hand, tsf_mbg, tsf_mh) = outs
+        fake_src = ops.compose(src_bg, src_obj, src_hand, src_mbg, src_mh)
+        fake_tsf = ops.compose(tsf_bg, tsf_obj, tsf_hand, tsf_mbg, tsf_mh)
+        masks_bg = torch.cat([src_mbg, tsf_mbg], dim=0)
+        masks_hand = torch.cat([src_mh, tsf_mh], dim=0)
+        if keep_data_for_visuals:
+            self.visual_imgs(outs, fake_src, fake_tsf, masks_bg, masks_hand)
+        return (as_nchw(src_bg), as_nchw(tsf_bg), as_nchw(fake_src), as_nchw(fake_tsf), as_nchw(masks_bg),
+                as_nchw(masks_hand))
+
+    # ------------------------------------------------------------------ one GAN iteration (trainer.py:417-434)
+    def optimize_parameters(self, trainable=True, keep_data_for_visuals=False):
+        if not self._is_train:
+            return
+        _, _, fake_src_imgs, fake_tsf_imgs, fake_masks_bg, fake_masks_hand = \
+            self.forward(keep_data_for_visuals=keep_data_for_visuals)
+
+        netD = self._net(self._D)
+        netD.set_requires_grad(False)       # the reference computes D grads here and zeroes them at :432
+        loss_G = self._optimize_G(fake_src_imgs, fake_tsf_imgs, fake_masks_bg, fake_masks_hand)
+        self._optimizer_G.zero_grad()
+        loss_G.backward()
+        netD.set_requires_grad(True)
+        self._step(self._G, self._optimizer_G, overlap=trainable)
+
+        if trainable:
+            loss_D = self._optimize_D(fake_tsf_imgs)
+            self._optimizer_D.zero_grad()
+            loss_D.backward()
+            self._step(self._D, self._optimizer_D, overlap=False)
+
+    def _step(self, net, optimizer, overlap):
+        """gradient exchange (RCCL) + fused Adam; for G under DDP both run on the side stream, overlapped with the
+        D step that follows on the main stream."""
+        if isinstance(net, FlatDDP) and self._world > 1:
+            if overlap:
+                main = torch.cuda.current_stream()
+                self._side.wait_stream(main)
+                with torch.cuda.stream(self._side):
+                    scale = net.sync.all_reduce_grads()
+                    optimizer.step(grad_scale=scale)
+                    self._g_ready = torch.cuda.Event()
+                    self._g_ready.record(self._side)
+            else:
+                self._wait_g()
+                scale = net.sync.all_reduce_grads()
+                optimizer.step(grad_scale=scale)
+        else:
+            optimizer.step()
+
+    def _optimize_G(self, fake_src_imgs, fake_tsf_imgs, fake_masks_bg, fake_masks_hand):
+        """trainer.py:436-457."""
+        o, n = self._opt, self._n
+        fake_src, fake_tsf = to_nhwc(fake_src_imgs), to_nhwc(fake_tsf_imgs)
+        mbg, mh = to_nhwc(fake_masks_bg), to_nhwc(fake_masks_hand)
+        d_fake = self._D.forward_nhwc(ops.cat_channels([fake_tsf, n['tsf_cond']]))
+        self._loss_g_adv = ops.lsgan_loss(d_fake, 0.0, o.lambda_D_prob)
+        self._loss_g_rec = ops.l1_loss(fake_src, n['real_src'], o.lambda_rec)
+        # the reference uses self._crt_tsf in both branches of `if use_vgg` (:443-446); it only exists with --use_vgg
+        self._loss_g_tsf = self._crt_tsf.forward_nhwc(fake_tsf, n['real_tsf'], o.lambda_tsf)
+        crt = ops.bce_loss if o.mask_bce else ops.mse_loss
+        self._loss_g_mask = crt(mbg, n['bg_mask'], o.lambda_mask) + crt(mh, n['hand_mask'], o.lambda_mask)
+        if o.lambda_mask_smooth != 0:
+            self._loss_g_mask_smooth = ops.tv_loss(mbg, o.lambda_mask_smooth) + ops.tv_loss(mh, o.lambda_mask_smooth)
+        return self._loss_g_adv + self._loss_g_rec + self._loss_g_tsf + self._loss_g_mask + self._loss_g_mask_smooth
+
+    def _optimize_D(self, fake_tsf_imgs):
+        """trainer.py:459-474."""
+        o, n = self._opt, self._n
+        fake_tsf = to_nhwc(fake_tsf_imgs).detach()
+        d_real = self._D.forward_nhwc(ops.cat_channels([n['real_tsf'], n['tsf_cond']]))
+        d_fake = self._D.forward_nhwc(ops.cat_channels([fake_tsf, n['tsf_cond']]))
+        loss_real = ops.lsgan_loss(d_real, 1.0, o.lambda_D_prob)
+        loss_fake = ops.lsgan_loss(d_fake, -1.0, o.lambda_D_prob)
+        with torch.no_grad():
+            self._d_real = ops.mean(d_real)
+            self._d_fake = ops.mean(d_fake)
+        return loss_real + loss_fake
+
+    backward_G = _optimize_G        # north_star vocabulary
+    backward_D = _optimize_D
+
+    def _compute_loss_D(self, x, y):
+        return ops.lsgan_loss(to_nhwc(x), float(y), 1.0)
+
+    def _compute_loss_smooth(self, mat):
+        return ops.tv_loss(to_nhwc(mat), 1.0)
+
+    # ------------------------------------------------------------------ reporting (trainer.py:483-551)
+    def get_current_errors(self):
+        return OrderedDict([('g_rec', self._loss_g_rec.item()), ('g_tsf', self._loss_g_tsf.item()),
+                            ('g_adv', self._loss_g_adv.item()), ('g_mask', self._loss_g_mask.item()),
+                            ('g_mask_smooth', self._loss_g_mask_smooth.item()), ('d_real', self._d_real.item()),
+                            ('d_fake', self._d_fake.item())])
+
+    def get_current_scalars(self):
+        return OrderedDict([('lr_G', self._current_lr_G), ('lr_D', self._current_lr_D)])
+
+    def get_current_visuals(self):
+        keys = [('1_real_img', '_vis_input'), ('2_input_src_obj', '_vis_src_obj'), ('2_input_src_hand', '_vis_src_hand'),
+                ('2_input_tsf_obj', '_vis_tsf_obj'), ('2_input_tsf_hand', '_vis_tsf_hand'),
+                ('3_fake_src_bg', '_vis_fake_src_bg'), ('4_fake_tsf_bg', '_vis_fake_tsf_bg'),
+                ('5_fake_src_color', '_vis_fake_src_color'), ('6_fake_tsf_color', '_vis_fake_tsf_color'),
+                ('7_src_seg', '_vis_src_seg'), ('8_ref_seg', '_vis_ref_seg'), ('10_fake_tsf', '_vis_fake_tsf'),
+                ('11_fake_src', '_vis_fake_src'), ('12_fake_mask_bg', '_vis_mask_bg'),
+                ('13_fake_mask_hand', '_vis_mask_hand'), ('14_batch_real_img', '_vis_batch_real'),
+                ('15_batch_fake_img', '_vis_batch_fake'), ('16_batch_src_img', '_vis_batch_src')]
+        return OrderedDict((k, getattr(self, a)) for k, a in keys)
+
+    @staticmethod
+    def _im(x_nhwc, idx=0, unnormalize=True):
+        """utils/util.py:249-264 tensor2im: CHW uint8 of sample `idx`, or of the padding-0 grid when idx < 0."""
+        if idx >= 0:
+            return ops.tensor2im_u8(x_nhwc[idx:idx + 1].contiguous(), 1, unnormalize).cpu().numpy()
+        nrow = int(math.sqrt(x_nhwc.shape[0]))
+        return ops.tensor2im_u8(x_nhwc, nrow, unnormalize).cpu().numpy()
+
+    def _seg_vis(self, seg_nhwc):
+        """trainer.py:542-545: label = (any channel != 0) * (argmax + 1), colourised, then tensor2im of sample 0."""
+        s = seg_nhwc[0]
+        lab = ((s.sum(-1) != 0).long() * (s.argmax(-1) + 1)).cpu().numpy()
+        col = np.zeros(lab.shape + (3,), np.uint8)
+        for label in range(len(self._cmap)):
+            col[lab == label] = self._cmap[label]
+        img = col.transpose(2, 0, 1).astype(np.float32)
+        img += 1.0
+        img /= 2.0
+        img *= 255.0
+        return img.astype(np.uint8)
+
+    @torch.no_grad()
+    def visual_imgs(self, outs, fake_src, fake_tsf, masks_bg, masks_hand):
+        n = self._n
+        (src_bg, tsf_bg, src_obj, src_hand, src_mbg, src_mh, tsf_obj, tsf_hand, tsf_mbg, tsf_mh) = outs
+        ids = masks_bg.shape[0] // 2
+        one = torch.ones_like(src_mbg)
+        # fg = -m_bg + (1-m_bg)*(...) = compose with a background of -1   (trainer.py:405-406)
+        src_fg = ops.compose(-one.expand_as(src_bg).contiguous(), src_obj, src_hand, src_mbg, src_mh)
+        tsf_fg = ops.compose(-one.expand_as(tsf_bg).contiguous(), tsf_obj, tsf_hand, tsf_mbg, tsf_mh)
+        self._vis_input = self._im(n['real_src'])
+        self._vis_src_obj = self._im(n['src_obj_rgb'])
+        self._vis_src_hand = self._im(n['src_hand_rgb'])
+        self._vis_tsf_obj = self._im(n['tsf_obj_rgb'])
+        self._vis_tsf_hand = self._im(n['tsf_hand_rgb'])
+        self._vis_fake_src_bg = self._im(src_bg)
+        self._vis_fake_tsf_bg = self._im(tsf_bg)
+        self._vis_fake_src_color = self._im(src_fg)
+        self._vis_fake_tsf_color = self._im(tsf_fg)
+        self._vis_fake_src = self._im(fake_src)
+        self._vis_fake_tsf = self._im(fake_tsf)
+        self._vis_mask_bg = self._im(masks_bg, idx=ids, unnormalize=False)
+        self._vis_mask_hand = self._im(masks_hand, idx=ids, unnormalize=False)
+        src_seg = torch.cat([n['input_G_src_hand'][..., 6:], n['input_G_src_obj'][..., 3:]], dim=-1)
+        tsf_seg = torch.cat([n['input_G_tsf_hand'][..., 6:], n['input_G_tsf_obj'][..., 3:]], dim=-1)
+        self._vis_src_seg = self._seg_vis(src_seg)
+        self._vis_ref_seg = self._seg_vis(tsf_seg)
+        self._vis_batch_src = self._im(n['real_src'], idx=-1)
+        self._vis_batch_real = self._im(n['real_tsf'], idx=-1)
+        self._vis_batch_fake = self._im(fake_tsf, idx=-1)
+
+    # ------------------------------------------------------------------ checkpoints / schedule (trainer.py:553-591)
+    def save(self, label):
+        self._wait_g()
+        torch.cuda.synchronize()
+        self._save_network(self._G, 'G', label)
+        self._save_network(self._D, 'D', label)
+        self._save_optimizer(self._optimizer_G, 'G', label)
+        self._save_optimizer(self._optimizer_D, 'D', label)
+
+    def load(self):
+        load_epoch = self._opt.load_epoch
+        self._load_network(self._G, 'G', load_epoch, need_module=False)
+        if self._is_train:
+            self._load_network(self._D, 'D', load_epoch, need_module=False)
+            self._load_optimizer(self._optimizer_G, 'G', load_epoch)
+            self._load_optimizer(self._optimizer_D, 'D', load_epoch)
+
+    def update_learning_rate(self):
+        final_lr = self._opt.final_lr
+        lr_decay_G = (self._opt.lr_G - final_lr) / self._opt.nepochs_decay
+        self._current_lr_G -= lr_decay_G
+        for param_group in self._optimizer_G.param_groups:
+            param_group['lr'] = self._current_lr_G
+        print('update G learning rate: %f -> %f' % (self._current_lr_G + lr_decay_G, self._current_lr_G))
+        lr_decay_D = (self._opt.lr_D - final_lr) / self._opt.nepochs_decay
+        self._current_lr_D -= lr_decay_D
+        for param_group in self._optimizer_D.param_groups:
+            param_group['lr'] = self._current_lr_D
+        print('update D learning rate: %f -> %f' % (self._current_lr_D + lr_decay_D, self._current_lr_D))
+
+
+HOGANModel = Trainer

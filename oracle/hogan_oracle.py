@@ -639,4 +639,4 @@ class OracleTrainer(object):
 
     def get_current_errors(self):
         order = ['g_rec', 'g_tsf', 'g_adv', 'g_mask', 'g_mask_smooth', 'd_real', 'd_fake']   # trainer.py:483-492
-        return OrderedDict((k, float(self.errors[k])) for k in order if k in self.errors)
+        return OrderedDict((k, float(self.errors[k].detach())) for k in order if k in self.errors)
