@@ -50,20 +50,57 @@ def dominant_kernel_roofline(batch, side, precision, iters=20):
                 algorithmic_flop_per_launch=flops)
 
 
-def cpu_baseline():
-    """The oracle (a port: the reference's algorithm in fp32 torch-CPU, pinned bit-exact to the reference in the build
-    container) timed on this box's host cores on a BOUNDED sample: one full G+D step at 256x256, batch 1."""
+def usable_cores():
+    """Host cores this process may really use: scheduler affinity capped by the cgroup CPU quota (a thread pool
+    sized from os.cpu_count() inside a quota-limited container oversubscribes badly)."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, 'sched_getaffinity') else (os.cpu_count() or 1)
+    try:
+        q, per = open('/sys/fs/cgroup/cpu.max').read().split()
+        if q != 'max':
+            n = min(n, max(1, int(int(q) / int(per))))
+    except Exception:
+        try:
+            q = int(open('/sys/fs/cgroup/cpu/cpu.cfs_quota_us').read())
+            per = int(open('/sys/fs/cgroup/cpu/cpu.cfs_period_us').read())
+            if q > 0:
+                n = min(n, max(1, q // per))
+        except Exception:
+            pass
+    return max(1, n)
+
+
+def cpu_baseline_worker(side):
+    """Child process: time ONE full oracle G+D step (the reference's algorithm, fp32 torch-CPU) at `side`, batch 1."""
     from common import oracle_trainer
-    torch.set_num_threads(max(1, os.cpu_count() or 1))
+    cores = usable_cores()
+    torch.set_num_threads(cores)
     warm = oracle_trainer('generator_spade_attn', 1, 64)
     warm.optimize_parameters()
-    ot = oracle_trainer('generator_spade_attn', 1, 256)
+    ot = oracle_trainer('generator_spade_attn', 1, side)
     t0 = time.time()
     ot.optimize_parameters()
-    dt = time.time() - t0
-    return dict(value=round(1.0 / dt, 4), unit='images/s', cores=torch.get_num_threads(), kind='port',
-                sample='1 full G+D step (optimize_parameters), 256x256, batch 1, fp32, after a 64x64 warm-up step; '
-                       '%.1f s' % dt)
+    print(json.dumps(dict(seconds=time.time() - t0, cores=cores, side=side)))
+
+
+def cpu_baseline(side):
+    """The oracle (kind "port": pinned bit-exact to the reference in the build container) timed on this box's host
+    cores on a BOUNDED sample, in a child process under a hard timeout so the bench always finishes in minutes:
+    one full G+D step at the benchmark resolution, batch 1; if that does not finish in time, the same step at half
+    the side, scaled by the pixel ratio (the network is fully convolutional: work is proportional to pixels)."""
+    import subprocess
+    for s, budget in ((side, 150), (side // 2, 90)):
+        try:
+            out = subprocess.run([sys.executable, os.path.abspath(__file__), '--cpu-baseline-worker', str(s)],
+                                 stdout=subprocess.PIPE, stderr=subprocess.DEVNULL, text=True, timeout=budget)
+            r = json.loads(out.stdout.strip().splitlines()[-1])
+        except Exception:
+            continue
+        scale = (s / float(side)) ** 2
+        return dict(value=round(scale / r['seconds'], 4), unit='images/s', cores=r['cores'], kind='port',
+                    sample='1 full G+D step (optimize_parameters) of the oracle at %dx%d, batch 1, fp32, after a 64x64 '
+                           'warm-up step: %.1f s%s' % (s, s, r['seconds'],
+                                                        '' if s == side else '; scaled by the pixel ratio %.2f' % scale))
+    return dict(value=None, unit='images/s', cores=usable_cores(), kind='port', sample='did not finish within the budget')
 
 
 def main():
@@ -76,7 +113,10 @@ def main():
     ap.add_argument('--gen_name', default='generator_spade_attn')
     ap.add_argument('--precision', default=os.environ.get('HOIG_PRECISION', 'f32'))
     ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--cpu-baseline-worker', type=int, default=0, help=argparse.SUPPRESS)
     args = ap.parse_args()
+    if args.cpu_baseline_worker:
+        return cpu_baseline_worker(args.cpu_baseline_worker)
 
     rank = int(os.environ.get('RANK', 0))
     local_rank = int(os.environ.get('LOCAL_RANK', 0))
@@ -135,7 +175,7 @@ def main():
             'losses_finite': all(v == v and abs(v) != float('inf') for v in errors.values()),
         }
         if world == 1 and not args.no_cpu_baseline:
-            out['cpu_baseline'] = cpu_baseline()
+            out['cpu_baseline'] = cpu_baseline(args.side)
         print(json.dumps(out))
     if ddp:
         dist.destroy_process_group()

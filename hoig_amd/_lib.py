@@ -47,11 +47,14 @@ def declared_symbols():
     return sorted(set(re.findall(r'\b(hoig_[a-z0-9_]+)\s*\(', text)) - {'hoig_stream_t'})
 
 
-_vp, _i, _i64, _f = ctypes.c_void_p, ctypes.c_int, ctypes.c_int64, ctypes.c_float
+_vp, _i, _i64, _f, _d = ctypes.c_void_p, ctypes.c_int, ctypes.c_int64, ctypes.c_float, ctypes.c_double
 _SIGS = {
     'hoig_conv2d_fwd': [ctypes.POINTER(ConvDesc), _vp, _vp, _vp, _vp, _vp],
     'hoig_conv2d_bwd_data': [ctypes.POINTER(ConvDesc), _vp, _vp, _vp, _vp],
     'hoig_conv2d_bwd_weight': [ctypes.POINTER(ConvDesc), _vp, _vp, _vp, _vp, _vp],
+    'hoig_pack_conv_weight_bf16': [_vp, _i, _i, _i, _i, _vp, _vp, _vp],
+    'hoig_conv2d_fwd_packed': [ctypes.POINTER(ConvDesc), _vp, _vp, _vp, _vp, _vp, _vp],
+    'hoig_conv2d_bwd_data_packed': [ctypes.POINTER(ConvDesc), _vp, _vp, _vp, _vp, _vp],
     'hoig_inorm_stats': [_vp, _i, _i, _i, _f, _vp, _vp, _vp, _vp],
     'hoig_inorm_apply': [_vp, _vp, _vp, _i, _vp, _vp, _i, _f, _vp, _vp, _i, _i, _i, _vp],
     'hoig_inorm_bwd': [_vp, _vp, _vp, _i, _vp, _vp, _vp, _i, _f, _vp, _vp, _vp, _i, _i, _i, _vp, _vp],
@@ -79,7 +82,7 @@ _SIGS = {
     'hoig_loss_fwd_bwd': [_i, _vp, _vp, _f, _f, _vp, _vp, _i64, _vp],
     'hoig_tv_fwd_bwd': [_vp, _f, _f, _vp, _vp, _i, _i, _i, _vp],
     'hoig_sum': [_vp, _vp, _i64, _vp],
-    'hoig_adam_step': [_vp, _vp, _vp, _vp, _i64, _f, _f, _f, _f, _i, _f, _vp],
+    'hoig_adam_step': [_vp, _vp, _vp, _vp, _i64, _d, _d, _d, _d, _i, _f, _vp],
     'hoig_tensor2im_u8': [_vp, _vp] + [_i] * 6 + [_vp],
 }
 

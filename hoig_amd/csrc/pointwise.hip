@@ -393,16 +393,17 @@ extern "C" int hoig_maxpool2_bwd(const float *x, const float *y, const float *dy
     HOIG_LAUNCH_CHECK();
     return HOIG_OK;
 }
-extern "C" int hoig_adam_step(float *param, const float *grad, float *exp_avg, float *exp_avg_sq, int64_t n, float lr,
-                              float beta1, float beta2, float eps, int step, float grad_scale, hoig_stream_t stream) {
+extern "C" int hoig_adam_step(float *param, const float *grad, float *exp_avg, float *exp_avg_sq, int64_t n, double lr,
+                              double beta1, double beta2, double eps, int step, float grad_scale,
+                              hoig_stream_t stream) {
     if (!param || !grad || !exp_avg || !exp_avg_sq || step < 1) return HOIG_EINVAL;
-    const double bc1 = 1.0 - pow((double)beta1, step), bc2 = 1.0 - pow((double)beta2, step);
-    const float step_size = (float)((double)lr / bc1);
+    const double bc1 = 1.0 - pow(beta1, step), bc2 = 1.0 - pow(beta2, step);
+    const float step_size = (float)(lr / bc1);
     const float bc2_sqrt = (float)sqrt(bc2);
     // 1-beta evaluated in double like torch does (python floats), then rounded once
     adam_kernel<<<hoig_stream_grid(n / 4 + 1, NT), NT, 0, ST>>>(param, grad, exp_avg, exp_avg_sq, n, step_size,
-                                                               (float)(1.0 - (double)beta1), beta2,
-                                                               (float)(1.0 - (double)beta2), eps, bc2_sqrt, grad_scale);
+                                                               (float)(1.0 - beta1), (float)beta2, (float)(1.0 - beta2),
+                                                               (float)eps, bc2_sqrt, grad_scale);
     HOIG_LAUNCH_CHECK();
     return HOIG_OK;
 }

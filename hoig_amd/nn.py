@@ -43,6 +43,7 @@ class ParamTree(nn.Module):
         self.flat = torch.zeros(total, dtype=torch.float32, device=device)
         self.flat_grad = torch.zeros(total, dtype=torch.float32, device=device)
         self.P = OrderedDict()
+        self.version = 0                 # bumped whenever the weights change (packed bf16 planes are cached per version)
         self._offsets = offsets
         tset = set(transposed_names)
         for name, shp in self._shapes.items():
@@ -58,6 +59,7 @@ class ParamTree(nn.Module):
             p.grad = gview
             p._hoig_flat = True
             p._hoig_transposed = name in tset
+            p._hoig_owner = self
             self.P[name] = p
             self._register(name, p)
 
@@ -90,6 +92,7 @@ class ParamTree(nn.Module):
                     if tuple(src.shape) != tuple(p.shape):
                         raise RuntimeError('size mismatch for %s: %s vs %s' % (name, tuple(src.shape), tuple(p.shape)))
                     p.copy_(src.to(device=p.device, dtype=p.dtype))
+        self.version += 1
         return self
 
     def parameters(self, recurse=True):
@@ -122,6 +125,7 @@ class ParamTree(nn.Module):
                     p.zero_()
                 else:
                     p.fill_(1.0)
+        self.version += 1
         return self
 
 
@@ -147,6 +151,7 @@ class FusedAdam(object):
         L.call('hoig_adam_step', _p(self.tree.flat), _p(self.tree.flat_grad), _p(self.exp_avg), _p(self.exp_avg_sq),
                self.tree.flat.numel(), g['lr'], g['betas'][0], g['betas'][1], g['eps'], self.step_count,
                grad_scale, _st())
+        self.tree.version += 1
 
     def _views(self, flat):
         out = []

@@ -73,6 +73,33 @@ def _grad_target(p):
 
 
 # ------------------------------------------------------------------------------------------------- conv
+_pack_cache = {}
+
+
+def _packed_planes(w, transposed, for_dgrad):
+    """bf16 hi/lo planes of a packed conv weight (hoig_pack_conv_weight_bf16), cached per optimiser step for
+    parameters that live in a flat buffer (their owner bumps ``version`` whenever the weights change)."""
+    if transposed:
+        ci, co, r, s = w.shape
+    else:
+        co, ci, r, s = w.shape
+    owner = getattr(w, '_hoig_owner', None)
+    key = (w.data_ptr(), for_dgrad)
+    ver = owner.version if owner is not None else None
+    hit = _pack_cache.get(key)
+    if hit is not None and ver is not None and hit[0] == ver:
+        return hit[1], hit[2]
+    if hit is not None and hit[1].numel() == w.numel():
+        hi, lo = hit[1], hit[2]
+    else:
+        hi = torch.empty(w.numel(), dtype=torch.int16, device=w.device)
+        lo = torch.empty(w.numel(), dtype=torch.int16, device=w.device)
+    call('hoig_pack_conv_weight_bf16', _p(w), co, r * s, ci, 1 if for_dgrad else 0, _p(hi), _p(lo), _st())
+    if ver is not None:
+        _pack_cache[key] = (ver, hi, lo)
+    return hi, lo
+
+
 class _Conv(Function):
     @staticmethod
     def forward(ctx, x, w, b, stride, pad, transposed, act, slope, out_hw, prec):
@@ -92,8 +119,17 @@ class _Conv(Function):
         Ho, Wo = out_hw
         y = torch.empty((B, Ho, Wo, Co), dtype=x.dtype, device=x.device)
         d = ConvDesc(B, Hi, Wi, Ci, Ho, Wo, Co, R, S, stride, pad, 1 if transposed else 0, act, slope, prec)
-        call('hoig_conv2d_fwd', ctypes.byref(d), _p(x), _p(w), _p(b), _p(y), _st())
+        done = False
+        if prec != L.PREC_F32 and Ci % 32 == 0 and Co > 32:
+            hi, lo = _packed_planes(w, transposed, False)
+            rc = L.lib.hoig_conv2d_fwd_packed(ctypes.byref(d), _p(x), _p(hi), _p(lo), _p(b), _p(y), _st())
+            if rc != L.EUNSUPPORTED:
+                L.check(rc, 'hoig_conv2d_fwd_packed')
+                done = True
+        if not done:
+            call('hoig_conv2d_fwd', ctypes.byref(d), _p(x), _p(w), _p(b), _p(y), _st())
         ctx.d = d
+        ctx.transposed = transposed
         ctx.has_bias = b is not None
         ctx.save_for_backward(x, w, b, y if act != L.ACT_NONE else None)
         return y
@@ -120,7 +156,15 @@ class _Conv(Function):
         dx = None
         if ctx.needs_input_grad[0]:
             dx = torch.empty_like(x)
-            call('hoig_conv2d_bwd_data', ctypes.byref(d), _p(g), _p(w), _p(dx), _st())
+            done = False
+            if d.precision != L.PREC_F32 and d.Co % 32 == 0 and d.Ci > 32:
+                hi, lo = _packed_planes(w, ctx.transposed, True)
+                rc = L.lib.hoig_conv2d_bwd_data_packed(ctypes.byref(d), _p(g), _p(hi), _p(lo), _p(dx), _st())
+                if rc != L.EUNSUPPORTED:
+                    L.check(rc, 'hoig_conv2d_bwd_data_packed')
+                    done = True
+            if not done:
+                call('hoig_conv2d_bwd_data', ctypes.byref(d), _p(g), _p(w), _p(dx), _st())
         return dx, dw_ret, db_ret, None, None, None, None, None, None, None
 
 

@@ -66,6 +66,17 @@ int hoig_conv2d_bwd_data(const hoig_conv_desc *d, const float *dy, const float *
 int hoig_conv2d_bwd_weight(const hoig_conv_desc *d, const float *x, const float *dy, float *dw, float *dbias,
                            hoig_stream_t stream);
 
+/* bf16-operand fast path (HOIG_PREC_BF16X3 / HOIG_PREC_BF16): weights are pre-split once per optimiser step into
+ * K-contiguous bf16 planes hi (and lo = bf16(w - hi)).  for_dgrad=0: planes [Co][R*S][Ci] (forward GEMM);
+ * for_dgrad=1: planes [Ci][R*S][Co] (data-gradient GEMM).  The *_packed entry points return HOIG_EUNSUPPORTED for
+ * shapes outside the fast path (gathered channels % 32 != 0, <= 32 output channels); use the fp32 entry points then. */
+int hoig_pack_conv_weight_bf16(const float *w, int Co, int RS, int Ci, int for_dgrad, uint16_t *hi, uint16_t *lo /*nullable*/,
+                               hoig_stream_t stream);
+int hoig_conv2d_fwd_packed(const hoig_conv_desc *d, const float *x, const uint16_t *w_hi, const uint16_t *w_lo,
+                           const float *bias /*nullable*/, float *y, hoig_stream_t stream);
+int hoig_conv2d_bwd_data_packed(const hoig_conv_desc *d, const float *dy, const uint16_t *wt_hi, const uint16_t *wt_lo,
+                                float *dx, hoig_stream_t stream);
+
 /* ---- instance norm (generator.py:16-22,101-120,154-208; spade.py:13; discriminator.py:37,45 via
  *      base_network.py:31): per-(b,c) mean / biased variance over H*W, eps 1e-5, no running stats. ---- */
 /* stats: mean[b*C+c], rstd[b*C+c].  workspace: >= hoig_inorm_workspace_bytes(B,HW,C) bytes. */
@@ -171,8 +182,8 @@ int hoig_sum(const float *x, float *out, int64_t n, hoig_stream_t stream);
 
 /* ---- fused Adam over one flat parameter buffer (torch.optim.Adam defaults of trainer.py:275-278:
  *      no weight decay, no amsgrad): step is the 1-based step count after increment ---- */
-int hoig_adam_step(float *param, const float *grad, float *exp_avg, float *exp_avg_sq, int64_t n, float lr, float beta1,
-                   float beta2, float eps, int step, float grad_scale, hoig_stream_t stream);
+int hoig_adam_step(float *param, const float *grad, float *exp_avg, float *exp_avg_sq, int64_t n, double lr,
+                   double beta1, double beta2, double eps, int step, float grad_scale, hoig_stream_t stream);
 
 /* eval.py output stage (utils/util.py:249-264): uint8 = (x+1)/2*255 truncated, NHWC fp32 -> CHW uint8 grid tile */
 int hoig_tensor2im_u8(const float *x, uint8_t *out, int B, int H, int W, int C, int nrow, int unnormalize,

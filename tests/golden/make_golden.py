@@ -55,7 +55,15 @@ def run(gen_name, fname, side=64, batch=2, steps=2):
             out['grad_D_model.14.weight'] = t._D.model[14].weight.grad.numpy().copy()
             out['grad_G_bg_model.model.0.weight'] = t._G.bg_model.model[0].weight.grad.numpy().copy()
             out['grad_G_tsf_model.img_reg.0.weight'] = t._G.tsf_model.img_reg[0].weight.grad.numpy().copy()
-            out['grad_G_src_model.resnets.0.conv_0.bias'] = t._G.src_model.resnets[0].conv_0.bias.grad.numpy().copy()
+            # (a conv bias feeding an instance norm has an identically-zero gradient: pick the SPADE gamma bias instead)
+            out['grad_G_src_model.resnets.0.norm_0.mlp_gamma.bias'] = \
+                t._G.src_model.resnets[0].norm_0.mlp_gamma.bias.grad.numpy().copy()
+            out['grad_G_obj_model.skippers.2.0.weight'] = t._G.obj_model.skippers[2][0].weight.grad.numpy().copy()
+            if hasattr(t._G, 'attn_9'):
+                out['grad_G_attn_9.fully_connect_layer.2.weight'] = \
+                    t._G.attn_9.fully_connect_layer[2].weight.grad.numpy().copy()
+                out['grad_G_attn_2.fully_connect_layer.0.bias'] = \
+                    t._G.attn_2.fully_connect_layer[0].bias.grad.numpy().copy()
     out['error_keys'] = np.array(list(e.keys()))
     out['errors'] = np.array(errs, dtype=np.float64)
     gs, ds = t._G.state_dict(), t._D.state_dict()

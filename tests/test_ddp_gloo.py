@@ -1,0 +1,59 @@
+"""The N>1 path on CPU: two processes, gloo backend, world_size 2 -- parameter broadcast from rank 0 and the
+bucketed gradient exchange of hoig_amd/ddp.py over flat buffers (the same code runs over RCCL on the GPUs)."""
+import os
+import socket
+
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(('127.0.0.1', 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _worker(rank, world, port, q):
+    os.environ['MASTER_ADDR'] = '127.0.0.1'
+    os.environ['MASTER_PORT'] = str(port)
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    from hoig_amd.ddp import GradSync, FlatDDP
+    from hoig_amd.nn import ParamTree
+    from hoig_amd.models.networks.schema import discriminator_schema
+    torch.manual_seed(100 + rank)                      # different init per rank, as the reference's unseeded CPU init
+    tree = ParamTree(discriminator_schema(19, 8, 2).shapes, torch.device('cpu'))
+    tree.init_weights()
+    before = tree.flat.clone()
+    ddp = FlatDDP(tree, bucket_bytes=4096)             # small buckets -> several slices
+    assert len(ddp.sync.slices) > 1
+    tree.flat_grad.copy_(torch.arange(tree.flat_grad.numel(), dtype=torch.float32) * (rank + 1))
+    scale = ddp.sync.all_reduce_grads()
+    sd = ddp.state_dict()
+    q.put((rank, before.numpy().copy(), tree.flat.numpy().copy(), tree.flat_grad.numpy().copy(), scale,
+           list(sd.keys())[:2]))       # numpy: pickled by value (tensors would travel as shm handles)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_flat_ddp_broadcast_and_allreduce_world2():
+    world, port = 2, _free_port()
+    ctx = mp.get_context('spawn')
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = sorted([q.get(timeout=120) for _ in range(world)], key=lambda t: t[0])
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    (_, b0, p0, g0, s0, k0), (_, b1, p1, g1, s1, k1) = res
+    import numpy as np
+    assert not np.array_equal(b0, b1)                   # ranks started from different weights ...
+    assert np.array_equal(p0, b0) and np.array_equal(p1, b0)   # ... and both hold rank 0's after construction
+    want = np.arange(g0.size, dtype=np.float32) * 3.0   # SUM over ranks of arange*(rank+1)
+    assert np.array_equal(g0, want) and np.array_equal(g1, want)
+    assert s0 == 0.5 and s1 == 0.5                      # the mean is applied by the optimiser (grad_scale)
+    assert all(k.startswith('module.') for k in k0)

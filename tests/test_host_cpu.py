@@ -1,0 +1,125 @@
+"""CPU suite: host logic, the C-ABI library's exports, schema agreement, and the rule that the product never touches
+the oracle.  No compute kernels are launched (no GPU here)."""
+import ctypes
+import os
+import re
+
+import numpy as np
+import pytest
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_library_loads_and_exports_every_declared_symbol():
+    from hoig_amd import _lib as L
+    syms = L.declared_symbols()
+    assert len(syms) >= 30
+    lib = ctypes.CDLL(L.LIB_PATH)
+    for s in syms:
+        assert hasattr(lib, s), 'libhoig_hip.so does not export %s (declared in include/hoig_kernels.h)' % s
+    assert set(L._SIGS).issubset(set(syms))
+    assert b'gfx950' in L.lib.hoig_version()
+
+
+def test_c_abi_rejects_bad_arguments_without_a_gpu():
+    """Argument validation happens before any launch, so it can be exercised on the CPU box."""
+    from hoig_amd import _lib as L
+    d = L.ConvDesc(1, 8, 8, 4, 8, 8, 4, 3, 3, 1, 1, 0, 0, 0.0, 0)
+    assert L.lib.hoig_conv2d_fwd(ctypes.byref(d), None, None, None, None, None) == L.EINVAL
+    bad = L.ConvDesc(1, 8, 8, 4, 9, 9, 4, 3, 3, 1, 1, 0, 0, 0.0, 0)          # inconsistent output size
+    assert L.lib.hoig_conv2d_fwd(ctypes.byref(bad), 1, 1, None, 1, None) == L.EINVAL
+    assert L.lib.hoig_adam_step(None, None, None, None, 4, 1e-3, 0.9, 0.999, 1e-8, 1, 1.0, None) == L.EINVAL
+    assert L.lib.hoig_inorm_workspace_bytes(2, 1024, 512) == 2 * (16 + 1) * 2 * 512 * 4
+
+
+def test_product_never_imports_the_oracle():
+    pat = re.compile(r'^\s*(from|import)\s+(oracle|tests)\b|oracle[./]', re.M)
+    for dirpath, _, files in os.walk(os.path.join(ROOT, 'hoig_amd')):
+        for f in files:
+            if f.endswith(('.py', '.hip', '.h', '.sh')):
+                text = open(os.path.join(dirpath, f)).read()
+                assert not pat.search(text), '%s references the oracle' % os.path.join(dirpath, f)
+
+
+def test_ops_fail_loudly_on_cpu_tensors():
+    from hoig_amd import ops
+    with pytest.raises(NotImplementedError):
+        ops.conv2d(torch.zeros(1, 4, 4, 4), ops.pack_weight(torch.zeros(4, 4, 3, 3)), None, 1, 1)
+    with pytest.raises(NotImplementedError):
+        ops.instance_norm(torch.zeros(1, 4, 4, 4))
+
+
+@pytest.mark.parametrize('gen_name', ['generator_base', 'generator_spade', 'generator_spade_attn',
+                                      'generator_spade_attn_tiny'])
+@pytest.mark.parametrize('dataset', ['hov3', 'dexycb'])
+def test_product_schema_equals_oracle_schema(gen_name, dataset):
+    from oracle import hogan_oracle as O
+    from hoig_amd.models.networks.schema import GeneratorConfig, generator_schema, discriminator_schema, vgg_schema
+    cfg = O.make_cfg(gen_name, dataset)
+    pc = GeneratorConfig(gen_name, cfg['bg_dim'], 3, 3, cfg['img_cond_dim'], 12)
+    assert list(generator_schema(pc).shapes.items()) == list(O.gen_param_shapes(cfg).items())
+    assert list(discriminator_schema(cfg['d_input_nc'], 64, 4).shapes.items()) == list(O.disc_param_shapes(cfg).items())
+    assert list(vgg_schema().shapes.items()) == list(O.vgg_param_shapes().items())
+
+
+def test_schema_matches_reference_golden_names_and_counts():
+    from oracle import hogan_oracle as O
+    g = np.load(os.path.join(ROOT, 'tests', 'golden', 'hov3_spade_attn_64.npz'))
+    shp = O.gen_param_shapes(O.make_cfg('generator_spade_attn'))
+    assert [str(s) for s in g['param_names_G']] == list(shp.keys())
+    assert len(shp) == 425 and sum(int(np.prod(s)) for s in shp.values()) == 183501729
+    dshp = O.disc_param_shapes(O.make_cfg('generator_spade_attn'))
+    assert len(dshp) == 12 and sum(int(np.prod(s)) for s in dshp.values()) == 6975937
+
+
+def test_packed_weight_views():
+    from hoig_amd.ops import pack_weight, packed_strides
+    w = torch.arange(2 * 3 * 2 * 2, dtype=torch.float32).view(2, 3, 2, 2)      # conv (Co,Ci,R,S)
+    p = pack_weight(w)
+    assert torch.equal(p, w) and p.stride() == packed_strides(w.shape, False)
+    flat = p.as_strided((p.numel(),), (1,))
+    assert torch.equal(flat.view(2, 2, 2, 3), w.permute(0, 2, 3, 1))           # storage is [Co][R][S][Ci]
+    wt = torch.arange(3 * 2 * 2 * 2, dtype=torch.float32).view(3, 2, 2, 2)     # convT (Ci,Co,R,S)
+    pt = pack_weight(wt, transposed=True)
+    assert torch.equal(pt, wt)
+    assert torch.equal(pt.as_strided((pt.numel(),), (1,)).view(2, 2, 2, 3), wt.permute(1, 2, 3, 0))
+
+
+def test_param_tree_state_dict_roundtrip_cpu():
+    from hoig_amd.nn import ParamTree
+    from hoig_amd.models.networks.schema import discriminator_schema
+    sch = discriminator_schema(19, 8, 2)
+    tree = ParamTree(sch.shapes, torch.device('cpu'))
+    g = torch.Generator().manual_seed(0)
+    sd = {k: torch.randn(v, generator=g) for k, v in sch.shapes.items()}
+    tree.load_state_dict(sd)
+    out = tree.state_dict()
+    assert list(out.keys()) == list(sch.shapes.keys())
+    for k in sd:
+        assert out[k].is_contiguous() and torch.equal(out[k], sd[k])
+    assert [n for n, _ in tree.named_parameters()] == list(sch.shapes.keys())
+    assert tree.flat.numel() >= sum(v.numel() for v in sd.values())
+    for p in tree.parameters():
+        assert p.grad is not None and p.grad.data_ptr() >= tree.flat_grad.data_ptr()
+    with pytest.raises(RuntimeError):
+        tree.load_state_dict({'nope': torch.zeros(1)})
+    tree.init_weights(torch.Generator().manual_seed(1))
+    assert abs(float(tree.P['model.0.weight'].std()) - 0.02) < 5e-3 and float(tree.P['model.0.bias'].abs().max()) == 0
+
+
+def test_synthetic_inputs_deterministic_and_in_range():
+    from hoig_amd import synthetic
+    a = synthetic.make_inputs(2, 32, seed=8)
+    b = synthetic.make_inputs(2, 32, seed=8)
+    for k in a:
+        assert torch.equal(a[k], b[k])
+    assert tuple(a['input_G_bg'].shape) == (2, 4, 32, 32) and tuple(a['input_G_src_obj'].shape) == (2, 15, 32, 32)
+    assert tuple(a['input_G_src_hand'].shape) == (2, 6, 32, 32) and tuple(a['T'].shape) == (2, 32, 32, 2)
+    assert tuple(a['bg_mask'].shape) == (4, 1, 32, 32)
+    assert set(a['bg_mask'].unique().tolist()) <= {0.0, 1.0}
+    assert float(a['T'].min()) == -2.0 and float(a['real_src'].abs().max()) <= 1.0
+    d = synthetic.make_inputs(1, 32, seed=8, dataset='dexycb')
+    assert tuple(d['input_G_src_hand'].shape) == (1, 12, 32, 32) and 'armask_src' not in d
+    c = synthetic.make_inputs(2, 32, seed=9)
+    assert not torch.equal(a['real_src'], c['real_src'])

@@ -306,3 +306,48 @@ def test_fused_adam_matches_torch():
         assert rel_err(osd['state'][i]['exp_avg'], osr['state'][i]['exp_avg']) < 1e-6
         assert rel_err(osd['state'][i]['exp_avg_sq'], osr['state'][i]['exp_avg_sq']) < 1e-6
         assert float(osd['state'][i]['step']) == float(osr['state'][i]['step'])
+
+
+BF16_CASES = [
+    # B, Ci, Co, H, k, stride, pad, transposed
+    (2, 64, 64, 16, 3, 1, 1, False),
+    (2, 128, 256, 16, 3, 2, 1, False),
+    (1, 512, 512, 8, 3, 1, 1, False),
+    (8, 512, 512, 32, 3, 1, 1, False),
+    (2, 64, 128, 16, 4, 2, 1, False),
+    (2, 256, 256, 9, 4, 1, 1, False),
+    (3, 96, 160, 10, 3, 1, 1, False),
+    (2, 128, 64, 16, 3, 2, 1, True),
+    (1, 512, 256, 8, 3, 2, 1, True),
+]
+
+
+@pytest.mark.parametrize('B,Ci,Co,H,k,stride,pad,transposed', BF16_CASES)
+def test_conv_bf16x3_fast_path(B, Ci, Co, H, k, stride, pad, transposed):
+    """The split-bf16 MFMA path (3 x v_mfma_f32_32x32x16_bf16 per k-step) must stay fp32-class: bound 3e-4 relative,
+    inside north_star's 1e-3.  Forward and data gradient run on it; the weight gradient on the exact-fp32 kernel."""
+    ops = _ops()
+    from hoig_amd import _lib as L
+    g = torch.Generator().manual_seed(11)
+    x = torch.randn(B, Ci, H, H, generator=g)
+    bias = torch.randn(Co, generator=g)
+    if transposed:
+        w = torch.randn(Ci, Co, k, k, generator=g) * 0.05
+        xr, wr = x.clone().requires_grad_(True), w.clone().requires_grad_(True)
+        yr = F.conv_transpose2d(xr, wr, None, stride=2, padding=1, output_padding=1)
+    else:
+        w = torch.randn(Co, Ci, k, k, generator=g) * 0.05
+        xr, wr = x.clone().requires_grad_(True), w.clone().requires_grad_(True)
+        yr = F.conv2d(xr, wr, bias, stride=stride, padding=pad)
+    gy = torch.randn(yr.shape, generator=g)
+    yr.backward(gy)
+    xd = nhwc_cuda(x).requires_grad_(True)
+    wd = ops.pack_weight(w.cuda(), transposed=transposed).requires_grad_(True)
+    if transposed:
+        y = ops.conv_transpose2d(xd, wd, prec=L.PREC_BF16X3)
+    else:
+        y = ops.conv2d(xd, wd, bias.cuda(), stride, pad, prec=L.PREC_BF16X3)
+    y.backward(nhwc_cuda(gy))
+    assert rel_err(nchw_cpu(y), yr) < 3e-4
+    assert rel_err(nchw_cpu(xd.grad), xr.grad) < 3e-4
+    assert rel_err(wd.grad, wr.grad) < 3e-4
