@@ -77,11 +77,22 @@ __device__ __forceinline__ bool tap_alive(const Geom &g, int hp, int wp, int rs)
     return (((hp + g.pad - r) & 1) == 0) && (((wp + g.pad - s) & 1) == 0);
 }
 
-__device__ __forceinline__ uint2 pack4(float a, float b, float c, float d) {
-    return make_uint2((unsigned)hoig_f2bf(a) | ((unsigned)hoig_f2bf(b) << 16),
-                      (unsigned)hoig_f2bf(c) | ((unsigned)hoig_f2bf(d) << 16));
+typedef __bf16 bf2_t __attribute__((ext_vector_type(2)));
+typedef float f2_t __attribute__((ext_vector_type(2)));
+// two fp32 -> packed bf16 pair (round to nearest even): one v_cvt_pk_bf16_f32
+__device__ __forceinline__ unsigned cvt2(float a, float b) {
+    f2_t v = {a, b};
+    return __builtin_bit_cast(unsigned, __builtin_convertvector(v, bf2_t));
 }
-__device__ __forceinline__ float resid(float x) { return x - hoig_bf2f(hoig_f2bf(x)); }
+// hi = bf16(x), lo = bf16(x - hi) for four values
+__device__ __forceinline__ void split4(const float4 v, uint2 &hi, uint2 &lo) {
+    hi.x = cvt2(v.x, v.y);
+    hi.y = cvt2(v.z, v.w);
+    const float r0 = v.x - __uint_as_float(hi.x << 16), r1 = v.y - __uint_as_float(hi.x & 0xFFFF0000u);
+    const float r2 = v.z - __uint_as_float(hi.y << 16), r3 = v.w - __uint_as_float(hi.y & 0xFFFF0000u);
+    lo.x = cvt2(r0, r1);
+    lo.y = cvt2(r2, r3);
+}
 
 // byte offset of (row, k) inside one [rows][32] bf16 plane, k a multiple of 4
 __device__ __forceinline__ int lds_off(int row, int k) {
@@ -89,15 +100,18 @@ __device__ __forceinline__ int lds_off(int row, int k) {
 }
 
 template <int BM, int BN, int WM, int WN, int NS>
-__global__ __launch_bounds__(256) void igemm_bf16_kernel(const Args p) {
+__global__ __launch_bounds__(WM * WN * 64) void igemm_bf16_kernel(const Args p) {
+    constexpr int NT = WM * WN * 64;        // 256 or 512 threads
     constexpr int BK = 32;
     constexpr int TM = BM / (32 * WM), TN = BN / (32 * WN);
-    constexpr int RA = BM / 32;             // float4 gathers per thread
-    constexpr int RB = BN / 64;             // 16-B weight chunks per thread per plane
+    constexpr int RA = BM * 8 / NT;         // float4 gathers per thread
+    constexpr int RB = BN * 4 / NT;         // 16-B weight chunks per thread per plane
+    constexpr int AROWS = NT / 8, BROWS = NT / 4;
     constexpr int PLANE_A = BM * 64, PLANE_B = BN * 64;
-    __shared__ __attribute__((aligned(16))) unsigned char smem[NS * (PLANE_A + PLANE_B)];
-    unsigned char *Ah = smem, *Al = smem + PLANE_A;
-    unsigned char *Bh = smem + NS * PLANE_A, *Bl = Bh + PLANE_B;
+    constexpr int STAGE = NS * (PLANE_A + PLANE_B);
+    // two LDS stages: k-block t is multiplied out of one while k-block t+1 is converted into the other -> ONE barrier
+    // per k-block; 64 KB at 128x128 (2 workgroups per CU)
+    __shared__ __attribute__((aligned(16))) unsigned char smem[2 * STAGE];
 
     const Geom &g = p.g;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -110,7 +124,7 @@ __global__ __launch_bounds__(256) void igemm_bf16_kernel(const Args p) {
     int pb[RA], bh[RA], bw[RA];
 #pragma unroll
     for (int i = 0; i < RA; ++i) {
-        const int m = m0 + lrow + 32 * i;
+        const int m = m0 + lrow + AROWS * i;
         if (m < p.M) {
             int b, hp, wp;
             decode_m(g, m, b, hp, wp);
@@ -139,81 +153,109 @@ __global__ __launch_bounds__(256) void igemm_bf16_kernel(const Args p) {
 
     float4 ra[RA];
     uint4 rbh[RB], rbl[RB];
-    const int nkb = p.K / BK;
-
-    auto next_kb = [&](int kb) {
-        if (g.tile_skip)
-            while (kb < nkb && !tap_alive(g, t_hp, t_wp, (kb * BK) / g.Cg)) ++kb;
-        return kb;
-    };
-    auto load_tiles = [&](int kb) {
-        // one tap per k-block (Cg % 32 == 0)
-        const int k = kb * BK;
-        const int rs = k / g.Cg, c = k - rs * g.Cg + kc;
-        const int r = rs / g.S, s = rs - r * g.S;
+    // K is walked tap by tap ((r,s) outer, 32-channel blocks inner).  Everything that depends only on the tap -- the
+    // validity and the address of each gathered pixel row -- is computed once per tap, so the per-k-block VALU work is
+    // one pointer add per load plus the bf16 split (MFMA and VALU of ONE wave serialise; this keeps the matrix pipe fed).
+    const int cpb = g.Cg >> 5, RS = g.R * g.S;
+    const float *aptr[RA];
+    const unsigned short *wrow_h[RB], *wrow_l[RB];
+#pragma unroll
+    for (int i = 0; i < RB; ++i) {
+        const int n = n0 + brow + BROWS * i;
+        wrow_h[i] = n < p.N ? p.Wh + (size_t)n * p.K + bchunk * 8 : nullptr;
+        wrow_l[i] = (NS == 2 && n < p.N) ? p.Wl + (size_t)n * p.K + bchunk * 8 : nullptr;
+    }
+    int aoff[RA], boff[RB];
+#pragma unroll
+    for (int i = 0; i < RA; ++i) aoff[i] = lds_off(lrow + AROWS * i, kc);
+#pragma unroll
+    for (int i = 0; i < RB; ++i) {
+        const int row = brow + BROWS * i;
+        boff[i] = row * 64 + ((bchunk ^ ((row >> 2) & 3)) << 4);
+    }
+    int rs = -1, cb = cpb - 1, wk = 0;
+    auto advance = [&]() -> bool {      // move (rs, cb) to the next live k-block; false when K is exhausted
+        if (++cb < cpb) return true;
+        cb = 0;
+        do {
+            ++rs;
+        } while (rs < RS && g.tile_skip && !tap_alive(g, t_hp, t_wp, rs));
+        if (rs >= RS) return false;
+        const int r = rs / g.S, s_ = rs - r * g.S;
+        wk = rs * g.Cg;
 #pragma unroll
         for (int i = 0; i < RA; ++i) {
-            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+            aptr[i] = nullptr;
             if (pb[i] >= 0) {
-                const int hg = gcoord(g, bh[i], r, g.Hg), wg = gcoord(g, bw[i], s, g.Wg);
-                if (hg >= 0 && wg >= 0)
-                    v = *reinterpret_cast<const float4 *>(p.A + ((size_t)(pb[i] + hg) * g.Wg + wg) * g.Cg + c);
+                const int hg = gcoord(g, bh[i], r, g.Hg), wg = gcoord(g, bw[i], s_, g.Wg);
+                if (hg >= 0 && wg >= 0) aptr[i] = p.A + ((size_t)(pb[i] + hg) * g.Wg + wg) * g.Cg + kc;
             }
-            ra[i] = v;
         }
+        return true;
+    };
+    auto load_tiles = [&]() {
+        const int c = cb << 5;
+#pragma unroll
+        for (int i = 0; i < RA; ++i)
+            ra[i] = aptr[i] ? *reinterpret_cast<const float4 *>(aptr[i] + c) : make_float4(0.f, 0.f, 0.f, 0.f);
 #pragma unroll
         for (int i = 0; i < RB; ++i) {
-            const int n = n0 + brow + 64 * i;
-            uint4 vh = make_uint4(0, 0, 0, 0), vl = vh;
-            if (n < p.N) {
-                const size_t off = (size_t)n * p.K + k + bchunk * 8;
-                vh = *reinterpret_cast<const uint4 *>(p.Wh + off);
-                if (NS == 2) vl = *reinterpret_cast<const uint4 *>(p.Wl + off);
-            }
-            rbh[i] = vh;
-            rbl[i] = vl;
+            rbh[i] = wrow_h[i] ? *reinterpret_cast<const uint4 *>(wrow_h[i] + wk + c) : make_uint4(0, 0, 0, 0);
+            if (NS == 2) rbl[i] = wrow_l[i] ? *reinterpret_cast<const uint4 *>(wrow_l[i] + wk + c) : make_uint4(0, 0, 0, 0);
         }
     };
-    auto store_tiles = [&]() {
+    auto store_tiles = [&](int stage) {
+        unsigned char *Ah = smem + stage * STAGE, *Al = Ah + PLANE_A;
+        unsigned char *Bh = Ah + NS * PLANE_A, *Bl = Bh + PLANE_B;
 #pragma unroll
         for (int i = 0; i < RA; ++i) {
-            const int off = lds_off(lrow + 32 * i, kc);
-            const float4 v = ra[i];
-            *reinterpret_cast<uint2 *>(Ah + off) = pack4(v.x, v.y, v.z, v.w);
-            if (NS == 2) *reinterpret_cast<uint2 *>(Al + off) = pack4(resid(v.x), resid(v.y), resid(v.z), resid(v.w));
+            uint2 hi, lo;
+            split4(ra[i], hi, lo);
+            *reinterpret_cast<uint2 *>(Ah + aoff[i]) = hi;
+            if (NS == 2) *reinterpret_cast<uint2 *>(Al + aoff[i]) = lo;
         }
 #pragma unroll
         for (int i = 0; i < RB; ++i) {
-            const int row = brow + 64 * i;
-            const int off = row * 64 + ((bchunk ^ ((row >> 2) & 3)) << 4);
-            *reinterpret_cast<uint4 *>(Bh + off) = rbh[i];
-            if (NS == 2) *reinterpret_cast<uint4 *>(Bl + off) = rbl[i];
+            *reinterpret_cast<uint4 *>(Bh + boff[i]) = rbh[i];
+            if (NS == 2) *reinterpret_cast<uint4 *>(Bl + boff[i]) = rbl[i];
         }
     };
+    int aread[TM], bread[TN];       // ds_read_b128 offsets of this lane's fragments for ks = 0 (ks = 1: chunk ^ 2)
+#pragma unroll
+    for (int i = 0; i < TM; ++i) {
+        const int row = wm * (TM * 32) + i * 32 + l31;
+        aread[i] = row * 64 + ((lh ^ ((row >> 2) & 3)) << 4);
+    }
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+        const int row = wn * (TN * 32) + j * 32 + l31;
+        bread[j] = row * 64 + ((lh ^ ((row >> 2) & 3)) << 4);
+    }
 
-    int kb = next_kb(0);
-    if (kb < nkb) {
-        load_tiles(kb);
-        store_tiles();
+    bool more = advance();
+    if (more) {
+        load_tiles();
+        store_tiles(0);
     }
     __syncthreads();
-    while (kb < nkb) {
-        const int kn = next_kb(kb + 1);
-        if (kn < nkb) load_tiles(kn);
+    int cur = 0;
+    while (more) {
+        const bool nxt = advance();
+        if (nxt) load_tiles();
+        const unsigned char *Ah = smem + cur * STAGE, *Al = Ah + PLANE_A;
+        const unsigned char *Bh = Ah + NS * PLANE_A, *Bl = Bh + PLANE_B;
 #pragma unroll
         for (int ks = 0; ks < 2; ++ks) {
             bf16x8 ah[TM], al[TM], bhf[TN], blf[TN];
 #pragma unroll
             for (int i = 0; i < TM; ++i) {
-                const int row = wm * (TM * 32) + i * 32 + l31;
-                const int off = row * 64 + (((2 * ks + lh) ^ ((row >> 2) & 3)) << 4);
+                const int off = aread[i] ^ (ks << 5);
                 ah[i] = *reinterpret_cast<const bf16x8 *>(Ah + off);
                 if (NS == 2) al[i] = *reinterpret_cast<const bf16x8 *>(Al + off);
             }
 #pragma unroll
             for (int j = 0; j < TN; ++j) {
-                const int row = wn * (TN * 32) + j * 32 + l31;
-                const int off = row * 64 + (((2 * ks + lh) ^ ((row >> 2) & 3)) << 4);
+                const int off = bread[j] ^ (ks << 5);
                 bhf[j] = *reinterpret_cast<const bf16x8 *>(Bh + off);
                 if (NS == 2) blf[j] = *reinterpret_cast<const bf16x8 *>(Bl + off);
             }
@@ -228,10 +270,10 @@ __global__ __launch_bounds__(256) void igemm_bf16_kernel(const Args p) {
                     acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[i], bhf[j], acc[i][j], 0, 0, 0);
                 }
         }
+        if (nxt) store_tiles(cur ^ 1);
         __syncthreads();
-        if (kn < nkb) store_tiles();
-        __syncthreads();
-        kb = kn;
+        cur ^= 1;
+        more = nxt;
     }
 
 #pragma unroll
@@ -280,6 +322,7 @@ __global__ void pack_weight_kernel(const float *__restrict__ w, int Co, int RS, 
 
 template <int BM, int BN, int WM, int WN>
 int launch(Args a, int ns, hipStream_t st) {
+    constexpr int NT = WM * WN * 64;
     const int nbm = (int)hoig_cdiv(a.M, BM), nbn = (int)hoig_cdiv(a.N, BN);
     a.nblk_n = nbn;
     a.nblk = nbm * nbn;
@@ -288,8 +331,8 @@ int launch(Args a, int ns, hipStream_t st) {
         const long per_phase = (long)a.g.Bn * (a.g.Hp / 2) * (a.g.Wp / 2);
         a.g.tile_skip = (per_phase % BM == 0) ? 1 : 0;
     }
-    if (ns == 2) igemm_bf16_kernel<BM, BN, WM, WN, 2><<<a.nblk, 256, 0, st>>>(a);
-    else igemm_bf16_kernel<BM, BN, WM, WN, 1><<<a.nblk, 256, 0, st>>>(a);
+    if (ns == 2) igemm_bf16_kernel<BM, BN, WM, WN, 2><<<a.nblk, NT, 0, st>>>(a);
+    else igemm_bf16_kernel<BM, BN, WM, WN, 1><<<a.nblk, NT, 0, st>>>(a);
     HOIG_LAUNCH_CHECK();
     return HOIG_OK;
 }
@@ -324,7 +367,10 @@ int run(const hoig_conv_desc *d, const float *a, const unsigned short *wh, const
         return launch<64, 64, 2, 2>(p, ns, st);
     }
     const long n128 = hoig_cdiv(p.N, 128);
+    // fewer than two 128x128 workgroups per CU: run 8 waves per workgroup so every SIMD still holds two waves and one
+    // wave's bf16 split (VALU) overlaps the other's MFMAs
     if (t128 * n128 >= 512) return launch<128, 128, 2, 2>(p, ns, st);
+    if (t128 * n128 >= 128) return launch<128, 128, 2, 4>(p, ns, st);
     return launch<64, 128, 2, 2>(p, ns, st);
 }
 
@@ -333,9 +379,6 @@ int run(const hoig_conv_desc *d, const float *a, const unsigned short *wh, const
 // fp32-weight entry points cannot use the bf16 path (it needs the pre-split planes): tell the dispatcher to fall back.
 int hoig_conv_bf16_fwd_like(const hoig_conv_desc *, const float *, const float *, const float *, float *, bool,
                             hipStream_t) {
-    return HOIG_EUNSUPPORTED;
-}
-int hoig_conv_bf16_wgrad(const hoig_conv_desc *, const float *, const float *, float *, hipStream_t) {
     return HOIG_EUNSUPPORTED;
 }
 
@@ -360,4 +403,273 @@ extern "C" int hoig_conv2d_bwd_data_packed(const hoig_conv_desc *d, const float 
     if (!d || !dy || !wt_hi || !dx) return HOIG_EINVAL;
     if (d->precision != HOIG_PREC_BF16X3 && d->precision != HOIG_PREC_BF16) return HOIG_EINVAL;
     return run(d, dy, wt_hi, wt_lo, nullptr, dx, true, (hipStream_t)stream);
+}
+
+// =====================================================================================================================
+// Weight gradient on the bf16 MFMA:  dW[co][j] += sum_m P[m][co] * Q[m][j],  j = (r,s,ci), m = pixels.
+//   Conv2d          : m walks the OUTPUT grid, P = dy (plain), Q = x gathered at (hp*stride - pad + r, ...)
+//   ConvTranspose2d : m walks the INPUT grid (4x fewer pixels, no structural zeros), Q = x (plain),
+//                     P = dy gathered at (hi*stride - pad + r, ...) with the column tile's tap (needs Ci % 128 == 0)
+// Both operands arrive as [pixel][channel] rows (channel-contiguous, coalesced) but the MFMA wants 8 consecutive
+// REDUCTION indices (pixels) per lane, i.e. the transpose.  The tiles are therefore stored as they arrive,
+// [m][channel] bf16 with a 320-B row stride, and the fragments are read with ds_read_b64_tr_b16 (the LDS transpose
+// read of gfx950; lane semantics verified on hardware by tools/trtest.hip): per 16-lane group a 4(m) x 16(channel)
+// block is delivered column-major, two reads give the 8 k-values of one 32x32x16 operand.  Row stride 320 B puts the
+// four rows of a block and the two blocks of a 32-lane half on disjoint banks.
+namespace {
+
+struct WArgs {
+    const float *P, *Q;
+    float *DW;
+    int gatherP;               // 1: P is the gathered operand (ConvTranspose), 0: Q is (Conv)
+    int Bn, Hp, Wp;            // pixel grid walked by m
+    int Hg, Wg, Cg;            // gathered tensor
+    int Cplain;                // channel count of the plain tensor
+    int R, S, stride, pad;
+    int M, Co, Ci, K;
+    int nblk_n, nblk_mn, m_per_split;
+};
+
+struct Pix {
+    int b, h, w;
+};
+__device__ __forceinline__ void pix_advance(Pix &p, int step, int Hp, int Wp) {
+    p.w += step;
+    while (p.w >= Wp) {
+        p.w -= Wp;
+        if (++p.h >= Hp) {
+            p.h = 0;
+            ++p.b;
+        }
+    }
+}
+
+template <int BM, int NS>
+__global__ __launch_bounds__(256) void wgrad_bf16_kernel(const WArgs p) {
+    constexpr int BN = 128, BK = 32, TM = BM / 64, TN = 2;
+    constexpr int RSTR = 320;                              // LDS row stride in bytes (128 bf16 + pad)
+    constexpr int PLANE_P = BK * RSTR, PLANE_Q = BK * RSTR;
+    constexpr int STAGE = NS * (PLANE_P + PLANE_Q);
+    constexpr int RP = BM / 32;                            // float4 loads per thread for P (BM/4 columns, 8 row lanes)
+    __shared__ __attribute__((aligned(16))) unsigned char smem[2 * STAGE];
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave >> 1, wn = wave & 1;
+    const int tile = hoig_xcd_remap(blockIdx.x, p.nblk_mn);
+    const int c0 = (tile / p.nblk_n) * BM, j0 = (tile % p.nblk_n) * BN;
+    const int m_begin = blockIdx.y * p.m_per_split;
+    const int m_end = min(p.M, m_begin + p.m_per_split);
+
+    // loader roles: Q tile = 32 rows x 32 float4 columns (4 passes of 8 rows); P tile = 32 rows x BM/4 columns
+    const int qcol = tid & 31, qrow = tid >> 5;
+    constexpr int PCOLS = BM / 4;
+    const int pcol = tid % PCOLS, prow = tid / PCOLS;      // BM=128: 8 row lanes, 4 passes; BM=64: 16 row lanes, 2 passes
+    constexpr int PROWS = 256 / PCOLS;
+
+    // the tap(s): for the gathered operand.  Conv: per-thread tap from its Q column; ConvT: the tile's tap.
+    const int jq = j0 + qcol * 4;
+    int tap_r, tap_s, gch;                                 // tap and channel offset inside the gathered tensor
+    {
+        const int jj = p.gatherP ? j0 : jq;
+        const int rs = jj / p.Ci;
+        tap_r = rs / p.S;
+        tap_s = rs - tap_r * p.S;
+        gch = p.gatherP ? (c0 + pcol * 4) : (jq - rs * p.Ci);
+    }
+    const int plain_ch = p.gatherP ? (jq - (j0 / p.Ci) * p.Ci) : (c0 + pcol * 4);
+    const bool q_ok = jq < p.K, p_ok = (c0 + pcol * 4) < p.Co;
+
+    Pix pq[4], pp[RP];
+    {
+        const int hw = p.Hp * p.Wp;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int m = m_begin + qrow + 8 * i;
+            pq[i].b = m / hw;
+            const int rem = m - pq[i].b * hw;
+            pq[i].h = rem / p.Wp;
+            pq[i].w = rem - pq[i].h * p.Wp;
+        }
+#pragma unroll
+        for (int i = 0; i < RP; ++i) {
+            const int m = m_begin + prow + PROWS * i;
+            pp[i].b = m / hw;
+            const int rem = m - pp[i].b * hw;
+            pp[i].h = rem / p.Wp;
+            pp[i].w = rem - pp[i].h * p.Wp;
+        }
+    }
+
+    auto gather = [&](const float *T, const Pix &x) -> float4 {
+        const int hg = x.h * p.stride - p.pad + tap_r, wg = x.w * p.stride - p.pad + tap_s;
+        if (hg < 0 || hg >= p.Hg || wg < 0 || wg >= p.Wg) return make_float4(0.f, 0.f, 0.f, 0.f);
+        return *reinterpret_cast<const float4 *>(T + (((size_t)x.b * p.Hg + hg) * p.Wg + wg) * p.Cg + gch);
+    };
+    auto plain = [&](const float *T, const Pix &x) -> float4 {
+        return *reinterpret_cast<const float4 *>(T + (((size_t)x.b * p.Hp + x.h) * p.Wp + x.w) * p.Cplain + plain_ch);
+    };
+
+    f32x16 acc[TM][TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    float4 rp[RP], rq[4];
+    auto load_tiles = [&](int mb) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int m = mb + qrow + 8 * i;
+            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (m < m_end && q_ok) v = p.gatherP ? plain(p.Q, pq[i]) : gather(p.Q, pq[i]);
+            rq[i] = v;
+            pix_advance(pq[i], BK, p.Hp, p.Wp);
+        }
+#pragma unroll
+        for (int i = 0; i < RP; ++i) {
+            const int m = mb + prow + PROWS * i;
+            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (m < m_end && p_ok) v = p.gatherP ? gather(p.P, pp[i]) : plain(p.P, pp[i]);
+            rp[i] = v;
+            pix_advance(pp[i], BK, p.Hp, p.Wp);
+        }
+    };
+    auto store_tiles = [&](int stage) {
+        unsigned char *Ph = smem + stage * STAGE, *Pl = Ph + PLANE_P;
+        unsigned char *Qh = Ph + NS * PLANE_P, *Ql = Qh + PLANE_Q;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            uint2 hi, lo;
+            split4(rq[i], hi, lo);
+            const int off = (qrow + 8 * i) * RSTR + qcol * 8;
+            *reinterpret_cast<uint2 *>(Qh + off) = hi;
+            if (NS == 2) *reinterpret_cast<uint2 *>(Ql + off) = lo;
+        }
+#pragma unroll
+        for (int i = 0; i < RP; ++i) {
+            uint2 hi, lo;
+            split4(rp[i], hi, lo);
+            const int off = (prow + PROWS * i) * RSTR + pcol * 8;
+            *reinterpret_cast<uint2 *>(Ph + off) = hi;
+            if (NS == 2) *reinterpret_cast<uint2 *>(Pl + off) = lo;
+        }
+    };
+
+    // transpose-read addressing: 16-lane group g, lane 4q+p -> row (8*(g>>1) + q), channels 16*(g&1) + 4p ..
+    const int grp = lane >> 4, li = lane & 15;
+    const int tr_off = ((grp >> 1) * 8 + (li >> 2)) * RSTR + ((grp & 1) * 16 + (li & 3) * 4) * 2;
+    typedef short s4_t __attribute__((ext_vector_type(4)));
+    auto frag = [&](const unsigned char *plane, int chan_base, int ks) -> bf16x8 {
+        const unsigned char *a = plane + tr_off + ks * 16 * RSTR + chan_base * 2;
+        const s4_t lo4 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s4_t *)a);
+        const s4_t hi4 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s4_t *)(a + 4 * RSTR));
+        bf16x8 f;
+        f[0] = lo4[0]; f[1] = lo4[1]; f[2] = lo4[2]; f[3] = lo4[3];
+        f[4] = hi4[0]; f[5] = hi4[1]; f[6] = hi4[2]; f[7] = hi4[3];
+        return f;
+    };
+
+    if (m_begin < m_end) {
+        load_tiles(m_begin);
+        store_tiles(0);
+    }
+    __syncthreads();
+    int cur = 0;
+    for (int mb = m_begin; mb < m_end; mb += BK) {
+        const bool nxt = mb + BK < m_end;
+        if (nxt) load_tiles(mb + BK);
+        const unsigned char *Ph = smem + cur * STAGE, *Pl = Ph + PLANE_P;
+        const unsigned char *Qh = Ph + NS * PLANE_P, *Ql = Qh + PLANE_Q;
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+            bf16x8 ah[TM], al[TM], bh[TN], bl[TN];
+#pragma unroll
+            for (int i = 0; i < TM; ++i) {
+                ah[i] = frag(Ph, wm * (TM * 32) + i * 32, ks);
+                if (NS == 2) al[i] = frag(Pl, wm * (TM * 32) + i * 32, ks);
+            }
+#pragma unroll
+            for (int j = 0; j < TN; ++j) {
+                bh[j] = frag(Qh, wn * 64 + j * 32, ks);
+                if (NS == 2) bl[j] = frag(Ql, wn * 64 + j * 32, ks);
+            }
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int j = 0; j < TN; ++j) {
+                    if (NS == 2) {
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[i], bh[j], acc[i][j], 0, 0, 0);
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[i], bl[j], acc[i][j], 0, 0, 0);
+                    }
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[i], bh[j], acc[i][j], 0, 0, 0);
+                }
+        }
+        if (nxt) store_tiles(cur ^ 1);
+        __syncthreads();
+        cur ^= 1;
+    }
+
+    const int l31 = lane & 31, lh = lane >> 5;
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int co = c0 + wm * (TM * 32) + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+            if (co >= p.Co) continue;
+#pragma unroll
+            for (int j = 0; j < TN; ++j) {
+                const int jj = j0 + wn * 64 + j * 32 + l31;
+                if (jj < p.K) atomicAdd(&p.DW[(size_t)co * p.K + jj], acc[i][j][r]);
+            }
+        }
+}
+
+template <int BM>
+int launch_wgrad_bf16(WArgs a, int ns, hipStream_t st) {
+    const int nbm = (int)hoig_cdiv(a.Co, BM), nbn = (int)hoig_cdiv(a.K, 128);
+    a.nblk_n = nbn;
+    a.nblk_mn = nbm * nbn;
+    int splits = (int)hoig_cdiv(1024, a.nblk_mn);
+    const int max_splits = (int)hoig_cdiv(a.M, 512);
+    if (splits > max_splits) splits = max_splits;
+    if (splits < 1) splits = 1;
+    const int mps = (int)hoig_cdiv(hoig_cdiv(a.M, splits), 32) * 32;
+    a.m_per_split = mps;
+    splits = (int)hoig_cdiv(a.M, mps);
+    dim3 grid(a.nblk_mn, splits);
+    if (ns == 2) wgrad_bf16_kernel<BM, 2><<<grid, 256, 0, st>>>(a);
+    else wgrad_bf16_kernel<BM, 1><<<grid, 256, 0, st>>>(a);
+    HOIG_LAUNCH_CHECK();
+    return HOIG_OK;
+}
+
+}  // namespace
+
+int hoig_conv_bf16_wgrad(const hoig_conv_desc *d, const float *x, const float *dy, float *dw, hipStream_t st) {
+    if ((d->Co & 3) || (d->Ci & 3) || d->Co < 32) return HOIG_EUNSUPPORTED;
+    WArgs a;
+    a.DW = dw;
+    a.Bn = d->B;
+    a.R = d->R; a.S = d->S; a.stride = d->stride; a.pad = d->pad;
+    a.Co = d->Co; a.Ci = d->Ci; a.K = d->R * d->S * d->Ci;
+    if (!d->transposed) {
+        a.gatherP = 0;
+        a.P = dy; a.Q = x;
+        a.Hp = d->Ho; a.Wp = d->Wo;
+        a.Hg = d->Hi; a.Wg = d->Wi; a.Cg = d->Ci;
+        a.Cplain = d->Co;
+    } else {
+        if (d->Ci % 128) return HOIG_EUNSUPPORTED;
+        a.gatherP = 1;
+        a.P = dy; a.Q = x;
+        a.Hp = d->Hi; a.Wp = d->Wi;
+        a.Hg = d->Ho; a.Wg = d->Wo; a.Cg = d->Co;
+        a.Cplain = d->Ci;
+    }
+    a.M = d->B * a.Hp * a.Wp;
+    const int ns = d->precision == HOIG_PREC_BF16X3 ? 2 : 1;
+    if (a.Co <= 64) return launch_wgrad_bf16<64>(a, ns, st);
+    return launch_wgrad_bf16<128>(a, ns, st);
 }
