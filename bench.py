@@ -111,7 +111,7 @@ def main():
     ap.add_argument('--batch', type=int, default=8, help='pairs per GPU')
     ap.add_argument('--side', type=int, default=256)
     ap.add_argument('--gen_name', default='generator_spade_attn')
-    ap.add_argument('--precision', default=os.environ.get('HOIG_PRECISION', 'f32'))
+    ap.add_argument('--precision', default=os.environ.get('HOIG_PRECISION', 'bf16x3'))
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--cpu-baseline-worker', type=int, default=0, help=argparse.SUPPRESS)
     args = ap.parse_args()
