@@ -6,7 +6,7 @@ mkdir -p _build
 HIPCC=${HIPCC:-/opt/rocm/bin/hipcc}
 FLAGS="-O3 -std=c++17 --offload-arch=gfx950 -fPIC -I../../include -I. -Wno-unused-result"
 pids=()
-for f in conv_igemm conv_igemm_bf16 norm attn sample pointwise; do
+for f in conv_igemm conv_igemm_bf16 conv_small norm attn sample pointwise; do
   if [ ! -f _build/$f.o ] || [ $f.hip -nt _build/$f.o ] || [ common.h -nt _build/$f.o ] || [ ../../include/hoig_kernels.h -nt _build/$f.o ]; then
     $HIPCC $FLAGS -c $f.hip -o _build/$f.o &
     pids+=($!)

@@ -565,6 +565,9 @@ int check_desc(const hoig_conv_desc *d) {
 
 int hoig_conv_bf16_fwd_like(const hoig_conv_desc *d, const float *a, const float *w, const float *bias, float *c,
                             bool dgrad, hipStream_t st);  // conv_igemm_bf16.hip
+int hoig_conv_small_fwd(const hoig_conv_desc *d, const float *x, const float *w, const float *bias, float *y,
+                        hipStream_t st);                  // conv_small.hip
+int hoig_conv_small_wgrad(const hoig_conv_desc *d, const float *x, const float *dy, float *dw, hipStream_t st);
 
 extern "C" int hoig_conv2d_fwd(const hoig_conv_desc *d, const float *x, const float *w, const float *bias, float *y,
                                hoig_stream_t stream) {
@@ -572,6 +575,8 @@ extern "C" int hoig_conv2d_fwd(const hoig_conv_desc *d, const float *x, const fl
     if (rc) return rc;
     if (!x || !w || !y) return HOIG_EINVAL;
     hipStream_t st = (hipStream_t)stream;
+    rc = hoig_conv_small_fwd(d, x, w, bias, y, st);           // 7x7 heads with <= 4 output channels: direct fp32 kernel
+    if (rc != HOIG_EUNSUPPORTED) return rc;
     if (d->precision != HOIG_PREC_F32) {
         rc = hoig_conv_bf16_fwd_like(d, x, w, bias, y, false, st);
         if (rc != HOIG_EUNSUPPORTED) return rc;
@@ -637,6 +642,8 @@ extern "C" int hoig_conv2d_bwd_weight(const hoig_conv_desc *d, const float *x, c
         rc = hoig_colsum_accum(dy, dbias, (int64_t)d->B * d->Ho * d->Wo, d->Co, stream);
         if (rc) return rc;
     }
+    rc = hoig_conv_small_wgrad(d, x, dy, dw, st);
+    if (rc != HOIG_EUNSUPPORTED) return rc;
     if (d->precision != HOIG_PREC_F32) {
         rc = hoig_conv_bf16_wgrad(d, x, dy, dw, st);
         if (rc != HOIG_EUNSUPPORTED) return rc;
