@@ -44,10 +44,64 @@ def dominant_kernel_roofline(batch, side, precision, iters=20):
     ms = s.elapsed_time(e) / iters
     flops = 2.0 * batch * h * h * 512 * 512 * 9            # algorithmic: 2*M*N*K, M=B*h*h, N=512, K=9*512
     achieved = flops / (ms * 1e-3) / 1e12
-    return dict(bound='mfma', kernel='igemm_f32_kernel (conv3x3 s1 512->512 @%dx%d, B=%d)' % (h, h, batch),
+    kname = 'igemm_f32_kernel' if precision == 'f32' else 'conv_halo_bf16_kernel<3,%d>' % (2 if precision == 'bf16x3' else 1)
+    return dict(bound='mfma', kernel='%s (conv3x3 s1 512->512 @%dx%d, B=%d)' % (kname, h, h, batch),
                 achieved=round(achieved, 2), peak=PEAK[precision], unit='TFLOP/s',
                 frac=round(achieved / PEAK[precision], 4), traffic=None, avg_launch_ms=round(ms, 4),
                 algorithmic_flop_per_launch=flops)
+
+
+def gen_forward_latency(opt, batch, side, iters=10):
+    """BASELINE.json's second headline: generator-only inference (`Trainer.forward` under no_grad in eval mode,
+    eval.py:59-65), batch 32 at 256x256 (configs[4]); timed eagerly and as a captured hipGraph replay."""
+    from hoig_amd import synthetic
+    from hoig_amd.models import ModelsFactory
+    opt.is_train = False
+    opt.load_path = 'None'
+    opt.load_epoch = -1
+    from hoig_amd.models.trainer import Trainer
+    model = Trainer.__new__(Trainer)          # eval.py would load a checkpoint; here: random-init weights (no files)
+    from hoig_amd.models.base_model import BaseModel
+    BaseModel.__init__(model, opt)
+    model._name = 'Trainer'
+    model.device = torch.device('cuda', torch.cuda.current_device())
+    model._dexycb, model._world, model._side, model._g_ready = False, 1, None, None
+    model._init_create_networks(use_ddp=False)
+    model._init_prefetch_inputs()
+    model.set_eval()
+    model.set_input(synthetic.make_inputs(batch, side, seed=8))
+    out = {}
+    with torch.no_grad():
+        for _ in range(2):
+            model.forward()
+        torch.cuda.synchronize()
+        s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        s.record()
+        for _ in range(iters):
+            model.forward()
+        e.record()
+        torch.cuda.synchronize()
+        out['eager_ms_per_img'] = round(s.elapsed_time(e) / iters / batch, 4)
+        try:
+            graph = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(graph):
+                res = model.forward()
+            graph.replay()
+            torch.cuda.synchronize()
+            s.record()
+            for _ in range(iters):
+                graph.replay()
+            e.record()
+            torch.cuda.synchronize()
+            out['hipgraph_ms_per_img'] = round(s.elapsed_time(e) / iters / batch, 4)
+            out['finite'] = bool(torch.isfinite(res[3]).all().item())
+        except Exception as ex:          # report, do not hide
+            out['hipgraph_error'] = repr(ex)[:200]
+    out['batch'] = batch
+    out['gflop_per_img'] = 787.2 * (side / 256.0) ** 2       # BASELINE.md section 2
+    best = out.get('hipgraph_ms_per_img', out['eager_ms_per_img'])
+    out['tflops'] = round(out['gflop_per_img'] / best, 2)
+    return out
 
 
 def usable_cores():
@@ -113,6 +167,8 @@ def main():
     ap.add_argument('--gen_name', default='generator_spade_attn')
     ap.add_argument('--precision', default=os.environ.get('HOIG_PRECISION', 'bf16x3'))
     ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--no-gen-fwd', action='store_true')
+    ap.add_argument('--fwd-batch', type=int, default=32, help='batch of the generator-forward latency leg')
     ap.add_argument('--cpu-baseline-worker', type=int, default=0, help=argparse.SUPPRESS)
     args = ap.parse_args()
     if args.cpu_baseline_worker:
@@ -174,6 +230,10 @@ def main():
             'roofline': roof,
             'losses_finite': all(v == v and abs(v) != float('inf') for v in errors.values()),
         }
+        model = None
+        torch.cuda.empty_cache()
+        if world == 1 and not args.no_gen_fwd:
+            out['gen_fwd'] = gen_forward_latency(opt, args.fwd_batch, args.side)
         if world == 1 and not args.no_cpu_baseline:
             out['cpu_baseline'] = cpu_baseline(args.side)
         print(json.dumps(out))

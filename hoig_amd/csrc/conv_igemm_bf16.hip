@@ -14,6 +14,7 @@
 // Shapes outside the fast path (gathered channels not a multiple of 32) return HOIG_EUNSUPPORTED and the caller uses the
 // exact-fp32 kernels of conv_igemm.hip.
 #include "common.h"
+#include <cstdlib>
 
 namespace {
 
@@ -94,20 +95,28 @@ __device__ __forceinline__ void split4(const float4 v, uint2 &hi, uint2 &lo) {
     lo.y = cvt2(r2, r3);
 }
 
-// byte offset of (row, k) inside one [rows][32] bf16 plane, k a multiple of 4
+// LDS plane = [rows][BK] bf16; the 16-B chunk index of a row is XOR-ed with a row-dependent value so that the 16-lane
+// groups of ds_read_b128 (rows r..r+3, r+12.., r+20..) fall on 16 distinct slots of the 256-B bank row:
+//   BK = 32 (64-B rows, 4 chunks): chunk ^ ((row >> 2) & 3)      BK = 64 (128-B rows, 8 chunks): chunk ^ ((row >> 1) & 7)
+template <int BK>
+__device__ __forceinline__ int lds_swz(int row) {
+    return BK == 32 ? ((row >> 2) & 3) : ((row >> 1) & 7);
+}
+// byte offset of (row, k), k a multiple of 4
+template <int BK>
 __device__ __forceinline__ int lds_off(int row, int k) {
-    return row * 64 + ((((k >> 3) ^ ((row >> 2) & 3))) << 4) + ((k & 4) << 1);
+    return row * (BK * 2) + (((k >> 3) ^ lds_swz<BK>(row)) << 4) + ((k & 4) << 1);
 }
 
-template <int BM, int BN, int WM, int WN, int NS>
+template <int BM, int BN, int WM, int WN, int NS, int BK>
 __global__ __launch_bounds__(WM * WN * 64) void igemm_bf16_kernel(const Args p) {
     constexpr int NT = WM * WN * 64;        // 256 or 512 threads
-    constexpr int BK = 32;
     constexpr int TM = BM / (32 * WM), TN = BN / (32 * WN);
-    constexpr int RA = BM * 8 / NT;         // float4 gathers per thread
-    constexpr int RB = BN * 4 / NT;         // 16-B weight chunks per thread per plane
-    constexpr int AROWS = NT / 8, BROWS = NT / 4;
-    constexpr int PLANE_A = BM * 64, PLANE_B = BN * 64;
+    constexpr int TPR_A = BK / 4, TPR_B = BK / 8;      // threads per tile row: float4 gathers / 16-B weight chunks
+    constexpr int RA = BM * TPR_A / NT;     // float4 gathers per thread
+    constexpr int RB = BN * TPR_B / NT;     // 16-B weight chunks per thread per plane
+    constexpr int AROWS = NT / TPR_A, BROWS = NT / TPR_B;
+    constexpr int PLANE_A = BM * BK * 2, PLANE_B = BN * BK * 2;
     constexpr int STAGE = NS * (PLANE_A + PLANE_B);
     // two LDS stages: k-block t is multiplied out of one while k-block t+1 is converted into the other -> ONE barrier
     // per k-block; 64 KB at 128x128 (2 workgroups per CU)
@@ -120,7 +129,7 @@ __global__ __launch_bounds__(WM * WN * 64) void igemm_bf16_kernel(const Args p) 
     const int tile = hoig_xcd_remap(blockIdx.x, p.nblk);
     const int m0 = (tile / p.nblk_n) * BM, n0 = (tile % p.nblk_n) * BN;
 
-    const int kc = (tid & 7) * 4, lrow = tid >> 3;
+    const int kc = (tid % TPR_A) * 4, lrow = tid / TPR_A;
     int pb[RA], bh[RA], bw[RA];
 #pragma unroll
     for (int i = 0; i < RA; ++i) {
@@ -141,7 +150,7 @@ __global__ __launch_bounds__(WM * WN * 64) void igemm_bf16_kernel(const Args p) 
         int b;
         decode_m(g, m0, b, t_hp, t_wp);
     }
-    const int brow = tid >> 2, bchunk = tid & 3;
+    const int brow = tid / TPR_B, bchunk = tid % TPR_B;
 
     f32x16 acc[TM][TN];
 #pragma unroll
@@ -156,7 +165,7 @@ __global__ __launch_bounds__(WM * WN * 64) void igemm_bf16_kernel(const Args p) 
     // K is walked tap by tap ((r,s) outer, 32-channel blocks inner).  Everything that depends only on the tap -- the
     // validity and the address of each gathered pixel row -- is computed once per tap, so the per-k-block VALU work is
     // one pointer add per load plus the bf16 split (MFMA and VALU of ONE wave serialise; this keeps the matrix pipe fed).
-    const int cpb = g.Cg >> 5, RS = g.R * g.S;
+    const int cpb = g.Cg / BK, RS = g.R * g.S;
     const float *aptr[RA];
     const unsigned short *wrow_h[RB], *wrow_l[RB];
 #pragma unroll
@@ -167,11 +176,11 @@ __global__ __launch_bounds__(WM * WN * 64) void igemm_bf16_kernel(const Args p) 
     }
     int aoff[RA], boff[RB];
 #pragma unroll
-    for (int i = 0; i < RA; ++i) aoff[i] = lds_off(lrow + AROWS * i, kc);
+    for (int i = 0; i < RA; ++i) aoff[i] = lds_off<BK>(lrow + AROWS * i, kc);
 #pragma unroll
     for (int i = 0; i < RB; ++i) {
         const int row = brow + BROWS * i;
-        boff[i] = row * 64 + ((bchunk ^ ((row >> 2) & 3)) << 4);
+        boff[i] = row * (BK * 2) + ((bchunk ^ lds_swz<BK>(row)) << 4);
     }
     int rs = -1, cb = cpb - 1, wk = 0;
     auto advance = [&]() -> bool {      // move (rs, cb) to the next live k-block; false when K is exhausted
@@ -194,7 +203,7 @@ __global__ __launch_bounds__(WM * WN * 64) void igemm_bf16_kernel(const Args p) 
         return true;
     };
     auto load_tiles = [&]() {
-        const int c = cb << 5;
+        const int c = cb * BK;
 #pragma unroll
         for (int i = 0; i < RA; ++i)
             ra[i] = aptr[i] ? *reinterpret_cast<const float4 *>(aptr[i] + c) : make_float4(0.f, 0.f, 0.f, 0.f);
@@ -224,12 +233,12 @@ __global__ __launch_bounds__(WM * WN * 64) void igemm_bf16_kernel(const Args p) 
 #pragma unroll
     for (int i = 0; i < TM; ++i) {
         const int row = wm * (TM * 32) + i * 32 + l31;
-        aread[i] = row * 64 + ((lh ^ ((row >> 2) & 3)) << 4);
+        aread[i] = row * (BK * 2) + ((lh ^ lds_swz<BK>(row)) << 4);
     }
 #pragma unroll
     for (int j = 0; j < TN; ++j) {
         const int row = wn * (TN * 32) + j * 32 + l31;
-        bread[j] = row * 64 + ((lh ^ ((row >> 2) & 3)) << 4);
+        bread[j] = row * (BK * 2) + ((lh ^ lds_swz<BK>(row)) << 4);
     }
 
     bool more = advance();
@@ -245,7 +254,7 @@ __global__ __launch_bounds__(WM * WN * 64) void igemm_bf16_kernel(const Args p) 
         const unsigned char *Ah = smem + cur * STAGE, *Al = Ah + PLANE_A;
         const unsigned char *Bh = Ah + NS * PLANE_A, *Bl = Bh + PLANE_B;
 #pragma unroll
-        for (int ks = 0; ks < 2; ++ks) {
+        for (int ks = 0; ks < BK / 16; ++ks) {
             bf16x8 ah[TM], al[TM], bhf[TN], blf[TN];
 #pragma unroll
             for (int i = 0; i < TM; ++i) {
@@ -320,7 +329,7 @@ __global__ void pack_weight_kernel(const float *__restrict__ w, int Co, int RS, 
     }
 }
 
-template <int BM, int BN, int WM, int WN>
+template <int BM, int BN, int WM, int WN, int BK = 32>
 int launch(Args a, int ns, hipStream_t st) {
     constexpr int NT = WM * WN * 64;
     const int nbm = (int)hoig_cdiv(a.M, BM), nbn = (int)hoig_cdiv(a.N, BN);
@@ -331,8 +340,233 @@ int launch(Args a, int ns, hipStream_t st) {
         const long per_phase = (long)a.g.Bn * (a.g.Hp / 2) * (a.g.Wp / 2);
         a.g.tile_skip = (per_phase % BM == 0) ? 1 : 0;
     }
-    if (ns == 2) igemm_bf16_kernel<BM, BN, WM, WN, 2><<<a.nblk, NT, 0, st>>>(a);
-    else igemm_bf16_kernel<BM, BN, WM, WN, 1><<<a.nblk, NT, 0, st>>>(a);
+    if (ns == 2) igemm_bf16_kernel<BM, BN, WM, WN, 2, BK><<<a.nblk, NT, 0, st>>>(a);
+    else igemm_bf16_kernel<BM, BN, WM, WN, 1, BK><<<a.nblk, NT, 0, st>>>(a);
+    HOIG_LAUNCH_CHECK();
+    return HOIG_OK;
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// Stride-1 convolutions with an LDS-resident INPUT HALO tile.  The generic kernel above re-gathers the A tile from
+// L2 for every tap (9x for a 3x3) and is bound by the per-CU load path (~60-70 GB/s from L2), not by the matrix
+// pipe.  Here a workgroup owns 4 rows x 32 columns of output pixels (BM = 128); for each 32-channel block it stages the
+// (4+KS-1) x (32+KS-1) input halo ONCE (split to bf16 hi/lo) and all KS*KS taps read their A fragments out of that same
+// LDS image at a tap-dependent, lane-uniform row offset -- only the weight tile streams per tap (double-buffered).
+// Halo rows are 80 B apart (64 B of data + 16 B pad): any 16 consecutive rows fall on 16 distinct 16-B bank slots, so
+// ds_read_b128 stays conflict-free at every tap shift without an address-dependent swizzle.
+// Used for conv fwd (stride 1) and for the data gradient of stride-1 convs (taps walked flipped).
+struct HaloArgs {
+    const float *A;
+    const unsigned short *Wh, *Wl;
+    const float *bias;
+    float *C;
+    int Bn, H, W, Cg;       // input == output spatial size (stride 1, "same" padding), gathered channels
+    int N, K;               // output channels, KS*KS*Cg
+    int pad;                // halo origin = tile origin - pad   (dgrad: KS-1-pad)
+    int flip;               // 1: weight tap index = KS*KS-1 - (r*KS+s)   (data gradient)
+    int act;
+    float slope;
+    int nblk_n, nblk;
+    int tiles_x, tiles_y;
+};
+
+template <int KS, int NS>
+__global__ __launch_bounds__(256) void conv_halo_bf16_kernel(const HaloArgs p) {
+    constexpr int TH = 4, TW = 32, BN = 128;
+    constexpr int HH = TH + KS - 1, HW = TW + KS - 1, HPIX = HH * HW;
+    constexpr int AROW = 80;                               // bytes per halo pixel row (32 bf16 + pad)
+    constexpr int PLANE_A = HPIX * AROW, PLANE_B = BN * 64;
+    constexpr int TM = 2, TN = 2;
+    // LDS: one halo stage + two weight stages = 64 KB at KS=3 -> two workgroups per CU
+    __shared__ __attribute__((aligned(16))) unsigned char smem[NS * PLANE_A + 2 * NS * PLANE_B];
+    unsigned char *Ah = smem, *Al = smem + PLANE_A;
+    unsigned char *Bst = smem + NS * PLANE_A;              // two stages of (Bh, Bl)
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int l31 = lane & 31, lh = lane >> 5;
+    const int wm = wave >> 1, wn = wave & 1;
+    const int tile = hoig_xcd_remap(blockIdx.x, p.nblk);
+    int mt = tile / p.nblk_n;
+    const int n0 = (tile % p.nblk_n) * BN;
+    const int tx_ = mt % p.tiles_x;
+    mt /= p.tiles_x;
+    const int ty_ = mt % p.tiles_y, b = mt / p.tiles_y;
+    const int y0 = ty_ * TH, x0 = tx_ * TW;                // tile origin (output pixels)
+
+    const int brow = tid >> 2, bchunk = tid & 3;
+    const unsigned short *wrow_h[2], *wrow_l[2];
+    int boff[2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const int n = n0 + brow + 64 * i;
+        wrow_h[i] = n < p.N ? p.Wh + (size_t)n * p.K + bchunk * 8 : nullptr;
+        wrow_l[i] = (NS == 2 && n < p.N) ? p.Wl + (size_t)n * p.K + bchunk * 8 : nullptr;
+        const int row = brow + 64 * i;
+        boff[i] = row * 64 + ((bchunk ^ ((row >> 2) & 3)) << 4);
+    }
+    // fragment read offsets: wave wm owns output rows 2*wm, 2*wm+1 of the tile (32 pixels each = one MFMA row tile)
+    int aread[TM], bread[TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i) aread[i] = ((wm * TM + i) * HW + l31) * AROW + lh * 16;
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+        const int row = wn * 64 + j * 32 + l31;
+        bread[j] = row * 64 + ((lh ^ ((row >> 2) & 3)) << 4);
+    }
+
+    f32x16 acc[TM][TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    // Weight tiles are prefetched TWO steps ahead (step = one tap of one 32-channel block) into two register sets: the
+    // weights of a 512x512x3x3 layer (9.4 MB of bf16 planes) live in the Infinity Cache, whose latency under load exceeds
+    // one step's MFMA phase (768 cycles per wave).
+    uint4 rb0h[2], rb0l[2], rb1h[2], rb1l[2];
+    constexpr int KK = KS * KS;
+    const int ncb = p.Cg >> 5, T = ncb * KK;
+    auto load_b = [&](int step, uint4 (&rh)[2], uint4 (&rl)[2]) {
+        const int cb = step / KK, tap = step - cb * KK;
+        const int wtap = p.flip ? (KK - 1 - tap) : tap;
+        const int koff = wtap * p.Cg + cb * 32;
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            rh[i] = wrow_h[i] ? *reinterpret_cast<const uint4 *>(wrow_h[i] + koff) : make_uint4(0, 0, 0, 0);
+            if (NS == 2) rl[i] = wrow_l[i] ? *reinterpret_cast<const uint4 *>(wrow_l[i] + koff) : make_uint4(0, 0, 0, 0);
+        }
+    };
+    auto store_b = [&](int stage, const uint4 (&rh)[2], const uint4 (&rl)[2]) {
+        unsigned char *Bh = Bst + stage * NS * PLANE_B, *Bl = Bh + PLANE_B;
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            *reinterpret_cast<uint4 *>(Bh + boff[i]) = rh[i];
+            if (NS == 2) *reinterpret_cast<uint4 *>(Bl + boff[i]) = rl[i];
+        }
+    };
+    const float *Aimg = p.A + (size_t)b * p.H * p.W * p.Cg;
+    constexpr int HSLICES = (HPIX * 8 + 255) / 256;        // halo float4s per thread
+    float4 hreg[HSLICES];
+    auto halo_load = [&](int cb) {
+#pragma unroll
+        for (int sl = 0; sl < HSLICES; ++sl) {
+            const int i = tid + 256 * sl;
+            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (i < HPIX * 8) {
+                const int pix = i >> 3, c4 = i & 7;
+                const int hy = pix / HW, hx = pix - hy * HW;
+                const int gy = y0 - p.pad + hy, gx = x0 - p.pad + hx;
+                if (gy >= 0 && gy < p.H && gx >= 0 && gx < p.W)
+                    v = *reinterpret_cast<const float4 *>(Aimg + ((size_t)gy * p.W + gx) * p.Cg + cb * 32 + c4 * 4);
+            }
+            hreg[sl] = v;
+        }
+    };
+    auto halo_store = [&]() {
+#pragma unroll
+        for (int sl = 0; sl < HSLICES; ++sl) {
+            const int i = tid + 256 * sl;
+            if (i < HPIX * 8) {
+                const int pix = i >> 3, c4 = i & 7;
+                uint2 hi, lo;
+                split4(hreg[sl], hi, lo);
+                *reinterpret_cast<uint2 *>(Ah + pix * AROW + c4 * 8) = hi;
+                if (NS == 2) *reinterpret_cast<uint2 *>(Al + pix * AROW + c4 * 8) = lo;
+            }
+        }
+    };
+    auto compute = [&](int stage, int step) {
+        const int tap = step % KK;
+        const int r = tap / KS, s_ = tap - r * KS;
+        const int tapoff = (r * HW + s_) * AROW;
+        const unsigned char *Bh = Bst + stage * NS * PLANE_B, *Bl = Bh + PLANE_B;
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+            bf16x8 ah[TM], al[TM], bhf[TN], blf[TN];
+#pragma unroll
+            for (int i = 0; i < TM; ++i) {
+                const int off = aread[i] + tapoff + ks * 32;
+                ah[i] = *reinterpret_cast<const bf16x8 *>(Ah + off);
+                if (NS == 2) al[i] = *reinterpret_cast<const bf16x8 *>(Al + off);
+            }
+#pragma unroll
+            for (int j = 0; j < TN; ++j) {
+                const int off = bread[j] ^ (ks << 5);
+                bhf[j] = *reinterpret_cast<const bf16x8 *>(Bh + off);
+                if (NS == 2) blf[j] = *reinterpret_cast<const bf16x8 *>(Bl + off);
+            }
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int j = 0; j < TN; ++j) {
+                    if (NS == 2) {
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[i], bhf[j], acc[i][j], 0, 0, 0);
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[i], blf[j], acc[i][j], 0, 0, 0);
+                    }
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[i], bhf[j], acc[i][j], 0, 0, 0);
+                }
+        }
+    };
+    // one step: prefetch weights of step+2, multiply `stage`, then publish the weights of step+1 (and, at a channel-block
+    // boundary, the next halo, whose loads were issued before the multiply) behind one barrier
+    auto do_step = [&](int step, int stage, uint4 (&nh)[2], uint4 (&nl)[2], uint4 (&fh)[2], uint4 (&fl)[2]) {
+        if (step + 2 < T) load_b(step + 2, fh, fl);
+        const bool boundary = (step % KK == KK - 1) && (step + 1 < T);
+        if (boundary) halo_load(step / KK + 1);
+        compute(stage, step);
+        if (step + 1 < T) {
+            if (boundary) {
+                __syncthreads();                  // every wave has finished reading the current halo
+                halo_store();
+            }
+            store_b(stage ^ 1, nh, nl);
+            __syncthreads();
+        }
+    };
+
+    halo_load(0);
+    load_b(0, rb0h, rb0l);
+    halo_store();
+    store_b(0, rb0h, rb0l);
+    if (T > 1) load_b(1, rb0h, rb0l);
+    __syncthreads();
+#pragma unroll 1
+    for (int step = 0; step < T; step += 2) {
+        do_step(step, 0, rb0h, rb0l, rb1h, rb1l);
+        if (step + 1 < T) do_step(step + 1, 1, rb1h, rb1l, rb0h, rb0l);
+    }
+
+    // epilogue: MFMA row (reg) -> pixel inside the wave's 32-pixel image row; col = lane&31 -> channel
+#pragma unroll
+    for (int i = 0; i < TM; ++i) {
+        const int oy = y0 + wm * TM + i;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int ox = x0 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+            const size_t pix = ((size_t)b * p.H + oy) * p.W + ox;
+#pragma unroll
+            for (int j = 0; j < TN; ++j) {
+                const int n = n0 + wn * 64 + j * 32 + l31;
+                if (n < p.N) {
+                    float v = acc[i][j][r];
+                    if (p.bias) v += p.bias[n];
+                    p.C[pix * p.N + n] = hoig_act(v, p.act, p.slope);
+                }
+            }
+        }
+    }
+}
+
+template <int KS>
+int launch_halo(HaloArgs a, int ns, hipStream_t st) {
+    a.tiles_x = a.W / 32;
+    a.tiles_y = a.H / 4;
+    a.nblk_n = (int)hoig_cdiv(a.N, 128);
+    a.nblk = a.Bn * a.tiles_x * a.tiles_y * a.nblk_n;
+    if (ns == 2) conv_halo_bf16_kernel<KS, 2><<<a.nblk, 256, 0, st>>>(a);
+    else conv_halo_bf16_kernel<KS, 1><<<a.nblk, 256, 0, st>>>(a);
     HOIG_LAUNCH_CHECK();
     return HOIG_OK;
 }
@@ -362,6 +596,19 @@ int run(const hoig_conv_desc *d, const float *a, const unsigned short *wh, const
     if (ns == 2 && !wl) return HOIG_EINVAL;
     const long t128 = hoig_cdiv(p.M, 128);
     if (p.N <= 32) return HOIG_EUNSUPPORTED;
+    // stride-1 "same" convolutions (and their data gradients): LDS-resident input halo, weights streamed per tap
+    if (!d->transposed && d->stride == 1 && d->R == d->S && 2 * d->pad == d->R - 1 && (d->R == 1 || d->R == 3 || d->R == 5) &&
+        d->Wi % 32 == 0 && d->Hi % 4 == 0 && p.N % 128 == 0 && getenv("HOIG_NO_HALO") == nullptr) {
+        HaloArgs h;
+        h.A = a; h.Wh = wh; h.Wl = wl; h.bias = bias; h.C = c;
+        h.Bn = d->B; h.H = d->Hi; h.W = d->Wi; h.Cg = g.Cg; h.N = p.N; h.K = p.K;
+        h.pad = d->pad;                      // dgrad: KS-1-pad == pad for "same" convolutions
+        h.flip = dgrad ? 1 : 0;
+        h.act = p.act; h.slope = p.slope;
+        if (d->R == 1) return launch_halo<1>(h, ns, st);
+        if (d->R == 3) return launch_halo<3>(h, ns, st);
+        return launch_halo<5>(h, ns, st);
+    }
     if (p.N <= 64) {
         if (t128 >= 512) return launch<128, 64, 2, 2>(p, ns, st);
         return launch<64, 64, 2, 2>(p, ns, st);
@@ -369,6 +616,10 @@ int run(const hoig_conv_desc *d, const float *a, const unsigned short *wh, const
     const long n128 = hoig_cdiv(p.N, 128);
     // fewer than two 128x128 workgroups per CU: run 8 waves per workgroup so every SIMD still holds two waves and one
     // wave's bf16 split (VALU) overlaps the other's MFMAs
+    // BK = 64 (128 KB of LDS, one 8-wave workgroup per CU): a k-block's MFMA phase (>= 768 cycles per wave) then covers
+    // the L2/MALL latency of the next k-block's loads; BK = 32 keeps two 4-wave workgroups per CU for channel counts that
+    // are not multiples of 64
+    if (t128 * n128 >= 128 && g.Cg % 64 == 0 && getenv("HOIG_BK64") != nullptr) return launch<128, 128, 2, 4, 64>(p, ns, st);
     if (t128 * n128 >= 512) return launch<128, 128, 2, 2>(p, ns, st);
     if (t128 * n128 >= 128) return launch<128, 128, 2, 4>(p, ns, st);
     return launch<64, 128, 2, 2>(p, ns, st);
