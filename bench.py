@@ -43,11 +43,20 @@ def dominant_kernel_roofline(batch, side, precision, iters=20):
     torch.cuda.synchronize()
     ms = s.elapsed_time(e) / iters
     flops = 2.0 * batch * h * h * 512 * 512 * 9            # algorithmic: 2*M*N*K, M=B*h*h, N=512, K=9*512
+    # HBM/fabric traffic of this kernel comes from separate rocprofv3 --pmc passes (FETCH_SIZE and WRITE_SIZE cannot
+    # share a pass); the committed summary is attached when it was taken on the same kernel and shape
+    traffic = None
+    try:
+        pmc = json.load(open(os.path.join(ROOT, 'profiles', 'r01_pmc_dominant_conv.json')))
+        if precision == 'bf16x3' and batch == 8 and side == 256:
+            traffic = pmc['traffic_bytes_per_launch']
+    except Exception:
+        pass
     achieved = flops / (ms * 1e-3) / 1e12
     kname = 'igemm_f32_kernel' if precision == 'f32' else 'conv_halo_bf16_kernel<3,%d>' % (2 if precision == 'bf16x3' else 1)
     return dict(bound='mfma', kernel='%s (conv3x3 s1 512->512 @%dx%d, B=%d)' % (kname, h, h, batch),
                 achieved=round(achieved, 2), peak=PEAK[precision], unit='TFLOP/s',
-                frac=round(achieved / PEAK[precision], 4), traffic=None, avg_launch_ms=round(ms, 4),
+                frac=round(achieved / PEAK[precision], 4), traffic=traffic, avg_launch_ms=round(ms, 4),
                 algorithmic_flop_per_launch=flops)
 
 
