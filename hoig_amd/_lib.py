@@ -58,8 +58,12 @@ _SIGS = {
     'hoig_inorm_stats': [_vp, _i, _i, _i, _f, _vp, _vp, _vp, _vp],
     'hoig_inorm_apply': [_vp, _vp, _vp, _i, _vp, _vp, _i, _f, _vp, _vp, _i, _i, _i, _vp],
     'hoig_inorm_bwd': [_vp, _vp, _vp, _i, _vp, _vp, _vp, _i, _f, _vp, _vp, _vp, _i, _i, _i, _vp, _vp],
-    'hoig_local_attn_fwd': [_vp] * 10 + [_i] * 5 + [_vp],
-    'hoig_local_attn_bwd': [_vp] * 15 + [_i] * 5 + [_vp],
+    'hoig_replicate_pad_fwd': [_vp, _vp, _i, _i, _i, _i, _i, _vp],
+    'hoig_replicate_pad_bwd': [_vp, _vp, _i, _i, _i, _i, _i, _vp],
+    'hoig_attn_sample_fwd': [_vp, _vp, _vp, _i, _i, _i, _i, _vp],
+    'hoig_attn_sample_bwd': [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp],
+    'hoig_attn_pixel_fwd': [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _vp],
+    'hoig_attn_pixel_bwd': [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _vp],
     'hoig_block_extractor_forward': [_vp, _vp, _vp] + [_i] * 7 + [_vp],
     'hoig_block_extractor_backward': [_vp] * 5 + [_i] * 7 + [_vp],
     'hoig_local_attn_reshape_forward': [_vp, _vp] + [_i] * 4 + [_vp],

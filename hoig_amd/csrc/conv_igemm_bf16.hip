@@ -36,6 +36,7 @@ struct Args {
     int act;
     float slope;
     int nblk_n, nblk;
+    int ksplit, steps_per_split;   // split-K over blockIdx.y (atomic epilogue into a zeroed output)
 };
 
 __device__ __forceinline__ void decode_m(const Geom &g, int m, int &b, int &hp, int &wp) {
@@ -182,10 +183,16 @@ __global__ __launch_bounds__(WM * WN * 64) void igemm_bf16_kernel(const Args p) 
         const int row = brow + BROWS * i;
         boff[i] = row * (BK * 2) + ((bchunk ^ lds_swz<BK>(row)) << 4);
     }
-    int rs = -1, cb = cpb - 1, wk = 0;
+    // split-K: this workgroup multiplies k-blocks [begin, begin + steps_per_split) of the (tap, channel-block) walk
+    const int begin = p.ksplit > 1 ? (int)blockIdx.y * p.steps_per_split : 0;
+    int steps_left = p.ksplit > 1 ? min(p.steps_per_split, RS * cpb - begin) : 0x7fffffff;
+    int rs = begin / cpb - 1, cb = cpb - 1, wk = 0;
+    int cb_next_tap = begin - (begin / cpb) * cpb;      // channel block to start the first tap at
     auto advance = [&]() -> bool {      // move (rs, cb) to the next live k-block; false when K is exhausted
+        if (steps_left-- <= 0) return false;
         if (++cb < cpb) return true;
-        cb = 0;
+        cb = cb_next_tap;
+        cb_next_tap = 0;
         do {
             ++rs;
         } while (rs < RS && g.tile_skip && !tap_alive(g, t_hp, t_wp, rs));
@@ -302,8 +309,13 @@ __global__ __launch_bounds__(WM * WN * 64) void igemm_bf16_kernel(const Args p) 
                 const int n = n0 + wn * (TN * 32) + j * 32 + l31;
                 if (n < p.N) {
                     float v = acc[i][j][r];
-                    if (p.bias) v += p.bias[n];
-                    p.C[pix * p.N + n] = hoig_act(v, p.act, p.slope);
+                    if (p.ksplit > 1) {
+                        if (p.bias && blockIdx.y == 0) v += p.bias[n];
+                        atomicAdd(&p.C[pix * p.N + n], v);
+                    } else {
+                        if (p.bias) v += p.bias[n];
+                        p.C[pix * p.N + n] = hoig_act(v, p.act, p.slope);
+                    }
                 }
             }
         }
@@ -340,8 +352,22 @@ int launch(Args a, int ns, hipStream_t st) {
         const long per_phase = (long)a.g.Bn * (a.g.Hp / 2) * (a.g.Wp / 2);
         a.g.tile_skip = (per_phase % BM == 0) ? 1 : 0;
     }
-    if (ns == 2) igemm_bf16_kernel<BM, BN, WM, WN, 2, BK><<<a.nblk, NT, 0, st>>>(a);
-    else igemm_bf16_kernel<BM, BN, WM, WN, 1, BK><<<a.nblk, NT, 0, st>>>(a);
+    // few output tiles but a long K (the attention MLP: 128 outputs, K = 25*C): split K over blockIdx.y
+    a.ksplit = 1;
+    a.steps_per_split = 0;
+    const int steps = (a.K / BK);
+    if (a.nblk < 192 && steps >= 32 && a.act == HOIG_ACT_NONE && !a.g.tile_skip) {
+        int want = (int)hoig_cdiv(512, a.nblk);
+        if (want > steps / 8) want = steps / 8;
+        if (want > 1) {
+            a.steps_per_split = (int)hoig_cdiv(steps, want);
+            a.ksplit = (int)hoig_cdiv(steps, a.steps_per_split);
+            if (hipMemsetAsync(a.C, 0, (size_t)a.M * a.N * sizeof(float), st) != hipSuccess) return HOIG_ELAUNCH;
+        }
+    }
+    dim3 grid(a.nblk, a.ksplit);
+    if (ns == 2) igemm_bf16_kernel<BM, BN, WM, WN, 2, BK><<<grid, NT, 0, st>>>(a);
+    else igemm_bf16_kernel<BM, BN, WM, WN, 1, BK><<<grid, NT, 0, st>>>(a);
     HOIG_LAUNCH_CHECK();
     return HOIG_OK;
 }

@@ -33,7 +33,8 @@ class Generator(ParamTree):
         self.cfg = GeneratorConfig(gen_name, bg_dim, img_dim, obj_dim, img_cond_dim, obj_cond_dim, conv_dim, repeat_num)
         sch = generator_schema(self.cfg)
         device = device if device is not None else torch.device('cuda', torch.cuda.current_device())
-        super().__init__(sch.shapes, device, sch.transposed)
+        split = ['attn_%d.fully_connect_layer.0.weight' % l for l in self.cfg.attn_layers]
+        super().__init__(sch.shapes, device, sch.transposed, split)
         self._name = 'generator'
         self._seg_cache = {}
 
@@ -144,8 +145,8 @@ class Generator(ParamTree):
             if key not in self._seg_cache:
                 self._seg_cache[key] = ops.attn_flow(ts)
             p = 'attn_%d.fully_connect_layer' % layer
-            return ops.local_attention(x, y, self._seg_cache[key], self.P[p + '.0.weight'], self.P[p + '.0.bias'],
-                                       self.P[p + '.2.weight'], self.P[p + '.2.bias'])
+            return ops.local_attention(x, y, self._seg_cache[key], self.P[p + '.0.weight#t'], self.P[p + '.0.weight#s'],
+                                       self.P[p + '.0.bias'], self.P[p + '.2.weight'], self.P[p + '.2.bias'])
         return ops.grid_sample(x, ts)
 
     # ---- public forward: reference signature (generator.py:347-376), NCHW in / NCHW-shaped out ---

@@ -8,10 +8,14 @@ gradients / Adam moments in three more), so that
   * the data-parallel gradient exchange is a handful of large contiguous RCCL
     all-reduces (hoig_amd/ddp.py) instead of DDP's 25 MB buckets,
   * wgrad kernels accumulate straight into the gradient buffer.
-Each parameter is an ``nn.Parameter`` VIEW of the flat buffer that keeps the
-reference's logical name and shape so ``state_dict()`` /
-``load_state_dict()`` interoperate with reference checkpoints
-(models/base_model.py:78-124); conv weights are stored packed [Co][R][S][Ci].
+Each parameter is an ``nn.Parameter`` VIEW of the flat buffer; ``state_dict()`` /
+``load_state_dict()`` present the reference's names and logical NCHW shapes
+ so checkpoints interoperate (models/base_model.py:78-124).
+Storage layouts differ from the reference where the kernels want it:
+  * conv weights are packed [Co][R][S][Ci] (ConvTranspose2d too);
+  * the first attention conv (128, 2C, 5, 5) (extract_attn.py:18) is stored as TWO packed weights, the target half
+    ``<name>#t`` = (128, C, 5, 5) and the source half ``<name>#s`` = (128, 25*C, 1, 1) with k = tap*C + c, because the
+    path runs them as a 5x5 convolution of the padded target and a 1x1 convolution over the sampled source.
 """
 from collections import OrderedDict
 
@@ -29,36 +33,53 @@ def _numel(shape):
     return n
 
 
+def split_attn_weight(w):
+    """reference (128, 2C, 5, 5) -> target half (128, C, 5, 5), source half (128, 25*C, 1, 1) [k = tap*C + c]."""
+    n, c2, r, s = w.shape
+    c = c2 // 2
+    wt = w[:, :c]
+    ws = w[:, c:].reshape(n, c, r * s).permute(0, 2, 1).reshape(n, r * s * c, 1, 1)
+    return wt, ws
+
+
+def merge_attn_weight(wt, ws):
+    n, c, r, s = wt.shape
+    src = ws.reshape(n, r * s, c).permute(0, 2, 1).reshape(n, c, r, s)
+    return torch.cat([wt, src], dim=1)
+
+
 class ParamTree(nn.Module):
     """A module tree generated from dotted parameter names; parameters are views of flat buffers."""
 
-    def __init__(self, shapes, device, transposed_names=()):
+    def __init__(self, shapes, device, transposed_names=(), split_names=()):
         super().__init__()
-        self._shapes = OrderedDict(shapes)
+        self._ref_shapes = OrderedDict(shapes)            # reference names -> reference shapes
+        self._split = set(split_names)
+        tset = set(transposed_names)
+        internal = OrderedDict()                           # internal name -> (shape, transposed)
+        for name, shp in self._ref_shapes.items():
+            if name in self._split:
+                n, c2, r, s = shp
+                internal[name + '#t'] = ((n, c2 // 2, r, s), False)
+                internal[name + '#s'] = ((n, r * s * (c2 // 2), 1, 1), False)
+            else:
+                internal[name] = (tuple(shp), name in tset)
+        self._internal = internal
         total = 0
-        offsets = OrderedDict()
-        for name, shp in self._shapes.items():
-            offsets[name] = total
-            total += (_numel(shp) + 3) // 4 * 4          # keep every parameter 16-byte aligned
+        self._offsets = OrderedDict()
+        for name, (shp, _) in internal.items():
+            self._offsets[name] = total
+            total += (_numel(shp) + 3) // 4 * 4           # keep every parameter 16-byte aligned
         self.flat = torch.zeros(total, dtype=torch.float32, device=device)
         self.flat_grad = torch.zeros(total, dtype=torch.float32, device=device)
+        self.version = 0          # bumped whenever the weights change (packed bf16 planes are cached per version)
         self.P = OrderedDict()
-        self.version = 0                 # bumped whenever the weights change (packed bf16 planes are cached per version)
-        self._offsets = offsets
-        tset = set(transposed_names)
-        for name, shp in self._shapes.items():
-            off, n = offsets[name], _numel(shp)
-            if len(shp) == 4:
-                st = packed_strides(shp, name in tset)
-                view = self.flat.as_strided(shp, st, off)
-                gview = self.flat_grad.as_strided(shp, st, off)
-            else:
-                view = self.flat[off:off + n].view(shp)
-                gview = self.flat_grad[off:off + n].view(shp)
+        gviews = self.views_of(self.flat_grad)
+        for name, view in self.views_of(self.flat).items():
             p = nn.Parameter(view, requires_grad=True)
-            p.grad = gview
+            p.grad = gviews[name]
             p._hoig_flat = True
-            p._hoig_transposed = name in tset
+            p._hoig_transposed = internal[name][1]
             p._hoig_owner = self
             self.P[name] = p
             self._register(name, p)
@@ -70,30 +91,62 @@ class ParamTree(nn.Module):
             if not hasattr(mod, part) or not isinstance(getattr(mod, part), nn.Module):
                 mod.add_module(part, nn.Module())
             mod = getattr(mod, part)
-        mod.register_parameter(parts[-1], p)
+        mod.register_parameter(parts[-1].replace('#', '_'), p)
 
-    # --- reference-compatible (de)serialisation: contiguous NCHW tensors under the reference names
-    def state_dict(self, *args, **kwargs):
+    def views_of(self, flat):
+        """internal name -> strided view of `flat` (same layout as the parameters)."""
         out = OrderedDict()
-        prefix = kwargs.get('prefix', '')
-        for name, p in self.P.items():
-            out[prefix + name] = p.detach().clone(memory_format=torch.contiguous_format)
+        for name, (shp, transposed) in self._internal.items():
+            off, n = self._offsets[name], _numel(shp)
+            if len(shp) == 4:
+                out[name] = flat.as_strided(shp, packed_strides(shp, transposed), off)
+            else:
+                out[name] = flat[off:off + n].view(shp)
         return out
 
-    def load_state_dict(self, sd, strict=True):
-        missing = [k for k in self.P if k not in sd]
-        unexpected = [k for k in sd if k not in self.P]
+    # --- reference-compatible (de)serialisation of any flat buffer (weights, Adam moments)
+    def export_dict(self, flat, prefix=''):
+        v = self.views_of(flat)
+        out = OrderedDict()
+        for name in self._ref_shapes:
+            if name in self._split:
+                t = merge_attn_weight(v[name + '#t'].detach(), v[name + '#s'].detach())
+            else:
+                t = v[name].detach()
+            out[prefix + name] = t.clone(memory_format=torch.contiguous_format)
+        return out
+
+    def import_dict(self, flat, sd, strict=True):
+        missing = [k for k in self._ref_shapes if k not in sd]
+        unexpected = [k for k in sd if k not in self._ref_shapes]
         if strict and (missing or unexpected):
             raise RuntimeError('load_state_dict: missing %s unexpected %s' % (missing[:5], unexpected[:5]))
+        v = self.views_of(flat)
         with torch.no_grad():
-            for name, p in self.P.items():
-                if name in sd:
-                    src = sd[name]
-                    if tuple(src.shape) != tuple(p.shape):
-                        raise RuntimeError('size mismatch for %s: %s vs %s' % (name, tuple(src.shape), tuple(p.shape)))
-                    p.copy_(src.to(device=p.device, dtype=p.dtype))
+            for name, shp in self._ref_shapes.items():
+                if name not in sd:
+                    continue
+                src = sd[name]
+                if tuple(src.shape) != tuple(shp):
+                    raise RuntimeError('size mismatch for %s: %s vs %s' % (name, tuple(src.shape), tuple(shp)))
+                src = src.to(device=flat.device, dtype=flat.dtype)
+                if name in self._split:
+                    wt, ws = split_attn_weight(src)
+                    v[name + '#t'].copy_(wt)
+                    v[name + '#s'].copy_(ws)
+                else:
+                    v[name].copy_(src)
+
+    def state_dict(self, *args, **kwargs):
+        return self.export_dict(self.flat, kwargs.get('prefix', ''))
+
+    def load_state_dict(self, sd, strict=True):
+        self.import_dict(self.flat, sd, strict)
         self.version += 1
         return self
+
+    def ref_names(self):
+        return list(self._ref_shapes.keys())
 
     def parameters(self, recurse=True):
         return iter(self.P.values())
@@ -115,29 +168,29 @@ class ParamTree(nn.Module):
     def init_weights(self, generator=None):
         """NetworkBase.init_weights (base_network.py:14-25): every Conv* weight ~ N(0, 0.02), conv bias 0;
         InstanceNorm affine parameters stay (1, 0)."""
-        with torch.no_grad():
-            for name, p in self.P.items():
-                if p.dim() == 4:
-                    tmp = torch.empty(tuple(p.shape), dtype=torch.float32)
-                    tmp.normal_(0.0, 0.02, generator=generator)
-                    p.copy_(tmp)
-                elif name.endswith('.bias'):
-                    p.zero_()
-                else:
-                    p.fill_(1.0)
-        self.version += 1
-        return self
+        sd = OrderedDict()
+        for name, shp in self._ref_shapes.items():
+            if len(shp) == 4:
+                t = torch.empty(tuple(shp), dtype=torch.float32)
+                t.normal_(0.0, 0.02, generator=generator)
+            elif name.endswith('.bias'):
+                t = torch.zeros(tuple(shp))
+            else:
+                t = torch.ones(tuple(shp))
+            sd[name] = t
+        return self.load_state_dict(sd)
 
 
 class FusedAdam(object):
     """torch.optim.Adam semantics (lr, betas, eps=1e-8, no weight decay / amsgrad: trainer.py:275-278) as ONE
     kernel over the network's flat buffers.  ``state_dict()`` / ``load_state_dict()`` use torch.optim.Adam's
-    per-parameter layout so optimiser checkpoints interoperate (base_model.py:78-90)."""
+    per-parameter layout over the REFERENCE parameter list so optimiser checkpoints interoperate
+    (base_model.py:78-90)."""
 
     def __init__(self, tree, lr, betas=(0.9, 0.999), eps=1e-8):
         self.tree = tree
         self.param_groups = [dict(lr=lr, betas=tuple(betas), eps=eps, weight_decay=0, amsgrad=False,
-                                  params=list(range(len(tree.P))))]
+                                  params=list(range(len(tree.ref_names()))))]
         self.exp_avg = torch.zeros_like(tree.flat)
         self.exp_avg_sq = torch.zeros_like(tree.flat)
         self.step_count = 0
@@ -153,40 +206,29 @@ class FusedAdam(object):
                grad_scale, _st())
         self.tree.version += 1
 
-    def _views(self, flat):
-        out = []
-        for name, shp in self.tree._shapes.items():
-            off, n = self.tree._offsets[name], _numel(shp)
-            p = self.tree.P[name]
-            if len(shp) == 4:
-                out.append(flat.as_strided(shp, p.stride(), off))
-            else:
-                out.append(flat[off:off + n].view(shp))
-        return out
-
     def state_dict(self):
         state = {}
         if self.step_count > 0:
-            for i, (m, v) in enumerate(zip(self._views(self.exp_avg), self._views(self.exp_avg_sq))):
-                state[i] = dict(step=torch.tensor(float(self.step_count)),
-                                exp_avg=m.detach().clone(memory_format=torch.contiguous_format),
-                                exp_avg_sq=v.detach().clone(memory_format=torch.contiguous_format))
+            ms = self.tree.export_dict(self.exp_avg)
+            vs = self.tree.export_dict(self.exp_avg_sq)
+            for i, name in enumerate(self.tree.ref_names()):
+                state[i] = dict(step=torch.tensor(float(self.step_count)), exp_avg=ms[name], exp_avg_sq=vs[name])
         groups = [dict((k, v) for k, v in g.items()) for g in self.param_groups]
         return dict(state=state, param_groups=groups)
 
     def load_state_dict(self, sd):
         st = sd['state']
-        with torch.no_grad():
-            ms, vs = self._views(self.exp_avg), self._views(self.exp_avg_sq)
-            steps = set()
-            for i, (m, v) in enumerate(zip(ms, vs)):
-                if i in st:
-                    m.copy_(st[i]['exp_avg'].to(m.device))
-                    v.copy_(st[i]['exp_avg_sq'].to(v.device))
-                    s = st[i]['step']
-                    steps.add(int(s.item()) if torch.is_tensor(s) else int(s))
-            if len(steps) > 1:
-                raise RuntimeError('FusedAdam: per-parameter step counts differ: %s' % sorted(steps))
-            self.step_count = steps.pop() if steps else 0
+        names = self.tree.ref_names()
+        ms, vs, steps = {}, {}, set()
+        for i, name in enumerate(names):
+            if i in st:
+                ms[name], vs[name] = st[i]['exp_avg'], st[i]['exp_avg_sq']
+                s = st[i]['step']
+                steps.add(int(s.item()) if torch.is_tensor(s) else int(s))
+        if len(steps) > 1:
+            raise RuntimeError('FusedAdam: per-parameter step counts differ: %s' % sorted(steps))
+        self.tree.import_dict(self.exp_avg, ms, strict=False)
+        self.tree.import_dict(self.exp_avg_sq, vs, strict=False)
+        self.step_count = steps.pop() if steps else 0
         g = sd['param_groups'][0]
         self.param_groups[0].update(lr=g['lr'], betas=tuple(g['betas']), eps=g['eps'])

@@ -119,15 +119,7 @@ class _Conv(Function):
         Ho, Wo = out_hw
         y = torch.empty((B, Ho, Wo, Co), dtype=x.dtype, device=x.device)
         d = ConvDesc(B, Hi, Wi, Ci, Ho, Wo, Co, R, S, stride, pad, 1 if transposed else 0, act, slope, prec)
-        done = False
-        if prec != L.PREC_F32 and Ci % 32 == 0 and Co > 32:
-            hi, lo = _packed_planes(w, transposed, False)
-            rc = L.lib.hoig_conv2d_fwd_packed(ctypes.byref(d), _p(x), _p(hi), _p(lo), _p(b), _p(y), _st())
-            if rc != L.EUNSUPPORTED:
-                L.check(rc, 'hoig_conv2d_fwd_packed')
-                done = True
-        if not done:
-            call('hoig_conv2d_fwd', ctypes.byref(d), _p(x), _p(w), _p(b), _p(y), _st())
+        _conv_fwd_raw(d, x, w, b, y, transposed)
         ctx.d = d
         ctx.transposed = transposed
         ctx.has_bias = b is not None
@@ -156,15 +148,7 @@ class _Conv(Function):
         dx = None
         if ctx.needs_input_grad[0]:
             dx = torch.empty_like(x)
-            done = False
-            if d.precision != L.PREC_F32 and d.Co % 32 == 0 and d.Ci > 32:
-                hi, lo = _packed_planes(w, ctx.transposed, True)
-                rc = L.lib.hoig_conv2d_bwd_data_packed(ctypes.byref(d), _p(g), _p(hi), _p(lo), _p(dx), _st())
-                if rc != L.EUNSUPPORTED:
-                    L.check(rc, 'hoig_conv2d_bwd_data_packed')
-                    done = True
-            if not done:
-                call('hoig_conv2d_bwd_data', ctypes.byref(d), _p(g), _p(w), _p(dx), _st())
+            _conv_dgrad_raw(d, g, w, dx, ctx.transposed)
         return dx, dw_ret, db_ret, None, None, None, None, None, None, None
 
 
@@ -387,40 +371,91 @@ def grid_sample(x, grid):
     return _GridSample.apply(x, grid.contiguous())
 
 
+def _conv_fwd_raw(d, x, w, b, y, transposed=False):
+    """y = conv(x, w) (+bias, activation) on the kernel the precision mode selects."""
+    if d.precision != L.PREC_F32 and d.Ci % 32 == 0 and d.Co > 32:
+        hi, lo = _packed_planes(w, transposed, False)
+        rc = L.lib.hoig_conv2d_fwd_packed(ctypes.byref(d), _p(x), _p(hi), _p(lo), _p(b), _p(y), _st())
+        if rc != L.EUNSUPPORTED:
+            L.check(rc, 'hoig_conv2d_fwd_packed')
+            return
+    call('hoig_conv2d_fwd', ctypes.byref(d), _p(x), _p(w), _p(b), _p(y), _st())
+
+
+def _conv_dgrad_raw(d, g, w, dx, transposed=False):
+    if d.precision != L.PREC_F32 and d.Co % 32 == 0 and d.Ci > 32:
+        hi, lo = _packed_planes(w, transposed, True)
+        rc = L.lib.hoig_conv2d_bwd_data_packed(ctypes.byref(d), _p(g), _p(hi), _p(lo), _p(dx), _st())
+        if rc != L.EUNSUPPORTED:
+            L.check(rc, 'hoig_conv2d_bwd_data_packed')
+            return
+    call('hoig_conv2d_bwd_data', ctypes.byref(d), _p(g), _p(w), _p(dx), _st())
+
+
 class _LocalAttn(Function):
+    """ExtractorAttn.forward (extract_attn.py:23-29) as: replicate-pad(target) -> conv5x5 ; K1-sample(source) -> conv1x1 ;
+    + bias ; LeakyReLU ; conv1x1 128->25 ; softmax ; (1/25) sum_q a_q S_q.  `wt` (128,C,5,5) and `ws` (128,25C,1,1) are
+    the two halves of the reference's (128,2C,5,5) weight (hoig_amd.nn.split_attn_weight)."""
+
     @staticmethod
-    def forward(ctx, source, target, flow, w1, b1, w2, b2, prec):
-        for t in (source, target, flow, w1, b1, w2, b2):
+    def forward(ctx, source, target, flow, wt, ws, b1, w2, b2, prec):
+        for t in (source, target, flow, wt, ws, b1, w2, b2):
             _chk(t)
         B, H, W, C = source.shape
-        assert tuple(w1.shape) == (128, 2 * C, 5, 5) and tuple(w1.stride()) == packed_strides(w1.shape, False)
+        assert tuple(wt.shape) == (128, C, 5, 5) and tuple(wt.stride()) == packed_strides(wt.shape, False)
+        assert tuple(ws.shape) == (128, 25 * C, 1, 1) and tuple(ws.stride()) == packed_strides(ws.shape, False)
         M = B * H * W
-        hidden = torch.empty((M, 128), dtype=source.dtype, device=source.device)
-        attn = torch.empty((M, 25), dtype=source.dtype, device=source.device)
+        dev, dt = source.device, source.dtype
+        tpad = torch.empty((B, H + 4, W + 4, C), dtype=dt, device=dev)
+        call('hoig_replicate_pad_fwd', _p(target), _p(tpad), B, H, W, C, 2, _st())
+        S = torch.empty((B, H, W, 25 * C), dtype=dt, device=dev)
+        call('hoig_attn_sample_fwd', _p(source), _p(flow), _p(S), B, H, W, C, _st())
+        d_t = ConvDesc(B, H + 4, W + 4, C, H, W, 128, 5, 5, 1, 0, 0, L.ACT_NONE, 0.0, prec)
+        d_s = ConvDesc(B, H, W, 25 * C, H, W, 128, 1, 1, 1, 0, 0, L.ACT_NONE, 0.0, prec)
+        h1 = torch.empty((M, 128), dtype=dt, device=dev)
+        h2 = torch.empty_like(h1)
+        _conv_fwd_raw(d_t, tpad, wt, b1, h1)
+        _conv_fwd_raw(d_s, S, ws, None, h2)
+        hidden = torch.empty_like(h1)
+        call('hoig_add', _p(h1), _p(h2), _p(hidden), hidden.numel(), _st())
+        attn = torch.empty((M, 25), dtype=dt, device=dev)
         out = torch.empty_like(source)
-        call('hoig_local_attn_fwd', _p(source), _p(target), _p(flow), _p(w1), _p(b1), _p(w2), _p(b2), _p(hidden),
-             _p(attn), _p(out), B, H, W, C, prec, _st())
-        ctx.save_for_backward(source, target, flow, w1, b1, w2, b2, hidden, attn)
-        ctx.prec = prec
+        call('hoig_attn_pixel_fwd', _p(hidden), _p(w2), _p(b2), _p(S), _p(attn), _p(out), M, C, _st())
+        ctx.save_for_backward(flow, wt, ws, b1, w2, b2, tpad, S, hidden, attn)
+        ctx.descs = (d_t, d_s)
+        ctx.shape = (B, H, W, C)
         return out
 
     @staticmethod
     def backward(ctx, dout):
-        source, target, flow, w1, b1, w2, b2, hidden, attn = ctx.saved_tensors
-        B, H, W, C = source.shape
-        dsrc = torch.zeros_like(source)
-        dtgt = torch.zeros_like(target)
+        flow, wt, ws, b1, w2, b2, tpad, S, hidden, attn = ctx.saved_tensors
+        d_t, d_s = ctx.descs
+        B, H, W, C = ctx.shape
+        M = B * H * W
+        dout = dout.contiguous()
+        gs = [_grad_target(p) for p in (wt, ws, b1, w2, b2)]
         dhid = torch.empty_like(hidden)
-        gs = [_grad_target(p) for p in (w1, b1, w2, b2)]
-        call('hoig_local_attn_bwd', _p(source), _p(target), _p(flow), _p(w1), _p(w2), _p(hidden), _p(attn),
-             _p(dout.contiguous()), _p(dsrc), _p(dtgt), _p(gs[0][0]), _p(gs[1][0]), _p(gs[2][0]), _p(gs[3][0]),
-             _p(dhid), B, H, W, C, ctx.prec, _st())
+        call('hoig_attn_pixel_bwd', _p(hidden), _p(attn), _p(w2), _p(S), _p(dout), _p(dhid), _p(gs[3][0]), _p(gs[4][0]),
+             M, C, _st())
+        call('hoig_conv2d_bwd_weight', ctypes.byref(d_t), _p(tpad), _p(dhid), _p(gs[0][0]), _p(gs[2][0]), _st())
+        call('hoig_conv2d_bwd_weight', ctypes.byref(d_s), _p(S), _p(dhid), _p(gs[1][0]), None, _st())
+        dtgt = dsrc = None
+        if ctx.needs_input_grad[1]:
+            dtpad = torch.empty_like(tpad)
+            _conv_dgrad_raw(d_t, dhid, wt, dtpad)
+            dtgt = torch.empty((B, H, W, C), dtype=dout.dtype, device=dout.device)
+            call('hoig_replicate_pad_bwd', _p(dtpad), _p(dtgt), B, H, W, C, 2, _st())
+        if ctx.needs_input_grad[0]:
+            dS = torch.empty_like(S)
+            _conv_dgrad_raw(d_s, dhid, ws, dS)
+            dsrc = torch.zeros((B, H, W, C), dtype=dout.dtype, device=dout.device)
+            call('hoig_attn_sample_bwd', _p(flow), _p(dS), _p(attn), _p(dout), _p(dsrc), B, H, W, C, _st())
         rets = [g if r else None for g, r in gs]
-        return dsrc, dtgt, None, rets[0], rets[1], rets[2], rets[3], None
+        return dsrc, dtgt, None, rets[0], rets[1], rets[2], rets[3], rets[4], None
 
 
-def local_attention(source, target, flow, w1, b1, w2, b2, prec=None):
-    return _LocalAttn.apply(source, target, flow.contiguous(), w1, b1, w2, b2, precision if prec is None else prec)
+def local_attention(source, target, flow, wt, ws, b1, w2, b2, prec=None):
+    return _LocalAttn.apply(source, target, flow.contiguous(), wt, ws, b1, w2, b2, precision if prec is None else prec)
 
 
 # stand-alone equivalents of the reference's two extension modules (NCHW, caller-visible semantics of

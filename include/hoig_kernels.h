@@ -97,22 +97,29 @@ int hoig_inorm_bwd(const float *x, const float *mean, const float *rstd, int mod
                    const float *dy, int act, float slope, float *dx, float *dp0, float *dp1, int B, int HW, int C,
                    void *workspace, hoig_stream_t stream);
 
-/* ---- local attention warping: ExtractorAttn (extract_attn.py:23-29) = K1 block extraction of source
- *      (with flow) and target (zero flow) + conv k5/s5 + LeakyReLU(0.01) + conv1x1 + softmax(25) + K3 reshape +
- *      weighted 5x5 average, WITHOUT materialising the 25x tensors.
- *      source/target: [B,H,W,C] NHWC; flow: [B,2,H,W] (ch0 = x, ch1 = y, PIXEL units as K1 reads them,
- *      block_extractor_kernel.cu:62-67); w1: [128][5][5][2C] packed (first C = target, next C = source);
- *      b1[128]; w2[25][128]; b2[25].
- *      hidden: [B*H*W,128] pre-activation (saved for backward); attn: [B*H*W,25] softmax; out: [B,H,W,C]. ---- */
-int hoig_local_attn_fwd(const float *source, const float *target, const float *flow, const float *w1, const float *b1,
-                        const float *w2, const float *b2, float *hidden, float *attn, float *out, int B, int H, int W,
-                        int C, int precision, hoig_stream_t stream);
-/* backward: dsource, dtarget overwritten ([B,H,W,C], caller zero-fills), dw1/db1/dw2/db2 accumulate.
- * dhidden: scratch [B*H*W,128]. The flow carries no gradient on the path (it is data: generator.py:481-488). */
-int hoig_local_attn_bwd(const float *source, const float *target, const float *flow, const float *w1, const float *w2,
-                        const float *hidden, const float *attn, const float *dout, float *dsource, float *dtarget,
-                        float *dw1, float *db1, float *dw2, float *db2, float *dhidden, int B, int H, int W, int C,
-                        int precision, hoig_stream_t stream);
+/* ---- local attention warping: ExtractorAttn (extract_attn.py:23-29) = K1 block extraction of source (with flow)
+ *      and target (zero flow) + conv k5/s5 + LeakyReLU(0.01) + conv1x1 + softmax(25) + K3 reshape + weighted 5x5 average.
+ *      Composition (host: hoig_amd/ops.py::_LocalAttn): the target half of the k5/s5 conv is a 5x5 convolution of the
+ *      REPLICATE-padded target, the source half a 1x1 convolution over the sampled tensor S[m][q][c] (q = 25 taps);
+ *      both run on hoig_conv2d_*.  These entry points are the pieces around those GEMMs.
+ *      flow: [B,2,H,W] (ch0 = x, ch1 = y, PIXEL units as K1 reads them, block_extractor_kernel.cu:62-67). ---- */
+/* y[b, py, px] = x[b, clamp(py-pad), clamp(px-pad)]  ([B,H,W,C] -> [B,H+2pad,W+2pad,C]) and its adjoint */
+int hoig_replicate_pad_fwd(const float *x, float *y, int B, int H, int W, int C, int pad, hoig_stream_t stream);
+int hoig_replicate_pad_bwd(const float *dy, float *dx, int B, int H, int W, int C, int pad, hoig_stream_t stream);
+/* sampled[b,y,x,q,c] = K1 bilinear sample of source at (y,x) + flow + tap offset (clamped taps, raw weights) */
+int hoig_attn_sample_fwd(const float *source, const float *flow, float *sampled, int B, int H, int W, int C,
+                         hoig_stream_t stream);
+/* dsource += bilinear^T( dsampled[m][q][c] + attn[m][q]/25 * dout[m][c] ); dsampled nullable; dsource caller-zeroed.
+ * The flow carries no gradient on the path (it is data: generator.py:481-488). */
+int hoig_attn_sample_bwd(const float *flow, const float *dsampled, const float *attn, const float *dout, float *dsource,
+                         int B, int H, int W, int C, hoig_stream_t stream);
+/* attn[m] = softmax_25(w2 . leaky_0.01(hidden[m]) + b2); out[m][c] = (1/25) sum_q attn[m][q] sampled[m][q][c].
+ * hidden: [M,128] pre-activation, w2: [25][128], M = B*H*W */
+int hoig_attn_pixel_fwd(const float *hidden, const float *w2, const float *b2, const float *sampled, float *attn,
+                        float *out, int M, int C, hoig_stream_t stream);
+/* dhidden (overwritten), dw2 / db2 (accumulated) */
+int hoig_attn_pixel_bwd(const float *hidden, const float *attn, const float *w2, const float *sampled, const float *dout,
+                        float *dhidden, float *dw2, float *db2, int M, int C, hoig_stream_t stream);
 
 /* Stand-alone drop-ins for the reference's two pybind ops, same argument meaning, contiguous NCHW fp32,
  * caller zero-fills outputs: block_extractor_cuda.forward/backward (block_extractor_cuda.cc:5-33) and

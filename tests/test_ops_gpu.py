@@ -141,7 +141,7 @@ def test_instance_norm(mode, B, C, H, W):
         assert rel_err(dg, r.grad) < 5 * TOL
 
 
-@pytest.mark.parametrize('B,C,h', [(2, 128, 8), (1, 256, 6), (2, 512, 4)])
+@pytest.mark.parametrize('B,C,h', [(2, 128, 8), (1, 256, 6), (2, 512, 4), (1, 128, 32)])
 def test_local_attention_vs_oracle(B, C, h):
     """Fused attention (fc1 MFMA + pixel kernel) against the oracle's materialising restatement of
     extract_attn.py:23-29, forward and all gradients."""
@@ -162,17 +162,21 @@ def test_local_attention_vs_oracle(B, C, h):
     gy = torch.randn(yr.shape, generator=g)
     yr.backward(gy)
 
+    from hoig_amd.nn import split_attn_weight, merge_attn_weight
     sdv, tdv = nhwc_cuda(src).requires_grad_(True), nhwc_cuda(tgt).requires_grad_(True)
-    w1 = ops.pack_weight(sd['a.fully_connect_layer.0.weight'].cuda()).requires_grad_(True)
+    wt_l, ws_l = split_attn_weight(sd['a.fully_connect_layer.0.weight'].cuda())     # storage form of the (128,2C,5,5) weight
+    wt = ops.pack_weight(wt_l.contiguous()).requires_grad_(True)
+    ws = ops.pack_weight(ws_l.contiguous()).requires_grad_(True)
     b1 = sd['a.fully_connect_layer.0.bias'].cuda().requires_grad_(True)
     w2 = ops.pack_weight(sd['a.fully_connect_layer.2.weight'].cuda()).requires_grad_(True)
     b2 = sd['a.fully_connect_layer.2.bias'].cuda().requires_grad_(True)
-    y = ops.local_attention(sdv, tdv, flow.cuda(), w1, b1, w2, b2)
+    y = ops.local_attention(sdv, tdv, flow.cuda(), wt, ws, b1, w2, b2)
     y.backward(nhwc_cuda(gy))
     assert rel_err(nchw_cpu(y), yr) < TOL
     assert rel_err(nchw_cpu(sdv.grad), sr.grad) < 5 * TOL
     assert rel_err(nchw_cpu(tdv.grad), tr.grad) < 5 * TOL
-    assert rel_err(w1.grad, ref['a.fully_connect_layer.0.weight'].grad) < 5 * TOL
+    w1g = merge_attn_weight(wt.grad, ws.grad)
+    assert rel_err(w1g, ref['a.fully_connect_layer.0.weight'].grad) < 5 * TOL
     assert rel_err(b1.grad, ref['a.fully_connect_layer.0.bias'].grad) < 5 * TOL
     assert rel_err(w2.grad, ref['a.fully_connect_layer.2.weight'].grad) < 5 * TOL
     assert rel_err(b2.grad, ref['a.fully_connect_layer.2.bias'].grad) < 5 * TOL

@@ -86,14 +86,17 @@ def test_trainer_vs_oracle_128(precision):
         assert abs(eo[k] - ep[k]) <= 2e-3 * max(abs(eo[k]), 1e-2), (k, eo[k], ep[k])
     worst = 0.0
     for net_o, net_p in ((ot.G, m._G), (ot.D, m._D)):
+        grads = net_p.export_dict(net_p.flat_grad)            # reference names / shapes
         for name, po_ in net_o.items():
             ref = po_.grad
             # structurally-zero gradients: a conv bias that feeds an instance norm (both sides hold only noise there)
             if ref is None or name.endswith('.conv_0.bias') or name in ('model.2.bias', 'model.5.bias', 'model.8.bias',
                                                                           'model.11.bias'):
                 continue
-            worst = max(worst, rel_l2(net_p.P[name].grad, ref))
-            assert rel_l2(net_p.P[name].grad, ref) < GRAD_TOL, name
+            worst = max(worst, rel_l2(grads[name], ref))
+            # split-bf16 products carry 2^-16 relative error: on the cancellation-heavy, 1e-5-sized attention weight
+            # gradients that is ~3x the fp32 summation-order noise
+            assert rel_l2(grads[name], ref) < (GRAD_TOL if precision == 'f32' else 2 * GRAD_TOL), name
     print('worst gradient rel-L2 (%s): %.2e' % (precision, worst))
 
 
