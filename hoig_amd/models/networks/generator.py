@@ -169,8 +169,12 @@ class Generator(ParamTree):
         self._seg_cache = {}
         src_bg_in = [bg, src_hand_c] + ([src_armask] if src_armask is not None else [])
         tsf_bg_in = [bg, tsf_hand_c] + ([tsf_armask] if tsf_armask is not None else [])
-        src_img_bg = self._bg_net(ops.cat_channels(src_bg_in))
-        tsf_img_bg = self._bg_net(ops.cat_channels(tsf_bg_in))
+        # bg_model runs on the src and tsf inputs with SHARED weights (generator.py:367-369): one pass over the two
+        # batches stacked (instance norm is per sample, so the result is identical) -> twice the tiles per launch at the
+        # 32x32 bottleneck and one weight-gradient accumulation instead of two
+        nb = bg.shape[0]
+        bg_both = self._bg_net(torch.cat([ops.cat_channels(src_bg_in), ops.cat_channels(tsf_bg_in)], dim=0))
+        src_img_bg, tsf_img_bg = bg_both[:nb], bg_both[nb:]
 
         # infer_front (generator.py:379-464)
         sx = self._conv_in_relu(src_hand, 'src_model.encoders.0', pad=3)
@@ -187,8 +191,9 @@ class Generator(ParamTree):
             tx = self._resnet(tx, tsf_hand_c, 'tsf_model', i)
             tx = ops.add(tx, self._transform(sx, T, i + c.n_down + 1, y=tx))
 
-        sy = self._unet(src_obj, src_obj_c, 'obj_model')
-        ty = self._unet(tsf_obj, tsf_obj_c, 'obj_model')
+        # obj_model likewise serves both the src and the tsf object (generator.py:449-450): one stacked pass
+        obj_both = self._unet(torch.cat([src_obj, tsf_obj], dim=0), torch.cat([src_obj_c, tsf_obj_c], dim=0), 'obj_model')
+        sy, ty = obj_both[:nb], obj_both[nb:]
         sx = self._decode(sx, s_enc, src_hand_c, 'src_model')
         tx = self._decode(tx, t_enc, tsf_hand_c, 'tsf_model')
 
@@ -200,8 +205,8 @@ class Generator(ParamTree):
 
         src_hand_o, src_mask_hand, src_mask_bg = regress(sx, sy, 'src_model')
         tsf_hand_o, tsf_mask_hand, tsf_mask_bg = regress(tx, ty, 'tsf_model')
-        src_obj_o = self._conv(sy, 'obj_model.img_reg.0', pad=3, act=ACT_TANH)
-        tsf_obj_o = self._conv(ty, 'obj_model.img_reg.0', pad=3, act=ACT_TANH)
+        obj_o = self._conv(obj_both, 'obj_model.img_reg.0', pad=3, act=ACT_TANH)
+        src_obj_o, tsf_obj_o = obj_o[:nb], obj_o[nb:]
         self._seg_cache = {}
         return (src_img_bg, tsf_img_bg, src_obj_o, src_hand_o, src_mask_bg, src_mask_hand,
                 tsf_obj_o, tsf_hand_o, tsf_mask_bg, tsf_mask_hand)

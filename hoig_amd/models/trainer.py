@@ -263,8 +263,11 @@ class Trainer(BaseModel):
         """trainer.py:459-474."""
         o, n = self._opt, self._n
         fake_tsf = to_nhwc(fake_tsf_imgs).detach()
-        d_real = self._D.forward_nhwc(ops.cat_channels([n['real_tsf'], n['tsf_cond']]))
-        d_fake = self._D.forward_nhwc(ops.cat_channels([fake_tsf, n['tsf_cond']]))
+        # the reference runs D twice (trainer.py:464-465); instance norm is per sample, so one stacked pass is identical
+        nb = fake_tsf.shape[0]
+        d_both = self._D.forward_nhwc(torch.cat([ops.cat_channels([n['real_tsf'], n['tsf_cond']]),
+                                                 ops.cat_channels([fake_tsf, n['tsf_cond']])], dim=0))
+        d_real, d_fake = d_both[:nb], d_both[nb:]
         loss_real = ops.lsgan_loss(d_real, 1.0, o.lambda_D_prob)
         loss_fake = ops.lsgan_loss(d_fake, -1.0, o.lambda_D_prob)
         with torch.no_grad():
