@@ -705,6 +705,7 @@ struct WArgs {
     int R, S, stride, pad;
     int M, Co, Ci, K;
     int nblk_n, nblk_mn, m_per_split;
+    int lw, lh;                // log2 of Wp / Hp when both are powers of two, else -1
 };
 
 struct Pix {
@@ -756,34 +757,27 @@ __global__ __launch_bounds__(256) void wgrad_bf16_kernel(const WArgs p) {
     const int plain_ch = p.gatherP ? (jq - (j0 / p.Ci) * p.Ci) : (c0 + pcol * 4);
     const bool q_ok = jq < p.K, p_ok = (c0 + pcol * 4) < p.Co;
 
-    Pix pq[4], pp[RP];
-    {
-        const int hw = p.Hp * p.Wp;
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const int m = m_begin + qrow + 8 * i;
-            pq[i].b = m / hw;
-            const int rem = m - pq[i].b * hw;
-            pq[i].h = rem / p.Wp;
-            pq[i].w = rem - pq[i].h * p.Wp;
+    // pixel decode of the reduction index m: shifts/masks when the grid sides are powers of two (every HOGAN layer),
+    // divisions otherwise.  The plain operand needs no decode at all: its rows are enumerated exactly like m.
+    auto gather = [&](const float *T, int m) -> float4 {
+        int bq, h, w;
+        if (p.lw >= 0) {
+            w = m & (p.Wp - 1);
+            h = (m >> p.lw) & (p.Hp - 1);
+            bq = m >> (p.lw + p.lh);
+        } else {
+            const int hw = p.Hp * p.Wp;
+            bq = m / hw;
+            const int rem = m - bq * hw;
+            h = rem / p.Wp;
+            w = rem - h * p.Wp;
         }
-#pragma unroll
-        for (int i = 0; i < RP; ++i) {
-            const int m = m_begin + prow + PROWS * i;
-            pp[i].b = m / hw;
-            const int rem = m - pp[i].b * hw;
-            pp[i].h = rem / p.Wp;
-            pp[i].w = rem - pp[i].h * p.Wp;
-        }
-    }
-
-    auto gather = [&](const float *T, const Pix &x) -> float4 {
-        const int hg = x.h * p.stride - p.pad + tap_r, wg = x.w * p.stride - p.pad + tap_s;
+        const int hg = h * p.stride - p.pad + tap_r, wg = w * p.stride - p.pad + tap_s;
         if (hg < 0 || hg >= p.Hg || wg < 0 || wg >= p.Wg) return make_float4(0.f, 0.f, 0.f, 0.f);
-        return *reinterpret_cast<const float4 *>(T + (((size_t)x.b * p.Hg + hg) * p.Wg + wg) * p.Cg + gch);
+        return *reinterpret_cast<const float4 *>(T + (((size_t)bq * p.Hg + hg) * p.Wg + wg) * p.Cg + gch);
     };
-    auto plain = [&](const float *T, const Pix &x) -> float4 {
-        return *reinterpret_cast<const float4 *>(T + (((size_t)x.b * p.Hp + x.h) * p.Wp + x.w) * p.Cplain + plain_ch);
+    auto plain = [&](const float *T, int m) -> float4 {
+        return *reinterpret_cast<const float4 *>(T + (size_t)m * p.Cplain + plain_ch);
     };
 
     f32x16 acc[TM][TN];
@@ -800,17 +794,15 @@ __global__ __launch_bounds__(256) void wgrad_bf16_kernel(const WArgs p) {
         for (int i = 0; i < 4; ++i) {
             const int m = mb + qrow + 8 * i;
             float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (m < m_end && q_ok) v = p.gatherP ? plain(p.Q, pq[i]) : gather(p.Q, pq[i]);
+            if (m < m_end && q_ok) v = p.gatherP ? plain(p.Q, m) : gather(p.Q, m);
             rq[i] = v;
-            pix_advance(pq[i], BK, p.Hp, p.Wp);
         }
 #pragma unroll
         for (int i = 0; i < RP; ++i) {
             const int m = mb + prow + PROWS * i;
             float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (m < m_end && p_ok) v = p.gatherP ? gather(p.P, pp[i]) : plain(p.P, pp[i]);
+            if (m < m_end && p_ok) v = p.gatherP ? gather(p.P, m) : plain(p.P, m);
             rp[i] = v;
-            pix_advance(pp[i], BK, p.Hp, p.Wp);
         }
     };
     auto store_tiles = [&](int stage) {
@@ -908,7 +900,8 @@ int launch_wgrad_bf16(WArgs a, int ns, hipStream_t st) {
     const int nbm = (int)hoig_cdiv(a.Co, BM), nbn = (int)hoig_cdiv(a.K, 128);
     a.nblk_n = nbn;
     a.nblk_mn = nbm * nbn;
-    int splits = (int)hoig_cdiv(1024, a.nblk_mn);
+    static const int target_blocks = getenv("HOIG_WGRAD_BLOCKS") ? atoi(getenv("HOIG_WGRAD_BLOCKS")) : 2048;
+    int splits = (int)hoig_cdiv(target_blocks, a.nblk_mn);
     const int max_splits = (int)hoig_cdiv(a.M, 512);
     if (splits > max_splits) splits = max_splits;
     if (splits < 1) splits = 1;
@@ -946,6 +939,11 @@ int hoig_conv_bf16_wgrad(const hoig_conv_desc *d, const float *x, const float *d
         a.Cplain = d->Ci;
     }
     a.M = d->B * a.Hp * a.Wp;
+    a.lw = a.lh = -1;
+    if ((a.Hp & (a.Hp - 1)) == 0 && (a.Wp & (a.Wp - 1)) == 0) {
+        a.lw = __builtin_ctz(a.Wp);
+        a.lh = __builtin_ctz(a.Hp);
+    }
     const int ns = d->precision == HOIG_PREC_BF16X3 ? 2 : 1;
     if (a.Co <= 64) return launch_wgrad_bf16<64>(a, ns, st);
     return launch_wgrad_bf16<128>(a, ns, st);
