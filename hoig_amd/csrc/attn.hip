@@ -82,31 +82,58 @@ __global__ void replicate_pad_bwd_kernel(const float *__restrict__ dy, float *__
 }
 
 // ---------------------------------------------------------------------------------------------- source sampling
-// S[m][q][c] : one thread per (m, q, 4 channels); lanes run along channels (coalesced 16-B gathers and stores)
-__global__ void attn_sample_fwd_kernel(const float *__restrict__ src, const float *__restrict__ flow,
-                                       float *__restrict__ S, int B, int H, int W, int C) {
+// S[m][q][c]: one thread per (m, 4 channels) walks the 25 taps.  K1's sampling coordinate is separable -- dy depends
+// only on (flow_y, tap row, y), dx only on (flow_x, tap column, x) (block_extractor_kernel.cu:62-76) -- so the five row
+// and five column coordinate sets are computed once per pixel with exactly K1's arithmetic and shared by the 25 taps.
+struct Axis {
+    int i0[KS], i1[KS];
+    float w0[KS], w1[KS];
+};
+__device__ __forceinline__ void k1_axis(Axis &a, float f, int pos, int lim) {
+#pragma unroll
+    for (int t = 0; t < KS; ++t) {
+        const float fl_ = f + (float)(t - KS / 2);          // flow + offset   (:62-63)
+        const float d = fl_ + (float)pos;                   // + pixel index   (:66-67)
+        const float fl = floorf(d);
+        a.i0[t] = max(min((int)fl, lim - 1), 0);
+        a.i1[t] = max(min((int)fl + 1, lim - 1), 0);
+        a.w1[t] = d - fl;
+        a.w0[t] = 1.f - a.w1[t];
+    }
+}
+__global__ __launch_bounds__(256) void attn_sample_fwd_kernel(const float *__restrict__ src, const float *__restrict__ flow,
+                                                              float *__restrict__ S, int B, int H, int W, int C) {
     const int CV = C >> 2, hw = H * W;
-    const int64_t n = (int64_t)B * hw * NTAP * CV;
+    const int64_t n = (int64_t)B * hw * CV;
     for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
         const int cv = (int)(i % CV);
-        int64_t t = i / CV;
-        const int q = (int)(t % NTAP);
-        const int64_t m = t / NTAP;
+        const int64_t m = i / CV;
         const int b = (int)(m / hw), rem = (int)(m - (int64_t)b * hw);
         const int y = rem / W, x = rem - y * W;
-        const float fx = flow[((size_t)b * 2 + 0) * hw + rem], fy = flow[((size_t)b * 2 + 1) * hw + rem];
-        const Corner c = k1_corner(y, x, fx, fy, q, H, W);
+        Axis ay, ax;
+        k1_axis(ax, flow[((size_t)b * 2 + 0) * hw + rem], x, W);
+        k1_axis(ay, flow[((size_t)b * 2 + 1) * hw + rem], y, H);
         const float *s = src + (size_t)b * hw * C + cv * 4;
-        const float4 a = *reinterpret_cast<const float4 *>(s + ((size_t)c.y0 * W + c.x0) * C);
-        const float4 bb = *reinterpret_cast<const float4 *>(s + ((size_t)c.y0 * W + c.x1) * C);
-        const float4 d = *reinterpret_cast<const float4 *>(s + ((size_t)c.y1 * W + c.x0) * C);
-        const float4 e = *reinterpret_cast<const float4 *>(s + ((size_t)c.y1 * W + c.x1) * C);
-        float4 v;   // same summation order as K1 (:79-82)
-        v.x = c.w00 * a.x; v.x += c.w01 * bb.x; v.x += c.w10 * d.x; v.x += c.w11 * e.x;
-        v.y = c.w00 * a.y; v.y += c.w01 * bb.y; v.y += c.w10 * d.y; v.y += c.w11 * e.y;
-        v.z = c.w00 * a.z; v.z += c.w01 * bb.z; v.z += c.w10 * d.z; v.z += c.w11 * e.z;
-        v.w = c.w00 * a.w; v.w += c.w01 * bb.w; v.w += c.w10 * d.w; v.w += c.w11 * e.w;
-        reinterpret_cast<float4 *>(S)[i] = v;
+        float *o = S + (size_t)m * NTAP * C + cv * 4;
+#pragma unroll
+        for (int r = 0; r < KS; ++r) {
+            const float *row0 = s + (size_t)ay.i0[r] * W * C, *row1 = s + (size_t)ay.i1[r] * W * C;
+#pragma unroll
+            for (int t = 0; t < KS; ++t) {
+                const float4 a = *reinterpret_cast<const float4 *>(row0 + (size_t)ax.i0[t] * C);
+                const float4 bb = *reinterpret_cast<const float4 *>(row0 + (size_t)ax.i1[t] * C);
+                const float4 d = *reinterpret_cast<const float4 *>(row1 + (size_t)ax.i0[t] * C);
+                const float4 e = *reinterpret_cast<const float4 *>(row1 + (size_t)ax.i1[t] * C);
+                const float w00 = ax.w0[t] * ay.w0[r], w01 = ax.w1[t] * ay.w0[r];     // xL_P*yT_P, xR_P*yT_P (:79-82)
+                const float w10 = ax.w0[t] * ay.w1[r], w11 = ax.w1[t] * ay.w1[r];
+                float4 v;
+                v.x = w00 * a.x; v.x += w01 * bb.x; v.x += w10 * d.x; v.x += w11 * e.x;
+                v.y = w00 * a.y; v.y += w01 * bb.y; v.y += w10 * d.y; v.y += w11 * e.y;
+                v.z = w00 * a.z; v.z += w01 * bb.z; v.z += w10 * d.z; v.z += w11 * e.z;
+                v.w = w00 * a.w; v.w += w01 * bb.w; v.w += w10 * d.w; v.w += w11 * e.w;
+                *reinterpret_cast<float4 *>(o + (size_t)(r * KS + t) * C) = v;
+            }
+        }
     }
 }
 
@@ -330,8 +357,8 @@ extern "C" int hoig_replicate_pad_bwd(const float *dy, float *dx, int B, int H, 
 extern "C" int hoig_attn_sample_fwd(const float *source, const float *flow, float *sampled, int B, int H, int W, int C,
                                     hoig_stream_t stream) {
     if (!source || !flow || !sampled || (C & 3)) return HOIG_EINVAL;
-    const int64_t n = (int64_t)B * H * W * NTAP * (C / 4);
-    attn_sample_fwd_kernel<<<hoig_stream_grid(n, 256), 256, 0, ST>>>(source, flow, sampled, B, H, W, C);
+    const int64_t n = (int64_t)B * H * W * (C / 4);
+    attn_sample_fwd_kernel<<<(unsigned)hoig_cdiv(n, 256) > 65535u * 16u ? 65535u * 16u : (unsigned)hoig_cdiv(n, 256), 256, 0, ST>>>(source, flow, sampled, B, H, W, C);
     HOIG_LAUNCH_CHECK();
     return HOIG_OK;
 }

@@ -396,13 +396,15 @@ struct HaloArgs {
     int tiles_x, tiles_y;
 };
 
-template <int KS, int NS>
-__global__ __launch_bounds__(256) void conv_halo_bf16_kernel(const HaloArgs p) {
+template <int KS, int NS, int WN>
+__global__ __launch_bounds__(128 * WN) void conv_halo_bf16_kernel(const HaloArgs p) {
     constexpr int TH = 4, TW = 32, BN = 128;
+    constexpr int NT = 128 * WN;                           // 2 x WN waves: 256 or 512 threads
+    constexpr int RB = BN * 4 / NT;                        // 16-B weight chunks per thread per plane
     constexpr int HH = TH + KS - 1, HW = TW + KS - 1, HPIX = HH * HW;
     constexpr int AROW = 80;                               // bytes per halo pixel row (32 bf16 + pad)
     constexpr int PLANE_A = HPIX * AROW, PLANE_B = BN * 64;
-    constexpr int TM = 2, TN = 2;
+    constexpr int TM = 2, TN = 4 / WN;
     // LDS: one halo stage + two weight stages = 64 KB at KS=3 -> two workgroups per CU
     __shared__ __attribute__((aligned(16))) unsigned char smem[NS * PLANE_A + 2 * NS * PLANE_B];
     unsigned char *Ah = smem, *Al = smem + PLANE_A;
@@ -410,7 +412,7 @@ __global__ __launch_bounds__(256) void conv_halo_bf16_kernel(const HaloArgs p) {
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int l31 = lane & 31, lh = lane >> 5;
-    const int wm = wave >> 1, wn = wave & 1;
+    const int wm = wave / WN, wn = wave % WN;
     const int tile = hoig_xcd_remap(blockIdx.x, p.nblk);
     int mt = tile / p.nblk_n;
     const int n0 = (tile % p.nblk_n) * BN;
@@ -420,14 +422,14 @@ __global__ __launch_bounds__(256) void conv_halo_bf16_kernel(const HaloArgs p) {
     const int y0 = ty_ * TH, x0 = tx_ * TW;                // tile origin (output pixels)
 
     const int brow = tid >> 2, bchunk = tid & 3;
-    const unsigned short *wrow_h[2], *wrow_l[2];
-    int boff[2];
+    const unsigned short *wrow_h[RB], *wrow_l[RB];
+    int boff[RB];
 #pragma unroll
-    for (int i = 0; i < 2; ++i) {
-        const int n = n0 + brow + 64 * i;
+    for (int i = 0; i < RB; ++i) {
+        const int n = n0 + brow + (NT / 4) * i;
         wrow_h[i] = n < p.N ? p.Wh + (size_t)n * p.K + bchunk * 8 : nullptr;
         wrow_l[i] = (NS == 2 && n < p.N) ? p.Wl + (size_t)n * p.K + bchunk * 8 : nullptr;
-        const int row = brow + 64 * i;
+        const int row = brow + (NT / 4) * i;
         boff[i] = row * 64 + ((bchunk ^ ((row >> 2) & 3)) << 4);
     }
     // fragment read offsets: wave wm owns output rows 2*wm, 2*wm+1 of the tile (32 pixels each = one MFMA row tile)
@@ -436,7 +438,7 @@ __global__ __launch_bounds__(256) void conv_halo_bf16_kernel(const HaloArgs p) {
     for (int i = 0; i < TM; ++i) aread[i] = ((wm * TM + i) * HW + l31) * AROW + lh * 16;
 #pragma unroll
     for (int j = 0; j < TN; ++j) {
-        const int row = wn * 64 + j * 32 + l31;
+        const int row = wn * (TN * 32) + j * 32 + l31;
         bread[j] = row * 64 + ((lh ^ ((row >> 2) & 3)) << 4);
     }
 
@@ -451,34 +453,34 @@ __global__ __launch_bounds__(256) void conv_halo_bf16_kernel(const HaloArgs p) {
     // Weight tiles are prefetched TWO steps ahead (step = one tap of one 32-channel block) into two register sets: the
     // weights of a 512x512x3x3 layer (9.4 MB of bf16 planes) live in the Infinity Cache, whose latency under load exceeds
     // one step's MFMA phase (768 cycles per wave).
-    uint4 rb0h[2], rb0l[2], rb1h[2], rb1l[2];
+    uint4 rb0h[RB], rb0l[RB], rb1h[RB], rb1l[RB];
     constexpr int KK = KS * KS;
     const int ncb = p.Cg >> 5, T = ncb * KK;
-    auto load_b = [&](int step, uint4 (&rh)[2], uint4 (&rl)[2]) {
+    auto load_b = [&](int step, uint4 (&rh)[RB], uint4 (&rl)[RB]) {
         const int cb = step / KK, tap = step - cb * KK;
         const int wtap = p.flip ? (KK - 1 - tap) : tap;
         const int koff = wtap * p.Cg + cb * 32;
 #pragma unroll
-        for (int i = 0; i < 2; ++i) {
+        for (int i = 0; i < RB; ++i) {
             rh[i] = wrow_h[i] ? *reinterpret_cast<const uint4 *>(wrow_h[i] + koff) : make_uint4(0, 0, 0, 0);
             if (NS == 2) rl[i] = wrow_l[i] ? *reinterpret_cast<const uint4 *>(wrow_l[i] + koff) : make_uint4(0, 0, 0, 0);
         }
     };
-    auto store_b = [&](int stage, const uint4 (&rh)[2], const uint4 (&rl)[2]) {
+    auto store_b = [&](int stage, const uint4 (&rh)[RB], const uint4 (&rl)[RB]) {
         unsigned char *Bh = Bst + stage * NS * PLANE_B, *Bl = Bh + PLANE_B;
 #pragma unroll
-        for (int i = 0; i < 2; ++i) {
+        for (int i = 0; i < RB; ++i) {
             *reinterpret_cast<uint4 *>(Bh + boff[i]) = rh[i];
             if (NS == 2) *reinterpret_cast<uint4 *>(Bl + boff[i]) = rl[i];
         }
     };
     const float *Aimg = p.A + (size_t)b * p.H * p.W * p.Cg;
-    constexpr int HSLICES = (HPIX * 8 + 255) / 256;        // halo float4s per thread
+    constexpr int HSLICES = (HPIX * 8 + NT - 1) / NT;      // halo float4s per thread
     float4 hreg[HSLICES];
     auto halo_load = [&](int cb) {
 #pragma unroll
         for (int sl = 0; sl < HSLICES; ++sl) {
-            const int i = tid + 256 * sl;
+            const int i = tid + NT * sl;
             float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
             if (i < HPIX * 8) {
                 const int pix = i >> 3, c4 = i & 7;
@@ -493,7 +495,7 @@ __global__ __launch_bounds__(256) void conv_halo_bf16_kernel(const HaloArgs p) {
     auto halo_store = [&]() {
 #pragma unroll
         for (int sl = 0; sl < HSLICES; ++sl) {
-            const int i = tid + 256 * sl;
+            const int i = tid + NT * sl;
             if (i < HPIX * 8) {
                 const int pix = i >> 3, c4 = i & 7;
                 uint2 hi, lo;
@@ -537,7 +539,7 @@ __global__ __launch_bounds__(256) void conv_halo_bf16_kernel(const HaloArgs p) {
     };
     // one step: prefetch weights of step+2, multiply `stage`, then publish the weights of step+1 (and, at a channel-block
     // boundary, the next halo, whose loads were issued before the multiply) behind one barrier
-    auto do_step = [&](int step, int stage, uint4 (&nh)[2], uint4 (&nl)[2], uint4 (&fh)[2], uint4 (&fl)[2]) {
+    auto do_step = [&](int step, int stage, uint4 (&nh)[RB], uint4 (&nl)[RB], uint4 (&fh)[RB], uint4 (&fl)[RB]) {
         if (step + 2 < T) load_b(step + 2, fh, fl);
         const bool boundary = (step % KK == KK - 1) && (step + 1 < T);
         if (boundary) halo_load(step / KK + 1);
@@ -574,7 +576,7 @@ __global__ __launch_bounds__(256) void conv_halo_bf16_kernel(const HaloArgs p) {
             const size_t pix = ((size_t)b * p.H + oy) * p.W + ox;
 #pragma unroll
             for (int j = 0; j < TN; ++j) {
-                const int n = n0 + wn * 64 + j * 32 + l31;
+                const int n = n0 + wn * (TN * 32) + j * 32 + l31;
                 if (n < p.N) {
                     float v = acc[i][j][r];
                     if (p.bias) v += p.bias[n];
@@ -591,8 +593,15 @@ int launch_halo(HaloArgs a, int ns, hipStream_t st) {
     a.tiles_y = a.H / 4;
     a.nblk_n = (int)hoig_cdiv(a.N, 128);
     a.nblk = a.Bn * a.tiles_x * a.tiles_y * a.nblk_n;
-    if (ns == 2) conv_halo_bf16_kernel<KS, 2><<<a.nblk, 256, 0, st>>>(a);
-    else conv_halo_bf16_kernel<KS, 1><<<a.nblk, 256, 0, st>>>(a);
+    // fewer than ~1.5 workgroups per CU: 8 waves per workgroup keep two waves on every SIMD
+    const bool wide = a.nblk < 384 && getenv("HOIG_HALO_4W") == nullptr;
+    if (ns == 2) {
+        if (wide) conv_halo_bf16_kernel<KS, 2, 4><<<a.nblk, 512, 0, st>>>(a);
+        else conv_halo_bf16_kernel<KS, 2, 2><<<a.nblk, 256, 0, st>>>(a);
+    } else {
+        if (wide) conv_halo_bf16_kernel<KS, 1, 4><<<a.nblk, 512, 0, st>>>(a);
+        else conv_halo_bf16_kernel<KS, 1, 2><<<a.nblk, 256, 0, st>>>(a);
+    }
     HOIG_LAUNCH_CHECK();
     return HOIG_OK;
 }
@@ -624,7 +633,8 @@ int run(const hoig_conv_desc *d, const float *a, const unsigned short *wh, const
     if (p.N <= 32) return HOIG_EUNSUPPORTED;
     // stride-1 "same" convolutions (and their data gradients): LDS-resident input halo, weights streamed per tap
     if (!d->transposed && d->stride == 1 && d->R == d->S && 2 * d->pad == d->R - 1 && (d->R == 1 || d->R == 3 || d->R == 5) &&
-        d->Wi % 32 == 0 && d->Hi % 4 == 0 && p.N % 128 == 0 && getenv("HOIG_NO_HALO") == nullptr) {
+        d->Wi % 32 == 0 && d->Hi % 4 == 0 && p.N % 128 == 0 && getenv("HOIG_NO_HALO") == nullptr &&
+        (long)d->B * (d->Hi / 4) * (d->Wi / 32) * (p.N / 128) >= 160) {   // fewer tiles: the generic kernel splits K
         HaloArgs h;
         h.A = a; h.Wh = wh; h.Wl = wl; h.bias = bias; h.C = c;
         h.Bn = d->B; h.H = d->Hi; h.W = d->Wi; h.Cg = g.Cg; h.N = p.N; h.K = p.K;
