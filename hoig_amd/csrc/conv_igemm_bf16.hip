@@ -396,15 +396,16 @@ struct HaloArgs {
     int tiles_x, tiles_y;
 };
 
-template <int KS, int NS, int WN>
+template <int KS, int NS, int WN, int BN = 128>
 __global__ __launch_bounds__(128 * WN) void conv_halo_bf16_kernel(const HaloArgs p) {
-    constexpr int TH = 4, TW = 32, BN = 128;
+    constexpr int TH = 4, TW = 32;
     constexpr int NT = 128 * WN;                           // 2 x WN waves: 256 or 512 threads
     constexpr int RB = BN * 4 / NT;                        // 16-B weight chunks per thread per plane
     constexpr int HH = TH + KS - 1, HW = TW + KS - 1, HPIX = HH * HW;
     constexpr int AROW = 80;                               // bytes per halo pixel row (32 bf16 + pad)
     constexpr int PLANE_A = HPIX * AROW, PLANE_B = BN * 64;
-    constexpr int TM = 2, TN = 4 / WN;
+    constexpr int TM = 2, TN = BN / (32 * WN);
+    static_assert(TN >= 1, "BN = 64 needs the 4-wave variant");
     // LDS: one halo stage + two weight stages = 64 KB at KS=3 -> two workgroups per CU
     __shared__ __attribute__((aligned(16))) unsigned char smem[NS * PLANE_A + 2 * NS * PLANE_B];
     unsigned char *Ah = smem, *Al = smem + PLANE_A;
@@ -591,8 +592,15 @@ template <int KS>
 int launch_halo(HaloArgs a, int ns, hipStream_t st) {
     a.tiles_x = a.W / 32;
     a.tiles_y = a.H / 4;
-    a.nblk_n = (int)hoig_cdiv(a.N, 128);
+    const bool n64 = (a.N % 128) != 0;        // 64-channel layers (the full-resolution levels, VGG conv1): BN = 64 tiles
+    a.nblk_n = (int)hoig_cdiv(a.N, n64 ? 64 : 128);
     a.nblk = a.Bn * a.tiles_x * a.tiles_y * a.nblk_n;
+    if (n64) {
+        if (ns == 2) conv_halo_bf16_kernel<KS, 2, 2, 64><<<a.nblk, 256, 0, st>>>(a);
+        else conv_halo_bf16_kernel<KS, 1, 2, 64><<<a.nblk, 256, 0, st>>>(a);
+        HOIG_LAUNCH_CHECK();
+        return HOIG_OK;
+    }
     // fewer than ~1.5 workgroups per CU: 8 waves per workgroup keep two waves on every SIMD
     const bool wide = a.nblk < 384 && getenv("HOIG_HALO_4W") == nullptr;
     if (ns == 2) {
@@ -633,8 +641,8 @@ int run(const hoig_conv_desc *d, const float *a, const unsigned short *wh, const
     if (p.N <= 32) return HOIG_EUNSUPPORTED;
     // stride-1 "same" convolutions (and their data gradients): LDS-resident input halo, weights streamed per tap
     if (!d->transposed && d->stride == 1 && d->R == d->S && 2 * d->pad == d->R - 1 && (d->R == 1 || d->R == 3 || d->R == 5) &&
-        d->Wi % 32 == 0 && d->Hi % 4 == 0 && p.N % 128 == 0 && getenv("HOIG_NO_HALO") == nullptr &&
-        (long)d->B * (d->Hi / 4) * (d->Wi / 32) * (p.N / 128) >= 160) {   // fewer tiles: the generic kernel splits K
+        d->Wi % 32 == 0 && d->Hi % 4 == 0 && p.N % 64 == 0 && getenv("HOIG_NO_HALO") == nullptr &&
+        (long)d->B * (d->Hi / 4) * (d->Wi / 32) * ((p.N + 127) / 128) >= 160) {   // fewer tiles: the generic kernel splits K
         HaloArgs h;
         h.A = a; h.Wh = wh; h.Wl = wl; h.bias = bias; h.C = c;
         h.Bn = d->B; h.H = d->Hi; h.W = d->Wi; h.Cg = g.Cg; h.N = p.N; h.K = p.K;

@@ -1,7 +1,7 @@
 // Instance normalisation over NHWC fp32 (HBM-bound streaming kernels, 16-B accesses per lane).
 //   reference: nn.InstanceNorm2d (eps 1e-5, biased variance, no running stats) at generator.py:16-22,101-120,154-208,
 //   spade.py:13 (param-free, then SPADE modulate spade.py:36), discriminator.py:37,45 via base_network.py:31.
-// stats  : per (b,c) shifted sums over H*W split across workgroups -> workspace -> fixed-order finalise (deterministic)
+// stats  : per (b,c) shifted sums over H*W split across workgroups, one atomic per (workgroup, channel) -> finalise
 // apply  : y = act((x-mean)*rstd*scale+shift) (+ residual)       scale/shift = 1/0 | weight/bias[c] | 1+gamma/beta
 // bwd    : dx = rstd*(g' - mean(g') - xhat*mean(g'*xhat)),  g' = dy*act'(y)*scale ; affine / SPADE parameter grads
 #include "common.h"
@@ -75,12 +75,15 @@ __global__ __launch_bounds__(NT) void inorm_partial_kernel(const float *__restri
         *reinterpret_cast<float4 *>(r_ + C + c) = s2;
     }
     __syncthreads();
-    float *out = partial + ((size_t)b * nchunks + chunk) * 2 * C;
+    // one fp32 atomic per (workgroup, channel, moment) into sums[b][2][C] (zeroed by the launcher): the finalise step then
+    // reads two values per channel instead of walking up to 128 chunk partials (it was pure latency: ~14 us per launch)
+    float *out = partial + (size_t)b * 2 * C;
     for (int i = threadIdx.x; i < 2 * C; i += NT) {
         float s = 0.f;
         for (int k = 0; k < row_lanes; ++k) s += red[(size_t)k * 2 * C + i];
-        out[i] = s;
+        atomicAdd(&out[i], s);
     }
+    (void)chunk;
 }
 
 __global__ void inorm_finalize_kernel(const float *__restrict__ x, const float *__restrict__ partial, int HW, int C,
@@ -89,12 +92,8 @@ __global__ void inorm_finalize_kernel(const float *__restrict__ x, const float *
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= total) return;
     const int b = i / C, c = i - b * C;
-    float s1 = 0.f, s2 = 0.f;
-    for (int k = 0; k < nchunks; ++k) {
-        const float *p = partial + ((size_t)b * nchunks + k) * 2 * C;
-        s1 += p[c];
-        s2 += p[C + c];
-    }
+    const float s1 = partial[(size_t)b * 2 * C + c], s2 = partial[(size_t)b * 2 * C + C + c];
+    (void)nchunks;
     const float inv = 1.f / (float)HW;
     const float d = s1 * inv;
     float var = s2 * inv - d * d;
@@ -110,12 +109,8 @@ __global__ void inorm_bwd_finalize_kernel(const float *__restrict__ partial, int
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= total) return;
     const int b = i / C, c = i - b * C;
-    float s1 = 0.f, s2 = 0.f;
-    for (int k = 0; k < nchunks; ++k) {
-        const float *p = partial + ((size_t)b * nchunks + k) * 2 * C;
-        s1 += p[c];
-        s2 += p[C + c];
-    }
+    const float s1 = partial[(size_t)b * 2 * C + c], s2 = partial[(size_t)b * 2 * C + C + c];
+    (void)nchunks;
     sums[(size_t)b * 2 * C + c] = s1;
     sums[(size_t)b * 2 * C + C + c] = s2;
     if (mode == 1) {
@@ -235,6 +230,7 @@ extern "C" int hoig_inorm_stats(const float *x, int B, int HW, int C, float eps,
     hipStream_t st = (hipStream_t)stream;
     const int nch = inorm_chunks(HW);
     float *partial = (float *)workspace;
+    if (hipMemsetAsync(partial, 0, (size_t)B * 2 * C * sizeof(float), st) != hipSuccess) return HOIG_ELAUNCH;
     inorm_partial_kernel<false><<<dim3(nch, B), NT, red_bytes(C), st>>>(x, nullptr, nullptr, 0, nullptr, nullptr,
                                                                         nullptr, 0, 0.f, HW, C, nch, partial);
     HOIG_LAUNCH_CHECK();
@@ -269,6 +265,7 @@ extern "C" int hoig_inorm_bwd(const float *x, const float *mean, const float *rs
     const int nch = inorm_chunks(HW);
     float *partial = (float *)workspace;
     float *sums = partial + (size_t)B * nch * 2 * C;
+    if (hipMemsetAsync(partial, 0, (size_t)B * 2 * C * sizeof(float), st) != hipSuccess) return HOIG_ELAUNCH;
     inorm_partial_kernel<true><<<dim3(nch, B), NT, red_bytes(C), st>>>(x, mean, rstd, mode, p0, y, dy, act, slope, HW, C,
                                                                        nch, partial);
     HOIG_LAUNCH_CHECK();
