@@ -747,7 +747,10 @@ __global__ __launch_bounds__(256) void wgrad_bf16_kernel(const WArgs p) {
     constexpr int PLANE_P = BK * RSTR, PLANE_Q = BK * RSTR;
     constexpr int STAGE = NS * (PLANE_P + PLANE_Q);
     constexpr int RP = BM / 32;                            // float4 loads per thread for P (BM/4 columns, 8 row lanes)
-    __shared__ __attribute__((aligned(16))) unsigned char smem[2 * STAGE];
+    // ONE LDS stage (40 KB): four workgroups (16 waves) share a CU, and their unsynchronised phases cover each other's
+    // load / LDS / barrier waits -- measured better than two 80 KB double-buffered workgroups (SQ_WAIT_ANY was 48 %)
+    constexpr int NSTAGE = 1;
+    __shared__ __attribute__((aligned(16))) unsigned char smem[NSTAGE * STAGE];
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave >> 1, wn = wave & 1;
@@ -893,9 +896,15 @@ __global__ __launch_bounds__(256) void wgrad_bf16_kernel(const WArgs p) {
                     acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[i], bh[j], acc[i][j], 0, 0, 0);
                 }
         }
-        if (nxt) store_tiles(cur ^ 1);
-        __syncthreads();
-        cur ^= 1;
+        if (NSTAGE == 2) {
+            if (nxt) store_tiles(cur ^ 1);
+            __syncthreads();
+            cur ^= 1;
+        } else {
+            __syncthreads();                  // every wave is done reading the stage
+            if (nxt) store_tiles(0);
+            __syncthreads();
+        }
     }
 
     const int l31 = lane & 31, lh = lane >> 5;
