@@ -121,7 +121,10 @@ __global__ __launch_bounds__(WM * WN * 64) void igemm_bf16_kernel(const Args p) 
     constexpr int STAGE = NS * (PLANE_A + PLANE_B);
     // two LDS stages: k-block t is multiplied out of one while k-block t+1 is converted into the other -> ONE barrier
     // per k-block; 64 KB at 128x128 (2 workgroups per CU)
-    __shared__ __attribute__((aligned(16))) unsigned char smem[2 * STAGE];
+    // BK = 32: ONE stage (32 KB at 128x128) so that four or five workgroups share a CU and cover each other's waits
+    // (same finding as for wgrad); BK = 64 keeps two stages
+    constexpr int NSTAGE = BK == 32 ? 1 : 2;
+    __shared__ __attribute__((aligned(16))) unsigned char smem[NSTAGE * STAGE];
 
     const Geom &g = p.g;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -286,9 +289,15 @@ __global__ __launch_bounds__(WM * WN * 64) void igemm_bf16_kernel(const Args p) 
                     acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[i], bhf[j], acc[i][j], 0, 0, 0);
                 }
         }
-        if (nxt) store_tiles(cur ^ 1);
-        __syncthreads();
-        cur ^= 1;
+        if (NSTAGE == 2) {
+            if (nxt) store_tiles(cur ^ 1);
+            __syncthreads();
+            cur ^= 1;
+        } else {
+            __syncthreads();
+            if (nxt) store_tiles(0);
+            __syncthreads();
+        }
         more = nxt;
     }
 
