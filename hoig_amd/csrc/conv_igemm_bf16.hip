@@ -15,6 +15,9 @@
 // exact-fp32 kernels of conv_igemm.hip.
 #include "common.h"
 #include <cstdlib>
+#ifndef HOIG_HALO_BSTAGES
+#define HOIG_HALO_BSTAGES 1
+#endif
 
 namespace {
 
@@ -416,7 +419,8 @@ __global__ __launch_bounds__(128 * WN) void conv_halo_bf16_kernel(const HaloArgs
     constexpr int TM = 2, TN = BN / (32 * WN);
     static_assert(TN >= 1, "BN = 64 needs the 4-wave variant");
     // LDS: one halo stage + two weight stages = 64 KB at KS=3 -> two workgroups per CU
-    __shared__ __attribute__((aligned(16))) unsigned char smem[NS * PLANE_A + 2 * NS * PLANE_B];
+    constexpr int NBST = HOIG_HALO_BSTAGES;                // weight stages in LDS
+    __shared__ __attribute__((aligned(16))) unsigned char smem[NS * PLANE_A + NBST * NS * PLANE_B];
     unsigned char *Ah = smem, *Al = smem + PLANE_A;
     unsigned char *Bst = smem + NS * PLANE_A;              // two stages of (Bh, Bl)
 
@@ -553,13 +557,11 @@ __global__ __launch_bounds__(128 * WN) void conv_halo_bf16_kernel(const HaloArgs
         if (step + 2 < T) load_b(step + 2, fh, fl);
         const bool boundary = (step % KK == KK - 1) && (step + 1 < T);
         if (boundary) halo_load(step / KK + 1);
-        compute(stage, step);
+        compute(NBST == 2 ? stage : 0, step);
         if (step + 1 < T) {
-            if (boundary) {
-                __syncthreads();                  // every wave has finished reading the current halo
-                halo_store();
-            }
-            store_b(stage ^ 1, nh, nl);
+            if (boundary || NBST == 1) __syncthreads();   // every wave has finished reading the halo / the single B stage
+            if (boundary) halo_store();
+            store_b(NBST == 2 ? (stage ^ 1) : 0, nh, nl);
             __syncthreads();
         }
     };
