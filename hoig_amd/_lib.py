@@ -57,6 +57,8 @@ _SIGS = {
     'hoig_conv2d_bwd_data_packed': [ctypes.POINTER(ConvDesc), _vp, _vp, _vp, _vp, _vp],
     'hoig_inorm_stats': [_vp, _i, _i, _i, _f, _vp, _vp, _vp, _vp],
     'hoig_inorm_apply': [_vp, _vp, _vp, _i, _vp, _vp, _i, _f, _vp, _vp, _i, _i, _i, _vp],
+    'hoig_inorm_apply_ld': [_vp, _vp, _vp, _i, _vp, _vp, _i, _i, _f, _vp, _vp, _i, _i, _i, _vp],
+    'hoig_inorm_bwd_ld': [_vp, _vp, _vp, _i, _vp, _i, _vp, _vp, _i, _f, _vp, _vp, _vp, _i, _i, _i, _vp, _vp],
     'hoig_inorm_bwd': [_vp, _vp, _vp, _i, _vp, _vp, _vp, _i, _f, _vp, _vp, _vp, _i, _i, _i, _vp, _vp],
     'hoig_replicate_pad_fwd': [_vp, _vp, _i, _i, _i, _i, _i, _vp],
     'hoig_replicate_pad_bwd': [_vp, _vp, _i, _i, _i, _i, _i, _vp],

@@ -24,7 +24,7 @@ __global__ __launch_bounds__(NT) void inorm_partial_kernel(const float *__restri
                                                            const float *__restrict__ rstd, int mode,
                                                            const float *__restrict__ p0, const float *__restrict__ y,
                                                            const float *__restrict__ dy, int act, float slope, int HW,
-                                                           int C, int nchunks, float *__restrict__ partial) {
+                                                           int C, int nchunks, float *__restrict__ partial, int ldp) {
     const int b = blockIdx.y, chunk = blockIdx.x;
     const int CV = C >> 2;                 // float4 columns
     const int rows_per = (HW + nchunks - 1) / nchunks;
@@ -60,7 +60,7 @@ __global__ __launch_bounds__(NT) void inorm_partial_kernel(const float *__restri
                     g.w *= hoig_act_grad_from_y(yy.w, act, slope);
                 }
                 if (mode == 2) {
-                    const float4 ga = *reinterpret_cast<const float4 *>(p0 + off);
+                    const float4 ga = *reinterpret_cast<const float4 *>(p0 + ((size_t)b * HW + r) * ldp + c);
                     g.x *= 1.f + ga.x; g.y *= 1.f + ga.y; g.z *= 1.f + ga.z; g.w *= 1.f + ga.w;
                 }
                 const float hx = (v.x - mu.x) * rs.x, hy = (v.y - mu.y) * rs.y, hz = (v.z - mu.z) * rs.z,
@@ -123,7 +123,7 @@ __global__ __launch_bounds__(NT) void inorm_apply_kernel(const float *__restrict
                                                          const float *__restrict__ rstd, int mode,
                                                          const float *__restrict__ p0, const float *__restrict__ p1,
                                                          int act, float slope, const float *__restrict__ residual,
-                                                         float *__restrict__ y, int HW, int C, int64_t n4) {
+                                                         float *__restrict__ y, int HW, int C, int64_t n4, int ldp) {
     const int CV = C >> 2;
     for (int64_t i = (int64_t)blockIdx.x * NT + threadIdx.x; i < n4; i += (int64_t)gridDim.x * NT) {
         const int cv = (int)(i % CV);
@@ -138,8 +138,8 @@ __global__ __launch_bounds__(NT) void inorm_apply_kernel(const float *__restrict
             sc = *reinterpret_cast<const float4 *>(p0 + c);
             sh = *reinterpret_cast<const float4 *>(p1 + c);
         } else if (mode == 2) {
-            sc = reinterpret_cast<const float4 *>(p0)[i];
-            sh = reinterpret_cast<const float4 *>(p1)[i];
+            sc = *reinterpret_cast<const float4 *>(p0 + (size_t)pix * ldp + c);
+            sh = *reinterpret_cast<const float4 *>(p1 + (size_t)pix * ldp + c);
             sc.x += 1.f; sc.y += 1.f; sc.z += 1.f; sc.w += 1.f;
         }
         float4 o;
@@ -161,7 +161,7 @@ __global__ __launch_bounds__(NT) void inorm_bwd_apply_kernel(const float *__rest
                                                              const float *__restrict__ dy, int act, float slope,
                                                              const float *__restrict__ sums, float *__restrict__ dx,
                                                              float *__restrict__ dp0, float *__restrict__ dp1, int HW,
-                                                             int C, int64_t n4) {
+                                                             int C, int64_t n4, int ldp) {
     const int CV = C >> 2;
     const float inv = 1.f / (float)HW;
     for (int64_t i = (int64_t)blockIdx.x * NT + threadIdx.x; i < n4; i += (int64_t)gridDim.x * NT) {
@@ -190,10 +190,10 @@ __global__ __launch_bounds__(NT) void inorm_bwd_apply_kernel(const float *__rest
             s1.x *= sc.x; s1.y *= sc.y; s1.z *= sc.z; s1.w *= sc.w;
             s2.x *= sc.x; s2.y *= sc.y; s2.z *= sc.z; s2.w *= sc.w;
         } else if (mode == 2) {
-            const float4 ga = reinterpret_cast<const float4 *>(p0)[i];
+            const float4 ga = *reinterpret_cast<const float4 *>(p0 + (size_t)pix * ldp + c);
             sc = make_float4(1.f + ga.x, 1.f + ga.y, 1.f + ga.z, 1.f + ga.w);
-            reinterpret_cast<float4 *>(dp0)[i] = make_float4(g.x * h.x, g.y * h.y, g.z * h.z, g.w * h.w);
-            reinterpret_cast<float4 *>(dp1)[i] = g;
+            *reinterpret_cast<float4 *>(dp0 + (size_t)pix * ldp + c) = make_float4(g.x * h.x, g.y * h.y, g.z * h.z, g.w * h.w);
+            *reinterpret_cast<float4 *>(dp1 + (size_t)pix * ldp + c) = g;
         }
         float4 o;
         o.x = rs.x * (g.x * sc.x - s1.x * inv - h.x * s2.x * inv);
@@ -232,7 +232,7 @@ extern "C" int hoig_inorm_stats(const float *x, int B, int HW, int C, float eps,
     float *partial = (float *)workspace;
     if (hipMemsetAsync(partial, 0, (size_t)B * 2 * C * sizeof(float), st) != hipSuccess) return HOIG_ELAUNCH;
     inorm_partial_kernel<false><<<dim3(nch, B), NT, red_bytes(C), st>>>(x, nullptr, nullptr, 0, nullptr, nullptr,
-                                                                        nullptr, 0, 0.f, HW, C, nch, partial);
+                                                                        nullptr, 0, 0.f, HW, C, nch, partial, C);
     HOIG_LAUNCH_CHECK();
     const int total = B * C;
     inorm_finalize_kernel<<<(total + 255) / 256, 256, 0, st>>>(x, partial, HW, C, nch, eps, mean, rstd, total);
@@ -240,22 +240,40 @@ extern "C" int hoig_inorm_stats(const float *x, int B, int HW, int C, float eps,
     return HOIG_OK;
 }
 
+extern "C" int hoig_inorm_apply_ld(const float *x, const float *mean, const float *rstd, int mode, const float *p0,
+                                   const float *p1, int ld_p, int act, float slope, const float *residual, float *y, int B,
+                                   int HW, int C, hoig_stream_t stream);
 extern "C" int hoig_inorm_apply(const float *x, const float *mean, const float *rstd, int mode, const float *p0,
                                 const float *p1, int act, float slope, const float *residual, float *y, int B, int HW,
                                 int C, hoig_stream_t stream) {
+    return hoig_inorm_apply_ld(x, mean, rstd, mode, p0, p1, C, act, slope, residual, y, B, HW, C, stream);
+}
+extern "C" int hoig_inorm_apply_ld(const float *x, const float *mean, const float *rstd, int mode, const float *p0,
+                                   const float *p1, int ld_p, int act, float slope, const float *residual, float *y, int B,
+                                   int HW, int C, hoig_stream_t stream) {
+    if (mode == 2 && (ld_p < C || (ld_p & 3))) return HOIG_EINVAL;
     if (!x || !mean || !rstd || !y || mode < 0 || mode > 2) return HOIG_EINVAL;
     if (mode != 0 && (!p0 || !p1)) return HOIG_EINVAL;
     if (C & 3) return HOIG_EUNSUPPORTED;
     const int64_t n4 = (int64_t)B * HW * C / 4;
     inorm_apply_kernel<<<hoig_stream_grid(n4, NT), NT, 0, (hipStream_t)stream>>>(x, mean, rstd, mode, p0, p1, act, slope,
-                                                                               residual, y, HW, C, n4);
+                                                                               residual, y, HW, C, n4, ld_p);
     HOIG_LAUNCH_CHECK();
     return HOIG_OK;
 }
 
+extern "C" int hoig_inorm_bwd_ld(const float *x, const float *mean, const float *rstd, int mode, const float *p0, int ld_p,
+                                 const float *y, const float *dy, int act, float slope, float *dx, float *dp0, float *dp1,
+                                 int B, int HW, int C, void *workspace, hoig_stream_t stream);
 extern "C" int hoig_inorm_bwd(const float *x, const float *mean, const float *rstd, int mode, const float *p0,
                               const float *y, const float *dy, int act, float slope, float *dx, float *dp0, float *dp1,
                               int B, int HW, int C, void *workspace, hoig_stream_t stream) {
+    return hoig_inorm_bwd_ld(x, mean, rstd, mode, p0, C, y, dy, act, slope, dx, dp0, dp1, B, HW, C, workspace, stream);
+}
+extern "C" int hoig_inorm_bwd_ld(const float *x, const float *mean, const float *rstd, int mode, const float *p0, int ld_p,
+                                 const float *y, const float *dy, int act, float slope, float *dx, float *dp0, float *dp1,
+                                 int B, int HW, int C, void *workspace, hoig_stream_t stream) {
+    if (mode == 2 && (ld_p < C || (ld_p & 3))) return HOIG_EINVAL;
     if (!x || !mean || !rstd || !dy || !dx || !workspace || mode < 0 || mode > 2) return HOIG_EINVAL;
     if (act != HOIG_ACT_NONE && !y) return HOIG_EINVAL;
     if (mode != 0 && !p0) return HOIG_EINVAL;
@@ -267,14 +285,14 @@ extern "C" int hoig_inorm_bwd(const float *x, const float *mean, const float *rs
     float *sums = partial + (size_t)B * nch * 2 * C;
     if (hipMemsetAsync(partial, 0, (size_t)B * 2 * C * sizeof(float), st) != hipSuccess) return HOIG_ELAUNCH;
     inorm_partial_kernel<true><<<dim3(nch, B), NT, red_bytes(C), st>>>(x, mean, rstd, mode, p0, y, dy, act, slope, HW, C,
-                                                                       nch, partial);
+                                                                       nch, partial, ld_p);
     HOIG_LAUNCH_CHECK();
     const int total = B * C;
     inorm_bwd_finalize_kernel<<<(total + 255) / 256, 256, 0, st>>>(partial, C, nch, mode, sums, dp0, dp1, total);
     HOIG_LAUNCH_CHECK();
     const int64_t n4 = (int64_t)B * HW * C / 4;
     inorm_bwd_apply_kernel<<<hoig_stream_grid(n4, NT), NT, 0, st>>>(x, mean, rstd, mode, p0, y, dy, act, slope, sums, dx,
-                                                                   dp0, dp1, HW, C, n4);
+                                                                   dp0, dp1, HW, C, n4, ld_p);
     HOIG_LAUNCH_CHECK();
     return HOIG_OK;
 }

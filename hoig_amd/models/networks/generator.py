@@ -62,6 +62,11 @@ class Generator(ParamTree):
         """spade.py:25-38 (+ the ReLU that always follows it, generator.py:66-67,88)."""
         s = self._seg_at(seg, x.shape[1], x.shape[2])
         actv = self._conv(s, name + '.mlp_shared.0', act=ACT_RELU)
+        if name + '.mlp_gb.weight' in self.F:
+            # mlp_gamma and mlp_beta are two 3x3 convs over the same activation (spade.py:33-34): run them as ONE conv with
+            # 2C outputs (their weights sit back to back in the flat store) and modulate from the [.,2C] result in place
+            gb = ops.conv2d(actv, self.F[name + '.mlp_gb.weight'], self.F[name + '.mlp_gb.bias'], 1, 1)
+            return ops.spade_norm_fused(x, gb, act=act)
         gamma = self._conv(actv, name + '.mlp_gamma')
         beta = self._conv(actv, name + '.mlp_beta')
         return ops.spade_norm(x, gamma, beta, act=act)

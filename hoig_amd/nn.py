@@ -65,9 +65,22 @@ class ParamTree(nn.Module):
             else:
                 internal[name] = (tuple(shp), name in tset)
         self._internal = internal
+        # memory order: the reference order, except that SPADE's mlp_gamma / mlp_beta conv weights (and their biases) are
+        # placed back to back so the pair is ONE packed conv weight [2C][3][3][128] (fused views in self.F, below)
+        order = [n for n in internal if '.mlp_beta.' not in n]
+        fused = []
+        for n in list(order):
+            if n.endswith('.mlp_gamma.weight'):
+                pre = n[:-len('.mlp_gamma.weight')]
+                order.insert(order.index(n) + 1, pre + '.mlp_beta.weight')
+                fused.append(pre)
+            elif n.endswith('.mlp_gamma.bias'):
+                order.insert(order.index(n) + 1, n.replace('.mlp_gamma.', '.mlp_beta.'))
+        assert sorted(order) == sorted(internal), 'allocation order lost a parameter'
         total = 0
         self._offsets = OrderedDict()
-        for name, (shp, _) in internal.items():
+        for name in order:
+            shp = internal[name][0]
             self._offsets[name] = total
             total += (_numel(shp) + 3) // 4 * 4           # keep every parameter 16-byte aligned
         self.flat = torch.zeros(total, dtype=torch.float32, device=device)
@@ -83,6 +96,22 @@ class ParamTree(nn.Module):
             p._hoig_owner = self
             self.P[name] = p
             self._register(name, p)
+        # fused gamma|beta views (aliases of the two adjacent parameters; not separate entries of P / state_dict)
+        self.F = OrderedDict()
+        for pre in fused:
+            cg = internal[pre + '.mlp_gamma.weight'][0]
+            if _numel(cg) % 4 or cg[0] % 4:
+                continue
+            off_w, off_b = self._offsets[pre + '.mlp_gamma.weight'], self._offsets[pre + '.mlp_gamma.bias']
+            assert self._offsets[pre + '.mlp_beta.weight'] == off_w + _numel(cg)
+            assert self._offsets[pre + '.mlp_beta.bias'] == off_b + cg[0]
+            shp = (2 * cg[0],) + tuple(cg[1:])
+            for key, o, sh, st in ((pre + '.mlp_gb.weight', off_w, shp, packed_strides(shp, False)),
+                                   (pre + '.mlp_gb.bias', off_b, (2 * cg[0],), (1,))):
+                v = nn.Parameter(self.flat.as_strided(sh, st, o), requires_grad=True)
+                v.grad = self.flat_grad.as_strided(sh, st, o)
+                v._hoig_flat, v._hoig_transposed, v._hoig_owner = True, False, self
+                self.F[key] = v
 
     def _register(self, dotted, p):
         parts = dotted.split('.')
@@ -159,7 +188,7 @@ class ParamTree(nn.Module):
         self.flat_grad.zero_()
 
     def set_requires_grad(self, flag):
-        for p in self.P.values():
+        for p in list(self.P.values()) + list(self.F.values()):
             p.requires_grad_(flag)
 
     def cuda(self, device=None):      # storage is created on the target device; moving would break the flat views

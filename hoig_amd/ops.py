@@ -215,6 +215,45 @@ def spade_norm(x, gamma, beta, act=L.ACT_NONE, slope=0.0, eps=1e-5):
     return _INorm.apply(x, gamma, beta, 2, act, slope, None, eps)
 
 
+class _SpadeFused(Function):
+    """IN(x) * (1 + gamma) + beta with gamma | beta side by side in ONE tensor gb [B,H,W,2C] (the output of the fused
+    gamma|beta convolution); the backward writes dgamma | dbeta straight into the matching [.,2C] gradient."""
+
+    @staticmethod
+    def forward(ctx, x, gb, act, slope, eps):
+        _chk(x); _chk(gb)
+        assert x.is_contiguous() and gb.is_contiguous()
+        B, H, W, C = x.shape
+        assert gb.shape[-1] == 2 * C
+        HW = H * W
+        ws = torch.empty(L.lib.hoig_inorm_workspace_bytes(B, HW, C) // 4, dtype=torch.float32, device=x.device)
+        mean = torch.empty(B * C, dtype=torch.float32, device=x.device)
+        rstd = torch.empty_like(mean)
+        call('hoig_inorm_stats', _p(x), B, HW, C, eps, _p(mean), _p(rstd), _p(ws), _st())
+        y = torch.empty_like(x)
+        call('hoig_inorm_apply_ld', _p(x), _p(mean), _p(rstd), 2, _p(gb), gb.data_ptr() + 4 * C, 2 * C, act, slope, None,
+             _p(y), B, HW, C, _st())
+        ctx.cfg = (act, slope, B, HW, C)
+        ctx.save_for_backward(x, mean, rstd, gb, y if act != L.ACT_NONE else None)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, mean, rstd, gb, y = ctx.saved_tensors
+        act, slope, B, HW, C = ctx.cfg
+        dy = dy.contiguous()
+        ws = torch.empty(L.lib.hoig_inorm_workspace_bytes(B, HW, C) // 4, dtype=torch.float32, device=x.device)
+        dx = torch.empty_like(x)
+        dgb = torch.empty_like(gb)
+        call('hoig_inorm_bwd_ld', _p(x), _p(mean), _p(rstd), 2, _p(gb), 2 * C, _p(y), _p(dy), act, slope, _p(dx), _p(dgb),
+             dgb.data_ptr() + 4 * C, B, HW, C, _p(ws), _st())
+        return dx, dgb, None, None, None
+
+
+def spade_norm_fused(x, gb, act=L.ACT_NONE, slope=0.0, eps=1e-5):
+    return _SpadeFused.apply(x, gb, act, slope, eps)
+
+
 # ------------------------------------------------------------------------------------------------- small ops
 class _Add(Function):
     @staticmethod

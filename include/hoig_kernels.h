@@ -89,6 +89,14 @@ int hoig_inorm_stats(const float *x, int B, int HW, int C, float eps, float *mea
 int hoig_inorm_apply(const float *x, const float *mean, const float *rstd, int mode, const float *p0, const float *p1,
                      int act, float slope, const float *residual /*nullable*/, float *y, int B, int HW, int C,
                      hoig_stream_t stream);
+/* same with gamma/beta rows `ld_p` floats apart (mode 2 only): lets gamma and beta live side by side in ONE [.,2C] tensor
+ * (the output of the fused gamma|beta convolution), p0 = gb, p1 = gb + C, ld_p = 2C */
+int hoig_inorm_apply_ld(const float *x, const float *mean, const float *rstd, int mode, const float *p0, const float *p1,
+                        int ld_p, int act, float slope, const float *residual /*nullable*/, float *y, int B, int HW, int C,
+                        hoig_stream_t stream);
+int hoig_inorm_bwd_ld(const float *x, const float *mean, const float *rstd, int mode, const float *p0, int ld_p,
+                      const float *y, const float *dy, int act, float slope, float *dx, float *dp0, float *dp1, int B, int HW,
+                      int C, void *workspace, hoig_stream_t stream);
 /* backward of hoig_inorm_apply(+stats).  dy is d/d(y) ; y is the forward output (for the activation mask; pass
  * the pre-residual activation output, or NULL when act==NONE).
  * Outputs: dx; mode 1: dweight[c] += , dbias[c] += ; mode 2: dgamma, dbeta (same shape as x, overwritten).
