@@ -353,6 +353,35 @@ __global__ void pack_weight_kernel(const float *__restrict__ w, int Co, int RS, 
     }
 }
 
+// Every conv weight of a network in ONE launch: `segs` holds (offset, Co, RS, Ci, flags) per weight of the flat parameter
+// buffer; plane element i of a weight lands at the weight's own offset in the plane buffers.  blockIdx.y = weight.
+__global__ void pack_all_kernel(const float *__restrict__ flat, const int64_t *__restrict__ segs,
+                                unsigned short *__restrict__ hi_f, unsigned short *__restrict__ lo_f,
+                                unsigned short *__restrict__ hi_d, unsigned short *__restrict__ lo_d) {
+    const int64_t *sg = segs + (int64_t)blockIdx.y * 5;
+    const int64_t off = sg[0];
+    const int Co = (int)sg[1], RS = (int)sg[2], Ci = (int)sg[3], flags = (int)sg[4];
+    const int64_t n = (int64_t)Co * RS * Ci;
+    const float *w = flat + off;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+        if (flags & 1) {
+            const float x = w[i];
+            const unsigned short h = hoig_f2bf(x);
+            hi_f[off + i] = h;
+            lo_f[off + i] = hoig_f2bf(x - hoig_bf2f(h));
+        }
+        if (flags & 2) {   // i enumerates [ci][rs][co]
+            const int co = (int)(i % Co);
+            const int64_t t = i / Co;
+            const int rs = (int)(t % RS), ci = (int)(t / RS);
+            const float x = w[((int64_t)co * RS + rs) * Ci + ci];
+            const unsigned short h = hoig_f2bf(x);
+            hi_d[off + i] = h;
+            lo_d[off + i] = hoig_f2bf(x - hoig_bf2f(h));
+        }
+    }
+}
+
 template <int BM, int BN, int WM, int WN, int BK = 32>
 int launch(Args a, int ns, hipStream_t st) {
     constexpr int NT = WM * WN * 64;
@@ -693,6 +722,14 @@ extern "C" int hoig_pack_conv_weight_bf16(const float *w, int Co, int RS, int Ci
     if (!w || !hi || Co <= 0 || RS <= 0 || Ci <= 0) return HOIG_EINVAL;
     const int64_t n = (int64_t)Co * RS * Ci;
     pack_weight_kernel<<<hoig_stream_grid(n, 256), 256, 0, (hipStream_t)stream>>>(w, Co, RS, Ci, for_dgrad ? 1 : 0, hi, lo);
+    HOIG_LAUNCH_CHECK();
+    return HOIG_OK;
+}
+
+extern "C" int hoig_pack_conv_weights_bf16_all(const float *flat, const int64_t *segs, int nseg, uint16_t *hi_f,
+                                               uint16_t *lo_f, uint16_t *hi_d, uint16_t *lo_d, hoig_stream_t stream) {
+    if (!flat || !segs || nseg <= 0 || !hi_f || !lo_f || !hi_d || !lo_d) return HOIG_EINVAL;
+    pack_all_kernel<<<dim3(48, nseg), 256, 0, (hipStream_t)stream>>>(flat, segs, hi_f, lo_f, hi_d, lo_d);
     HOIG_LAUNCH_CHECK();
     return HOIG_OK;
 }

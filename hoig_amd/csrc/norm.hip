@@ -11,8 +11,10 @@ namespace {
 constexpr int NT = 256;
 
 __host__ __device__ inline int inorm_chunks(int HW) {
-    int n = (HW + 63) / 64;
-    if (n > 128) n = 128;
+    // 16 pixel rows per workgroup (partials are combined with atomics, so many small chunks cost nothing extra and a
+    // 32x32 map already yields 64 workgroups per image)
+    int n = (HW + 15) / 16;
+    if (n > 512) n = 512;
     if (n < 1) n = 1;
     return n;
 }

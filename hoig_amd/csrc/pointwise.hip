@@ -327,8 +327,9 @@ extern "C" int hoig_act_bwd(const float *y, const float *dy, float *dx, int act,
 }
 extern "C" int hoig_colsum_accum(const float *x, float *out, int64_t rows, int C, hoig_stream_t stream) {
     if (!x || !out || C <= 0) return HOIG_EINVAL;
-    int64_t nblk = hoig_cdiv(rows, 64);
-    if (nblk > 1024) nblk = 1024;
+    // ~32 rows per workgroup, at least ~1024 workgroups for large tensors: the kernel streams x once (HBM-bound)
+    int64_t nblk = hoig_cdiv(rows, 32);
+    if (nblk > 4096) nblk = 4096;
     const int64_t rpb = hoig_cdiv(rows, nblk);
     nblk = hoig_cdiv(rows, rpb);
     const int lanes = C < NT ? C : NT;

@@ -113,6 +113,54 @@ class ParamTree(nn.Module):
                 v._hoig_flat, v._hoig_transposed, v._hoig_owner = True, False, self
                 self.F[key] = v
 
+        self._plane_bufs = None
+        self._plane_version = -1
+        self._plane_flags = {}
+
+    # --- split-bf16 operand planes of every conv weight, refreshed by ONE kernel launch per weight version
+    def _build_plane_table(self):
+        rows = []
+        used = [(n, self._internal[n][0]) for n in self._offsets
+                if len(self._internal[n][0]) == 4 and not (('.mlp_gamma.' in n or '.mlp_beta.' in n)
+                                                            and n.replace('.mlp_gamma.', '.mlp_gb.').replace(
+                                                                '.mlp_beta.', '.mlp_gb.') in self.F)]
+        used = [(self._offsets[n], shp, self._internal[n][1]) for n, shp in used]
+        for key, v in self.F.items():
+            if v.dim() == 4:
+                used.append((v.storage_offset(), tuple(v.shape), False))
+        for off, shp, transposed in used:
+            ci, co = (shp[0], shp[1]) if transposed else (shp[1], shp[0])
+            flags = (1 if (ci % 32 == 0 and co > 32) else 0) | (2 if (co % 32 == 0 and ci > 32) else 0)
+            if flags:
+                rows.append([off, co, shp[2] * shp[3], ci, flags])
+                self._plane_flags[off] = flags
+        return rows
+
+    def packed_planes(self, w, for_dgrad):
+        """(hi, lo) bf16 planes of conv weight `w` (a view of self.flat) for the forward (for_dgrad=False) or data-
+        gradient GEMM, or None if `w` is not in the table (hoig_pack_conv_weights_bf16_all, include/hoig_kernels.h)."""
+        if self._plane_bufs is None:
+            rows = self._build_plane_table()
+            if not rows:
+                self._plane_bufs = ()
+                return None
+            self._plane_table = torch.tensor(rows, dtype=torch.int64, device=self.flat.device)
+            self._plane_bufs = tuple(torch.empty(self.flat.numel(), dtype=torch.int16, device=self.flat.device)
+                                     for _ in range(4))
+        if not self._plane_bufs:
+            return None
+        off = w.storage_offset()
+        if not (self._plane_flags.get(off, 0) & (2 if for_dgrad else 1)) or w.data_ptr() != self.flat.data_ptr() + 4 * off:
+            return None
+        if self._plane_version != self.version:
+            b = self._plane_bufs
+            L.call('hoig_pack_conv_weights_bf16_all', _p(self.flat), _p(self._plane_table), self._plane_table.shape[0],
+                   _p(b[0]), _p(b[1]), _p(b[2]), _p(b[3]), _st())
+            self._plane_version = self.version
+        n = w.numel()
+        hi, lo = (self._plane_bufs[2], self._plane_bufs[3]) if for_dgrad else (self._plane_bufs[0], self._plane_bufs[1])
+        return hi[off:off + n], lo[off:off + n]
+
     def _register(self, dotted, p):
         parts = dotted.split('.')
         mod = self

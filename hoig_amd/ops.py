@@ -84,6 +84,10 @@ def _packed_planes(w, transposed, for_dgrad):
     else:
         co, ci, r, s = w.shape
     owner = getattr(w, '_hoig_owner', None)
+    if owner is not None:
+        planes = owner.packed_planes(w, for_dgrad)      # all weights of the network split in one launch per step
+        if planes is not None:
+            return planes
     key = (w.data_ptr(), for_dgrad)
     ver = owner.version if owner is not None else None
     hit = _pack_cache.get(key)
