@@ -353,31 +353,61 @@ __global__ void pack_weight_kernel(const float *__restrict__ w, int Co, int RS, 
     }
 }
 
-// Every conv weight of a network in ONE launch: `segs` holds (offset, Co, RS, Ci, flags) per weight of the flat parameter
-// buffer; plane element i of a weight lands at the weight's own offset in the plane buffers.  blockIdx.y = weight.
-__global__ void pack_all_kernel(const float *__restrict__ flat, const int64_t *__restrict__ segs,
-                                unsigned short *__restrict__ hi_f, unsigned short *__restrict__ lo_f,
-                                unsigned short *__restrict__ hi_d, unsigned short *__restrict__ lo_d) {
-    const int64_t *sg = segs + (int64_t)blockIdx.y * 5;
+// Every conv weight of a network in ONE launch: `segs` holds (offset, Co, RS, Ci, flags, first tile) per weight of the
+// flat parameter buffer; the planes of a weight land at the weight's own offset in the plane buffers.  A workgroup owns one
+// 32(co) x 32(ci) tile of one weight (binary search over the tile prefix) and walks its RS taps: rows are read coalesced
+// along ci, the forward planes written in place, the data-gradient planes ([Ci][RS][Co]) written coalesced along co after a
+// transpose through LDS.
+__global__ __launch_bounds__(256) void pack_all_kernel(const float *__restrict__ flat, const int64_t *__restrict__ segs,
+                                                       int nseg, unsigned short *__restrict__ hi_f,
+                                                       unsigned short *__restrict__ lo_f,
+                                                       unsigned short *__restrict__ hi_d,
+                                                       unsigned short *__restrict__ lo_d) {
+    int lo_s = 0, hi_s = nseg - 1;
+    while (lo_s < hi_s) {                 // last segment whose first tile <= blockIdx.x
+        const int mid = (lo_s + hi_s + 1) >> 1;
+        if (segs[(int64_t)mid * 6 + 5] <= (int64_t)blockIdx.x) lo_s = mid; else hi_s = mid - 1;
+    }
+    const int64_t *sg = segs + (int64_t)lo_s * 6;
     const int64_t off = sg[0];
     const int Co = (int)sg[1], RS = (int)sg[2], Ci = (int)sg[3], flags = (int)sg[4];
-    const int64_t n = (int64_t)Co * RS * Ci;
+    const int t = (int)((int64_t)blockIdx.x - sg[5]);
+    const int tiles_ci = (Ci + 31) >> 5;
+    const int co0 = (t / tiles_ci) * 32, ci0 = (t % tiles_ci) * 32;
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+    __shared__ unsigned int tile[32][33];
     const float *w = flat + off;
-    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
-        if (flags & 1) {
-            const float x = w[i];
-            const unsigned short h = hoig_f2bf(x);
-            hi_f[off + i] = h;
-            lo_f[off + i] = hoig_f2bf(x - hoig_bf2f(h));
+    for (int rs = 0; rs < RS; ++rs) {
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const int co = co0 + ty + 8 * k, ci = ci0 + tx;
+            unsigned int pk = 0;
+            if (co < Co && ci < Ci) {
+                const int64_t i = ((int64_t)co * RS + rs) * Ci + ci;
+                const float x = w[i];
+                const unsigned short h = hoig_f2bf(x);
+                const unsigned short l = hoig_f2bf(x - hoig_bf2f(h));
+                if (flags & 1) {
+                    hi_f[off + i] = h;
+                    lo_f[off + i] = l;
+                }
+                pk = (unsigned int)h | ((unsigned int)l << 16);
+            }
+            tile[ty + 8 * k][tx] = pk;
         }
-        if (flags & 2) {   // i enumerates [ci][rs][co]
-            const int co = (int)(i % Co);
-            const int64_t t = i / Co;
-            const int rs = (int)(t % RS), ci = (int)(t / RS);
-            const float x = w[((int64_t)co * RS + rs) * Ci + ci];
-            const unsigned short h = hoig_f2bf(x);
-            hi_d[off + i] = h;
-            lo_d[off + i] = hoig_f2bf(x - hoig_bf2f(h));
+        if (flags & 2) {
+            __syncthreads();
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const int ci = ci0 + ty + 8 * k, co = co0 + tx;
+                if (co < Co && ci < Ci) {
+                    const unsigned int pk = tile[tx][ty + 8 * k];
+                    const int64_t o = off + ((int64_t)ci * RS + rs) * Co + co;
+                    hi_d[o] = (unsigned short)(pk & 0xffffu);
+                    lo_d[o] = (unsigned short)(pk >> 16);
+                }
+            }
+            __syncthreads();
         }
     }
 }
@@ -726,10 +756,11 @@ extern "C" int hoig_pack_conv_weight_bf16(const float *w, int Co, int RS, int Ci
     return HOIG_OK;
 }
 
-extern "C" int hoig_pack_conv_weights_bf16_all(const float *flat, const int64_t *segs, int nseg, uint16_t *hi_f,
-                                               uint16_t *lo_f, uint16_t *hi_d, uint16_t *lo_d, hoig_stream_t stream) {
-    if (!flat || !segs || nseg <= 0 || !hi_f || !lo_f || !hi_d || !lo_d) return HOIG_EINVAL;
-    pack_all_kernel<<<dim3(48, nseg), 256, 0, (hipStream_t)stream>>>(flat, segs, hi_f, lo_f, hi_d, lo_d);
+extern "C" int hoig_pack_conv_weights_bf16_all(const float *flat, const int64_t *segs, int nseg, int64_t ntiles,
+                                               uint16_t *hi_f, uint16_t *lo_f, uint16_t *hi_d, uint16_t *lo_d,
+                                               hoig_stream_t stream) {
+    if (!flat || !segs || nseg <= 0 || ntiles <= 0 || !hi_f || !lo_f || !hi_d || !lo_d) return HOIG_EINVAL;
+    pack_all_kernel<<<(unsigned)ntiles, 256, 0, (hipStream_t)stream>>>(flat, segs, nseg, hi_f, lo_f, hi_d, lo_d);
     HOIG_LAUNCH_CHECK();
     return HOIG_OK;
 }

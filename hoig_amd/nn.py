@@ -116,6 +116,7 @@ class ParamTree(nn.Module):
         self._plane_bufs = None
         self._plane_version = -1
         self._plane_flags = {}
+        self._plane_tiles = 0
 
     # --- split-bf16 operand planes of every conv weight, refreshed by ONE kernel launch per weight version
     def _build_plane_table(self):
@@ -132,7 +133,8 @@ class ParamTree(nn.Module):
             ci, co = (shp[0], shp[1]) if transposed else (shp[1], shp[0])
             flags = (1 if (ci % 32 == 0 and co > 32) else 0) | (2 if (co % 32 == 0 and ci > 32) else 0)
             if flags:
-                rows.append([off, co, shp[2] * shp[3], ci, flags])
+                rows.append([off, co, shp[2] * shp[3], ci, flags, self._plane_tiles])
+                self._plane_tiles += ((co + 31) // 32) * ((ci + 31) // 32)
                 self._plane_flags[off] = flags
         return rows
 
@@ -155,7 +157,7 @@ class ParamTree(nn.Module):
         if self._plane_version != self.version:
             b = self._plane_bufs
             L.call('hoig_pack_conv_weights_bf16_all', _p(self.flat), _p(self._plane_table), self._plane_table.shape[0],
-                   _p(b[0]), _p(b[1]), _p(b[2]), _p(b[3]), _st())
+                   self._plane_tiles, _p(b[0]), _p(b[1]), _p(b[2]), _p(b[3]), _st())
             self._plane_version = self.version
         n = w.numel()
         hi, lo = (self._plane_bufs[2], self._plane_bufs[3]) if for_dgrad else (self._plane_bufs[0], self._plane_bufs[1])

@@ -73,10 +73,11 @@ int hoig_conv2d_bwd_weight(const hoig_conv_desc *d, const float *x, const float 
 int hoig_pack_conv_weight_bf16(const float *w, int Co, int RS, int Ci, int for_dgrad, uint16_t *hi, uint16_t *lo /*nullable*/,
                                hoig_stream_t stream);
 /* The same split for every conv weight of a network's flat parameter buffer in one launch.  segs (device memory) holds
- * nseg rows of 5 int64: {element offset in flat, Co, R*S, Ci, flags (1: forward planes, 2: data-gradient planes)}; the
- * planes of a weight are written at the weight's own element offset of hi_f/lo_f (forward) and hi_d/lo_d (dgrad). */
-int hoig_pack_conv_weights_bf16_all(const float *flat, const int64_t *segs, int nseg, uint16_t *hi_f, uint16_t *lo_f,
-                                    uint16_t *hi_d, uint16_t *lo_d, hoig_stream_t stream);
+ * nseg rows of 6 int64: {element offset in flat, Co, R*S, Ci, flags (1: forward planes, 2: data-gradient planes), index
+ * of the weight's first 32x32 (co, ci) tile}; ntiles = total tile count (the grid).  The planes of a weight are written
+ * at the weight's own element offset of hi_f/lo_f (forward) and hi_d/lo_d (dgrad). */
+int hoig_pack_conv_weights_bf16_all(const float *flat, const int64_t *segs, int nseg, int64_t ntiles, uint16_t *hi_f,
+                                    uint16_t *lo_f, uint16_t *hi_d, uint16_t *lo_d, hoig_stream_t stream);
 int hoig_conv2d_fwd_packed(const hoig_conv_desc *d, const float *x, const uint16_t *w_hi, const uint16_t *w_lo,
                            const float *bias /*nullable*/, float *y, hoig_stream_t stream);
 int hoig_conv2d_bwd_data_packed(const hoig_conv_desc *d, const float *dy, const uint16_t *wt_hi, const uint16_t *wt_lo,

@@ -355,3 +355,39 @@ def test_conv_bf16x3_fast_path(B, Ci, Co, H, k, stride, pad, transposed):
     assert rel_err(nchw_cpu(y), yr) < 3e-4
     assert rel_err(nchw_cpu(xd.grad), xr.grad) < 3e-4
     assert rel_err(wd.grad, wr.grad) < 3e-4
+
+
+def test_batched_weight_split_matches_per_weight_split():
+    """hoig_pack_conv_weights_bf16_all (one launch over a network's flat buffer, LDS-tiled transpose for the data-gradient
+    planes) must produce exactly the planes hoig_pack_conv_weight_bf16 produces weight by weight, including for the fused
+    SPADE gamma|beta view and a ConvTranspose weight."""
+    import ctypes
+    from hoig_amd import _lib as L
+    from hoig_amd.nn import ParamTree
+    from hoig_amd.ops import _p, _st
+    shapes = [('a.weight', (64, 96, 3, 3)), ('a.bias', (64,)),
+              ('s.mlp_gamma.weight', (40, 128, 3, 3)), ('s.mlp_gamma.bias', (40,)),
+              ('s.mlp_beta.weight', (40, 128, 3, 3)), ('s.mlp_beta.bias', (40,)),
+              ('up.weight', (128, 64, 3, 3)), ('head.weight', (3, 64, 7, 7)), ('one.weight', (128, 800, 1, 1))]
+    tree = ParamTree(shapes, torch.device('cuda'), transposed_names=('up.weight',))
+    torch.manual_seed(3)
+    tree.flat.normal_()
+    tree.version += 1
+    checked = 0
+    for name, w, transposed in [('a.weight', tree.P['a.weight'], False), ('gb', tree.F['s.mlp_gb.weight'], False),
+                                ('up.weight', tree.P['up.weight'], True), ('one.weight', tree.P['one.weight'], False)]:
+        ci, co = (w.shape[0], w.shape[1]) if transposed else (w.shape[1], w.shape[0])
+        for for_dgrad in (False, True):
+            got = tree.packed_planes(w, for_dgrad)
+            eligible = (co % 32 == 0 and ci > 32) if for_dgrad else (ci % 32 == 0 and co > 32)
+            assert (got is not None) == eligible, (name, for_dgrad)
+            if got is None:
+                continue
+            hi = torch.empty(w.numel(), dtype=torch.int16, device='cuda')
+            lo = torch.empty_like(hi)
+            L.call('hoig_pack_conv_weight_bf16', _p(w), co, w.shape[2] * w.shape[3], ci, 1 if for_dgrad else 0,
+                   _p(hi), _p(lo), _st())
+            assert torch.equal(got[0], hi) and torch.equal(got[1], lo), (name, for_dgrad)
+            checked += 1
+    assert checked >= 6
+    assert tree.packed_planes(tree.P['head.weight'], False) is None
