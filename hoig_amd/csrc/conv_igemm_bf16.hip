@@ -1021,6 +1021,183 @@ int launch_wgrad_bf16(WArgs a, int ns, hipStream_t st) {
     return HOIG_OK;
 }
 
+// ---------------------------------------------------------------------------------------------------------------------
+// Weight gradient of stride-1 "same" 3x3 convolutions with an LDS-resident INPUT HALO.  The kernel above re-reads both
+// operands from L2 for every (co tile, tap, ci tile) pair -- 30 KB per MFLOP, which at full matrix rate would need
+// ~42 B/clk/CU from a 64 B/clk load path -- and is bound there.  Here a workgroup owns dW[64 co][9 taps][32 ci]: per
+// m-tile (2 rows x 32 output pixels) it stages dy[64 px][64 co] and the x halo [4 x 34 px][32 ci] ONCE (split to bf16
+// hi/lo, rows as they arrive) and all nine taps read their x fragments out of the same halo image at a tap-dependent
+// row offset: 14 KB per MFLOP.  Six waves: wave = (co half, tap row); each accumulates 32 co x 32 ci for the three taps
+// of its row (48 accumulator registers, so three workgroups = 18 waves share a CU).
+// Both operands want pixels along k, so both are read with ds_read_b64_tr_b16; the halo rows are 64 B apart (no pad):
+// the four rows a 32-lane half reads (256 B) cover all 64 banks once for any row offset.  dy rows are 192 B apart.
+struct WHaloArgs {
+    const float *DY, *X;
+    float *DW;
+    int Bn, H, W, Co, Ci;
+    int tiles_x, tiles_y, n_mtiles, mt_per_split;
+    int nblk_ci, nblk;
+};
+
+template <int NS>
+__global__ __launch_bounds__(384) void wgrad_halo_bf16_kernel(const WHaloArgs p) {
+    constexpr int KS = 3, TH = 2, TW = 32, BM = 64, BC = 32, NT = 384;
+    constexpr int HH = TH + KS - 1, HWID = TW + KS - 1, HPIX = HH * HWID;     // 4 x 34 halo pixels
+    constexpr int PSTR = 192, QSTR = 64;
+    constexpr int PLANE_P = TH * TW * PSTR, PLANE_Q = ((HPIX * QSTR + 255) / 256) * 256;
+    __shared__ __attribute__((aligned(16))) unsigned char smem[NS * (PLANE_P + PLANE_Q)];
+    unsigned char *Ph = smem, *Pl = smem + PLANE_P;
+    unsigned char *Qh = smem + NS * PLANE_P, *Ql = Qh + PLANE_Q;
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int cb = wave & 1, tr = wave >> 1;               // co half, tap row
+    const int tile = hoig_xcd_remap(blockIdx.x, p.nblk);
+    const int c0 = (tile / p.nblk_ci) * BM, ci0 = (tile % p.nblk_ci) * BC;
+    const int mt_begin = blockIdx.y * p.mt_per_split;
+    const int mt_end = min(p.n_mtiles, mt_begin + p.mt_per_split);
+
+    constexpr int PSL = (TH * TW * 16 + NT - 1) / NT;      // dy float4s per thread (3)
+    constexpr int QSL = (HPIX * 8 + NT - 1) / NT;          // halo float4s per thread (3)
+    float4 rp[PSL], rq[QSL];
+    auto load_tiles = [&](int mt) {
+        const int tx = mt % p.tiles_x;
+        const int t2 = mt / p.tiles_x;
+        const int ty = t2 % p.tiles_y, b = t2 / p.tiles_y;
+        const int y0 = ty * TH, x0 = tx * TW;
+        const float *dyb = p.DY + (((size_t)b * p.H + y0) * p.W + x0) * p.Co + c0;
+#pragma unroll
+        for (int i = 0; i < PSL; ++i) {
+            const int idx = tid + NT * i;
+            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (idx < TH * TW * 16) {
+                const int pp = idx >> 4, c4 = idx & 15;    // pixel of the tile: row pp>>5, column pp&31
+                v = *reinterpret_cast<const float4 *>(dyb + ((size_t)(pp >> 5) * p.W + (pp & 31)) * p.Co + c4 * 4);
+            }
+            rp[i] = v;
+        }
+        const float *xb = p.X + (size_t)b * p.H * p.W * p.Ci + ci0;
+#pragma unroll
+        for (int i = 0; i < QSL; ++i) {
+            const int idx = tid + NT * i;
+            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (idx < HPIX * 8) {
+                const int hp = idx >> 3, c4 = idx & 7;
+                const int hy = hp / HWID, hx = hp - hy * HWID;
+                const int gy = y0 - 1 + hy, gx = x0 - 1 + hx;
+                if (gy >= 0 && gy < p.H && gx >= 0 && gx < p.W)
+                    v = *reinterpret_cast<const float4 *>(xb + ((size_t)gy * p.W + gx) * p.Ci + c4 * 4);
+            }
+            rq[i] = v;
+        }
+    };
+    auto store_tiles = [&]() {
+#pragma unroll
+        for (int i = 0; i < PSL; ++i) {
+            const int idx = tid + NT * i;
+            if (idx < TH * TW * 16) {
+                uint2 hi, lo;
+                split4(rp[i], hi, lo);
+                const int off = (idx >> 4) * PSTR + (idx & 15) * 8;
+                *reinterpret_cast<uint2 *>(Ph + off) = hi;
+                if (NS == 2) *reinterpret_cast<uint2 *>(Pl + off) = lo;
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < QSL; ++i) {
+            const int idx = tid + NT * i;
+            if (idx < HPIX * 8) {
+                uint2 hi, lo;
+                split4(rq[i], hi, lo);
+                *reinterpret_cast<uint2 *>(Qh + idx * 8) = hi;
+                if (NS == 2) *reinterpret_cast<uint2 *>(Ql + idx * 8) = lo;
+            }
+        }
+    };
+
+    // transpose-read addressing (see wgrad_bf16_kernel): 16-lane group g, lane 4q+c -> row 8*(g>>1)+q, channels 16*(g&1)+4c
+    const int grp = lane >> 4, li = lane & 15;
+    const int trow = (grp >> 1) * 8 + (li >> 2), tch = ((grp & 1) * 16 + (li & 3) * 4) * 2;
+    const int trP = trow * PSTR + tch + cb * 64, trQ = (trow + tr * HWID) * QSTR + tch;
+    typedef short s4_t __attribute__((ext_vector_type(4)));
+    auto frag = [&](const unsigned char *a, int stride4) -> bf16x8 {
+        const s4_t lo4 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s4_t *)a);
+        const s4_t hi4 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s4_t *)(a + stride4));
+        bf16x8 f;
+        f[0] = lo4[0]; f[1] = lo4[1]; f[2] = lo4[2]; f[3] = lo4[3];
+        f[4] = hi4[0]; f[5] = hi4[1]; f[6] = hi4[2]; f[7] = hi4[3];
+        return f;
+    };
+
+    f32x16 acc[KS];
+#pragma unroll
+    for (int t = 0; t < KS; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
+
+    if (mt_begin < mt_end) {
+        load_tiles(mt_begin);
+        store_tiles();
+    }
+    __syncthreads();
+    for (int mt = mt_begin; mt < mt_end; ++mt) {
+        const bool nxt = mt + 1 < mt_end;
+        if (nxt) load_tiles(mt + 1);
+#pragma unroll
+        for (int kk = 0; kk < TH * 2; ++kk) {              // 16 consecutive pixels of one tile row per k-step
+            const int prow0 = kk * 16;
+            const int qrow0 = (kk >> 1) * HWID + (kk & 1) * 16;
+            bf16x8 ah = frag(Ph + trP + prow0 * PSTR, 4 * PSTR), al;
+            if (NS == 2) al = frag(Pl + trP + prow0 * PSTR, 4 * PSTR);
+#pragma unroll
+            for (int t = 0; t < KS; ++t) {
+                const int qoff = trQ + (qrow0 + t) * QSTR;
+                const bf16x8 bh = frag(Qh + qoff, 4 * QSTR);
+                if (NS == 2) {
+                    const bf16x8 bl = frag(Ql + qoff, 4 * QSTR);
+                    acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, bh, acc[t], 0, 0, 0);
+                    acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bl, acc[t], 0, 0, 0);
+                }
+                acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bh, acc[t], 0, 0, 0);
+            }
+        }
+        __syncthreads();                      // every wave is done reading the stage
+        if (nxt) store_tiles();
+        __syncthreads();
+    }
+
+    const int l31 = lane & 31, lh = lane >> 5;
+    const int K = KS * KS * p.Ci;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        const int co = c0 + cb * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+        float *row = p.DW + (size_t)co * K + (tr * KS) * p.Ci + ci0 + l31;
+#pragma unroll
+        for (int t = 0; t < KS; ++t) atomicAdd(row + t * p.Ci, acc[t][r]);
+    }
+}
+
+int launch_wgrad_halo(const hoig_conv_desc *d, const float *x, const float *dy, float *dw, int ns, hipStream_t st) {
+    WHaloArgs a;
+    a.DY = dy; a.X = x; a.DW = dw;
+    a.Bn = d->B; a.H = d->Ho; a.W = d->Wo; a.Co = d->Co; a.Ci = d->Ci;
+    a.tiles_x = a.W / 32;
+    a.tiles_y = a.H / 2;
+    a.n_mtiles = a.Bn * a.tiles_x * a.tiles_y;
+    a.nblk_ci = a.Ci / 32;
+    a.nblk = (a.Co / 64) * a.nblk_ci;
+    static const int target_blocks = getenv("HOIG_WGRAD_HALO_BLOCKS") ? atoi(getenv("HOIG_WGRAD_HALO_BLOCKS")) : 512;
+    int splits = (int)hoig_cdiv(target_blocks, a.nblk);
+    if (splits > a.n_mtiles) splits = a.n_mtiles;
+    if (splits < 1) splits = 1;
+    a.mt_per_split = (int)hoig_cdiv(a.n_mtiles, splits);
+    splits = (int)hoig_cdiv(a.n_mtiles, a.mt_per_split);
+    dim3 grid(a.nblk, splits);
+    if (ns == 2) wgrad_halo_bf16_kernel<2><<<grid, 384, 0, st>>>(a);
+    else wgrad_halo_bf16_kernel<1><<<grid, 384, 0, st>>>(a);
+    HOIG_LAUNCH_CHECK();
+    return HOIG_OK;
+}
+
 }  // namespace
 
 int hoig_conv_bf16_wgrad(const hoig_conv_desc *d, const float *x, const float *dy, float *dw, hipStream_t st) {
@@ -1051,6 +1228,10 @@ int hoig_conv_bf16_wgrad(const hoig_conv_desc *d, const float *x, const float *d
         a.lh = __builtin_ctz(a.Hp);
     }
     const int ns = d->precision == HOIG_PREC_BF16X3 ? 2 : 1;
+    static const bool no_halo = getenv("HOIG_NO_WGRAD_HALO") != nullptr;
+    if (!no_halo && !d->transposed && d->stride == 1 && d->R == 3 && d->S == 3 && d->pad == 1 && d->Hi == d->Ho &&
+        d->Wi == d->Wo && d->Wo % 32 == 0 && d->Ho % 2 == 0 && d->Ci % 32 == 0 && d->Co % 64 == 0)
+        return launch_wgrad_halo(d, x, dy, dw, ns, st);
     if (a.Co <= 64) return launch_wgrad_bf16<64>(a, ns, st);
     return launch_wgrad_bf16<128>(a, ns, st);
 }

@@ -318,6 +318,8 @@ BF16_CASES = [
     (2, 128, 256, 16, 3, 2, 1, False),
     (1, 512, 512, 8, 3, 1, 1, False),
     (8, 512, 512, 32, 3, 1, 1, False),
+    (2, 64, 64, 64, 3, 1, 1, False),
+    (3, 32, 192, 32, 3, 1, 1, False),
     (2, 64, 128, 16, 4, 2, 1, False),
     (2, 256, 256, 9, 4, 1, 1, False),
     (3, 96, 160, 10, 3, 1, 1, False),
