@@ -99,6 +99,13 @@ __device__ __forceinline__ void split4(const float4 v, uint2 &hi, uint2 &lo) {
     lo.y = cvt2(r2, r3);
 }
 
+// Layout of a packed bf16 weight plane in HBM: 32(n) x 32(k) blocks, each 2 KB contiguous, block (n/32, k/32) at
+// ((n/32) * (K/32) + k/32) * 1024.  The weight tile of one k-step (BN rows x 32 k) is then BN/32 fully used 2-KB runs
+// instead of BN half-used 128-B lines K*2 bytes apart; N and K are multiples of 32 on this path.
+__host__ __device__ __forceinline__ size_t plane_index(int n, int k, int K) {
+    return ((size_t)(n >> 5) * (K >> 5) + (k >> 5)) * 1024 + (n & 31) * 32 + (k & 31);
+}
+
 // LDS plane = [rows][BK] bf16; the 16-B chunk index of a row is XOR-ed with a row-dependent value so that the 16-lane
 // groups of ds_read_b128 (rows r..r+3, r+12.., r+20..) fall on 16 distinct slots of the 256-B bank row:
 //   BK = 32 (64-B rows, 4 chunks): chunk ^ ((row >> 2) & 3)      BK = 64 (128-B rows, 8 chunks): chunk ^ ((row >> 1) & 7)
@@ -178,8 +185,9 @@ __global__ __launch_bounds__(WM * WN * 64) void igemm_bf16_kernel(const Args p) 
 #pragma unroll
     for (int i = 0; i < RB; ++i) {
         const int n = n0 + brow + BROWS * i;
-        wrow_h[i] = n < p.N ? p.Wh + (size_t)n * p.K + bchunk * 8 : nullptr;
-        wrow_l[i] = (NS == 2 && n < p.N) ? p.Wl + (size_t)n * p.K + bchunk * 8 : nullptr;
+        const size_t o = plane_index(n, bchunk * 8, p.K);
+        wrow_h[i] = n < p.N ? p.Wh + o : nullptr;
+        wrow_l[i] = (NS == 2 && n < p.N) ? p.Wl + o : nullptr;
     }
     int aoff[RA], boff[RB];
 #pragma unroll
@@ -222,8 +230,9 @@ __global__ __launch_bounds__(WM * WN * 64) void igemm_bf16_kernel(const Args p) 
             ra[i] = aptr[i] ? *reinterpret_cast<const float4 *>(aptr[i] + c) : make_float4(0.f, 0.f, 0.f, 0.f);
 #pragma unroll
         for (int i = 0; i < RB; ++i) {
-            rbh[i] = wrow_h[i] ? *reinterpret_cast<const uint4 *>(wrow_h[i] + wk + c) : make_uint4(0, 0, 0, 0);
-            if (NS == 2) rbl[i] = wrow_l[i] ? *reinterpret_cast<const uint4 *>(wrow_l[i] + wk + c) : make_uint4(0, 0, 0, 0);
+            rbh[i] = wrow_h[i] ? *reinterpret_cast<const uint4 *>(wrow_h[i] + (size_t)(wk + c) * 32) : make_uint4(0, 0, 0, 0);
+            if (NS == 2)
+                rbl[i] = wrow_l[i] ? *reinterpret_cast<const uint4 *>(wrow_l[i] + (size_t)(wk + c) * 32) : make_uint4(0, 0, 0, 0);
         }
     };
     auto store_tiles = [&](int stage) {
@@ -334,22 +343,20 @@ __global__ __launch_bounds__(WM * WN * 64) void igemm_bf16_kernel(const Args p) 
     }
 }
 
-// w: fp32 [Co][RS][Ci].  mode 0 -> planes [Co][RS][Ci] (forward), mode 1 -> planes [Ci][RS][Co] (data gradient)
+// w: fp32 [Co][RS][Ci].  mode 0 -> plane rows n = co, k = (rs, ci) (forward); mode 1 -> rows n = ci, k = (rs, co) (data
+// gradient); both in the blocked plane layout (plane_index)
 __global__ void pack_weight_kernel(const float *__restrict__ w, int Co, int RS, int Ci, int mode,
                                    unsigned short *__restrict__ hi, unsigned short *__restrict__ lo) {
     const int64_t n = (int64_t)Co * RS * Ci;
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
-        int64_t src = i;
-        if (mode == 1) {   // i enumerates [ci][rs][co]
-            const int co = (int)(i % Co);
-            const int64_t t = i / Co;
-            const int rs = (int)(t % RS), ci = (int)(t / RS);
-            src = ((int64_t)co * RS + rs) * Ci + ci;
-        }
-        const float x = w[src];
+        const int ci = (int)(i % Ci);
+        const int64_t t = i / Ci;
+        const int rs = (int)(t % RS), co = (int)(t / RS);
+        const size_t dst = mode == 1 ? plane_index(ci, rs * Co + co, RS * Co) : plane_index(co, rs * Ci + ci, RS * Ci);
+        const float x = w[i];
         const unsigned short h = hoig_f2bf(x);
-        hi[i] = h;
-        if (lo) lo[i] = hoig_f2bf(x - hoig_bf2f(h));
+        hi[dst] = h;
+        if (lo) lo[dst] = hoig_f2bf(x - hoig_bf2f(h));
     }
 }
 
@@ -388,8 +395,9 @@ __global__ __launch_bounds__(256) void pack_all_kernel(const float *__restrict__
                 const unsigned short h = hoig_f2bf(x);
                 const unsigned short l = hoig_f2bf(x - hoig_bf2f(h));
                 if (flags & 1) {
-                    hi_f[off + i] = h;
-                    lo_f[off + i] = l;
+                    const size_t o = off + plane_index(co, rs * Ci + ci, RS * Ci);
+                    hi_f[o] = h;
+                    lo_f[o] = l;
                 }
                 pk = (unsigned int)h | ((unsigned int)l << 16);
             }
@@ -402,7 +410,7 @@ __global__ __launch_bounds__(256) void pack_all_kernel(const float *__restrict__
                 const int ci = ci0 + ty + 8 * k, co = co0 + tx;
                 if (co < Co && ci < Ci) {
                     const unsigned int pk = tile[tx][ty + 8 * k];
-                    const int64_t o = off + ((int64_t)ci * RS + rs) * Co + co;
+                    const size_t o = off + plane_index(ci, rs * Co + co, RS * Co);
                     hi_d[o] = (unsigned short)(pk & 0xffffu);
                     lo_d[o] = (unsigned short)(pk >> 16);
                 }
@@ -500,8 +508,9 @@ __global__ __launch_bounds__(128 * WN) void conv_halo_bf16_kernel(const HaloArgs
 #pragma unroll
     for (int i = 0; i < RB; ++i) {
         const int n = n0 + brow + (NT / 4) * i;
-        wrow_h[i] = n < p.N ? p.Wh + (size_t)n * p.K + bchunk * 8 : nullptr;
-        wrow_l[i] = (NS == 2 && n < p.N) ? p.Wl + (size_t)n * p.K + bchunk * 8 : nullptr;
+        const size_t o = plane_index(n, bchunk * 8, p.K);
+        wrow_h[i] = n < p.N ? p.Wh + o : nullptr;
+        wrow_l[i] = (NS == 2 && n < p.N) ? p.Wl + o : nullptr;
         const int row = brow + (NT / 4) * i;
         boff[i] = row * 64 + ((bchunk ^ ((row >> 2) & 3)) << 4);
     }
@@ -532,7 +541,7 @@ __global__ __launch_bounds__(128 * WN) void conv_halo_bf16_kernel(const HaloArgs
     auto load_b = [&](int step, uint4 (&rh)[RB], uint4 (&rl)[RB]) {
         const int cb = step / KK, tap = step - cb * KK;
         const int wtap = p.flip ? (KK - 1 - tap) : tap;
-        const int koff = wtap * p.Cg + cb * 32;
+        const size_t koff = (size_t)(wtap * p.Cg + cb * 32) * 32;      // k-block index * 1024
 #pragma unroll
         for (int i = 0; i < RB; ++i) {
             rh[i] = wrow_h[i] ? *reinterpret_cast<const uint4 *>(wrow_h[i] + koff) : make_uint4(0, 0, 0, 0);
@@ -658,6 +667,226 @@ __global__ __launch_bounds__(128 * WN) void conv_halo_bf16_kernel(const HaloArgs
     }
 }
 
+// 3x3 variant with ONE TAP ROW (three taps) per step: the weight tiles of taps (r,0..2) of a 32-channel block are
+// published together, so the two barriers, the weight publication and the fragment-read ramp that bracket every step are
+// paid once per 3 x 768 MFMA cycles instead of once per 768.  LDS: halo 32 KB + 3 weight tiles 48 KB = 80 KB (dynamic),
+// exactly two workgroups per CU.  Weights are prefetched one step (2304 MFMA cycles per wave) ahead.
+template <int NS, int WN, int BN = 128>
+__global__ __launch_bounds__(128 * WN) void conv_halo3_bf16_kernel(const HaloArgs p) {
+    constexpr int KS = 3, TH = 4, TW = 32;
+    constexpr int NT = 128 * WN;
+    constexpr int RB = BN * 4 / NT;                        // 16-B weight chunks per thread per plane per tap
+    constexpr int HH = TH + KS - 1, HW = TW + KS - 1, HPIX = HH * HW;
+    constexpr int AROW = 80;
+    constexpr int PLANE_A = HPIX * AROW, PLANE_B = BN * 64;
+    constexpr int TM = 2, TN = BN / (32 * WN);
+    static_assert(TN >= 1, "BN = 64 needs the 4-wave variant");
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];   // NS*PLANE_A + KS*NS*PLANE_B
+    unsigned char *Ah = smem, *Al = smem + PLANE_A;
+    unsigned char *Bst = smem + NS * PLANE_A;              // KS tap tiles of (Bh, Bl)
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int l31 = lane & 31, lh = lane >> 5;
+    const int wm = wave / WN, wn = wave % WN;
+    const int tile = hoig_xcd_remap(blockIdx.x, p.nblk);
+    int mt = tile / p.nblk_n;
+    const int n0 = (tile % p.nblk_n) * BN;
+    const int tx_ = mt % p.tiles_x;
+    mt /= p.tiles_x;
+    const int ty_ = mt % p.tiles_y, b = mt / p.tiles_y;
+    const int y0 = ty_ * TH, x0 = tx_ * TW;
+
+    const int brow = tid >> 2, bchunk = tid & 3;
+    const unsigned short *wrow_h[RB], *wrow_l[RB];
+    int boff[RB];
+#pragma unroll
+    for (int i = 0; i < RB; ++i) {
+        const int n = n0 + brow + (NT / 4) * i;
+        const size_t o = plane_index(n, bchunk * 8, p.K);
+        wrow_h[i] = n < p.N ? p.Wh + o : nullptr;
+        wrow_l[i] = (NS == 2 && n < p.N) ? p.Wl + o : nullptr;
+        const int row = brow + (NT / 4) * i;
+        boff[i] = row * 64 + ((bchunk ^ ((row >> 2) & 3)) << 4);
+    }
+    int aread[TM], bread[TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i) aread[i] = ((wm * TM + i) * HW + l31) * AROW + lh * 16;
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+        const int row = wn * (TN * 32) + j * 32 + l31;
+        bread[j] = row * 64 + ((lh ^ ((row >> 2) & 3)) << 4);
+    }
+
+    f32x16 acc[TM][TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    uint4 rbh[KS][RB], rbl[KS][RB];
+    const int ncb = p.Cg >> 5, T = ncb * KS;               // step = (channel block, tap row)
+    auto load_b = [&](int step) {
+        const int cb = step / KS, r = step - cb * KS;
+#pragma unroll
+        for (int t = 0; t < KS; ++t) {
+            const int tap = r * KS + t;
+            const int wtap = p.flip ? (KS * KS - 1 - tap) : tap;
+            const size_t koff = (size_t)(wtap * p.Cg + cb * 32) * 32;
+#pragma unroll
+            for (int i = 0; i < RB; ++i) {
+                rbh[t][i] = wrow_h[i] ? *reinterpret_cast<const uint4 *>(wrow_h[i] + koff) : make_uint4(0, 0, 0, 0);
+                if (NS == 2)
+                    rbl[t][i] = wrow_l[i] ? *reinterpret_cast<const uint4 *>(wrow_l[i] + koff) : make_uint4(0, 0, 0, 0);
+            }
+        }
+    };
+    auto store_b = [&]() {
+#pragma unroll
+        for (int t = 0; t < KS; ++t) {
+            unsigned char *Bh = Bst + t * NS * PLANE_B, *Bl = Bh + PLANE_B;
+#pragma unroll
+            for (int i = 0; i < RB; ++i) {
+                *reinterpret_cast<uint4 *>(Bh + boff[i]) = rbh[t][i];
+                if (NS == 2) *reinterpret_cast<uint4 *>(Bl + boff[i]) = rbl[t][i];
+            }
+        }
+    };
+    const float *Aimg = p.A + (size_t)b * p.H * p.W * p.Cg;
+    constexpr int HSLICES = (HPIX * 8 + NT - 1) / NT;
+    float4 hreg[HSLICES];
+    auto halo_load = [&](int cb) {
+#pragma unroll
+        for (int sl = 0; sl < HSLICES; ++sl) {
+            const int i = tid + NT * sl;
+            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (i < HPIX * 8) {
+                const int pix = i >> 3, c4 = i & 7;
+                const int hy = pix / HW, hx = pix - hy * HW;
+                const int gy = y0 - p.pad + hy, gx = x0 - p.pad + hx;
+                if (gy >= 0 && gy < p.H && gx >= 0 && gx < p.W)
+                    v = *reinterpret_cast<const float4 *>(Aimg + ((size_t)gy * p.W + gx) * p.Cg + cb * 32 + c4 * 4);
+            }
+            hreg[sl] = v;
+        }
+    };
+    auto halo_store = [&]() {
+#pragma unroll
+        for (int sl = 0; sl < HSLICES; ++sl) {
+            const int i = tid + NT * sl;
+            if (i < HPIX * 8) {
+                const int pix = i >> 3, c4 = i & 7;
+                uint2 hi, lo;
+                split4(hreg[sl], hi, lo);
+                *reinterpret_cast<uint2 *>(Ah + pix * AROW + c4 * 8) = hi;
+                if (NS == 2) *reinterpret_cast<uint2 *>(Al + pix * AROW + c4 * 8) = lo;
+            }
+        }
+    };
+    auto compute = [&](int r) {
+#pragma unroll
+        for (int t = 0; t < KS; ++t) {
+            const int tapoff = (r * HW + t) * AROW;
+            const unsigned char *Bh = Bst + t * NS * PLANE_B, *Bl = Bh + PLANE_B;
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks) {
+                bf16x8 ah[TM], al[TM], bhf[TN], blf[TN];
+#pragma unroll
+                for (int i = 0; i < TM; ++i) {
+                    const int off = aread[i] + tapoff + ks * 32;
+                    ah[i] = *reinterpret_cast<const bf16x8 *>(Ah + off);
+                    if (NS == 2) al[i] = *reinterpret_cast<const bf16x8 *>(Al + off);
+                }
+#pragma unroll
+                for (int j = 0; j < TN; ++j) {
+                    const int off = bread[j] ^ (ks << 5);
+                    bhf[j] = *reinterpret_cast<const bf16x8 *>(Bh + off);
+                    if (NS == 2) blf[j] = *reinterpret_cast<const bf16x8 *>(Bl + off);
+                }
+#pragma unroll
+                for (int i = 0; i < TM; ++i)
+#pragma unroll
+                    for (int j = 0; j < TN; ++j) {
+                        if (NS == 2) {
+                            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[i], bhf[j], acc[i][j], 0, 0, 0);
+                            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[i], blf[j], acc[i][j], 0, 0, 0);
+                        }
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[i], bhf[j], acc[i][j], 0, 0, 0);
+                    }
+            }
+        }
+    };
+
+    halo_load(0);
+    load_b(0);
+    halo_store();
+    store_b();
+    __syncthreads();
+#pragma unroll 1
+    for (int step = 0; step < T; ++step) {
+        const int cb = step / KS, r = step - cb * KS;
+        const bool more = step + 1 < T;
+        const bool boundary = more && r == KS - 1;
+        if (more) load_b(step + 1);
+        if (boundary) halo_load(cb + 1);
+        compute(r);
+        if (more) {
+            __syncthreads();                  // every wave has finished reading the weight tiles (and the halo)
+            if (boundary) halo_store();
+            store_b();
+            __syncthreads();
+        }
+    }
+
+#pragma unroll
+    for (int i = 0; i < TM; ++i) {
+        const int oy = y0 + wm * TM + i;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int ox = x0 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+            const size_t pix = ((size_t)b * p.H + oy) * p.W + ox;
+#pragma unroll
+            for (int j = 0; j < TN; ++j) {
+                const int n = n0 + wn * (TN * 32) + j * 32 + l31;
+                if (n < p.N) {
+                    float v = acc[i][j][r];
+                    if (p.bias) v += p.bias[n];
+                    p.C[pix * p.N + n] = hoig_act(v, p.act, p.slope);
+                }
+            }
+        }
+    }
+}
+
+template <int NS, int WN, int BN>
+int launch_halo3_one(const HaloArgs &a, hipStream_t st) {
+    constexpr int HPIX = 6 * 34;
+    constexpr size_t shm = NS * (HPIX * 80) + 3 * NS * (BN * 64);
+    static bool once = false;
+    if (!once) {
+        if (hipFuncSetAttribute(reinterpret_cast<const void *>(&conv_halo3_bf16_kernel<NS, WN, BN>),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm) != hipSuccess)
+            return HOIG_ELAUNCH;
+        once = true;
+    }
+    conv_halo3_bf16_kernel<NS, WN, BN><<<a.nblk, 128 * WN, shm, st>>>(a);
+    HOIG_LAUNCH_CHECK();
+    return HOIG_OK;
+}
+
+int launch_halo3(HaloArgs a, int ns, hipStream_t st) {
+    a.tiles_x = a.W / 32;
+    a.tiles_y = a.H / 4;
+    const bool n64 = (a.N % 128) != 0;
+    a.nblk_n = (int)hoig_cdiv(a.N, n64 ? 64 : 128);
+    a.nblk = a.Bn * a.tiles_x * a.tiles_y * a.nblk_n;
+    if (n64) return ns == 2 ? launch_halo3_one<2, 2, 64>(a, st) : launch_halo3_one<1, 2, 64>(a, st);
+    const bool wide = a.nblk < 384 && getenv("HOIG_HALO_4W") == nullptr;
+    if (ns == 2) return wide ? launch_halo3_one<2, 4, 128>(a, st) : launch_halo3_one<2, 2, 128>(a, st);
+    return wide ? launch_halo3_one<1, 4, 128>(a, st) : launch_halo3_one<1, 2, 128>(a, st);
+}
+
 template <int KS>
 int launch_halo(HaloArgs a, int ns, hipStream_t st) {
     a.tiles_x = a.W / 32;
@@ -708,7 +937,7 @@ int run(const hoig_conv_desc *d, const float *a, const unsigned short *wh, const
     const int ns = d->precision == HOIG_PREC_BF16X3 ? 2 : 1;
     if (ns == 2 && !wl) return HOIG_EINVAL;
     const long t128 = hoig_cdiv(p.M, 128);
-    if (p.N <= 32) return HOIG_EUNSUPPORTED;
+    if (p.N <= 32 || p.N % 32 != 0) return HOIG_EUNSUPPORTED;
     // stride-1 "same" convolutions (and their data gradients): LDS-resident input halo, weights streamed per tap
     if (!d->transposed && d->stride == 1 && d->R == d->S && 2 * d->pad == d->R - 1 && (d->R == 1 || d->R == 3 || d->R == 5) &&
         d->Wi % 32 == 0 && d->Hi % 4 == 0 && p.N % 64 == 0 && getenv("HOIG_NO_HALO") == nullptr &&
@@ -720,7 +949,7 @@ int run(const hoig_conv_desc *d, const float *a, const unsigned short *wh, const
         h.flip = dgrad ? 1 : 0;
         h.act = p.act; h.slope = p.slope;
         if (d->R == 1) return launch_halo<1>(h, ns, st);
-        if (d->R == 3) return launch_halo<3>(h, ns, st);
+        if (d->R == 3) return getenv("HOIG_HALO_TAPSTEP") ? launch_halo<3>(h, ns, st) : launch_halo3(h, ns, st);
         return launch_halo<5>(h, ns, st);
     }
     if (p.N <= 64) {
@@ -750,6 +979,7 @@ int hoig_conv_bf16_fwd_like(const hoig_conv_desc *, const float *, const float *
 extern "C" int hoig_pack_conv_weight_bf16(const float *w, int Co, int RS, int Ci, int for_dgrad, uint16_t *hi,
                                           uint16_t *lo, hoig_stream_t stream) {
     if (!w || !hi || Co <= 0 || RS <= 0 || Ci <= 0) return HOIG_EINVAL;
+    if ((Co & 31) || (Ci & 31)) return HOIG_EUNSUPPORTED;      // the blocked plane layout needs whole 32x32 blocks
     const int64_t n = (int64_t)Co * RS * Ci;
     pack_weight_kernel<<<hoig_stream_grid(n, 256), 256, 0, (hipStream_t)stream>>>(w, Co, RS, Ci, for_dgrad ? 1 : 0, hi, lo);
     HOIG_LAUNCH_CHECK();

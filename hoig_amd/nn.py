@@ -131,7 +131,9 @@ class ParamTree(nn.Module):
                 used.append((v.storage_offset(), tuple(v.shape), False))
         for off, shp, transposed in used:
             ci, co = (shp[0], shp[1]) if transposed else (shp[1], shp[0])
-            flags = (1 if (ci % 32 == 0 and co > 32) else 0) | (2 if (co % 32 == 0 and ci > 32) else 0)
+            flags = 0
+            if ci % 32 == 0 and co % 32 == 0:      # same conditions as ops._conv_fwd_raw / _conv_dgrad_raw
+                flags = (1 if co > 32 else 0) | (2 if ci > 32 else 0)
             if flags:
                 rows.append([off, co, shp[2] * shp[3], ci, flags, self._plane_tiles])
                 self._plane_tiles += ((co + 31) // 32) * ((ci + 31) // 32)

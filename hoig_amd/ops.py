@@ -416,7 +416,7 @@ def grid_sample(x, grid):
 
 def _conv_fwd_raw(d, x, w, b, y, transposed=False):
     """y = conv(x, w) (+bias, activation) on the kernel the precision mode selects."""
-    if d.precision != L.PREC_F32 and d.Ci % 32 == 0 and d.Co > 32:
+    if d.precision != L.PREC_F32 and d.Ci % 32 == 0 and d.Co % 32 == 0 and d.Co > 32:
         hi, lo = _packed_planes(w, transposed, False)
         rc = L.lib.hoig_conv2d_fwd_packed(ctypes.byref(d), _p(x), _p(hi), _p(lo), _p(b), _p(y), _st())
         if rc != L.EUNSUPPORTED:
@@ -426,7 +426,7 @@ def _conv_fwd_raw(d, x, w, b, y, transposed=False):
 
 
 def _conv_dgrad_raw(d, g, w, dx, transposed=False):
-    if d.precision != L.PREC_F32 and d.Co % 32 == 0 and d.Ci > 32:
+    if d.precision != L.PREC_F32 and d.Co % 32 == 0 and d.Ci % 32 == 0 and d.Ci > 32:
         hi, lo = _packed_planes(w, transposed, True)
         rc = L.lib.hoig_conv2d_bwd_data_packed(ctypes.byref(d), _p(g), _p(hi), _p(lo), _p(dx), _st())
         if rc != L.EUNSUPPORTED:

@@ -67,9 +67,12 @@ int hoig_conv2d_bwd_weight(const hoig_conv_desc *d, const float *x, const float 
                            hoig_stream_t stream);
 
 /* bf16-operand fast path (HOIG_PREC_BF16X3 / HOIG_PREC_BF16): weights are pre-split once per optimiser step into
- * K-contiguous bf16 planes hi (and lo = bf16(w - hi)).  for_dgrad=0: planes [Co][R*S][Ci] (forward GEMM);
- * for_dgrad=1: planes [Ci][R*S][Co] (data-gradient GEMM).  The *_packed entry points return HOIG_EUNSUPPORTED for
- * shapes outside the fast path (gathered channels % 32 != 0, <= 32 output channels); use the fp32 entry points then. */
+ * bf16 planes hi (and lo = bf16(w - hi)) of n rows x K reduction indices.  for_dgrad=0: n = co, k = (r*S+s)*Ci + ci
+ * (forward GEMM); for_dgrad=1: n = ci, k = (r*S+s)*Co + co (data-gradient GEMM).  A plane is stored in 32(n) x 32(k)
+ * blocks of 2 KB: element (n, k) at ((n/32)*(K/32) + k/32)*1024 + (n%32)*32 + k%32, so that the weight tile of one
+ * k-step is a few fully used contiguous runs.  Co and Ci must be multiples of 32 (else HOIG_EUNSUPPORTED).  The *_packed
+ * entry points return HOIG_EUNSUPPORTED for shapes outside the fast path (channels % 32 != 0, <= 32 output channels);
+ * use the fp32 entry points then. */
 int hoig_pack_conv_weight_bf16(const float *w, int Co, int RS, int Ci, int for_dgrad, uint16_t *hi, uint16_t *lo /*nullable*/,
                                hoig_stream_t stream);
 /* The same split for every conv weight of a network's flat parameter buffer in one launch.  segs (device memory) holds

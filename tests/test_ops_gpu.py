@@ -368,8 +368,8 @@ def test_batched_weight_split_matches_per_weight_split():
     from hoig_amd.nn import ParamTree
     from hoig_amd.ops import _p, _st
     shapes = [('a.weight', (64, 96, 3, 3)), ('a.bias', (64,)),
-              ('s.mlp_gamma.weight', (40, 128, 3, 3)), ('s.mlp_gamma.bias', (40,)),
-              ('s.mlp_beta.weight', (40, 128, 3, 3)), ('s.mlp_beta.bias', (40,)),
+              ('s.mlp_gamma.weight', (48, 128, 3, 3)), ('s.mlp_gamma.bias', (48,)),
+              ('s.mlp_beta.weight', (48, 128, 3, 3)), ('s.mlp_beta.bias', (48,)),
               ('up.weight', (128, 64, 3, 3)), ('head.weight', (3, 64, 7, 7)), ('one.weight', (128, 800, 1, 1))]
     tree = ParamTree(shapes, torch.device('cuda'), transposed_names=('up.weight',))
     torch.manual_seed(3)
@@ -381,7 +381,7 @@ def test_batched_weight_split_matches_per_weight_split():
         ci, co = (w.shape[0], w.shape[1]) if transposed else (w.shape[1], w.shape[0])
         for for_dgrad in (False, True):
             got = tree.packed_planes(w, for_dgrad)
-            eligible = (co % 32 == 0 and ci > 32) if for_dgrad else (ci % 32 == 0 and co > 32)
+            eligible = co % 32 == 0 and ci % 32 == 0 and (ci > 32 if for_dgrad else co > 32)
             assert (got is not None) == eligible, (name, for_dgrad)
             if got is None:
                 continue
