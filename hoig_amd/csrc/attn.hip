@@ -138,74 +138,128 @@ __global__ __launch_bounds__(256) void attn_sample_fwd_kernel(const float *__res
 }
 
 // dsource += bilinear^T( dS[m][q][c] + attn[m][q]/25 * dout[m][c] ).
-// Workgroup = 8x8 pixel tile x 32 channels; LDS patch covers the tile +- PR pixels.
-constexpr int PT = 8, PR = 8, PS = PT + 2 * PR, PCH = 32;
-__global__ __launch_bounds__(256) void attn_sample_bwd_kernel(const float *__restrict__ flow, const float *__restrict__ dS,
-                                                              const float *__restrict__ attn, const float *__restrict__ dout,
-                                                              float *__restrict__ dsrc, int B, int H, int W, int C) {
-    __shared__ float patch[PS * PS * PCH];          // 24*24*32*4 = 72 KB
-    const int tiles_x = (W + PT - 1) / PT, tiles_y = (H + PT - 1) / PT;
+// The 25 taps of a pixel sample a regular 5x5 grid shifted by the pixel's flow, all with the SAME bilinear fractions, so
+// their 100 (tap, corner) contributions collapse to a 6x6 footprint: out[i][j] = sum_{a,b in {0,1}} w_ab * v[i-a][j-b]
+// (a 2x2 "full" correlation done in registers).  (Per-tap K1 arithmetic can differ from the shared fraction by one ulp of
+// the sampling coordinate; for this gradient scatter that is a ~1e-7 relative effect.)
+// LDS float atomics run at ~0.5 lane/clk/CU on gfx950 (measured: they were 80 % of this kernel), so the footprints are
+// accumulated WITHOUT atomics: a workgroup is ONE wave that owns 32 channels of a TILE x TILE pixel tile and walks its
+// pixels one after the other; lanes = 32 channels x 2 footprint halves (rows 0-2 / 3-5), i.e. the 64 lanes of one
+// instruction always touch 64 distinct patch words, and LDS operations of one wave execute in order, so a plain
+// read / add / write per cell is exact.  The patch is indexed by UNCLAMPED image coordinates (tile +- PRAD); K1's
+// border clamp is applied when the patch is flushed to dsource with global atomics.  Pixels whose footprint leaves the
+// patch (|flow| > ~PRAD-3) scatter straight to global memory.
+constexpr int PCH = 32;
+template <int TILE, int PRAD>
+__global__ __launch_bounds__(64) void attn_sample_bwd_kernel(const float *__restrict__ flow, const float *__restrict__ dS,
+                                                             const float *__restrict__ attn, const float *__restrict__ dout,
+                                                             float *__restrict__ dsrc, int B, int H, int W, int C) {
+    constexpr int PS = TILE + 2 * PRAD;
+    __shared__ float patch[PS * PS * PCH];
+    const int tiles_x = (W + TILE - 1) / TILE, tiles_y = (H + TILE - 1) / TILE;
     int t = blockIdx.x;
     const int bx = t % tiles_x;
     t /= tiles_x;
     const int by = t % tiles_y, b = t / tiles_y;
     const int c0 = blockIdx.y * PCH;
     const int hw = H * W;
-    const int py0 = by * PT - PR, px0 = bx * PT - PR;   // patch origin (image coordinates)
-    for (int i = threadIdx.x; i < PS * PS * PCH; i += 256) patch[i] = 0.f;
+    const int py0 = by * TILE - PRAD, px0 = bx * TILE - PRAD;   // patch origin (unclamped image coordinates)
+    const int lane = threadIdx.x, c = lane & 31, h = lane >> 5;
+    for (int i = lane; i < PS * PS * PCH; i += 64) patch[i] = 0.f;
     __syncthreads();
-    const int lane_c = threadIdx.x & 31, grp = threadIdx.x >> 5;          // 8 groups of 32 channel-lanes
-    float *dimg = dsrc + (size_t)b * hw * C + c0 + lane_c;
-    // group g walks pixels g, g+8, ... of the tile.  The 25 taps of a pixel sample a regular 5x5 grid shifted by the
-    // pixel's flow, all with the SAME bilinear fractions, so their 100 (tap, corner) contributions collapse to a 6x6
-    // footprint: out[i][j] = sum_{a,b in {0,1}} w_ab * v[i-a][j-b]  (a 2x2 "full" correlation done in registers), i.e.
-    // 36 atomics instead of 100 and one tap computation per pixel.  (Per-tap K1 arithmetic can differ from the shared
-    // fraction by one ulp of the sampling coordinate; for this gradient scatter that is a ~1e-7 relative effect.)
-    for (int pl = grp; pl < PT * PT; pl += 8) {
-        const int y = by * PT + pl / PT, x = bx * PT + pl % PT;
-        if (y >= H || x >= W) continue;
-        const int rem = y * W + x;
+    float *dimg = dsrc + (size_t)b * hw * C + c0 + c;
+    const int rb = h ? 2 : 0;                                   // first dS tap row this half reads
+    // (explicit software pipelining of the next pixels' loads -- 1 or 4 pixels ahead -- measured slower than letting five
+    // one-wave workgroups per CU interleave)
+    struct Pix {
+        float v[3][KS];
+        float fx, fy;
+        int y, x;
+    };
+    auto load_pix = [&](int pl, Pix &P) {
+        P.y = by * TILE + pl / TILE;
+        P.x = bx * TILE + pl % TILE;
+        if (pl >= TILE * TILE || P.y >= H || P.x >= W) {
+            P.y = -1;
+            return;
+        }
+        const int rem = P.y * W + P.x;
         const size_t m = (size_t)b * hw + rem;
-        const float fx = flow[((size_t)b * 2 + 0) * hw + rem], fy = flow[((size_t)b * 2 + 1) * hw + rem];
-        const float go = dout[m * C + c0 + lane_c] * (1.f / NTAP);
-        const float *dSm = dS ? dS + m * NTAP * C + c0 + lane_c : nullptr;
+        P.fx = flow[((size_t)b * 2 + 0) * hw + rem];
+        P.fy = flow[((size_t)b * 2 + 1) * hw + rem];
+        const float go = dout[m * C + c0 + c] * (1.f / NTAP);
+        const float *dSm = dS ? dS + m * NTAP * C + c0 + c : nullptr;
         const float *am = attn + m * NTAP;
-        float v[KS][KS];
 #pragma unroll
-        for (int q = 0; q < NTAP; ++q) v[q / KS][q % KS] = dSm ? dSm[(size_t)q * C] : 0.f;
+        for (int k = 0; k < 3; ++k)
 #pragma unroll
-        for (int q = 0; q < NTAP; ++q) v[q / KS][q % KS] += am[q] * go;
-        const float dyc = (fy + (float)(-KS / 2)) + (float)y, dxc = (fx + (float)(-KS / 2)) + (float)x;   // tap (0,0)
+            for (int q = 0; q < KS; ++q) {
+                const int tap = (rb + k) * KS + q;
+                P.v[k][q] = (dSm ? dSm[(size_t)tap * C] : 0.f) + am[tap] * go;
+            }
+    };
+    auto scatter = [&](const Pix &P) {
+        if (P.y < 0) return;
+        const float dyc = (P.fy + (float)(-KS / 2)) + (float)P.y, dxc = (P.fx + (float)(-KS / 2)) + (float)P.x;   // tap (0,0)
         const float fly = floorf(dyc), flx = floorf(dxc);
         const float wy1 = dyc - fly, wy0 = 1.f - wy1, wx1 = dxc - flx, wx0 = 1.f - wx1;
         const int by0 = (int)fly, bx0 = (int)flx;
+        // x pass: xr[k][j] = wx0 * v[k][j] + wx1 * v[k][j-1], j = 0..5
+        float xr[3][KS + 1];
 #pragma unroll
-        for (int i = 0; i <= KS; ++i) {
-            const int yy = max(min(by0 + i, H - 1), 0);
-            const int ly = yy - py0;
+        for (int k = 0; k < 3; ++k) {
+            xr[k][0] = wx0 * P.v[k][0];
+#pragma unroll
+            for (int j = 1; j < KS; ++j) xr[k][j] = wx0 * P.v[k][j] + wx1 * P.v[k][j - 1];
+            xr[k][KS] = wx1 * P.v[k][KS - 1];
+        }
+        // y pass for this half's three footprint rows i = 3h + k:
+        //   h = 0 (v rows 0,1,2): o_k = wy0 * xr[k]   + wy1 * xr[k-1]      h = 1 (v rows 2,3,4): o_k = wy0 * xr[k+1] + wy1 * xr[k]
+        float o[3][KS + 1];
+#pragma unroll
+        for (int k = 0; k < 3; ++k)
 #pragma unroll
             for (int j = 0; j <= KS; ++j) {
-                float o = 0.f;
-                if (i < KS && j < KS) o += wy0 * wx0 * v[i < KS ? i : 0][j < KS ? j : 0];
-                if (i < KS && j > 0) o += wy0 * wx1 * v[i < KS ? i : 0][j > 0 ? j - 1 : 0];
-                if (i > 0 && j < KS) o += wy1 * wx0 * v[i > 0 ? i - 1 : 0][j < KS ? j : 0];
-                if (i > 0 && j > 0) o += wy1 * wx1 * v[i > 0 ? i - 1 : 0][j > 0 ? j - 1 : 0];
-                const int xx = max(min(bx0 + j, W - 1), 0);
-                const int lx = xx - px0;
-                if (ly >= 0 && ly < PS && lx >= 0 && lx < PS)
-                    atomicAdd(&patch[(ly * PS + lx) * PCH + lane_c], o);                // ds_add_f32
-                else
-                    atomicAdd(dimg + ((size_t)yy * W + xx) * C, o);                    // far tap: global atomic
+                const float up = h ? (k < 2 ? xr[k + 1][j] : 0.f) : xr[k][j];
+                const float dn = h ? xr[k][j] : (k > 0 ? xr[k - 1][j] : 0.f);
+                o[k][j] = wy0 * up + wy1 * dn;
+            }
+        const int ly0 = by0 - py0, lx0 = bx0 - px0;
+        if (ly0 >= 0 && ly0 + KS < PS && lx0 >= 0 && lx0 + KS < PS) {
+            float *cell = patch + ((ly0 + 3 * h) * PS + lx0) * PCH + c;
+            float old[3][KS + 1];
+#pragma unroll
+            for (int k = 0; k < 3; ++k)
+#pragma unroll
+                for (int j = 0; j <= KS; ++j) old[k][j] = cell[(k * PS + j) * PCH];
+#pragma unroll
+            for (int k = 0; k < 3; ++k)
+#pragma unroll
+                for (int j = 0; j <= KS; ++j) cell[(k * PS + j) * PCH] = old[k][j] + o[k][j];
+        } else {
+#pragma unroll
+            for (int k = 0; k < 3; ++k) {
+                const int yy = max(min(by0 + 3 * h + k, H - 1), 0);
+#pragma unroll
+                for (int j = 0; j <= KS; ++j) {
+                    const int xx = max(min(bx0 + j, W - 1), 0);
+                    atomicAdd(dimg + ((size_t)yy * W + xx) * C, o[k][j]);
+                }
             }
         }
+    };
+#pragma unroll 2
+    for (int pl = 0; pl < TILE * TILE; ++pl) {
+        Pix P;
+        load_pix(pl, P);
+        scatter(P);
     }
     __syncthreads();
-    for (int i = threadIdx.x; i < PS * PS * PCH; i += 256) {
-        const float v = patch[i];
+    for (int cell = h; cell < PS * PS; cell += 2) {
+        const float v = patch[cell * PCH + c];
         if (v != 0.f) {
-            const int cc = i & (PCH - 1), cell = i / PCH;
-            const int yy = py0 + cell / PS, xx = px0 + cell % PS;      // in range by construction (only clamped taps land)
-            atomicAdd(dsrc + (((size_t)b * H + yy) * W + xx) * C + c0 + cc, v);
+            const int yy = max(min(py0 + cell / PS, H - 1), 0), xx = max(min(px0 + cell % PS, W - 1), 0);
+            atomicAdd(dimg + ((size_t)yy * W + xx) * C, v);
         }
     }
 }
@@ -365,8 +419,17 @@ extern "C" int hoig_attn_sample_fwd(const float *source, const float *flow, floa
 extern "C" int hoig_attn_sample_bwd(const float *flow, const float *dsampled, const float *attn, const float *dout,
                                     float *dsource, int B, int H, int W, int C, hoig_stream_t stream) {
     if (!flow || !attn || !dout || !dsource || (C % PCH)) return HOIG_EINVAL;
-    const int tiles = B * (int)hoig_cdiv(H, PT) * (int)hoig_cdiv(W, PT);
-    attn_sample_bwd_kernel<<<dim3(tiles, C / PCH), 256, 0, ST>>>(flow, dsampled, attn, dout, dsource, B, H, W, C);
+    // 8x8 tiles (32 KB patch, 4-5 one-wave workgroups per CU) unless that leaves too few pixels per flush: 16x16 tiles for
+    // the large maps
+    static const int force = getenv("HOIG_ASB_TILE") ? atoi(getenv("HOIG_ASB_TILE")) : 0;
+    const bool big = force ? force == 16 : (int64_t)B * hoig_cdiv(H, 8) * hoig_cdiv(W, 8) * (C / PCH) > 8192;
+    if (big) {
+        const int tiles = B * (int)hoig_cdiv(H, 16) * (int)hoig_cdiv(W, 16);
+        attn_sample_bwd_kernel<16, 4><<<dim3(tiles, C / PCH), 64, 0, ST>>>(flow, dsampled, attn, dout, dsource, B, H, W, C);
+    } else {
+        const int tiles = B * (int)hoig_cdiv(H, 8) * (int)hoig_cdiv(W, 8);
+        attn_sample_bwd_kernel<8, 4><<<dim3(tiles, C / PCH), 64, 0, ST>>>(flow, dsampled, attn, dout, dsource, B, H, W, C);
+    }
     HOIG_LAUNCH_CHECK();
     return HOIG_OK;
 }
