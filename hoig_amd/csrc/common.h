@@ -34,6 +34,13 @@ __device__ __forceinline__ float hoig_act(float v, int act, float slope) {
     }
 }
 
+// epilogue form: none / ReLU / LeakyReLU are one select + one fma (negative slope 1 / 0 / slope; "+ 0" turns ReLU's -0
+// into +0), tanh / sigmoid take the (wave-uniform) slow branch
+__device__ __forceinline__ float fast_act(float v, float nslope, bool special, int act, float slope) {
+    if (special) return hoig_act(v, act, slope);
+    return v > 0.f ? v : fmaf(v, nslope, 0.f);
+}
+
 // derivative of the activation expressed through its OUTPUT y
 __device__ __forceinline__ float hoig_act_grad_from_y(float y, int act, float slope) {
     switch (act) {

@@ -295,6 +295,16 @@ __global__ __launch_bounds__(256) void igemm_f32_kernel(const IgemmArgs p) {
     }
 
     // epilogue: C/D layout col = lane&31, row = (reg&3) + 8*(reg>>2) + 4*(lane>>5)
+    // bias values of this lane's TN output columns, loaded once (a load inside the store loop is re-issued and waited for
+    // per element: the stores may alias it)
+    const float nslope = p.act == HOIG_ACT_NONE ? 1.f : (p.act == HOIG_ACT_RELU ? 0.f : p.slope);
+    const bool special = p.act == HOIG_ACT_TANH || p.act == HOIG_ACT_SIGMOID;
+    float bias_r[TN];
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+        const int n = n0 + wn * (TN * 32) + j * 32 + l31;
+        bias_r[j] = (p.bias && n < p.N) ? p.bias[n] : 0.f;
+    }
 #pragma unroll
     for (int i = 0; i < TM; ++i) {
 #pragma unroll
@@ -312,8 +322,8 @@ __global__ __launch_bounds__(256) void igemm_f32_kernel(const IgemmArgs p) {
                 const int n = n0 + wn * (TN * 32) + j * 32 + l31;
                 if (n < p.N) {
                     float v = acc[i][j][r];
-                    if (p.bias) v += p.bias[n];
-                    p.C[pix * p.N + n] = hoig_act(v, p.act, p.slope);
+                    v += bias_r[j];
+                    p.C[pix * p.N + n] = fast_act(v, nslope, special, p.act, p.slope);
                 }
             }
         }
@@ -630,7 +640,8 @@ static int launch_wgrad(WgradArgs a, hipStream_t st) {
     return HOIG_OK;
 }
 
-int hoig_conv_bf16_wgrad(const hoig_conv_desc *d, const float *x, const float *dy, float *dw, hipStream_t st);
+int hoig_conv_bf16_wgrad(const hoig_conv_desc *d, const float *x, const float *dy, float *dw, float *dbias, hipStream_t st);
+bool hoig_conv_bf16_wgrad_fuses_bias(const hoig_conv_desc *d);
 
 extern "C" int hoig_conv2d_bwd_weight(const hoig_conv_desc *d, const float *x, const float *dy, float *dw, float *dbias,
                                       hoig_stream_t stream) {
@@ -638,14 +649,15 @@ extern "C" int hoig_conv2d_bwd_weight(const hoig_conv_desc *d, const float *x, c
     if (rc) return rc;
     if (!x || !dy || !dw) return HOIG_EINVAL;
     hipStream_t st = (hipStream_t)stream;
-    if (dbias) {
+    const bool fused_bias = dbias && hoig_conv_bf16_wgrad_fuses_bias(d);   // the halo wgrad kernel sums dy as it stages it
+    if (dbias && !fused_bias) {
         rc = hoig_colsum_accum(dy, dbias, (int64_t)d->B * d->Ho * d->Wo, d->Co, stream);
         if (rc) return rc;
     }
     rc = hoig_conv_small_wgrad(d, x, dy, dw, st);
     if (rc != HOIG_EUNSUPPORTED) return rc;
     if (d->precision != HOIG_PREC_F32) {
-        rc = hoig_conv_bf16_wgrad(d, x, dy, dw, st);
+        rc = hoig_conv_bf16_wgrad(d, x, dy, dw, fused_bias ? dbias : nullptr, st);
         if (rc != HOIG_EUNSUPPORTED) return rc;
     }
     WgradArgs a;

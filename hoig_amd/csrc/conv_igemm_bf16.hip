@@ -101,9 +101,12 @@ __device__ __forceinline__ void split4(const float4 v, uint2 &hi, uint2 &lo) {
 
 // Layout of a packed bf16 weight plane in HBM: 32(n) x 32(k) blocks, each 2 KB contiguous, block (n/32, k/32) at
 // ((n/32) * (K/32) + k/32) * 1024.  The weight tile of one k-step (BN rows x 32 k) is then BN/32 fully used 2-KB runs
-// instead of BN half-used 128-B lines K*2 bytes apart; N and K are multiples of 32 on this path.
+// instead of BN half-used 128-B lines K*2 bytes apart; N and K are multiples of 32 on this path.  Inside a block, row n
+// holds its four 16-B chunks at position chunk ^ ((n >> 2) & 3): the block is byte for byte the XOR-swizzled LDS image
+// the kernels read (lds_swz<32>), so a tile can be copied to LDS linearly -- by global_load_lds, 1 KB per wave-instruction.
 __host__ __device__ __forceinline__ size_t plane_index(int n, int k, int K) {
-    return ((size_t)(n >> 5) * (K >> 5) + (k >> 5)) * 1024 + (n & 31) * 32 + (k & 31);
+    return ((size_t)(n >> 5) * (K >> 5) + (k >> 5)) * 1024 + (n & 31) * 32 + (((((k & 31) >> 3) ^ ((n >> 2) & 3))) << 3) +
+           (k & 7);
 }
 
 // LDS plane = [rows][BK] bf16; the 16-B chunk index of a row is XOR-ed with a row-dependent value so that the 16-lane
@@ -313,6 +316,16 @@ __global__ __launch_bounds__(WM * WN * 64) void igemm_bf16_kernel(const Args p) 
         more = nxt;
     }
 
+    // bias values of this lane's TN output columns, loaded once (a load inside the store loop is re-issued and waited for
+    // per element: the stores may alias it)
+    const float nslope = p.act == HOIG_ACT_NONE ? 1.f : (p.act == HOIG_ACT_RELU ? 0.f : p.slope);
+    const bool special = p.act == HOIG_ACT_TANH || p.act == HOIG_ACT_SIGMOID;
+    float bias_r[TN];
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+        const int n = n0 + wn * (TN * 32) + j * 32 + l31;
+        bias_r[j] = (p.bias && n < p.N) ? p.bias[n] : 0.f;
+    }
 #pragma unroll
     for (int i = 0; i < TM; ++i) {
 #pragma unroll
@@ -331,11 +344,11 @@ __global__ __launch_bounds__(WM * WN * 64) void igemm_bf16_kernel(const Args p) 
                 if (n < p.N) {
                     float v = acc[i][j][r];
                     if (p.ksplit > 1) {
-                        if (p.bias && blockIdx.y == 0) v += p.bias[n];
+                        if (blockIdx.y == 0) v += bias_r[j];
                         atomicAdd(&p.C[pix * p.N + n], v);
                     } else {
-                        if (p.bias) v += p.bias[n];
-                        p.C[pix * p.N + n] = hoig_act(v, p.act, p.slope);
+                        v += bias_r[j];
+                        p.C[pix * p.N + n] = fast_act(v, nslope, special, p.act, p.slope);
                     }
                 }
             }
@@ -647,6 +660,14 @@ __global__ __launch_bounds__(128 * WN) void conv_halo_bf16_kernel(const HaloArgs
     }
 
     // epilogue: MFMA row (reg) -> pixel inside the wave's 32-pixel image row; col = lane&31 -> channel
+    const float nslope = p.act == HOIG_ACT_NONE ? 1.f : (p.act == HOIG_ACT_RELU ? 0.f : p.slope);
+    const bool special = p.act == HOIG_ACT_TANH || p.act == HOIG_ACT_SIGMOID;
+    float bias_r[TN];
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+        const int n = n0 + wn * (TN * 32) + j * 32 + l31;
+        bias_r[j] = (p.bias && n < p.N) ? p.bias[n] : 0.f;
+    }
 #pragma unroll
     for (int i = 0; i < TM; ++i) {
         const int oy = y0 + wm * TM + i;
@@ -659,8 +680,8 @@ __global__ __launch_bounds__(128 * WN) void conv_halo_bf16_kernel(const HaloArgs
                 const int n = n0 + wn * (TN * 32) + j * 32 + l31;
                 if (n < p.N) {
                     float v = acc[i][j][r];
-                    if (p.bias) v += p.bias[n];
-                    p.C[pix * p.N + n] = hoig_act(v, p.act, p.slope);
+                    v += bias_r[j];
+                    p.C[pix * p.N + n] = fast_act(v, nslope, special, p.act, p.slope);
                 }
             }
         }
@@ -671,7 +692,7 @@ __global__ __launch_bounds__(128 * WN) void conv_halo_bf16_kernel(const HaloArgs
 // published together, so the two barriers, the weight publication and the fragment-read ramp that bracket every step are
 // paid once per 3 x 768 MFMA cycles instead of once per 768.  LDS: halo 32 KB + 3 weight tiles 48 KB = 80 KB (dynamic),
 // exactly two workgroups per CU.  Weights are prefetched one step (2304 MFMA cycles per wave) ahead.
-template <int NS, int WN, int BN = 128>
+template <int NS, int WN, int BN = 128, bool DB = false>
 __global__ __launch_bounds__(128 * WN) void conv_halo3_bf16_kernel(const HaloArgs p) {
     constexpr int KS = 3, TH = 4, TW = 32;
     constexpr int NT = 128 * WN;
@@ -681,9 +702,14 @@ __global__ __launch_bounds__(128 * WN) void conv_halo3_bf16_kernel(const HaloArg
     constexpr int PLANE_A = HPIX * AROW, PLANE_B = BN * 64;
     constexpr int TM = 2, TN = BN / (32 * WN);
     static_assert(TN >= 1, "BN = 64 needs the 4-wave variant");
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];   // NS*PLANE_A + KS*NS*PLANE_B
-    unsigned char *Ah = smem, *Al = smem + PLANE_A;
-    unsigned char *Bst = smem + NS * PLANE_A;              // KS tap tiles of (Bh, Bl)
+    // DB (the 8-wave variant: ONE workgroup per CU, so LDS is free): halo and weight tiles are double-buffered -- the next
+    // step's weights (and, at a channel-block boundary, the next halo) are written into the other buffer BEFORE this
+    // step's multiply, one barrier per step, nothing but barrier skew is exposed.  160 KB exactly.
+    constexpr int NBUF = DB ? 2 : 1;
+    constexpr int ABUF = NS * PLANE_A, BBUF = KS * NS * PLANE_B;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];   // NBUF * (ABUF + BBUF)
+    unsigned char *Abase = smem;
+    unsigned char *Bbase = smem + NBUF * ABUF;
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int l31 = lane & 31, lh = lane >> 5;
@@ -742,10 +768,10 @@ __global__ __launch_bounds__(128 * WN) void conv_halo3_bf16_kernel(const HaloArg
             }
         }
     };
-    auto store_b = [&]() {
+    auto store_b = [&](int buf) {
 #pragma unroll
         for (int t = 0; t < KS; ++t) {
-            unsigned char *Bh = Bst + t * NS * PLANE_B, *Bl = Bh + PLANE_B;
+            unsigned char *Bh = Bbase + buf * BBUF + t * NS * PLANE_B, *Bl = Bh + PLANE_B;
 #pragma unroll
             for (int i = 0; i < RB; ++i) {
                 *reinterpret_cast<uint4 *>(Bh + boff[i]) = rbh[t][i];
@@ -771,7 +797,8 @@ __global__ __launch_bounds__(128 * WN) void conv_halo3_bf16_kernel(const HaloArg
             hreg[sl] = v;
         }
     };
-    auto halo_store = [&]() {
+    auto halo_store = [&](int buf) {
+        unsigned char *Ah = Abase + buf * ABUF, *Al = Ah + PLANE_A;
 #pragma unroll
         for (int sl = 0; sl < HSLICES; ++sl) {
             const int i = tid + NT * sl;
@@ -784,11 +811,12 @@ __global__ __launch_bounds__(128 * WN) void conv_halo3_bf16_kernel(const HaloArg
             }
         }
     };
-    auto compute = [&](int r) {
+    auto compute = [&](int r, int abuf, int bbuf) {
+        const unsigned char *Ah = Abase + abuf * ABUF, *Al = Ah + PLANE_A;
 #pragma unroll
         for (int t = 0; t < KS; ++t) {
             const int tapoff = (r * HW + t) * AROW;
-            const unsigned char *Bh = Bst + t * NS * PLANE_B, *Bl = Bh + PLANE_B;
+            const unsigned char *Bh = Bbase + bbuf * BBUF + t * NS * PLANE_B, *Bl = Bh + PLANE_B;
 #pragma unroll
             for (int ks = 0; ks < 2; ++ks) {
                 bf16x8 ah[TM], al[TM], bhf[TN], blf[TN];
@@ -818,27 +846,57 @@ __global__ __launch_bounds__(128 * WN) void conv_halo3_bf16_kernel(const HaloArg
         }
     };
 
+    // (staging the weight tiles by LDS-DMA -- global_load_lds, the pre-swizzled plane blocks are LDS images -- measured
+    // ~9 % SLOWER here than the register-staged ds_write_b128 path below)
     halo_load(0);
+    halo_store(0);
     load_b(0);
-    halo_store();
-    store_b();
-    __syncthreads();
+    store_b(0);
+    if (DB) {
+        if (T > 1) load_b(1);
+        __syncthreads();
+        int abuf = 0, bbuf = 0;
 #pragma unroll 1
-    for (int step = 0; step < T; ++step) {
-        const int cb = step / KS, r = step - cb * KS;
-        const bool more = step + 1 < T;
-        const bool boundary = more && r == KS - 1;
-        if (more) load_b(step + 1);
-        if (boundary) halo_load(cb + 1);
-        compute(r);
-        if (more) {
-            __syncthreads();                  // every wave has finished reading the weight tiles (and the halo)
-            if (boundary) halo_store();
-            store_b();
+        for (int step = 0; step < T; ++step) {
+            const int cb = step / KS, r = step - cb * KS;
+            const bool more = step + 1 < T;
+            const bool boundary = more && r == KS - 1;
+            if (more) store_b(bbuf ^ 1);                  // weights of step+1 (registers loaded during the previous step)
+            if (boundary) halo_store(abuf ^ 1);           // halo of the next channel block (loaded during the previous step)
+            if (step + 2 < T) load_b(step + 2);
+            if (r == KS - 2 && cb + 1 < ncb) halo_load(cb + 1);
+            compute(r, abuf, bbuf);
             __syncthreads();
+            bbuf ^= 1;
+            if (boundary) abuf ^= 1;
+        }
+    } else {
+        __syncthreads();
+#pragma unroll 1
+        for (int step = 0; step < T; ++step) {
+            const int cb = step / KS, r = step - cb * KS;
+            const bool more = step + 1 < T;
+            const bool boundary = more && r == KS - 1;
+            if (more) load_b(step + 1);
+            if (boundary) halo_load(cb + 1);
+            compute(r, 0, 0);
+            if (more) {
+                __syncthreads();                  // every wave has finished reading the weight tiles (and the halo)
+                if (boundary) halo_store(0);
+                store_b(0);
+                __syncthreads();
+            }
         }
     }
 
+    const float nslope = p.act == HOIG_ACT_NONE ? 1.f : (p.act == HOIG_ACT_RELU ? 0.f : p.slope);
+    const bool special = p.act == HOIG_ACT_TANH || p.act == HOIG_ACT_SIGMOID;
+    float bias_r[TN];
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+        const int n = n0 + wn * (TN * 32) + j * 32 + l31;
+        bias_r[j] = (p.bias && n < p.N) ? p.bias[n] : 0.f;
+    }
 #pragma unroll
     for (int i = 0; i < TM; ++i) {
         const int oy = y0 + wm * TM + i;
@@ -851,8 +909,8 @@ __global__ __launch_bounds__(128 * WN) void conv_halo3_bf16_kernel(const HaloArg
                 const int n = n0 + wn * (TN * 32) + j * 32 + l31;
                 if (n < p.N) {
                     float v = acc[i][j][r];
-                    if (p.bias) v += p.bias[n];
-                    p.C[pix * p.N + n] = hoig_act(v, p.act, p.slope);
+                    v += bias_r[j];
+                    p.C[pix * p.N + n] = fast_act(v, nslope, special, p.act, p.slope);
                 }
             }
         }
@@ -862,15 +920,16 @@ __global__ __launch_bounds__(128 * WN) void conv_halo3_bf16_kernel(const HaloArg
 template <int NS, int WN, int BN>
 int launch_halo3_one(const HaloArgs &a, hipStream_t st) {
     constexpr int HPIX = 6 * 34;
-    constexpr size_t shm = NS * (HPIX * 80) + 3 * NS * (BN * 64);
+    constexpr bool DB = WN == 4;              // one workgroup per CU anyway: spend the LDS on double buffering
+    constexpr size_t shm = (DB ? 2 : 1) * (NS * (HPIX * 80) + 3 * NS * (BN * 64));
     static bool once = false;
     if (!once) {
-        if (hipFuncSetAttribute(reinterpret_cast<const void *>(&conv_halo3_bf16_kernel<NS, WN, BN>),
+        if (hipFuncSetAttribute(reinterpret_cast<const void *>(&conv_halo3_bf16_kernel<NS, WN, BN, DB>),
                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm) != hipSuccess)
             return HOIG_ELAUNCH;
         once = true;
     }
-    conv_halo3_bf16_kernel<NS, WN, BN><<<a.nblk, 128 * WN, shm, st>>>(a);
+    conv_halo3_bf16_kernel<NS, WN, BN, DB><<<a.nblk, 128 * WN, shm, st>>>(a);
     HOIG_LAUNCH_CHECK();
     return HOIG_OK;
 }
@@ -1263,7 +1322,7 @@ int launch_wgrad_bf16(WArgs a, int ns, hipStream_t st) {
 // the four rows a 32-lane half reads (256 B) cover all 64 banks once for any row offset.  dy rows are 192 B apart.
 struct WHaloArgs {
     const float *DY, *X;
-    float *DW;
+    float *DW, *DB;            // DB (nullable): bias gradient = column sums of dy, taken from the dy tiles as they are staged
     int Bn, H, W, Co, Ci;
     int tiles_x, tiles_y, n_mtiles, mt_per_split;
     int nblk_ci, nblk;
@@ -1289,6 +1348,8 @@ __global__ __launch_bounds__(384) void wgrad_halo_bf16_kernel(const WHaloArgs p)
     constexpr int PSL = (TH * TW * 16 + NT - 1) / NT;      // dy float4s per thread (3)
     constexpr int QSL = (HPIX * 8 + NT - 1) / NT;          // halo float4s per thread (3)
     float4 rp[PSL], rq[QSL];
+    const bool do_bias = p.DB != nullptr && ci0 == 0;      // the workgroups of the first ci tile also own the bias gradient
+    float4 bsum = make_float4(0.f, 0.f, 0.f, 0.f);
     auto load_tiles = [&](int mt) {
         const int tx = mt % p.tiles_x;
         const int t2 = mt / p.tiles_x;
@@ -1304,6 +1365,9 @@ __global__ __launch_bounds__(384) void wgrad_halo_bf16_kernel(const WHaloArgs p)
                 v = *reinterpret_cast<const float4 *>(dyb + ((size_t)(pp >> 5) * p.W + (pp & 31)) * p.Co + c4 * 4);
             }
             rp[i] = v;
+            if (do_bias) {                 // this thread always loads the same four channels (NT % 16 == 0)
+                bsum.x += v.x; bsum.y += v.y; bsum.z += v.z; bsum.w += v.w;
+            }
         }
         const float *xb = p.X + (size_t)b * p.H * p.W * p.Ci + ci0;
 #pragma unroll
@@ -1395,6 +1459,18 @@ __global__ __launch_bounds__(384) void wgrad_halo_bf16_kernel(const WHaloArgs p)
         __syncthreads();
     }
 
+    if (do_bias) {                         // 24 threads hold partial sums of the same four channels: combine in LDS
+        float *red = reinterpret_cast<float *>(smem);          // (the tiles are dead: the loop ended with a barrier)
+        if (tid < BM) red[tid] = 0.f;
+        __syncthreads();
+        const int ch = (tid & 15) * 4;
+        atomicAdd(&red[ch + 0], bsum.x);
+        atomicAdd(&red[ch + 1], bsum.y);
+        atomicAdd(&red[ch + 2], bsum.z);
+        atomicAdd(&red[ch + 3], bsum.w);
+        __syncthreads();
+        if (tid < BM) atomicAdd(&p.DB[c0 + tid], red[tid]);
+    }
     const int l31 = lane & 31, lh = lane >> 5;
     const int K = KS * KS * p.Ci;
 #pragma unroll
@@ -1406,9 +1482,10 @@ __global__ __launch_bounds__(384) void wgrad_halo_bf16_kernel(const WHaloArgs p)
     }
 }
 
-int launch_wgrad_halo(const hoig_conv_desc *d, const float *x, const float *dy, float *dw, int ns, hipStream_t st) {
+int launch_wgrad_halo(const hoig_conv_desc *d, const float *x, const float *dy, float *dw, float *dbias, int ns,
+                      hipStream_t st) {
     WHaloArgs a;
-    a.DY = dy; a.X = x; a.DW = dw;
+    a.DY = dy; a.X = x; a.DW = dw; a.DB = dbias;
     a.Bn = d->B; a.H = d->Ho; a.W = d->Wo; a.Co = d->Co; a.Ci = d->Ci;
     a.tiles_x = a.W / 32;
     a.tiles_y = a.H / 2;
@@ -1430,7 +1507,16 @@ int launch_wgrad_halo(const hoig_conv_desc *d, const float *x, const float *dy, 
 
 }  // namespace
 
-int hoig_conv_bf16_wgrad(const hoig_conv_desc *d, const float *x, const float *dy, float *dw, hipStream_t st) {
+bool hoig_conv_bf16_wgrad_fuses_bias(const hoig_conv_desc *d) {
+    static const bool no_halo = getenv("HOIG_NO_WGRAD_HALO") != nullptr;
+    return !no_halo && d->precision != HOIG_PREC_F32 && !d->transposed && d->stride == 1 && d->R == 3 && d->S == 3 &&
+           d->pad == 1 && d->Hi == d->Ho && d->Wi == d->Wo && d->Wo % 32 == 0 && d->Ho % 2 == 0 && d->Ci % 32 == 0 &&
+           d->Co % 64 == 0;
+}
+
+// dbias: only passed (non-null) when hoig_conv_bf16_wgrad_fuses_bias(d); every other shape gets its bias gradient from
+// hoig_colsum_accum in the caller
+int hoig_conv_bf16_wgrad(const hoig_conv_desc *d, const float *x, const float *dy, float *dw, float *dbias, hipStream_t st) {
     if ((d->Co & 3) || (d->Ci & 3) || d->Co < 32) return HOIG_EUNSUPPORTED;
     WArgs a;
     a.DW = dw;
@@ -1458,10 +1544,7 @@ int hoig_conv_bf16_wgrad(const hoig_conv_desc *d, const float *x, const float *d
         a.lh = __builtin_ctz(a.Hp);
     }
     const int ns = d->precision == HOIG_PREC_BF16X3 ? 2 : 1;
-    static const bool no_halo = getenv("HOIG_NO_WGRAD_HALO") != nullptr;
-    if (!no_halo && !d->transposed && d->stride == 1 && d->R == 3 && d->S == 3 && d->pad == 1 && d->Hi == d->Ho &&
-        d->Wi == d->Wo && d->Wo % 32 == 0 && d->Ho % 2 == 0 && d->Ci % 32 == 0 && d->Co % 64 == 0)
-        return launch_wgrad_halo(d, x, dy, dw, ns, st);
+    if (hoig_conv_bf16_wgrad_fuses_bias(d)) return launch_wgrad_halo(d, x, dy, dw, dbias, ns, st);
     if (a.Co <= 64) return launch_wgrad_bf16<64>(a, ns, st);
     return launch_wgrad_bf16<128>(a, ns, st);
 }

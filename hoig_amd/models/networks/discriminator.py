@@ -31,10 +31,10 @@ class PatchDiscriminator(ParamTree):
         x = ops.conv2d(x, P['model.0.weight'], P['model.0.bias'], 2, 1, ACT_LRELU, 0.2)
         idx = 2
         for _ in range(1, self.n_layers):
-            x = ops.conv2d(x, P['model.%d.weight' % idx], P['model.%d.bias' % idx], 2, 1)
+            x = ops.conv2d(x, P['model.%d.weight' % idx], P['model.%d.bias' % idx], 2, 1, dead_bias=True)
             x = ops.instance_norm(x, act=ACT_LRELU, slope=0.2)
             idx += 3
-        x = ops.conv2d(x, P['model.%d.weight' % idx], P['model.%d.bias' % idx], 1, 1)
+        x = ops.conv2d(x, P['model.%d.weight' % idx], P['model.%d.bias' % idx], 1, 1, dead_bias=True)
         x = ops.instance_norm(x, act=ACT_LRELU, slope=0.2)
         idx += 3
         return ops.conv2d(x, P['model.%d.weight' % idx], P['model.%d.bias' % idx], 1, 1, ACT_NONE)

@@ -43,8 +43,9 @@ class Generator(ParamTree):
         return self._name
 
     # ---- building blocks -------------------------------------------------------------------
-    def _conv(self, x, name, stride=1, pad=1, act=ACT_NONE):
-        return ops.conv2d(x, self.P[name + '.weight'], self.P.get(name + '.bias'), stride, pad, act)
+    def _conv(self, x, name, stride=1, pad=1, act=ACT_NONE, to_norm=False):
+        # to_norm: the output goes straight into an instance norm, which cancels the bias (ops.conv2d dead_bias)
+        return ops.conv2d(x, self.P[name + '.weight'], self.P.get(name + '.bias'), stride, pad, act, dead_bias=to_norm)
 
     def _convT(self, x, name):
         return ops.conv_transpose2d(x, self.P[name + '.weight'])
@@ -72,28 +73,28 @@ class Generator(ParamTree):
         return ops.spade_norm(x, gamma, beta, act=act)
 
     def _conv_in_relu(self, x, name, stride=1, pad=1, transposed=False):
-        h = self._convT(x, name + '.0') if transposed else self._conv(x, name + '.0', stride, pad)
+        h = self._convT(x, name + '.0') if transposed else self._conv(x, name + '.0', stride, pad, to_norm=True)
         return self._in(h, name + '.1', act=ACT_RELU)
 
     def _resblock(self, x, name):                                          # generator.py:9-32
-        h = self._in(self._conv(x, name + '.main.0'), name + '.main.1', act=ACT_RELU)
-        return self._in(self._conv(h, name + '.main.3'), name + '.main.4', residual=x)
+        h = self._in(self._conv(x, name + '.main.0', to_norm=True), name + '.main.1', act=ACT_RELU)
+        return self._in(self._conv(h, name + '.main.3', to_norm=True), name + '.main.4', residual=x)
 
     def _spade_resblock(self, x, seg, name):                               # generator.py:63-71
-        dx = self._conv(self._spade(x, seg, name + '.norm_0', ACT_RELU), name + '.conv_0')
+        dx = self._conv(self._spade(x, seg, name + '.norm_0', ACT_RELU), name + '.conv_0', to_norm=True)
         dx = self._conv(self._spade(dx, seg, name + '.norm_1', ACT_RELU), name + '.conv_1')
         return ops.add(x, dx)
 
     def _spade_block(self, x, seg, name, down):                            # generator.py:74-90
-        h = self._conv(x, name + '.conv', stride=2) if down else self._convT(x, name + '.conv')
+        h = self._conv(x, name + '.conv', stride=2, to_norm=True) if down else self._convT(x, name + '.conv')
         return self._spade(h, seg, name + '.norm', ACT_RELU)
 
     def _bg_net(self, x):                                                  # generator.py:93-135
         c, p = self.cfg, 'bg_model.model'
-        x = self._in(self._conv(x, p + '.0', pad=3), p + '.1', act=ACT_RELU)
+        x = self._in(self._conv(x, p + '.0', pad=3, to_norm=True), p + '.1', act=ACT_RELU)
         idx = 3
         for _ in range(c.n_down):
-            x = self._in(self._conv(x, p + '.%d' % idx, stride=2), p + '.%d' % (idx + 1), act=ACT_RELU)
+            x = self._in(self._conv(x, p + '.%d' % idx, stride=2, to_norm=True), p + '.%d' % (idx + 1), act=ACT_RELU)
             idx += 3
         for _ in range(c.repeat_num):
             x = self._resblock(x, p + '.%d' % idx)

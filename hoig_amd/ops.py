@@ -106,7 +106,7 @@ def _packed_planes(w, transposed, for_dgrad):
 
 class _Conv(Function):
     @staticmethod
-    def forward(ctx, x, w, b, stride, pad, transposed, act, slope, out_hw, prec):
+    def forward(ctx, x, w, b, stride, pad, transposed, act, slope, out_hw, prec, dead_bias=False):
         _chk(x, 'x'); _chk(w, 'w'); _chk(b, 'bias')
         assert x.is_contiguous() and x.dim() == 4
         B, Hi, Wi, Ci = x.shape
@@ -126,7 +126,7 @@ class _Conv(Function):
         _conv_fwd_raw(d, x, w, b, y, transposed)
         ctx.d = d
         ctx.transposed = transposed
-        ctx.has_bias = b is not None
+        ctx.has_bias = b is not None and not dead_bias
         ctx.save_for_backward(x, w, b, y if act != L.ACT_NONE else None)
         return y
 
@@ -153,11 +153,14 @@ class _Conv(Function):
         if ctx.needs_input_grad[0]:
             dx = torch.empty_like(x)
             _conv_dgrad_raw(d, g, w, dx, ctx.transposed)
-        return dx, dw_ret, db_ret, None, None, None, None, None, None, None
+        return dx, dw_ret, db_ret, None, None, None, None, None, None, None, None
 
 
-def conv2d(x, w, b=None, stride=1, pad=0, act=L.ACT_NONE, slope=0.0, prec=None):
-    return _Conv.apply(x, w, b, stride, pad, False, act, slope, None, precision if prec is None else prec)
+def conv2d(x, w, b=None, stride=1, pad=0, act=L.ACT_NONE, slope=0.0, prec=None, dead_bias=False):
+    """dead_bias=True: the output feeds an instance normalisation directly, whose mean subtraction makes the bias
+    gradient exactly zero in exact arithmetic (the reference computes ~1e-10 rounding noise there); the column sum of dy
+    is skipped and the bias gradient left at zero."""
+    return _Conv.apply(x, w, b, stride, pad, False, act, slope, None, precision if prec is None else prec, dead_bias)
 
 
 def conv_transpose2d(x, w, stride=2, pad=1, output_padding=1, prec=None):
