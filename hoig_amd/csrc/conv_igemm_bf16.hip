@@ -937,11 +937,13 @@ int launch_halo3_one(const HaloArgs &a, hipStream_t st) {
 int launch_halo3(HaloArgs a, int ns, hipStream_t st) {
     a.tiles_x = a.W / 32;
     a.tiles_y = a.H / 4;
-    const bool n64 = (a.N % 128) != 0;
+    static const int n64_max = getenv("HOIG_HALO_N64_MAX") ? atoi(getenv("HOIG_HALO_N64_MAX")) : 0;
+    const bool n64 = (a.N % 128) != 0 || a.Bn * a.tiles_x * a.tiles_y * (a.N / 128) < n64_max;
     a.nblk_n = (int)hoig_cdiv(a.N, n64 ? 64 : 128);
     a.nblk = a.Bn * a.tiles_x * a.tiles_y * a.nblk_n;
     if (n64) return ns == 2 ? launch_halo3_one<2, 2, 64>(a, st) : launch_halo3_one<1, 2, 64>(a, st);
-    const bool wide = a.nblk < 384 && getenv("HOIG_HALO_4W") == nullptr;
+    static const int wide_max = getenv("HOIG_HALO_WIDE_MAX") ? atoi(getenv("HOIG_HALO_WIDE_MAX")) : 384;
+    const bool wide = a.nblk < wide_max;
     if (ns == 2) return wide ? launch_halo3_one<2, 4, 128>(a, st) : launch_halo3_one<2, 2, 128>(a, st);
     return wide ? launch_halo3_one<1, 4, 128>(a, st) : launch_halo3_one<1, 2, 128>(a, st);
 }
@@ -1295,9 +1297,13 @@ int launch_wgrad_bf16(WArgs a, int ns, hipStream_t st) {
     const int nbm = (int)hoig_cdiv(a.Co, BM), nbn = (int)hoig_cdiv(a.K, 128);
     a.nblk_n = nbn;
     a.nblk_mn = nbm * nbn;
-    static const int target_blocks = getenv("HOIG_WGRAD_BLOCKS") ? atoi(getenv("HOIG_WGRAD_BLOCKS")) : 2048;
+    static const int target_blocks = getenv("HOIG_WGRAD_BLOCKS") ? atoi(getenv("HOIG_WGRAD_BLOCKS")) : 512;
     int splits = (int)hoig_cdiv(target_blocks, a.nblk_mn);
-    const int max_splits = (int)hoig_cdiv(a.M, 512);
+    // every split adds |dW| fp32 atomics (~235 G/s chip-wide, i.e. as slow as the MFMA work of ~2000 pixels) while fewer
+    // than ~2 workgroups per CU leave SIMDs idle: measured optimum ~512 workgroups (sweep 512/1024/2048: 32.7/33.1/33.1 ms
+    // of weight gradients per step), splits of at least 512 pixels
+    static const int min_px = getenv("HOIG_WGRAD_MIN_PX") ? atoi(getenv("HOIG_WGRAD_MIN_PX")) : 512;
+    const int max_splits = (int)hoig_cdiv(a.M, min_px);
     if (splits > max_splits) splits = max_splits;
     if (splits < 1) splits = 1;
     const int mps = (int)hoig_cdiv(hoig_cdiv(a.M, splits), 32) * 32;
