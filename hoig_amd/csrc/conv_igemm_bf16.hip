@@ -486,6 +486,9 @@ struct HaloArgs {
     float slope;
     int nblk_n, nblk;
     int tiles_x, tiles_y;
+#ifdef HOIG_STAMP
+    unsigned long long *dbg;   // diagnostic build only (tools/stamp_halo.py): per-wave cycle sums of the step phases
+#endif
 };
 
 template <int KS, int NS, int WN, int BN = 128>
@@ -692,11 +695,18 @@ __global__ __launch_bounds__(128 * WN) void conv_halo_bf16_kernel(const HaloArgs
 // published together, so the two barriers, the weight publication and the fragment-read ramp that bracket every step are
 // paid once per 3 x 768 MFMA cycles instead of once per 768.  LDS: halo 32 KB + 3 weight tiles 48 KB = 80 KB (dynamic),
 // exactly two workgroups per CU.  Weights are prefetched one step (2304 MFMA cycles per wave) ahead.
-template <int NS, int WN, int BN = 128, bool DB = false>
-__global__ __launch_bounds__(128 * WN) void conv_halo3_bf16_kernel(const HaloArgs p) {
-    constexpr int KS = 3, TH = 4, TW = 32;
-    constexpr int NT = 128 * WN;
-    constexpr int RB = BN * 4 / NT;                        // 16-B weight chunks per thread per plane per tap
+// MODE 0: single LDS stage (two barriers per step; two 80-KB workgroups per CU)
+// MODE 1: halo and weight tiles double-buffered (one 160-KB workgroup per CU, one barrier per step)
+// MODE 2: weight tiles double-buffered, halo single (WM = 4: 8 rows x 32 pixels per workgroup, 152 KB) -- the weight tile
+//         of a step is shared by twice the pixels, which halves the dominant L2 -> LDS stream: in-kernel stamps
+//         (tools/stamp_halo.py) show the 4x32 tile waiting on the per-CU fill path (~30 B/clk/CU), not on the MFMA
+template <int NS, int WM, int WN, int BN = 128, int MODE = 0>
+__global__ __launch_bounds__(64 * WM * WN) void conv_halo3_bf16_kernel(const HaloArgs p) {
+    constexpr int KS = 3, TH = 2 * WM, TW = 32;
+    constexpr int NT = 64 * WM * WN;
+    constexpr bool DB = MODE == 1;
+    constexpr int RB = BN * 4 >= NT ? BN * 4 / NT : 1;     // 16-B weight chunks per thread per plane per tap
+    constexpr bool B_PART = BN * 4 < NT;                   // more threads than chunks: only the first BN*4 threads load weights
     constexpr int HH = TH + KS - 1, HW = TW + KS - 1, HPIX = HH * HW;
     constexpr int AROW = 80;
     constexpr int PLANE_A = HPIX * AROW, PLANE_B = BN * 64;
@@ -705,11 +715,11 @@ __global__ __launch_bounds__(128 * WN) void conv_halo3_bf16_kernel(const HaloArg
     // DB (the 8-wave variant: ONE workgroup per CU, so LDS is free): halo and weight tiles are double-buffered -- the next
     // step's weights (and, at a channel-block boundary, the next halo) are written into the other buffer BEFORE this
     // step's multiply, one barrier per step, nothing but barrier skew is exposed.  160 KB exactly.
-    constexpr int NBUF = DB ? 2 : 1;
+    constexpr int NBUF_A = MODE == 1 ? 2 : 1, NBUF_B = MODE == 0 ? 1 : 2;
     constexpr int ABUF = NS * PLANE_A, BBUF = KS * NS * PLANE_B;
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];   // NBUF * (ABUF + BBUF)
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];   // NBUF_A * ABUF + NBUF_B * BBUF
     unsigned char *Abase = smem;
-    unsigned char *Bbase = smem + NBUF * ABUF;
+    unsigned char *Bbase = smem + NBUF_A * ABUF;
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int l31 = lane & 31, lh = lane >> 5;
@@ -729,8 +739,9 @@ __global__ __launch_bounds__(128 * WN) void conv_halo3_bf16_kernel(const HaloArg
     for (int i = 0; i < RB; ++i) {
         const int n = n0 + brow + (NT / 4) * i;
         const size_t o = plane_index(n, bchunk * 8, p.K);
-        wrow_h[i] = n < p.N ? p.Wh + o : nullptr;
-        wrow_l[i] = (NS == 2 && n < p.N) ? p.Wl + o : nullptr;
+        const bool ok = n < p.N && (!B_PART || brow < BN);
+        wrow_h[i] = ok ? p.Wh + o : nullptr;
+        wrow_l[i] = (NS == 2 && ok) ? p.Wl + o : nullptr;
         const int row = brow + (NT / 4) * i;
         boff[i] = row * 64 + ((bchunk ^ ((row >> 2) & 3)) << 4);
     }
@@ -774,6 +785,7 @@ __global__ __launch_bounds__(128 * WN) void conv_halo3_bf16_kernel(const HaloArg
             unsigned char *Bh = Bbase + buf * BBUF + t * NS * PLANE_B, *Bl = Bh + PLANE_B;
 #pragma unroll
             for (int i = 0; i < RB; ++i) {
+                if (B_PART && brow >= BN) continue;
                 *reinterpret_cast<uint4 *>(Bh + boff[i]) = rbh[t][i];
                 if (NS == 2) *reinterpret_cast<uint4 *>(Bl + boff[i]) = rbl[t][i];
             }
@@ -811,48 +823,83 @@ __global__ __launch_bounds__(128 * WN) void conv_halo3_bf16_kernel(const HaloArg
             }
         }
     };
+    // fragments of sub-step i+1 (tap t, k-half ks) are read into a second register set before the MFMAs of sub-step i
+    // issue: with one or two waves per SIMD the LDS latency of a just-in-time read is otherwise exposed
+    struct Frags {
+        bf16x8 ah[TM], al[TM], bh[TN], bl[TN];
+    };
     auto compute = [&](int r, int abuf, int bbuf) {
         const unsigned char *Ah = Abase + abuf * ABUF, *Al = Ah + PLANE_A;
-#pragma unroll
-        for (int t = 0; t < KS; ++t) {
+        auto read = [&](Frags &f, int i) {
+            const int t = i >> 1, ks = i & 1;
             const int tapoff = (r * HW + t) * AROW;
             const unsigned char *Bh = Bbase + bbuf * BBUF + t * NS * PLANE_B, *Bl = Bh + PLANE_B;
 #pragma unroll
-            for (int ks = 0; ks < 2; ++ks) {
-                bf16x8 ah[TM], al[TM], bhf[TN], blf[TN];
+            for (int ii = 0; ii < TM; ++ii) {
+                const int off = aread[ii] + tapoff + ks * 32;
+                f.ah[ii] = *reinterpret_cast<const bf16x8 *>(Ah + off);
+                if (NS == 2) f.al[ii] = *reinterpret_cast<const bf16x8 *>(Al + off);
+            }
 #pragma unroll
-                for (int i = 0; i < TM; ++i) {
-                    const int off = aread[i] + tapoff + ks * 32;
-                    ah[i] = *reinterpret_cast<const bf16x8 *>(Ah + off);
-                    if (NS == 2) al[i] = *reinterpret_cast<const bf16x8 *>(Al + off);
-                }
+            for (int j = 0; j < TN; ++j) {
+                const int off = bread[j] ^ (ks << 5);
+                f.bh[j] = *reinterpret_cast<const bf16x8 *>(Bh + off);
+                if (NS == 2) f.bl[j] = *reinterpret_cast<const bf16x8 *>(Bl + off);
+            }
+        };
+        auto mma = [&](const Frags &f) {
+#pragma unroll
+            for (int ii = 0; ii < TM; ++ii)
 #pragma unroll
                 for (int j = 0; j < TN; ++j) {
-                    const int off = bread[j] ^ (ks << 5);
-                    bhf[j] = *reinterpret_cast<const bf16x8 *>(Bh + off);
-                    if (NS == 2) blf[j] = *reinterpret_cast<const bf16x8 *>(Bl + off);
-                }
-#pragma unroll
-                for (int i = 0; i < TM; ++i)
-#pragma unroll
-                    for (int j = 0; j < TN; ++j) {
-                        if (NS == 2) {
-                            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[i], bhf[j], acc[i][j], 0, 0, 0);
-                            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[i], blf[j], acc[i][j], 0, 0, 0);
-                        }
-                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[i], bhf[j], acc[i][j], 0, 0, 0);
+                    if (NS == 2) {
+                        acc[ii][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f.al[ii], f.bh[j], acc[ii][j], 0, 0, 0);
+                        acc[ii][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f.ah[ii], f.bl[j], acc[ii][j], 0, 0, 0);
                     }
-            }
+                    acc[ii][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f.ah[ii], f.bh[j], acc[ii][j], 0, 0, 0);
+                }
+        };
+        Frags f0, f1;
+        read(f0, 0);
+#pragma unroll
+        for (int i = 0; i < 2 * KS; i += 2) {
+            read(f1, i + 1);
+            __builtin_amdgcn_sched_barrier(0);      // keep the reads of sub-step i+1 AHEAD of the MFMAs of sub-step i
+            mma(f0);
+            __builtin_amdgcn_sched_barrier(0);
+            if (i + 2 < 2 * KS) read(f0, i + 2);
+            __builtin_amdgcn_sched_barrier(0);
+            mma(f1);
+            __builtin_amdgcn_sched_barrier(0);
         }
     };
-
     // (staging the weight tiles by LDS-DMA -- global_load_lds, the pre-swizzled plane blocks are LDS images -- measured
     // ~9 % SLOWER here than the register-staged ds_write_b128 path below)
     halo_load(0);
     halo_store(0);
     load_b(0);
     store_b(0);
-    if (DB) {
+    if (MODE == 2) {
+        if (T > 1) load_b(1);
+        __syncthreads();
+        int bbuf = 0;
+#pragma unroll 1
+        for (int step = 0; step < T; ++step) {
+            const int cb = step / KS, r = step - cb * KS;
+            const bool more = step + 1 < T;
+            const bool boundary = more && r == KS - 1;
+            if (more) store_b(bbuf ^ 1);                  // weights of step+1 (registers loaded during the previous step)
+            if (step + 2 < T) load_b(step + 2);
+            if (boundary) halo_load(cb + 1);
+            compute(r, 0, bbuf);
+            if (boundary) {
+                __syncthreads();                          // every wave is done with the halo
+                halo_store(0);
+            }
+            __syncthreads();
+            bbuf ^= 1;
+        }
+    } else if (DB) {
         if (T > 1) load_b(1);
         __syncthreads();
         int abuf = 0, bbuf = 0;
@@ -872,6 +919,14 @@ __global__ __launch_bounds__(128 * WN) void conv_halo3_bf16_kernel(const HaloArg
         }
     } else {
         __syncthreads();
+#ifdef HOIG_STAMP
+        unsigned long long c_issue = 0, c_comp = 0, c_b1 = 0, c_st = 0, c_b2 = 0;
+        const unsigned long long t_begin = clock64();
+#define STAMP(v) { const unsigned long long t_ = clock64(); v += t_ - t_prev; t_prev = t_; }
+        unsigned long long t_prev = t_begin;
+#else
+#define STAMP(v)
+#endif
 #pragma unroll 1
         for (int step = 0; step < T; ++step) {
             const int cb = step / KS, r = step - cb * KS;
@@ -879,14 +934,26 @@ __global__ __launch_bounds__(128 * WN) void conv_halo3_bf16_kernel(const HaloArg
             const bool boundary = more && r == KS - 1;
             if (more) load_b(step + 1);
             if (boundary) halo_load(cb + 1);
+            STAMP(c_issue)
             compute(r, 0, 0);
+            STAMP(c_comp)
             if (more) {
                 __syncthreads();                  // every wave has finished reading the weight tiles (and the halo)
+                STAMP(c_b1)
                 if (boundary) halo_store(0);
                 store_b(0);
+                STAMP(c_st)
                 __syncthreads();
+                STAMP(c_b2)
             }
         }
+#ifdef HOIG_STAMP
+        if (p.dbg && lane == 0) {
+            unsigned long long *d = p.dbg + ((size_t)blockIdx.x * (NT / 64) + wave) * 8;
+            d[0] = c_issue; d[1] = c_comp; d[2] = c_b1; d[3] = c_st; d[4] = c_b2; d[5] = clock64() - t_begin;
+            d[6] = __builtin_amdgcn_s_memrealtime();
+        }
+#endif
     }
 
     const float nslope = p.act == HOIG_ACT_NONE ? 1.f : (p.act == HOIG_ACT_RELU ? 0.f : p.slope);
@@ -917,35 +984,56 @@ __global__ __launch_bounds__(128 * WN) void conv_halo3_bf16_kernel(const HaloArg
     }
 }
 
-template <int NS, int WN, int BN>
+template <int NS, int WM, int WN, int BN, int MODE>
 int launch_halo3_one(const HaloArgs &a, hipStream_t st) {
-    constexpr int HPIX = 6 * 34;
-    constexpr bool DB = WN == 4;              // one workgroup per CU anyway: spend the LDS on double buffering
-    constexpr size_t shm = (DB ? 2 : 1) * (NS * (HPIX * 80) + 3 * NS * (BN * 64));
+    constexpr int HPIX = (2 * WM + 2) * 34;
+    constexpr size_t shm = (MODE == 1 ? 2 : 1) * (NS * (HPIX * 80)) + (MODE == 0 ? 1 : 2) * (3 * NS * (BN * 64));
     static bool once = false;
     if (!once) {
-        if (hipFuncSetAttribute(reinterpret_cast<const void *>(&conv_halo3_bf16_kernel<NS, WN, BN, DB>),
+        if (hipFuncSetAttribute(reinterpret_cast<const void *>(&conv_halo3_bf16_kernel<NS, WM, WN, BN, MODE>),
                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm) != hipSuccess)
             return HOIG_ELAUNCH;
         once = true;
     }
-    conv_halo3_bf16_kernel<NS, WN, BN, DB><<<a.nblk, 128 * WN, shm, st>>>(a);
+    conv_halo3_bf16_kernel<NS, WM, WN, BN, MODE><<<a.nblk, 64 * WM * WN, shm, st>>>(a);
     HOIG_LAUNCH_CHECK();
     return HOIG_OK;
 }
 
+#ifdef HOIG_STAMP
+static unsigned long long *g_stamp_buf = nullptr;
+extern "C" void hoig_debug_set_stamp_buffer(unsigned long long *buf) { g_stamp_buf = buf; }
+#endif
+
 int launch_halo3(HaloArgs a, int ns, hipStream_t st) {
+#ifdef HOIG_STAMP
+    a.dbg = g_stamp_buf;
+#endif
     a.tiles_x = a.W / 32;
     a.tiles_y = a.H / 4;
     static const int n64_max = getenv("HOIG_HALO_N64_MAX") ? atoi(getenv("HOIG_HALO_N64_MAX")) : 0;
     const bool n64 = (a.N % 128) != 0 || a.Bn * a.tiles_x * a.tiles_y * (a.N / 128) < n64_max;
     a.nblk_n = (int)hoig_cdiv(a.N, n64 ? 64 : 128);
     a.nblk = a.Bn * a.tiles_x * a.tiles_y * a.nblk_n;
-    if (n64) return ns == 2 ? launch_halo3_one<2, 2, 64>(a, st) : launch_halo3_one<1, 2, 64>(a, st);
+    if (n64) return ns == 2 ? launch_halo3_one<2, 2, 2, 64, 0>(a, st) : launch_halo3_one<1, 2, 2, 64, 0>(a, st);
+    static const bool tall64 = getenv("HOIG_HALO_NO_TALL64") == nullptr;
+    if (tall64 && a.H % 8 == 0 && a.nblk / 2 < 256 && a.nblk >= 192) {   // too few 8-row tiles at BN = 128: 8 rows x 64 channels
+        a.tiles_y = a.H / 8;
+        a.nblk_n = a.N / 64;
+        a.nblk = a.Bn * a.tiles_x * a.tiles_y * a.nblk_n;
+        return ns == 2 ? launch_halo3_one<2, 4, 2, 64, 2>(a, st) : launch_halo3_one<1, 4, 2, 64, 2>(a, st);
+    }
+    // 8 x 32 pixel tiles (8 waves, weight tile shared by 256 pixels) when that still gives every CU a workgroup
+    static const int tall_min = getenv("HOIG_HALO_TALL_MIN") ? atoi(getenv("HOIG_HALO_TALL_MIN")) : 256;
+    if (a.H % 8 == 0 && a.nblk / 2 >= tall_min) {
+        a.tiles_y = a.H / 8;
+        a.nblk = a.Bn * a.tiles_x * a.tiles_y * a.nblk_n;
+        return ns == 2 ? launch_halo3_one<2, 4, 2, 128, 2>(a, st) : launch_halo3_one<1, 4, 2, 128, 2>(a, st);
+    }
     static const int wide_max = getenv("HOIG_HALO_WIDE_MAX") ? atoi(getenv("HOIG_HALO_WIDE_MAX")) : 384;
     const bool wide = a.nblk < wide_max;
-    if (ns == 2) return wide ? launch_halo3_one<2, 4, 128>(a, st) : launch_halo3_one<2, 2, 128>(a, st);
-    return wide ? launch_halo3_one<1, 4, 128>(a, st) : launch_halo3_one<1, 2, 128>(a, st);
+    if (ns == 2) return wide ? launch_halo3_one<2, 2, 4, 128, 1>(a, st) : launch_halo3_one<2, 2, 2, 128, 0>(a, st);
+    return wide ? launch_halo3_one<1, 2, 4, 128, 1>(a, st) : launch_halo3_one<1, 2, 2, 128, 0>(a, st);
 }
 
 template <int KS>
