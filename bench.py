@@ -174,6 +174,7 @@ def main():
     ap.add_argument('--batch', type=int, default=8, help='pairs per GPU')
     ap.add_argument('--side', type=int, default=256)
     ap.add_argument('--gen_name', default='generator_spade_attn')
+    ap.add_argument('--dataset', default='hov3', choices=['hov3', 'dexycb'], help='channel configuration (config C4 = dexycb at --side 512 --batch 4)')
     ap.add_argument('--precision', default=os.environ.get('HOIG_PRECISION', 'bf16x3'))
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-gen-fwd', action='store_true')
@@ -197,11 +198,11 @@ def main():
     from common import opt_namespace
     ops.set_precision(args.precision)
 
-    opt = opt_namespace(gen_name=args.gen_name, local_rank=local_rank, image_size=args.side)
+    opt = opt_namespace(gen_name=args.gen_name, local_rank=local_rank, image_size=args.side, dataset_mode=args.dataset)
     torch.manual_seed(8)
     model = ModelsFactory.get_by_name('trainer', opt, use_ddp=ddp)
     model.set_train()
-    model.set_input(synthetic.make_inputs(args.batch, args.side, seed=8 + rank))
+    model.set_input(synthetic.make_inputs(args.batch, args.side, seed=8 + rank, dataset=args.dataset))
     torch.cuda.synchronize()
 
     def barrier():
@@ -232,8 +233,9 @@ def main():
             'value': round(value, 3), 'unit': 'images/s', 'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
             'ms_per_step': round(ms, 3), 'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
             'dtype': args.precision, 'data': 'synthetic',
-            'config': {'workload': '%dx%d HO3Dv3-shaped synthetic, batch %d per GPU, G+D full step (%s, VGG19 '
-                                   'surrogate weights)' % (args.side, args.side, args.batch, args.gen_name),
+            'config': {'workload': '%dx%d %s-shaped synthetic, batch %d per GPU, G+D full step (%s, VGG19 '
+                                   'surrogate weights)' % (args.side, args.side, 'HO3Dv3' if args.dataset == 'hov3' else 'DexYCB',
+                                                           args.batch, args.gen_name),
                        'global_batch': world * args.batch, 'parallelism': 'dp%d' % world},
             'step_tflops': round(GFLOP_PER_PAIR_TRAIN_256 * (args.side / 256.0) ** 2 * value / 1e3, 2),
             'roofline': roof,

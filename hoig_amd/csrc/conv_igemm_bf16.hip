@@ -486,6 +486,7 @@ struct HaloArgs {
     float slope;
     int nblk_n, nblk;
     int tiles_x, tiles_y;
+    int nmajor;                // tile index = channel tile * pixel tiles + pixel tile (3x3 kernel)
 #ifdef HOIG_STAMP
     unsigned long long *dbg;   // diagnostic build only (tools/stamp_halo.py): per-wave cycle sums of the step phases
 #endif
@@ -724,9 +725,12 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_halo3_bf16_kernel(const Hal
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int l31 = lane & 31, lh = lane >> 5;
     const int wm = wave / WN, wn = wave % WN;
+    // XCD-contiguous tile ranges (hoig_xcd_remap) enumerate the PIXEL tiles of one channel tile first: an XCD then streams
+    // the weights of one or two channel tiles (2.4 MB each at 512x512x3x3) through its 4-MB L2 instead of all of them
     const int tile = hoig_xcd_remap(blockIdx.x, p.nblk);
-    int mt = tile / p.nblk_n;
-    const int n0 = (tile % p.nblk_n) * BN;
+    const int n_mt = p.nblk / p.nblk_n;
+    int mt = p.nmajor ? tile % n_mt : tile / p.nblk_n;
+    const int n0 = (p.nmajor ? tile / n_mt : tile % p.nblk_n) * BN;
     const int tx_ = mt % p.tiles_x;
     mt /= p.tiles_x;
     const int ty_ = mt % p.tiles_y, b = mt / p.tiles_y;
@@ -1011,6 +1015,8 @@ int launch_halo3(HaloArgs a, int ns, hipStream_t st) {
 #endif
     a.tiles_x = a.W / 32;
     a.tiles_y = a.H / 4;
+    static const int nmajor = getenv("HOIG_HALO_NMAJOR") ? atoi(getenv("HOIG_HALO_NMAJOR")) : 1;
+    a.nmajor = nmajor;
     static const int n64_max = getenv("HOIG_HALO_N64_MAX") ? atoi(getenv("HOIG_HALO_N64_MAX")) : 0;
     const bool n64 = (a.N % 128) != 0 || a.Bn * a.tiles_x * a.tiles_y * (a.N / 128) < n64_max;
     a.nblk_n = (int)hoig_cdiv(a.N, n64 ? 64 : 128);

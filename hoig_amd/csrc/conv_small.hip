@@ -71,6 +71,133 @@ __global__ __launch_bounds__(256) void conv_small_fwd_kernel(const float *__rest
     }
 }
 
+// Forward, register-blocked: a thread owns FOUR adjacent output pixels of one row, so the 10 input pixels a tap row needs
+// are read from LDS once and feed 7 taps x 4 pixels (0.36 LDS reads per tap-pixel instead of 1), and the channel pairs of
+// a float4 go through v_pk_fma_f32 (two FMAs per lane per instruction: the 157 TF form of the fp32 VALU).
+// Tile: 16 rows x 64 columns per workgroup; the halo tile is staged 8 channels at a time as two float4 planes
+// [plane][row][slot], slot = px + (px >> 4) (one pad slot per 16 pixels) with rows 80 slots apart: the 16 lanes a
+// ds_read_b128 services together (pixels 4*tg + j of up to two rows) then fall on 16 distinct 16-B bank slots.
+typedef float f2_t __attribute__((ext_vector_type(2)));
+constexpr int F4_TW = 64, F4_TH = 16, F4_ROW = 80, F4_CC = 8;
+
+template <int CO>
+__global__ __launch_bounds__(256) void conv_small_fwd4_kernel(const float *__restrict__ x, const float *__restrict__ w,
+                                                              const float *__restrict__ bias, float *__restrict__ y,
+                                                              int B, int H, int W, int Ci, int pad, int act, float slope,
+                                                              int CoReal) {
+    constexpr int HT = F4_TH + KS - 1, WT = F4_TW + KS - 1;          // 22 x 70 halo pixels
+    constexpr int PLANE = HT * F4_ROW;                               // float4 slots per plane
+    __shared__ float4 xs[2 * PLANE];                                 // 56 KB
+    __shared__ float4 wsm[KS * KS * CO * 2];                         // this chunk's weights [tap][n][plane] (broadcast reads)
+    const int tiles_x = (W + F4_TW - 1) / F4_TW, tiles_y = (H + F4_TH - 1) / F4_TH;
+    int t = blockIdx.x;
+    const int bx = t % tiles_x;
+    t /= tiles_x;
+    const int by = t % tiles_y, b = t / tiles_y;
+    const int tg = threadIdx.x & 15, ty = threadIdx.x >> 4;
+    const int y0 = by * F4_TH - pad, x0 = bx * F4_TW - pad;
+    f2_t acc[4][CO];
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+#pragma unroll
+        for (int n = 0; n < CO; ++n) acc[j][n] = (f2_t){0.f, 0.f};
+    const size_t wn = (size_t)KS * KS * Ci;                          // weight stride between output channels
+    // the next 8-channel chunk of the halo is fetched into registers while the current one is multiplied (the fetch is an
+    // HBM-latency wait of about the length of a chunk's arithmetic; two workgroups per CU do not hide it alone)
+    constexpr int NSL = (HT * WT * 2 + 255) / 256;
+    float4 stage[NSL];
+    constexpr int NW = (KS * KS * CO * 2 + 255) / 256;
+    float4 wstage[NW];
+    auto fetch = [&](int c0) {
+#pragma unroll
+        for (int k = 0; k < NW; ++k) {
+            const int i = threadIdx.x + 256 * k;
+            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (i < KS * KS * CO * 2) {
+                const int pl = i & 1, n = (i >> 1) % CO, tap = (i >> 1) / CO;
+                v = *reinterpret_cast<const float4 *>(w + (size_t)n * wn + (size_t)tap * Ci + c0 + pl * 4);
+            }
+            wstage[k] = v;
+        }
+#pragma unroll
+        for (int k = 0; k < NSL; ++k) {
+            const int i = threadIdx.x + 256 * k;
+            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (i < HT * WT * 2) {
+                const int pl = i & 1, pix = i >> 1;
+                const int py = pix / WT, px = pix - py * WT;
+                const int gy = y0 + py, gx = x0 + px;
+                if (gy >= 0 && gy < H && gx >= 0 && gx < W)
+                    v = *reinterpret_cast<const float4 *>(x + (((size_t)b * H + gy) * W + gx) * Ci + c0 + pl * 4);
+            }
+            stage[k] = v;
+        }
+    };
+    auto publish = [&]() {
+#pragma unroll
+        for (int k = 0; k < NW; ++k) {
+            const int i = threadIdx.x + 256 * k;
+            if (i < KS * KS * CO * 2) wsm[i] = wstage[k];
+        }
+#pragma unroll
+        for (int k = 0; k < NSL; ++k) {
+            const int i = threadIdx.x + 256 * k;
+            if (i < HT * WT * 2) {
+                const int pl = i & 1, pix = i >> 1;
+                const int py = pix / WT, px = pix - py * WT;
+                xs[pl * PLANE + py * F4_ROW + px + (px >> 4)] = stage[k];
+            }
+        }
+    };
+    fetch(0);
+    for (int c0 = 0; c0 < Ci; c0 += F4_CC) {
+        __syncthreads();                                             // every wave is done with the previous chunk
+        publish();
+        __syncthreads();
+        if (c0 + F4_CC < Ci) fetch(c0 + F4_CC);
+#pragma unroll
+        for (int pl = 0; pl < 2; ++pl) {
+#pragma unroll 1
+            for (int r = 0; r < KS; ++r) {
+                const float4 *row = xs + pl * PLANE + (ty + r) * F4_ROW;
+                float4 in[4 + KS - 1];
+#pragma unroll
+                for (int q = 0; q < 4 + KS - 1; ++q) {
+                    const int px = 4 * tg + q;
+                    in[q] = row[px + (px >> 4)];
+                }
+#pragma unroll
+                for (int s = 0; s < KS; ++s) {
+#pragma unroll
+                    for (int n = 0; n < CO; ++n) {
+                        const float4 ww = wsm[((r * KS + s) * CO + n) * 2 + pl];
+                        const f2_t w01 = {ww.x, ww.y}, w23 = {ww.z, ww.w};
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) {
+                            const f2_t v01 = {in[j + s].x, in[j + s].y}, v23 = {in[j + s].z, in[j + s].w};
+                            acc[j][n] = __builtin_elementwise_fma(v01, w01, acc[j][n]);
+                            acc[j][n] = __builtin_elementwise_fma(v23, w23, acc[j][n]);
+                        }
+                    }
+                }
+            }
+        }
+    }
+    const int oy = by * F4_TH + ty;
+    if (oy < H) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int ox = bx * F4_TW + 4 * tg + j;
+            if (ox < W) {
+                float *o = y + (((size_t)b * H + oy) * W + ox) * CoReal;
+#pragma unroll
+                for (int n = 0; n < CO; ++n)
+                    o[n] = hoig_act(acc[j][n].x + acc[j][n].y + (bias ? bias[n] : 0.f), act, slope);
+            }
+        }
+    }
+}
+
 // grid: (tile groups, Ci/16).  Threads: c = tid & 15, r = (tid >> 4) % R, half = (tid >> 4) / R  (needs 2*16*R <= 256)
 template <int CO>
 __global__ __launch_bounds__(256) void conv_small_wgrad_kernel(const float *__restrict__ x, const float *__restrict__ dy,
@@ -157,10 +284,16 @@ int hoig_conv_small_fwd(const hoig_conv_desc *d, const float *x, const float *w,
                         hipStream_t st) {
     if (d->transposed || d->stride != 1 || d->Co > 4 || (d->Ci % CC) || d->R != KS || d->S != KS) return HOIG_EUNSUPPORTED;
     if (d->Ho != d->Hi || d->Wo != d->Wi || 2 * d->pad != d->R - 1 || d->R != d->S) return HOIG_EUNSUPPORTED;
-    const int tiles = d->B * (int)hoig_cdiv(d->Hi, TILE) * (int)hoig_cdiv(d->Wi, TILE);
+    static const bool old_fwd = getenv("HOIG_SMALL_FWD_OLD") != nullptr;
+    const int tiles = old_fwd ? d->B * (int)hoig_cdiv(d->Hi, TILE) * (int)hoig_cdiv(d->Wi, TILE)
+                              : d->B * (int)hoig_cdiv(d->Hi, F4_TH) * (int)hoig_cdiv(d->Wi, F4_TW);
 #define HOIG_SMALL_FWD(N)                                                                                              \
-    conv_small_fwd_kernel<N><<<tiles, 256, 0, st>>>(x, w, bias, y, d->B, d->Hi, d->Wi, d->Ci, d->R, d->S, d->pad, d->act, \
-                                                    d->slope, d->Co)
+    if (old_fwd)                                                                                                       \
+        conv_small_fwd_kernel<N><<<tiles, 256, 0, st>>>(x, w, bias, y, d->B, d->Hi, d->Wi, d->Ci, d->R, d->S, d->pad,    \
+                                                        d->act, d->slope, d->Co);                                      \
+    else                                                                                                               \
+        conv_small_fwd4_kernel<N><<<tiles, 256, 0, st>>>(x, w, bias, y, d->B, d->Hi, d->Wi, d->Ci, d->pad, d->act,       \
+                                                         d->slope, d->Co)
     switch (d->Co) {
         case 1: HOIG_SMALL_FWD(1); break;
         case 2: HOIG_SMALL_FWD(2); break;
