@@ -578,6 +578,9 @@ int hoig_conv_bf16_fwd_like(const hoig_conv_desc *d, const float *a, const float
 int hoig_conv_small_fwd(const hoig_conv_desc *d, const float *x, const float *w, const float *bias, float *y,
                         hipStream_t st);                  // conv_small.hip
 int hoig_conv_small_wgrad(const hoig_conv_desc *d, const float *x, const float *dy, float *dw, hipStream_t st);
+int hoig_conv_small_dgrad(const hoig_conv_desc *d, const float *dy, const float *w, float *dx, hipStream_t st);
+int hoig_conv_small_ci_fwd(const hoig_conv_desc *d, const float *x, const float *w, const float *bias, float *y,
+                           hipStream_t st);
 
 extern "C" int hoig_conv2d_fwd(const hoig_conv_desc *d, const float *x, const float *w, const float *bias, float *y,
                                hoig_stream_t stream) {
@@ -586,6 +589,7 @@ extern "C" int hoig_conv2d_fwd(const hoig_conv_desc *d, const float *x, const fl
     if (!x || !w || !y) return HOIG_EINVAL;
     hipStream_t st = (hipStream_t)stream;
     rc = hoig_conv_small_fwd(d, x, w, bias, y, st);           // 7x7 heads with <= 4 output channels: direct fp32 kernel
+    if (rc == HOIG_EUNSUPPORTED) rc = hoig_conv_small_ci_fwd(d, x, w, bias, y, st);    // 7x7 stems with <= 8 input channels
     if (rc != HOIG_EUNSUPPORTED) return rc;
     if (d->precision != HOIG_PREC_F32) {
         rc = hoig_conv_bf16_fwd_like(d, x, w, bias, y, false, st);
@@ -605,6 +609,8 @@ extern "C" int hoig_conv2d_bwd_data(const hoig_conv_desc *d, const float *dy, co
     if (rc) return rc;
     if (!dy || !w || !dx) return HOIG_EINVAL;
     hipStream_t st = (hipStream_t)stream;
+    rc = hoig_conv_small_dgrad(d, dy, w, dx, st);              // 7x7 heads with <= 4 output channels: direct fp32 kernel
+    if (rc != HOIG_EUNSUPPORTED) return rc;
     if (d->precision != HOIG_PREC_F32) {
         rc = hoig_conv_bf16_fwd_like(d, dy, w, nullptr, dx, true, st);
         if (rc != HOIG_EUNSUPPORTED) return rc;

@@ -198,7 +198,125 @@ __global__ __launch_bounds__(256) void conv_small_fwd4_kernel(const float *__res
     }
 }
 
+// Data gradient of the same heads: dx[p][c] = sum_{r,s,n} dy[p + pad - (r,s)][n] * w[n][r][s][c].  On the implicit GEMM this
+// is N = Ci columns over a K = 49*Co <= 147 reduction -- mostly padding.  Here: the same 16x64 pixel tile and the same four
+// adjacent pixels per thread; the dy halo tile (Co <= 4 values per pixel = one float4) and the 16-channel weight slice
+// [tap][n][4 quads] sit in LDS; a thread accumulates 4 pixels x 16 channels (32 packed accumulators); blockIdx.y walks the
+// 16-channel groups.
+// FWD = true turns the same kernel into the FORWARD of the first-layer convs (3 / 8 input channels -> 64): "dy" is then the
+// input image (channels s_off .. s_off+CO-1 of its CoReal), "dx" the output, taps are walked unflipped, the weight slice is
+// gathered from w[co][tap][ci] and, for the second 4-channel group of an 8-channel input, the result accumulates into y.
+template <int CO, bool FWD>
+__global__ __launch_bounds__(256) void conv_small_dgrad4_kernel(const float *__restrict__ dy, const float *__restrict__ w,
+                                                                float *__restrict__ dx, int B, int H, int W, int Ci,
+                                                                int pad, int CoReal, int s_off, int accumulate,
+                                                                const float *__restrict__ bias, int act, float slope) {
+    constexpr int HT = F4_TH + KS - 1, WT = F4_TW + KS - 1;
+    constexpr int PLANE = HT * F4_ROW;
+    __shared__ float4 gs[PLANE];                                     // dy halo, channels n in .x .y .z .w
+    __shared__ float4 wsm[KS * KS * CO * 4];                         // [tap][n][quad] : w[n][tap][c0 + 4*quad ..]
+    const int tiles_x = (W + F4_TW - 1) / F4_TW, tiles_y = (H + F4_TH - 1) / F4_TH;
+    int t = blockIdx.x;
+    const int bx = t % tiles_x;
+    t /= tiles_x;
+    const int by = t % tiles_y, b = t / tiles_y;
+    const int c0 = blockIdx.y * 16;
+    const int tg = threadIdx.x & 15, ty = threadIdx.x >> 4;
+    // dx[p] gathers dy at p + pad - tap: halo origin = tile origin + pad - (KS-1);  forward: x at p - pad + tap
+    const int y0 = by * F4_TH + (FWD ? -pad : pad - (KS - 1)), x0 = bx * F4_TW + (FWD ? -pad : pad - (KS - 1));
+    for (int i = threadIdx.x; i < HT * WT; i += 256) {
+        const int py = i / WT, px = i - py * WT;
+        const int gy = y0 + py, gx = x0 + px;
+        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (gy >= 0 && gy < H && gx >= 0 && gx < W) {
+            const float *g = dy + (((size_t)b * H + gy) * W + gx) * CoReal + s_off;
+            v.x = g[0];
+            if (CO > 1) v.y = g[1];
+            if (CO > 2) v.z = g[2];
+            if (CO > 3) v.w = g[3];
+        }
+        gs[py * F4_ROW + px + (px >> 4)] = v;
+    }
+    const size_t wn = (size_t)KS * KS * Ci;
+    for (int i = threadIdx.x; i < KS * KS * CO * 4; i += 256) {
+        const int q = i & 3, n = (i >> 2) % CO, tap = (i >> 2) / CO;
+        if (FWD) {      // w[co][tap][ci]: Ci = output channels here, CoReal = input channels
+            const float *wp = w + ((size_t)(c0 + q * 4) * KS * KS + tap) * CoReal + s_off + n;
+            const size_t st_ = (size_t)KS * KS * CoReal;
+            wsm[i] = make_float4(wp[0], wp[st_], wp[2 * st_], wp[3 * st_]);
+        } else {
+            wsm[i] = *reinterpret_cast<const float4 *>(w + (size_t)n * wn + (size_t)tap * Ci + c0 + q * 4);
+        }
+    }
+    __syncthreads();
+    f2_t acc[4][8];
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+#pragma unroll
+        for (int k = 0; k < 8; ++k) acc[j][k] = (f2_t){0.f, 0.f};
+#pragma unroll 1
+    for (int r = 0; r < KS; ++r) {
+        // output pixel (ty, 4tg+j) reads halo row ty + (KS-1-r), column 4tg + j + (KS-1-s)   (forward: ty + r, 4tg + j + s)
+        const float4 *row = gs + (ty + (FWD ? r : KS - 1 - r)) * F4_ROW;
+        float4 in[4 + KS - 1];
+#pragma unroll
+        for (int q = 0; q < 4 + KS - 1; ++q) {
+            const int px = 4 * tg + q;
+            in[q] = row[px + (px >> 4)];
+        }
+#pragma unroll
+        for (int s = 0; s < KS; ++s) {
+#pragma unroll
+            for (int n = 0; n < CO; ++n) {
+                float4 wq[4];
+#pragma unroll
+                for (int q = 0; q < 4; ++q) wq[q] = wsm[((r * KS + s) * CO + n) * 4 + q];
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const float4 g4 = in[j + (FWD ? s : KS - 1 - s)];
+                    const float g = n == 0 ? g4.x : (n == 1 ? g4.y : (n == 2 ? g4.z : g4.w));
+                    const f2_t gg = {g, g};
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        acc[j][2 * q] = __builtin_elementwise_fma(gg, (f2_t){wq[q].x, wq[q].y}, acc[j][2 * q]);
+                        acc[j][2 * q + 1] = __builtin_elementwise_fma(gg, (f2_t){wq[q].z, wq[q].w}, acc[j][2 * q + 1]);
+                    }
+                }
+            }
+        }
+    }
+    const int oy = by * F4_TH + ty;
+    if (oy < H) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int ox = bx * F4_TW + 4 * tg + j;
+            if (ox < W) {
+                float *o = dx + (((size_t)b * H + oy) * W + ox) * Ci + c0;
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    float4 v = make_float4(acc[j][2 * q].x, acc[j][2 * q].y, acc[j][2 * q + 1].x, acc[j][2 * q + 1].y);
+                    if (FWD) {
+                        if (accumulate) {
+                            const float4 old_ = *reinterpret_cast<const float4 *>(o + 4 * q);
+                            v.x += old_.x; v.y += old_.y; v.z += old_.z; v.w += old_.w;
+                        }
+                        if (bias) {
+                            const float4 bb = *reinterpret_cast<const float4 *>(bias + c0 + 4 * q);
+                            v.x += bb.x; v.y += bb.y; v.z += bb.z; v.w += bb.w;
+                        }
+                        v.x = hoig_act(v.x, act, slope); v.y = hoig_act(v.y, act, slope);
+                        v.z = hoig_act(v.z, act, slope); v.w = hoig_act(v.w, act, slope);
+                    }
+                    *reinterpret_cast<float4 *>(o + 4 * q) = v;
+                }
+            }
+        }
+    }
+}
+
 // grid: (tile groups, Ci/16).  Threads: c = tid & 15, r = (tid >> 4) % R, half = (tid >> 4) / R  (needs 2*16*R <= 256)
+// (running the stems' weight gradient -- few INPUT channels -- on this kernel with the tensors exchanged measured 1.3-1.7x
+// SLOWER than the fp32 MFMA wgrad kernel; they stay there)
 template <int CO>
 __global__ __launch_bounds__(256) void conv_small_wgrad_kernel(const float *__restrict__ x, const float *__restrict__ dy,
                                                                float *__restrict__ dw, int B, int H, int W, int Ci, int R,
@@ -254,8 +372,8 @@ __global__ __launch_bounds__(256) void conv_small_wgrad_kernel(const float *__re
                 float win[KS];                        // x[py+r][px + s][c], s = 0..KS-1 (sliding register window)
 #pragma unroll
                 for (int s = 0; s < KS - 1; ++s) win[s + 1] = xrow[s * PSTR];
-#pragma unroll 4
-                for (int px = 0; px < TILE; ++px) {
+#pragma unroll
+                for (int px = 0; px < TILE; ++px) {      // fully unrolled: the sliding window becomes register renaming
 #pragma unroll
                     for (int s = 0; s < KS - 1; ++s) win[s] = win[s + 1];
                     win[KS - 1] = xrow[(px + KS - 1) * PSTR];
@@ -301,6 +419,51 @@ int hoig_conv_small_fwd(const hoig_conv_desc *d, const float *x, const float *w,
         default: HOIG_SMALL_FWD(4); break;
     }
 #undef HOIG_SMALL_FWD
+    HOIG_LAUNCH_CHECK();
+    return HOIG_OK;
+}
+
+// forward of 7x7 stride-1 "same" convs with few INPUT channels (3, 8: the stems) and Co % 16 == 0: groups of <= 4 input
+// channels, the activation (and bias) applied by the last group's launch
+int hoig_conv_small_ci_fwd(const hoig_conv_desc *d, const float *x, const float *w, const float *bias, float *y,
+                           hipStream_t st) {
+    if (d->transposed || d->stride != 1 || d->Ci > 8 || (d->Co % 16) || d->R != KS || d->S != KS) return HOIG_EUNSUPPORTED;
+    if (d->Ho != d->Hi || d->Wo != d->Wi || 2 * d->pad != d->R - 1) return HOIG_EUNSUPPORTED;
+    dim3 grid(d->B * (unsigned)hoig_cdiv(d->Hi, F4_TH) * (unsigned)hoig_cdiv(d->Wi, F4_TW), d->Co / 16);
+    for (int off = 0; off < d->Ci; off += 4) {
+        const int n = d->Ci - off < 4 ? d->Ci - off : 4;
+        const bool last = off + 4 >= d->Ci;
+        const float *bb = last ? bias : nullptr;
+        const int act = last ? d->act : HOIG_ACT_NONE;
+#define HOIG_SMALL_CF(N) \
+    conv_small_dgrad4_kernel<N, true><<<grid, 256, 0, st>>>(x, w, y, d->B, d->Hi, d->Wi, d->Co, d->pad, d->Ci, off,       \
+                                                            off > 0 ? 1 : 0, bb, act, d->slope)
+        switch (n) {
+            case 1: HOIG_SMALL_CF(1); break;
+            case 2: HOIG_SMALL_CF(2); break;
+            case 3: HOIG_SMALL_CF(3); break;
+            default: HOIG_SMALL_CF(4); break;
+        }
+#undef HOIG_SMALL_CF
+        HOIG_LAUNCH_CHECK();
+    }
+    return HOIG_OK;
+}
+
+int hoig_conv_small_dgrad(const hoig_conv_desc *d, const float *dy, const float *w, float *dx, hipStream_t st) {
+    if (d->transposed || d->stride != 1 || d->Co > 4 || (d->Ci % 16) || d->R != KS || d->S != KS) return HOIG_EUNSUPPORTED;
+    if (d->Ho != d->Hi || d->Wo != d->Wi || 2 * d->pad != d->R - 1) return HOIG_EUNSUPPORTED;
+    dim3 grid(d->B * (unsigned)hoig_cdiv(d->Hi, F4_TH) * (unsigned)hoig_cdiv(d->Wi, F4_TW), d->Ci / 16);
+#define HOIG_SMALL_DG(N) \
+    conv_small_dgrad4_kernel<N, false><<<grid, 256, 0, st>>>(dy, w, dx, d->B, d->Hi, d->Wi, d->Ci, d->pad, d->Co, 0, 0, \
+                                                             nullptr, 0, 0.f)
+    switch (d->Co) {
+        case 1: HOIG_SMALL_DG(1); break;
+        case 2: HOIG_SMALL_DG(2); break;
+        case 3: HOIG_SMALL_DG(3); break;
+        default: HOIG_SMALL_DG(4); break;
+    }
+#undef HOIG_SMALL_DG
     HOIG_LAUNCH_CHECK();
     return HOIG_OK;
 }
