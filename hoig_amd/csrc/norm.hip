@@ -88,7 +88,7 @@ __global__ __launch_bounds__(NT) void inorm_partial_kernel(const float *__restri
     (void)chunk;
 }
 
-__global__ void inorm_finalize_kernel(const float *__restrict__ x, const float *__restrict__ partial, int HW, int C,
+__global__ void inorm_finalize_kernel(const float *__restrict__ x, float *__restrict__ partial, int HW, int C,
                                       int nchunks, float eps, float *__restrict__ mean, float *__restrict__ rstd,
                                       int total) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -102,10 +102,12 @@ __global__ void inorm_finalize_kernel(const float *__restrict__ x, const float *
     var = var > 0.f ? var : 0.f;
     mean[i] = x[(size_t)b * HW * C + c] + d;
     rstd[i] = 1.f / sqrtf(var + eps);
+    partial[(size_t)b * 2 * C + c] = 0.f;          // leave the accumulators zeroed for the next call (no memset launches)
+    partial[(size_t)b * 2 * C + C + c] = 0.f;
 }
 
 // sums[b][0/1][c] for the backward; affine grads accumulate atomically
-__global__ void inorm_bwd_finalize_kernel(const float *__restrict__ partial, int C, int nchunks, int mode,
+__global__ void inorm_bwd_finalize_kernel(float *__restrict__ partial, int C, int nchunks, int mode,
                                           float *__restrict__ sums, float *__restrict__ dweight,
                                           float *__restrict__ dbias, int total) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -115,6 +117,8 @@ __global__ void inorm_bwd_finalize_kernel(const float *__restrict__ partial, int
     (void)nchunks;
     sums[(size_t)b * 2 * C + c] = s1;
     sums[(size_t)b * 2 * C + C + c] = s2;
+    partial[(size_t)b * 2 * C + c] = 0.f;
+    partial[(size_t)b * 2 * C + C + c] = 0.f;
     if (mode == 1) {
         if (dbias) atomicAdd(&dbias[c], s1);
         if (dweight) atomicAdd(&dweight[c], s2);
@@ -221,18 +225,22 @@ size_t red_bytes(int C) {
 
 }  // namespace
 
+// workspace = [accumulators: B*2*C floats inside a fixed pool of ACC_POOL floats | backward sums: B*2*C floats].  The pool
+// only ever holds accumulators, which every call leaves zeroed; the sums live outside it, so a later call with a larger
+// B*2*C never finds them inside its accumulator range.
+constexpr int64_t ACC_POOL = 1 << 18;
 extern "C" int64_t hoig_inorm_workspace_bytes(int B, int HW, int C) {
-    return (int64_t)B * (inorm_chunks(HW) + 1) * 2 * C * (int64_t)sizeof(float);
+    (void)HW;
+    return (ACC_POOL + (int64_t)B * 2 * C) * (int64_t)sizeof(float);
 }
 
 extern "C" int hoig_inorm_stats(const float *x, int B, int HW, int C, float eps, float *mean, float *rstd,
                                 void *workspace, hoig_stream_t stream) {
     if (!x || !mean || !rstd || !workspace) return HOIG_EINVAL;
-    if (!shape_ok(B, HW, C)) return HOIG_EUNSUPPORTED;
+    if (!shape_ok(B, HW, C) || (int64_t)B * 2 * C > ACC_POOL) return HOIG_EUNSUPPORTED;
     hipStream_t st = (hipStream_t)stream;
     const int nch = inorm_chunks(HW);
     float *partial = (float *)workspace;
-    if (hipMemsetAsync(partial, 0, (size_t)B * 2 * C * sizeof(float), st) != hipSuccess) return HOIG_ELAUNCH;
     inorm_partial_kernel<false><<<dim3(nch, B), NT, red_bytes(C), st>>>(x, nullptr, nullptr, 0, nullptr, nullptr,
                                                                         nullptr, 0, 0.f, HW, C, nch, partial, C);
     HOIG_LAUNCH_CHECK();
@@ -280,12 +288,11 @@ extern "C" int hoig_inorm_bwd_ld(const float *x, const float *mean, const float 
     if (act != HOIG_ACT_NONE && !y) return HOIG_EINVAL;
     if (mode != 0 && !p0) return HOIG_EINVAL;
     if (mode == 2 && (!dp0 || !dp1)) return HOIG_EINVAL;
-    if (!shape_ok(B, HW, C)) return HOIG_EUNSUPPORTED;
+    if (!shape_ok(B, HW, C) || (int64_t)B * 2 * C > ACC_POOL) return HOIG_EUNSUPPORTED;
     hipStream_t st = (hipStream_t)stream;
     const int nch = inorm_chunks(HW);
     float *partial = (float *)workspace;
-    float *sums = partial + (size_t)B * nch * 2 * C;
-    if (hipMemsetAsync(partial, 0, (size_t)B * 2 * C * sizeof(float), st) != hipSuccess) return HOIG_ELAUNCH;
+    float *sums = partial + ACC_POOL;
     inorm_partial_kernel<true><<<dim3(nch, B), NT, red_bytes(C), st>>>(x, mean, rstd, mode, p0, y, dy, act, slope, HW, C,
                                                                        nch, partial, ld_p);
     HOIG_LAUNCH_CHECK();

@@ -172,6 +172,20 @@ def conv_transpose2d(x, w, stride=2, pad=1, output_padding=1, prec=None):
 
 
 # ------------------------------------------------------------------------------------------------- instance norm
+_norm_ws = {}
+
+
+def _norm_workspace(nfloats, device):
+    """One zero-initialised instance-norm workspace per (device, stream): the kernels leave their accumulators zeroed
+    (include/hoig_kernels.h), so it is never memset again."""
+    key = (device, torch.cuda.current_stream(device).cuda_stream)
+    ws = _norm_ws.get(key)
+    if ws is None or ws.numel() < nfloats:
+        ws = torch.zeros(max(nfloats, 1 << 20), dtype=torch.float32, device=device)
+        _norm_ws[key] = ws
+    return ws
+
+
 class _INorm(Function):
     @staticmethod
     def forward(ctx, x, p0, p1, mode, act, slope, residual, eps):
@@ -179,7 +193,7 @@ class _INorm(Function):
         assert x.is_contiguous()
         B, H, W, C = x.shape
         HW = H * W
-        ws = torch.empty(L.lib.hoig_inorm_workspace_bytes(B, HW, C) // 4, dtype=torch.float32, device=x.device)
+        ws = _norm_workspace(L.lib.hoig_inorm_workspace_bytes(B, HW, C) // 4, x.device)
         mean = torch.empty(B * C, dtype=torch.float32, device=x.device)
         rstd = torch.empty_like(mean)
         call('hoig_inorm_stats', _p(x), B, HW, C, eps, _p(mean), _p(rstd), _p(ws), _st())
@@ -197,7 +211,7 @@ class _INorm(Function):
         x, mean, rstd, p0, p1, y = ctx.saved_tensors
         mode, act, slope, B, HW, C, has_res = ctx.cfg
         dy = dy.contiguous()
-        ws = torch.empty(L.lib.hoig_inorm_workspace_bytes(B, HW, C) // 4, dtype=torch.float32, device=x.device)
+        ws = _norm_workspace(L.lib.hoig_inorm_workspace_bytes(B, HW, C) // 4, x.device)
         dx = torch.empty_like(x)
         dp0 = dp1 = r0 = r1 = None
         if mode == 1:
@@ -233,7 +247,7 @@ class _SpadeFused(Function):
         B, H, W, C = x.shape
         assert gb.shape[-1] == 2 * C
         HW = H * W
-        ws = torch.empty(L.lib.hoig_inorm_workspace_bytes(B, HW, C) // 4, dtype=torch.float32, device=x.device)
+        ws = _norm_workspace(L.lib.hoig_inorm_workspace_bytes(B, HW, C) // 4, x.device)
         mean = torch.empty(B * C, dtype=torch.float32, device=x.device)
         rstd = torch.empty_like(mean)
         call('hoig_inorm_stats', _p(x), B, HW, C, eps, _p(mean), _p(rstd), _p(ws), _st())
@@ -249,7 +263,7 @@ class _SpadeFused(Function):
         x, mean, rstd, gb, y = ctx.saved_tensors
         act, slope, B, HW, C = ctx.cfg
         dy = dy.contiguous()
-        ws = torch.empty(L.lib.hoig_inorm_workspace_bytes(B, HW, C) // 4, dtype=torch.float32, device=x.device)
+        ws = _norm_workspace(L.lib.hoig_inorm_workspace_bytes(B, HW, C) // 4, x.device)
         dx = torch.empty_like(x)
         dgb = torch.empty_like(gb)
         call('hoig_inorm_bwd_ld', _p(x), _p(mean), _p(rstd), 2, _p(gb), 2 * C, _p(y), _p(dy), act, slope, _p(dx), _p(dgb),

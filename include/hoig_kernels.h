@@ -88,7 +88,9 @@ int hoig_conv2d_bwd_data_packed(const hoig_conv_desc *d, const float *dy, const 
 
 /* ---- instance norm (generator.py:16-22,101-120,154-208; spade.py:13; discriminator.py:37,45 via
  *      base_network.py:31): per-(b,c) mean / biased variance over H*W, eps 1e-5, no running stats. ---- */
-/* stats: mean[b*C+c], rstd[b*C+c].  workspace: >= hoig_inorm_workspace_bytes(B,HW,C) bytes. */
+/* stats: mean[b*C+c], rstd[b*C+c].  workspace: >= hoig_inorm_workspace_bytes(B,HW,C) bytes whose first 2^18 floats (the pool
+ * of atomic accumulators, B*2*C of them used) must be ZERO on entry; hoig_inorm_stats / hoig_inorm_bwd* leave them zero again on return, so one
+ * zero-initialised workspace per stream serves every call without memset launches. */
 int64_t hoig_inorm_workspace_bytes(int B, int HW, int C);
 int hoig_inorm_stats(const float *x, int B, int HW, int C, float eps, float *mean, float *rstd, void *workspace,
                      hoig_stream_t stream);

@@ -30,7 +30,7 @@ def test_c_abi_rejects_bad_arguments_without_a_gpu():
     bad = L.ConvDesc(1, 8, 8, 4, 9, 9, 4, 3, 3, 1, 1, 0, 0, 0.0, 0)          # inconsistent output size
     assert L.lib.hoig_conv2d_fwd(ctypes.byref(bad), 1, 1, None, 1, None) == L.EINVAL
     assert L.lib.hoig_adam_step(None, None, None, None, 4, 1e-3, 0.9, 0.999, 1e-8, 1, 1.0, None) == L.EINVAL
-    assert L.lib.hoig_inorm_workspace_bytes(2, 1024, 512) == 2 * (64 + 1) * 2 * 512 * 4
+    assert L.lib.hoig_inorm_workspace_bytes(2, 1024, 512) == ((1 << 18) + 2 * 2 * 512) * 4
 
 
 def test_product_never_imports_the_oracle():
