@@ -1042,6 +1042,303 @@ int launch_halo3(HaloArgs a, int ns, hipStream_t st) {
     return wide ? launch_halo3_one<1, 2, 4, 128, 1>(a, st) : launch_halo3_one<1, 2, 2, 128, 0>(a, st);
 }
 
+// ---------------------------------------------------------------------------------------------------------------------
+// Stride-2 3x3 layers (pad 1; ConvTranspose2d with output_padding 1) on LDS halo tiles.  On the generic kernel these re-gather
+// their fp32 input from L2 / HBM for every tap (the 268-MB full-resolution tensors do not stay in L2) and run at 85-150 TF.
+// Decomposed by the PARITY of the fine-grid coordinate, every tap becomes a unit-stride read of a small halo image:
+//   GATHER mode (Conv2d s2 forward, ConvTranspose2d data gradient): out[o] = sum_{r,s} in[2o - 1 + (r,s)] w[r][s].  The input
+//     is read as its four parity phases in[2i+p][2j+q]; tap r uses phase p = (r != 1) at coarse index o + (r == 0 ? -1 : 0).
+//     Per 32-channel block: phase (1,1) serves taps (0,0),(0,2),(2,0),(2,2), phase (1,0) taps (0,1),(2,1), phase (0,1) taps
+//     (1,0),(1,2), phase (0,0) tap (1,1): five steps of <= 2 taps, four (TH+1) x 33 halo loads (stride-2 source addressing).
+//   SCATTER mode (ConvTranspose2d forward, Conv2d s2 data gradient): out[2i - 1 + (r,s)] += in[i] w[r][s].  A workgroup owns ONE
+//     output parity phase (P,Q) of a coarse tile: out[2I+P][2J+Q] = sum over the taps with r = 1 (P = 0) or r in {0,2} (P = 1)
+//     of in[I + (r == 0)][J + (s == 0)] w[r][s] -- a stride-1 conv with 1, 2 or 4 taps over one halo image; strided stores.
+// Tile: 4 x 32 coarse pixels x BN channels, 4 waves, single LDS stage (58 KB: two workgroups per CU).
+template <int NS, int BN, bool SCATTER>
+__global__ __launch_bounds__(256) void conv_halo_s2_bf16_kernel(const HaloArgs p) {
+    constexpr int TH = 4, TW = 32, NT = 256, WN = 2;
+    constexpr int RB = BN * 4 / NT;                        // 16-B weight chunks per thread per plane per tap
+    constexpr int HH = TH + 1, HW = TW + 1, HPIX = HH * HW;
+    constexpr int AROW = 80;
+    constexpr int PLANE_A = HPIX * AROW, PLANE_B = BN * 64;
+    constexpr int TM = 2, TN = BN / (32 * WN);
+    __shared__ __attribute__((aligned(16))) unsigned char smem[NS * PLANE_A + 2 * NS * PLANE_B];
+    unsigned char *Ah = smem, *Al = smem + PLANE_A;
+    unsigned char *Bbase = smem + NS * PLANE_A;            // two tap tiles of (Bh, Bl)
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int l31 = lane & 31, lh = lane >> 5;
+    const int wm = wave / WN, wn = wave % WN;
+    int tile = hoig_xcd_remap(blockIdx.x, p.nblk);
+    int P = 0, Q = 0;
+    if (SCATTER) {
+        P = (tile >> 1) & 1;
+        Q = tile & 1;
+        tile >>= 2;
+    }
+    int mt = tile / p.nblk_n;
+    const int n0 = (tile % p.nblk_n) * BN;
+    const int tx_ = mt % p.tiles_x;
+    mt /= p.tiles_x;
+    const int ty_ = mt % p.tiles_y, b = mt / p.tiles_y;
+    const int y0 = ty_ * TH, x0 = tx_ * TW;                // coarse-grid tile origin
+
+    const int brow = tid >> 2, bchunk = tid & 3;
+    const unsigned short *wrow_h[RB], *wrow_l[RB];
+    int boff[RB];
+#pragma unroll
+    for (int i = 0; i < RB; ++i) {
+        const int n = n0 + brow + (NT / 4) * i;
+        const size_t o = plane_index(n, bchunk * 8, p.K);
+        wrow_h[i] = n < p.N ? p.Wh + o : nullptr;
+        wrow_l[i] = (NS == 2 && n < p.N) ? p.Wl + o : nullptr;
+        const int row = brow + (NT / 4) * i;
+        boff[i] = row * 64 + ((bchunk ^ ((row >> 2) & 3)) << 4);
+    }
+    int aread[TM], bread[TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i) aread[i] = ((wm * TM + i) * HW + l31) * AROW + lh * 16;
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+        const int row = wn * (TN * 32) + j * 32 + l31;
+        bread[j] = row * 64 + ((lh ^ ((row >> 2) & 3)) << 4);
+    }
+    f32x16 acc[TM][TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    // ---- step table (wave-uniform scalar code) ----
+    struct Step {
+        int cb, ntap, tap[2], pp, qq;
+        bool load;
+    };
+    const int spc = SCATTER ? ((P ? 2 : 1) * (Q ? 2 : 1) + 1) / 2 : 5;     // steps per 32-channel block
+    const int ncb = p.Cg >> 5, T = ncb * spc;
+    auto step_info = [&](int step) -> Step {
+        Step s_;
+        s_.cb = step / spc;
+        const int idx = step - s_.cb * spc;
+        s_.pp = s_.qq = 0;
+        if (!SCATTER) {
+            s_.load = idx != 1;
+            switch (idx) {
+                case 0: s_.pp = 1; s_.qq = 1; s_.ntap = 2; s_.tap[0] = 0; s_.tap[1] = 2; break;
+                case 1: s_.pp = 1; s_.qq = 1; s_.ntap = 2; s_.tap[0] = 6; s_.tap[1] = 8; break;
+                case 2: s_.pp = 1; s_.qq = 0; s_.ntap = 2; s_.tap[0] = 1; s_.tap[1] = 7; break;
+                case 3: s_.pp = 0; s_.qq = 1; s_.ntap = 2; s_.tap[0] = 3; s_.tap[1] = 5; break;
+                default: s_.ntap = 1; s_.tap[0] = 4; s_.tap[1] = 4; break;
+            }
+        } else {
+            s_.load = idx == 0;
+            // rows of the phase: P = 0 -> r = 1; P = 1 -> r in {0, 2}; same for columns
+            const int r0 = P ? 0 : 1, r1 = 2, s0 = Q ? 0 : 1, s1 = 2;
+            if (P && Q) {
+                s_.ntap = 2;
+                s_.tap[0] = (idx ? r1 : r0) * 3 + s0;
+                s_.tap[1] = (idx ? r1 : r0) * 3 + s1;
+            } else if (P) {
+                s_.ntap = 2; s_.tap[0] = r0 * 3 + s0; s_.tap[1] = r1 * 3 + s0;
+            } else if (Q) {
+                s_.ntap = 2; s_.tap[0] = r0 * 3 + s0; s_.tap[1] = r0 * 3 + s1;
+            } else {
+                s_.ntap = 1; s_.tap[0] = s_.tap[1] = 4;
+            }
+        }
+        return s_;
+    };
+    // halo offset (rows, columns in {0,1}) of tap (r,s):  gather: (r != 0, s != 0)   scatter: (r == 0, s == 0)
+    auto tap_off = [&](int tap) -> int {
+        const int r = tap / 3, s_ = tap - r * 3;
+        const int dr = SCATTER ? (r == 0) : (r != 0), dc = SCATTER ? (s_ == 0) : (s_ != 0);
+        return (dr * HW + dc) * AROW;
+    };
+
+    uint4 rbh[2][RB], rbl[2][RB];
+    auto load_b = [&](const Step &s_) {
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {
+            const size_t koff = (size_t)(s_.tap[t] * p.Cg + s_.cb * 32) * 32;
+#pragma unroll
+            for (int i = 0; i < RB; ++i) {
+                rbh[t][i] = wrow_h[i] ? *reinterpret_cast<const uint4 *>(wrow_h[i] + koff) : make_uint4(0, 0, 0, 0);
+                if (NS == 2)
+                    rbl[t][i] = wrow_l[i] ? *reinterpret_cast<const uint4 *>(wrow_l[i] + koff) : make_uint4(0, 0, 0, 0);
+            }
+        }
+    };
+    auto store_b = [&]() {
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {
+            unsigned char *Bh = Bbase + t * NS * PLANE_B, *Bl = Bh + PLANE_B;
+#pragma unroll
+            for (int i = 0; i < RB; ++i) {
+                *reinterpret_cast<uint4 *>(Bh + boff[i]) = rbh[t][i];
+                if (NS == 2) *reinterpret_cast<uint4 *>(Bl + boff[i]) = rbl[t][i];
+            }
+        }
+    };
+    const float *Aimg = p.A + (size_t)b * p.H * p.W * p.Cg;       // p.H x p.W: the gathered tensor (fine grid in gather mode)
+    constexpr int HSLICES = (HPIX * 8 + NT - 1) / NT;
+    // halo images are fetched TWO steps ahead into alternating register sets: a step is only one or two taps long (768-1536
+    // MFMA cycles per wave), less than the HBM latency of the full-resolution tensors
+    float4 hregs[2][HSLICES];
+    auto halo_load = [&](const Step &s_, float4 (&hreg)[HSLICES]) {
+#pragma unroll
+        for (int sl = 0; sl < HSLICES; ++sl) {
+            const int i = tid + NT * sl;
+            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (i < HPIX * 8) {
+                const int pix = i >> 3, c4 = i & 7;
+                const int hy = pix / HW, hx = pix - hy * HW;
+                const int gy = SCATTER ? y0 + hy : 2 * (y0 - 1 + hy) + s_.pp;
+                const int gx = SCATTER ? x0 + hx : 2 * (x0 - 1 + hx) + s_.qq;
+                if (gy >= 0 && gy < p.H && gx >= 0 && gx < p.W)
+                    v = *reinterpret_cast<const float4 *>(Aimg + ((size_t)gy * p.W + gx) * p.Cg + s_.cb * 32 + c4 * 4);
+            }
+            hreg[sl] = v;
+        }
+    };
+    auto halo_store = [&](const float4 (&hreg)[HSLICES]) {
+#pragma unroll
+        for (int sl = 0; sl < HSLICES; ++sl) {
+            const int i = tid + NT * sl;
+            if (i < HPIX * 8) {
+                const int pix = i >> 3, c4 = i & 7;
+                uint2 hi, lo;
+                split4(hreg[sl], hi, lo);
+                *reinterpret_cast<uint2 *>(Ah + pix * AROW + c4 * 8) = hi;
+                if (NS == 2) *reinterpret_cast<uint2 *>(Al + pix * AROW + c4 * 8) = lo;
+            }
+        }
+    };
+    auto compute = [&](const Step &s_) {
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {
+            if (t >= s_.ntap) break;
+            const int tapoff = tap_off(s_.tap[t]);
+            const unsigned char *Bh = Bbase + t * NS * PLANE_B, *Bl = Bh + PLANE_B;
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks) {
+                bf16x8 ah[TM], al[TM], bhf[TN], blf[TN];
+#pragma unroll
+                for (int i = 0; i < TM; ++i) {
+                    const int off = aread[i] + tapoff + ks * 32;
+                    ah[i] = *reinterpret_cast<const bf16x8 *>(Ah + off);
+                    if (NS == 2) al[i] = *reinterpret_cast<const bf16x8 *>(Al + off);
+                }
+#pragma unroll
+                for (int j = 0; j < TN; ++j) {
+                    const int off = bread[j] ^ (ks << 5);
+                    bhf[j] = *reinterpret_cast<const bf16x8 *>(Bh + off);
+                    if (NS == 2) blf[j] = *reinterpret_cast<const bf16x8 *>(Bl + off);
+                }
+#pragma unroll
+                for (int i = 0; i < TM; ++i)
+#pragma unroll
+                    for (int j = 0; j < TN; ++j) {
+                        if (NS == 2) {
+                            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[i], bhf[j], acc[i][j], 0, 0, 0);
+                            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[i], blf[j], acc[i][j], 0, 0, 0);
+                        }
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[i], bhf[j], acc[i][j], 0, 0, 0);
+                    }
+            }
+        }
+    };
+
+    Step cur = step_info(0);
+    halo_load(cur, hregs[0]);
+    load_b(cur);
+    halo_store(hregs[0]);
+    store_b();
+    Step nxt = cur;
+    if (T > 1) {
+        nxt = step_info(1);
+        if (nxt.load) halo_load(nxt, hregs[1]);           // (the set that "step -1" would have filled)
+    }
+    __syncthreads();
+    // two-fold unrolled so that the register-set index is static
+    auto one_step = [&](int step, float4 (&mine)[HSLICES], float4 (&other)[HSLICES]) {
+        const bool more = step + 1 < T;
+        if (more) load_b(nxt);
+        if (step + 2 < T) {
+            const Step n2 = step_info(step + 2);
+            if (n2.load) halo_load(n2, mine);             // stored at the end of step+1
+        }
+        compute(cur);
+        if (more) {
+            __syncthreads();                  // every wave has finished reading the weight tiles (and the halo)
+            if (nxt.load) halo_store(other);  // fetched during step-1
+            store_b();
+            __syncthreads();
+            cur = nxt;
+            if (step + 2 < T) nxt = step_info(step + 2);
+        }
+    };
+#pragma unroll 1
+    for (int step = 0; step < T; step += 2) {
+        one_step(step, hregs[0], hregs[1]);
+        if (step + 1 < T) one_step(step + 1, hregs[1], hregs[0]);
+    }
+
+    const float nslope = p.act == HOIG_ACT_NONE ? 1.f : (p.act == HOIG_ACT_RELU ? 0.f : p.slope);
+    const bool special = p.act == HOIG_ACT_TANH || p.act == HOIG_ACT_SIGMOID;
+    float bias_r[TN];
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+        const int n = n0 + wn * (TN * 32) + j * 32 + l31;
+        bias_r[j] = (p.bias && n < p.N) ? p.bias[n] : 0.f;
+    }
+    // output grid: gather mode = the coarse grid (tiles_y*TH x tiles_x*TW); scatter mode = twice the coarse grid, phase (P,Q)
+    const int Ho = SCATTER ? 2 * p.H : p.tiles_y * TH, Wo = SCATTER ? 2 * p.W : p.tiles_x * TW;
+#pragma unroll
+    for (int i = 0; i < TM; ++i) {
+        const int cy = y0 + wm * TM + i;
+        const int oy = SCATTER ? 2 * cy + P : cy;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int cx = x0 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+            const int ox = SCATTER ? 2 * cx + Q : cx;
+            const size_t pix = ((size_t)b * Ho + oy) * Wo + ox;
+#pragma unroll
+            for (int j = 0; j < TN; ++j) {
+                const int n = n0 + wn * (TN * 32) + j * 32 + l31;
+                if (n < p.N) {
+                    float v = acc[i][j][r];
+                    v += bias_r[j];
+                    p.C[pix * p.N + n] = fast_act(v, nslope, special, p.act, p.slope);
+                }
+            }
+        }
+    }
+}
+
+// a: H, W = spatial size of the GATHERED tensor (gather mode: the fine grid, output is H/2 x W/2; scatter mode: the coarse
+// grid, output is 2H x 2W)
+template <bool SCATTER>
+int launch_halo_s2(HaloArgs a, int ns, hipStream_t st) {
+    const int ch = SCATTER ? a.H : a.H / 2, cw = SCATTER ? a.W : a.W / 2;      // coarse grid
+    a.tiles_x = cw / 32;
+    a.tiles_y = ch / 4;
+    const bool n64 = (a.N % 128) != 0;
+    a.nblk_n = a.N / (n64 ? 64 : 128);
+    a.nblk = a.Bn * a.tiles_x * a.tiles_y * a.nblk_n * (SCATTER ? 4 : 1);
+    a.nmajor = 0;
+    if (n64) {
+        if (ns == 2) conv_halo_s2_bf16_kernel<2, 64, SCATTER><<<a.nblk, 256, 0, st>>>(a);
+        else conv_halo_s2_bf16_kernel<1, 64, SCATTER><<<a.nblk, 256, 0, st>>>(a);
+    } else {
+        if (ns == 2) conv_halo_s2_bf16_kernel<2, 128, SCATTER><<<a.nblk, 256, 0, st>>>(a);
+        else conv_halo_s2_bf16_kernel<1, 128, SCATTER><<<a.nblk, 256, 0, st>>>(a);
+    }
+    HOIG_LAUNCH_CHECK();
+    return HOIG_OK;
+}
+
 template <int KS>
 int launch_halo(HaloArgs a, int ns, hipStream_t st) {
     a.tiles_x = a.W / 32;
@@ -1106,6 +1403,29 @@ int run(const hoig_conv_desc *d, const float *a, const unsigned short *wh, const
         if (d->R == 1) return launch_halo<1>(h, ns, st);
         if (d->R == 3) return getenv("HOIG_HALO_TAPSTEP") ? launch_halo<3>(h, ns, st) : launch_halo3(h, ns, st);
         return launch_halo<5>(h, ns, st);
+    }
+    // stride-2 3x3 pad-1 layers on the parity-phase halo kernel.  gather: Conv2d forward / ConvTranspose2d data gradient;
+    // scatter: ConvTranspose2d forward / Conv2d data gradient
+    static const bool no_s2 = getenv("HOIG_NO_HALO_S2") != nullptr;
+    if (!no_s2 && d->stride == 2 && d->R == 3 && d->S == 3 && d->pad == 1 && d->Hi % 2 == 0 && d->Wi % 2 == 0 &&
+        p.N % 64 == 0) {
+        // fine / coarse grids: Conv2d: fine = input (Hi), coarse = output (Ho = Hi/2); ConvTranspose2d: fine = output
+        const int fine_h = d->transposed ? d->Ho : d->Hi, fine_w = d->transposed ? d->Wo : d->Wi;
+        const int coarse_h = d->transposed ? d->Hi : d->Ho, coarse_w = d->transposed ? d->Wi : d->Wo;
+        if (fine_h == 2 * coarse_h && fine_w == 2 * coarse_w && coarse_w % 32 == 0 && coarse_h % 4 == 0) {
+            HaloArgs h;
+            h.A = a; h.Wh = wh; h.Wl = wl; h.bias = bias; h.C = c;
+            h.Bn = d->B; h.Cg = g.Cg; h.N = p.N; h.K = p.K;
+            h.pad = 1; h.flip = 0;
+            h.act = p.act; h.slope = p.slope;
+            const bool gather = !g.gatherT;      // the operand is read at 2*o - 1 + tap (fine grid) -> gather mode
+            if (gather) {
+                h.H = fine_h; h.W = fine_w;
+                return launch_halo_s2<false>(h, ns, st);
+            }
+            h.H = coarse_h; h.W = coarse_w;
+            return launch_halo_s2<true>(h, ns, st);
+        }
     }
     if (p.N <= 64) {
         if (t128 >= 512) return launch<128, 64, 2, 2>(p, ns, st);

@@ -324,6 +324,9 @@ BF16_CASES = [
     (2, 256, 256, 9, 4, 1, 1, False),
     (3, 96, 160, 10, 3, 1, 1, False),
     (2, 128, 64, 16, 3, 2, 1, True),
+    (2, 64, 128, 64, 3, 2, 1, False),      # stride-2 conv on the parity-phase halo kernel (gather fwd, scatter dgrad)
+    (2, 128, 64, 32, 3, 2, 1, True),       # ConvTranspose2d on it (scatter fwd, gather dgrad; 64-channel tiles)
+    (1, 256, 128, 32, 3, 2, 1, True),
     (1, 512, 256, 8, 3, 2, 1, True),
 ]
 
