@@ -39,6 +39,8 @@ class GradSync(object):
     def all_reduce_grads(self):
         """SUM over ranks, in place; returns the scale (1/world) the optimiser must apply."""
         if self.world > 1:
+            from .ops import join_wgrad_streams
+            join_wgrad_streams()
             handles = [dist.all_reduce(self.flat_grad[a:b], op=dist.ReduceOp.SUM, group=self.group, async_op=True)
                        for a, b in self.slices]
             for h in handles:

@@ -23,7 +23,7 @@ import torch
 import torch.nn as nn
 
 from . import _lib as L
-from .ops import packed_strides, _p, _st
+from .ops import packed_strides, _p, _st, join_wgrad_streams
 
 
 def _numel(shape):
@@ -237,6 +237,7 @@ class ParamTree(nn.Module):
             yield (prefix + ('.' if prefix else '') + k, v)
 
     def zero_grad(self, set_to_none=False):
+        join_wgrad_streams()
         self.flat_grad.zero_()
 
     def set_requires_grad(self, flag):
@@ -277,11 +278,13 @@ class FusedAdam(object):
         self.step_count = 0
 
     def zero_grad(self, set_to_none=False):
+        join_wgrad_streams()
         self.tree.flat_grad.zero_()
 
     def step(self, grad_scale=1.0):
         g = self.param_groups[0]
         self.step_count += 1
+        join_wgrad_streams()
         L.call('hoig_adam_step', _p(self.tree.flat), _p(self.tree.flat_grad), _p(self.exp_avg), _p(self.exp_avg_sq),
                self.tree.flat.numel(), g['lr'], g['betas'][0], g['betas'][1], g['eps'], self.step_count,
                grad_scale, _st())

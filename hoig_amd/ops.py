@@ -104,6 +104,26 @@ def _packed_planes(w, transposed, for_dgrad):
     return hi, lo
 
 
+_wgrad_streams = {}
+_WGRAD_SIDE = os.environ.get('HOIG_WGRAD_STREAM', '1') == '1'
+
+
+def _wgrad_side_stream(device):
+    if not _WGRAD_SIDE:
+        return None
+    s = _wgrad_streams.get(device)
+    if s is None:
+        s = _wgrad_streams[device] = torch.cuda.Stream(device=device)
+    return s
+
+
+def join_wgrad_streams():
+    """Make the current stream wait for every weight gradient launched on a side stream (called before anything reads a
+    flat gradient buffer: the optimiser step, the gradient all-reduce)."""
+    for s in _wgrad_streams.values():
+        torch.cuda.current_stream(s.device).wait_stream(s)
+
+
 class _Conv(Function):
     @staticmethod
     def forward(ctx, x, w, b, stride, pad, transposed, act, slope, out_hw, prec, dead_bias=False):
@@ -147,7 +167,17 @@ class _Conv(Function):
             if ctx.has_bias and ctx.needs_input_grad[2]:
                 db, ret_b = _grad_target(b)
                 db_ret = db if ret_b else None
-            call('hoig_conv2d_bwd_weight', ctypes.byref(d), _p(x), _p(g), _p(dw), _p(db), _st())
+            side = _wgrad_side_stream(x.device) if not (ret_w or (db is not None and ret_b)) else None
+            if side is not None:
+                # weight gradients that accumulate straight into a network's flat gradient buffer have no consumer before
+                # the optimiser: run them on a side stream, concurrently with the data-gradient chain on the main stream
+                side.wait_stream(torch.cuda.current_stream())
+                with torch.cuda.stream(side):
+                    call('hoig_conv2d_bwd_weight', ctypes.byref(d), _p(x), _p(g), _p(dw), _p(db), _st())
+                x.record_stream(side)
+                g.record_stream(side)
+            else:
+                call('hoig_conv2d_bwd_weight', ctypes.byref(d), _p(x), _p(g), _p(dw), _p(db), _st())
             dw_ret = dw if ret_w else None
         dx = None
         if ctx.needs_input_grad[0]:
@@ -497,8 +527,17 @@ class _LocalAttn(Function):
         dhid = torch.empty_like(hidden)
         call('hoig_attn_pixel_bwd', _p(hidden), _p(attn), _p(w2), _p(S), _p(dout), _p(dhid), _p(gs[3][0]), _p(gs[4][0]),
              M, C, _st())
-        call('hoig_conv2d_bwd_weight', ctypes.byref(d_t), _p(tpad), _p(dhid), _p(gs[0][0]), _p(gs[2][0]), _st())
-        call('hoig_conv2d_bwd_weight', ctypes.byref(d_s), _p(S), _p(dhid), _p(gs[1][0]), None, _st())
+        side = _wgrad_side_stream(dout.device) if not any(r for _, r in gs) else None
+        if side is not None:          # (see _Conv.backward)
+            side.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(side):
+                call('hoig_conv2d_bwd_weight', ctypes.byref(d_t), _p(tpad), _p(dhid), _p(gs[0][0]), _p(gs[2][0]), _st())
+                call('hoig_conv2d_bwd_weight', ctypes.byref(d_s), _p(S), _p(dhid), _p(gs[1][0]), None, _st())
+            for t in (tpad, S, dhid):
+                t.record_stream(side)
+        else:
+            call('hoig_conv2d_bwd_weight', ctypes.byref(d_t), _p(tpad), _p(dhid), _p(gs[0][0]), _p(gs[2][0]), _st())
+            call('hoig_conv2d_bwd_weight', ctypes.byref(d_s), _p(S), _p(dhid), _p(gs[1][0]), None, _st())
         dtgt = dsrc = None
         if ctx.needs_input_grad[1]:
             dtpad = torch.empty_like(tpad)
