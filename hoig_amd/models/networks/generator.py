@@ -4,6 +4,8 @@ Mirrors the reference's ``Generator`` interface (models/networks/generator.py:31
 arguments, ``forward`` signature, ``init_weights`` and parameter names; the computation is a functional
 pass over a flat parameter store, every operator a hand-written gfx950 kernel (hoig_amd/ops.py).
 """
+import os
+
 import torch
 
 from ... import ops
@@ -27,6 +29,9 @@ def as_nchw(t):
     return t.permute(0, 3, 1, 2)
 
 
+_FORK_STREAMS = os.environ.get('HOIG_G_STREAMS', '1') == '1'
+
+
 class Generator(ParamTree):
     def __init__(self, bg_dim, img_dim, obj_dim, img_cond_dim=0, obj_cond_dim=0, conv_dim=64, repeat_num=6,
                  gen_name='generator_spade_attn', device=None):
@@ -41,6 +46,11 @@ class Generator(ParamTree):
     @property
     def name(self):
         return self._name
+
+    def _branch_streams(self, device):
+        if getattr(self, '_streams', None) is None:
+            self._streams = (torch.cuda.Stream(device=device), torch.cuda.Stream(device=device))
+        return self._streams
 
     # ---- building blocks -------------------------------------------------------------------
     def _conv(self, x, name, stride=1, pad=1, act=ACT_NONE, to_norm=False):
@@ -179,8 +189,27 @@ class Generator(ParamTree):
         # batches stacked (instance norm is per sample, so the result is identical) -> twice the tiles per launch at the
         # 32x32 bottleneck and one weight-gradient accumulation instead of two
         nb = bg.shape[0]
-        bg_both = self._bg_net(torch.cat([ops.cat_channels(src_bg_in), ops.cat_channels(tsf_bg_in)], dim=0))
-        src_img_bg, tsf_img_bg = bg_both[:nb], bg_both[nb:]
+        # The three sub-networks that do not depend on each other until the heads -- bg_model, obj_model, and the src/tsf
+        # pair -- run on separate HIP streams: their kernels fill each other's tails (autograd replays each branch's
+        # backward on its own stream too).  The weight split is refreshed first, on the main stream.
+        main = torch.cuda.current_stream()
+        fork = _FORK_STREAMS and bg.is_cuda and not torch.cuda.is_current_stream_capturing()
+        self.refresh_planes()
+        bg_in = torch.cat([ops.cat_channels(src_bg_in), ops.cat_channels(tsf_bg_in)], dim=0)
+        obj_in = torch.cat([src_obj, tsf_obj], dim=0)
+        obj_c = torch.cat([src_obj_c, tsf_obj_c], dim=0)
+        if fork:
+            s_bg, s_obj = self._branch_streams(bg.device)
+            s_bg.wait_stream(main)
+            s_obj.wait_stream(main)
+            with torch.cuda.stream(s_bg):
+                bg_both = self._bg_net(bg_in)
+            with torch.cuda.stream(s_obj):
+                obj_both = self._unet(obj_in, obj_c, 'obj_model')
+            for t_, st_ in ((bg_in, s_bg), (obj_in, s_obj), (obj_c, s_obj)):
+                t_.record_stream(st_)
+        else:
+            bg_both = self._bg_net(bg_in)
 
         # infer_front (generator.py:379-464)
         sx = self._conv_in_relu(src_hand, 'src_model.encoders.0', pad=3)
@@ -198,7 +227,14 @@ class Generator(ParamTree):
             tx = ops.add(tx, self._transform(sx, T, i + c.n_down + 1, y=tx))
 
         # obj_model likewise serves both the src and the tsf object (generator.py:449-450): one stacked pass
-        obj_both = self._unet(torch.cat([src_obj, tsf_obj], dim=0), torch.cat([src_obj_c, tsf_obj_c], dim=0), 'obj_model')
+        if fork:
+            main.wait_stream(s_bg)
+            main.wait_stream(s_obj)
+            bg_both.record_stream(main)
+            obj_both.record_stream(main)
+        else:
+            obj_both = self._unet(obj_in, obj_c, 'obj_model')
+        src_img_bg, tsf_img_bg = bg_both[:nb], bg_both[nb:]
         sy, ty = obj_both[:nb], obj_both[nb:]
         sx = self._decode(sx, s_enc, src_hand_c, 'src_model')
         tx = self._decode(tx, t_enc, tsf_hand_c, 'tsf_model')

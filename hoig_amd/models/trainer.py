@@ -59,7 +59,7 @@ class Trainer(BaseModel):
         torch.cuda.set_device(self.device)
         self._dexycb = 'dex' in str(getattr(opt, 'dataset_mode', 'hov3')).lower()
         self._world = dist.get_world_size() if (use_ddp and dist.is_initialized()) else 1
-        self._side = torch.cuda.Stream(device=self.device) if self._world > 1 else None
+        self._side = torch.cuda.Stream(device=self.device)      # G's gradient exchange + Adam, overlapped with the D step
         self._g_ready = None
 
         self._init_create_networks(use_ddp=use_ddp)
@@ -223,23 +223,26 @@ class Trainer(BaseModel):
             self._optimizer_D.zero_grad()
             loss_D.backward()
             self._step(self._D, self._optimizer_D, overlap=False)
+            self._wait_g()                # G's update has had the whole D step to finish; later readers need no special care
 
     def _step(self, net, optimizer, overlap):
-        """gradient exchange (RCCL) + fused Adam; for G under DDP both run on the side stream, overlapped with the
-        D step that follows on the main stream."""
-        if isinstance(net, FlatDDP) and self._world > 1:
-            if overlap:
-                main = torch.cuda.current_stream()
-                self._side.wait_stream(main)
-                with torch.cuda.stream(self._side):
-                    scale = net.sync.all_reduce_grads()
-                    optimizer.step(grad_scale=scale)
-                    self._g_ready = torch.cuda.Event()
-                    self._g_ready.record(self._side)
-            else:
-                self._wait_g()
-                scale = net.sync.all_reduce_grads()
+        """gradient exchange (RCCL, under DDP) + fused Adam; for G both run on the side stream, overlapped with the D step
+        that follows on the main stream."""
+        ddp = isinstance(net, FlatDDP) and self._world > 1
+        if overlap:
+            # the D step that follows never touches G's parameters: G's exchange + Adam (HBM-bound, 5 GB of traffic) run on
+            # the side stream beside it; forward() waits for the event before the next use of G
+            main = torch.cuda.current_stream()
+            self._side.wait_stream(main)
+            with torch.cuda.stream(self._side):
+                scale = net.sync.all_reduce_grads() if ddp else 1.0
                 optimizer.step(grad_scale=scale)
+                self._g_ready = torch.cuda.Event()
+                self._g_ready.record(self._side)
+        elif ddp:
+            self._wait_g()
+            scale = net.sync.all_reduce_grads()
+            optimizer.step(grad_scale=scale)
         else:
             optimizer.step()
 

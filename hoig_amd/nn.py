@@ -140,6 +140,16 @@ class ParamTree(nn.Module):
                 self._plane_flags[off] = flags
         return rows
 
+    def refresh_planes(self):
+        """Split the current weights into bf16 planes (one launch) if they changed since the last split.  Called lazily by
+        packed_planes(); a forward that forks onto several streams calls it FIRST, on the main stream, so that no branch
+        races the split."""
+        if self._plane_bufs and self._plane_version != self.version:
+            b = self._plane_bufs
+            L.call('hoig_pack_conv_weights_bf16_all', _p(self.flat), _p(self._plane_table), self._plane_table.shape[0],
+                   self._plane_tiles, _p(b[0]), _p(b[1]), _p(b[2]), _p(b[3]), _st())
+            self._plane_version = self.version
+
     def packed_planes(self, w, for_dgrad):
         """(hi, lo) bf16 planes of conv weight `w` (a view of self.flat) for the forward (for_dgrad=False) or data-
         gradient GEMM, or None if `w` is not in the table (hoig_pack_conv_weights_bf16_all, include/hoig_kernels.h)."""
@@ -156,11 +166,7 @@ class ParamTree(nn.Module):
         off = w.storage_offset()
         if not (self._plane_flags.get(off, 0) & (2 if for_dgrad else 1)) or w.data_ptr() != self.flat.data_ptr() + 4 * off:
             return None
-        if self._plane_version != self.version:
-            b = self._plane_bufs
-            L.call('hoig_pack_conv_weights_bf16_all', _p(self.flat), _p(self._plane_table), self._plane_table.shape[0],
-                   self._plane_tiles, _p(b[0]), _p(b[1]), _p(b[2]), _p(b[3]), _st())
-            self._plane_version = self.version
+        self.refresh_planes()
         n = w.numel()
         hi, lo = (self._plane_bufs[2], self._plane_bufs[3]) if for_dgrad else (self._plane_bufs[0], self._plane_bufs[1])
         return hi[off:off + n], lo[off:off + n]
