@@ -123,3 +123,38 @@ def test_synthetic_inputs_deterministic_and_in_range():
     assert tuple(d['input_G_src_hand'].shape) == (1, 12, 32, 32) and 'armask_src' not in d
     c = synthetic.make_inputs(2, 32, seed=9)
     assert not torch.equal(a['real_src'], c['real_src'])
+
+
+def test_eval_writer_matches_reference_layout(tmp_path):
+    """eval.py:59-79: crops (r, c) = (i // cols, i % cols) of the three batch grids, named <srcvid>_<srcframe>_<tsfframe>.png."""
+    import numpy as np
+    from PIL import Image
+    from hoig_amd.eval_output import EvalWriter, crops_of, pair_name
+    side, B = 8, 5
+    nrow = int(np.sqrt(B))                                   # tensor2im: make_grid(img, nrows=int(sqrt(B)), padding=0)
+    rows = (B + nrow - 1) // nrow
+    rng = np.random.default_rng(0)
+    imgs = {k: rng.integers(0, 256, size=(B, 3, side, side), dtype=np.uint8) for k in ('src', 'fake', 'real')}
+
+    def grid(x):
+        g = np.zeros((3, rows * side, nrow * side), np.uint8)
+        for i in range(B):
+            r, c = i // nrow, i % nrow
+            g[:, r * side:(r + 1) * side, c * side:(c + 1) * side] = x[i]
+        return g
+
+    vis = {'16_batch_src_img': grid(imgs['src']), '15_batch_fake_img': grid(imgs['fake']), '14_batch_real_img': grid(imgs['real'])}
+    a = ['vidA/%04d.jpg' % i for i in range(B)]
+    b = ['vidB/%04d.jpg' % (i + 7) for i in range(B)]
+    assert pair_name(a[1], b[1]) == 'vidA_0001_0008.png'
+    w = EvalWriter(str(tmp_path), sav_gt=True, side=side, workers=2)
+    w.write(vis, a, b)
+    w.close()
+    assert w.written == 3 * B
+    for sub, key in (('source', 'src'), ('imitators', 'fake'), ('gt', 'real')):
+        for i in range(B):
+            got = np.asarray(Image.open(str(tmp_path / sub / pair_name(a[i], b[i]))))
+            assert np.array_equal(got, imgs[key][i].transpose(1, 2, 0))
+    assert len(crops_of(vis['14_batch_real_img'], B, side)) == B
+    with pytest.raises(ValueError):
+        crops_of(vis['14_batch_real_img'], rows * nrow + 1, side)
