@@ -83,6 +83,7 @@ _SIGS = {
     'hoig_copy_channels': [_vp, _vp, _i64, _i, _i, _i, _i, _i, _i, _vp],
     'hoig_add': [_vp, _vp, _vp, _i64, _vp],
     'hoig_act_bwd': [_vp, _vp, _vp, _i, _f, _i64, _vp],
+    'hoig_act_bwd_colsum': [_vp, _vp, _vp, _vp, _i, _f, _i64, _i, _vp],
     'hoig_colsum_accum': [_vp, _vp, _i64, _i, _vp],
     'hoig_compose_fwd': [_vp] * 6 + [_i64, _i, _vp],
     'hoig_compose_bwd': [_vp] * 11 + [_i64, _i, _vp],

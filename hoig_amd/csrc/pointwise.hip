@@ -64,6 +64,36 @@ __global__ void act_bwd_kernel(const float *__restrict__ y, const float *__restr
         dx[i] = dy[i] * hoig_act_grad_from_y(y[i], act, slope);
 }
 
+// activation backward fused with the bias gradient of the convolution that produced y: g = dy * act'(y) is written AND its
+// column sums accumulate into dbias (same slab / lane layout as colsum_kernel) -- one pass over dy instead of two
+__global__ __launch_bounds__(NT) void act_bwd_colsum_kernel(const float *__restrict__ y, const float *__restrict__ dy,
+                                                            float *__restrict__ g, float *__restrict__ dbias, int act,
+                                                            float slope, int64_t rows, int C, int64_t rows_per_block) {
+    const int64_t r0 = (int64_t)blockIdx.x * rows_per_block;
+    const int64_t r1 = r0 + rows_per_block < rows ? r0 + rows_per_block : rows;
+    const int lanes = C < NT ? C : NT;
+    const int rl_n = NT / lanes;
+    const int c0 = threadIdx.x % lanes, rl = threadIdx.x / lanes;
+    extern __shared__ float red[];
+    if (threadIdx.x < lanes * rl_n) {
+        for (int c = c0; c < C; c += lanes) {
+            float s = 0.f;
+            for (int64_t r = r0 + rl; r < r1; r += rl_n) {
+                const float v = dy[r * C + c] * hoig_act_grad_from_y(y[r * C + c], act, slope);
+                g[r * C + c] = v;
+                s += v;
+            }
+            red[rl * C + c] = s;
+        }
+    }
+    __syncthreads();
+    for (int c = threadIdx.x; c < C; c += NT) {
+        float s = 0.f;
+        for (int k = 0; k < rl_n; ++k) s += red[k * C + c];
+        atomicAdd(&dbias[c], s);
+    }
+}
+
 // out[c] += sum_rows x[row][c]; one workgroup per row slab, lanes along channels (coalesced), LDS combine, one
 // atomic per (workgroup, channel)
 __global__ __launch_bounds__(NT) void colsum_kernel(const float *__restrict__ x, float *__restrict__ out, int64_t rows,
@@ -322,6 +352,19 @@ extern "C" int hoig_act_bwd(const float *y, const float *dy, float *dx, int act,
                             hoig_stream_t stream) {
     if (!y || !dy || !dx) return HOIG_EINVAL;
     act_bwd_kernel<<<hoig_stream_grid(n, NT), NT, 0, ST>>>(y, dy, dx, act, slope, n);
+    HOIG_LAUNCH_CHECK();
+    return HOIG_OK;
+}
+extern "C" int hoig_act_bwd_colsum(const float *y, const float *dy, float *g, float *dbias, int act, float slope,
+                                   int64_t rows, int C, hoig_stream_t stream) {
+    if (!y || !dy || !g || !dbias || C <= 0) return HOIG_EINVAL;
+    int64_t nblk = hoig_cdiv(rows, 32);
+    if (nblk > 4096) nblk = 4096;
+    const int64_t rpb = hoig_cdiv(rows, nblk);
+    nblk = hoig_cdiv(rows, rpb);
+    const int lanes = C < NT ? C : NT;
+    const size_t shm = (size_t)(NT / lanes) * C * sizeof(float);
+    act_bwd_colsum_kernel<<<(int)nblk, NT, shm, ST>>>(y, dy, g, dbias, act, slope, rows, C, rpb);
     HOIG_LAUNCH_CHECK();
     return HOIG_OK;
 }

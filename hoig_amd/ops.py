@@ -155,18 +155,22 @@ class _Conv(Function):
         x, w, b, y = ctx.saved_tensors
         d = ctx.d
         dy = dy.contiguous()
+        dw_ret = db_ret = None
+        db, ret_b = None, False
+        if ctx.needs_input_grad[1] and ctx.has_bias and ctx.needs_input_grad[2]:
+            db, ret_b = _grad_target(b)
+            db_ret = db if ret_b else None
         if d.act != L.ACT_NONE:
             g = torch.empty_like(dy)
-            call('hoig_act_bwd', _p(y), _p(dy), _p(g), d.act, d.slope, dy.numel(), _st())
+            if db is not None:       # one pass: activation backward + the bias gradient (column sums of g)
+                call('hoig_act_bwd_colsum', _p(y), _p(dy), _p(g), _p(db), d.act, d.slope, dy.numel() // d.Co, d.Co, _st())
+                db = None            # done: the weight-gradient call below must not sum again
+            else:
+                call('hoig_act_bwd', _p(y), _p(dy), _p(g), d.act, d.slope, dy.numel(), _st())
         else:
             g = dy
-        dw_ret = db_ret = None
         if ctx.needs_input_grad[1]:
             dw, ret_w = _grad_target(w)
-            db = None
-            if ctx.has_bias and ctx.needs_input_grad[2]:
-                db, ret_b = _grad_target(b)
-                db_ret = db if ret_b else None
             side = _wgrad_side_stream(x.device) if not (ret_w or (db is not None and ret_b)) else None
             if side is not None:
                 # weight gradients that accumulate straight into a network's flat gradient buffer have no consumer before

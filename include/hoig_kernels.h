@@ -183,6 +183,9 @@ int hoig_copy_channels(const float *x, float *y, int64_t npix, int Cx, int x_off
 /* y = a + b (n elements) ; y = act_bwd: dx = dy * act'(y) */
 int hoig_add(const float *a, const float *b, float *y, int64_t n, hoig_stream_t stream);
 int hoig_act_bwd(const float *y, const float *dy, float *dx, int act, float slope, int64_t n, hoig_stream_t stream);
+/* the same, fused with the bias gradient of the convolution that produced y [rows][C]: g = dy * act'(y), dbias[c] += sum_rows g */
+int hoig_act_bwd_colsum(const float *y, const float *dy, float *g, float *dbias, int act, float slope, int64_t rows, int C,
+                        hoig_stream_t stream);
 /* column sums: out[c] += sum_rows x[row][c]  (bias gradients) */
 int hoig_colsum_accum(const float *x, float *out, int64_t rows, int C, hoig_stream_t stream);
 
