@@ -59,8 +59,8 @@ _SIGS = {
     'hoig_inorm_stats': [_vp, _i, _i, _i, _f, _vp, _vp, _vp, _vp],
     'hoig_inorm_apply': [_vp, _vp, _vp, _i, _vp, _vp, _i, _f, _vp, _vp, _i, _i, _i, _vp],
     'hoig_inorm_apply_ld': [_vp, _vp, _vp, _i, _vp, _vp, _i, _i, _f, _vp, _vp, _i, _i, _i, _vp],
-    'hoig_inorm_bwd_ld': [_vp, _vp, _vp, _i, _vp, _i, _vp, _vp, _i, _f, _vp, _vp, _vp, _i, _i, _i, _vp, _vp],
-    'hoig_inorm_bwd': [_vp, _vp, _vp, _i, _vp, _vp, _vp, _i, _f, _vp, _vp, _vp, _i, _i, _i, _vp, _vp],
+    'hoig_inorm_bwd_ld': [_vp, _vp, _vp, _i, _vp, _vp, _i, _vp, _vp, _i, _f, _vp, _vp, _vp, _i, _i, _i, _vp, _vp],
+    'hoig_inorm_bwd': [_vp, _vp, _vp, _i, _vp, _vp, _vp, _vp, _i, _f, _vp, _vp, _vp, _i, _i, _i, _vp, _vp],
     'hoig_replicate_pad_fwd': [_vp, _vp, _i, _i, _i, _i, _i, _vp],
     'hoig_replicate_pad_bwd': [_vp, _vp, _i, _i, _i, _i, _i, _vp],
     'hoig_attn_sample_fwd': [_vp, _vp, _vp, _i, _i, _i, _i, _vp],

@@ -26,7 +26,8 @@ __global__ __launch_bounds__(NT) void inorm_partial_kernel(const float *__restri
                                                            const float *__restrict__ rstd, int mode,
                                                            const float *__restrict__ p0, const float *__restrict__ y,
                                                            const float *__restrict__ dy, int act, float slope, int HW,
-                                                           int C, int nchunks, float *__restrict__ partial, int ldp) {
+                                                           int C, int nchunks, float *__restrict__ partial, int ldp,
+                                                           const float *__restrict__ p1) {
     const int b = blockIdx.y, chunk = blockIdx.x;
     const int CV = C >> 2;                 // float4 columns
     const int rows_per = (HW + nchunks - 1) / nchunks;
@@ -38,12 +39,16 @@ __global__ __launch_bounds__(NT) void inorm_partial_kernel(const float *__restri
     for (int cv = cv0; cv < CV; cv += lanes_per_row) {
         const int c = cv * 4;
         float4 s1 = make_float4(0, 0, 0, 0), s2 = make_float4(0, 0, 0, 0);
-        float4 pv = make_float4(0, 0, 0, 0), mu = pv, rs = pv, sc = make_float4(1, 1, 1, 1);
+        float4 pv = make_float4(0, 0, 0, 0), mu = pv, rs = pv, sc = make_float4(1, 1, 1, 1), aw = sc, ab = pv;
         if (!BWD) {
             pv = *reinterpret_cast<const float4 *>(x + (size_t)b * HW * C + c);
         } else {
             mu = *reinterpret_cast<const float4 *>(mean + (size_t)b * C + c);
             rs = *reinterpret_cast<const float4 *>(rstd + (size_t)b * C + c);
+            if (mode == 1 && p1) {
+                aw = *reinterpret_cast<const float4 *>(p0 + c);
+                ab = *reinterpret_cast<const float4 *>(p1 + c);
+            }
         }
         for (int r = r0 + rl; r < r1; r += row_lanes) {
             const size_t off = ((size_t)b * HW + r) * C + c;
@@ -54,19 +59,26 @@ __global__ __launch_bounds__(NT) void inorm_partial_kernel(const float *__restri
                 s2.x += dx * dx; s2.y += dy_ * dy_; s2.z += dz * dz; s2.w += dw * dw;
             } else {
                 float4 g = *reinterpret_cast<const float4 *>(dy + off);
+                const float hx = (v.x - mu.x) * rs.x, hy = (v.y - mu.y) * rs.y, hz = (v.z - mu.z) * rs.z,
+                            hw = (v.w - mu.w) * rs.w;
                 if (act != HOIG_ACT_NONE) {
-                    const float4 yy = *reinterpret_cast<const float4 *>(y + off);
-                    g.x *= hoig_act_grad_from_y(yy.x, act, slope);
-                    g.y *= hoig_act_grad_from_y(yy.y, act, slope);
-                    g.z *= hoig_act_grad_from_y(yy.z, act, slope);
-                    g.w *= hoig_act_grad_from_y(yy.w, act, slope);
+                    if (y) {
+                        const float4 yy = *reinterpret_cast<const float4 *>(y + off);
+                        g.x *= hoig_act_grad_from_y(yy.x, act, slope);
+                        g.y *= hoig_act_grad_from_y(yy.y, act, slope);
+                        g.z *= hoig_act_grad_from_y(yy.z, act, slope);
+                        g.w *= hoig_act_grad_from_y(yy.w, act, slope);
+                    } else {        // (Leaky)ReLU: the sign of y is the sign of xhat * weight + bias, recomputed bit for bit
+                        g.x *= hoig_act_grad_from_y(fmaf(hx, aw.x, ab.x), act, slope);
+                        g.y *= hoig_act_grad_from_y(fmaf(hy, aw.y, ab.y), act, slope);
+                        g.z *= hoig_act_grad_from_y(fmaf(hz, aw.z, ab.z), act, slope);
+                        g.w *= hoig_act_grad_from_y(fmaf(hw, aw.w, ab.w), act, slope);
+                    }
                 }
                 if (mode == 2) {
                     const float4 ga = *reinterpret_cast<const float4 *>(p0 + ((size_t)b * HW + r) * ldp + c);
                     g.x *= 1.f + ga.x; g.y *= 1.f + ga.y; g.z *= 1.f + ga.z; g.w *= 1.f + ga.w;
                 }
-                const float hx = (v.x - mu.x) * rs.x, hy = (v.y - mu.y) * rs.y, hz = (v.z - mu.z) * rs.z,
-                            hw = (v.w - mu.w) * rs.w;
                 s1.x += g.x; s1.y += g.y; s1.z += g.z; s1.w += g.w;
                 s2.x += g.x * hx; s2.y += g.y * hy; s2.z += g.z * hz; s2.w += g.w * hw;
             }
@@ -149,10 +161,10 @@ __global__ __launch_bounds__(NT) void inorm_apply_kernel(const float *__restrict
             sc.x += 1.f; sc.y += 1.f; sc.z += 1.f; sc.w += 1.f;
         }
         float4 o;
-        o.x = hoig_act((v.x - mu.x) * rs.x * sc.x + sh.x, act, slope);
-        o.y = hoig_act((v.y - mu.y) * rs.y * sc.y + sh.y, act, slope);
-        o.z = hoig_act((v.z - mu.z) * rs.z * sc.z + sh.z, act, slope);
-        o.w = hoig_act((v.w - mu.w) * rs.w * sc.w + sh.w, act, slope);
+        o.x = hoig_act(fmaf((v.x - mu.x) * rs.x, sc.x, sh.x), act, slope);
+        o.y = hoig_act(fmaf((v.y - mu.y) * rs.y, sc.y, sh.y), act, slope);
+        o.z = hoig_act(fmaf((v.z - mu.z) * rs.z, sc.z, sh.z), act, slope);
+        o.w = hoig_act(fmaf((v.w - mu.w) * rs.w, sc.w, sh.w), act, slope);
         if (residual) {
             const float4 r = reinterpret_cast<const float4 *>(residual)[i];
             o.x += r.x; o.y += r.y; o.z += r.z; o.w += r.w;
@@ -167,7 +179,7 @@ __global__ __launch_bounds__(NT) void inorm_bwd_apply_kernel(const float *__rest
                                                              const float *__restrict__ dy, int act, float slope,
                                                              const float *__restrict__ sums, float *__restrict__ dx,
                                                              float *__restrict__ dp0, float *__restrict__ dp1, int HW,
-                                                             int C, int64_t n4, int ldp) {
+                                                             int C, int64_t n4, int ldp, const float *__restrict__ p1) {
     const int CV = C >> 2;
     const float inv = 1.f / (float)HW;
     for (int64_t i = (int64_t)blockIdx.x * NT + threadIdx.x; i < n4; i += (int64_t)gridDim.x * NT) {
@@ -177,17 +189,29 @@ __global__ __launch_bounds__(NT) void inorm_bwd_apply_kernel(const float *__rest
         const int c = cv * 4;
         const float4 v = reinterpret_cast<const float4 *>(x)[i];
         float4 g = reinterpret_cast<const float4 *>(dy)[i];
-        if (act != HOIG_ACT_NONE) {
-            const float4 yy = reinterpret_cast<const float4 *>(y)[i];
-            g.x *= hoig_act_grad_from_y(yy.x, act, slope);
-            g.y *= hoig_act_grad_from_y(yy.y, act, slope);
-            g.z *= hoig_act_grad_from_y(yy.z, act, slope);
-            g.w *= hoig_act_grad_from_y(yy.w, act, slope);
-        }
         const float4 mu = *reinterpret_cast<const float4 *>(mean + (size_t)b * C + c);
         const float4 rs = *reinterpret_cast<const float4 *>(rstd + (size_t)b * C + c);
         float4 h;
         h.x = (v.x - mu.x) * rs.x; h.y = (v.y - mu.y) * rs.y; h.z = (v.z - mu.z) * rs.z; h.w = (v.w - mu.w) * rs.w;
+        if (act != HOIG_ACT_NONE) {
+            if (y) {
+                const float4 yy = reinterpret_cast<const float4 *>(y)[i];
+                g.x *= hoig_act_grad_from_y(yy.x, act, slope);
+                g.y *= hoig_act_grad_from_y(yy.y, act, slope);
+                g.z *= hoig_act_grad_from_y(yy.z, act, slope);
+                g.w *= hoig_act_grad_from_y(yy.w, act, slope);
+            } else {
+                float4 aw = make_float4(1, 1, 1, 1), ab = make_float4(0, 0, 0, 0);
+                if (mode == 1) {
+                    aw = *reinterpret_cast<const float4 *>(p0 + c);
+                    ab = *reinterpret_cast<const float4 *>(p1 + c);
+                }
+                g.x *= hoig_act_grad_from_y(fmaf(h.x, aw.x, ab.x), act, slope);
+                g.y *= hoig_act_grad_from_y(fmaf(h.y, aw.y, ab.y), act, slope);
+                g.z *= hoig_act_grad_from_y(fmaf(h.z, aw.z, ab.z), act, slope);
+                g.w *= hoig_act_grad_from_y(fmaf(h.w, aw.w, ab.w), act, slope);
+            }
+        }
         float4 s1 = *reinterpret_cast<const float4 *>(sums + (size_t)b * 2 * C + c);
         float4 s2 = *reinterpret_cast<const float4 *>(sums + (size_t)b * 2 * C + C + c);
         float4 sc = make_float4(1, 1, 1, 1);
@@ -242,7 +266,7 @@ extern "C" int hoig_inorm_stats(const float *x, int B, int HW, int C, float eps,
     const int nch = inorm_chunks(HW);
     float *partial = (float *)workspace;
     inorm_partial_kernel<false><<<dim3(nch, B), NT, red_bytes(C), st>>>(x, nullptr, nullptr, 0, nullptr, nullptr,
-                                                                        nullptr, 0, 0.f, HW, C, nch, partial, C);
+                                                                        nullptr, 0, 0.f, HW, C, nch, partial, C, nullptr);
     HOIG_LAUNCH_CHECK();
     const int total = B * C;
     inorm_finalize_kernel<<<(total + 255) / 256, 256, 0, st>>>(x, partial, HW, C, nch, eps, mean, rstd, total);
@@ -272,20 +296,24 @@ extern "C" int hoig_inorm_apply_ld(const float *x, const float *mean, const floa
     return HOIG_OK;
 }
 
-extern "C" int hoig_inorm_bwd_ld(const float *x, const float *mean, const float *rstd, int mode, const float *p0, int ld_p,
-                                 const float *y, const float *dy, int act, float slope, float *dx, float *dp0, float *dp1,
-                                 int B, int HW, int C, void *workspace, hoig_stream_t stream);
+extern "C" int hoig_inorm_bwd_ld(const float *x, const float *mean, const float *rstd, int mode, const float *p0,
+                                 const float *p1, int ld_p, const float *y, const float *dy, int act, float slope, float *dx,
+                                 float *dp0, float *dp1, int B, int HW, int C, void *workspace, hoig_stream_t stream);
 extern "C" int hoig_inorm_bwd(const float *x, const float *mean, const float *rstd, int mode, const float *p0,
-                              const float *y, const float *dy, int act, float slope, float *dx, float *dp0, float *dp1,
-                              int B, int HW, int C, void *workspace, hoig_stream_t stream) {
-    return hoig_inorm_bwd_ld(x, mean, rstd, mode, p0, C, y, dy, act, slope, dx, dp0, dp1, B, HW, C, workspace, stream);
+                              const float *p1, const float *y, const float *dy, int act, float slope, float *dx, float *dp0,
+                              float *dp1, int B, int HW, int C, void *workspace, hoig_stream_t stream) {
+    return hoig_inorm_bwd_ld(x, mean, rstd, mode, p0, p1, C, y, dy, act, slope, dx, dp0, dp1, B, HW, C, workspace, stream);
 }
-extern "C" int hoig_inorm_bwd_ld(const float *x, const float *mean, const float *rstd, int mode, const float *p0, int ld_p,
-                                 const float *y, const float *dy, int act, float slope, float *dx, float *dp0, float *dp1,
-                                 int B, int HW, int C, void *workspace, hoig_stream_t stream) {
+extern "C" int hoig_inorm_bwd_ld(const float *x, const float *mean, const float *rstd, int mode, const float *p0,
+                                 const float *p1, int ld_p, const float *y, const float *dy, int act, float slope, float *dx,
+                                 float *dp0, float *dp1, int B, int HW, int C, void *workspace, hoig_stream_t stream) {
     if (mode == 2 && (ld_p < C || (ld_p & 3))) return HOIG_EINVAL;
     if (!x || !mean || !rstd || !dy || !dx || !workspace || mode < 0 || mode > 2) return HOIG_EINVAL;
-    if (act != HOIG_ACT_NONE && !y) return HOIG_EINVAL;
+    // y may be NULL for (Leaky)ReLU after a plain or affine instance norm: the sign of y is recomputed from x (for the
+    // affine form this needs its bias p1) -- the backward then reads two tensors per pass instead of three
+    if (act != HOIG_ACT_NONE && !y &&
+        !((act == HOIG_ACT_RELU || act == HOIG_ACT_LRELU) && (mode == 0 || (mode == 1 && p1))))
+        return HOIG_EINVAL;
     if (mode != 0 && !p0) return HOIG_EINVAL;
     if (mode == 2 && (!dp0 || !dp1)) return HOIG_EINVAL;
     if (!shape_ok(B, HW, C) || (int64_t)B * 2 * C > ACC_POOL) return HOIG_EUNSUPPORTED;
@@ -294,14 +322,14 @@ extern "C" int hoig_inorm_bwd_ld(const float *x, const float *mean, const float 
     float *partial = (float *)workspace;
     float *sums = partial + ACC_POOL;
     inorm_partial_kernel<true><<<dim3(nch, B), NT, red_bytes(C), st>>>(x, mean, rstd, mode, p0, y, dy, act, slope, HW, C,
-                                                                       nch, partial, ld_p);
+                                                                       nch, partial, ld_p, p1);
     HOIG_LAUNCH_CHECK();
     const int total = B * C;
     inorm_bwd_finalize_kernel<<<(total + 255) / 256, 256, 0, st>>>(partial, C, nch, mode, sums, dp0, dp1, total);
     HOIG_LAUNCH_CHECK();
     const int64_t n4 = (int64_t)B * HW * C / 4;
     inorm_bwd_apply_kernel<<<hoig_stream_grid(n4, NT), NT, 0, st>>>(x, mean, rstd, mode, p0, y, dy, act, slope, sums, dx,
-                                                                   dp0, dp1, HW, C, n4, ld_p);
+                                                                   dp0, dp1, HW, C, n4, ld_p, p1);
     HOIG_LAUNCH_CHECK();
     return HOIG_OK;
 }

@@ -207,6 +207,7 @@ def conv_transpose2d(x, w, stride=2, pad=1, output_padding=1, prec=None):
 
 # ------------------------------------------------------------------------------------------------- instance norm
 _norm_ws = {}
+_NORM_KEEP_Y = os.environ.get('HOIG_NORM_KEEP_Y', '0') == '1'      # A/B switch: read y in the backward as before
 
 
 def _norm_workspace(nfloats, device):
@@ -237,7 +238,9 @@ class _INorm(Function):
         call('hoig_inorm_apply', _p(x), _p(mean), _p(rstd), mode, _p(p0), _p(p1), act, slope, _p(residual), _p(y),
              B, HW, C, _st())
         ctx.cfg = (mode, act, slope, B, HW, C, residual is not None)
-        ctx.save_for_backward(x, mean, rstd, p0, p1, y if act != L.ACT_NONE else None)
+        # (Leaky)ReLU after a plain / affine norm: the backward recomputes the activation mask from x instead of reading y
+        y_free = act in (L.ACT_RELU, L.ACT_LRELU) and mode in (0, 1) and not _NORM_KEEP_Y
+        ctx.save_for_backward(x, mean, rstd, p0, p1, y if (act != L.ACT_NONE and not y_free) else None)
         return y
 
     @staticmethod
@@ -255,8 +258,8 @@ class _INorm(Function):
         elif mode == 2:
             dp0, dp1 = torch.empty_like(x), torch.empty_like(x)
             r0, r1 = dp0, dp1
-        call('hoig_inorm_bwd', _p(x), _p(mean), _p(rstd), mode, _p(p0), _p(y), _p(dy), act, slope, _p(dx), _p(dp0),
-             _p(dp1), B, HW, C, _p(ws), _st())
+        call('hoig_inorm_bwd', _p(x), _p(mean), _p(rstd), mode, _p(p0), _p(p1) if mode == 1 else None, _p(y), _p(dy), act,
+             slope, _p(dx), _p(dp0), _p(dp1), B, HW, C, _p(ws), _st())
         return dx, r0, r1, None, None, None, (dy if has_res else None), None
 
 
@@ -300,7 +303,7 @@ class _SpadeFused(Function):
         ws = _norm_workspace(L.lib.hoig_inorm_workspace_bytes(B, HW, C) // 4, x.device)
         dx = torch.empty_like(x)
         dgb = torch.empty_like(gb)
-        call('hoig_inorm_bwd_ld', _p(x), _p(mean), _p(rstd), 2, _p(gb), 2 * C, _p(y), _p(dy), act, slope, _p(dx), _p(dgb),
+        call('hoig_inorm_bwd_ld', _p(x), _p(mean), _p(rstd), 2, _p(gb), None, 2 * C, _p(y), _p(dy), act, slope, _p(dx), _p(dgb),
              dgb.data_ptr() + 4 * C, B, HW, C, _p(ws), _st())
         return dx, dgb, None, None, None
 

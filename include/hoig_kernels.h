@@ -105,16 +105,18 @@ int hoig_inorm_apply(const float *x, const float *mean, const float *rstd, int m
 int hoig_inorm_apply_ld(const float *x, const float *mean, const float *rstd, int mode, const float *p0, const float *p1,
                         int ld_p, int act, float slope, const float *residual /*nullable*/, float *y, int B, int HW, int C,
                         hoig_stream_t stream);
-int hoig_inorm_bwd_ld(const float *x, const float *mean, const float *rstd, int mode, const float *p0, int ld_p,
-                      const float *y, const float *dy, int act, float slope, float *dx, float *dp0, float *dp1, int B, int HW,
-                      int C, void *workspace, hoig_stream_t stream);
+int hoig_inorm_bwd_ld(const float *x, const float *mean, const float *rstd, int mode, const float *p0, const float *p1,
+                      int ld_p, const float *y, const float *dy, int act, float slope, float *dx, float *dp0, float *dp1, int B,
+                      int HW, int C, void *workspace, hoig_stream_t stream);
 /* backward of hoig_inorm_apply(+stats).  dy is d/d(y) ; y is the forward output (for the activation mask; pass
- * the pre-residual activation output, or NULL when act==NONE).
+ * the pre-residual activation output, or NULL when act==NONE).  For ReLU / LeakyReLU after a plain (mode 0) or affine
+ * (mode 1, p1 = its bias) norm, y may also be NULL: the mask is recomputed from x, one tensor less to read per pass.
+ * p1 is only read in that case (nullable otherwise).
  * Outputs: dx; mode 1: dweight[c] += , dbias[c] += ; mode 2: dgamma, dbeta (same shape as x, overwritten).
  * workspace >= hoig_inorm_workspace_bytes. */
-int hoig_inorm_bwd(const float *x, const float *mean, const float *rstd, int mode, const float *p0, const float *y,
-                   const float *dy, int act, float slope, float *dx, float *dp0, float *dp1, int B, int HW, int C,
-                   void *workspace, hoig_stream_t stream);
+int hoig_inorm_bwd(const float *x, const float *mean, const float *rstd, int mode, const float *p0, const float *p1,
+                   const float *y, const float *dy, int act, float slope, float *dx, float *dp0, float *dp1, int B, int HW,
+                   int C, void *workspace, hoig_stream_t stream);
 
 /* ---- local attention warping: ExtractorAttn (extract_attn.py:23-29) = K1 block extraction of source (with flow)
  *      and target (zero flow) + conv k5/s5 + LeakyReLU(0.01) + conv1x1 + softmax(25) + K3 reshape + weighted 5x5 average.
