@@ -633,7 +633,8 @@ static int launch_wgrad(WgradArgs a, hipStream_t st) {
     // phase-major order, never straddle a parity class boundary badly (a straddling 32-row block is still correct:
     // dead taps are then filtered per element).
     int splits = (int)hoig_cdiv(1024, a.nblk_mn);
-    const int max_splits = (int)hoig_cdiv(a.M, 256);
+    // (tiny-K layers -- SPADE's 3->128 3x3 over 32x32 maps -- are launch-shaped: 64 pixels per split give them 128 workgroups)
+    const int max_splits = (int)hoig_cdiv(a.M, a.K <= 128 ? 64 : 256);
     if (splits > max_splits) splits = max_splits;
     if (splits < 1) splits = 1;
     int mps = (int)hoig_cdiv(hoig_cdiv(a.M, splits), 32) * 32;
