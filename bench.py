@@ -27,9 +27,12 @@ PEAK = {'f32': 157.3, 'bf16x3': 2500.0, 'bf16': 2500.0}          # TFLOP/s dense
 
 def dominant_kernel_roofline(batch, side, precision, iters=20):
     """The dominant kernel of the step is the 3x3 stride-1 512->512 convolution at side/8 (72 of ~260 conv calls of a
-    forward, 44% of G's MACs).  Time that kernel alone with HIP events on the launch stream."""
+    forward, 44% of G's MACs).  Most of its time is spent in the launches of bg_model and obj_model,
+    which process the src and the tsf batch STACKED (2*batch images per launch: profiles/r01_conv_table.txt), so that is
+    the launch shape timed here: the kernel alone, HIP events on the launch stream."""
     from hoig_amd import ops
     h = side // 8
+    batch = 2 * batch
     x = torch.randn(batch, h, h, 512, device='cuda')
     w = ops.pack_weight(torch.randn(512, 512, 3, 3, device='cuda') * 0.02)
     for _ in range(3):
@@ -48,13 +51,13 @@ def dominant_kernel_roofline(batch, side, precision, iters=20):
     traffic = None
     try:
         pmc = json.load(open(os.path.join(ROOT, 'profiles', 'r01_pmc_dominant_conv.json')))
-        if precision == 'bf16x3' and batch == 8 and side == 256:
+        if precision == 'bf16x3' and batch == 16 and side == 256:
             traffic = pmc['traffic_bytes_per_launch']
     except Exception:
         pass
     achieved = flops / (ms * 1e-3) / 1e12
-    kname = 'igemm_f32_kernel' if precision == 'f32' else 'conv_halo3_bf16_kernel<%d,4,2,64,2>' % (2 if precision == 'bf16x3' else 1)
-    return dict(bound='mfma', kernel='%s (conv3x3 s1 512->512 @%dx%d, B=%d)' % (kname, h, h, batch),
+    kname = 'igemm_f32_kernel' if precision == 'f32' else 'conv_halo3_bf16_kernel<%d,4,2,128,2>' % (2 if precision == 'bf16x3' else 1)
+    return dict(bound='mfma', kernel='%s (conv3x3 s1 512->512 @%dx%d, %d images = src+tsf stacked)' % (kname, h, h, batch),
                 achieved=round(achieved, 2), peak=PEAK[precision], unit='TFLOP/s',
                 frac=round(achieved / PEAK[precision], 4), traffic=traffic, avg_launch_ms=round(ms, 4),
                 algorithmic_flop_per_launch=flops)
