@@ -81,6 +81,7 @@ _SIGS = {
     'hoig_nchw_to_nhwc': [_vp, _vp] + [_i] * 4 + [_vp],
     'hoig_nhwc_to_nchw': [_vp, _vp] + [_i] * 4 + [_vp],
     'hoig_copy_channels': [_vp, _vp, _i64, _i, _i, _i, _i, _i, _i, _vp],
+    'hoig_cat2_channels': [_vp, _i, _vp, _i, _vp, _i64, _vp],
     'hoig_add': [_vp, _vp, _vp, _i64, _vp],
     'hoig_act_bwd': [_vp, _vp, _vp, _i, _f, _i64, _vp],
     'hoig_act_bwd_colsum': [_vp, _vp, _vp, _vp, _i, _f, _i64, _i, _vp],

@@ -48,6 +48,33 @@ __global__ void copy_channels_kernel(const float *__restrict__ x, float *__restr
     }
 }
 
+// y[p][0:C1] = x1[p][:], y[p][C1:C1+C2] = x2[p][:] in ONE pass that walks y linearly: the destination is written as fully
+// coalesced runs even when its row length is odd (the 19-channel discriminator input: 3 image + 16 condition channels --
+// two strided partial-row copies into 76-B rows took 390 us each)
+template <int VEC>
+__global__ void cat2_kernel(const float *__restrict__ x1, int C1, const float *__restrict__ x2, int C2,
+                            float *__restrict__ y, int64_t npix) {
+    const int Cy = C1 + C2;
+    if (VEC == 4) {
+        const int Q1 = C1 >> 2, Qy = Cy >> 2;
+        const int64_t n = npix * Qy;
+        for (int64_t i = (int64_t)blockIdx.x * NT + threadIdx.x; i < n; i += (int64_t)gridDim.x * NT) {
+            const int64_t p = i / Qy;
+            const int q = (int)(i - p * Qy);
+            const float4 v = q < Q1 ? reinterpret_cast<const float4 *>(x1)[p * Q1 + q]
+                                    : reinterpret_cast<const float4 *>(x2)[p * (C2 >> 2) + (q - Q1)];
+            reinterpret_cast<float4 *>(y)[i] = v;
+        }
+    } else {
+        const int64_t n = npix * Cy;
+        for (int64_t i = (int64_t)blockIdx.x * NT + threadIdx.x; i < n; i += (int64_t)gridDim.x * NT) {
+            const int64_t p = i / Cy;
+            const int c = (int)(i - p * Cy);
+            y[i] = c < C1 ? x1[p * C1 + c] : x2[p * C2 + (c - C1)];
+        }
+    }
+}
+
 __global__ void add_kernel(const float *__restrict__ a, const float *__restrict__ b, float *__restrict__ y, int64_t n) {
     const int64_t n4 = n >> 2;
     for (int64_t i = (int64_t)blockIdx.x * NT + threadIdx.x; i < n4; i += (int64_t)gridDim.x * NT) {
@@ -339,6 +366,16 @@ extern "C" int hoig_copy_channels(const float *x, float *y, int64_t npix, int Cx
                                   int accumulate, hoig_stream_t stream) {
     if (!x || !y || x_off + Cc > Cx || y_off + Cc > Cy) return HOIG_EINVAL;
     copy_channels_kernel<<<hoig_stream_grid(npix * Cc, NT), NT, 0, ST>>>(x, y, npix, Cx, x_off, Cy, y_off, Cc, accumulate);
+    HOIG_LAUNCH_CHECK();
+    return HOIG_OK;
+}
+extern "C" int hoig_cat2_channels(const float *x1, int C1, const float *x2, int C2, float *y, int64_t npix,
+                                  hoig_stream_t stream) {
+    if (!x1 || !x2 || !y || C1 <= 0 || C2 <= 0) return HOIG_EINVAL;
+    if (((C1 | C2) & 3) == 0)
+        cat2_kernel<4><<<hoig_stream_grid(npix * ((C1 + C2) >> 2), NT), NT, 0, ST>>>(x1, C1, x2, C2, y, npix);
+    else
+        cat2_kernel<1><<<hoig_stream_grid(npix * (C1 + C2), NT), NT, 0, ST>>>(x1, C1, x2, C2, y, npix);
     HOIG_LAUNCH_CHECK();
     return HOIG_OK;
 }

@@ -337,6 +337,9 @@ def _copy_channels(x, y, x_off, y_off, n, accumulate=False):
          _st())
 
 
+_CAT_BWD_VIEWS = os.environ.get('HOIG_CAT_BWD_VIEWS', '1') == '1'
+
+
 class _Cat(Function):
     @staticmethod
     def forward(ctx, *xs):
@@ -345,10 +348,13 @@ class _Cat(Function):
             assert t.is_contiguous()
         cs = [t.shape[-1] for t in xs]
         y = torch.empty(xs[0].shape[:-1] + (sum(cs),), dtype=xs[0].dtype, device=xs[0].device)
-        off = 0
-        for t, c in zip(xs, cs):
-            _copy_channels(t, y, 0, off, c)
-            off += c
+        if len(xs) == 2:
+            call('hoig_cat2_channels', _p(xs[0]), cs[0], _p(xs[1]), cs[1], _p(y), y.numel() // y.shape[-1], _st())
+        else:
+            off = 0
+            for t, c in zip(xs, cs):
+                _copy_channels(t, y, 0, off, c)
+                off += c
         ctx.cs = cs
         return y
 
@@ -358,9 +364,15 @@ class _Cat(Function):
         outs, off = [], 0
         for i, c in enumerate(ctx.cs):
             if ctx.needs_input_grad[i]:
-                g = torch.empty(dy.shape[:-1] + (c,), dtype=dy.dtype, device=dy.device)
-                _copy_channels(dy, g, off, 0, c)
-                outs.append(g)
+                if _CAT_BWD_VIEWS:
+                    # a strided VIEW: where autograd sums it with another gradient of the same tensor (an encoder output also
+                    # feeds the next level) the add reads it in place and the slice copy never happens; single consumers
+                    # make it contiguous themselves
+                    outs.append(dy[..., off:off + c])
+                else:
+                    g = torch.empty(dy.shape[:-1] + (c,), dtype=dy.dtype, device=dy.device)
+                    _copy_channels(dy, g, off, 0, c)
+                    outs.append(g)
             else:
                 outs.append(None)
             off += c

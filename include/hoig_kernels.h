@@ -182,6 +182,8 @@ int hoig_nhwc_to_nchw(const float *x, float *y, int B, int C, int H, int W, hoig
 /* y[:, c_off : c_off+Cx] = x  for NHWC tensors with Cy channels (channel concat building block) */
 int hoig_copy_channels(const float *x, float *y, int64_t npix, int Cx, int x_off, int Cy, int y_off, int Ccopy,
                        int accumulate, hoig_stream_t stream);
+/* torch.cat([x1, x2], channel axis) of two contiguous [npix][C] tensors in one pass over y (coalesced for any C1 + C2) */
+int hoig_cat2_channels(const float *x1, int C1, const float *x2, int C2, float *y, int64_t npix, hoig_stream_t stream);
 /* y = a + b (n elements) ; y = act_bwd: dx = dy * act'(y) */
 int hoig_add(const float *a, const float *b, float *y, int64_t n, hoig_stream_t stream);
 int hoig_act_bwd(const float *y, const float *dy, float *dx, int act, float slope, int64_t n, hoig_stream_t stream);
