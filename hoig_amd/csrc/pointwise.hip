@@ -121,6 +121,44 @@ __global__ __launch_bounds__(NT) void act_bwd_colsum_kernel(const float *__restr
     }
 }
 
+// float4 form of the two kernels below for C % 4 == 0 (16-B accesses; FUSED: also writes g = dy * act'(y))
+template <bool FUSED>
+__global__ __launch_bounds__(NT) void colsum4_kernel(const float *__restrict__ y, const float *__restrict__ dy,
+                                                     float *__restrict__ g, float *__restrict__ out, int act, float slope,
+                                                     int64_t rows, int C, int64_t rows_per_block) {
+    const int64_t r0 = (int64_t)blockIdx.x * rows_per_block;
+    const int64_t r1 = r0 + rows_per_block < rows ? r0 + rows_per_block : rows;
+    const int CV = C >> 2;
+    const int lanes = CV < NT ? CV : NT;
+    const int rl_n = NT / lanes;
+    const int c0 = threadIdx.x % lanes, rl = threadIdx.x / lanes;
+    extern __shared__ float red[];                                     // [rl_n][C]
+    if (threadIdx.x < lanes * rl_n) {
+        for (int cv = c0; cv < CV; cv += lanes) {
+            float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
+            for (int64_t r = r0 + rl; r < r1; r += rl_n) {
+                float4 v = reinterpret_cast<const float4 *>(dy)[r * CV + cv];
+                if (FUSED) {
+                    const float4 yy = reinterpret_cast<const float4 *>(y)[r * CV + cv];
+                    v.x *= hoig_act_grad_from_y(yy.x, act, slope);
+                    v.y *= hoig_act_grad_from_y(yy.y, act, slope);
+                    v.z *= hoig_act_grad_from_y(yy.z, act, slope);
+                    v.w *= hoig_act_grad_from_y(yy.w, act, slope);
+                    reinterpret_cast<float4 *>(g)[r * CV + cv] = v;
+                }
+                s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
+            }
+            *reinterpret_cast<float4 *>(&red[rl * C + cv * 4]) = s;
+        }
+    }
+    __syncthreads();
+    for (int c = threadIdx.x; c < C; c += NT) {
+        float s = 0.f;
+        for (int k = 0; k < rl_n; ++k) s += red[k * C + c];
+        atomicAdd(&out[c], s);
+    }
+}
+
 // out[c] += sum_rows x[row][c]; one workgroup per row slab, lanes along channels (coalesced), LDS combine, one
 // atomic per (workgroup, channel)
 __global__ __launch_bounds__(NT) void colsum_kernel(const float *__restrict__ x, float *__restrict__ out, int64_t rows,
@@ -399,6 +437,13 @@ extern "C" int hoig_act_bwd_colsum(const float *y, const float *dy, float *g, fl
     if (nblk > 4096) nblk = 4096;
     const int64_t rpb = hoig_cdiv(rows, nblk);
     nblk = hoig_cdiv(rows, rpb);
+    if ((C & 3) == 0) {
+        const int lanes4 = (C >> 2) < NT ? (C >> 2) : NT;
+        colsum4_kernel<true><<<(int)nblk, NT, (size_t)(NT / lanes4) * C * sizeof(float), ST>>>(y, dy, g, dbias, act, slope,
+                                                                                               rows, C, rpb);
+        HOIG_LAUNCH_CHECK();
+        return HOIG_OK;
+    }
     const int lanes = C < NT ? C : NT;
     const size_t shm = (size_t)(NT / lanes) * C * sizeof(float);
     act_bwd_colsum_kernel<<<(int)nblk, NT, shm, ST>>>(y, dy, g, dbias, act, slope, rows, C, rpb);
@@ -412,6 +457,13 @@ extern "C" int hoig_colsum_accum(const float *x, float *out, int64_t rows, int C
     if (nblk > 4096) nblk = 4096;
     const int64_t rpb = hoig_cdiv(rows, nblk);
     nblk = hoig_cdiv(rows, rpb);
+    if ((C & 3) == 0) {
+        const int lanes4 = (C >> 2) < NT ? (C >> 2) : NT;
+        colsum4_kernel<false><<<(int)nblk, NT, (size_t)(NT / lanes4) * C * sizeof(float), ST>>>(nullptr, x, nullptr, out, 0, 0.f,
+                                                                                                rows, C, rpb);
+        HOIG_LAUNCH_CHECK();
+        return HOIG_OK;
+    }
     const int lanes = C < NT ? C : NT;
     const size_t shm = (size_t)(NT / lanes) * C * sizeof(float);
     colsum_kernel<<<(int)nblk, NT, shm, ST>>>(x, out, rows, C, rpb);
