@@ -396,3 +396,46 @@ def test_batched_weight_split_matches_per_weight_split():
             checked += 1
     assert checked >= 6
     assert tree.packed_planes(tree.P['head.weight'], False) is None
+
+
+RECT_CASES = [
+    # Ci, Co, H, W, k, stride, pad, transposed
+    (64, 128, 16, 64, 3, 1, 1, False),      # halo conv, 8x32 tiles: tiles_x != tiles_y
+    (128, 128, 8, 96, 3, 1, 1, False),
+    (64, 128, 16, 128, 3, 2, 1, False),     # parity-phase stride-2 kernel (gather fwd / scatter dgrad)
+    (128, 64, 8, 64, 3, 2, 1, True),        # ConvTranspose2d on it
+    (64, 3, 20, 72, 7, 1, 3, False),        # direct head kernels, ragged 16x64 tiles
+    (3, 64, 20, 40, 7, 1, 3, False),        # direct stem forward, ragged tiles
+    (8, 64, 12, 72, 7, 1, 3, False),        # two 4-channel groups (accumulating second pass)
+]
+
+
+@pytest.mark.parametrize('Ci,Co,H,W,k,stride,pad,transposed', RECT_CASES)
+def test_conv_rectangular_images(Ci, Co, H, W, k, stride, pad, transposed):
+    """Non-square feature maps and sizes that do not fill the last tile, through the fast paths (the model itself only
+    ever sees squares): forward, data gradient and weight gradient against torch fp32."""
+    ops = _ops()
+    from hoig_amd import _lib as L
+    g = torch.Generator().manual_seed(23)
+    B = 2
+    x = torch.randn(B, Ci, H, W, generator=g)
+    if transposed:
+        w = torch.randn(Ci, Co, k, k, generator=g) * 0.05
+        xr, wr = x.clone().requires_grad_(True), w.clone().requires_grad_(True)
+        yr = F.conv_transpose2d(xr, wr, None, stride=2, padding=1, output_padding=1)
+    else:
+        w = torch.randn(Co, Ci, k, k, generator=g) * 0.05
+        xr, wr = x.clone().requires_grad_(True), w.clone().requires_grad_(True)
+        yr = F.conv2d(xr, wr, None, stride=stride, padding=pad)
+    gy = torch.randn(yr.shape, generator=g)
+    yr.backward(gy)
+    xd = nhwc_cuda(x).requires_grad_(True)
+    wd = ops.pack_weight(w.cuda(), transposed=transposed).requires_grad_(True)
+    if transposed:
+        y = ops.conv_transpose2d(xd, wd, prec=L.PREC_BF16X3)
+    else:
+        y = ops.conv2d(xd, wd, None, stride, pad, prec=L.PREC_BF16X3)
+    y.backward(nhwc_cuda(gy))
+    assert rel_err(nchw_cpu(y), yr) < 3e-4
+    assert rel_err(nchw_cpu(xd.grad), xr.grad) < 3e-4
+    assert rel_err(wd.grad, wr.grad) < 3e-4
