@@ -1015,29 +1015,24 @@ int launch_halo3(HaloArgs a, int ns, hipStream_t st) {
 #endif
     a.tiles_x = a.W / 32;
     a.tiles_y = a.H / 4;
-    static const int nmajor = getenv("HOIG_HALO_NMAJOR") ? atoi(getenv("HOIG_HALO_NMAJOR")) : 1;
-    a.nmajor = nmajor;
-    static const int n64_max = getenv("HOIG_HALO_N64_MAX") ? atoi(getenv("HOIG_HALO_N64_MAX")) : 0;
-    const bool n64 = (a.N % 128) != 0 || a.Bn * a.tiles_x * a.tiles_y * (a.N / 128) < n64_max;
+    a.nmajor = 1;
+    const bool n64 = (a.N % 128) != 0;
     a.nblk_n = (int)hoig_cdiv(a.N, n64 ? 64 : 128);
     a.nblk = a.Bn * a.tiles_x * a.tiles_y * a.nblk_n;
     if (n64) return ns == 2 ? launch_halo3_one<2, 2, 2, 64, 0>(a, st) : launch_halo3_one<1, 2, 2, 64, 0>(a, st);
-    static const bool tall64 = getenv("HOIG_HALO_NO_TALL64") == nullptr;
-    if (tall64 && a.H % 8 == 0 && a.nblk / 2 < 256 && a.nblk >= 192) {   // too few 8-row tiles at BN = 128: 8 rows x 64 channels
+    if (a.H % 8 == 0 && a.nblk / 2 < 256 && a.nblk >= 192) {   // too few 8-row tiles at BN = 128: 8 rows x 64 channels
         a.tiles_y = a.H / 8;
         a.nblk_n = a.N / 64;
         a.nblk = a.Bn * a.tiles_x * a.tiles_y * a.nblk_n;
         return ns == 2 ? launch_halo3_one<2, 4, 2, 64, 2>(a, st) : launch_halo3_one<1, 4, 2, 64, 2>(a, st);
     }
     // 8 x 32 pixel tiles (8 waves, weight tile shared by 256 pixels) when that still gives every CU a workgroup
-    static const int tall_min = getenv("HOIG_HALO_TALL_MIN") ? atoi(getenv("HOIG_HALO_TALL_MIN")) : 256;
-    if (a.H % 8 == 0 && a.nblk / 2 >= tall_min) {
+    if (a.H % 8 == 0 && a.nblk / 2 >= 256) {
         a.tiles_y = a.H / 8;
         a.nblk = a.Bn * a.tiles_x * a.tiles_y * a.nblk_n;
         return ns == 2 ? launch_halo3_one<2, 4, 2, 128, 2>(a, st) : launch_halo3_one<1, 4, 2, 128, 2>(a, st);
     }
-    static const int wide_max = getenv("HOIG_HALO_WIDE_MAX") ? atoi(getenv("HOIG_HALO_WIDE_MAX")) : 384;
-    const bool wide = a.nblk < wide_max;
+    const bool wide = a.nblk < 384;
     if (ns == 2) return wide ? launch_halo3_one<2, 2, 4, 128, 1>(a, st) : launch_halo3_one<2, 2, 2, 128, 0>(a, st);
     return wide ? launch_halo3_one<1, 2, 4, 128, 1>(a, st) : launch_halo3_one<1, 2, 2, 128, 0>(a, st);
 }
@@ -1353,7 +1348,7 @@ int launch_halo(HaloArgs a, int ns, hipStream_t st) {
         return HOIG_OK;
     }
     // fewer than ~1.5 workgroups per CU: 8 waves per workgroup keep two waves on every SIMD
-    const bool wide = a.nblk < 384 && getenv("HOIG_HALO_4W") == nullptr;
+    const bool wide = a.nblk < 384;
     if (ns == 2) {
         if (wide) conv_halo_bf16_kernel<KS, 2, 4><<<a.nblk, 512, 0, st>>>(a);
         else conv_halo_bf16_kernel<KS, 2, 2><<<a.nblk, 256, 0, st>>>(a);
@@ -1401,7 +1396,7 @@ int run(const hoig_conv_desc *d, const float *a, const unsigned short *wh, const
         h.flip = dgrad ? 1 : 0;
         h.act = p.act; h.slope = p.slope;
         if (d->R == 1) return launch_halo<1>(h, ns, st);
-        if (d->R == 3) return getenv("HOIG_HALO_TAPSTEP") ? launch_halo<3>(h, ns, st) : launch_halo3(h, ns, st);
+        if (d->R == 3) return launch_halo3(h, ns, st);
         return launch_halo<5>(h, ns, st);
     }
     // stride-2 3x3 pad-1 layers on the parity-phase halo kernel.  gather: Conv2d forward / ConvTranspose2d data gradient;
@@ -1433,11 +1428,7 @@ int run(const hoig_conv_desc *d, const float *a, const unsigned short *wh, const
     }
     const long n128 = hoig_cdiv(p.N, 128);
     // fewer than two 128x128 workgroups per CU: run 8 waves per workgroup so every SIMD still holds two waves and one
-    // wave's bf16 split (VALU) overlaps the other's MFMAs
-    // BK = 64 (128 KB of LDS, one 8-wave workgroup per CU): a k-block's MFMA phase (>= 768 cycles per wave) then covers
-    // the L2/MALL latency of the next k-block's loads; BK = 32 keeps two 4-wave workgroups per CU for channel counts that
-    // are not multiples of 64
-    if (t128 * n128 >= 128 && g.Cg % 64 == 0 && getenv("HOIG_BK64") != nullptr) return launch<128, 128, 2, 4, 64>(p, ns, st);
+    // wave's bf16 split (VALU) overlaps the other's MFMAs.  (A BK = 64, double-buffered variant measured slower.)
     if (t128 * n128 >= 512) return launch<128, 128, 2, 2>(p, ns, st);
     if (t128 * n128 >= 128) return launch<128, 128, 2, 4>(p, ns, st);
     return launch<64, 128, 2, 2>(p, ns, st);

@@ -14,63 +14,6 @@ namespace {
 constexpr int TILE = 16, CC = 16, PSTR = 20;   // output tile side, channel chunk, LDS pixel stride (floats)
 constexpr int KMAX = 7, KS = 7;                 // the heads are all 7x7 (R = S = KS)
 
-template <int CO>
-__global__ __launch_bounds__(256) void conv_small_fwd_kernel(const float *__restrict__ x, const float *__restrict__ w,
-                                                             const float *__restrict__ bias, float *__restrict__ y,
-                                                             int B, int H, int W, int Ci, int R, int S, int pad, int act,
-                                                             float slope, int CoReal) {
-    // x: [B][H][W][Ci], w: [CoReal][R][S][Ci], y: [B][H][W][CoReal]; stride 1, "same" size output
-    __shared__ __attribute__((aligned(16))) float xs[(TILE + KMAX - 1) * (TILE + KMAX - 1) * PSTR];
-    const int tiles_x = (W + TILE - 1) / TILE, tiles_y = (H + TILE - 1) / TILE;
-    int t = blockIdx.x;
-    const int bx = t % tiles_x;
-    t /= tiles_x;
-    const int by = t % tiles_y, b = t / tiles_y;
-    const int tx = threadIdx.x & 15, ty = threadIdx.x >> 4;
-    const int TW = TILE + S - 1, TH = TILE + R - 1;
-    const int y0 = by * TILE - pad, x0 = bx * TILE - pad;
-    float acc[CO];
-#pragma unroll
-    for (int n = 0; n < CO; ++n) acc[n] = 0.f;
-    for (int c0 = 0; c0 < Ci; c0 += CC) {
-        __syncthreads();
-        // stage the halo tile: TH*TW pixels x 16 channels, one float4 per thread-iteration
-        for (int i = threadIdx.x; i < TH * TW * (CC / 4); i += 256) {
-            const int c4 = i & 3, pix = i >> 2;
-            const int py = pix / TW, px = pix - py * TW;
-            const int gy = y0 + py, gx = x0 + px;
-            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (gy >= 0 && gy < H && gx >= 0 && gx < W)
-                v = *reinterpret_cast<const float4 *>(x + (((size_t)b * H + gy) * W + gx) * Ci + c0 + c4 * 4);
-            *reinterpret_cast<float4 *>(&xs[pix * PSTR + c4 * 4]) = v;
-        }
-        __syncthreads();
-        for (int r = 0; r < R; ++r)
-            for (int s = 0; s < S; ++s) {
-                const float *px_ = &xs[((ty + r) * TW + tx + s) * PSTR];   // R = S = KS
-                const float *wp = w + ((size_t)r * S + s) * Ci + c0;      // + n*R*S*Ci ; wave-uniform -> scalar loads
-#pragma unroll
-                for (int c4 = 0; c4 < CC / 4; ++c4) {
-                    const float4 v = *reinterpret_cast<const float4 *>(px_ + c4 * 4);
-#pragma unroll
-                    for (int n = 0; n < CO; ++n) {
-                        const float4 ww = *reinterpret_cast<const float4 *>(wp + (size_t)n * R * S * Ci + c4 * 4);
-                        acc[n] = fmaf(v.x, ww.x, acc[n]);
-                        acc[n] = fmaf(v.y, ww.y, acc[n]);
-                        acc[n] = fmaf(v.z, ww.z, acc[n]);
-                        acc[n] = fmaf(v.w, ww.w, acc[n]);
-                    }
-                }
-            }
-    }
-    const int oy = by * TILE + ty, ox = bx * TILE + tx;
-    if (oy < H && ox < W) {
-        float *o = y + (((size_t)b * H + oy) * W + ox) * CoReal;
-#pragma unroll
-        for (int n = 0; n < CO; ++n) o[n] = hoig_act(acc[n] + (bias ? bias[n] : 0.f), act, slope);
-    }
-}
-
 // Forward, register-blocked: a thread owns FOUR adjacent output pixels of one row, so the 10 input pixels a tap row needs
 // are read from LDS once and feed 7 taps x 4 pixels (0.36 LDS reads per tap-pixel instead of 1), and the channel pairs of
 // a float4 go through v_pk_fma_f32 (two FMAs per lane per instruction: the 157 TF form of the fp32 VALU).
@@ -402,16 +345,10 @@ int hoig_conv_small_fwd(const hoig_conv_desc *d, const float *x, const float *w,
                         hipStream_t st) {
     if (d->transposed || d->stride != 1 || d->Co > 4 || (d->Ci % CC) || d->R != KS || d->S != KS) return HOIG_EUNSUPPORTED;
     if (d->Ho != d->Hi || d->Wo != d->Wi || 2 * d->pad != d->R - 1 || d->R != d->S) return HOIG_EUNSUPPORTED;
-    static const bool old_fwd = getenv("HOIG_SMALL_FWD_OLD") != nullptr;
-    const int tiles = old_fwd ? d->B * (int)hoig_cdiv(d->Hi, TILE) * (int)hoig_cdiv(d->Wi, TILE)
-                              : d->B * (int)hoig_cdiv(d->Hi, F4_TH) * (int)hoig_cdiv(d->Wi, F4_TW);
-#define HOIG_SMALL_FWD(N)                                                                                              \
-    if (old_fwd)                                                                                                       \
-        conv_small_fwd_kernel<N><<<tiles, 256, 0, st>>>(x, w, bias, y, d->B, d->Hi, d->Wi, d->Ci, d->R, d->S, d->pad,    \
-                                                        d->act, d->slope, d->Co);                                      \
-    else                                                                                                               \
-        conv_small_fwd4_kernel<N><<<tiles, 256, 0, st>>>(x, w, bias, y, d->B, d->Hi, d->Wi, d->Ci, d->pad, d->act,       \
-                                                         d->slope, d->Co)
+    const int tiles = d->B * (int)hoig_cdiv(d->Hi, F4_TH) * (int)hoig_cdiv(d->Wi, F4_TW);
+#define HOIG_SMALL_FWD(N)                                                                                          \
+    conv_small_fwd4_kernel<N><<<tiles, 256, 0, st>>>(x, w, bias, y, d->B, d->Hi, d->Wi, d->Ci, d->pad, d->act, d->slope, \
+                                                     d->Co)
     switch (d->Co) {
         case 1: HOIG_SMALL_FWD(1); break;
         case 2: HOIG_SMALL_FWD(2); break;
