@@ -1734,14 +1734,17 @@ int launch_wgrad_bf16(WArgs a, int ns, hipStream_t st) {
 struct WHaloArgs {
     const float *DY, *X;
     float *DW, *DB;            // DB (nullable): bias gradient = column sums of dy, taken from the dy tiles as they are staged
-    int Bn, H, W, Co, Ci;
+    int Bn, H, W, Co, Ci;     // H, W: output (= dy) size
+    int Hin, Win, pad;         // input (= x) size and padding
     int tiles_x, tiles_y, n_mtiles, mt_per_split;
     int nblk_ci, nblk;
 };
 
-template <int NS>
-__global__ __launch_bounds__(384) void wgrad_halo_bf16_kernel(const WHaloArgs p) {
-    constexpr int KS = 3, TH = 2, TW = 32, BM = 64, BC = 32, NT = 384;
+// KS = 3: "same" 3x3 (pad 1, input = output size).  KS = 5: the attention's 5x5 VALID convolution over the replicate-padded
+// target (input (H+4) x (W+4), pad 0): ten waves = co half x tap row, five taps each.
+template <int NS, int KS>
+__global__ __launch_bounds__(128 * KS) void wgrad_halo_bf16_kernel(const WHaloArgs p) {
+    constexpr int TH = 2, TW = 32, BM = 64, BC = 32, NT = 128 * KS;
     constexpr int HH = TH + KS - 1, HWID = TW + KS - 1, HPIX = HH * HWID;     // 4 x 34 halo pixels
     constexpr int PSTR = 192, QSTR = 64;
     constexpr int PLANE_P = TH * TW * PSTR, PLANE_Q = ((HPIX * QSTR + 255) / 256) * 256;
@@ -1780,7 +1783,7 @@ __global__ __launch_bounds__(384) void wgrad_halo_bf16_kernel(const WHaloArgs p)
                 bsum.x += v.x; bsum.y += v.y; bsum.z += v.z; bsum.w += v.w;
             }
         }
-        const float *xb = p.X + (size_t)b * p.H * p.W * p.Ci + ci0;
+        const float *xb = p.X + (size_t)b * p.Hin * p.Win * p.Ci + ci0;
 #pragma unroll
         for (int i = 0; i < QSL; ++i) {
             const int idx = tid + NT * i;
@@ -1788,9 +1791,9 @@ __global__ __launch_bounds__(384) void wgrad_halo_bf16_kernel(const WHaloArgs p)
             if (idx < HPIX * 8) {
                 const int hp = idx >> 3, c4 = idx & 7;
                 const int hy = hp / HWID, hx = hp - hy * HWID;
-                const int gy = y0 - 1 + hy, gx = x0 - 1 + hx;
-                if (gy >= 0 && gy < p.H && gx >= 0 && gx < p.W)
-                    v = *reinterpret_cast<const float4 *>(xb + ((size_t)gy * p.W + gx) * p.Ci + c4 * 4);
+                const int gy = y0 - p.pad + hy, gx = x0 - p.pad + hx;
+                if (gy >= 0 && gy < p.Hin && gx >= 0 && gx < p.Win)
+                    v = *reinterpret_cast<const float4 *>(xb + ((size_t)gy * p.Win + gx) * p.Ci + c4 * 4);
             }
             rq[i] = v;
         }
@@ -1898,20 +1901,27 @@ int launch_wgrad_halo(const hoig_conv_desc *d, const float *x, const float *dy, 
     WHaloArgs a;
     a.DY = dy; a.X = x; a.DW = dw; a.DB = dbias;
     a.Bn = d->B; a.H = d->Ho; a.W = d->Wo; a.Co = d->Co; a.Ci = d->Ci;
+    a.Hin = d->Hi; a.Win = d->Wi; a.pad = d->pad;
     a.tiles_x = a.W / 32;
     a.tiles_y = a.H / 2;
     a.n_mtiles = a.Bn * a.tiles_x * a.tiles_y;
     a.nblk_ci = a.Ci / 32;
     a.nblk = (a.Co / 64) * a.nblk_ci;
     static const int target_blocks = getenv("HOIG_WGRAD_HALO_BLOCKS") ? atoi(getenv("HOIG_WGRAD_HALO_BLOCKS")) : 512;
-    int splits = (int)hoig_cdiv(target_blocks, a.nblk);
+    // 5x5: a workgroup owns 25 taps x 64 x 32 outputs, so every pixel split costs 2.8x the atomics of a 3x3 one: 256 (measured)
+    int splits = (int)hoig_cdiv(d->R == 5 ? target_blocks / 2 : target_blocks, a.nblk);
     if (splits > a.n_mtiles) splits = a.n_mtiles;
     if (splits < 1) splits = 1;
     a.mt_per_split = (int)hoig_cdiv(a.n_mtiles, splits);
     splits = (int)hoig_cdiv(a.n_mtiles, a.mt_per_split);
     dim3 grid(a.nblk, splits);
-    if (ns == 2) wgrad_halo_bf16_kernel<2><<<grid, 384, 0, st>>>(a);
-    else wgrad_halo_bf16_kernel<1><<<grid, 384, 0, st>>>(a);
+    if (d->R == 5) {
+        if (ns == 2) wgrad_halo_bf16_kernel<2, 5><<<grid, 640, 0, st>>>(a);
+        else wgrad_halo_bf16_kernel<1, 5><<<grid, 640, 0, st>>>(a);
+    } else {
+        if (ns == 2) wgrad_halo_bf16_kernel<2, 3><<<grid, 384, 0, st>>>(a);
+        else wgrad_halo_bf16_kernel<1, 3><<<grid, 384, 0, st>>>(a);
+    }
     HOIG_LAUNCH_CHECK();
     return HOIG_OK;
 }
@@ -1920,9 +1930,10 @@ int launch_wgrad_halo(const hoig_conv_desc *d, const float *x, const float *dy, 
 
 bool hoig_conv_bf16_wgrad_fuses_bias(const hoig_conv_desc *d) {
     static const bool no_halo = getenv("HOIG_NO_WGRAD_HALO") != nullptr;
-    return !no_halo && d->precision != HOIG_PREC_F32 && !d->transposed && d->stride == 1 && d->R == 3 && d->S == 3 &&
-           d->pad == 1 && d->Hi == d->Ho && d->Wi == d->Wo && d->Wo % 32 == 0 && d->Ho % 2 == 0 && d->Ci % 32 == 0 &&
-           d->Co % 64 == 0;
+    if (no_halo || d->precision == HOIG_PREC_F32 || d->transposed || d->stride != 1 || d->R != d->S) return false;
+    if (d->Wo % 32 || d->Ho % 2 || d->Ci % 32 || d->Co % 64) return false;
+    if (d->R == 3) return d->pad == 1 && d->Hi == d->Ho && d->Wi == d->Wo;
+    return d->R == 5 && d->pad == 0 && d->Hi == d->Ho + 4 && d->Wi == d->Wo + 4;      // the attention's valid 5x5
 }
 
 // dbias: only passed (non-null) when hoig_conv_bf16_wgrad_fuses_bias(d); every other shape gets its bias gradient from
