@@ -235,7 +235,8 @@ def main():
             'metric': 'HOGAN train images/sec at %dx%d' % (args.side, args.side),
             'value': round(value, 3), 'unit': 'images/s', 'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
             'ms_per_step': round(ms, 3), 'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
-            'dtype': args.precision, 'data': 'synthetic',
+            'dtype': {'bf16x3': 'f16x3 fwd / bf16x3 bwd (split 16-bit operands, f32 accumulate)'}.get(args.precision, args.precision),
+            'data': 'synthetic',
             'config': {'workload': '%dx%d %s-shaped synthetic, batch %d per GPU, G+D full step (%s, VGG19 '
                                    'surrogate weights)' % (args.side, args.side, 'HO3Dv3' if args.dataset == 'hov3' else 'DexYCB',
                                                            args.batch, args.gen_name),

@@ -40,6 +40,8 @@ struct Args {
     float slope;
     int nblk_n, nblk;
     int ksplit, steps_per_split;   // split-K over blockIdx.y (atomic epilogue into a zeroed output)
+    int f16;                       // forward launch: fp16-split operands, weights pre-scaled by 2^8
+    float oscale;                  // accumulator scale of the epilogue (2^-8 or 1)
 };
 
 __device__ __forceinline__ void decode_m(const Geom &g, int m, int &b, int &hp, int &wp) {
@@ -89,6 +91,32 @@ __device__ __forceinline__ unsigned cvt2(float a, float b) {
     f2_t v = {a, b};
     return __builtin_bit_cast(unsigned, __builtin_convertvector(v, bf2_t));
 }
+// FORWARD operands are split on fp16 instead (11-bit mantissas: x = hi + lo to 2^-22, the three products to ~2^-21 at the
+// same MFMA rate): the error of the forward point, not the backward arithmetic, sets the gradient parity of the fast mode
+// (precision).  Forward activations are O(1)-O(100) (post-norm / images / VGG features), far inside fp16's
+// range; weights are scaled by 2^8 when they are split (exact) and the accumulator by 2^-8 in the epilogue.
+typedef _Float16 h2_t __attribute__((ext_vector_type(2)));
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+constexpr float W_SCALE_F16 = 256.f;
+__device__ __forceinline__ unsigned cvt2h(float a, float b) {
+    f2_t v = {a, b};
+    return __builtin_bit_cast(unsigned, __builtin_convertvector(v, h2_t));
+}
+__device__ __forceinline__ void split4h(const float4 v, uint2 &hi, uint2 &lo) {
+    hi.x = cvt2h(v.x, v.y);
+    hi.y = cvt2h(v.z, v.w);
+    const h2_t h0 = __builtin_bit_cast(h2_t, hi.x), h1 = __builtin_bit_cast(h2_t, hi.y);
+    lo.x = cvt2h(v.x - (float)h0[0], v.y - (float)h0[1]);
+    lo.y = cvt2h(v.z - (float)h1[0], v.w - (float)h1[1]);
+}
+template <bool F16>
+__device__ __forceinline__ f32x16 mfma16(const bf16x8 a, const bf16x8 b, const f32x16 c) {
+    if constexpr (F16)
+        return __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, a), __builtin_bit_cast(f16x8, b), c, 0, 0, 0);
+    else
+        return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0);
+}
+
 // hi = bf16(x), lo = bf16(x - hi) for four values
 __device__ __forceinline__ void split4(const float4 v, uint2 &hi, uint2 &lo) {
     hi.x = cvt2(v.x, v.y);
@@ -97,6 +125,11 @@ __device__ __forceinline__ void split4(const float4 v, uint2 &hi, uint2 &lo) {
     const float r2 = v.z - __uint_as_float(hi.y << 16), r3 = v.w - __uint_as_float(hi.y & 0xFFFF0000u);
     lo.x = cvt2(r0, r1);
     lo.y = cvt2(r2, r3);
+}
+template <bool F16>
+__device__ __forceinline__ void split4t(const float4 v, uint2 &hi, uint2 &lo) {
+    if constexpr (F16) split4h(v, hi, lo);
+    else split4(v, hi, lo);
 }
 
 // Layout of a packed bf16 weight plane in HBM: 32(n) x 32(k) blocks, each 2 KB contiguous, block (n/32, k/32) at
@@ -122,7 +155,7 @@ __device__ __forceinline__ int lds_off(int row, int k) {
     return row * (BK * 2) + (((k >> 3) ^ lds_swz<BK>(row)) << 4) + ((k & 4) << 1);
 }
 
-template <int BM, int BN, int WM, int WN, int NS, int BK>
+template <int BM, int BN, int WM, int WN, int NS, int BK, bool F16>
 __global__ __launch_bounds__(WM * WN * 64) void igemm_bf16_kernel(const Args p) {
     constexpr int NT = WM * WN * 64;        // 256 or 512 threads
     constexpr int TM = BM / (32 * WM), TN = BN / (32 * WN);
@@ -244,7 +277,7 @@ __global__ __launch_bounds__(WM * WN * 64) void igemm_bf16_kernel(const Args p) 
 #pragma unroll
         for (int i = 0; i < RA; ++i) {
             uint2 hi, lo;
-            split4(ra[i], hi, lo);
+            split4t<F16>(ra[i], hi, lo);
             *reinterpret_cast<uint2 *>(Ah + aoff[i]) = hi;
             if (NS == 2) *reinterpret_cast<uint2 *>(Al + aoff[i]) = lo;
         }
@@ -298,10 +331,10 @@ __global__ __launch_bounds__(WM * WN * 64) void igemm_bf16_kernel(const Args p) 
 #pragma unroll
                 for (int j = 0; j < TN; ++j) {
                     if (NS == 2) {
-                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[i], bhf[j], acc[i][j], 0, 0, 0);
-                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[i], blf[j], acc[i][j], 0, 0, 0);
+                        acc[i][j] = mfma16<F16>(al[i], bhf[j], acc[i][j]);
+                        acc[i][j] = mfma16<F16>(ah[i], blf[j], acc[i][j]);
                     }
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[i], bhf[j], acc[i][j], 0, 0, 0);
+                    acc[i][j] = mfma16<F16>(ah[i], bhf[j], acc[i][j]);
                 }
         }
         if (NSTAGE == 2) {
@@ -342,7 +375,7 @@ __global__ __launch_bounds__(WM * WN * 64) void igemm_bf16_kernel(const Args p) 
             for (int j = 0; j < TN; ++j) {
                 const int n = n0 + wn * (TN * 32) + j * 32 + l31;
                 if (n < p.N) {
-                    float v = acc[i][j][r];
+                    float v = acc[i][j][r] * p.oscale;
                     if (p.ksplit > 1) {
                         if (blockIdx.y == 0) v += bias_r[j];
                         atomicAdd(&p.C[pix * p.N + n], v);
@@ -356,6 +389,20 @@ __global__ __launch_bounds__(WM * WN * 64) void igemm_bf16_kernel(const Args p) 
     }
 }
 
+// forward planes: fp16 split of w * 2^8;   data-gradient planes: bf16 split of w
+__device__ __forceinline__ void split_weight(float x, bool f16, unsigned short &h, unsigned short &l) {
+    if (f16) {
+        const float xs = x * W_SCALE_F16;
+        const _Float16 hh = (_Float16)xs;
+        const _Float16 ll = (_Float16)(xs - (float)hh);
+        h = __builtin_bit_cast(unsigned short, hh);
+        l = __builtin_bit_cast(unsigned short, ll);
+    } else {
+        h = hoig_f2bf(x);
+        l = hoig_f2bf(x - hoig_bf2f(h));
+    }
+}
+
 // w: fp32 [Co][RS][Ci].  mode 0 -> plane rows n = co, k = (rs, ci) (forward); mode 1 -> rows n = ci, k = (rs, co) (data
 // gradient); both in the blocked plane layout (plane_index)
 __global__ void pack_weight_kernel(const float *__restrict__ w, int Co, int RS, int Ci, int mode,
@@ -366,10 +413,10 @@ __global__ void pack_weight_kernel(const float *__restrict__ w, int Co, int RS, 
         const int64_t t = i / Ci;
         const int rs = (int)(t % RS), co = (int)(t / RS);
         const size_t dst = mode == 1 ? plane_index(ci, rs * Co + co, RS * Co) : plane_index(co, rs * Ci + ci, RS * Ci);
-        const float x = w[i];
-        const unsigned short h = hoig_f2bf(x);
+        unsigned short h, l;
+        split_weight(w[i], mode == 0, h, l);
         hi[dst] = h;
-        if (lo) lo[dst] = hoig_f2bf(x - hoig_bf2f(h));
+        if (lo) lo[dst] = l;
     }
 }
 
@@ -405,13 +452,14 @@ __global__ __launch_bounds__(256) void pack_all_kernel(const float *__restrict__
             if (co < Co && ci < Ci) {
                 const int64_t i = ((int64_t)co * RS + rs) * Ci + ci;
                 const float x = w[i];
-                const unsigned short h = hoig_f2bf(x);
-                const unsigned short l = hoig_f2bf(x - hoig_bf2f(h));
+                unsigned short h, l;
                 if (flags & 1) {
+                    split_weight(x, true, h, l);
                     const size_t o = off + plane_index(co, rs * Ci + ci, RS * Ci);
                     hi_f[o] = h;
                     lo_f[o] = l;
                 }
+                split_weight(x, false, h, l);
                 pk = (unsigned int)h | ((unsigned int)l << 16);
             }
             tile[ty + 8 * k][tx] = pk;
@@ -458,8 +506,13 @@ int launch(Args a, int ns, hipStream_t st) {
         }
     }
     dim3 grid(a.nblk, a.ksplit);
-    if (ns == 2) igemm_bf16_kernel<BM, BN, WM, WN, 2, BK><<<grid, NT, 0, st>>>(a);
-    else igemm_bf16_kernel<BM, BN, WM, WN, 1, BK><<<grid, NT, 0, st>>>(a);
+    if (a.f16) {
+        if (ns == 2) igemm_bf16_kernel<BM, BN, WM, WN, 2, BK, true><<<grid, NT, 0, st>>>(a);
+        else igemm_bf16_kernel<BM, BN, WM, WN, 1, BK, true><<<grid, NT, 0, st>>>(a);
+    } else {
+        if (ns == 2) igemm_bf16_kernel<BM, BN, WM, WN, 2, BK, false><<<grid, NT, 0, st>>>(a);
+        else igemm_bf16_kernel<BM, BN, WM, WN, 1, BK, false><<<grid, NT, 0, st>>>(a);
+    }
     HOIG_LAUNCH_CHECK();
     return HOIG_OK;
 }
@@ -487,12 +540,14 @@ struct HaloArgs {
     int nblk_n, nblk;
     int tiles_x, tiles_y;
     int nmajor;                // tile index = channel tile * pixel tiles + pixel tile (3x3 kernel)
+    int f16;                   // forward launch: fp16-split operands, weights pre-scaled by 2^8
+    float oscale;              // accumulator scale of the epilogue (2^-8 or 1)
 #ifdef HOIG_STAMP
     unsigned long long *dbg;   // diagnostic build only (tools/stamp_halo.py): per-wave cycle sums of the step phases
 #endif
 };
 
-template <int KS, int NS, int WN, int BN = 128>
+template <int KS, int NS, int WN, int BN, bool F16>
 __global__ __launch_bounds__(128 * WN) void conv_halo_bf16_kernel(const HaloArgs p) {
     constexpr int TH = 4, TW = 32;
     constexpr int NT = 128 * WN;                           // 2 x WN waves: 256 or 512 threads
@@ -598,7 +653,7 @@ __global__ __launch_bounds__(128 * WN) void conv_halo_bf16_kernel(const HaloArgs
             if (i < HPIX * 8) {
                 const int pix = i >> 3, c4 = i & 7;
                 uint2 hi, lo;
-                split4(hreg[sl], hi, lo);
+                split4t<F16>(hreg[sl], hi, lo);
                 *reinterpret_cast<uint2 *>(Ah + pix * AROW + c4 * 8) = hi;
                 if (NS == 2) *reinterpret_cast<uint2 *>(Al + pix * AROW + c4 * 8) = lo;
             }
@@ -629,10 +684,10 @@ __global__ __launch_bounds__(128 * WN) void conv_halo_bf16_kernel(const HaloArgs
 #pragma unroll
                 for (int j = 0; j < TN; ++j) {
                     if (NS == 2) {
-                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[i], bhf[j], acc[i][j], 0, 0, 0);
-                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[i], blf[j], acc[i][j], 0, 0, 0);
+                        acc[i][j] = mfma16<F16>(al[i], bhf[j], acc[i][j]);
+                        acc[i][j] = mfma16<F16>(ah[i], blf[j], acc[i][j]);
                     }
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[i], bhf[j], acc[i][j], 0, 0, 0);
+                    acc[i][j] = mfma16<F16>(ah[i], bhf[j], acc[i][j]);
                 }
         }
     };
@@ -683,7 +738,7 @@ __global__ __launch_bounds__(128 * WN) void conv_halo_bf16_kernel(const HaloArgs
             for (int j = 0; j < TN; ++j) {
                 const int n = n0 + wn * (TN * 32) + j * 32 + l31;
                 if (n < p.N) {
-                    float v = acc[i][j][r];
+                    float v = acc[i][j][r] * p.oscale;
                     v += bias_r[j];
                     p.C[pix * p.N + n] = fast_act(v, nslope, special, p.act, p.slope);
                 }
@@ -701,7 +756,7 @@ __global__ __launch_bounds__(128 * WN) void conv_halo_bf16_kernel(const HaloArgs
 // MODE 2: weight tiles double-buffered, halo single (WM = 4: 8 rows x 32 pixels per workgroup, 152 KB) -- the weight tile
 //         of a step is shared by twice the pixels, which halves the dominant L2 -> LDS stream: in-kernel stamps
 //         (tools/stamp_halo.py) show the 4x32 tile waiting on the per-CU fill path (~30 B/clk/CU), not on the MFMA
-template <int NS, int WM, int WN, int BN = 128, int MODE = 0>
+template <int NS, int WM, int WN, int BN, int MODE, bool F16>
 __global__ __launch_bounds__(64 * WM * WN) void conv_halo3_bf16_kernel(const HaloArgs p) {
     constexpr int KS = 3, TH = 2 * WM, TW = 32;
     constexpr int NT = 64 * WM * WN;
@@ -821,7 +876,7 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_halo3_bf16_kernel(const Hal
             if (i < HPIX * 8) {
                 const int pix = i >> 3, c4 = i & 7;
                 uint2 hi, lo;
-                split4(hreg[sl], hi, lo);
+                split4t<F16>(hreg[sl], hi, lo);
                 *reinterpret_cast<uint2 *>(Ah + pix * AROW + c4 * 8) = hi;
                 if (NS == 2) *reinterpret_cast<uint2 *>(Al + pix * AROW + c4 * 8) = lo;
             }
@@ -857,10 +912,10 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_halo3_bf16_kernel(const Hal
 #pragma unroll
                 for (int j = 0; j < TN; ++j) {
                     if (NS == 2) {
-                        acc[ii][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f.al[ii], f.bh[j], acc[ii][j], 0, 0, 0);
-                        acc[ii][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f.ah[ii], f.bl[j], acc[ii][j], 0, 0, 0);
+                        acc[ii][j] = mfma16<F16>(f.al[ii], f.bh[j], acc[ii][j]);
+                        acc[ii][j] = mfma16<F16>(f.ah[ii], f.bl[j], acc[ii][j]);
                     }
-                    acc[ii][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f.ah[ii], f.bh[j], acc[ii][j], 0, 0, 0);
+                    acc[ii][j] = mfma16<F16>(f.ah[ii], f.bh[j], acc[ii][j]);
                 }
         };
         Frags f0, f1;
@@ -979,7 +1034,7 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_halo3_bf16_kernel(const Hal
             for (int j = 0; j < TN; ++j) {
                 const int n = n0 + wn * (TN * 32) + j * 32 + l31;
                 if (n < p.N) {
-                    float v = acc[i][j][r];
+                    float v = acc[i][j][r] * p.oscale;
                     v += bias_r[j];
                     p.C[pix * p.N + n] = fast_act(v, nslope, special, p.act, p.slope);
                 }
@@ -994,12 +1049,15 @@ int launch_halo3_one(const HaloArgs &a, hipStream_t st) {
     constexpr size_t shm = (MODE == 1 ? 2 : 1) * (NS * (HPIX * 80)) + (MODE == 0 ? 1 : 2) * (3 * NS * (BN * 64));
     static bool once = false;
     if (!once) {
-        if (hipFuncSetAttribute(reinterpret_cast<const void *>(&conv_halo3_bf16_kernel<NS, WM, WN, BN, MODE>),
+        if (hipFuncSetAttribute(reinterpret_cast<const void *>(&conv_halo3_bf16_kernel<NS, WM, WN, BN, MODE, true>),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm) != hipSuccess ||
+            hipFuncSetAttribute(reinterpret_cast<const void *>(&conv_halo3_bf16_kernel<NS, WM, WN, BN, MODE, false>),
                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm) != hipSuccess)
             return HOIG_ELAUNCH;
         once = true;
     }
-    conv_halo3_bf16_kernel<NS, WM, WN, BN, MODE><<<a.nblk, 64 * WM * WN, shm, st>>>(a);
+    if (a.f16) conv_halo3_bf16_kernel<NS, WM, WN, BN, MODE, true><<<a.nblk, 64 * WM * WN, shm, st>>>(a);
+    else conv_halo3_bf16_kernel<NS, WM, WN, BN, MODE, false><<<a.nblk, 64 * WM * WN, shm, st>>>(a);
     HOIG_LAUNCH_CHECK();
     return HOIG_OK;
 }
@@ -1049,7 +1107,7 @@ int launch_halo3(HaloArgs a, int ns, hipStream_t st) {
 //     output parity phase (P,Q) of a coarse tile: out[2I+P][2J+Q] = sum over the taps with r = 1 (P = 0) or r in {0,2} (P = 1)
 //     of in[I + (r == 0)][J + (s == 0)] w[r][s] -- a stride-1 conv with 1, 2 or 4 taps over one halo image; strided stores.
 // Tile: 4 x 32 coarse pixels x BN channels, 4 waves, single LDS stage (58 KB: two workgroups per CU).
-template <int NS, int BN, bool SCATTER>
+template <int NS, int BN, bool SCATTER, bool F16>
 __global__ __launch_bounds__(256) void conv_halo_s2_bf16_kernel(const HaloArgs p) {
     constexpr int TH = 4, TW = 32, NT = 256, WN = 2;
     constexpr int RB = BN * 4 / NT;                        // 16-B weight chunks per thread per plane per tap
@@ -1204,7 +1262,7 @@ __global__ __launch_bounds__(256) void conv_halo_s2_bf16_kernel(const HaloArgs p
             if (i < HPIX * 8) {
                 const int pix = i >> 3, c4 = i & 7;
                 uint2 hi, lo;
-                split4(hreg[sl], hi, lo);
+                split4t<F16>(hreg[sl], hi, lo);
                 *reinterpret_cast<uint2 *>(Ah + pix * AROW + c4 * 8) = hi;
                 if (NS == 2) *reinterpret_cast<uint2 *>(Al + pix * AROW + c4 * 8) = lo;
             }
@@ -1236,10 +1294,10 @@ __global__ __launch_bounds__(256) void conv_halo_s2_bf16_kernel(const HaloArgs p
 #pragma unroll
                     for (int j = 0; j < TN; ++j) {
                         if (NS == 2) {
-                            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[i], bhf[j], acc[i][j], 0, 0, 0);
-                            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[i], blf[j], acc[i][j], 0, 0, 0);
+                            acc[i][j] = mfma16<F16>(al[i], bhf[j], acc[i][j]);
+                            acc[i][j] = mfma16<F16>(ah[i], blf[j], acc[i][j]);
                         }
-                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[i], bhf[j], acc[i][j], 0, 0, 0);
+                        acc[i][j] = mfma16<F16>(ah[i], bhf[j], acc[i][j]);
                     }
             }
         }
@@ -1303,7 +1361,7 @@ __global__ __launch_bounds__(256) void conv_halo_s2_bf16_kernel(const HaloArgs p
             for (int j = 0; j < TN; ++j) {
                 const int n = n0 + wn * (TN * 32) + j * 32 + l31;
                 if (n < p.N) {
-                    float v = acc[i][j][r];
+                    float v = acc[i][j][r] * p.oscale;
                     v += bias_r[j];
                     p.C[pix * p.N + n] = fast_act(v, nslope, special, p.act, p.slope);
                 }
@@ -1324,11 +1382,11 @@ int launch_halo_s2(HaloArgs a, int ns, hipStream_t st) {
     a.nblk = a.Bn * a.tiles_x * a.tiles_y * a.nblk_n * (SCATTER ? 4 : 1);
     a.nmajor = 0;
     if (n64) {
-        if (ns == 2) conv_halo_s2_bf16_kernel<2, 64, SCATTER><<<a.nblk, 256, 0, st>>>(a);
-        else conv_halo_s2_bf16_kernel<1, 64, SCATTER><<<a.nblk, 256, 0, st>>>(a);
+        if (ns == 2) { if (a.f16) conv_halo_s2_bf16_kernel<2, 64, SCATTER, true><<<a.nblk, 256, 0, st>>>(a); else conv_halo_s2_bf16_kernel<2, 64, SCATTER, false><<<a.nblk, 256, 0, st>>>(a); }
+        else { if (a.f16) conv_halo_s2_bf16_kernel<1, 64, SCATTER, true><<<a.nblk, 256, 0, st>>>(a); else conv_halo_s2_bf16_kernel<1, 64, SCATTER, false><<<a.nblk, 256, 0, st>>>(a); }
     } else {
-        if (ns == 2) conv_halo_s2_bf16_kernel<2, 128, SCATTER><<<a.nblk, 256, 0, st>>>(a);
-        else conv_halo_s2_bf16_kernel<1, 128, SCATTER><<<a.nblk, 256, 0, st>>>(a);
+        if (ns == 2) { if (a.f16) conv_halo_s2_bf16_kernel<2, 128, SCATTER, true><<<a.nblk, 256, 0, st>>>(a); else conv_halo_s2_bf16_kernel<2, 128, SCATTER, false><<<a.nblk, 256, 0, st>>>(a); }
+        else { if (a.f16) conv_halo_s2_bf16_kernel<1, 128, SCATTER, true><<<a.nblk, 256, 0, st>>>(a); else conv_halo_s2_bf16_kernel<1, 128, SCATTER, false><<<a.nblk, 256, 0, st>>>(a); }
     }
     HOIG_LAUNCH_CHECK();
     return HOIG_OK;
@@ -1342,19 +1400,19 @@ int launch_halo(HaloArgs a, int ns, hipStream_t st) {
     a.nblk_n = (int)hoig_cdiv(a.N, n64 ? 64 : 128);
     a.nblk = a.Bn * a.tiles_x * a.tiles_y * a.nblk_n;
     if (n64) {
-        if (ns == 2) conv_halo_bf16_kernel<KS, 2, 2, 64><<<a.nblk, 256, 0, st>>>(a);
-        else conv_halo_bf16_kernel<KS, 1, 2, 64><<<a.nblk, 256, 0, st>>>(a);
+        if (ns == 2) { if (a.f16) conv_halo_bf16_kernel<KS, 2, 2, 64, true><<<a.nblk, 256, 0, st>>>(a); else conv_halo_bf16_kernel<KS, 2, 2, 64, false><<<a.nblk, 256, 0, st>>>(a); }
+        else { if (a.f16) conv_halo_bf16_kernel<KS, 1, 2, 64, true><<<a.nblk, 256, 0, st>>>(a); else conv_halo_bf16_kernel<KS, 1, 2, 64, false><<<a.nblk, 256, 0, st>>>(a); }
         HOIG_LAUNCH_CHECK();
         return HOIG_OK;
     }
     // fewer than ~1.5 workgroups per CU: 8 waves per workgroup keep two waves on every SIMD
     const bool wide = a.nblk < 384;
     if (ns == 2) {
-        if (wide) conv_halo_bf16_kernel<KS, 2, 4><<<a.nblk, 512, 0, st>>>(a);
-        else conv_halo_bf16_kernel<KS, 2, 2><<<a.nblk, 256, 0, st>>>(a);
+        if (wide) { if (a.f16) conv_halo_bf16_kernel<KS, 2, 4, 128, true><<<a.nblk, 512, 0, st>>>(a); else conv_halo_bf16_kernel<KS, 2, 4, 128, false><<<a.nblk, 512, 0, st>>>(a); }
+        else { if (a.f16) conv_halo_bf16_kernel<KS, 2, 2, 128, true><<<a.nblk, 256, 0, st>>>(a); else conv_halo_bf16_kernel<KS, 2, 2, 128, false><<<a.nblk, 256, 0, st>>>(a); }
     } else {
-        if (wide) conv_halo_bf16_kernel<KS, 1, 4><<<a.nblk, 512, 0, st>>>(a);
-        else conv_halo_bf16_kernel<KS, 1, 2><<<a.nblk, 256, 0, st>>>(a);
+        if (wide) { if (a.f16) conv_halo_bf16_kernel<KS, 1, 4, 128, true><<<a.nblk, 512, 0, st>>>(a); else conv_halo_bf16_kernel<KS, 1, 4, 128, false><<<a.nblk, 512, 0, st>>>(a); }
+        else { if (a.f16) conv_halo_bf16_kernel<KS, 1, 2, 128, true><<<a.nblk, 256, 0, st>>>(a); else conv_halo_bf16_kernel<KS, 1, 2, 128, false><<<a.nblk, 256, 0, st>>>(a); }
     }
     HOIG_LAUNCH_CHECK();
     return HOIG_OK;
@@ -1364,6 +1422,8 @@ int run(const hoig_conv_desc *d, const float *a, const unsigned short *wh, const
         float *c, bool dgrad, hipStream_t st) {
     Args p;
     p.A = a; p.Wh = wh; p.Wl = wl; p.bias = bias; p.C = c;
+    p.f16 = dgrad ? 0 : 1;                       // forward: fp16-split operands over the 2^8-scaled forward planes
+    p.oscale = dgrad ? 1.f : 1.f / W_SCALE_F16;
     Geom &g = p.g;
     g.Bn = d->B;
     if (!dgrad) {
@@ -1395,6 +1455,7 @@ int run(const hoig_conv_desc *d, const float *a, const unsigned short *wh, const
         h.pad = d->pad;                      // dgrad: KS-1-pad == pad for "same" convolutions
         h.flip = dgrad ? 1 : 0;
         h.act = p.act; h.slope = p.slope;
+            h.f16 = p.f16; h.oscale = p.oscale;
         if (d->R == 1) return launch_halo<1>(h, ns, st);
         if (d->R == 3) return launch_halo3(h, ns, st);
         return launch_halo<5>(h, ns, st);
@@ -1413,6 +1474,7 @@ int run(const hoig_conv_desc *d, const float *a, const unsigned short *wh, const
             h.Bn = d->B; h.Cg = g.Cg; h.N = p.N; h.K = p.K;
             h.pad = 1; h.flip = 0;
             h.act = p.act; h.slope = p.slope;
+            h.f16 = p.f16; h.oscale = p.oscale;
             const bool gather = !g.gatherT;      // the operand is read at 2*o - 1 + tap (fine grid) -> gather mode
             if (gather) {
                 h.H = fine_h; h.W = fine_w;

@@ -7,6 +7,7 @@ ConvTranspose2d (Ci,Co,R,S) -- over PACKED storage [Co][R][S][Ci] (see
 their weight gradients accumulated in place by the kernels; for ordinary
 tensors the gradient is returned through autograd.
 """
+import collections
 import ctypes
 import os
 
@@ -117,11 +118,29 @@ def _wgrad_side_stream(device):
     return s
 
 
+_wgrad_pending = collections.deque()
+
+
+def _wgrad_hold(side, tensors):
+    """Keep `tensors` (the operands of a weight gradient just launched on `side`) referenced until that launch has run.
+    Autograd accumulates a multi-consumer gradient IN PLACE into an incoming gradient tensor when nobody else references it
+    (InputBuffer::accumulate): the dy of a residual add reaches both the convolution and the block input's accumulation
+    buffer, and once the convolution's backward has returned, the accumulation may overwrite dy while the side stream is
+    still reading it.  A live reference keeps the accumulation out of place; record_stream() alone only guards reuse after
+    free."""
+    ev = torch.cuda.Event()
+    ev.record(side)
+    _wgrad_pending.append((ev, tensors))
+    while _wgrad_pending and _wgrad_pending[0][0].query():
+        _wgrad_pending.popleft()
+
+
 def join_wgrad_streams():
     """Make the current stream wait for every weight gradient launched on a side stream (called before anything reads a
     flat gradient buffer: the optimiser step, the gradient all-reduce)."""
     for s in _wgrad_streams.values():
         torch.cuda.current_stream(s.device).wait_stream(s)
+    _wgrad_pending.clear()          # later work on this stream is ordered after the side stream's reads
 
 
 class _Conv(Function):
@@ -180,6 +199,7 @@ class _Conv(Function):
                     call('hoig_conv2d_bwd_weight', ctypes.byref(d), _p(x), _p(g), _p(dw), _p(db), _st())
                 x.record_stream(side)
                 g.record_stream(side)
+                _wgrad_hold(side, (x, g))
             else:
                 call('hoig_conv2d_bwd_weight', ctypes.byref(d), _p(x), _p(g), _p(dw), _p(db), _st())
             dw_ret = dw if ret_w else None
@@ -554,6 +574,7 @@ class _LocalAttn(Function):
                 call('hoig_conv2d_bwd_weight', ctypes.byref(d_s), _p(S), _p(dhid), _p(gs[1][0]), None, _st())
             for t in (tpad, S, dhid):
                 t.record_stream(side)
+            _wgrad_hold(side, (tpad, S, dhid))
         else:
             call('hoig_conv2d_bwd_weight', ctypes.byref(d_t), _p(tpad), _p(dhid), _p(gs[0][0]), _p(gs[2][0]), _st())
             call('hoig_conv2d_bwd_weight', ctypes.byref(d_s), _p(S), _p(dhid), _p(gs[1][0]), None, _st())

@@ -66,8 +66,10 @@ int hoig_conv2d_bwd_data(const hoig_conv_desc *d, const float *dy, const float *
 int hoig_conv2d_bwd_weight(const hoig_conv_desc *d, const float *x, const float *dy, float *dw, float *dbias,
                            hoig_stream_t stream);
 
-/* bf16-operand fast path (HOIG_PREC_BF16X3 / HOIG_PREC_BF16): weights are pre-split once per optimiser step into
- * bf16 planes hi (and lo = bf16(w - hi)) of n rows x K reduction indices.  for_dgrad=0: n = co, k = (r*S+s)*Ci + ci
+/* 16-bit-operand fast path (HOIG_PREC_BF16X3 / HOIG_PREC_BF16): weights are pre-split once per optimiser step into
+ * 16-bit planes hi and lo of n rows x K reduction indices: the FORWARD planes (for_dgrad=0) hold fp16(256*w) and
+ * fp16(256*w - hi) -- forward launches split their operands on fp16 and scale the accumulator by 1/256 -- the
+ * DATA-GRADIENT planes (for_dgrad=1) hold bf16(w) and bf16(w - hi).  for_dgrad=0: n = co, k = (r*S+s)*Ci + ci
  * (forward GEMM); for_dgrad=1: n = ci, k = (r*S+s)*Co + co (data-gradient GEMM).  A plane is stored in 32(n) x 32(k)
  * blocks of 2 KB: element (n, k) at ((n/32)*(K/32) + k/32)*1024 + (n%32)*32 + k%32, so that the weight tile of one
  * k-step is a few fully used contiguous runs.  Co and Ci must be multiples of 32 (else HOIG_EUNSUPPORTED).  The *_packed

@@ -98,14 +98,14 @@ def test_trainer_vs_oracle_128(precision):
     worst, worst_name = max(errs)
     print('gradient rel-L2 over %d tensors (%s): median %.2e  p95 %.2e  worst %.2e (%s)'
           % (len(vals), precision, vals[len(vals) // 2], vals[int(0.95 * len(vals))], worst, worst_name))
-    # Measured (128x128, batch 1, 7 runs): exact-fp32 MFMA mode  median 1.4e-3..4.7e-3 / p95 4.5e-3..8.2e-3 / worst
-    # 6e-3..1.3e-2 -- the spread is RUN TO RUN on identical inputs (fp32 atomics change the summation order of instance-
+    # Measured (128x128, batch 1, 10 runs): exact-fp32 MFMA mode  median 1.4e-3..5.6e-3 / p95 3.6e-3..9.0e-3 / worst
+    # 6e-3..1.6e-2 -- the spread is RUN TO RUN on identical inputs (fp32 atomics change the summation order of instance-
     # norm statistics and split-K partial sums; at 128x128 the deepest maps are 4x4, so a 1e-7 perturbation of a 16-sample
     # variance flips ReLU / max-pool decisions downstream), i.e. that floor is conditioning, not kernel rounding.
-    # Split-bf16 mode  median 1.2e-2 / p95 1.7e-2 / worst 2.6e-2: its 2^-16 product error is amplified by the cancellation
-    # inside every gradient dot product (random-sign sums over K ~ 5e3 terms) through ~20 back-propagated layers.
-    # Forward outputs and all loss terms meet 1e-3 / 2e-3 in BOTH modes (asserted above).
-    lim = dict(f32=(8e-3, 1.5e-2, GRAD_TOL), bf16x3=(2e-2, 3e-2, 3 * GRAD_TOL))[precision]
+    # Split mode (fp16-split forward operands, bf16-split backward operands): median 1.9e-3..2.0e-3 / p95 4.5e-3..8.2e-3 /
+    # worst 5.7e-3..1.2e-2 -- the same floor.  (With a bf16-split FORWARD it was median 1.1e-2: the gradient is that
+    # sensitive to the forward point; the backward arithmetic was shown not to matter)
+    lim = dict(f32=(8e-3, 1.5e-2, GRAD_TOL), bf16x3=(8e-3, 1.5e-2, GRAD_TOL))[precision]
     assert vals[len(vals) // 2] < lim[0]
     assert vals[int(0.95 * len(vals))] < lim[1]
     assert worst < lim[2], worst_name
