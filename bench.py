@@ -56,7 +56,7 @@ def dominant_kernel_roofline(batch, side, precision, iters=20):
     except Exception:
         pass
     achieved = flops / (ms * 1e-3) / 1e12
-    kname = 'igemm_f32_kernel' if precision == 'f32' else 'conv_halo3_bf16_kernel<%d,4,2,128,2>' % (2 if precision == 'bf16x3' else 1)
+    kname = 'igemm_f32_kernel' if precision == 'f32' else 'conv_halo3_bf16_kernel<%d,4,2,128,2,true>' % (2 if precision == 'bf16x3' else 1)
     return dict(bound='mfma', kernel='%s (conv3x3 s1 512->512 @%dx%d, %d images = src+tsf stacked)' % (kname, h, h, batch),
                 achieved=round(achieved, 2), peak=PEAK[precision], unit='TFLOP/s',
                 frac=round(achieved / PEAK[precision], 4), traffic=traffic, avg_launch_ms=round(ms, 4),
