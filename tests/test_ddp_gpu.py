@@ -1,0 +1,96 @@
+"""The N>1 training step ON THE GPU: two ranks share cuda:0 and exchange gradients over gloo (RCCL refuses two ranks on one
+device; the collective is the only thing that differs from the 8-GPU run), through the real Trainer with use_ddp=True --
+flat-buffer broadcast, G's exchange + Adam on the side stream beside the D step, weight gradients on their side stream.
+Checks: both ranks end with identical weights, and their update equals a single-process step on the combined batch
+(mean-reduced losses + per-sample instance norm make data parallelism exact up to summation order)."""
+import os
+import socket
+
+import numpy as np
+import pytest
+import torch
+import torch.multiprocessing as mp
+
+pytestmark = pytest.mark.gpu
+SIDE, STEPS = 64, 2
+PROBE = ['bg_model.model.12.main.0.weight', 'src_model.resnets.1.conv_0.weight', 'obj_model.decoders.0.0.weight',
+         'attn_6.fully_connect_layer.0.weight']
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(('127.0.0.1', 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _slice(inputs, lo, hi):
+    """Samples lo..hi-1 of a synthetic batch (bg_mask / hand_mask hold src then tsf, each of the full batch)."""
+    full = inputs['real_src'].shape[0]
+    out = {}
+    for k, v in inputs.items():
+        if v.shape[0] == 2 * full:
+            out[k] = torch.cat([v[lo:hi], v[full + lo:full + hi]], 0).contiguous()
+        else:
+            out[k] = v[lo:hi].contiguous()
+    return out
+
+
+def _run(rank, world, port, q):
+    import torch.distributed as dist
+    from common import opt_namespace
+    from hoig_amd import ops, synthetic
+    from hoig_amd.models import ModelsFactory
+    ddp = world > 1
+    if ddp:
+        os.environ['MASTER_ADDR'] = '127.0.0.1'
+        os.environ['MASTER_PORT'] = str(port)
+        dist.init_process_group('gloo', rank=rank, world_size=world)
+    torch.cuda.set_device(0)
+    ops.set_precision('bf16x3')
+    torch.manual_seed(77)                          # same init on every rank and in the single-process run
+    opt = opt_namespace(gen_name='generator_spade_attn', local_rank=0, image_size=SIDE)
+    model = ModelsFactory.get_by_name('trainer', opt, use_ddp=ddp)
+    model.set_train()
+    batch = synthetic.make_inputs(2, SIDE, seed=8)
+    model.set_input(_slice(batch, rank, rank + 1) if ddp else batch)
+    g = model._G.module if ddp else model._G
+    before = {k: g.state_dict()[k].cpu().numpy().copy() for k in PROBE}
+    for _ in range(STEPS):
+        model.optimize_parameters()
+    torch.cuda.synchronize()
+    sd = g.state_dict()
+    q.put((rank, {k: sd[k].cpu().numpy().copy() for k in PROBE}, before,
+           float(g.flat.double().sum().item())))
+    if ddp:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+def _spawn(world):
+    ctx = mp.get_context('spawn')
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_run, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = sorted([q.get(timeout=600) for _ in range(world)], key=lambda t: t[0])
+    for p in procs:
+        p.join(timeout=120)
+        assert p.exitcode == 0
+    return res
+
+
+def test_trainer_ddp_world2_matches_single_process():
+    (_, w0, b0, s0), (_, w1, b1, s1) = _spawn(2)
+    (_, ws, bs, _), = _spawn(1)
+    for k in PROBE:
+        assert np.array_equal(b0[k], b1[k]) and np.array_equal(b0[k], bs[k]), k      # same start everywhere
+        assert np.array_equal(w0[k], w1[k]), k                                       # ranks stay bit-identical
+        d_ddp, d_one = w0[k] - b0[k], ws[k] - bs[k]
+        assert np.linalg.norm(d_one) > 0
+        # Adam's first steps move every element by ~lr*sign(g): elements whose gradient is at rounding level may flip
+        rel = np.linalg.norm(d_ddp - d_one) / np.linalg.norm(d_one)
+        assert rel < 0.1, (k, rel)
+    assert s0 == s1
