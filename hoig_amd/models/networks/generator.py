@@ -193,7 +193,8 @@ class Generator(ParamTree):
         # pair -- run on separate HIP streams: their kernels fill each other's tails (autograd replays each branch's
         # backward on its own stream too).  The weight split is refreshed first, on the main stream.
         main = torch.cuda.current_stream()
-        fork = _FORK_STREAMS and bg.is_cuda and not torch.cuda.is_current_stream_capturing()
+        fork = _FORK_STREAMS and bg.is_cuda
+        capturing = fork and torch.cuda.is_current_stream_capturing()      # graph memory is private: no record_stream
         self.refresh_planes()
         bg_in = torch.cat([ops.cat_channels(src_bg_in), ops.cat_channels(tsf_bg_in)], dim=0)
         obj_in = torch.cat([src_obj, tsf_obj], dim=0)
@@ -206,8 +207,9 @@ class Generator(ParamTree):
                 bg_both = self._bg_net(bg_in)
             with torch.cuda.stream(s_obj):
                 obj_both = self._unet(obj_in, obj_c, 'obj_model')
-            for t_, st_ in ((bg_in, s_bg), (obj_in, s_obj), (obj_c, s_obj)):
-                t_.record_stream(st_)
+            if not capturing:
+                for t_, st_ in ((bg_in, s_bg), (obj_in, s_obj), (obj_c, s_obj)):
+                    t_.record_stream(st_)
         else:
             bg_both = self._bg_net(bg_in)
 
@@ -230,8 +232,9 @@ class Generator(ParamTree):
         if fork:
             main.wait_stream(s_bg)
             main.wait_stream(s_obj)
-            bg_both.record_stream(main)
-            obj_both.record_stream(main)
+            if not capturing:
+                bg_both.record_stream(main)
+                obj_both.record_stream(main)
         else:
             obj_both = self._unet(obj_in, obj_c, 'obj_model')
         src_img_bg, tsf_img_bg = bg_both[:nb], bg_both[nb:]
