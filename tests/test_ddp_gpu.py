@@ -1,8 +1,10 @@
 """The N>1 training step ON THE GPU: two ranks share cuda:0 and exchange gradients over gloo (RCCL refuses two ranks on one
 device; the collective is the only thing that differs from the 8-GPU run), through the real Trainer with use_ddp=True --
 flat-buffer broadcast, G's exchange + Adam on the side stream beside the D step, weight gradients on their side stream.
-Checks: both ranks end with identical weights, and their update equals a single-process step on the combined batch
-(mean-reduced losses + per-sample instance norm make data parallelism exact up to summation order)."""
+Checks: both ranks end with identical weights, and the averaged gradient (read from Adam's first moment after one step,
+(1 - beta1) * g) equals that of a single-process step on the combined batch (mean-reduced losses + per-sample instance norm
+make data parallelism exact up to summation order; the weights themselves move by ~lr*sign(g) in Adam's first step, so
+rounding-level gradient elements may flip and are not compared element-wise)."""
 import os
 import socket
 
@@ -12,7 +14,7 @@ import torch
 import torch.multiprocessing as mp
 
 pytestmark = pytest.mark.gpu
-SIDE, STEPS = 64, 2
+SIDE, STEPS = 64, 1
 PROBE = ['bg_model.model.12.main.0.weight', 'src_model.resnets.1.conv_0.weight', 'obj_model.decoders.0.0.weight',
          'attn_6.fully_connect_layer.0.weight']
 
@@ -61,8 +63,9 @@ def _run(rank, world, port, q):
         model.optimize_parameters()
     torch.cuda.synchronize()
     sd = g.state_dict()
+    mom = g.export_dict(model._optimizer_G.exp_avg)
     q.put((rank, {k: sd[k].cpu().numpy().copy() for k in PROBE}, before,
-           float(g.flat.double().sum().item())))
+           float(g.flat.double().sum().item()), {k: mom[k].cpu().numpy().copy() for k in PROBE}))
     if ddp:
         dist.barrier()
         dist.destroy_process_group()
@@ -83,14 +86,15 @@ def _spawn(world):
 
 
 def test_trainer_ddp_world2_matches_single_process():
-    (_, w0, b0, s0), (_, w1, b1, s1) = _spawn(2)
-    (_, ws, bs, _), = _spawn(1)
+    (_, w0, b0, s0, m0), (_, w1, b1, s1, m1) = _spawn(2)
+    (_, ws, bs, _, ms), = _spawn(1)
     for k in PROBE:
         assert np.array_equal(b0[k], b1[k]) and np.array_equal(b0[k], bs[k]), k      # same start everywhere
-        assert np.array_equal(w0[k], w1[k]), k                                       # ranks stay bit-identical
-        d_ddp, d_one = w0[k] - b0[k], ws[k] - bs[k]
-        assert np.linalg.norm(d_one) > 0
-        # Adam's first steps move every element by ~lr*sign(g): elements whose gradient is at rounding level may flip
-        rel = np.linalg.norm(d_ddp - d_one) / np.linalg.norm(d_one)
-        assert rel < 0.1, (k, rel)
+        assert np.array_equal(w0[k], w1[k]) and np.array_equal(m0[k], m1[k]), k      # ranks stay bit-identical
+        assert np.linalg.norm(ms[k]) > 0
+        rel = np.linalg.norm(m0[k] - ms[k]) / np.linalg.norm(ms[k])                  # averaged gradient == combined-batch gradient
+        assert rel < 5e-2, (k, rel)
+        # and the weights moved the same way for the bulk of the elements
+        agree = np.mean(np.sign(w0[k] - b0[k]) == np.sign(ws[k] - bs[k]))
+        assert agree > 0.9, (k, agree)
     assert s0 == s1
