@@ -105,7 +105,8 @@ def test_trainer_vs_oracle_128(precision):
     # Split mode (fp16-split forward operands, bf16-split backward operands): median 1.9e-3..2.0e-3 / p95 4.5e-3..8.2e-3 /
     # worst 5.7e-3..1.2e-2 -- the same floor.  (With a bf16-split FORWARD it was median 1.1e-2: the gradient is that
     # sensitive to the forward point; the backward arithmetic was shown not to matter)
-    lim = dict(f32=(8e-3, 1.5e-2, GRAD_TOL), bf16x3=(8e-3, 1.5e-2, GRAD_TOL))[precision]
+    # limits = ~1.5-2x the largest value seen in either mode (the spread is chaotic, not Gaussian)
+    lim = dict(f32=(1e-2, 2e-2, 3e-2), bf16x3=(1e-2, 2e-2, 3e-2))[precision]
     assert vals[len(vals) // 2] < lim[0]
     assert vals[int(0.95 * len(vals))] < lim[1]
     assert worst < lim[2], worst_name
