@@ -47,6 +47,21 @@ class GradSync(object):
                 h.wait()
         return 1.0 / self.world
 
+    def iter_all_reduce(self):
+        """All slices are submitted at once; yields each slice's (begin, end) once its exchange has been waited for (on NCCL
+        / RCCL `wait()` only orders the current stream behind the collective), so a consumer can start on slice i while
+        slices i+1.. are still in flight."""
+        if self.world <= 1:
+            yield (0, self.flat_grad.numel())
+            return
+        from .ops import join_wgrad_streams
+        join_wgrad_streams()
+        handles = [dist.all_reduce(self.flat_grad[a:b], op=dist.ReduceOp.SUM, group=self.group, async_op=True)
+                   for a, b in self.slices]
+        for h, ab in zip(handles, self.slices):
+            h.wait()
+            yield ab
+
 
 class FlatDDP(object):
     """Stands where ``DistributedDataParallel(net)`` stands in the reference: exposes ``.module``, forwards calls,

@@ -235,14 +235,15 @@ class Trainer(BaseModel):
             main = torch.cuda.current_stream()
             self._side.wait_stream(main)
             with torch.cuda.stream(self._side):
-                scale = net.sync.all_reduce_grads() if ddp else 1.0
-                optimizer.step(grad_scale=scale)
+                if ddp:           # Adam of slice i runs while slices i+1.. are still being exchanged
+                    optimizer.step(grad_scale=1.0 / net.sync.world, ready=net.sync.iter_all_reduce())
+                else:
+                    optimizer.step()
                 self._g_ready = torch.cuda.Event()
                 self._g_ready.record(self._side)
         elif ddp:
             self._wait_g()
-            scale = net.sync.all_reduce_grads()
-            optimizer.step(grad_scale=scale)
+            optimizer.step(grad_scale=1.0 / net.sync.world, ready=net.sync.iter_all_reduce())
         else:
             optimizer.step()
 

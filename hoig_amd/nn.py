@@ -287,13 +287,18 @@ class FusedAdam(object):
         join_wgrad_streams()
         self.tree.flat_grad.zero_()
 
-    def step(self, grad_scale=1.0):
+    def step(self, grad_scale=1.0, ready=None):
+        """One Adam step over the flat buffers.  `ready` (DDP): an iterator of (begin, end) element ranges whose gradients
+        have just been exchanged -- the update of a range is launched as soon as it is yielded, so Adam pipelines behind
+        the sliced all-reduce instead of waiting for the last slice (GradSync.iter_all_reduce)."""
         g = self.param_groups[0]
         self.step_count += 1
         join_wgrad_streams()
-        L.call('hoig_adam_step', _p(self.tree.flat), _p(self.tree.flat_grad), _p(self.exp_avg), _p(self.exp_avg_sq),
-               self.tree.flat.numel(), g['lr'], g['betas'][0], g['betas'][1], g['eps'], self.step_count,
-               grad_scale, _st())
+        fl, gr, m, v = self.tree.flat, self.tree.flat_grad, self.exp_avg, self.exp_avg_sq
+        for a, b in (ready if ready is not None else [(0, fl.numel())]):
+            L.call('hoig_adam_step', fl.data_ptr() + 4 * a, gr.data_ptr() + 4 * a, m.data_ptr() + 4 * a,
+                   v.data_ptr() + 4 * a, b - a, g['lr'], g['betas'][0], g['betas'][1], g['eps'], self.step_count,
+                   grad_scale, _st())
         self.tree.version += 1
 
     def state_dict(self):
