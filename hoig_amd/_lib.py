@@ -56,6 +56,9 @@ _SIGS = {
     'hoig_pack_conv_weights_bf16_all': [_vp, _vp, _i, _i64, _vp, _vp, _vp, _vp, _vp],
     'hoig_conv2d_fwd_packed': [ctypes.POINTER(ConvDesc), _vp, _vp, _vp, _vp, _vp, _vp],
     'hoig_conv2d_bwd_data_packed': [ctypes.POINTER(ConvDesc), _vp, _vp, _vp, _vp, _vp],
+    'hoig_conv2d_cat_fwd_packed': [ctypes.POINTER(ConvDesc), _vp, _i, _vp, _vp, _vp, _vp, _vp, _vp],
+    'hoig_conv2d_cat_bwd_data_packed': [ctypes.POINTER(ConvDesc), _vp, _vp, _vp, _vp, _i, _vp, _vp],
+    'hoig_conv2d_cat_bwd_weight': [ctypes.POINTER(ConvDesc), _vp, _i, _vp, _vp, _vp, _vp, _vp],
     'hoig_inorm_stats': [_vp, _i, _i, _i, _f, _vp, _vp, _vp, _vp],
     'hoig_inorm_apply': [_vp, _vp, _vp, _i, _vp, _vp, _i, _f, _vp, _vp, _i, _i, _i, _vp],
     'hoig_inorm_apply_ld': [_vp, _vp, _vp, _i, _vp, _vp, _i, _i, _f, _vp, _vp, _i, _i, _i, _vp],

@@ -542,6 +542,12 @@ struct HaloArgs {
     int nmajor;                // tile index = channel tile * pixel tiles + pixel tile (3x3 kernel)
     int f16;                   // forward launch: fp16-split operands, weights pre-scaled by 2^8
     float oscale;              // accumulator scale of the epilogue (2^-8 or 1)
+    // channel concatenation without the copy (3x3 kernel): the gathered tensor is [A | A2] along channels (A holds the
+    // first cg1 of the Cg channels), and / or the output is [C | C2] (C receives the first n1 of the N columns)
+    const float *A2;
+    int cg1;
+    float *C2;
+    int n1;
 #ifdef HOIG_STAMP
     unsigned long long *dbg;   // diagnostic build only (tools/stamp_halo.py): per-wave cycle sums of the step phases
 #endif
@@ -850,10 +856,13 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_halo3_bf16_kernel(const Hal
             }
         }
     };
-    const float *Aimg = p.A + (size_t)b * p.H * p.W * p.Cg;
     constexpr int HSLICES = (HPIX * 8 + NT - 1) / NT;
     float4 hreg[HSLICES];
     auto halo_load = [&](int cb) {
+        // one or two source tensors along the channel axis (p.A2: see HaloArgs)
+        const bool second = p.A2 != nullptr && cb * 32 >= p.cg1;
+        const int ld = p.A2 ? (second ? p.Cg - p.cg1 : p.cg1) : p.Cg;
+        const float *Aimg = (second ? p.A2 : p.A) + (size_t)b * p.H * p.W * ld + (second ? cb * 32 - p.cg1 : cb * 32);
 #pragma unroll
         for (int sl = 0; sl < HSLICES; ++sl) {
             const int i = tid + NT * sl;
@@ -863,7 +872,7 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_halo3_bf16_kernel(const Hal
                 const int hy = pix / HW, hx = pix - hy * HW;
                 const int gy = y0 - p.pad + hy, gx = x0 - p.pad + hx;
                 if (gy >= 0 && gy < p.H && gx >= 0 && gx < p.W)
-                    v = *reinterpret_cast<const float4 *>(Aimg + ((size_t)gy * p.W + gx) * p.Cg + cb * 32 + c4 * 4);
+                    v = *reinterpret_cast<const float4 *>(Aimg + ((size_t)gy * p.W + gx) * ld + c4 * 4);
             }
             hreg[sl] = v;
         }
@@ -1036,7 +1045,10 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_halo3_bf16_kernel(const Hal
                 if (n < p.N) {
                     float v = acc[i][j][r] * p.oscale;
                     v += bias_r[j];
-                    p.C[pix * p.N + n] = fast_act(v, nslope, special, p.act, p.slope);
+                    v = fast_act(v, nslope, special, p.act, p.slope);
+                    if (!p.C2) p.C[pix * p.N + n] = v;
+                    else if (n < p.n1) p.C[pix * p.n1 + n] = v;                  // (a whole 32-column group goes one way)
+                    else p.C2[pix * (p.N - p.n1) + (n - p.n1)] = v;
                 }
             }
         }
@@ -1074,7 +1086,7 @@ int launch_halo3(HaloArgs a, int ns, hipStream_t st) {
     a.tiles_x = a.W / 32;
     a.tiles_y = a.H / 4;
     a.nmajor = 1;
-    const bool n64 = (a.N % 128) != 0;
+    const bool n64 = (a.N % 128) != 0 || (a.C2 && a.n1 % 128 != 0);      // (a channel tile must not straddle the two outputs)
     a.nblk_n = (int)hoig_cdiv(a.N, n64 ? 64 : 128);
     a.nblk = a.Bn * a.tiles_x * a.tiles_y * a.nblk_n;
     if (n64) return ns == 2 ? launch_halo3_one<2, 2, 2, 64, 0>(a, st) : launch_halo3_one<1, 2, 2, 64, 0>(a, st);
@@ -1418,8 +1430,10 @@ int launch_halo(HaloArgs a, int ns, hipStream_t st) {
     return HOIG_OK;
 }
 
+// a2 / cg1: the gathered tensor is [a | a2] along channels; c2 / n1: the output is [c | c2] (3x3 stride-1 halo kernel only:
+// HOIG_EUNSUPPORTED for every other shape, the caller then concatenates / slices itself)
 int run(const hoig_conv_desc *d, const float *a, const unsigned short *wh, const unsigned short *wl, const float *bias,
-        float *c, bool dgrad, hipStream_t st) {
+        float *c, bool dgrad, hipStream_t st, const float *a2 = nullptr, int cg1 = 0, float *c2 = nullptr, int n1 = 0) {
     Args p;
     p.A = a; p.Wh = wh; p.Wl = wl; p.bias = bias; p.C = c;
     p.f16 = dgrad ? 0 : 1;                       // forward: fp16-split operands over the 2^8-scaled forward planes
@@ -1451,6 +1465,10 @@ int run(const hoig_conv_desc *d, const float *a, const unsigned short *wh, const
         (long)d->B * (d->Hi / 4) * (d->Wi / 32) * ((p.N + 127) / 128) >= 160) {   // fewer tiles: the generic kernel splits K
         HaloArgs h;
         h.A = a; h.Wh = wh; h.Wl = wl; h.bias = bias; h.C = c;
+        h.A2 = a2; h.cg1 = cg1; h.C2 = c2; h.n1 = n1;
+        if ((a2 || c2) && d->R != 3) return HOIG_EUNSUPPORTED;
+        if (a2 && (cg1 % 32 || cg1 <= 0 || cg1 >= g.Cg)) return HOIG_EINVAL;
+        if (c2 && (n1 % 64 || n1 <= 0 || n1 >= p.N)) return HOIG_EINVAL;
         h.Bn = d->B; h.H = d->Hi; h.W = d->Wi; h.Cg = g.Cg; h.N = p.N; h.K = p.K;
         h.pad = d->pad;                      // dgrad: KS-1-pad == pad for "same" convolutions
         h.flip = dgrad ? 1 : 0;
@@ -1460,6 +1478,7 @@ int run(const hoig_conv_desc *d, const float *a, const unsigned short *wh, const
         if (d->R == 3) return launch_halo3(h, ns, st);
         return launch_halo<5>(h, ns, st);
     }
+    if (a2 || c2) return HOIG_EUNSUPPORTED;
     // stride-2 3x3 pad-1 layers on the parity-phase halo kernel.  gather: Conv2d forward / ConvTranspose2d data gradient;
     // scatter: ConvTranspose2d forward / Conv2d data gradient
     static const bool no_s2 = getenv("HOIG_NO_HALO_S2") != nullptr;
@@ -1473,6 +1492,7 @@ int run(const hoig_conv_desc *d, const float *a, const unsigned short *wh, const
             h.A = a; h.Wh = wh; h.Wl = wl; h.bias = bias; h.C = c;
             h.Bn = d->B; h.Cg = g.Cg; h.N = p.N; h.K = p.K;
             h.pad = 1; h.flip = 0;
+            h.A2 = nullptr; h.cg1 = 0; h.C2 = nullptr; h.n1 = 0;
             h.act = p.act; h.slope = p.slope;
             h.f16 = p.f16; h.oscale = p.oscale;
             const bool gather = !g.gatherT;      // the operand is read at 2*o - 1 + tap (fine grid) -> gather mode
@@ -1535,6 +1555,22 @@ extern "C" int hoig_conv2d_bwd_data_packed(const hoig_conv_desc *d, const float 
     if (!d || !dy || !wt_hi || !dx) return HOIG_EINVAL;
     if (d->precision != HOIG_PREC_BF16X3 && d->precision != HOIG_PREC_BF16) return HOIG_EINVAL;
     return run(d, dy, wt_hi, wt_lo, nullptr, dx, true, (hipStream_t)stream);
+}
+
+// conv(cat[x1, x2]) and its data gradient [dx1 | dx2] without materialising the concatenation (3x3 stride-1 "same" only)
+extern "C" int hoig_conv2d_cat_fwd_packed(const hoig_conv_desc *d, const float *x1, int C1, const float *x2,
+                                          const uint16_t *w_hi, const uint16_t *w_lo, const float *bias, float *y,
+                                          hoig_stream_t stream) {
+    if (!d || !x1 || !x2 || !w_hi || !y) return HOIG_EINVAL;
+    if (d->precision != HOIG_PREC_BF16X3 && d->precision != HOIG_PREC_BF16) return HOIG_EINVAL;
+    return run(d, x1, w_hi, w_lo, bias, y, false, (hipStream_t)stream, x2, C1, nullptr, 0);
+}
+extern "C" int hoig_conv2d_cat_bwd_data_packed(const hoig_conv_desc *d, const float *dy, const uint16_t *wt_hi,
+                                               const uint16_t *wt_lo, float *dx1, int C1, float *dx2,
+                                               hoig_stream_t stream) {
+    if (!d || !dy || !wt_hi || !dx1 || !dx2) return HOIG_EINVAL;
+    if (d->precision != HOIG_PREC_BF16X3 && d->precision != HOIG_PREC_BF16) return HOIG_EINVAL;
+    return run(d, dy, wt_hi, wt_lo, nullptr, dx1, true, (hipStream_t)stream, nullptr, 0, dx2, C1);
 }
 
 // =====================================================================================================================
@@ -1794,7 +1830,8 @@ int launch_wgrad_bf16(WArgs a, int ns, hipStream_t st) {
 // Both operands want pixels along k, so both are read with ds_read_b64_tr_b16; the halo rows are 64 B apart (no pad):
 // the four rows a 32-lane half reads (256 B) cover all 64 banks once for any row offset.  dy rows are 192 B apart.
 struct WHaloArgs {
-    const float *DY, *X;
+    const float *DY, *X, *X2;  // X2 (nullable): the input is [X | X2] along channels, X holding the first ci1
+    int ci1;
     float *DW, *DB;            // DB (nullable): bias gradient = column sums of dy, taken from the dy tiles as they are staged
     int Bn, H, W, Co, Ci;     // H, W: output (= dy) size
     int Hin, Win, pad;         // input (= x) size and padding
@@ -1845,7 +1882,9 @@ __global__ __launch_bounds__(128 * KS) void wgrad_halo_bf16_kernel(const WHaloAr
                 bsum.x += v.x; bsum.y += v.y; bsum.z += v.z; bsum.w += v.w;
             }
         }
-        const float *xb = p.X + (size_t)b * p.Hin * p.Win * p.Ci + ci0;
+        const bool second = p.X2 != nullptr && ci0 >= p.ci1;
+        const int ldx = p.X2 ? (second ? p.Ci - p.ci1 : p.ci1) : p.Ci;
+        const float *xb = (second ? p.X2 : p.X) + (size_t)b * p.Hin * p.Win * ldx + (second ? ci0 - p.ci1 : ci0);
 #pragma unroll
         for (int i = 0; i < QSL; ++i) {
             const int idx = tid + NT * i;
@@ -1855,7 +1894,7 @@ __global__ __launch_bounds__(128 * KS) void wgrad_halo_bf16_kernel(const WHaloAr
                 const int hy = hp / HWID, hx = hp - hy * HWID;
                 const int gy = y0 - p.pad + hy, gx = x0 - p.pad + hx;
                 if (gy >= 0 && gy < p.Hin && gx >= 0 && gx < p.Win)
-                    v = *reinterpret_cast<const float4 *>(xb + ((size_t)gy * p.Win + gx) * p.Ci + c4 * 4);
+                    v = *reinterpret_cast<const float4 *>(xb + ((size_t)gy * p.Win + gx) * ldx + c4 * 4);
             }
             rq[i] = v;
         }
@@ -1959,9 +1998,9 @@ __global__ __launch_bounds__(128 * KS) void wgrad_halo_bf16_kernel(const WHaloAr
 }
 
 int launch_wgrad_halo(const hoig_conv_desc *d, const float *x, const float *dy, float *dw, float *dbias, int ns,
-                      hipStream_t st) {
+                      hipStream_t st, const float *x2 = nullptr, int ci1 = 0) {
     WHaloArgs a;
-    a.DY = dy; a.X = x; a.DW = dw; a.DB = dbias;
+    a.DY = dy; a.X = x; a.DW = dw; a.DB = dbias; a.X2 = x2; a.ci1 = ci1;
     a.Bn = d->B; a.H = d->Ho; a.W = d->Wo; a.Co = d->Co; a.Ci = d->Ci;
     a.Hin = d->Hi; a.Win = d->Wi; a.pad = d->pad;
     a.tiles_x = a.W / 32;
@@ -2031,4 +2070,13 @@ int hoig_conv_bf16_wgrad(const hoig_conv_desc *d, const float *x, const float *d
     if (hoig_conv_bf16_wgrad_fuses_bias(d)) return launch_wgrad_halo(d, x, dy, dw, dbias, ns, st);
     if (a.Co <= 64) return launch_wgrad_bf16<64>(a, ns, st);
     return launch_wgrad_bf16<128>(a, ns, st);
+}
+
+// weight gradient of conv(cat[x1, x2]) (3x3 stride-1 "same", bf16 halo kernel only)
+extern "C" int hoig_conv2d_cat_bwd_weight(const hoig_conv_desc *d, const float *x1, int C1, const float *x2, const float *dy,
+                                          float *dw, float *dbias, hoig_stream_t stream) {
+    if (!d || !x1 || !x2 || !dy || !dw) return HOIG_EINVAL;
+    if (!hoig_conv_bf16_wgrad_fuses_bias(d) || d->R != 3 || C1 % 32 || C1 <= 0 || C1 >= d->Ci) return HOIG_EUNSUPPORTED;
+    const int ns = d->precision == HOIG_PREC_BF16X3 ? 2 : 1;
+    return launch_wgrad_halo(d, x1, dy, dw, dbias, ns, (hipStream_t)stream, x2, C1);
 }

@@ -132,8 +132,12 @@ class Generator(ParamTree):
                 x = self._spade_block(x, seg, p + '.decoders.%d' % i, False)
             else:
                 x = self._conv_in_relu(x, p + '.decoders.%d' % i, transposed=True)
-            x = ops.cat_channels([enc[nd - 1 - i], x])
-            x = self._conv_in_relu(x, p + '.skippers.%d' % i)
+            # cat[skip, up] -> conv3x3 -> IN -> ReLU: the convolution reads the two tensors directly (ops.conv2d_cat2)
+            name = p + '.skippers.%d' % i
+            if self.P.get(name + '.0.bias') is None:
+                x = self._in(ops.conv2d_cat2(enc[nd - 1 - i], x, self.P[name + '.0.weight']), name + '.1', act=ACT_RELU)
+            else:
+                x = self._conv_in_relu(ops.cat_channels([enc[nd - 1 - i], x]), name)
         return x
 
     def _unet(self, x, seg, p):                                            # generator.py:261-283

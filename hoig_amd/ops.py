@@ -217,6 +217,70 @@ def conv2d(x, w, b=None, stride=1, pad=0, act=L.ACT_NONE, slope=0.0, prec=None, 
     return _Conv.apply(x, w, b, stride, pad, False, act, slope, None, precision if prec is None else prec, dead_bias)
 
 
+class _ConvCat2(Function):
+    """conv3x3(cat[x1, x2]) for the decoder's skip convolutions (generator.py:305-306) WITHOUT the concatenated tensor: the
+    halo kernels read their input halo from x1 or x2 by channel block (forward, weight gradient) and write the data
+    gradient as two tensors.  Only taken when every launch is on the 16-bit halo path (`conv2d_cat2` checks); otherwise the
+    caller concatenates."""
+
+    @staticmethod
+    def forward(ctx, x1, x2, w, prec):
+        B, H, W_, C1 = x1.shape
+        C2 = x2.shape[-1]
+        Co = w.shape[0]
+        assert tuple(w.stride()) == packed_strides(w.shape, False), 'conv weight is not in packed layout'
+        d = ConvDesc(B, H, W_, C1 + C2, H, W_, Co, 3, 3, 1, 1, 0, L.ACT_NONE, 0.0, prec)
+        y = torch.empty((B, H, W_, Co), dtype=x1.dtype, device=x1.device)
+        hi, lo = _packed_planes(w, False, False)
+        L.check(L.lib.hoig_conv2d_cat_fwd_packed(ctypes.byref(d), _p(x1), C1, _p(x2), _p(hi), _p(lo), None, _p(y), _st()),
+                'hoig_conv2d_cat_fwd_packed')
+        ctx.d = d
+        ctx.save_for_backward(x1, x2, w)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x1, x2, w = ctx.saved_tensors
+        d = ctx.d
+        C1 = x1.shape[-1]
+        dy = dy.contiguous()
+        dw, ret_w = _grad_target(w)
+        side = _wgrad_side_stream(dy.device) if not ret_w else None
+        if side is not None:
+            side.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(side):
+                call('hoig_conv2d_cat_bwd_weight', ctypes.byref(d), _p(x1), C1, _p(x2), _p(dy), _p(dw), None, _st())
+            for t in (x1, x2, dy):
+                t.record_stream(side)
+            _wgrad_hold(side, (x1, x2, dy))
+        else:
+            call('hoig_conv2d_cat_bwd_weight', ctypes.byref(d), _p(x1), C1, _p(x2), _p(dy), _p(dw), None, _st())
+        dx1, dx2 = torch.empty_like(x1), torch.empty_like(x2)
+        hi, lo = _packed_planes(w, False, True)
+        L.check(L.lib.hoig_conv2d_cat_bwd_data_packed(ctypes.byref(d), _p(dy), _p(hi), _p(lo), _p(dx1), C1, _p(dx2), _st()),
+                'hoig_conv2d_cat_bwd_data_packed')
+        return dx1, dx2, (dw if ret_w else None), None
+
+
+_CAT_CONV = os.environ.get('HOIG_CAT_CONV', '1') == '1'
+
+
+def conv2d_cat2(x1, x2, w, prec=None):
+    """conv2d(cat_channels([x1, x2]), w, None, 1, 1) (3x3, no bias); without the concatenation when the shapes are on the
+    16-bit halo path, else through cat_channels."""
+    prec = precision if prec is None else prec
+    B, H, W_, C1 = x1.shape
+    C2 = x2.shape[-1]
+    Co = w.shape[0]
+    ok = (_CAT_CONV and prec != L.PREC_F32 and x1.is_cuda and tuple(w.shape[2:]) == (3, 3) and w.shape[1] == C1 + C2 and
+          C1 % 64 == 0 and C2 % 64 == 0 and Co % 64 == 0 and W_ % 32 == 0 and H % 4 == 0 and
+          B * (H // 4) * (W_ // 32) * ((Co + 127) // 128) >= 160 and B * (H // 4) * (W_ // 32) * ((C1 + C2 + 127) // 128) >= 160 and
+          x1.shape[:3] == x2.shape[:3] and x1.is_contiguous() and x2.is_contiguous())
+    if not ok:
+        return conv2d(cat_channels([x1, x2]), w, None, 1, 1, prec=prec)
+    return _ConvCat2.apply(x1, x2, w, prec)
+
+
 def conv_transpose2d(x, w, stride=2, pad=1, output_padding=1, prec=None):
     """nn.ConvTranspose2d(k, stride, padding, output_padding, bias=False) (generator.py:118,201)."""
     B, Hi, Wi, _ = x.shape

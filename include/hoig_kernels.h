@@ -88,6 +88,17 @@ int hoig_conv2d_fwd_packed(const hoig_conv_desc *d, const float *x, const uint16
 int hoig_conv2d_bwd_data_packed(const hoig_conv_desc *d, const float *dy, const uint16_t *wt_hi, const uint16_t *wt_lo,
                                 float *dx, hoig_stream_t stream);
 
+/* conv(cat[x1, x2] along channels) without materialising the concatenation (the decoder's skip convolutions,
+ * generator.py:305-306): 3x3 stride-1 "same" convolutions on the fast path only -- every other shape returns
+ * HOIG_EUNSUPPORTED and the caller concatenates.  d->Ci = C1 + C2; x1 holds the first C1 (multiple of 32) channels.
+ * The data gradient writes [dx1 | dx2] (C1 a multiple of 64); the weight gradient accumulates like hoig_conv2d_bwd_weight. */
+int hoig_conv2d_cat_fwd_packed(const hoig_conv_desc *d, const float *x1, int C1, const float *x2, const uint16_t *w_hi,
+                               const uint16_t *w_lo, const float *bias /*nullable*/, float *y, hoig_stream_t stream);
+int hoig_conv2d_cat_bwd_data_packed(const hoig_conv_desc *d, const float *dy, const uint16_t *wt_hi, const uint16_t *wt_lo,
+                                    float *dx1, int C1, float *dx2, hoig_stream_t stream);
+int hoig_conv2d_cat_bwd_weight(const hoig_conv_desc *d, const float *x1, int C1, const float *x2, const float *dy, float *dw,
+                               float *dbias /*nullable*/, hoig_stream_t stream);
+
 /* ---- instance norm (generator.py:16-22,101-120,154-208; spade.py:13; discriminator.py:37,45 via
  *      base_network.py:31): per-(b,c) mean / biased variance over H*W, eps 1e-5, no running stats. ---- */
 /* stats: mean[b*C+c], rstd[b*C+c].  workspace: >= hoig_inorm_workspace_bytes(B,HW,C) bytes whose first 2^18 floats (the pool
