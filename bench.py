@@ -9,6 +9,7 @@ configs[2] is the same per-GPU batch on 8 GPUs).  Inputs are resident in HBM bef
 Prints ONE JSON line on rank 0.
 """
 import argparse
+import contextlib
 import json
 import os
 import sys
@@ -78,7 +79,8 @@ def gen_forward_latency(opt, batch, side, iters=10):
     model._name = 'Trainer'
     model.device = torch.device('cuda', torch.cuda.current_device())
     model._dexycb, model._world, model._side, model._g_ready = False, 1, None, None
-    model._init_create_networks(use_ddp=False)
+    with contextlib.redirect_stdout(sys.stderr):       # 'Network ... was created' banners: keep stdout to the JSON line
+        model._init_create_networks(use_ddp=False)
     model._init_prefetch_inputs()
     model.set_eval()
     model.set_input(synthetic.make_inputs(batch, side, seed=8))
@@ -203,7 +205,8 @@ def main():
 
     opt = opt_namespace(gen_name=args.gen_name, local_rank=local_rank, image_size=args.side, dataset_mode=args.dataset)
     torch.manual_seed(8)
-    model = ModelsFactory.get_by_name('trainer', opt, use_ddp=ddp)
+    with contextlib.redirect_stdout(sys.stderr):       # the reference-style construction banners go to stderr
+        model = ModelsFactory.get_by_name('trainer', opt, use_ddp=ddp)
     model.set_train()
     model.set_input(synthetic.make_inputs(args.batch, args.side, seed=8 + rank, dataset=args.dataset))
     torch.cuda.synchronize()
