@@ -93,8 +93,10 @@ def test_trainer_ddp_world2_matches_single_process():
         assert np.array_equal(w0[k], w1[k]) and np.array_equal(m0[k], m1[k]), k      # ranks stay bit-identical
         assert np.linalg.norm(ms[k]) > 0
         rel = np.linalg.norm(m0[k] - ms[k]) / np.linalg.norm(ms[k])                  # averaged gradient == combined-batch gradient
+        print('ddp vs single  %-44s gradient rel-L2 %.2e' % (k, rel))
         assert rel < 5e-2, (k, rel)
         # and the weights moved the same way for the bulk of the elements
         agree = np.mean(np.sign(w0[k] - b0[k]) == np.sign(ws[k] - bs[k]))
+        print('                %-44s update sign agreement %.3f' % (k, agree))
         assert agree > 0.9, (k, agree)
     assert s0 == s1
