@@ -941,8 +941,22 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_halo3_bf16_kernel(const Hal
             __builtin_amdgcn_sched_barrier(0);
         }
     };
+
     // (staging the weight tiles by LDS-DMA -- global_load_lds, the pre-swizzled plane blocks are LDS images -- measured
     // ~9 % SLOWER here than the register-staged ds_write_b128 path below)
+#ifdef HOIG_STAMP
+    unsigned long long c_issue = 0, c_comp = 0, c_b1 = 0, c_st = 0, c_b2 = 0;
+    const unsigned long long t_begin = clock64();
+    const unsigned long long rt_begin = __builtin_amdgcn_s_memrealtime();
+#if HOIG_STAMP == 2                /* clock check: only the two stamps around the loop execute */
+#define STAMP(v)
+#else
+#define STAMP(v) { const unsigned long long t_ = clock64(); v += t_ - t_prev; t_prev = t_; }
+#endif
+    unsigned long long t_prev = t_begin;
+#else
+#define STAMP(v)
+#endif
     halo_load(0);
     halo_store(0);
     load_b(0);
@@ -959,14 +973,26 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_halo3_bf16_kernel(const Hal
             if (more) store_b(bbuf ^ 1);                  // weights of step+1 (registers loaded during the previous step)
             if (step + 2 < T) load_b(step + 2);
             if (boundary) halo_load(cb + 1);
+            STAMP(c_issue)
             compute(r, 0, bbuf);
+            STAMP(c_comp)
             if (boundary) {
                 __syncthreads();                          // every wave is done with the halo
+                STAMP(c_b1)
                 halo_store(0);
+                STAMP(c_st)
             }
             __syncthreads();
+            STAMP(c_b2)
             bbuf ^= 1;
         }
+#ifdef HOIG_STAMP
+        if (p.dbg && lane == 0) {
+            unsigned long long *d = p.dbg + ((size_t)blockIdx.x * (NT / 64) + wave) * 8;
+            d[0] = c_issue; d[1] = c_comp; d[2] = c_b1; d[3] = c_st; d[4] = c_b2; d[5] = clock64() - t_begin;
+            d[6] = __builtin_amdgcn_s_memrealtime() - rt_begin;
+        }
+#endif
     } else if (DB) {
         if (T > 1) load_b(1);
         __syncthreads();
@@ -987,14 +1013,6 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_halo3_bf16_kernel(const Hal
         }
     } else {
         __syncthreads();
-#ifdef HOIG_STAMP
-        unsigned long long c_issue = 0, c_comp = 0, c_b1 = 0, c_st = 0, c_b2 = 0;
-        const unsigned long long t_begin = clock64();
-#define STAMP(v) { const unsigned long long t_ = clock64(); v += t_ - t_prev; t_prev = t_; }
-        unsigned long long t_prev = t_begin;
-#else
-#define STAMP(v)
-#endif
 #pragma unroll 1
         for (int step = 0; step < T; ++step) {
             const int cb = step / KS, r = step - cb * KS;
@@ -1019,7 +1037,7 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_halo3_bf16_kernel(const Hal
         if (p.dbg && lane == 0) {
             unsigned long long *d = p.dbg + ((size_t)blockIdx.x * (NT / 64) + wave) * 8;
             d[0] = c_issue; d[1] = c_comp; d[2] = c_b1; d[3] = c_st; d[4] = c_b2; d[5] = clock64() - t_begin;
-            d[6] = __builtin_amdgcn_s_memrealtime();
+            d[6] = __builtin_amdgcn_s_memrealtime() - rt_begin;
         }
 #endif
     }

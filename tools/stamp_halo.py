@@ -25,6 +25,9 @@ assert lib.hoig_pack_conv_weight_bf16(vp(w.data_ptr()), C, 9, C, 0, vp(hi.data_p
 d = ConvDesc(B, H, H, C, H, H, C, 3, 3, 1, 1, 0, ACT_NONE, 0.0, PREC_BF16X3)
 nblk = B * (H // 4) * (H // 32) * (C // 128)
 waves = 4 if nblk >= 384 else 8
+tall = nblk // 2 >= 256                    # launch_halo3: 8 x 32-pixel tiles on eight waves, weights double-buffered
+if tall:
+    nblk, waves = nblk // 2, 8
 dbg = torch.zeros(nblk * waves * 8, dtype=torch.int64, device='cuda')
 
 
@@ -51,4 +54,4 @@ for i, n in enumerate(names):
     print('  %-9s median %8.0f cycles  %5.1f %% of the loop' % (n, np.median(v), 100 * np.median(v / tot)))
 steps = (C // 32) * 3
 print('  per step: %.0f cycles total, %.0f compute (MFMA-only floor %d)' % (np.median(tot) / steps, np.median(t[:, 1]) / steps,
-                                                                         3 * 2 * (12 if waves == 4 else 6) * 32))
+                                                                         3 * 2 * (12 if (waves == 4 or tall) else 6) * 32))
