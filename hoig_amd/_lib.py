@@ -96,6 +96,9 @@ _SIGS = {
     'hoig_sum': [_vp, _vp, _i64, _vp],
     'hoig_adam_step': [_vp, _vp, _vp, _vp, _i64, _d, _d, _d, _d, _i, _f, _vp],
     'hoig_tensor2im_u8': [_vp, _vp] + [_i] * 6 + [_vp],
+    'hoig_prep_texture': [_vp] * 9,
+    'hoig_prep_lookup': [_vp] * 5 + [_i] + [_vp] * 8,
+    'hoig_prep_assemble': [_i] + [_vp] * 23,
 }
 
 

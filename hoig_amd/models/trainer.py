@@ -28,6 +28,7 @@ from .networks.vgg19 import Vgg19, VGGLoss
 
 PREPARED_KEYS = ['input_G_bg', 'input_G_src_obj', 'input_G_tsf_obj', 'input_G_src_hand', 'input_G_tsf_hand', 'T',
                  'real_src', 'real_tsf', 'bg_mask', 'hand_mask']
+RASTER_KEYS = ['src_img', 'ref_img', 'src_faces', 'src_fim', 'src_wim', 'ref_fim', 'ref_wim', 'tables']
 
 
 def _labelcolormap(n):
@@ -134,9 +135,27 @@ class Trainer(BaseModel):
     def set_input(self, input):
         if all(k in input for k in PREPARED_KEYS):
             return self.set_prepared_input(input)
+        if all(k in input for k in RASTER_KEYS):
+            return self.set_rasterised_input(input)
         raise NotImplementedError(
             'Trainer.set_input: raw dataloader batches need HandRecoveryFlow (MANO + neural renderer, '
             'trainer.py:324-362), which is outside the accelerated path; pass the prepared tensors %s' % PREPARED_KEYS)
+
+    def set_rasterised_input(self, inp):
+        """Raw images + the rasteriser's outputs (``render_fim_wim``: face vertices, face index / weight maps) and the
+        per-sample object tables: runs the tensor stage of HandRecoveryFlow.forward (trainer.py:46-145) on the device
+        (hoig_amd.input_prep) and stages the result as Trainer.set_input does (trainer.py:346-362).  `tables`: one
+        input_prep.ObjectTables (or dict of the object's MANORenderer buffers) per sample; `maskA` / `maskB`: the HOv3
+        arm masks (trainer.py:329-337)."""
+        from .. import input_prep as IP
+        dev = self.device
+        with torch.no_grad():
+            t = {k: (v.to(dev, non_blocking=True) if torch.is_tensor(v) else v) for k, v in inp.items()}
+            tabs = [tb if isinstance(tb, IP.ObjectTables) else IP.ObjectTables(tb, dev) for tb in t['tables']]
+            out = IP.prepare_inputs(t['src_img'], t['ref_img'], t['src_faces'], t['src_fim'], t['src_wim'], t['ref_fim'],
+                                    t['ref_wim'], tabs, bg_both=bool(getattr(self._opt, 'bg_both', False)))
+            return self.set_prepared_input(IP.to_prepared(out, t['src_img'].float(), t['ref_img'].float(),
+                                                          t.get('maskA'), t.get('maskB')))
 
     def set_prepared_input(self, inp):
         """Stage the a2 attributes (what trainer.py:346-362 assigns).  NCHW tensors (T: B,S,S,2), CPU or device."""

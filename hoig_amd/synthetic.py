@@ -96,3 +96,121 @@ def make_inputs(batch, side, seed=8, dataset='hov3'):
     if not hov3:
         del res['armask_src'], res['armask_tsf']
     return res
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# Synthetic RASTERISER outputs + per-object tables: the input surface of hoig_amd.input_prep (the stage of
+# HandRecoveryFlow.forward, trainer.py:46-145, that follows render_fim_wim).  The reference hard-wires 256 x 256 images and a
+# 256 x 640 texture atlas (nmr.py:975,1040-1051,1070), so there is one size.  Scene: 8x8-pixel cells; the cells of a hand disk
+# carry hand faces (ids < 1538), the cells of an object box object faces (ids >= 1538); a face present in the SOURCE view
+# is a triangle over its source cell, so the visibility test of get_texture_backward_warp (nmr.py:1006-1044) has both outcomes.
+N_HAND_FACES = 1538
+PREP_SIDE, TEX_W = 256, 640
+
+
+def _cells(g, kind):
+    """8x8-pixel cell masks (32 x 32) of a hand disk and an object box."""
+    yy, xx = np.mgrid[0:32, 0:32]
+    cy, cx, r = g.uniform(10, 22), g.uniform(10, 22), g.uniform(5, 8)
+    hand = (yy - cy) ** 2 + (xx - cx) ** 2 <= r * r
+    y0, x0 = int(g.integers(3, 18)), int(g.integers(3, 18))
+    obj = np.zeros((32, 32), bool)
+    obj[y0:y0 + int(g.integers(6, 11)), x0:x0 + int(g.integers(6, 11))] = True
+    obj &= ~hand
+    return hand, obj
+
+
+def make_object_tables(obj_id, seed=8):
+    """Per-object tables with the shapes / value conventions of MANORenderer's buffers (nmr.py:295-406)."""
+    g = _rng(seed, 1000 + obj_id)
+    n_obj = int(g.integers(200, 500))
+    F = N_HAND_FACES + n_obj
+    map_fn = np.zeros((F + 1, 3), np.float32)                  # (u, v, background flag); last row = background
+    map_fn[:N_HAND_FACES, :2] = g.uniform(0.05, 0.95, size=(N_HAND_FACES, 2))
+    map_fn[N_HAND_FACES:F, 0] = 1.5 * (obj_id + 1) + g.uniform(0.05, 0.95, size=n_obj)      # nmr.py:325
+    map_fn[N_HAND_FACES:F, 1] = g.uniform(0.05, 0.95, size=n_obj)
+    map_fn[F] = (0.0, 0.0, 1.0)
+    sem = np.zeros((F + 1, 1), np.float32)                     # nmr.py:303-313
+    sem[:N_HAND_FACES, 0] = g.integers(0, 7, size=N_HAND_FACES)
+    sem[N_HAND_FACES:F, 0] = obj_id + 7
+    # texture atlas: hand charts in columns 0..255, nothing in 256..383, object charts in 384..639 (nmr.py:393-394)
+    fim_uv = -np.ones((PREP_SIDE, TEX_W), np.int32)
+    uv_coord = g.uniform(-1.0, 1.0, size=(F, 3, 2)).astype(np.float32)        # faces absent from the atlas: anywhere
+    cells = [(cy, cx) for cy in range(32) for cx in range(32)] + [(cy, cx) for cy in range(32) for cx in range(48, 80)]
+    hand_ids = g.permutation(N_HAND_FACES)[:900]
+    obj_ids = N_HAND_FACES + g.permutation(n_obj)[:min(n_obj, 700)]
+    order = g.permutation(1024)
+    for n, f in enumerate(hand_ids):
+        cy, cx = cells[order[n]]
+        fim_uv[cy * 8:cy * 8 + 8, cx * 8:cx * 8 + 8] = f
+    order = g.permutation(1024)
+    for n, f in enumerate(obj_ids):
+        cy, cx = cells[1024 + order[n]]
+        fim_uv[cy * 8:cy * 8 + 8, cx * 8:cx * 8 + 8] = f
+    for f in np.concatenate([hand_ids, obj_ids]):
+        ys, xs = np.nonzero(fim_uv == f)
+        y0, x0 = ys.min(), xs.min()
+        px = np.array([[x0, y0], [x0 + 7, y0], [x0, y0 + 7]], np.float32)
+        uv_coord[f, :, 0] = px[:, 0] / (TEX_W - 1) * 2 - 1                     # align_corners=True texel centres
+        uv_coord[f, :, 1] = px[:, 1] / (PREP_SIDE - 1) * 2 - 1
+    wim_uv = g.uniform(0.05, 1.0, size=(PREP_SIDE, TEX_W, 3)).astype(np.float32)
+    wim_uv /= wim_uv.sum(-1, keepdims=True)
+    wim_uv[fim_uv < 0] = 0.0
+    tex = g.uniform(-1.0, 1.0, size=(PREP_SIDE, PREP_SIDE, 3)).astype(np.float32)
+    t = torch.from_numpy
+    return dict(n_faces=F, map_fn=t(map_fn), sem_full=t(sem), fim_uv=t(fim_uv)[None], wim_uv=t(wim_uv)[None],
+                faces_uv_coord=t(uv_coord)[None], obj_tex_img=t(tex))
+
+
+def make_raster(batch, seed=8):
+    """Seeded synthetic outputs of `render_fim_wim` for `batch` source / reference views (+ the two images, the object id of
+    each sample).  CPU tensors: faces (B, Fmax, 3, 3) fp32 [only the first n_faces rows of a sample are meaningful], fim
+    (B,256,256) int32 with -1 = no face, wim (B,256,256,3) fp32."""
+    S = PREP_SIDE
+    objs = [int(_rng(seed, 2000 + b).integers(0, N_OBJECTS)) for b in range(batch)]
+    tables = {k: make_object_tables(k, seed) for k in sorted(set(objs))}
+    fmax = max(tb['n_faces'] for tb in tables.values())
+    out = dict(src_img=[], ref_img=[], src_faces=[], src_fim=[], src_wim=[], ref_fim=[], ref_wim=[])
+    for b in range(batch):
+        g = _rng(seed, 3000 + b)
+        F = tables[objs[b]]['n_faces']
+        faces = np.zeros((fmax, 3, 3), np.float32)
+        faces[:F, :, :2] = g.uniform(-1.1, 1.1, size=(F, 1, 2)) + g.uniform(-0.03, 0.03, size=(F, 3, 2))
+        faces[:F, :, 2] = g.uniform(1.0, 3.0, size=(F, 3))
+        views = {}
+        for name in ('src', 'ref'):
+            hand, obj = _cells(g, name)
+            fim = -np.ones((S, S), np.int32)
+            hid = g.permutation(N_HAND_FACES)
+            oid = N_HAND_FACES + g.permutation(F - N_HAND_FACES)
+            for n, (cy, cx) in enumerate(zip(*np.nonzero(hand))):
+                fim[cy * 8:cy * 8 + 8, cx * 8:cx * 8 + 8] = hid[n]
+            for n, (cy, cx) in enumerate(zip(*np.nonzero(obj))):
+                fim[cy * 8:cy * 8 + 8, cx * 8:cx * 8 + 8] = oid[n % len(oid)]
+            # ragged silhouette: drop random pixels at the cell borders so that the 3x3 erosions see 1-pixel structures
+            drop = (g.uniform(size=(S, S)) < 0.02)
+            fim[drop] = -1
+            wim = g.uniform(0.05, 1.0, size=(S, S, 3)).astype(np.float32)
+            wim /= wim.sum(-1, keepdims=True)
+            wim[fim < 0] = 0.0
+            views[name] = (fim, wim)
+        # faces seen in the source view: a triangle over their source cell (image coords in the align_corners=True convention
+        # of nmr.py:1012; y is stored NEGATED, trainer.py:69 flips it back)
+        sfim = views['src'][0]
+        for f in np.unique(sfim[sfim >= 0]):
+            ys, xs = np.nonzero(sfim == f)
+            y0, x0 = ys.min(), xs.min()
+            px = np.array([[x0 + 1, y0 + 1], [x0 + 6, y0 + 1], [x0 + 1, y0 + 6]], np.float32)
+            faces[f, :, 0] = px[:, 0] / (S - 1) * 2 - 1
+            faces[f, :, 1] = -(px[:, 1] / (S - 1) * 2 - 1)
+        out['src_img'].append(g.uniform(-1.0, 1.0, size=(3, S, S)).astype(np.float32))
+        out['ref_img'].append(g.uniform(-1.0, 1.0, size=(3, S, S)).astype(np.float32))
+        out['src_faces'].append(faces)
+        out['src_fim'].append(views['src'][0])
+        out['src_wim'].append(views['src'][1])
+        out['ref_fim'].append(views['ref'][0])
+        out['ref_wim'].append(views['ref'][1])
+    res = {k: torch.from_numpy(np.stack(v)) for k, v in out.items()}
+    res['obj_ids'] = objs
+    res['tables'] = tables
+    return res

@@ -235,6 +235,35 @@ int hoig_adam_step(float *param, const float *grad, float *exp_avg, float *exp_a
 int hoig_tensor2im_u8(const float *x, uint8_t *out, int B, int H, int W, int C, int nrow, int unnormalize,
                       hoig_stream_t stream);
 
+/* ---- input preparation AFTER the rasteriser (tensor stage): HandRecoveryFlow.forward
+ *      (models/trainer.py:46-145) + the MANORenderer helpers it calls (utils/nmr.py:567-595, 874-968, 973-1100) +
+ *      util.morph (utils/util.py:142-158).  Planar NCHW fp32 (the reference's layout at this boundary), int32 face index
+ *      maps (-1 = no face; ids < 1538 are hand faces), 256 x 256 images and a 256 x 640 texture atlas as in the reference.
+ *      Replaces, per sample: get_texture_backward_warp -> hoig_prep_texture; encode_fim / encode_sem /
+ *      sample_from_texture_dense + F.grid_sample(align_corners=True) / cal_bc_transform -> hoig_prep_lookup (once per view);
+ *      and, per batch, trainer.py:73,79,82,110-141 -> hoig_prep_assemble. ---- */
+/* src_img [3,256,256]; src_faces [F,3,3] (x, y, z of the projected face vertices as render_fim_wim returns them: y is
+ * negated here, trainer.py:67-68); fim_uv [256,640], wim_uv [256,640,3], obj_tex_img [256,256,3] (HWC): the object's
+ * buffers; occ_ws: 256*640 bytes of workspace; tex [3,256,640] out */
+int hoig_prep_texture(const float *src_img, const float *src_faces, const int32_t *src_fim, const int32_t *fim_uv,
+                      const float *wim_uv, const float *obj_tex_img, unsigned char *occ_ws, float *tex,
+                      hoig_stream_t stream);
+/* one view of one sample: fim [256,256], wim [256,256,3]; map_fn [(F+1),3], sem_full [F+1], faces_uv_coord [F,3,2] with
+ * F = n_faces (row F = background, what index -1 addresses in the reference); tex from hoig_prep_texture.
+ * out: cond [3,256,256], seg [256,256] (label), hand_region [256,256] (1 - hand faces, BEFORE the erosion),
+ * rend [3,256,256]; T [256,256,2] (nullable; needs src_faces): cal_bc_transform of THIS view's fim / wim */
+int hoig_prep_lookup(const int32_t *fim, const float *wim, const float *map_fn, const float *sem_full,
+                     const float *faces_uv_coord, int n_faces, const float *tex, const float *src_faces, float *cond,
+                     float *seg, float *hand_region, float *rend, float *T, hoig_stream_t stream);
+/* batch: images [B,3,256,256]; the hoig_prep_lookup outputs of both views stacked over the batch; T_raw [B,256,256,2].
+ * out: src_bg [B,4,..], tsf_bg (nullable: bg_both) [B,4,..], src_obj / tsf_obj [B,15,..], src_hand / ref_hand [B,6,..],
+ * T_hand [B,256,256,2], the four crop masks [B,1,..] (bg src, bg ref, hand src, hand ref) */
+int hoig_prep_assemble(int B, const float *src_img, const float *ref_img, const float *cond_s, const float *cond_r,
+                       const float *seg_s, const float *seg_r, const float *hr_s, const float *hr_r, const float *rend_s,
+                       const float *rend_r, const float *T_raw, float *src_bg, float *tsf_bg, float *src_obj,
+                       float *tsf_obj, float *src_hand, float *ref_hand, float *T_hand, float *smb, float *rmb, float *smh,
+                       float *rmh, hoig_stream_t stream);
+
 const char *hoig_version(void);
 
 #ifdef __cplusplus

@@ -169,3 +169,44 @@ def build_reference_trainer(opt, copy='hov3', attn_ops='oracle'):
                   '_loss_g_mask_smooth', '_d_real', '_d_fake']:
             setattr(t, n, torch.zeros(1))
     return t
+
+
+def reference_input_prep(raster, bg_both=False, copy='hov3'):
+    """Runs the reference's OWN ``HandRecoveryFlow.forward`` (models/trainer.py:46-145) and the MANORenderer methods it
+    calls (utils/nmr.py:567-595,874-968,973-1100) on CPU, with ONLY the rasteriser call ``render_fim_wim`` (neural_renderer
+    CUDA, needs MANO + YCB assets) replaced by the seeded synthetic rasteriser outputs of
+    ``hoig_amd.synthetic.make_raster`` and the per-object buffers by its synthetic tables.  Returns the reference's return
+    tuple (12 entries, the last one None)."""
+    import torch
+    install(copy)
+    trainer_mod = importlib.import_module('models.trainer')
+    nmr_mod = importlib.import_module('utils.nmr')
+    names = trainer_mod.OBJNAMES
+
+    render = nmr_mod.MANORenderer.__new__(nmr_mod.MANORenderer)
+    torch.nn.Module.__init__(render)
+    render.image_size = 256
+    for k, tb in raster['tables'].items():
+        n = names[k]
+        render.register_buffer('faces_' + n, torch.arange(tb['n_faces'] * 3, dtype=torch.int32).reshape(-1, 3) % 64)
+        for key in ('map_fn', 'sem_full', 'fim_uv', 'wim_uv', 'faces_uv_coord', 'obj_tex_img'):
+            render.register_buffer('%s_%s' % (key, n), tb[key].clone())
+    calls = []
+
+    def render_fim_wim(cam, vertices, obj_name, faces=None):           # src view, then ref view, per sample (trainer.py:66,74)
+        i, which = len(calls) // 2, 'src' if len(calls) % 2 == 0 else 'ref'
+        calls.append(which)
+        nf = raster['tables'][raster['obj_ids'][i]]['n_faces']
+        return (raster['src_faces'][i:i + 1, :nf].clone(), raster[which + '_fim'][i:i + 1].clone(),
+                raster[which + '_wim'][i:i + 1].clone())
+    render.render_fim_wim = render_fim_wim
+
+    bs = raster['src_img'].shape[0]
+    info = dict(objName=torch.tensor(raster['obj_ids'])[:, None], cam=torch.zeros(bs, 3), verts=torch.zeros(bs, 64, 3))
+    hdr = trainer_mod.HandRecoveryFlow.__new__(trainer_mod.HandRecoveryFlow)
+    torch.nn.Module.__init__(hdr)
+    hdr._opt = types.SimpleNamespace(bg_both=bg_both)
+    hdr._hmr = types.SimpleNamespace(get_details=lambda mano: info)
+    hdr._render = render
+    with torch.no_grad():
+        return hdr.forward(raster['src_img'].clone(), raster['ref_img'].clone(), None, None)

@@ -1,0 +1,134 @@
+"""GPU: hoig_amd.input_prep (HIP, through the C ABI) against the oracle restatement of HandRecoveryFlow.forward
+(trainer.py:46-145) and against the reference-made fixture.  Every discrete output -- the four crop masks, the eroded
+background mask, one-hot segments, the -2 flow sentinel, which atlas texels are painted -- must match EXACTLY; the
+interpolated values (two bilinear samplers, 3-tap barycentric sums) within 2e-6 absolute on data in [-2, 10]."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from hoig_amd import synthetic
+from oracle import input_prep_oracle as P
+
+pytestmark = pytest.mark.gpu
+NAMES = ['input_G_src_bg', 'input_G_tsf_bg', 'input_G_src_obj', 'input_G_tsf_obj', 'input_G_src_hand', 'input_G_ref_hand',
+         'T_hand', 'src_crop_mask_bg', 'ref_crop_mask_bg', 'src_crop_mask_hand', 'ref_crop_mask_hand']
+ATOL = 2e-6
+
+
+def run_hip(r, bg_both):
+    from hoig_amd import input_prep as IP
+    dev = torch.device('cuda', 0)
+    tabs = {k: IP.ObjectTables(tb, dev) for k, tb in r['tables'].items()}
+    c = lambda k: r[k].to(dev)
+    return IP.prepare_inputs(c('src_img'), c('ref_img'), c('src_faces'), c('src_fim'), c('src_wim'), c('ref_fim'),
+                             c('ref_wim'), [tabs[k] for k in r['obj_ids']], bg_both)
+
+
+def run_oracle(r, bg_both):
+    tabs = [r['tables'][k] for k in r['obj_ids']]
+    return P.prepare_inputs(r['src_img'], r['ref_img'], r['src_faces'], r['src_fim'], r['src_wim'], r['ref_fim'],
+                            r['ref_wim'], tabs, bg_both)
+
+
+def compare(hip, ora):
+    for name, a, b in zip(NAMES, hip, ora):
+        assert (a is None) == (b is None), name
+        if a is None:
+            continue
+        a = a.cpu()
+        assert a.shape == b.shape, name
+        if 'mask' in name:
+            assert torch.equal(a, b), name
+        else:
+            bad = ((a - b).abs() > ATOL)
+            assert not bad.any(), '%s: %d of %d values differ, max %g' % (name, int(bad.sum()), a.numel(),
+                                                                        float((a - b).abs().max()))
+    # discrete channels inside the float tensors: exact
+    assert torch.equal(hip[0][:, 3].cpu(), ora[0][:, 3])                          # 15x15-eroded background mask
+    for i in (2, 3):
+        assert torch.equal(hip[i][:, 5:].cpu(), ora[i][:, 5:])                    # flag + one-hot object segments
+    assert torch.equal((hip[6] == -2).cpu(), ora[6] == -2)                        # the flow sentinel
+
+
+@pytest.mark.parametrize('seed,batch,bg_both', [(8, 2, False), (8, 2, True), (11, 3, False), (13, 8, False)])
+def test_hip_matches_oracle(seed, batch, bg_both):
+    r = synthetic.make_raster(batch, seed)
+    compare(run_hip(r, bg_both), run_oracle(r, bg_both))
+
+
+def test_hip_matches_reference_fixture():
+    g = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), 'golden', 'input_prep_256.npz'))
+    r = synthetic.make_raster(int(g['batch']), int(g['seed']))
+    for bg_both in (False, True):
+        out = run_hip(r, bg_both)
+        for name, v in zip(NAMES, out):
+            if v is None:
+                continue
+            a = v.cpu().numpy()
+            sub = a[:, 1::4, 2::4, :] if name == 'T_hand' else a[:, :, 1::4, 2::4]
+            want = g['bg_both%d/%s/sub' % (bg_both, name)]
+            if 'mask' in name:
+                np.testing.assert_array_equal(sub, want, err_msg=name)
+            else:
+                np.testing.assert_allclose(sub, want, rtol=0, atol=ATOL, err_msg=name)
+            np.testing.assert_allclose(a.astype(np.float64).sum(), float(g['bg_both%d/%s/sum' % (bg_both, name)]),
+                                       rtol=1e-6, atol=1e-2)
+
+
+def test_edge_cases_empty_and_full():
+    r = synthetic.make_raster(1, 8)
+    r['src_fim'] = -torch.ones_like(r['src_fim'])
+    r['ref_fim'] = -torch.ones_like(r['ref_fim'])
+    r['src_wim'] = torch.zeros_like(r['src_wim'])
+    r['ref_wim'] = torch.zeros_like(r['ref_wim'])
+    out = run_hip(r, True)
+    compare(out, run_oracle(r, True))
+    assert (out[6] == -2).all() and (out[7] == 1).all() and (out[9] == 1).all()
+    r['src_fim'] = torch.zeros_like(r['src_fim'])
+    r['ref_fim'] = torch.zeros_like(r['ref_fim'])
+    r['src_wim'] = torch.full_like(r['src_wim'], 1.0 / 3)
+    r['ref_wim'] = torch.full_like(r['ref_wim'], 1.0 / 3)
+    out = run_hip(r, False)
+    compare(out, run_oracle(r, False))
+    assert (out[9] == 0).all() and (out[6] != -2).all()
+
+
+def test_rejects_cpu_tensors_and_wrong_size():
+    from hoig_amd import input_prep as IP
+    r = synthetic.make_raster(1, 8)
+    tabs = [IP.ObjectTables(r['tables'][r['obj_ids'][0]], torch.device('cuda', 0))]
+    with pytest.raises(NotImplementedError):
+        IP.prepare_inputs(r['src_img'], r['ref_img'], r['src_faces'], r['src_fim'], r['src_wim'], r['ref_fim'], r['ref_wim'],
+                          tabs)
+    with pytest.raises(ValueError):
+        IP.prepare_inputs(r['src_img'][:, :, :128, :128].cuda(), r['ref_img'].cuda(), r['src_faces'].cuda(),
+                          r['src_fim'].cuda(), r['src_wim'].cuda(), r['ref_fim'].cuda(), r['ref_wim'].cuda(), tabs)
+
+
+def test_trainer_accepts_rasterised_batches():
+    """Trainer.set_input on a raw batch (images + rasteriser outputs + tables): stages what the oracle's tuple implies
+    (trainer.py:346-362) and one optimisation step runs on it."""
+    from hoig_amd import ops
+    from hoig_amd.models import ModelsFactory
+    from common import opt_namespace
+    ops.set_precision('bf16x3')
+    r = synthetic.make_raster(1, 9)
+    opt = opt_namespace(gen_name='generator_spade_attn', local_rank=0, image_size=256)
+    torch.manual_seed(3)
+    model = ModelsFactory.get_by_name('trainer', opt, use_ddp=False)
+    model.set_train()
+    arm = torch.zeros(1, 1, 256, 256)
+    batch = dict(src_img=r['src_img'], ref_img=r['ref_img'], src_faces=r['src_faces'], src_fim=r['src_fim'],
+                 src_wim=r['src_wim'], ref_fim=r['ref_fim'], ref_wim=r['ref_wim'],
+                 tables=[r['tables'][k] for k in r['obj_ids']], maskA=arm, maskB=arm)
+    model.set_input(batch)
+    want = P.to_prepared(run_oracle(r, False), r['src_img'], r['ref_img'], arm, arm)
+    assert torch.equal(model._bg_mask.cpu(), want['bg_mask']) and torch.equal(model._hand_mask.cpu(), want['hand_mask'])
+    assert (model._input_G_src_obj.cpu() - want['input_G_src_obj']).abs().max() <= ATOL
+    assert (model._input_G_tsf_hand.cpu() - want['input_G_tsf_hand']).abs().max() <= ATOL
+    assert (model._T.cpu() - want['T']).abs().max() <= ATOL
+    model.optimize_parameters()
+    errs = model.get_current_errors()
+    assert all(np.isfinite(v) for v in errs.values()), errs
