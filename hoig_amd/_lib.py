@@ -99,6 +99,7 @@ _SIGS = {
     'hoig_prep_texture': [_vp] * 9,
     'hoig_prep_lookup': [_vp] * 5 + [_i] + [_vp] * 8,
     'hoig_prep_assemble': [_i] + [_vp] * 23,
+    'hoig_rasterize_fim_wim': [_vp, _i, _i, _i, _f, _f, _vp, _vp, _vp, _vp],
 }
 
 
@@ -114,6 +115,8 @@ def _load():
         fn.restype = ctypes.c_int
     lib.hoig_inorm_workspace_bytes.argtypes = [_i, _i, _i]
     lib.hoig_inorm_workspace_bytes.restype = ctypes.c_int64
+    lib.hoig_rasterize_workspace_bytes.restype = ctypes.c_size_t
+    lib.hoig_rasterize_workspace_bytes.argtypes = [ctypes.c_int, ctypes.c_int]
     lib.hoig_version.argtypes = []
     lib.hoig_version.restype = ctypes.c_char_p
     return lib

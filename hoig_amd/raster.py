@@ -1,0 +1,59 @@
+"""Face-index / weight-map rasteriser on the device: what ``MANORenderer.render_fim_wim`` (utils/nmr.py:496-513)
+gets from ``nr.rasterize_face_index_map_and_weight_map(faces, image_size, False)`` -- neural_renderer's CUDA kernels
+(thirdparty/neural_renderer/neural_renderer/cuda/rasterize_cuda_kernel.cu:40-186) plus the wrapper's fill and vertical flip
+(neural_renderer/rasterize.py:50-52,334-338) -- as one tile-binned HIP launch pair (hoig_amd/csrc/raster.hip).
+``render_fim_wim`` mirrors the reference method: projection (nmr.py:109-140), y flip, look-at translation
+(neural_renderer/look_at.py with the renderer's fixed eye) and ``vertices_to_faces`` are a handful of batched torch ops
+(plumbing: 3 x 3 matrix products over ~2 k vertices); the rasterisation is the kernel."""
+import math
+
+import torch
+
+from . import _lib as L
+
+DEFAULT_NEAR, DEFAULT_FAR = 0.1, 100.0        # neural_renderer/rasterize.py:10-11 (the call at nmr.py:512 passes neither)
+
+
+def rasterize_fim_wim(faces, image_size=256, near=DEFAULT_NEAR, far=DEFAULT_FAR):
+    """faces (B,F,3,3) fp32 on the HIP device -> (fim (B,S,S) int32 with -1 = no face, wim (B,S,S,3))."""
+    if not faces.is_cuda:
+        raise NotImplementedError('hoig_amd.raster runs on the HIP device only (no CPU path)')
+    if faces.dim() != 4 or tuple(faces.shape[2:]) != (3, 3):
+        raise ValueError('faces must be (B,F,3,3)')
+    faces = faces.float().contiguous()
+    B, F = int(faces.shape[0]), int(faces.shape[1])
+    S = int(image_size)
+    fim = torch.empty(B, S, S, dtype=torch.int32, device=faces.device)
+    wim = torch.empty(B, S, S, 3, dtype=torch.float32, device=faces.device)
+    ws = torch.empty(int(L.lib.hoig_rasterize_workspace_bytes(B, F)), dtype=torch.uint8, device=faces.device)
+    L.call('hoig_rasterize_fim_wim', faces.data_ptr(), B, F, S, float(near), float(far), fim.data_ptr(), wim.data_ptr(),
+           ws.data_ptr(), torch.cuda.current_stream().cuda_stream)
+    return fim, wim
+
+
+def project(vertices, cam):
+    """orthographic_proj_withz_idrot (nmr.py:109-140): OpenGL axis change, camera matrix, perspective divide, 2x3 crop
+    transform, pixel -> [-1,1]; z = the axis-changed depth.  vertices (B,V,3), cam (B,15)."""
+    bs = cam.shape[0]
+    cam_mat, trans = cam[:, 0:9].reshape(bs, 3, 3), cam[:, 9:].reshape(bs, 2, 3)
+    change = torch.tensor([[1., 0., 0.], [0., -1., 0.], [0., 0., -1.]], dtype=torch.float32, device=vertices.device)
+    pts = torch.einsum('ijk,mk->ijm', vertices, change)
+    proj = torch.einsum('ijk,imk->ijm', pts, cam_mat)
+    xy = torch.stack([proj[:, :, 0] / proj[:, :, 2], proj[:, :, 1] / proj[:, :, 2], torch.ones_like(proj[:, :, 0])], dim=2)
+    xy = torch.einsum('ijk,imk->ijm', trans, xy).permute(0, 2, 1)
+    return torch.cat((xy / 255.0 * 2 - 1, pts[:, :, 2:3]), dim=2)
+
+
+def render_fim_wim(cam, vertices, faces_idx, image_size=256, viewing_angle=30.0):
+    """MANORenderer.render_fim_wim (nmr.py:496-513): returns (faces (B,F,3,3), fim, wim).  faces_idx (F,3) or (B,F,3) int."""
+    v = project(vertices, cam)
+    v = torch.stack([v[:, :, 0], -v[:, :, 1], v[:, :, 2]], dim=2)                     # nmr.py:506
+    # nr.look_at with eye = (0, 0, -(1/tan(angle) + 1)), at = origin, up = +y (nmr.py:357,508): the rotation is the identity,
+    # what remains is the translation by -eye
+    v = v - torch.tensor([0.0, 0.0, -(1.0 / math.tan(math.radians(viewing_angle)) + 1.0)], device=v.device)
+    if faces_idx.dim() == 2:
+        faces_idx = faces_idx[None].expand(v.shape[0], -1, -1)
+    idx = faces_idx.long()
+    faces = torch.gather(v[:, :, None, :].expand(-1, -1, 3, -1), 1, idx[:, :, :, None].expand(-1, -1, -1, 3))   # vertices_to_faces
+    fim, wim = rasterize_fim_wim(faces, image_size)
+    return faces, fim, wim

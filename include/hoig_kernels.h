@@ -23,6 +23,7 @@
 #ifndef HOIG_KERNELS_H
 #define HOIG_KERNELS_H
 
+#include <stddef.h>
 #include <stdint.h>
 
 #ifdef __cplusplus
@@ -263,6 +264,16 @@ int hoig_prep_assemble(int B, const float *src_img, const float *ref_img, const 
                        const float *rend_r, const float *T_raw, float *src_bg, float *tsf_bg, float *src_obj,
                        float *tsf_obj, float *src_hand, float *ref_hand, float *T_hand, float *smb, float *rmb, float *smh,
                        float *rmh, hoig_stream_t stream);
+
+/* ---- rasteriser of MANORenderer.render_fim_wim (utils/nmr.py:496-513): replaces
+ *      nr.rasterize_face_index_map_and_weight_map(faces, image_size, anti_aliasing=False), i.e. neural_renderer's
+ *      forward_face_index_map kernels 1+2 (thirdparty/neural_renderer/neural_renderer/cuda/rasterize_cuda_kernel.cu:40-186)
+ *      with the wrapper's -1 / 0 fill and vertical flip (neural_renderer/rasterize.py:50-52,334-338).
+ *      faces [B,F,3,3] (vertices_to_faces output: x, y in [-1,1], y up, z depth); fim [B,S,S] int32 (-1 = no face),
+ *      wim [B,S,S,3]; workspace: hoig_rasterize_workspace_bytes(B, F) bytes.  Tile-binned (16x16-pixel tiles). ---- */
+size_t hoig_rasterize_workspace_bytes(int B, int F);
+int hoig_rasterize_fim_wim(const float *faces, int B, int F, int image_size, float near, float far, int32_t *fim,
+                           float *wim, void *workspace, hoig_stream_t stream);
 
 const char *hoig_version(void);
 

@@ -5,8 +5,8 @@ cd "$(dirname "$0")/../hoig_amd/csrc"
 OUT=../../tools/_build
 mkdir -p $OUT
 FLAGS="-O3 -std=c++17 --offload-arch=gfx950 -fPIC -I../../include -I. -Wno-unused-result -DHOIG_STAMP=${HOIG_STAMP:-1}"
-for f in conv_igemm conv_igemm_bf16 conv_small norm attn sample pointwise input_prep; do
-  EXTRA=""; [ $f = input_prep ] && EXTRA="-ffp-contract=off"
+for f in conv_igemm conv_igemm_bf16 conv_small norm attn sample pointwise input_prep raster; do
+  EXTRA=""; { [ $f = input_prep ] || [ $f = raster ]; } && EXTRA="-ffp-contract=off"
   /opt/rocm/bin/hipcc $FLAGS $EXTRA -c $f.hip -o $OUT/$f.stamp.o &
 done
 wait
