@@ -10,8 +10,8 @@
 //           -- one pixel -- runs the reference's per-face test only over that list, reading records as LDS broadcasts.
 // The reference keeps the FIRST face (in index order) among equal depths (`zp < depth_min`, strict); the unordered list
 // reproduces that by breaking depth ties towards the smaller face index.  Per-pixel arithmetic is the reference's, literal
-// for literal (its unsuffixed constants are doubles); the file is compiled with -ffp-contract=off like its oracle
-// (oracle/raster.c), because an FMA in an edge function moves pixels across a triangle's border.
+// for literal (its unsuffixed constants are doubles); the file is compiled with -ffp-contract=off (as the CPU
+// restatement it is tested against), because an FMA in an edge function moves pixels across a triangle's border.
 #include "common.h"
 #pragma clang fp contract(off)
 
