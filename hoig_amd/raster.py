@@ -44,16 +44,22 @@ def project(vertices, cam):
     return torch.cat((xy / 255.0 * 2 - 1, pts[:, :, 2:3]), dim=2)
 
 
-def render_fim_wim(cam, vertices, faces_idx, image_size=256, viewing_angle=30.0):
-    """MANORenderer.render_fim_wim (nmr.py:496-513): returns (faces (B,F,3,3), fim, wim).  faces_idx (F,3) or (B,F,3) int."""
+def project_to_faces(cam, vertices, faces_idx, viewing_angle=30.0):
+    """The vertex stage of render_fim_wim (nmr.py:503-511): projection, y flip, nr.look_at, nr.vertices_to_faces -> (B,F,3,3)."""
     v = project(vertices, cam)
     v = torch.stack([v[:, :, 0], -v[:, :, 1], v[:, :, 2]], dim=2)                     # nmr.py:506
     # nr.look_at with eye = (0, 0, -(1/tan(angle) + 1)), at = origin, up = +y (nmr.py:357,508): the rotation is the identity,
     # what remains is the translation by -eye
-    v = v - torch.tensor([0.0, 0.0, -(1.0 / math.tan(math.radians(viewing_angle)) + 1.0)], device=v.device)
+    eye = torch.tensor([0.0, 0.0, -(1.0 / math.tan(math.radians(viewing_angle)) + 1.0)], dtype=torch.float32, device=v.device)
+    v = v - eye
     if faces_idx.dim() == 2:
         faces_idx = faces_idx[None].expand(v.shape[0], -1, -1)
     idx = faces_idx.long()
-    faces = torch.gather(v[:, :, None, :].expand(-1, -1, 3, -1), 1, idx[:, :, :, None].expand(-1, -1, -1, 3))   # vertices_to_faces
+    return v[torch.arange(v.shape[0], device=v.device)[:, None, None], idx]           # vertices_to_faces
+
+
+def render_fim_wim(cam, vertices, faces_idx, image_size=256, viewing_angle=30.0):
+    """MANORenderer.render_fim_wim (nmr.py:496-513): returns (faces (B,F,3,3), fim, wim).  faces_idx (F,3) or (B,F,3) int."""
+    faces = project_to_faces(cam, vertices, faces_idx, viewing_angle)
     fim, wim = rasterize_fim_wim(faces, image_size)
     return faces, fim, wim

@@ -20,8 +20,8 @@ static float clamp01(float v) { return (float)(v < 0. ? 0. : (v > 1. ? 1. : (dou
 
 /* faces [B][F][3][3] (x, y, z per vertex; x, y in [-1,1] normalised image coordinates, y up), outputs fim [B][S][S]
  * (int32, -1 = no face), wim [B][S][S][3]; scratch faces_inv [B][F][9] */
-void oracle_rasterize_fim_wim(const float *faces, int B, int F, int S, float near, float far, int32_t *fim, float *wim,
-                              float *faces_inv) {
+static void rasterize(const float *faces, int B, int F, int S, float near, float far, int32_t *fim, float *wim,
+                      float *faces_inv, int wrapper) {
     const int is = S;
     for (size_t i = 0; i < (size_t)B * F * 9; ++i) faces_inv[i] = 0.f;               /* torch.zeros_like, rasterize.py:164 */
     for (int i = 0; i < B * F; ++i) {                                                 /* R1 */
@@ -66,8 +66,29 @@ void oracle_rasterize_fim_wim(const float *faces, int B, int F, int S, float nea
                         for (int k = 0; k < 3; ++k) wmin[k] = w[k];
                     }
                 }
+                if (!wrapper) {                    /* the bare kernel: writes covered pixels only, no flip  :173-178 */
+                    const size_t o = ((size_t)b * is + yi) * is + xi;
+                    if (best >= 0) {
+                        fim[o] = best;
+                        for (int k = 0; k < 3; ++k) wim[o * 3 + k] = wmin[k];
+                    }
+                    continue;
+                }
                 const size_t o = ((size_t)b * is + (is - 1 - yi)) * is + xi;          /* vertical flip, rasterize.py:334-338 */
                 fim[o] = best;
                 for (int k = 0; k < 3; ++k) wim[o * 3 + k] = best >= 0 ? wmin[k] : 0.f;
             }
+}
+
+/* what nr.rasterize_face_index_map_and_weight_map(faces, S, False) returns: kernels + the wrapper's fill and flip */
+void oracle_rasterize_fim_wim(const float *faces, int B, int F, int S, float near, float far, int32_t *fim, float *wim,
+                              float *faces_inv) {
+    rasterize(faces, B, F, S, near, far, fim, wim, faces_inv, 1);
+}
+
+/* the two CUDA kernels alone (rasterize_cuda.forward_face_index_map): fim / wim pre-filled by the caller, no flip.  Used by
+ * oracle/ref_harness.py to run the reference's own Python wrapper (neural_renderer/rasterize.py) on top of it. */
+void oracle_rasterize_kernels(const float *faces, int B, int F, int S, float near, float far, int32_t *fim, float *wim,
+                              float *faces_inv) {
+    rasterize(faces, B, F, S, near, far, fim, wim, faces_inv, 0);
 }

@@ -210,3 +210,70 @@ def reference_input_prep(raster, bg_both=False, copy='hov3'):
     hdr._render = render
     with torch.no_grad():
         return hdr.forward(raster['src_img'].clone(), raster['ref_img'].clone(), None, None)
+
+
+def reference_vertex_stage(cam, vertices, faces_idx, viewing_angle=30.0, copy='hov3'):
+    """The reference's own vertex stage of ``render_fim_wim`` (utils/nmr.py:503-511) on CPU: ``orthographic_proj_withz_idrot``
+    (nmr.py:109-140), the y flip, and neural_renderer's pure-Python ``look_at`` / ``vertices_to_faces`` loaded from their files
+    (the package itself imports its CUDA extensions)."""
+    import importlib.util
+    import numpy as np
+    install(copy)
+    nmr_mod = importlib.import_module('utils.nmr')
+    root = REF_HOV3 if copy == 'hov3' else REF_DEXYCB
+    mods = {}
+    for name in ('look_at', 'vertices_to_faces'):
+        spec = importlib.util.spec_from_file_location(
+            'hoig_ref_nr_' + name, os.path.join(root, 'thirdparty', 'neural_renderer', 'neural_renderer', name + '.py'))
+        mods[name] = importlib.util.module_from_spec(spec)
+        spec.loader.exec_module(mods[name])
+    eye = [0, 0, -(1. / np.tan(np.radians(viewing_angle)) + 1)]                      # nmr.py:357
+    proj = nmr_mod.orthographic_proj_withz_idrot(vertices, cam)
+    proj[:, :, 1] *= -1
+    v = mods['look_at'].look_at(proj, eye)
+    faces = faces_idx if faces_idx.dim() == 3 else faces_idx[None].repeat(cam.shape[0], 1, 1)
+    return mods['vertices_to_faces'].vertices_to_faces(v, faces)
+
+
+def reference_rasterize_wrapper(faces, image_size, copy='hov3'):
+    """The reference's own Python wrapper ``rasterize_face_index_map_and_weight_map(faces, image_size, False)``
+    (thirdparty/neural_renderer/neural_renderer/rasterize.py: output allocation and fill :50-52, the call sequence of
+    ``Rasterize.forward``, the vertical flips :334-338) executed on CPU over the ORACLE's restatement of the two CUDA kernels
+    it calls (oracle/raster.c::oracle_rasterize_kernels) -- 'composition-pinned': pins the fill / flip / return conventions,
+    not the kernels."""
+    import ctypes
+    import importlib.util
+    import numpy as np
+    import torch
+    install(copy)
+    root = REF_HOV3 if copy == 'hov3' else REF_DEXYCB
+    here = os.path.dirname(os.path.abspath(__file__))
+    clib = ctypes.CDLL(os.path.join(here, '_build', 'libhoig_oracle_c.so'))
+    vp = ctypes.c_void_p
+    clib.oracle_rasterize_kernels.argtypes = [vp, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_float, ctypes.c_float,
+                                              vp, vp, vp]
+
+    def forward_face_index_map(faces, face_index_map, weight_map, depth_map, face_inv_map, faces_inv, image_size, near, far,
+                               return_rgb, return_alpha, return_depth):
+        f = np.ascontiguousarray(faces.numpy(), dtype=np.float32)
+        fim, wim, inv = face_index_map.numpy(), weight_map.numpy(), faces_inv.numpy()
+        clib.oracle_rasterize_kernels(f.ctypes.data, f.shape[0], f.shape[1], image_size, near, far, fim.ctypes.data,
+                                      wim.ctypes.data, inv.ctypes.data)
+        return face_index_map, weight_map, depth_map, face_inv_map
+
+    for pkg in ('neural_renderer', 'neural_renderer.cuda'):
+        if pkg not in sys.modules or not hasattr(sys.modules[pkg], '__path__'):
+            _stub(pkg).__path__ = []
+    _stub('neural_renderer.cuda.rasterize', forward_face_index_map=forward_face_index_map)
+    sys.modules['neural_renderer.cuda'].rasterize = sys.modules['neural_renderer.cuda.rasterize']
+    saved = (torch.cuda.FloatTensor, torch.cuda.IntTensor)
+    torch.cuda.FloatTensor, torch.cuda.IntTensor = torch.FloatTensor, torch.IntTensor
+    try:
+        spec = importlib.util.spec_from_file_location(
+            'hoig_ref_nr_rasterize', os.path.join(root, 'thirdparty', 'neural_renderer', 'neural_renderer', 'rasterize.py'))
+        mod = importlib.util.module_from_spec(spec)
+        spec.loader.exec_module(mod)
+        with torch.no_grad():
+            return mod.rasterize_face_index_map_and_weight_map(faces.clone(), image_size, False)
+    finally:
+        torch.cuda.FloatTensor, torch.cuda.IntTensor = saved

@@ -70,3 +70,12 @@ def test_render_fim_wim_feeds_input_prep():
     assert (fim >= 0).any() and (fim == -1).any()
     covered = fim[0] >= 0
     assert torch.allclose(wim[0][covered].sum(-1), torch.ones_like(wim[0][covered].sum(-1)), atol=1e-5)
+
+
+def test_vertex_stage_on_device_matches_reference_fixture():
+    import os
+    from hoig_amd import raster
+    g = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), 'golden', 'raster_vertex_stage.npz'))
+    faces = raster.project_to_faces(torch.from_numpy(g['cam']).cuda(), torch.from_numpy(g['vertices']).cuda(),
+                                    torch.from_numpy(g['faces_idx']).cuda())
+    np.testing.assert_allclose(faces.cpu().numpy(), g['faces'], rtol=0, atol=2e-5)
