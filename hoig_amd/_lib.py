@@ -98,7 +98,7 @@ _SIGS = {
     'hoig_tensor2im_u8': [_vp, _vp] + [_i] * 6 + [_vp],
     'hoig_prep_texture': [_vp] * 9,
     'hoig_prep_lookup': [_vp] * 5 + [_i] + [_vp] * 8,
-    'hoig_prep_assemble': [_i] + [_vp] * 23,
+    'hoig_prep_assemble': [_i] + [_vp] * 17 + [_i] + [_vp] * 6,
     'hoig_rasterize_fim_wim': [_vp, _i, _i, _i, _f, _f, _vp, _vp, _vp, _vp],
 }
 

@@ -167,10 +167,10 @@ struct AsmArgs {
     const float *T_raw;                                   // [B,S,S,2]
     float *src_bg, *tsf_bg;                               // [B,4,S,S] (tsf_bg nullable)
     float *src_obj, *tsf_obj;                             // [B,15,S,S]
-    float *src_hand, *ref_hand;                           // [B,6,S,S]
+    float *src_hand, *ref_hand;                           // [B,hand_c,S,S]: 6 (HOv3) or 12 (DexYCB: + six hand-part one-hots)
     float *T_hand;                                        // [B,S,S,2]
     float *smb, *rmb, *smh, *rmh;                         // [B,1,S,S]
-    int B;
+    int B, hand_c;
 };
 
 // trainer.py:110-141
@@ -193,7 +193,7 @@ __global__ void prep_assemble_kernel(const AsmArgs a) {
         const float u = cond[p], v = cond[P + p], flag = cond[2 * P + p];
         const float hm = u < 1.5f ? 1.f : 0.f, om = u > 1.5f ? 1.f : 0.f;       // trainer.py:113-125
         float *obj = (view ? a.tsf_obj : a.src_obj) + b * 15 * P + p;
-        float *hand = (view ? a.ref_hand : a.src_hand) + b * 6 * P + p;
+        float *hand = (view ? a.ref_hand : a.src_hand) + (size_t)b * a.hand_c * P + p;
         const float r0 = rend[p], r1 = rend[P + p], r2 = rend[2 * P + p];
         const float mo = mh - mb;                                                // trainer.py:128,132
         obj[0] = r0 * mo; obj[P] = r1 * mo; obj[2 * P] = r2 * mo;
@@ -204,6 +204,10 @@ __global__ void prep_assemble_kernel(const AsmArgs a) {
         if (view == 0) { hand[0] = img[p] * nh; hand[P] = img[P + p] * nh; hand[2 * P] = img[2 * P + p] * nh; }
         else { hand[0] = r0 * nh; hand[P] = r1 * nh; hand[2 * P] = r2 * nh; }
         hand[3 * P] = hm * u; hand[4 * P] = hm * v; hand[5 * P] = flag + 1.f - hm;
+        if (a.hand_c == 12) {                                                    // HOIG_DexYCB/models/trainer.py:131,135: seg[:, :6]
+#pragma unroll
+            for (int j = 0; j < 6; ++j) hand[(6 + j) * P] = seg == (float)(j + 1) ? 1.f : 0.f;
+        }
         float *bg = view ? a.tsf_bg : a.src_bg;
         if (bg) {                                                                // trainer.py:136-141
             const float e = erode(cond + 2 * P, y, x, 7);
@@ -247,13 +251,14 @@ extern "C" int hoig_prep_lookup(const int32_t *fim, const float *wim, const floa
 extern "C" int hoig_prep_assemble(int B, const float *src_img, const float *ref_img, const float *cond_s, const float *cond_r,
                                   const float *seg_s, const float *seg_r, const float *hr_s, const float *hr_r,
                                   const float *rend_s, const float *rend_r, const float *T_raw, float *src_bg, float *tsf_bg,
-                                  float *src_obj, float *tsf_obj, float *src_hand, float *ref_hand, float *T_hand, float *smb,
-                                  float *rmb, float *smh, float *rmh, hoig_stream_t stream) {
+                                  float *src_obj, float *tsf_obj, float *src_hand, float *ref_hand, int hand_channels,
+                                  float *T_hand, float *smb, float *rmb, float *smh, float *rmh, hoig_stream_t stream) {
+    if (hand_channels != 6 && hand_channels != 12) return HOIG_EINVAL;
     if (B <= 0 || !src_img || !ref_img || !cond_s || !cond_r || !seg_s || !seg_r || !hr_s || !hr_r || !rend_s || !rend_r ||
         !T_raw || !src_bg || !src_obj || !tsf_obj || !src_hand || !ref_hand || !T_hand || !smb || !rmb || !smh || !rmh)
         return HOIG_EINVAL;
     AsmArgs a{src_img, ref_img, cond_s, cond_r, seg_s, seg_r, hr_s, hr_r, rend_s, rend_r, T_raw, src_bg, tsf_bg, src_obj,
-              tsf_obj, src_hand, ref_hand, T_hand, smb, rmb, smh, rmh, B};
+              tsf_obj, src_hand, ref_hand, T_hand, smb, rmb, smh, rmh, B, hand_channels};
     prep_assemble_kernel<<<(int)(((int64_t)B * S * S + NT - 1) / NT), NT, 0, ST>>>(a);
     HOIG_LAUNCH_CHECK();
     return HOIG_OK;

@@ -7,7 +7,7 @@ the barycentric weight map.  Everything downstream -- encode_fim / encode_sem (n
 (nmr.py:874-968), get_texture_backward_warp (nmr.py:973-1058), sample_from_texture_dense (nmr.py:1068-1100), the two
 ``F.grid_sample`` calls and the 3x3 / 15x15 ``util.morph`` erosions with the channel bookkeeping of trainer.py:103-145 -- runs
 as three HIP kernels per sample plus one per batch (hoig_amd/csrc/input_prep.hip); the reference runs ~60 small torch ops per
-sample in a Python loop.  HOv3 channel layout; 256 x 256 only, as the reference hard-wires it.
+sample in a Python loop.  HOv3 and DexYCB channel layouts; 256 x 256 only, as the reference hard-wires it.
 
 ``prepare_inputs`` returns the reference's 12-tuple (NCHW).  ``to_prepared`` turns it into the dict ``Trainer.set_input``
 stages (trainer.py:346-362).  No CPU path: tensors must live on the HIP device.
@@ -44,10 +44,11 @@ def _dev(t, dtype, name):
     return t.to(dtype).contiguous()
 
 
-def prepare_inputs(src_img, ref_img, src_faces, src_fim, src_wim, ref_fim, ref_wim, tables, bg_both=False):
+def prepare_inputs(src_img, ref_img, src_faces, src_fim, src_wim, ref_fim, ref_wim, tables, bg_both=False, dexycb=False):
     """trainer.py:46-145 after the rasteriser.  src_img / ref_img (B,3,256,256); src_faces (B,F,3,3) as returned by
     render_fim_wim for the SOURCE view (rows beyond a sample's own face count are ignored); *_fim (B,256,256) integer,
-    *_wim (B,256,256,3); tables: one ObjectTables per sample.
+    *_wim (B,256,256,3); tables: one ObjectTables per sample; dexycb: the DexYCB copy's hand inputs (12 channels: + the six
+    hand-part one-hots, HOIG_DexYCB/models/trainer.py:131,135).
     Returns (input_G_src_bg, input_G_tsf_bg | None, input_G_src_obj, input_G_tsf_obj, input_G_src_hand, input_G_ref_hand,
     T_hand, src_crop_mask_bg, ref_crop_mask_bg, src_crop_mask_hand, ref_crop_mask_hand, None)."""
     B = int(src_img.shape[0])
@@ -80,13 +81,14 @@ def prepare_inputs(src_img, ref_img, src_faces, src_fim, src_wim, ref_fim, ref_w
                    seg[i].data_ptr(), hr[i].data_ptr(), rend[i].data_ptr(), None if T is None else T[i].data_ptr(), st)
     src_bg = new(B, 4, S, S)
     tsf_bg = new(B, 4, S, S) if bg_both else None
-    src_obj, tsf_obj, src_hand, ref_hand = new(B, 15, S, S), new(B, 15, S, S), new(B, 6, S, S), new(B, 6, S, S)
+    hc = 12 if dexycb else 6
+    src_obj, tsf_obj, src_hand, ref_hand = new(B, 15, S, S), new(B, 15, S, S), new(B, hc, S, S), new(B, hc, S, S)
     T_hand = new(B, S, S, 2)
     smb, rmb, smh, rmh = new(B, 1, S, S), new(B, 1, S, S), new(B, 1, S, S), new(B, 1, S, S)
     L.call('hoig_prep_assemble', B, src_img.data_ptr(), ref_img.data_ptr(), cond_s.data_ptr(), cond_r.data_ptr(),
            seg_s.data_ptr(), seg_r.data_ptr(), hr_s.data_ptr(), hr_r.data_ptr(), rend_s.data_ptr(), rend_r.data_ptr(),
            T_raw.data_ptr(), src_bg.data_ptr(), None if tsf_bg is None else tsf_bg.data_ptr(), src_obj.data_ptr(),
-           tsf_obj.data_ptr(), src_hand.data_ptr(), ref_hand.data_ptr(), T_hand.data_ptr(), smb.data_ptr(), rmb.data_ptr(),
+           tsf_obj.data_ptr(), src_hand.data_ptr(), ref_hand.data_ptr(), hc, T_hand.data_ptr(), smb.data_ptr(), rmb.data_ptr(),
            smh.data_ptr(), rmh.data_ptr(), st)
     return src_bg, tsf_bg, src_obj, tsf_obj, src_hand, ref_hand, T_hand, smb, rmb, smh, rmh, None
 

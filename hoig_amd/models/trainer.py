@@ -153,7 +153,7 @@ class Trainer(BaseModel):
             t = {k: (v.to(dev, non_blocking=True) if torch.is_tensor(v) else v) for k, v in inp.items()}
             tabs = [tb if isinstance(tb, IP.ObjectTables) else IP.ObjectTables(tb, dev) for tb in t['tables']]
             out = IP.prepare_inputs(t['src_img'], t['ref_img'], t['src_faces'], t['src_fim'], t['src_wim'], t['ref_fim'],
-                                    t['ref_wim'], tabs, bg_both=bool(getattr(self._opt, 'bg_both', False)))
+                                    t['ref_wim'], tabs, bg_both=bool(getattr(self._opt, 'bg_both', False)), dexycb=self._dexycb)
             return self.set_prepared_input(IP.to_prepared(out, t['src_img'].float(), t['ref_img'].float(),
                                                           t.get('maskA'), t.get('maskB')))
 

@@ -257,13 +257,14 @@ int hoig_prep_lookup(const int32_t *fim, const float *wim, const float *map_fn, 
                      const float *faces_uv_coord, int n_faces, const float *tex, const float *src_faces, float *cond,
                      float *seg, float *hand_region, float *rend, float *T, hoig_stream_t stream);
 /* batch: images [B,3,256,256]; the hoig_prep_lookup outputs of both views stacked over the batch; T_raw [B,256,256,2].
- * out: src_bg [B,4,..], tsf_bg (nullable: bg_both) [B,4,..], src_obj / tsf_obj [B,15,..], src_hand / ref_hand [B,6,..],
+ * out: src_bg [B,4,..], tsf_bg (nullable: bg_both) [B,4,..], src_obj / tsf_obj [B,15,..], src_hand / ref_hand
+ * [B,hand_channels,..] with hand_channels = 6 (HOv3) or 12 (DexYCB: + the six hand-part one-hots, HOIG_DexYCB/models/trainer.py:131,135),
  * T_hand [B,256,256,2], the four crop masks [B,1,..] (bg src, bg ref, hand src, hand ref) */
 int hoig_prep_assemble(int B, const float *src_img, const float *ref_img, const float *cond_s, const float *cond_r,
                        const float *seg_s, const float *seg_r, const float *hr_s, const float *hr_r, const float *rend_s,
                        const float *rend_r, const float *T_raw, float *src_bg, float *tsf_bg, float *src_obj,
-                       float *tsf_obj, float *src_hand, float *ref_hand, float *T_hand, float *smb, float *rmb, float *smh,
-                       float *rmh, hoig_stream_t stream);
+                       float *tsf_obj, float *src_hand, float *ref_hand, int hand_channels, float *T_hand, float *smb,
+                       float *rmb, float *smh, float *rmh, hoig_stream_t stream);
 
 /* ---- rasteriser of MANORenderer.render_fim_wim (utils/nmr.py:496-513): replaces
  *      nr.rasterize_face_index_map_and_weight_map(faces, image_size, anti_aliasing=False), i.e. neural_renderer's

@@ -1,7 +1,7 @@
 """CPU restatement (TEST INFRASTRUCTURE: only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may import
 this) of the input-preparation stage that FOLLOWS the rasteriser in the reference: ``HandRecoveryFlow.forward``
 (HOIG_HOv3/models/trainer.py:46-145) with the MANORenderer helpers it calls (utils/nmr.py) and ``util.morph``
-(utils/util.py:142-158).  Plain torch on CPU, HOv3 channel layout.
+(utils/util.py:142-158).  Plain torch on CPU; HOv3 channel layout, or the DexYCB copy's with dexycb=True.
 
 Pinned: tests/test_input_prep_oracle.py compares it bit-for-bit with the reference's own code run in the build container
 (oracle/ref_harness.py::reference_input_prep -- only ``render_fim_wim`` is replaced, by seeded synthetic rasteriser
@@ -61,7 +61,7 @@ def texture_backward_warp(im, f2pts, src_fim, tb):
     return syn
 
 
-def prepare_inputs(src_img, ref_img, src_faces, src_fim, src_wim, ref_fim, ref_wim, tables, bg_both=False):
+def prepare_inputs(src_img, ref_img, src_faces, src_fim, src_wim, ref_fim, ref_wim, tables, bg_both=False, dexycb=False):
     """HandRecoveryFlow.forward (trainer.py:46-145) after the rasteriser.  `tables`: one dict per sample.
     Returns the reference's tuple: (input_G_src_bg, input_G_tsf_bg | None, input_G_src_obj, input_G_tsf_obj,
     input_G_src_hand, input_G_ref_hand, T_hand, src_crop_mask_bg, ref_crop_mask_bg, src_crop_mask_hand,
@@ -105,9 +105,10 @@ def prepare_inputs(src_img, ref_img, src_faces, src_fim, src_wim, ref_fim, ref_w
     s_hand, s_obj = split(c['scond'])
     r_hand, r_obj = split(c['rcond'])
     in_src_obj = torch.cat([c['rsrc'] * (c['smh'] - smb), s_obj, c['sseg'][:, 6:]], dim=1)    # trainer.py:128
-    in_src_hand = torch.cat([src_img * (1 - c['smh']), s_hand], dim=1)                        # :129
+    in_src_hand = torch.cat([src_img * (1 - c['smh']), s_hand] + ([c['sseg'][:, :6]] if dexycb else []), dim=1)   # :129
     in_tsf_obj = torch.cat([c['rref'] * (c['rmh'] - rmb), r_obj, c['rseg'][:, 6:]], dim=1)    # :132
-    in_ref_hand = torch.cat([c['rref'] * (1 - c['rmh']), r_hand], dim=1)                      # :133
+    in_ref_hand = torch.cat([c['rref'] * (1 - c['rmh']), r_hand] + ([c['rseg'][:, :6]] if dexycb else []), dim=1)  # :133
+    # (dexycb: HOIG_DexYCB/models/trainer.py:131,135 append the six hand-part one-hots; everything else is identical)
     sbg = morph_erode(c['scond'][:, -1:], 15)                                                 # :136
     in_src_bg = torch.cat([src_img * sbg, sbg], dim=1)                                        # :137
     in_tsf_bg = None

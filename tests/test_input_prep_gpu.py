@@ -17,19 +17,19 @@ NAMES = ['input_G_src_bg', 'input_G_tsf_bg', 'input_G_src_obj', 'input_G_tsf_obj
 ATOL = 2e-6
 
 
-def run_hip(r, bg_both):
+def run_hip(r, bg_both, dexycb=False):
     from hoig_amd import input_prep as IP
     dev = torch.device('cuda', 0)
     tabs = {k: IP.ObjectTables(tb, dev) for k, tb in r['tables'].items()}
     c = lambda k: r[k].to(dev)
     return IP.prepare_inputs(c('src_img'), c('ref_img'), c('src_faces'), c('src_fim'), c('src_wim'), c('ref_fim'),
-                             c('ref_wim'), [tabs[k] for k in r['obj_ids']], bg_both)
+                             c('ref_wim'), [tabs[k] for k in r['obj_ids']], bg_both, dexycb)
 
 
-def run_oracle(r, bg_both):
+def run_oracle(r, bg_both, dexycb=False):
     tabs = [r['tables'][k] for k in r['obj_ids']]
     return P.prepare_inputs(r['src_img'], r['ref_img'], r['src_faces'], r['src_fim'], r['src_wim'], r['ref_fim'],
-                            r['ref_wim'], tabs, bg_both)
+                            r['ref_wim'], tabs, bg_both, dexycb)
 
 
 def compare(hip, ora):
@@ -56,6 +56,15 @@ def compare(hip, ora):
 def test_hip_matches_oracle(seed, batch, bg_both):
     r = synthetic.make_raster(batch, seed)
     compare(run_hip(r, bg_both), run_oracle(r, bg_both))
+
+
+def test_hip_matches_oracle_dexycb_layout():
+    r = synthetic.make_raster(2, 14)
+    hip, ora = run_hip(r, True, dexycb=True), run_oracle(r, True, dexycb=True)
+    assert hip[4].shape[1] == 12 and hip[5].shape[1] == 12
+    compare(hip, ora)
+    for i in (4, 5):
+        assert torch.equal(hip[i][:, 5:].cpu(), ora[i][:, 5:])                    # flag + the six hand-part one-hots
 
 
 def test_hip_matches_reference_fixture():

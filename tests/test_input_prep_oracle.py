@@ -17,17 +17,19 @@ NAMES = ['input_G_src_bg', 'input_G_tsf_bg', 'input_G_src_obj', 'input_G_tsf_obj
 GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'golden', 'input_prep_256.npz')
 
 
-def run_oracle(r, bg_both):
+def run_oracle(r, bg_both, dexycb=False):
     tabs = [r['tables'][k] for k in r['obj_ids']]
     return P.prepare_inputs(r['src_img'], r['ref_img'], r['src_faces'], r['src_fim'], r['src_wim'], r['ref_fim'],
-                            r['ref_wim'], tabs, bg_both)
+                            r['ref_wim'], tabs, bg_both, dexycb)
 
 
-@pytest.mark.parametrize('bg_both', [False, True])
-def test_oracle_matches_reference_fixture_bitwise(bg_both):
-    g = np.load(GOLD)
+@pytest.mark.parametrize('bg_both,copy', [(False, 'hov3'), (True, 'hov3'), (False, 'dexycb'), (True, 'dexycb')])
+def test_oracle_matches_reference_fixture_bitwise(bg_both, copy):
+    g = np.load(GOLD if copy == 'hov3' else GOLD.replace('.npz', '_dexycb.npz'))
+    assert str(g['copy']) == copy
     r = synthetic.make_raster(int(g['batch']), int(g['seed']))
-    out = run_oracle(r, bg_both)
+    out = run_oracle(r, bg_both, dexycb=copy == 'dexycb')
+    assert out[4].shape[1] == (12 if copy == 'dexycb' else 6)
     assert out[11] is None and (out[1] is None) == (not bg_both)
     for name, v in zip(NAMES, out):
         if v is None:
