@@ -79,3 +79,37 @@ def test_vertex_stage_on_device_matches_reference_fixture():
     faces = raster.project_to_faces(torch.from_numpy(g['cam']).cuda(), torch.from_numpy(g['vertices']).cuda(),
                                     torch.from_numpy(g['faces_idx']).cuda())
     np.testing.assert_allclose(faces.cpu().numpy(), g['faces'], rtol=0, atol=2e-5)
+
+
+def test_vertices_to_generator_inputs_end_to_end():
+    """The whole HandRecoveryFlow.forward chain on the device -- render_fim_wim for the source and the reference pose, then
+    the input preparation -- against the oracle chain (C rasteriser + torch restatement) on the same vertices."""
+    from hoig_amd import raster, input_prep as IP, synthetic
+    from oracle import input_prep_oracle as P
+    tb = synthetic.make_object_tables(3, seed=21)
+    F, NH = tb['n_faces'], synthetic.N_HAND_FACES
+    g = np.random.default_rng(4)
+    hand_v = np.concatenate([g.uniform(-0.06, 0.02, size=(300, 2)), g.uniform(-0.62, -0.56, size=(300, 1))], -1)
+    obj_v = np.concatenate([g.uniform(0.0, 0.08, size=(200, 2)), g.uniform(-0.66, -0.58, size=(200, 1))], -1)
+    verts = torch.from_numpy(np.concatenate([hand_v, obj_v])[None].astype(np.float32))
+    near = lambda n, lo, hi: g.integers(lo, hi, size=(n, 3))
+    idx = torch.from_numpy(np.concatenate([near(NH, 0, 300), near(F - NH, 300, 500)]).astype(np.int32))
+    cams = [torch.tensor([[600.0, 0, 128, 0, 600.0, 128, 0, 0, 1, 1, 0, 0, 0, 1, 0]], dtype=torch.float32),
+            torch.tensor([[560.0, 0, 120, 0, 580.0, 140, 0, 0, 1, 1, 0.02, 3, -0.02, 1, -2]], dtype=torch.float32)]
+    src_img = torch.from_numpy(g.uniform(-1, 1, size=(1, 3, 256, 256)).astype(np.float32))
+    ref_img = torch.from_numpy(g.uniform(-1, 1, size=(1, 3, 256, 256)).astype(np.float32))
+    dev = torch.device('cuda', 0)
+    s_faces, s_fim, s_wim = raster.render_fim_wim(cams[0].to(dev), verts.to(dev), idx.to(dev))
+    _, r_fim, r_wim = raster.render_fim_wim(cams[1].to(dev), verts.to(dev), idx.to(dev))
+    assert ((s_fim >= 0) & (s_fim < NH)).any() and (s_fim >= NH).any() and (s_fim == -1).any()
+    out = IP.prepare_inputs(src_img.to(dev), ref_img.to(dev), s_faces, s_fim, s_wim, r_fim, r_wim, [IP.ObjectTables(tb, dev)])
+    # oracle chain from the same face tensors (the vertex stage is pinned separately)
+    of, ow = oracle_rasterize(s_faces.cpu(), 256)
+    rf, rw = oracle_rasterize(raster.project_to_faces(cams[1].to(dev), verts.to(dev), idx.to(dev)).cpu(), 256)
+    assert torch.equal(s_fim.cpu(), of) and torch.equal(r_fim.cpu(), rf)
+    want = P.prepare_inputs(src_img, ref_img, s_faces.cpu(), of, ow, rf, rw, [tb])
+    for a, b in zip(out, want):
+        if a is not None:
+            assert (a.cpu() - b).abs().max() <= 2e-6
+    for i in (7, 8, 9, 10):
+        assert torch.equal(out[i].cpu(), want[i])
