@@ -1855,6 +1855,9 @@ struct WHaloArgs {
     int Hin, Win, pad;         // input (= x) size and padding
     int tiles_x, tiles_y, n_mtiles, mt_per_split;
     int nblk_ci, nblk;
+#ifdef HOIG_STAMP
+    unsigned long long *dbg;
+#endif
 };
 
 // KS = 3: "same" 3x3 (pad 1, input = output size).  KS = 5: the attention's 5x5 VALID convolution over the replicate-padded
@@ -1961,6 +1964,18 @@ __global__ __launch_bounds__(128 * KS) void wgrad_halo_bf16_kernel(const WHaloAr
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
 
+#ifdef HOIG_STAMP
+    unsigned long long w_issue = 0, w_comp = 0, w_b1 = 0, w_st = 0, w_b2 = 0;
+    const unsigned long long wt_begin = clock64(), wrt_begin = __builtin_amdgcn_s_memrealtime();
+    unsigned long long wt_prev = wt_begin;
+#if HOIG_STAMP == 2
+#define WSTAMP(v)
+#else
+#define WSTAMP(v) { const unsigned long long t_ = clock64(); v += t_ - wt_prev; wt_prev = t_; }
+#endif
+#else
+#define WSTAMP(v)
+#endif
     if (mt_begin < mt_end) {
         load_tiles(mt_begin);
         store_tiles();
@@ -1969,6 +1984,7 @@ __global__ __launch_bounds__(128 * KS) void wgrad_halo_bf16_kernel(const WHaloAr
     for (int mt = mt_begin; mt < mt_end; ++mt) {
         const bool nxt = mt + 1 < mt_end;
         if (nxt) load_tiles(mt + 1);
+        WSTAMP(w_issue)
 #pragma unroll
         for (int kk = 0; kk < TH * 2; ++kk) {              // 16 consecutive pixels of one tile row per k-step
             const int prow0 = kk * 16;
@@ -1987,10 +2003,17 @@ __global__ __launch_bounds__(128 * KS) void wgrad_halo_bf16_kernel(const WHaloAr
                 acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bh, acc[t], 0, 0, 0);
             }
         }
+        WSTAMP(w_comp)
         __syncthreads();                      // every wave is done reading the stage
+        WSTAMP(w_b1)
         if (nxt) store_tiles();
+        WSTAMP(w_st)
         __syncthreads();
+        WSTAMP(w_b2)
     }
+#ifdef HOIG_STAMP
+    const unsigned long long wt_loop = clock64() - wt_begin;
+#endif
 
     if (do_bias) {                         // 24 threads hold partial sums of the same four channels: combine in LDS
         float *red = reinterpret_cast<float *>(smem);          // (the tiles are dead: the loop ended with a barrier)
@@ -2013,6 +2036,14 @@ __global__ __launch_bounds__(128 * KS) void wgrad_halo_bf16_kernel(const WHaloAr
 #pragma unroll
         for (int t = 0; t < KS; ++t) atomicAdd(row + t * p.Ci, acc[t][r]);
     }
+#ifdef HOIG_STAMP
+    if (p.dbg && lane == 0) {
+        __builtin_amdgcn_s_waitcnt(0);         // (the atomics are fire-and-forget: this only bounds their ISSUE)
+        unsigned long long *d = p.dbg + (((size_t)blockIdx.y * gridDim.x + blockIdx.x) * (NT / 64) + wave) * 8;
+        d[0] = w_issue; d[1] = w_comp; d[2] = w_b1; d[3] = w_st; d[4] = w_b2; d[5] = wt_loop;
+        d[6] = clock64() - wt_begin; d[7] = __builtin_amdgcn_s_memrealtime() - wrt_begin;
+    }
+#endif
 }
 
 int launch_wgrad_halo(const hoig_conv_desc *d, const float *x, const float *dy, float *dw, float *dbias, int ns,
@@ -2034,6 +2065,9 @@ int launch_wgrad_halo(const hoig_conv_desc *d, const float *x, const float *dy, 
     a.mt_per_split = (int)hoig_cdiv(a.n_mtiles, splits);
     splits = (int)hoig_cdiv(a.n_mtiles, a.mt_per_split);
     dim3 grid(a.nblk, splits);
+#ifdef HOIG_STAMP
+    a.dbg = g_stamp_buf;
+#endif
     if (d->R == 5) {
         if (ns == 2) wgrad_halo_bf16_kernel<2, 5><<<grid, 640, 0, st>>>(a);
         else wgrad_halo_bf16_kernel<1, 5><<<grid, 640, 0, st>>>(a);
