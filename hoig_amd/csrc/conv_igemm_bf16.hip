@@ -1862,24 +1862,27 @@ struct WHaloArgs {
 
 // KS = 3: "same" 3x3 (pad 1, input = output size).  KS = 5: the attention's 5x5 VALID convolution over the replicate-padded
 // target (input (H+4) x (W+4), pad 0): ten waves = co half x tap row, five taps each.
-template <int NS, int KS>
-__global__ __launch_bounds__(128 * KS) void wgrad_halo_bf16_kernel(const WHaloArgs p) {
-    constexpr int TH = 2, TW = 32, BM = 64, BC = 32, NT = 128 * KS;
+// CM = 2: 128 output channels per workgroup on twice the waves (wave = co quarter x tap row): the same work per wave, but the x
+// halo is loaded and split once for twice the MFMAs -- the kernel is short of VALU issue slots, not of clock.
+template <int NS, int KS, int CM>
+__global__ __launch_bounds__(128 * KS * CM) void wgrad_halo_bf16_kernel(const WHaloArgs p) {
+    constexpr int TH = 2, TW = 32, BM = 64 * CM, BC = 32, NT = 128 * KS * CM;
+    constexpr int CQ = 2 * CM, C4 = 16 * CM;               // 32-channel groups / float4s of a dy pixel row
     constexpr int HH = TH + KS - 1, HWID = TW + KS - 1, HPIX = HH * HWID;     // 4 x 34 halo pixels
-    constexpr int PSTR = 192, QSTR = 64;
+    constexpr int PSTR = 128 * CM + 64, QSTR = 64;         // (192 / 320 B: four consecutive rows cover the 64 banks once)
     constexpr int PLANE_P = TH * TW * PSTR, PLANE_Q = ((HPIX * QSTR + 255) / 256) * 256;
     __shared__ __attribute__((aligned(16))) unsigned char smem[NS * (PLANE_P + PLANE_Q)];
     unsigned char *Ph = smem, *Pl = smem + PLANE_P;
     unsigned char *Qh = smem + NS * PLANE_P, *Ql = Qh + PLANE_Q;
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int cb = wave & 1, tr = wave >> 1;               // co half, tap row
+    const int cb = wave % CQ, tr = wave / CQ;              // 32-channel group of co, tap row
     const int tile = hoig_xcd_remap(blockIdx.x, p.nblk);
     const int c0 = (tile / p.nblk_ci) * BM, ci0 = (tile % p.nblk_ci) * BC;
     const int mt_begin = blockIdx.y * p.mt_per_split;
     const int mt_end = min(p.n_mtiles, mt_begin + p.mt_per_split);
 
-    constexpr int PSL = (TH * TW * 16 + NT - 1) / NT;      // dy float4s per thread (3)
+    constexpr int PSL = (TH * TW * C4 + NT - 1) / NT;      // dy float4s per thread (3)
     constexpr int QSL = (HPIX * 8 + NT - 1) / NT;          // halo float4s per thread (3)
     float4 rp[PSL], rq[QSL];
     const bool do_bias = p.DB != nullptr && ci0 == 0;      // the workgroups of the first ci tile also own the bias gradient
@@ -1894,12 +1897,12 @@ __global__ __launch_bounds__(128 * KS) void wgrad_halo_bf16_kernel(const WHaloAr
         for (int i = 0; i < PSL; ++i) {
             const int idx = tid + NT * i;
             float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (idx < TH * TW * 16) {
-                const int pp = idx >> 4, c4 = idx & 15;    // pixel of the tile: row pp>>5, column pp&31
+            if (idx < TH * TW * C4) {
+                const int pp = idx / C4, c4 = idx % C4;    // pixel of the tile: row pp>>5, column pp&31
                 v = *reinterpret_cast<const float4 *>(dyb + ((size_t)(pp >> 5) * p.W + (pp & 31)) * p.Co + c4 * 4);
             }
             rp[i] = v;
-            if (do_bias) {                 // this thread always loads the same four channels (NT % 16 == 0)
+            if (do_bias) {                 // this thread always loads the same four channels (NT % C4 == 0)
                 bsum.x += v.x; bsum.y += v.y; bsum.z += v.z; bsum.w += v.w;
             }
         }
@@ -1924,10 +1927,10 @@ __global__ __launch_bounds__(128 * KS) void wgrad_halo_bf16_kernel(const WHaloAr
 #pragma unroll
         for (int i = 0; i < PSL; ++i) {
             const int idx = tid + NT * i;
-            if (idx < TH * TW * 16) {
+            if (idx < TH * TW * C4) {
                 uint2 hi, lo;
                 split4(rp[i], hi, lo);
-                const int off = (idx >> 4) * PSTR + (idx & 15) * 8;
+                const int off = (idx / C4) * PSTR + (idx % C4) * 8;
                 *reinterpret_cast<uint2 *>(Ph + off) = hi;
                 if (NS == 2) *reinterpret_cast<uint2 *>(Pl + off) = lo;
             }
@@ -2019,7 +2022,7 @@ __global__ __launch_bounds__(128 * KS) void wgrad_halo_bf16_kernel(const WHaloAr
         float *red = reinterpret_cast<float *>(smem);          // (the tiles are dead: the loop ended with a barrier)
         if (tid < BM) red[tid] = 0.f;
         __syncthreads();
-        const int ch = (tid & 15) * 4;
+        const int ch = (tid % C4) * 4;
         atomicAdd(&red[ch + 0], bsum.x);
         atomicAdd(&red[ch + 1], bsum.y);
         atomicAdd(&red[ch + 2], bsum.z);
@@ -2056,10 +2059,12 @@ int launch_wgrad_halo(const hoig_conv_desc *d, const float *x, const float *dy, 
     a.tiles_y = a.H / 2;
     a.n_mtiles = a.Bn * a.tiles_x * a.tiles_y;
     a.nblk_ci = a.Ci / 32;
-    a.nblk = (a.Co / 64) * a.nblk_ci;
+    static const int cm_env = getenv("HOIG_WGRAD_HALO_CM") ? atoi(getenv("HOIG_WGRAD_HALO_CM")) : 2;
+    const int cm = (d->R == 3 && cm_env == 2 && a.Co % 128 == 0) ? 2 : 1;
+    a.nblk = (a.Co / (64 * cm)) * a.nblk_ci;
     static const int target_blocks = getenv("HOIG_WGRAD_HALO_BLOCKS") ? atoi(getenv("HOIG_WGRAD_HALO_BLOCKS")) : 512;
     // 5x5: a workgroup owns 25 taps x 64 x 32 outputs, so every pixel split costs 2.8x the atomics of a 3x3 one: 256 (measured)
-    int splits = (int)hoig_cdiv(d->R == 5 ? target_blocks / 2 : target_blocks, a.nblk);
+    int splits = (int)hoig_cdiv((d->R == 5 ? target_blocks / 2 : target_blocks) / cm, a.nblk);
     if (splits > a.n_mtiles) splits = a.n_mtiles;
     if (splits < 1) splits = 1;
     a.mt_per_split = (int)hoig_cdiv(a.n_mtiles, splits);
@@ -2069,11 +2074,14 @@ int launch_wgrad_halo(const hoig_conv_desc *d, const float *x, const float *dy, 
     a.dbg = g_stamp_buf;
 #endif
     if (d->R == 5) {
-        if (ns == 2) wgrad_halo_bf16_kernel<2, 5><<<grid, 640, 0, st>>>(a);
-        else wgrad_halo_bf16_kernel<1, 5><<<grid, 640, 0, st>>>(a);
+        if (ns == 2) wgrad_halo_bf16_kernel<2, 5, 1><<<grid, 640, 0, st>>>(a);
+        else wgrad_halo_bf16_kernel<1, 5, 1><<<grid, 640, 0, st>>>(a);
+    } else if (cm == 2) {
+        if (ns == 2) wgrad_halo_bf16_kernel<2, 3, 2><<<grid, 768, 0, st>>>(a);
+        else wgrad_halo_bf16_kernel<1, 3, 2><<<grid, 768, 0, st>>>(a);
     } else {
-        if (ns == 2) wgrad_halo_bf16_kernel<2, 3><<<grid, 384, 0, st>>>(a);
-        else wgrad_halo_bf16_kernel<1, 3><<<grid, 384, 0, st>>>(a);
+        if (ns == 2) wgrad_halo_bf16_kernel<2, 3, 1><<<grid, 384, 0, st>>>(a);
+        else wgrad_halo_bf16_kernel<1, 3, 1><<<grid, 384, 0, st>>>(a);
     }
     HOIG_LAUNCH_CHECK();
     return HOIG_OK;
