@@ -26,7 +26,7 @@ GFLOP_PER_PAIR_TRAIN_256 = 2555.2      # BASELINE.md §2 / SURVEY.md §8d (3*G +
 PEAK = {'f32': 157.3, 'bf16x3': 2500.0, 'bf16': 2500.0}          # TFLOP/s dense MFMA, MI355X_MICROARCH.md
 
 
-def dominant_kernel_roofline(batch, side, precision, iters=20):
+def dominant_kernel_roofline(batch, side, precision, iters=50):
     """The dominant kernel of the step is the 3x3 stride-1 512->512 convolution at side/8 (72 of ~260 conv calls of a
     forward, 44% of G's MACs).  Most of its time is spent in the launches of bg_model and obj_model,
     which process the src and the tsf batch STACKED (2*batch images per launch: profiles/r01_conv_table.txt), so that is
@@ -40,7 +40,7 @@ def dominant_kernel_roofline(batch, side, precision, iters=20):
     # the timed loop launches the convolution kernel only (in the training step the split happens once per optimiser step)
     import types
     w._hoig_owner = types.SimpleNamespace(version=0, packed_planes=lambda w_, for_dgrad: None)
-    for _ in range(3):
+    for _ in range(10):
         ops.conv2d(x, w, None, 1, 1)
     s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     torch.cuda.synchronize()
