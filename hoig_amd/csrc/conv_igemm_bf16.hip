@@ -1824,7 +1824,10 @@ int launch_wgrad_bf16(WArgs a, int ns, hipStream_t st) {
     // than ~2 workgroups per CU leave SIMDs idle: measured optimum ~512 workgroups (sweep 512/1024/2048: 32.7/33.1/33.1 ms
     // of weight gradients per step), splits of at least 512 pixels
     static const int min_px = getenv("HOIG_WGRAD_MIN_PX") ? atoi(getenv("HOIG_WGRAD_MIN_PX")) : 512;
-    const int max_splits = (int)hoig_cdiv(a.M, min_px);
+    // tiny K (the SPADE label convs: 12 channels x 9 taps): one column tile, next to no atomics, and a workgroup's pixel loop
+    // is pure load latency -- split four times finer
+    static const int small_k_px = getenv("HOIG_WGRAD_SMALLK_PX") ? atoi(getenv("HOIG_WGRAD_SMALLK_PX")) : 128;
+    const int max_splits = (int)hoig_cdiv(a.M, a.K <= 128 ? (small_k_px < min_px ? small_k_px : min_px) : min_px);
     if (splits > max_splits) splits = max_splits;
     if (splits < 1) splits = 1;
     const int mps = (int)hoig_cdiv(hoig_cdiv(a.M, splits), 32) * 32;

@@ -44,11 +44,13 @@ def _dev(t, dtype, name):
     return t.to(dtype).contiguous()
 
 
-def prepare_inputs(src_img, ref_img, src_faces, src_fim, src_wim, ref_fim, ref_wim, tables, bg_both=False, dexycb=False):
+def prepare_inputs(src_img, ref_img, src_faces, src_fim, src_wim, ref_fim, ref_wim, tables, bg_both=False, dexycb=False,
+                   validate=False):
     """trainer.py:46-145 after the rasteriser.  src_img / ref_img (B,3,256,256); src_faces (B,F,3,3) as returned by
     render_fim_wim for the SOURCE view (rows beyond a sample's own face count are ignored); *_fim (B,256,256) integer,
     *_wim (B,256,256,3); tables: one ObjectTables per sample; dexycb: the DexYCB copy's hand inputs (12 channels: + the six
-    hand-part one-hots, HOIG_DexYCB/models/trainer.py:131,135).
+    hand-part one-hots, HOIG_DexYCB/models/trainer.py:131,135); validate: check on the host that every face index addresses
+    its sample's tables (the reference's indexing would raise; the kernels do not check) -- costs a device synchronisation.
     Returns (input_G_src_bg, input_G_tsf_bg | None, input_G_src_obj, input_G_tsf_obj, input_G_src_hand, input_G_ref_hand,
     T_hand, src_crop_mask_bg, ref_crop_mask_bg, src_crop_mask_hand, ref_crop_mask_hand, None)."""
     B = int(src_img.shape[0])
@@ -60,6 +62,13 @@ def prepare_inputs(src_img, ref_img, src_faces, src_fim, src_wim, ref_fim, ref_w
     src_faces = _dev(src_faces, torch.float32, 'src_faces')
     src_fim, ref_fim = _dev(src_fim, torch.int32, 'src_fim'), _dev(ref_fim, torch.int32, 'ref_fim')
     src_wim, ref_wim = _dev(src_wim, torch.float32, 'src_wim'), _dev(ref_wim, torch.float32, 'ref_wim')
+    if validate:
+        for i, tb in enumerate(tables):
+            for name, fim in (('src_fim', src_fim), ('ref_fim', ref_fim)):
+                lo, hi = int(fim[i].min()), int(fim[i].max())
+                if lo < -1 or hi >= tb.n_faces:
+                    raise IndexError('%s[%d] holds face indices in [%d, %d]; the sample has %d faces' % (name, i, lo, hi,
+                                                                                                      tb.n_faces))
     dev = src_img.device
     new = lambda *shape: torch.empty(shape, dtype=torch.float32, device=dev)
     st = torch.cuda.current_stream().cuda_stream

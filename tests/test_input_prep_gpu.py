@@ -111,6 +111,11 @@ def test_rejects_cpu_tensors_and_wrong_size():
     with pytest.raises(NotImplementedError):
         IP.prepare_inputs(r['src_img'], r['ref_img'], r['src_faces'], r['src_fim'], r['src_wim'], r['ref_fim'], r['ref_wim'],
                           tabs)
+    bad = r['src_fim'].clone()
+    bad[0, 0, 0] = 10 ** 6
+    with pytest.raises(IndexError):
+        IP.prepare_inputs(r['src_img'].cuda(), r['ref_img'].cuda(), r['src_faces'].cuda(), bad.cuda(), r['src_wim'].cuda(),
+                          r['ref_fim'].cuda(), r['ref_wim'].cuda(), tabs, validate=True)
     with pytest.raises(ValueError):
         IP.prepare_inputs(r['src_img'][:, :, :128, :128].cuda(), r['ref_img'].cuda(), r['src_faces'].cuda(),
                           r['src_fim'].cuda(), r['src_wim'].cuda(), r['ref_fim'].cuda(), r['ref_wim'].cuda(), tabs)
