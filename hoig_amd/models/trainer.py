@@ -138,8 +138,9 @@ class Trainer(BaseModel):
         if all(k in input for k in RASTER_KEYS):
             return self.set_rasterised_input(input)
         raise NotImplementedError(
-            'Trainer.set_input: raw dataloader batches need HandRecoveryFlow (MANO + neural renderer, '
-            'trainer.py:324-362), which is outside the accelerated path; pass the prepared tensors %s' % PREPARED_KEYS)
+            'Trainer.set_input: raw dataloader batches need the MANO layer of HandRecoveryFlow (smplx, trainer.py:46-49), '
+            'which is outside the accelerated path; pass the prepared tensors %s or images + rasteriser outputs %s'
+            % (PREPARED_KEYS, RASTER_KEYS))
 
     def set_rasterised_input(self, inp):
         """Raw images + the rasteriser's outputs (``render_fim_wim``: face vertices, face index / weight maps) and the
