@@ -115,6 +115,40 @@ __global__ __launch_bounds__(256) void attn_sample_fwd_kernel(const float *__res
         k1_axis(ay, flow[((size_t)b * 2 + 1) * hw + rem], y, H);
         const float *s = src + (size_t)b * hw * C + cv * 4;
         float *o = S + (size_t)m * NTAP * C + cv * 4;
+        // The 25 taps sample a 5x5 grid with a common shift: their 100 corner reads hit a 6x6 footprint whenever every
+        // tap's right / lower neighbour is the next tap's left / upper one (always, up to a rounding coincidence of the
+        // per-tap floor at an exact integer coordinate).  Then 36 loads serve all taps, with K1's arithmetic unchanged.
+        bool chained = true;
+#pragma unroll
+        for (int t = 0; t + 1 < KS; ++t) chained = chained && ax.i1[t] == ax.i0[t + 1] && ay.i1[t] == ay.i0[t + 1];
+        if (chained) {
+            float4 R0[KS + 1], R1[KS + 1];
+            const float *row = s + (size_t)ay.i0[0] * W * C;
+#pragma unroll
+            for (int t = 0; t <= KS; ++t) R0[t] = *reinterpret_cast<const float4 *>(row + (size_t)(t < KS ? ax.i0[t] : ax.i1[KS - 1]) * C);
+#pragma unroll
+            for (int r = 0; r < KS; ++r) {
+                row = s + (size_t)ay.i1[r] * W * C;
+#pragma unroll
+                for (int t = 0; t <= KS; ++t)
+                    R1[t] = *reinterpret_cast<const float4 *>(row + (size_t)(t < KS ? ax.i0[t] : ax.i1[KS - 1]) * C);
+#pragma unroll
+                for (int t = 0; t < KS; ++t) {
+                    const float4 a = R0[t], bb = R0[t + 1], d = R1[t], e = R1[t + 1];
+                    const float w00 = ax.w0[t] * ay.w0[r], w01 = ax.w1[t] * ay.w0[r];
+                    const float w10 = ax.w0[t] * ay.w1[r], w11 = ax.w1[t] * ay.w1[r];
+                    float4 v;
+                    v.x = w00 * a.x; v.x += w01 * bb.x; v.x += w10 * d.x; v.x += w11 * e.x;
+                    v.y = w00 * a.y; v.y += w01 * bb.y; v.y += w10 * d.y; v.y += w11 * e.y;
+                    v.z = w00 * a.z; v.z += w01 * bb.z; v.z += w10 * d.z; v.z += w11 * e.z;
+                    v.w = w00 * a.w; v.w += w01 * bb.w; v.w += w10 * d.w; v.w += w11 * e.w;
+                    *reinterpret_cast<float4 *>(o + (size_t)(r * KS + t) * C) = v;
+                }
+#pragma unroll
+                for (int t = 0; t <= KS; ++t) R0[t] = R1[t];
+            }
+            continue;
+        }
 #pragma unroll
         for (int r = 0; r < KS; ++r) {
             const float *row0 = s + (size_t)ay.i0[r] * W * C, *row1 = s + (size_t)ay.i1[r] * W * C;
