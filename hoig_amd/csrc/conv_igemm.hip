@@ -581,6 +581,7 @@ int hoig_conv_small_wgrad(const hoig_conv_desc *d, const float *x, const float *
 int hoig_conv_small_dgrad(const hoig_conv_desc *d, const float *dy, const float *w, float *dx, hipStream_t st);
 int hoig_conv_small_ci_fwd(const hoig_conv_desc *d, const float *x, const float *w, const float *bias, float *y,
                            hipStream_t st);
+int hoig_conv_dot_fwd(const hoig_conv_desc *d, const float *x, const float *w, const float *bias, float *y, hipStream_t st);
 
 extern "C" int hoig_conv2d_fwd(const hoig_conv_desc *d, const float *x, const float *w, const float *bias, float *y,
                                hoig_stream_t stream) {
@@ -590,6 +591,7 @@ extern "C" int hoig_conv2d_fwd(const hoig_conv_desc *d, const float *x, const fl
     hipStream_t st = (hipStream_t)stream;
     rc = hoig_conv_small_fwd(d, x, w, bias, y, st);           // 7x7 heads with <= 4 output channels: direct fp32 kernel
     if (rc == HOIG_EUNSUPPORTED) rc = hoig_conv_small_ci_fwd(d, x, w, bias, y, st);    // 7x7 stems with <= 8 input channels
+    if (rc == HOIG_EUNSUPPORTED) rc = hoig_conv_dot_fwd(d, x, w, bias, y, st);         // <= 4 outputs over >= 1024 products
     if (rc != HOIG_EUNSUPPORTED) return rc;
     if (d->precision != HOIG_PREC_F32) {
         rc = hoig_conv_bf16_fwd_like(d, x, w, bias, y, false, st);

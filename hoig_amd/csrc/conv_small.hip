@@ -425,3 +425,66 @@ int hoig_conv_small_wgrad(const hoig_conv_desc *d, const float *x, const float *
     HOIG_LAUNCH_CHECK();
     return HOIG_OK;
 }
+
+
+// ---------------------------------------------------------------------------------------------------------------------
+// Convolutions with <= 4 output channels over MANY input channels (the PatchGAN head, discriminator.py:46: 4x4, 512 -> 1):
+// every output is a dot product over K = R*S*Ci >= 1024 values.  On the GEMM kernels the single output channel sits in a
+// 128-wide tile and a handful of workgroups walk K serially (385 us for 1568 outputs).  Here: one wave per output pixel,
+// lanes stride over (tap, 4 channels) with coalesced float4 reads, one reduction per output channel.
+namespace {
+template <int CO>
+__global__ __launch_bounds__(256) void conv_dot_fwd_kernel(const float *__restrict__ x, const float *__restrict__ w,
+                                                          const float *__restrict__ bias, float *__restrict__ y, int B, int Hi,
+                                                          int Wi, int Ci, int Ho, int Wo, int R, int S, int stride, int pad,
+                                                          int act, float slope) {
+    const int lane = threadIdx.x & 63;
+    const int64_t o = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (o >= (int64_t)B * Ho * Wo) return;
+    const int ox = (int)(o % Wo), oy = (int)((o / Wo) % Ho), b = (int)(o / ((int64_t)Wo * Ho));
+    const int CV = Ci >> 2, K4 = R * S * CV;
+    float acc[CO];
+#pragma unroll
+    for (int c = 0; c < CO; ++c) acc[c] = 0.f;
+    for (int i = lane; i < K4; i += 64) {
+        const int tap = i / CV, cv = i - tap * CV;
+        const int r = tap / S, t = tap - r * S;
+        const int iy = oy * stride - pad + r, ix = ox * stride - pad + t;
+        if (iy < 0 || iy >= Hi || ix < 0 || ix >= Wi) continue;
+        const float4 xv = *reinterpret_cast<const float4 *>(x + (((size_t)b * Hi + iy) * Wi + ix) * Ci + cv * 4);
+#pragma unroll
+        for (int c = 0; c < CO; ++c) {
+            const float4 wv = *reinterpret_cast<const float4 *>(w + ((size_t)c * R * S + tap) * Ci + cv * 4);
+            acc[c] += xv.x * wv.x + xv.y * wv.y + xv.z * wv.z + xv.w * wv.w;
+        }
+    }
+    const float nslope = act == HOIG_ACT_NONE ? 1.f : (act == HOIG_ACT_RELU ? 0.f : slope);
+    const bool special = act == HOIG_ACT_TANH || act == HOIG_ACT_SIGMOID;
+#pragma unroll
+    for (int c = 0; c < CO; ++c) {
+        float v = hoig_wave_sum(acc[c]);
+        if (lane == 0) {
+            v += bias ? bias[c] : 0.f;
+            y[o * CO + c] = fast_act(v, nslope, special, act, slope);
+        }
+    }
+}
+}  // namespace
+
+int hoig_conv_dot_fwd(const hoig_conv_desc *d, const float *x, const float *w, const float *bias, float *y, hipStream_t st) {
+    if (d->transposed || d->Co > 4 || (d->Ci & 3) || d->R * d->S * d->Ci < 1024) return HOIG_EUNSUPPORTED;
+    const int64_t outs = (int64_t)d->B * d->Ho * d->Wo;
+    const unsigned grid = (unsigned)hoig_cdiv(outs, 4);
+#define HOIG_DOT_FWD(N)                                                                                                    \
+    conv_dot_fwd_kernel<N><<<grid, 256, 0, st>>>(x, w, bias, y, d->B, d->Hi, d->Wi, d->Ci, d->Ho, d->Wo, d->R, d->S, d->stride, \
+                                                 d->pad, d->act, d->slope)
+    switch (d->Co) {
+        case 1: HOIG_DOT_FWD(1); break;
+        case 2: HOIG_DOT_FWD(2); break;
+        case 3: HOIG_DOT_FWD(3); break;
+        default: HOIG_DOT_FWD(4); break;
+    }
+#undef HOIG_DOT_FWD
+    HOIG_LAUNCH_CHECK();
+    return HOIG_OK;
+}
