@@ -197,7 +197,11 @@ __global__ __launch_bounds__(64) void attn_sample_bwd_kernel(const float *__rest
     const int by = t % tiles_y, b = t / tiles_y;
     const int c0 = blockIdx.y * PCH;
     const int hw = H * W;
-    const int py0 = by * TILE - PRAD, px0 = bx * TILE - PRAD;   // patch origin (unclamped image coordinates)
+    // patch origin (unclamped image coordinates), one cell further up-left than centred: the footprint of a pixel starts at
+    // floor(flow) - 2, and off-hand pixels carry flow = -2 - identity in (-3, -1] (generator.py:484-488 on the -2 sentinel,
+    // treated as PIXELS by K1) -- centred, the first row / column of every tile fell off the patch onto the atomic path
+    constexpr int shift = 1;
+    const int py0 = by * TILE - PRAD - shift, px0 = bx * TILE - PRAD - shift;
     const int lane = threadIdx.x, c = lane & 31, h = lane >> 5;
     for (int i = lane; i < PS * PS * PCH; i += 64) patch[i] = 0.f;
     __syncthreads();
