@@ -496,8 +496,10 @@ int launch(Args a, int ns, hipStream_t st) {
     a.ksplit = 1;
     a.steps_per_split = 0;
     const int steps = (a.K / BK);
-    if (a.nblk < 192 && steps >= 32 && a.act == HOIG_ACT_NONE && !a.g.tile_skip) {
-        int want = (int)hoig_cdiv(512, a.nblk);
+    static const int sk_target = getenv("HOIG_SPLITK_TARGET") ? atoi(getenv("HOIG_SPLITK_TARGET")) : 1024;   // (sweep 512 / 768 / 1024: 2.07 / 1.90 / 1.91 ms for the attention forward GEMMs)
+    static const int sk_maxblk = getenv("HOIG_SPLITK_MAXBLK") ? atoi(getenv("HOIG_SPLITK_MAXBLK")) : 192;
+    if (a.nblk < sk_maxblk && steps >= 32 && a.act == HOIG_ACT_NONE && !a.g.tile_skip) {
+        int want = (int)hoig_cdiv(sk_target, a.nblk);
         if (want > steps / 8) want = steps / 8;
         if (want > 1) {
             a.steps_per_split = (int)hoig_cdiv(steps, want);
