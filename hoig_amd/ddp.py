@@ -13,6 +13,8 @@ at construction, gradients averaged over ranks once per optimiser step -- but de
 The averaging factor 1/world is folded into the Adam kernel (grad_scale), not a separate pass.
 Works on CPU tensors with the gloo backend too (tests/test_ddp_gloo.py, world_size 2).
 """
+import os
+
 import torch
 import torch.distributed as dist
 
@@ -22,10 +24,17 @@ def _is_dist():
 
 
 class GradSync(object):
-    def __init__(self, flat_param, flat_grad, bucket_bytes=64 << 20, group=None):
+    def __init__(self, flat_param, flat_grad, bucket_bytes=64 << 20, group=None, force=None):
+        """`force` (default: env HOIG_DDP_FORCE=1): run the collectives even in a world of one rank, so that the whole
+        exchange path -- RCCL all-reduce per slice, stream ordering, sliced Adam -- executes on a single-GPU box
+        (tests/test_ddp_rccl_gpu.py); a one-rank SUM leaves the gradients unchanged."""
         self.flat_param, self.flat_grad = flat_param, flat_grad
         self.group = group
-        self.world = dist.get_world_size(group) if (dist.is_available() and dist.is_initialized()) else 1
+        inited = dist.is_available() and dist.is_initialized()
+        self.world = dist.get_world_size(group) if inited else 1
+        if force is None:
+            force = os.environ.get('HOIG_DDP_FORCE', '0') == '1'
+        self.active = self.world > 1 or (bool(force) and inited)
         n = flat_grad.numel()
         per = max(1, bucket_bytes // 4)
         self.slices = [(s, min(n, s + per)) for s in range(0, n, per)]
@@ -33,12 +42,12 @@ class GradSync(object):
     def broadcast_params(self, src=0):
         """DDP-constructor behaviour: make rank 0's (unseeded, CPU-RNG) initialisation the one everybody uses
         (trainer.py:233-239)."""
-        if self.world > 1:
+        if self.active:
             dist.broadcast(self.flat_param, src=src, group=self.group)
 
     def all_reduce_grads(self):
         """SUM over ranks, in place; returns the scale (1/world) the optimiser must apply."""
-        if self.world > 1:
+        if self.active:
             from .ops import join_wgrad_streams
             join_wgrad_streams()
             handles = [dist.all_reduce(self.flat_grad[a:b], op=dist.ReduceOp.SUM, group=self.group, async_op=True)
@@ -51,7 +60,7 @@ class GradSync(object):
         """All slices are submitted at once; yields each slice's (begin, end) once its exchange has been waited for (on NCCL
         / RCCL `wait()` only orders the current stream behind the collective), so a consumer can start on slice i while
         slices i+1.. are still in flight."""
-        if self.world <= 1:
+        if not self.active:
             yield (0, self.flat_grad.numel())
             return
         from .ops import join_wgrad_streams

@@ -36,6 +36,9 @@ class ObjectTables(object):
             raise ValueError('fim_uv / wim_uv must cover the 256 x 640 atlas')
         if self.faces_uv_coord.numel() != self.n_faces * 6 or self.obj_tex_img.numel() != S * S * 3:
             raise ValueError('faces_uv_coord must be (1,F,3,2) and obj_tex_img (256,256,3)')
+        lo, hi = int(self.fim_uv.min()), int(self.fim_uv.max())          # once per object, at construction
+        if lo < -1 or hi >= self.n_faces:
+            raise IndexError('fim_uv holds face indices in [%d, %d]; the object has %d faces' % (lo, hi, self.n_faces))
 
 
 def _dev(t, dtype, name):
@@ -45,12 +48,14 @@ def _dev(t, dtype, name):
 
 
 def prepare_inputs(src_img, ref_img, src_faces, src_fim, src_wim, ref_fim, ref_wim, tables, bg_both=False, dexycb=False,
-                   validate=False):
+                   validate=True):
     """trainer.py:46-145 after the rasteriser.  src_img / ref_img (B,3,256,256); src_faces (B,F,3,3) as returned by
     render_fim_wim for the SOURCE view (rows beyond a sample's own face count are ignored); *_fim (B,256,256) integer,
     *_wim (B,256,256,3); tables: one ObjectTables per sample; dexycb: the DexYCB copy's hand inputs (12 channels: + the six
-    hand-part one-hots, HOIG_DexYCB/models/trainer.py:131,135); validate: check on the host that every face index addresses
-    its sample's tables (the reference's indexing would raise; the kernels do not check) -- costs a device synchronisation.
+    hand-part one-hots, HOIG_DexYCB/models/trainer.py:131,135); validate (default on): check that every face index addresses
+    its sample's tables, as the reference's indexing would raise IndexError (the kernels index unchecked: an out-of-range face
+    would be a device memory fault) -- one small reduction and one host read per batch; pass False only for inputs that come
+    straight from hoig_amd.raster, whose indices are in range by construction.
     Returns (input_G_src_bg, input_G_tsf_bg | None, input_G_src_obj, input_G_tsf_obj, input_G_src_hand, input_G_ref_hand,
     T_hand, src_crop_mask_bg, ref_crop_mask_bg, src_crop_mask_hand, ref_crop_mask_hand, None)."""
     B = int(src_img.shape[0])
@@ -63,9 +68,11 @@ def prepare_inputs(src_img, ref_img, src_faces, src_fim, src_wim, ref_fim, ref_w
     src_fim, ref_fim = _dev(src_fim, torch.int32, 'src_fim'), _dev(ref_fim, torch.int32, 'ref_fim')
     src_wim, ref_wim = _dev(src_wim, torch.float32, 'src_wim'), _dev(ref_wim, torch.float32, 'ref_wim')
     if validate:
+        # one reduction + one host read for the whole batch: [B,4] = (min, max) of the two index maps of every sample
+        rng = torch.stack([src_fim.amin(dim=(1, 2)), src_fim.amax(dim=(1, 2)), ref_fim.amin(dim=(1, 2)),
+                           ref_fim.amax(dim=(1, 2))], dim=1).cpu().tolist()
         for i, tb in enumerate(tables):
-            for name, fim in (('src_fim', src_fim), ('ref_fim', ref_fim)):
-                lo, hi = int(fim[i].min()), int(fim[i].max())
+            for name, lo, hi in (('src_fim', rng[i][0], rng[i][1]), ('ref_fim', rng[i][2], rng[i][3])):
                 if lo < -1 or hi >= tb.n_faces:
                     raise IndexError('%s[%d] holds face indices in [%d, %d]; the sample has %d faces' % (name, i, lo, hi,
                                                                                                       tb.n_faces))

@@ -12,6 +12,8 @@ trainer.py:14-185).  ``set_input`` therefore accepts the tensors that stage prod
 with the keys of ``hoig_amd.synthetic.make_inputs`` -- and raises for raw dataloader batches.
 """
 import math
+import os
+import sys
 from collections import OrderedDict
 
 import numpy as np
@@ -120,10 +122,30 @@ class Trainer(BaseModel):
         self._armask_src = self._armask_tsf = None
 
     def _init_losses(self, use_ddp=False):
+        """trainer.py:302-304 builds ``Vgg19()`` = torchvision's ImageNet-pretrained VGG19.  Those weights are looked for at
+        ``opt.vgg_weights`` (a ``vgg19().features`` or full-model state_dict), then in torch hub's cache, where torchvision
+        itself would have put them.  Without them the perceptual loss would be computed against a random feature extractor:
+        that is refused unless the caller opts in with ``opt.vgg_surrogate=True`` (benchmarks and parity tests, where both
+        sides carry the same deterministic surrogate weights)."""
         vgg_net = Vgg19()
         vgg_path = getattr(self._opt, 'vgg_weights', None)
+        if not vgg_path:
+            hub = os.path.join(torch.hub.get_dir(), 'checkpoints', 'vgg19-dcbb9e9d.pth')
+            vgg_path = hub if os.path.exists(hub) else None
         if vgg_path:
-            vgg_net.load_torchvision_features(torch.load(vgg_path, map_location='cpu'))
+            sd = torch.load(vgg_path, map_location='cpu')
+            if any(k.startswith('features.') for k in sd):
+                sd = {k[len('features.'):]: v for k, v in sd.items() if k.startswith('features.')}
+            vgg_net.load_torchvision_features(sd)
+        elif self._opt.use_vgg and not getattr(self._opt, 'vgg_surrogate', False):
+            raise RuntimeError(
+                'Trainer: --use_vgg needs the ImageNet VGG19 weights (the reference downloads them through torchvision, '
+                'models/networks/vgg19.py:56); none found at opt.vgg_weights or in %s.  Pass --vgg_weights <vgg19 .pth>, or '
+                'opt in to deterministic surrogate weights with opt.vgg_surrogate=True (benchmarks / parity tests only: the '
+                'perceptual loss is then NOT the reference\'s).' % os.path.join(torch.hub.get_dir(), 'checkpoints'))
+        elif self._opt.use_vgg:
+            print('hoig_amd.Trainer: WARNING: VGG19 perceptual loss runs on SURROGATE (random He-normal) weights '
+                  '(opt.vgg_surrogate=True)', file=sys.stderr)
         if self._opt.use_vgg:
             self._crt_tsf = VGGLoss(vgg=vgg_net)
         z = lambda: torch.zeros((), device=self.device)
@@ -248,7 +270,7 @@ class Trainer(BaseModel):
     def _step(self, net, optimizer, overlap):
         """gradient exchange (RCCL, under DDP) + fused Adam; for G both run on the side stream, overlapped with the D step
         that follows on the main stream."""
-        ddp = isinstance(net, FlatDDP) and self._world > 1
+        ddp = isinstance(net, FlatDDP) and net.sync.active
         if overlap:
             # the D step that follows never touches G's parameters: G's exchange + Adam (HBM-bound, 5 GB of traffic) run on
             # the side stream beside it; forward() waits for the event before the next use of G

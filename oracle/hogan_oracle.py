@@ -2,7 +2,8 @@
 
 TEST INFRASTRUCTURE ONLY.  Only ``tests/``, ``__graft_entry__.smoke()`` and
 ``bench.py``'s ``cpu_baseline`` leg may import this file; the product package
-``hoig_amd`` never does (tests/test_no_oracle_in_product.py enforces it).
+``hoig_amd`` never does (tests/test_host_cpu.py::test_product_never_imports_the_oracle
+enforces it).
 
 What it is: a functional, state-dict driven restatement in plain fp32 PyTorch
 (CPU) of the reference's algorithm for the path SURVEY.md §8a lists -- the

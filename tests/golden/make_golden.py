@@ -9,6 +9,11 @@ Provenance per file:
   hov3_spade_attn_64.npz  generator_spade_attn (default): reference composition code (extract_attn.py,
                           generator.py:480-491) over the ORACLE's K1-K4 (the CUDA kernels cannot run on CPU)
                           -> 'composition-pinned'.
+  hov3_spade_attn_tiny_64.npz  generator_spade_attn_tiny (attention on layers 4-9 only): composition-pinned likewise.
+  hov3_base_64.npz        generator_base (no SPADE, grid_sample warping): fully pinned.
+  dexycb_spade_attn_64.npz  the HOIG_DexYCB copy of the trainer (HOIG_DexYCB/models/trainer.py: bg 13, hand cond 9,
+                          D input 24 channels, no arm mask), generator_spade_attn: composition-pinned.
+Usage:  python tests/golden/make_golden.py <gen_name> [hov3|dexycb]      (one reference copy per process)
 """
 import os
 import sys
@@ -25,24 +30,27 @@ SEEDS = dict(G=8, D=9, VGG=10, inputs=8)
 OUT_NAMES = ['fake_src_bg', 'fake_tsf_bg', 'fake_src_imgs', 'fake_tsf_imgs', 'fake_masks_bg', 'fake_masks_hand']
 
 
-def run(gen_name, fname, side=64, batch=2, steps=2):
+def run(gen_name, fname, side=64, batch=2, steps=2, copy='hov3'):
     opt = RH.namespace(gen_name=gen_name)
-    t = RH.build_reference_trainer(opt)
-    cfg = O.make_cfg(gen_name)
+    t = RH.build_reference_trainer(opt, copy=copy)
+    cfg = O.make_cfg(gen_name, copy)
     sdG = O.make_weights(O.gen_param_shapes(cfg), seed=SEEDS['G'], mode='random')
     sdD = O.make_weights(O.disc_param_shapes(cfg), seed=SEEDS['D'], mode='random')
     sdV = O.make_weights(O.vgg_param_shapes(), seed=SEEDS['VGG'], kind='vgg')
     t._G.load_state_dict(sdG)
     t._D.load_state_dict(sdD)
     t._crt_tsf.vgg.load_state_dict(sdV)
-    inp = synthetic.make_inputs(batch, side, seed=SEEDS['inputs'])
+    inp = synthetic.make_inputs(batch, side, seed=SEEDS['inputs'], dataset=copy)
     for k, v in inp.items():
         setattr(t, '_' + k, v.clone())
     out = dict(gen_name=gen_name, side=side, batch=batch, steps=steps, **{'seed_' + k: v for k, v in SEEDS.items()})
+    if copy != 'hov3':
+        out['copy'] = copy
     with torch.no_grad():
         for name, v in zip(OUT_NAMES, t.forward()):
             out['fwd_' + name] = v.numpy().astype(np.float32)
-        tsf_cond = torch.cat([inp['input_G_tsf_obj'][:, 3:], inp['input_G_tsf_hand'][:, 3:], inp['armask_tsf']], 1)
+        tsf_cond = torch.cat([inp['input_G_tsf_obj'][:, 3:], inp['input_G_tsf_hand'][:, 3:]] +
+                             ([inp['armask_tsf']] if copy == 'hov3' else []), 1)
         out['d_real_out'] = t._D.forward(torch.cat([inp['real_tsf'], tsf_cond], 1)).numpy()
     errs = []
     for s in range(steps):
@@ -56,12 +64,14 @@ def run(gen_name, fname, side=64, batch=2, steps=2):
             out['grad_G_bg_model.model.0.weight'] = t._G.bg_model.model[0].weight.grad.numpy().copy()
             out['grad_G_tsf_model.img_reg.0.weight'] = t._G.tsf_model.img_reg[0].weight.grad.numpy().copy()
             # (a conv bias feeding an instance norm has an identically-zero gradient: pick the SPADE gamma bias instead)
-            out['grad_G_src_model.resnets.0.norm_0.mlp_gamma.bias'] = \
-                t._G.src_model.resnets[0].norm_0.mlp_gamma.bias.grad.numpy().copy()
+            if hasattr(t._G.src_model.resnets[0], 'norm_0'):
+                out['grad_G_src_model.resnets.0.norm_0.mlp_gamma.bias'] = \
+                    t._G.src_model.resnets[0].norm_0.mlp_gamma.bias.grad.numpy().copy()
             out['grad_G_obj_model.skippers.2.0.weight'] = t._G.obj_model.skippers[2][0].weight.grad.numpy().copy()
             if hasattr(t._G, 'attn_9'):
                 out['grad_G_attn_9.fully_connect_layer.2.weight'] = \
                     t._G.attn_9.fully_connect_layer[2].weight.grad.numpy().copy()
+            if hasattr(t._G, 'attn_2'):
                 out['grad_G_attn_2.fully_connect_layer.0.bias'] = \
                     t._G.attn_2.fully_connect_layer[0].bias.grad.numpy().copy()
     out['error_keys'] = np.array(list(e.keys()))
@@ -80,4 +90,7 @@ def run(gen_name, fname, side=64, batch=2, steps=2):
 
 if __name__ == '__main__':
     which = sys.argv[1] if len(sys.argv) > 1 else 'generator_spade_attn'
-    run(which, {'generator_spade_attn': 'hov3_spade_attn_64.npz', 'generator_spade': 'hov3_spade_64.npz'}[which])
+    copy = sys.argv[2] if len(sys.argv) > 2 else 'hov3'
+    short = {'generator_spade_attn': 'spade_attn', 'generator_spade': 'spade', 'generator_base': 'base',
+             'generator_spade_attn_tiny': 'spade_attn_tiny'}[which]
+    run(which, '%s_%s_64.npz' % (copy, short), copy=copy)

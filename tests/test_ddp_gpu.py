@@ -1,7 +1,8 @@
 """The N>1 training step ON THE GPU: two ranks share cuda:0 and exchange gradients over gloo (RCCL refuses two ranks on one
 device; the collective is the only thing that differs from the 8-GPU run), through the real Trainer with use_ddp=True --
 flat-buffer broadcast, G's exchange + Adam on the side stream beside the D step, weight gradients on their side stream.
-Checks: both ranks end with identical weights, and the averaged gradient (read from Adam's first moment after one step,
+Checks: both ranks end with identical weights, the averaged gradient equals the ORACLE's gradient of the combined batch,
+and the averaged gradient (read from Adam's first moment after one step,
 (1 - beta1) * g) equals that of a single-process step on the combined batch (mean-reduced losses + per-sample instance norm
 make data parallelism exact up to summation order; the weights themselves move by ~lr*sign(g) in Adam's first step, so
 rounding-level gradient elements may flip and are not compared element-wise)."""
@@ -41,9 +42,8 @@ def _slice(inputs, lo, hi):
 
 def _run(rank, world, port, q):
     import torch.distributed as dist
-    from common import opt_namespace
+    from common import product_trainer, SEEDS
     from hoig_amd import ops, synthetic
-    from hoig_amd.models import ModelsFactory
     ddp = world > 1
     if ddp:
         os.environ['MASTER_ADDR'] = '127.0.0.1'
@@ -51,12 +51,10 @@ def _run(rank, world, port, q):
         dist.init_process_group('gloo', rank=rank, world_size=world)
     torch.cuda.set_device(0)
     ops.set_precision('bf16x3')
-    torch.manual_seed(77)                          # same init on every rank and in the single-process run
-    opt = opt_namespace(gen_name='generator_spade_attn', local_rank=0, image_size=SIDE)
-    model = ModelsFactory.get_by_name('trainer', opt, use_ddp=ddp)
+    batch = synthetic.make_inputs(2, SIDE, seed=SEEDS['inputs'])
+    # the seeded weights of the parity tests (the oracle below starts from the same ones)
+    model = product_trainer('generator_spade_attn', 2, SIDE, use_ddp=ddp, inputs=_slice(batch, rank, rank + 1) if ddp else batch)
     model.set_train()
-    batch = synthetic.make_inputs(2, SIDE, seed=8)
-    model.set_input(_slice(batch, rank, rank + 1) if ddp else batch)
     g = model._G.module if ddp else model._G
     before = {k: g.state_dict()[k].cpu().numpy().copy() for k in PROBE}
     for _ in range(STEPS):
@@ -88,13 +86,23 @@ def _spawn(world):
 def test_trainer_ddp_world2_matches_single_process():
     (_, w0, b0, s0, m0), (_, w1, b1, s1, m1) = _spawn(2)
     (_, ws, bs, _, ms), = _spawn(1)
+    # the ORACLE's gradient of the combined batch of 2 (what DDP's average over the two 1-sample ranks must equal:
+    # mean-reduced losses, per-sample instance norm): models/trainer.py:425-434 on the CPU restatement
+    from common import oracle_trainer
+    ot = oracle_trainer('generator_spade_attn', 2, SIDE)
+    ot.optimize_parameters()
     for k in PROBE:
+        want = ot.G[k].grad.numpy()
+        got = m0[k] / (1.0 - 0.5)                      # Adam's first moment after one step = (1 - beta1) * g, beta1 = 0.5
+        rel_o = np.linalg.norm(got - want) / np.linalg.norm(want)
+        print('ddp vs ORACLE  %-44s gradient rel-L2 %.2e' % (k, rel_o))
+        assert rel_o < 2e-2, (k, rel_o)
         assert np.array_equal(b0[k], b1[k]) and np.array_equal(b0[k], bs[k]), k      # same start everywhere
         assert np.array_equal(w0[k], w1[k]) and np.array_equal(m0[k], m1[k]), k      # ranks stay bit-identical
         assert np.linalg.norm(ms[k]) > 0
         rel = np.linalg.norm(m0[k] - ms[k]) / np.linalg.norm(ms[k])                  # averaged gradient == combined-batch gradient
         print('ddp vs single  %-44s gradient rel-L2 %.2e' % (k, rel))
-        assert rel < 5e-2, (k, rel)
+        assert rel < 2e-2, (k, rel)
         # and the weights moved the same way for the bulk of the elements
         agree = np.mean(np.sign(w0[k] - b0[k]) == np.sign(ws[k] - bs[k]))
         print('                %-44s update sign agreement %.3f' % (k, agree))

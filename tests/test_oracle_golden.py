@@ -7,12 +7,17 @@ import torch
 from common import oracle_trainer, load_golden, OUT_NAMES
 
 
-@pytest.mark.parametrize('gen_name,fname', [('generator_spade_attn', 'hov3_spade_attn_64.npz'),
-                                            ('generator_spade', 'hov3_spade_64.npz')])
+GOLDEN = [('generator_spade_attn', 'hov3_spade_attn_64.npz'), ('generator_spade', 'hov3_spade_64.npz'),
+          ('generator_spade_attn_tiny', 'hov3_spade_attn_tiny_64.npz'), ('generator_base', 'hov3_base_64.npz'),
+          ('generator_spade_attn', 'dexycb_spade_attn_64.npz')]
+
+
+@pytest.mark.parametrize('gen_name,fname', GOLDEN)
 def test_oracle_matches_reference_golden(gen_name, fname):
     g = load_golden(fname)
     assert str(g['gen_name']) == gen_name
-    ot = oracle_trainer(gen_name, int(g['batch']), int(g['side']))
+    dataset = str(g['copy']) if 'copy' in g.files else 'hov3'
+    ot = oracle_trainer(gen_name, int(g['batch']), int(g['side']), dataset=dataset)
     assert list(ot.G.keys()) == [str(s) for s in g['param_names_G']]
     assert list(ot.D.keys()) == [str(s) for s in g['param_names_D']]
     with torch.no_grad():
