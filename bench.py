@@ -27,7 +27,11 @@ sys.path.insert(0, ROOT)          # the product package only; tests/ + oracle/ a
 
 GFLOP_PER_PAIR_TRAIN_256 = 2555.2      # BASELINE.md §2 / SURVEY.md §8d (3*G + 3*VGG + 9*D), generator_spade_attn
 PMC_FILES = ['r02_pmc_dominant_conv.json', 'r01_pmc_dominant_conv.json']      # newest first
-PEAK = {'f32': 157.3, 'bf16x3': 2500.0, 'bf16': 2500.0}          # TFLOP/s dense MFMA, MI355X_MICROARCH.md
+PEAK_F32, PEAK_16 = 157.3, 2500.0          # TFLOP/s dense MFMA (fp32 / fp16-bf16), MI355X_MICROARCH.md
+DTYPE_NAMES = {'bf16x3': 'f16x3 fwd / bf16x3 bwd (both operands split hi+lo in 16-bit halves, 3 MFMAs per product, f32 accumulate)',
+               'f16x2': 'f16x2 fwd / bf16x2 bwd (gathered operand split hi+lo, weights single 16-bit, 2 MFMAs per product, f32 accumulate)',
+               'bf16': 'f16 fwd / bf16 bwd (single-pass 16-bit operands, f32 accumulate)', 'f32': 'f32 (v_mfma_f32_32x32x2_f32)'}
+MFMA_TERMS = {'f32': 1, 'bf16x3': 3, 'f16x3': 3, 'f16x2': 2, 'bf16x2': 2, 'bf16': 1, 'f16': 1}      # issued MFMAs per algorithmic one
 
 
 def dominant_kernel_roofline(batch, side, precision, iters=50):
@@ -58,21 +62,24 @@ def dominant_kernel_roofline(batch, side, precision, iters=50):
     # HBM/fabric traffic of this kernel comes from separate rocprofv3 --pmc passes (FETCH_SIZE and WRITE_SIZE cannot
     # share a pass); the committed summary is attached when it was taken on the same kernel and shape
     traffic, traffic_source = None, None
+    fwd_prec = precision.partition(':')[0]
     for fn in PMC_FILES:
         try:
             pmc = json.load(open(os.path.join(ROOT, 'profiles', fn)))
         except Exception:
             continue
-        if pmc.get('precision', 'bf16x3') == precision and batch == pmc.get('images', 16) and side == 256:
+        if pmc.get('precision', 'bf16x3') == fwd_prec and batch == pmc.get('images', 16) and side == 256:
             traffic = pmc['traffic_bytes_per_launch']
             traffic_source = ('profiles/%s: separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes over this kernel and shape, '
                               'committed; NOT measured in this run (counters cannot be read from inside the process)' % fn)
             break
     achieved = flops / (ms * 1e-3) / 1e12
-    kname = 'igemm_f32_kernel' if precision == 'f32' else 'conv_halo3_bf16_kernel<%d,4,2,128,2,true>' % (2 if precision == 'bf16x3' else 1)
+    fwd = precision.partition(':')[0]
+    peak = PEAK_F32 if fwd == 'f32' else PEAK_16
+    kname = 'igemm_f32_kernel' if fwd == 'f32' else 'conv_halo3_bf16_kernel<%d,4,2,128,2,true>' % {3: 2, 2: 3, 1: 1}[MFMA_TERMS[fwd]]
     return dict(bound='mfma', kernel='%s (conv3x3 s1 512->512 @%dx%d, %d images = src+tsf stacked)' % (kname, h, h, batch),
-                achieved=round(achieved, 2), peak=PEAK[precision], unit='TFLOP/s',
-                frac=round(achieved / PEAK[precision], 4), traffic=traffic, traffic_source=traffic_source, avg_launch_ms=round(ms, 4),
+                achieved=round(achieved, 2), peak=peak, unit='TFLOP/s', mfma_terms_per_product=MFMA_TERMS[fwd],
+                frac=round(achieved / peak, 4), traffic=traffic, traffic_source=traffic_source, avg_launch_ms=round(ms, 4),
                 algorithmic_flop_per_launch=flops)
 
 
@@ -315,7 +322,7 @@ def main():
             'metric': 'HOGAN train images/sec at %dx%d' % (args.side, args.side),
             'value': round(value, 3), 'unit': 'images/s', 'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
             'ms_per_step': round(ms, 3), 'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
-            'dtype': {'bf16x3': 'f16x3 fwd / bf16x3 bwd (split 16-bit operands, f32 accumulate)'}.get(args.precision, args.precision),
+            'dtype': DTYPE_NAMES.get(args.precision, args.precision),
             'data': 'synthetic',
             'config': {'workload': '%dx%d %s-shaped synthetic, batch %d per GPU, G+D full step (%s, VGG19 '
                                    'surrogate weights)' % (args.side, args.side, 'HO3Dv3' if args.dataset == 'hov3' else 'DexYCB',

@@ -15,7 +15,7 @@ HEADER_PATH = os.path.join(os.path.dirname(_HERE), 'include', 'hoig_kernels.h')
 
 OK, EINVAL, ELAUNCH, EUNSUPPORTED = 0, -1, -2, -3
 ACT_NONE, ACT_RELU, ACT_LRELU, ACT_TANH, ACT_SIGMOID = 0, 1, 2, 3, 4
-PREC_F32, PREC_BF16X3, PREC_BF16 = 0, 1, 2
+PREC_F32, PREC_BF16X3, PREC_BF16, PREC_F16X2 = 0, 1, 2, 3
 LOSS_L1, LOSS_MSE, LOSS_BCE = 0, 1, 2
 _ERR = {EINVAL: 'invalid argument', ELAUNCH: 'kernel launch failed', EUNSUPPORTED: 'unsupported shape'}
 
@@ -66,10 +66,10 @@ _SIGS = {
     'hoig_inorm_bwd': [_vp, _vp, _vp, _i, _vp, _vp, _vp, _vp, _i, _f, _vp, _vp, _vp, _i, _i, _i, _vp, _vp],
     'hoig_replicate_pad_fwd': [_vp, _vp, _i, _i, _i, _i, _i, _vp],
     'hoig_replicate_pad_bwd': [_vp, _vp, _i, _i, _i, _i, _i, _vp],
-    'hoig_attn_sample_fwd': [_vp, _vp, _vp, _i, _i, _i, _i, _vp],
-    'hoig_attn_sample_bwd': [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp],
-    'hoig_attn_pixel_fwd': [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _vp],
-    'hoig_attn_pixel_bwd': [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _vp],
+    'hoig_attn_sample_bwd': [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp],
+    'hoig_attn_pixel_fwd': [_vp] * 9 + [_i, _i, _i, _i, _vp],
+    'hoig_attn_pixel_bwd': [_vp] * 9 + [_i, _i, _i, _i, _vp],
+    'hoig_attn_gs_scatter': [_vp, _vp, _vp, _i, _i, _i, _vp],
     'hoig_block_extractor_forward': [_vp, _vp, _vp] + [_i] * 7 + [_vp],
     'hoig_block_extractor_backward': [_vp] * 5 + [_i] * 7 + [_vp],
     'hoig_local_attn_reshape_forward': [_vp, _vp] + [_i] * 4 + [_vp],

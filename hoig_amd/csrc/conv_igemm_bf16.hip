@@ -21,6 +21,26 @@
 
 namespace {
 
+// Number of 16-bit MFMA terms per algorithmic product, as the launchers' runtime `ns` and the kernels' NSX template value:
+//   1 : a*b ~= ah*bh                       one plane per operand                      (HOIG_PREC_BF16)
+//   2 : a*b ~= ah*bh + al*bh + ah*bl       both operands split hi + lo   (3 MFMAs)    (HOIG_PREC_BF16X3)
+//   3 : a*b ~= ah*bh + al*bh               A split, B = its rounded hi plane only (2 MFMAs: the B-side -- weight -- LDS image,
+//                                          its L2 stream and the ah*bl pass are dropped)                (HOIG_PREC_F16X2)
+#define HOIG_NS_SWITCH(ns, ...)                                                \
+    do {                                                                       \
+        if ((ns) == 2) { constexpr int NSX = 2; __VA_ARGS__; }                 \
+        else if ((ns) == 3) { constexpr int NSX = 3; __VA_ARGS__; }            \
+        else { constexpr int NSX = 1; __VA_ARGS__; }                           \
+    } while (0)
+__host__ __device__ constexpr int ns_a(int nsx) { return nsx == 1 ? 1 : 2; }
+__host__ __device__ constexpr int ns_b(int nsx) { return nsx == 2 ? 2 : 1; }
+inline int ns_of_precision(int precision) {
+    return precision == HOIG_PREC_BF16X3 ? 2 : (precision == HOIG_PREC_F16X2 ? 3 : 1);
+}
+inline bool is_16bit_precision(int precision) {
+    return precision == HOIG_PREC_BF16X3 || precision == HOIG_PREC_BF16 || precision == HOIG_PREC_F16X2;
+}
+
 struct Geom {
     int Bn, Hg, Wg, Cg;
     int Hp, Wp;
@@ -155,8 +175,9 @@ __device__ __forceinline__ int lds_off(int row, int k) {
     return row * (BK * 2) + (((k >> 3) ^ lds_swz<BK>(row)) << 4) + ((k & 4) << 1);
 }
 
-template <int BM, int BN, int WM, int WN, int NS, int BK, bool F16>
+template <int BM, int BN, int WM, int WN, int NSX, int BK, bool F16>
 __global__ __launch_bounds__(WM * WN * 64) void igemm_bf16_kernel(const Args p) {
+    constexpr int NS = NSX == 1 ? 1 : 2, NB = NSX == 2 ? 2 : 1;      // operand planes: A (activations / dy), B (weights / x)
     constexpr int NT = WM * WN * 64;        // 256 or 512 threads
     constexpr int TM = BM / (32 * WM), TN = BN / (32 * WN);
     constexpr int TPR_A = BK / 4, TPR_B = BK / 8;      // threads per tile row: float4 gathers / 16-B weight chunks
@@ -164,7 +185,7 @@ __global__ __launch_bounds__(WM * WN * 64) void igemm_bf16_kernel(const Args p) 
     constexpr int RB = BN * TPR_B / NT;     // 16-B weight chunks per thread per plane
     constexpr int AROWS = NT / TPR_A, BROWS = NT / TPR_B;
     constexpr int PLANE_A = BM * BK * 2, PLANE_B = BN * BK * 2;
-    constexpr int STAGE = NS * (PLANE_A + PLANE_B);
+    constexpr int STAGE = NS * PLANE_A + NB * PLANE_B;
     // two LDS stages: k-block t is multiplied out of one while k-block t+1 is converted into the other -> ONE barrier
     // per k-block; 64 KB at 128x128 (2 workgroups per CU)
     // BK = 32: ONE stage (32 KB at 128x128) so that four or five workgroups share a CU and cover each other's waits
@@ -223,7 +244,7 @@ __global__ __launch_bounds__(WM * WN * 64) void igemm_bf16_kernel(const Args p) 
         const int n = n0 + brow + BROWS * i;
         const size_t o = plane_index(n, bchunk * 8, p.K);
         wrow_h[i] = n < p.N ? p.Wh + o : nullptr;
-        wrow_l[i] = (NS == 2 && n < p.N) ? p.Wl + o : nullptr;
+        wrow_l[i] = (NB == 2 && n < p.N) ? p.Wl + o : nullptr;
     }
     int aoff[RA], boff[RB];
 #pragma unroll
@@ -267,7 +288,7 @@ __global__ __launch_bounds__(WM * WN * 64) void igemm_bf16_kernel(const Args p) 
 #pragma unroll
         for (int i = 0; i < RB; ++i) {
             rbh[i] = wrow_h[i] ? *reinterpret_cast<const uint4 *>(wrow_h[i] + (size_t)(wk + c) * 32) : make_uint4(0, 0, 0, 0);
-            if (NS == 2)
+            if (NB == 2)
                 rbl[i] = wrow_l[i] ? *reinterpret_cast<const uint4 *>(wrow_l[i] + (size_t)(wk + c) * 32) : make_uint4(0, 0, 0, 0);
         }
     };
@@ -284,7 +305,7 @@ __global__ __launch_bounds__(WM * WN * 64) void igemm_bf16_kernel(const Args p) 
 #pragma unroll
         for (int i = 0; i < RB; ++i) {
             *reinterpret_cast<uint4 *>(Bh + boff[i]) = rbh[i];
-            if (NS == 2) *reinterpret_cast<uint4 *>(Bl + boff[i]) = rbl[i];
+            if (NB == 2) *reinterpret_cast<uint4 *>(Bl + boff[i]) = rbl[i];
         }
     };
     int aread[TM], bread[TN];       // ds_read_b128 offsets of this lane's fragments for ks = 0 (ks = 1: chunk ^ 2)
@@ -324,16 +345,15 @@ __global__ __launch_bounds__(WM * WN * 64) void igemm_bf16_kernel(const Args p) 
             for (int j = 0; j < TN; ++j) {
                 const int off = bread[j] ^ (ks << 5);
                 bhf[j] = *reinterpret_cast<const bf16x8 *>(Bh + off);
-                if (NS == 2) blf[j] = *reinterpret_cast<const bf16x8 *>(Bl + off);
+                if (NB == 2) blf[j] = *reinterpret_cast<const bf16x8 *>(Bl + off);
             }
 #pragma unroll
             for (int i = 0; i < TM; ++i)
 #pragma unroll
                 for (int j = 0; j < TN; ++j) {
-                    if (NS == 2) {
+                    if (NS == 2)
                         acc[i][j] = mfma16<F16>(al[i], bhf[j], acc[i][j]);
-                        acc[i][j] = mfma16<F16>(ah[i], blf[j], acc[i][j]);
-                    }
+                        if (NB == 2) acc[i][j] = mfma16<F16>(ah[i], blf[j], acc[i][j]);
                     acc[i][j] = mfma16<F16>(ah[i], bhf[j], acc[i][j]);
                 }
         }
@@ -508,13 +528,8 @@ int launch(Args a, int ns, hipStream_t st) {
         }
     }
     dim3 grid(a.nblk, a.ksplit);
-    if (a.f16) {
-        if (ns == 2) igemm_bf16_kernel<BM, BN, WM, WN, 2, BK, true><<<grid, NT, 0, st>>>(a);
-        else igemm_bf16_kernel<BM, BN, WM, WN, 1, BK, true><<<grid, NT, 0, st>>>(a);
-    } else {
-        if (ns == 2) igemm_bf16_kernel<BM, BN, WM, WN, 2, BK, false><<<grid, NT, 0, st>>>(a);
-        else igemm_bf16_kernel<BM, BN, WM, WN, 1, BK, false><<<grid, NT, 0, st>>>(a);
-    }
+    if (a.f16) HOIG_NS_SWITCH(ns, igemm_bf16_kernel<BM, BN, WM, WN, NSX, BK, true><<<grid, NT, 0, st>>>(a));
+    else HOIG_NS_SWITCH(ns, igemm_bf16_kernel<BM, BN, WM, WN, NSX, BK, false><<<grid, NT, 0, st>>>(a));
     HOIG_LAUNCH_CHECK();
     return HOIG_OK;
 }
@@ -555,8 +570,9 @@ struct HaloArgs {
 #endif
 };
 
-template <int KS, int NS, int WN, int BN, bool F16>
+template <int KS, int NSX, int WN, int BN, bool F16>
 __global__ __launch_bounds__(128 * WN) void conv_halo_bf16_kernel(const HaloArgs p) {
+    constexpr int NS = NSX == 1 ? 1 : 2, NB = NSX == 2 ? 2 : 1;      // operand planes: A (activations / dy), B (weights / x)
     constexpr int TH = 4, TW = 32;
     constexpr int NT = 128 * WN;                           // 2 x WN waves: 256 or 512 threads
     constexpr int RB = BN * 4 / NT;                        // 16-B weight chunks per thread per plane
@@ -567,7 +583,7 @@ __global__ __launch_bounds__(128 * WN) void conv_halo_bf16_kernel(const HaloArgs
     static_assert(TN >= 1, "BN = 64 needs the 4-wave variant");
     // LDS: one halo stage + two weight stages = 64 KB at KS=3 -> two workgroups per CU
     constexpr int NBST = HOIG_HALO_BSTAGES;                // weight stages in LDS
-    __shared__ __attribute__((aligned(16))) unsigned char smem[NS * PLANE_A + NBST * NS * PLANE_B];
+    __shared__ __attribute__((aligned(16))) unsigned char smem[NS * PLANE_A + NBST * NB * PLANE_B];
     unsigned char *Ah = smem, *Al = smem + PLANE_A;
     unsigned char *Bst = smem + NS * PLANE_A;              // two stages of (Bh, Bl)
 
@@ -590,7 +606,7 @@ __global__ __launch_bounds__(128 * WN) void conv_halo_bf16_kernel(const HaloArgs
         const int n = n0 + brow + (NT / 4) * i;
         const size_t o = plane_index(n, bchunk * 8, p.K);
         wrow_h[i] = n < p.N ? p.Wh + o : nullptr;
-        wrow_l[i] = (NS == 2 && n < p.N) ? p.Wl + o : nullptr;
+        wrow_l[i] = (NB == 2 && n < p.N) ? p.Wl + o : nullptr;
         const int row = brow + (NT / 4) * i;
         boff[i] = row * 64 + ((bchunk ^ ((row >> 2) & 3)) << 4);
     }
@@ -625,15 +641,15 @@ __global__ __launch_bounds__(128 * WN) void conv_halo_bf16_kernel(const HaloArgs
 #pragma unroll
         for (int i = 0; i < RB; ++i) {
             rh[i] = wrow_h[i] ? *reinterpret_cast<const uint4 *>(wrow_h[i] + koff) : make_uint4(0, 0, 0, 0);
-            if (NS == 2) rl[i] = wrow_l[i] ? *reinterpret_cast<const uint4 *>(wrow_l[i] + koff) : make_uint4(0, 0, 0, 0);
+            if (NB == 2) rl[i] = wrow_l[i] ? *reinterpret_cast<const uint4 *>(wrow_l[i] + koff) : make_uint4(0, 0, 0, 0);
         }
     };
     auto store_b = [&](int stage, const uint4 (&rh)[RB], const uint4 (&rl)[RB]) {
-        unsigned char *Bh = Bst + stage * NS * PLANE_B, *Bl = Bh + PLANE_B;
+        unsigned char *Bh = Bst + stage * NB * PLANE_B, *Bl = Bh + PLANE_B;
 #pragma unroll
         for (int i = 0; i < RB; ++i) {
             *reinterpret_cast<uint4 *>(Bh + boff[i]) = rh[i];
-            if (NS == 2) *reinterpret_cast<uint4 *>(Bl + boff[i]) = rl[i];
+            if (NB == 2) *reinterpret_cast<uint4 *>(Bl + boff[i]) = rl[i];
         }
     };
     const float *Aimg = p.A + (size_t)b * p.H * p.W * p.Cg;
@@ -671,7 +687,7 @@ __global__ __launch_bounds__(128 * WN) void conv_halo_bf16_kernel(const HaloArgs
         const int tap = step % KK;
         const int r = tap / KS, s_ = tap - r * KS;
         const int tapoff = (r * HW + s_) * AROW;
-        const unsigned char *Bh = Bst + stage * NS * PLANE_B, *Bl = Bh + PLANE_B;
+        const unsigned char *Bh = Bst + stage * NB * PLANE_B, *Bl = Bh + PLANE_B;
 #pragma unroll
         for (int ks = 0; ks < 2; ++ks) {
             bf16x8 ah[TM], al[TM], bhf[TN], blf[TN];
@@ -685,16 +701,15 @@ __global__ __launch_bounds__(128 * WN) void conv_halo_bf16_kernel(const HaloArgs
             for (int j = 0; j < TN; ++j) {
                 const int off = bread[j] ^ (ks << 5);
                 bhf[j] = *reinterpret_cast<const bf16x8 *>(Bh + off);
-                if (NS == 2) blf[j] = *reinterpret_cast<const bf16x8 *>(Bl + off);
+                if (NB == 2) blf[j] = *reinterpret_cast<const bf16x8 *>(Bl + off);
             }
 #pragma unroll
             for (int i = 0; i < TM; ++i)
 #pragma unroll
                 for (int j = 0; j < TN; ++j) {
-                    if (NS == 2) {
+                    if (NS == 2)
                         acc[i][j] = mfma16<F16>(al[i], bhf[j], acc[i][j]);
-                        acc[i][j] = mfma16<F16>(ah[i], blf[j], acc[i][j]);
-                    }
+                        if (NB == 2) acc[i][j] = mfma16<F16>(ah[i], blf[j], acc[i][j]);
                     acc[i][j] = mfma16<F16>(ah[i], bhf[j], acc[i][j]);
                 }
         }
@@ -764,8 +779,9 @@ __global__ __launch_bounds__(128 * WN) void conv_halo_bf16_kernel(const HaloArgs
 // MODE 2: weight tiles double-buffered, halo single (WM = 4: 8 rows x 32 pixels per workgroup, 152 KB) -- the weight tile
 //         of a step is shared by twice the pixels, which halves the dominant L2 -> LDS stream: in-kernel stamps
 //         (tools/stamp_halo.py) show the 4x32 tile waiting on the per-CU fill path (~30 B/clk/CU), not on the MFMA
-template <int NS, int WM, int WN, int BN, int MODE, bool F16>
+template <int NSX, int WM, int WN, int BN, int MODE, bool F16>
 __global__ __launch_bounds__(64 * WM * WN) void conv_halo3_bf16_kernel(const HaloArgs p) {
+    constexpr int NS = NSX == 1 ? 1 : 2, NB = NSX == 2 ? 2 : 1;      // operand planes: A (activations / dy), B (weights / x)
     constexpr int KS = 3, TH = 2 * WM, TW = 32;
     constexpr int NT = 64 * WM * WN;
     constexpr bool DB = MODE == 1;
@@ -780,7 +796,7 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_halo3_bf16_kernel(const Hal
     // step's weights (and, at a channel-block boundary, the next halo) are written into the other buffer BEFORE this
     // step's multiply, one barrier per step, nothing but barrier skew is exposed.  160 KB exactly.
     constexpr int NBUF_A = MODE == 1 ? 2 : 1, NBUF_B = MODE == 0 ? 1 : 2;
-    constexpr int ABUF = NS * PLANE_A, BBUF = KS * NS * PLANE_B;
+    constexpr int ABUF = NS * PLANE_A, BBUF = KS * NB * PLANE_B;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];   // NBUF_A * ABUF + NBUF_B * BBUF
     unsigned char *Abase = smem;
     unsigned char *Bbase = smem + NBUF_A * ABUF;
@@ -808,7 +824,7 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_halo3_bf16_kernel(const Hal
         const size_t o = plane_index(n, bchunk * 8, p.K);
         const bool ok = n < p.N && (!B_PART || brow < BN);
         wrow_h[i] = ok ? p.Wh + o : nullptr;
-        wrow_l[i] = (NS == 2 && ok) ? p.Wl + o : nullptr;
+        wrow_l[i] = (NB == 2 && ok) ? p.Wl + o : nullptr;
         const int row = brow + (NT / 4) * i;
         boff[i] = row * 64 + ((bchunk ^ ((row >> 2) & 3)) << 4);
     }
@@ -841,7 +857,7 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_halo3_bf16_kernel(const Hal
 #pragma unroll
             for (int i = 0; i < RB; ++i) {
                 rbh[t][i] = wrow_h[i] ? *reinterpret_cast<const uint4 *>(wrow_h[i] + koff) : make_uint4(0, 0, 0, 0);
-                if (NS == 2)
+                if (NB == 2)
                     rbl[t][i] = wrow_l[i] ? *reinterpret_cast<const uint4 *>(wrow_l[i] + koff) : make_uint4(0, 0, 0, 0);
             }
         }
@@ -849,12 +865,12 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_halo3_bf16_kernel(const Hal
     auto store_b = [&](int buf) {
 #pragma unroll
         for (int t = 0; t < KS; ++t) {
-            unsigned char *Bh = Bbase + buf * BBUF + t * NS * PLANE_B, *Bl = Bh + PLANE_B;
+            unsigned char *Bh = Bbase + buf * BBUF + t * NB * PLANE_B, *Bl = Bh + PLANE_B;
 #pragma unroll
             for (int i = 0; i < RB; ++i) {
                 if (B_PART && brow >= BN) continue;
                 *reinterpret_cast<uint4 *>(Bh + boff[i]) = rbh[t][i];
-                if (NS == 2) *reinterpret_cast<uint4 *>(Bl + boff[i]) = rbl[t][i];
+                if (NB == 2) *reinterpret_cast<uint4 *>(Bl + boff[i]) = rbl[t][i];
             }
         }
     };
@@ -903,7 +919,7 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_halo3_bf16_kernel(const Hal
         auto read = [&](Frags &f, int i) {
             const int t = i >> 1, ks = i & 1;
             const int tapoff = (r * HW + t) * AROW;
-            const unsigned char *Bh = Bbase + bbuf * BBUF + t * NS * PLANE_B, *Bl = Bh + PLANE_B;
+            const unsigned char *Bh = Bbase + bbuf * BBUF + t * NB * PLANE_B, *Bl = Bh + PLANE_B;
 #pragma unroll
             for (int ii = 0; ii < TM; ++ii) {
                 const int off = aread[ii] + tapoff + ks * 32;
@@ -914,7 +930,7 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_halo3_bf16_kernel(const Hal
             for (int j = 0; j < TN; ++j) {
                 const int off = bread[j] ^ (ks << 5);
                 f.bh[j] = *reinterpret_cast<const bf16x8 *>(Bh + off);
-                if (NS == 2) f.bl[j] = *reinterpret_cast<const bf16x8 *>(Bl + off);
+                if (NB == 2) f.bl[j] = *reinterpret_cast<const bf16x8 *>(Bl + off);
             }
         };
         auto mma = [&](const Frags &f) {
@@ -922,10 +938,9 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_halo3_bf16_kernel(const Hal
             for (int ii = 0; ii < TM; ++ii)
 #pragma unroll
                 for (int j = 0; j < TN; ++j) {
-                    if (NS == 2) {
+                    if (NS == 2)
                         acc[ii][j] = mfma16<F16>(f.al[ii], f.bh[j], acc[ii][j]);
-                        acc[ii][j] = mfma16<F16>(f.ah[ii], f.bl[j], acc[ii][j]);
-                    }
+                        if (NB == 2) acc[ii][j] = mfma16<F16>(f.ah[ii], f.bl[j], acc[ii][j]);
                     acc[ii][j] = mfma16<F16>(f.ah[ii], f.bh[j], acc[ii][j]);
                 }
         };
@@ -1078,7 +1093,7 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_halo3_bf16_kernel(const Hal
 template <int NS, int WM, int WN, int BN, int MODE>
 int launch_halo3_one(const HaloArgs &a, hipStream_t st) {
     constexpr int HPIX = (2 * WM + 2) * 34;
-    constexpr size_t shm = (MODE == 1 ? 2 : 1) * (NS * (HPIX * 80)) + (MODE == 0 ? 1 : 2) * (3 * NS * (BN * 64));
+    constexpr size_t shm = (MODE == 1 ? 2 : 1) * (ns_a(NS) * (HPIX * 80)) + (MODE == 0 ? 1 : 2) * (3 * ns_b(NS) * (BN * 64));
     static bool once = false;
     if (!once) {
         if (hipFuncSetAttribute(reinterpret_cast<const void *>(&conv_halo3_bf16_kernel<NS, WM, WN, BN, MODE, true>),
@@ -1109,22 +1124,22 @@ int launch_halo3(HaloArgs a, int ns, hipStream_t st) {
     const bool n64 = (a.N % 128) != 0 || (a.C2 && a.n1 % 128 != 0);      // (a channel tile must not straddle the two outputs)
     a.nblk_n = (int)hoig_cdiv(a.N, n64 ? 64 : 128);
     a.nblk = a.Bn * a.tiles_x * a.tiles_y * a.nblk_n;
-    if (n64) return ns == 2 ? launch_halo3_one<2, 2, 2, 64, 0>(a, st) : launch_halo3_one<1, 2, 2, 64, 0>(a, st);
+    if (n64) HOIG_NS_SWITCH(ns, return launch_halo3_one<NSX, 2, 2, 64, 0>(a, st));
     if (a.H % 8 == 0 && a.nblk / 2 < 256 && a.nblk >= 192) {   // too few 8-row tiles at BN = 128: 8 rows x 64 channels
         a.tiles_y = a.H / 8;
         a.nblk_n = a.N / 64;
         a.nblk = a.Bn * a.tiles_x * a.tiles_y * a.nblk_n;
-        return ns == 2 ? launch_halo3_one<2, 4, 2, 64, 2>(a, st) : launch_halo3_one<1, 4, 2, 64, 2>(a, st);
+        HOIG_NS_SWITCH(ns, return launch_halo3_one<NSX, 4, 2, 64, 2>(a, st));
     }
     // 8 x 32 pixel tiles (8 waves, weight tile shared by 256 pixels) when that still gives every CU a workgroup
     if (a.H % 8 == 0 && a.nblk / 2 >= 256) {
         a.tiles_y = a.H / 8;
         a.nblk = a.Bn * a.tiles_x * a.tiles_y * a.nblk_n;
-        return ns == 2 ? launch_halo3_one<2, 4, 2, 128, 2>(a, st) : launch_halo3_one<1, 4, 2, 128, 2>(a, st);
+        HOIG_NS_SWITCH(ns, return launch_halo3_one<NSX, 4, 2, 128, 2>(a, st));
     }
     const bool wide = a.nblk < 384;
-    if (ns == 2) return wide ? launch_halo3_one<2, 2, 4, 128, 1>(a, st) : launch_halo3_one<2, 2, 2, 128, 0>(a, st);
-    return wide ? launch_halo3_one<1, 2, 4, 128, 1>(a, st) : launch_halo3_one<1, 2, 2, 128, 0>(a, st);
+    HOIG_NS_SWITCH(ns, return wide ? launch_halo3_one<NSX, 2, 4, 128, 1>(a, st) : launch_halo3_one<NSX, 2, 2, 128, 0>(a, st));
+    return HOIG_EINVAL;
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
@@ -1139,15 +1154,16 @@ int launch_halo3(HaloArgs a, int ns, hipStream_t st) {
 //     output parity phase (P,Q) of a coarse tile: out[2I+P][2J+Q] = sum over the taps with r = 1 (P = 0) or r in {0,2} (P = 1)
 //     of in[I + (r == 0)][J + (s == 0)] w[r][s] -- a stride-1 conv with 1, 2 or 4 taps over one halo image; strided stores.
 // Tile: 4 x 32 coarse pixels x BN channels, 4 waves, single LDS stage (58 KB: two workgroups per CU).
-template <int NS, int BN, bool SCATTER, bool F16>
+template <int NSX, int BN, bool SCATTER, bool F16>
 __global__ __launch_bounds__(256) void conv_halo_s2_bf16_kernel(const HaloArgs p) {
+    constexpr int NS = NSX == 1 ? 1 : 2, NB = NSX == 2 ? 2 : 1;      // operand planes: A (activations / dy), B (weights / x)
     constexpr int TH = 4, TW = 32, NT = 256, WN = 2;
     constexpr int RB = BN * 4 / NT;                        // 16-B weight chunks per thread per plane per tap
     constexpr int HH = TH + 1, HW = TW + 1, HPIX = HH * HW;
     constexpr int AROW = 80;
     constexpr int PLANE_A = HPIX * AROW, PLANE_B = BN * 64;
     constexpr int TM = 2, TN = BN / (32 * WN);
-    __shared__ __attribute__((aligned(16))) unsigned char smem[NS * PLANE_A + 2 * NS * PLANE_B];
+    __shared__ __attribute__((aligned(16))) unsigned char smem[NS * PLANE_A + 2 * NB * PLANE_B];
     unsigned char *Ah = smem, *Al = smem + PLANE_A;
     unsigned char *Bbase = smem + NS * PLANE_A;            // two tap tiles of (Bh, Bl)
 
@@ -1176,7 +1192,7 @@ __global__ __launch_bounds__(256) void conv_halo_s2_bf16_kernel(const HaloArgs p
         const int n = n0 + brow + (NT / 4) * i;
         const size_t o = plane_index(n, bchunk * 8, p.K);
         wrow_h[i] = n < p.N ? p.Wh + o : nullptr;
-        wrow_l[i] = (NS == 2 && n < p.N) ? p.Wl + o : nullptr;
+        wrow_l[i] = (NB == 2 && n < p.N) ? p.Wl + o : nullptr;
         const int row = brow + (NT / 4) * i;
         boff[i] = row * 64 + ((bchunk ^ ((row >> 2) & 3)) << 4);
     }
@@ -1250,7 +1266,7 @@ __global__ __launch_bounds__(256) void conv_halo_s2_bf16_kernel(const HaloArgs p
 #pragma unroll
             for (int i = 0; i < RB; ++i) {
                 rbh[t][i] = wrow_h[i] ? *reinterpret_cast<const uint4 *>(wrow_h[i] + koff) : make_uint4(0, 0, 0, 0);
-                if (NS == 2)
+                if (NB == 2)
                     rbl[t][i] = wrow_l[i] ? *reinterpret_cast<const uint4 *>(wrow_l[i] + koff) : make_uint4(0, 0, 0, 0);
             }
         }
@@ -1258,11 +1274,11 @@ __global__ __launch_bounds__(256) void conv_halo_s2_bf16_kernel(const HaloArgs p
     auto store_b = [&]() {
 #pragma unroll
         for (int t = 0; t < 2; ++t) {
-            unsigned char *Bh = Bbase + t * NS * PLANE_B, *Bl = Bh + PLANE_B;
+            unsigned char *Bh = Bbase + t * NB * PLANE_B, *Bl = Bh + PLANE_B;
 #pragma unroll
             for (int i = 0; i < RB; ++i) {
                 *reinterpret_cast<uint4 *>(Bh + boff[i]) = rbh[t][i];
-                if (NS == 2) *reinterpret_cast<uint4 *>(Bl + boff[i]) = rbl[t][i];
+                if (NB == 2) *reinterpret_cast<uint4 *>(Bl + boff[i]) = rbl[t][i];
             }
         }
     };
@@ -1305,7 +1321,7 @@ __global__ __launch_bounds__(256) void conv_halo_s2_bf16_kernel(const HaloArgs p
         for (int t = 0; t < 2; ++t) {
             if (t >= s_.ntap) break;
             const int tapoff = tap_off(s_.tap[t]);
-            const unsigned char *Bh = Bbase + t * NS * PLANE_B, *Bl = Bh + PLANE_B;
+            const unsigned char *Bh = Bbase + t * NB * PLANE_B, *Bl = Bh + PLANE_B;
 #pragma unroll
             for (int ks = 0; ks < 2; ++ks) {
                 bf16x8 ah[TM], al[TM], bhf[TN], blf[TN];
@@ -1319,16 +1335,15 @@ __global__ __launch_bounds__(256) void conv_halo_s2_bf16_kernel(const HaloArgs p
                 for (int j = 0; j < TN; ++j) {
                     const int off = bread[j] ^ (ks << 5);
                     bhf[j] = *reinterpret_cast<const bf16x8 *>(Bh + off);
-                    if (NS == 2) blf[j] = *reinterpret_cast<const bf16x8 *>(Bl + off);
+                    if (NB == 2) blf[j] = *reinterpret_cast<const bf16x8 *>(Bl + off);
                 }
 #pragma unroll
                 for (int i = 0; i < TM; ++i)
 #pragma unroll
                     for (int j = 0; j < TN; ++j) {
-                        if (NS == 2) {
+                        if (NS == 2)
                             acc[i][j] = mfma16<F16>(al[i], bhf[j], acc[i][j]);
-                            acc[i][j] = mfma16<F16>(ah[i], blf[j], acc[i][j]);
-                        }
+                            if (NB == 2) acc[i][j] = mfma16<F16>(ah[i], blf[j], acc[i][j]);
                         acc[i][j] = mfma16<F16>(ah[i], bhf[j], acc[i][j]);
                     }
             }
@@ -1414,11 +1429,11 @@ int launch_halo_s2(HaloArgs a, int ns, hipStream_t st) {
     a.nblk = a.Bn * a.tiles_x * a.tiles_y * a.nblk_n * (SCATTER ? 4 : 1);
     a.nmajor = 0;
     if (n64) {
-        if (ns == 2) { if (a.f16) conv_halo_s2_bf16_kernel<2, 64, SCATTER, true><<<a.nblk, 256, 0, st>>>(a); else conv_halo_s2_bf16_kernel<2, 64, SCATTER, false><<<a.nblk, 256, 0, st>>>(a); }
-        else { if (a.f16) conv_halo_s2_bf16_kernel<1, 64, SCATTER, true><<<a.nblk, 256, 0, st>>>(a); else conv_halo_s2_bf16_kernel<1, 64, SCATTER, false><<<a.nblk, 256, 0, st>>>(a); }
+        if (a.f16) HOIG_NS_SWITCH(ns, conv_halo_s2_bf16_kernel<NSX, 64, SCATTER, true><<<a.nblk, 256, 0, st>>>(a));
+        else HOIG_NS_SWITCH(ns, conv_halo_s2_bf16_kernel<NSX, 64, SCATTER, false><<<a.nblk, 256, 0, st>>>(a));
     } else {
-        if (ns == 2) { if (a.f16) conv_halo_s2_bf16_kernel<2, 128, SCATTER, true><<<a.nblk, 256, 0, st>>>(a); else conv_halo_s2_bf16_kernel<2, 128, SCATTER, false><<<a.nblk, 256, 0, st>>>(a); }
-        else { if (a.f16) conv_halo_s2_bf16_kernel<1, 128, SCATTER, true><<<a.nblk, 256, 0, st>>>(a); else conv_halo_s2_bf16_kernel<1, 128, SCATTER, false><<<a.nblk, 256, 0, st>>>(a); }
+        if (a.f16) HOIG_NS_SWITCH(ns, conv_halo_s2_bf16_kernel<NSX, 128, SCATTER, true><<<a.nblk, 256, 0, st>>>(a));
+        else HOIG_NS_SWITCH(ns, conv_halo_s2_bf16_kernel<NSX, 128, SCATTER, false><<<a.nblk, 256, 0, st>>>(a));
     }
     HOIG_LAUNCH_CHECK();
     return HOIG_OK;
@@ -1432,19 +1447,19 @@ int launch_halo(HaloArgs a, int ns, hipStream_t st) {
     a.nblk_n = (int)hoig_cdiv(a.N, n64 ? 64 : 128);
     a.nblk = a.Bn * a.tiles_x * a.tiles_y * a.nblk_n;
     if (n64) {
-        if (ns == 2) { if (a.f16) conv_halo_bf16_kernel<KS, 2, 2, 64, true><<<a.nblk, 256, 0, st>>>(a); else conv_halo_bf16_kernel<KS, 2, 2, 64, false><<<a.nblk, 256, 0, st>>>(a); }
-        else { if (a.f16) conv_halo_bf16_kernel<KS, 1, 2, 64, true><<<a.nblk, 256, 0, st>>>(a); else conv_halo_bf16_kernel<KS, 1, 2, 64, false><<<a.nblk, 256, 0, st>>>(a); }
+        if (a.f16) HOIG_NS_SWITCH(ns, conv_halo_bf16_kernel<KS, NSX, 2, 64, true><<<a.nblk, 256, 0, st>>>(a));
+        else HOIG_NS_SWITCH(ns, conv_halo_bf16_kernel<KS, NSX, 2, 64, false><<<a.nblk, 256, 0, st>>>(a));
         HOIG_LAUNCH_CHECK();
         return HOIG_OK;
     }
     // fewer than ~1.5 workgroups per CU: 8 waves per workgroup keep two waves on every SIMD
     const bool wide = a.nblk < 384;
-    if (ns == 2) {
-        if (wide) { if (a.f16) conv_halo_bf16_kernel<KS, 2, 4, 128, true><<<a.nblk, 512, 0, st>>>(a); else conv_halo_bf16_kernel<KS, 2, 4, 128, false><<<a.nblk, 512, 0, st>>>(a); }
-        else { if (a.f16) conv_halo_bf16_kernel<KS, 2, 2, 128, true><<<a.nblk, 256, 0, st>>>(a); else conv_halo_bf16_kernel<KS, 2, 2, 128, false><<<a.nblk, 256, 0, st>>>(a); }
+    if (wide) {
+        if (a.f16) HOIG_NS_SWITCH(ns, conv_halo_bf16_kernel<KS, NSX, 4, 128, true><<<a.nblk, 512, 0, st>>>(a));
+        else HOIG_NS_SWITCH(ns, conv_halo_bf16_kernel<KS, NSX, 4, 128, false><<<a.nblk, 512, 0, st>>>(a));
     } else {
-        if (wide) { if (a.f16) conv_halo_bf16_kernel<KS, 1, 4, 128, true><<<a.nblk, 512, 0, st>>>(a); else conv_halo_bf16_kernel<KS, 1, 4, 128, false><<<a.nblk, 512, 0, st>>>(a); }
-        else { if (a.f16) conv_halo_bf16_kernel<KS, 1, 2, 128, true><<<a.nblk, 256, 0, st>>>(a); else conv_halo_bf16_kernel<KS, 1, 2, 128, false><<<a.nblk, 256, 0, st>>>(a); }
+        if (a.f16) HOIG_NS_SWITCH(ns, conv_halo_bf16_kernel<KS, NSX, 2, 128, true><<<a.nblk, 256, 0, st>>>(a));
+        else HOIG_NS_SWITCH(ns, conv_halo_bf16_kernel<KS, NSX, 2, 128, false><<<a.nblk, 256, 0, st>>>(a));
     }
     HOIG_LAUNCH_CHECK();
     return HOIG_OK;
@@ -1466,9 +1481,10 @@ struct ThinArgs {
     int M, N, nsteps, steps_per_wg;
 };
 
-template <int NS>
+template <int NSX>
 __global__ __launch_bounds__(256, 2) void dgrad_thin_k128_kernel(const ThinArgs p) {
-    constexpr int K = 128, PLANE = 8 * 2048, STAGE = NS * PLANE;     // a stage: NS planes x [4 k-blocks][2 n-blocks] x 2 KB
+    constexpr int NS = NSX == 1 ? 1 : 2, NB = NSX == 2 ? 2 : 1;      // operand planes: A (activations / dy), B (weights / x)
+    constexpr int K = 128, PLANE = 8 * 2048, STAGE = NB * PLANE;     // a stage: NB planes x [4 k-blocks][2 n-blocks] x 2 KB
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l31 = lane & 31, lh = lane >> 5;
     const int m0 = blockIdx.x * 128 + wave * 32;
@@ -1498,7 +1514,7 @@ __global__ __launch_bounds__(256, 2) void dgrad_thin_k128_kernel(const ThinArgs 
             const int idx = tid + 256 * i, blk = idx >> 7, within = idx & 127;      // blk = kb * 2 + nb
             const size_t src = ((size_t)(step * 2 + (blk & 1)) * (K / 32) + (blk >> 1)) * 1024 + within * 8;
             rbh[i] = *reinterpret_cast<const u32x4_t *>(p.Wh + src);
-            if (NS == 2) rbl[i] = *reinterpret_cast<const u32x4_t *>(p.Wl + src);
+            if (NB == 2) rbl[i] = *reinterpret_cast<const u32x4_t *>(p.Wl + src);
         }
     };
     auto store_b = [&](int buf) __attribute__((always_inline)) {
@@ -1506,7 +1522,7 @@ __global__ __launch_bounds__(256, 2) void dgrad_thin_k128_kernel(const ThinArgs 
         for (int i = 0; i < 4; ++i) {
             const int idx = tid + 256 * i;
             *reinterpret_cast<u32x4_t *>(smem + buf * STAGE + idx * 16) = rbh[i];
-            if (NS == 2) *reinterpret_cast<u32x4_t *>(smem + buf * STAGE + PLANE + idx * 16) = rbl[i];
+            if (NB == 2) *reinterpret_cast<u32x4_t *>(smem + buf * STAGE + PLANE + idx * 16) = rbl[i];
         }
     };
     load_b(s_begin);
@@ -1530,9 +1546,9 @@ __global__ __launch_bounds__(256, 2) void dgrad_thin_k128_kernel(const ThinArgs 
             for (int j = 0; j < 2; ++j) {
                 const int off = ((ks >> 1) * 2 + j) * 2048 + l31 * 64 + ((((ks & 1) * 2 + lh) ^ ((l31 >> 2) & 3)) << 4);
                 const bf16x8 bh = *reinterpret_cast<const bf16x8 *>(Bh + off);
-                if (NS == 2) {
+                if (NS == 2) acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[ks], bh, acc[j], 0, 0, 0);
+                    if (NB == 2) {
                     const bf16x8 bl = *reinterpret_cast<const bf16x8 *>(Bl + off);
-                    acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[ks], bh, acc[j], 0, 0, 0);
                     acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[ks], bl, acc[j], 0, 0, 0);
                 }
                 acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[ks], bh, acc[j], 0, 0, 0);
@@ -1558,16 +1574,16 @@ int launch_dgrad_thin(const float *dy, const unsigned short *wh, const unsigned 
     if (split < 1) split = 1;
     a.steps_per_wg = (int)hoig_cdiv(a.nsteps, split);
     split = (int)hoig_cdiv(a.nsteps, a.steps_per_wg);
-    const size_t shm = (size_t)2 * ns * 8 * 2048;
+    const size_t shm = (size_t)2 * ns_b(ns) * 8 * 2048;
     static bool once = false;
     if (!once) {
         if (hipFuncSetAttribute(reinterpret_cast<const void *>(&dgrad_thin_k128_kernel<2>), hipFuncAttributeMaxDynamicSharedMemorySize, 65536) != hipSuccess ||
+            hipFuncSetAttribute(reinterpret_cast<const void *>(&dgrad_thin_k128_kernel<3>), hipFuncAttributeMaxDynamicSharedMemorySize, 32768) != hipSuccess ||
             hipFuncSetAttribute(reinterpret_cast<const void *>(&dgrad_thin_k128_kernel<1>), hipFuncAttributeMaxDynamicSharedMemorySize, 32768) != hipSuccess)
             return HOIG_ELAUNCH;
         once = true;
     }
-    if (ns == 2) dgrad_thin_k128_kernel<2><<<dim3(mtiles, split), 256, shm, st>>>(a);
-    else dgrad_thin_k128_kernel<1><<<dim3(mtiles, split), 256, shm, st>>>(a);
+    HOIG_NS_SWITCH(ns, dgrad_thin_k128_kernel<NSX><<<dim3(mtiles, split), 256, shm, st>>>(a));
     HOIG_LAUNCH_CHECK();
     return HOIG_OK;
 }
@@ -1595,7 +1611,7 @@ int run(const hoig_conv_desc *d, const float *a, const unsigned short *wh, const
     g.phase_major = 0; g.tile_skip = 0;
     if (g.Cg % 32 != 0) return HOIG_EUNSUPPORTED;
     if (g.gatherT && g.stride == 2 && ((g.Hp | g.Wp) & 1)) return HOIG_EUNSUPPORTED;
-    const int ns = d->precision == HOIG_PREC_BF16X3 ? 2 : 1;
+    const int ns = ns_of_precision(d->precision);
     if (ns == 2 && !wl) return HOIG_EINVAL;
     const long t128 = hoig_cdiv(p.M, 128);
     if (p.N <= 32 || p.N % 32 != 0) return HOIG_EUNSUPPORTED;
@@ -1690,14 +1706,14 @@ extern "C" int hoig_pack_conv_weights_bf16_all(const float *flat, const int64_t 
 extern "C" int hoig_conv2d_fwd_packed(const hoig_conv_desc *d, const float *x, const uint16_t *w_hi, const uint16_t *w_lo,
                                       const float *bias, float *y, hoig_stream_t stream) {
     if (!d || !x || !w_hi || !y) return HOIG_EINVAL;
-    if (d->precision != HOIG_PREC_BF16X3 && d->precision != HOIG_PREC_BF16) return HOIG_EINVAL;
+    if (!is_16bit_precision(d->precision)) return HOIG_EINVAL;
     return run(d, x, w_hi, w_lo, bias, y, false, (hipStream_t)stream);
 }
 
 extern "C" int hoig_conv2d_bwd_data_packed(const hoig_conv_desc *d, const float *dy, const uint16_t *wt_hi,
                                            const uint16_t *wt_lo, float *dx, hoig_stream_t stream) {
     if (!d || !dy || !wt_hi || !dx) return HOIG_EINVAL;
-    if (d->precision != HOIG_PREC_BF16X3 && d->precision != HOIG_PREC_BF16) return HOIG_EINVAL;
+    if (!is_16bit_precision(d->precision)) return HOIG_EINVAL;
     return run(d, dy, wt_hi, wt_lo, nullptr, dx, true, (hipStream_t)stream);
 }
 
@@ -1706,14 +1722,14 @@ extern "C" int hoig_conv2d_cat_fwd_packed(const hoig_conv_desc *d, const float *
                                           const uint16_t *w_hi, const uint16_t *w_lo, const float *bias, float *y,
                                           hoig_stream_t stream) {
     if (!d || !x1 || !x2 || !w_hi || !y) return HOIG_EINVAL;
-    if (d->precision != HOIG_PREC_BF16X3 && d->precision != HOIG_PREC_BF16) return HOIG_EINVAL;
+    if (!is_16bit_precision(d->precision)) return HOIG_EINVAL;
     return run(d, x1, w_hi, w_lo, bias, y, false, (hipStream_t)stream, x2, C1, nullptr, 0);
 }
 extern "C" int hoig_conv2d_cat_bwd_data_packed(const hoig_conv_desc *d, const float *dy, const uint16_t *wt_hi,
                                                const uint16_t *wt_lo, float *dx1, int C1, float *dx2,
                                                hoig_stream_t stream) {
     if (!d || !dy || !wt_hi || !dx1 || !dx2) return HOIG_EINVAL;
-    if (d->precision != HOIG_PREC_BF16X3 && d->precision != HOIG_PREC_BF16) return HOIG_EINVAL;
+    if (!is_16bit_precision(d->precision)) return HOIG_EINVAL;
     return run(d, dy, wt_hi, wt_lo, nullptr, dx1, true, (hipStream_t)stream, nullptr, 0, dx2, C1);
 }
 
@@ -1757,12 +1773,13 @@ __device__ __forceinline__ void pix_advance(Pix &p, int step, int Hp, int Wp) {
     }
 }
 
-template <int BM, int NS>
+template <int BM, int NSX>
 __global__ __launch_bounds__(256) void wgrad_bf16_kernel(const WArgs p) {
+    constexpr int NS = NSX == 1 ? 1 : 2, NB = NSX == 2 ? 2 : 1;      // operand planes: A (activations / dy), B (weights / x)
     constexpr int BN = 128, BK = 32, TM = BM / 64, TN = 2;
     constexpr int RSTR = 320;                              // LDS row stride in bytes (128 bf16 + pad)
     constexpr int PLANE_P = BK * RSTR, PLANE_Q = BK * RSTR;
-    constexpr int STAGE = NS * (PLANE_P + PLANE_Q);
+    constexpr int STAGE = NS * PLANE_P + NB * PLANE_Q;
     constexpr int RP = BM / 32;                            // float4 loads per thread for P (BM/4 columns, 8 row lanes)
     // ONE LDS stage (40 KB): four workgroups (16 waves) share a CU, and their unsynchronised phases cover each other's
     // load / LDS / barrier waits -- measured better than two 80 KB double-buffered workgroups (SQ_WAIT_ANY was 48 %)
@@ -1852,7 +1869,7 @@ __global__ __launch_bounds__(256) void wgrad_bf16_kernel(const WArgs p) {
             split4(rq[i], hi, lo);
             const int off = (qrow + 8 * i) * RSTR + qcol * 8;
             *reinterpret_cast<uint2 *>(Qh + off) = hi;
-            if (NS == 2) *reinterpret_cast<uint2 *>(Ql + off) = lo;
+            if (NB == 2) *reinterpret_cast<uint2 *>(Ql + off) = lo;
         }
 #pragma unroll
         for (int i = 0; i < RP; ++i) {
@@ -1900,16 +1917,15 @@ __global__ __launch_bounds__(256) void wgrad_bf16_kernel(const WArgs p) {
 #pragma unroll
             for (int j = 0; j < TN; ++j) {
                 bh[j] = frag(Qh, wn * 64 + j * 32, ks);
-                if (NS == 2) bl[j] = frag(Ql, wn * 64 + j * 32, ks);
+                if (NB == 2) bl[j] = frag(Ql, wn * 64 + j * 32, ks);
             }
 #pragma unroll
             for (int i = 0; i < TM; ++i)
 #pragma unroll
                 for (int j = 0; j < TN; ++j) {
-                    if (NS == 2) {
+                    if (NS == 2)
                         acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[i], bh[j], acc[i][j], 0, 0, 0);
-                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[i], bl[j], acc[i][j], 0, 0, 0);
-                    }
+                        if (NB == 2) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[i], bl[j], acc[i][j], 0, 0, 0);
                     acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[i], bh[j], acc[i][j], 0, 0, 0);
                 }
         }
@@ -1960,8 +1976,7 @@ int launch_wgrad_bf16(WArgs a, int ns, hipStream_t st) {
     a.m_per_split = mps;
     splits = (int)hoig_cdiv(a.M, mps);
     dim3 grid(a.nblk_mn, splits);
-    if (ns == 2) wgrad_bf16_kernel<BM, 2><<<grid, 256, 0, st>>>(a);
-    else wgrad_bf16_kernel<BM, 1><<<grid, 256, 0, st>>>(a);
+    HOIG_NS_SWITCH(ns, wgrad_bf16_kernel<BM, NSX><<<grid, 256, 0, st>>>(a));
     HOIG_LAUNCH_CHECK();
     return HOIG_OK;
 }
@@ -1993,14 +2008,15 @@ struct WHaloArgs {
 // target (input (H+4) x (W+4), pad 0): ten waves = co half x tap row, five taps each.
 // CM = 2: 128 output channels per workgroup on twice the waves (wave = co quarter x tap row): the same work per wave, but the x
 // halo is loaded and split once for twice the MFMAs -- the kernel is short of VALU issue slots, not of clock.
-template <int NS, int KS, int CM>
+template <int NSX, int KS, int CM>
 __global__ __launch_bounds__(128 * KS * CM) void wgrad_halo_bf16_kernel(const WHaloArgs p) {
+    constexpr int NS = NSX == 1 ? 1 : 2, NB = NSX == 2 ? 2 : 1;      // operand planes: A (activations / dy), B (weights / x)
     constexpr int TH = 2, TW = 32, BM = 64 * CM, BC = 32, NT = 128 * KS * CM;
     constexpr int CQ = 2 * CM, C4 = 16 * CM;               // 32-channel groups / float4s of a dy pixel row
     constexpr int HH = TH + KS - 1, HWID = TW + KS - 1, HPIX = HH * HWID;     // 4 x 34 halo pixels
     constexpr int PSTR = 128 * CM + 64, QSTR = 64;         // (192 / 320 B: four consecutive rows cover the 64 banks once)
     constexpr int PLANE_P = TH * TW * PSTR, PLANE_Q = ((HPIX * QSTR + 255) / 256) * 256;
-    __shared__ __attribute__((aligned(16))) unsigned char smem[NS * (PLANE_P + PLANE_Q)];
+    __shared__ __attribute__((aligned(16))) unsigned char smem[NS * PLANE_P + NB * PLANE_Q];
     unsigned char *Ph = smem, *Pl = smem + PLANE_P;
     unsigned char *Qh = smem + NS * PLANE_P, *Ql = Qh + PLANE_Q;
 
@@ -2071,7 +2087,7 @@ __global__ __launch_bounds__(128 * KS * CM) void wgrad_halo_bf16_kernel(const WH
                 uint2 hi, lo;
                 split4(rq[i], hi, lo);
                 *reinterpret_cast<uint2 *>(Qh + idx * 8) = hi;
-                if (NS == 2) *reinterpret_cast<uint2 *>(Ql + idx * 8) = lo;
+                if (NB == 2) *reinterpret_cast<uint2 *>(Ql + idx * 8) = lo;
             }
         }
     };
@@ -2127,9 +2143,9 @@ __global__ __launch_bounds__(128 * KS * CM) void wgrad_halo_bf16_kernel(const WH
             for (int t = 0; t < KS; ++t) {
                 const int qoff = trQ + (qrow0 + t) * QSTR;
                 const bf16x8 bh = frag(Qh + qoff, 4 * QSTR);
-                if (NS == 2) {
+                if (NS == 2) acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, bh, acc[t], 0, 0, 0);
+                    if (NB == 2) {
                     const bf16x8 bl = frag(Ql + qoff, 4 * QSTR);
-                    acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, bh, acc[t], 0, 0, 0);
                     acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bl, acc[t], 0, 0, 0);
                 }
                 acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bh, acc[t], 0, 0, 0);
@@ -2202,16 +2218,9 @@ int launch_wgrad_halo(const hoig_conv_desc *d, const float *x, const float *dy, 
 #ifdef HOIG_STAMP
     a.dbg = g_stamp_buf;
 #endif
-    if (d->R == 5) {
-        if (ns == 2) wgrad_halo_bf16_kernel<2, 5, 1><<<grid, 640, 0, st>>>(a);
-        else wgrad_halo_bf16_kernel<1, 5, 1><<<grid, 640, 0, st>>>(a);
-    } else if (cm == 2) {
-        if (ns == 2) wgrad_halo_bf16_kernel<2, 3, 2><<<grid, 768, 0, st>>>(a);
-        else wgrad_halo_bf16_kernel<1, 3, 2><<<grid, 768, 0, st>>>(a);
-    } else {
-        if (ns == 2) wgrad_halo_bf16_kernel<2, 3, 1><<<grid, 384, 0, st>>>(a);
-        else wgrad_halo_bf16_kernel<1, 3, 1><<<grid, 384, 0, st>>>(a);
-    }
+    if (d->R == 5) HOIG_NS_SWITCH(ns, wgrad_halo_bf16_kernel<NSX, 5, 1><<<grid, 640, 0, st>>>(a));
+    else if (cm == 2) HOIG_NS_SWITCH(ns, wgrad_halo_bf16_kernel<NSX, 3, 2><<<grid, 768, 0, st>>>(a));
+    else HOIG_NS_SWITCH(ns, wgrad_halo_bf16_kernel<NSX, 3, 1><<<grid, 384, 0, st>>>(a));
     HOIG_LAUNCH_CHECK();
     return HOIG_OK;
 }
@@ -2255,7 +2264,7 @@ int hoig_conv_bf16_wgrad(const hoig_conv_desc *d, const float *x, const float *d
         a.lw = __builtin_ctz(a.Wp);
         a.lh = __builtin_ctz(a.Hp);
     }
-    const int ns = d->precision == HOIG_PREC_BF16X3 ? 2 : 1;
+    const int ns = ns_of_precision(d->precision);
     if (hoig_conv_bf16_wgrad_fuses_bias(d)) return launch_wgrad_halo(d, x, dy, dw, dbias, ns, st);
     if (a.Co <= 64) return launch_wgrad_bf16<64>(a, ns, st);
     return launch_wgrad_bf16<128>(a, ns, st);
@@ -2266,6 +2275,6 @@ extern "C" int hoig_conv2d_cat_bwd_weight(const hoig_conv_desc *d, const float *
                                           float *dw, float *dbias, hoig_stream_t stream) {
     if (!d || !x1 || !x2 || !dy || !dw) return HOIG_EINVAL;
     if (!hoig_conv_bf16_wgrad_fuses_bias(d) || d->R != 3 || C1 % 32 || C1 <= 0 || C1 >= d->Ci) return HOIG_EUNSUPPORTED;
-    const int ns = d->precision == HOIG_PREC_BF16X3 ? 2 : 1;
+    const int ns = ns_of_precision(d->precision);
     return launch_wgrad_halo(d, x1, dy, dw, dbias, ns, (hipStream_t)stream, x2, C1);
 }

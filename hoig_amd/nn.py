@@ -13,9 +13,9 @@ Each parameter is an ``nn.Parameter`` VIEW of the flat buffer; ``state_dict()`` 
  so checkpoints interoperate (models/base_model.py:78-124).
 Storage layouts differ from the reference where the kernels want it:
   * conv weights are packed [Co][R][S][Ci] (ConvTranspose2d too);
-  * the first attention conv (128, 2C, 5, 5) (extract_attn.py:18) is stored as TWO packed weights, the target half
-    ``<name>#t`` = (128, C, 5, 5) and the source half ``<name>#s`` = (128, 25*C, 1, 1) with k = tap*C + c, because the
-    path runs them as a 5x5 convolution of the padded target and a 1x1 convolution over the sampled source.
+  * the first attention conv (128, 2C, 5, 5) (extract_attn.py:18) is stored as TWO packed 5x5 weights, the target half
+    ``<name>#t`` = w[:, :C] and the source half ``<name>#s`` = w[:, C:], both (128, C, 5, 5), because the path runs them as
+    two 5x5 convolutions over different tensors (the padded target; the padded source, read back bilinearly).
 """
 from collections import OrderedDict
 
@@ -34,18 +34,14 @@ def _numel(shape):
 
 
 def split_attn_weight(w):
-    """reference (128, 2C, 5, 5) -> target half (128, C, 5, 5), source half (128, 25*C, 1, 1) [k = tap*C + c]."""
-    n, c2, r, s = w.shape
-    c = c2 // 2
-    wt = w[:, :c]
-    ws = w[:, c:].reshape(n, c, r * s).permute(0, 2, 1).reshape(n, r * s * c, 1, 1)
-    return wt, ws
+    """reference (128, 2C, 5, 5) -> target half w[:, :C], source half w[:, C:] (the reference concatenates
+    [target, source] along channels: extract_attn.py:25-26)."""
+    c = w.shape[1] // 2
+    return w[:, :c], w[:, c:]
 
 
 def merge_attn_weight(wt, ws):
-    n, c, r, s = wt.shape
-    src = ws.reshape(n, r * s, c).permute(0, 2, 1).reshape(n, c, r, s)
-    return torch.cat([wt, src], dim=1)
+    return torch.cat([wt, ws], dim=1)
 
 
 class ParamTree(nn.Module):
@@ -61,7 +57,7 @@ class ParamTree(nn.Module):
             if name in self._split:
                 n, c2, r, s = shp
                 internal[name + '#t'] = ((n, c2 // 2, r, s), False)
-                internal[name + '#s'] = ((n, r * s * (c2 // 2), 1, 1), False)
+                internal[name + '#s'] = ((n, c2 // 2, r, s), False)
             else:
                 internal[name] = (tuple(shp), name in tset)
         self._internal = internal

@@ -17,13 +17,40 @@ from torch.autograd import Function
 from . import _lib as L
 from ._lib import call, ConvDesc
 
-_PREC = {'f32': L.PREC_F32, 'bf16x3': L.PREC_BF16X3, 'bf16': L.PREC_BF16}
-precision = _PREC[os.environ.get('HOIG_PRECISION', 'f32')]
+# arithmetic of the MFMA contractions (include/hoig_kernels.h HOIG_PREC_*).  'f16x3' is the name of what 'bf16x3' has always
+# been in the forward (fp16 halves; the backward splits on bf16); 'f16' / 'bf16' likewise name the single-pass mode.
+_PREC = {'f32': L.PREC_F32, 'bf16x3': L.PREC_BF16X3, 'f16x3': L.PREC_BF16X3, 'f16x2': L.PREC_F16X2, 'bf16x2': L.PREC_F16X2,
+         'bf16': L.PREC_BF16, 'f16': L.PREC_BF16}
+precision = precision_dgrad = precision_wgrad = L.PREC_F32
 
 
 def set_precision(name):
-    global precision
-    precision = _PREC[name]
+    """'f32' | 'bf16x3' | 'f16x2' | 'bf16', or '<forward>:<backward>', or '<forward>:<data gradient>:<weight gradient>'
+    (e.g. 'bf16x3:f16x2': forward launches on three MFMA terms, data and weight gradients on two)."""
+    global precision, precision_dgrad, precision_wgrad
+    parts = name.split(':')
+    if len(parts) > 3:
+        raise ValueError('precision %r' % name)
+    precision = _PREC[parts[0]]
+    precision_dgrad = _PREC[parts[1]] if len(parts) > 1 else precision
+    precision_wgrad = _PREC[parts[2]] if len(parts) > 2 else precision_dgrad
+
+
+set_precision(os.environ.get('HOIG_PRECISION', 'f32'))
+
+
+def _bwd_descs(d):
+    """(data-gradient, weight-gradient) descriptors of a convolution: same problem, the backward arithmetic modes.  An
+    exact-fp32 forward keeps its backward exact (first-layer convolutions are routed to f32 per call)."""
+    out = []
+    for prec in (precision_dgrad, precision_wgrad):
+        if d.precision == prec or d.precision == L.PREC_F32:
+            out.append(d)
+        else:
+            b = ConvDesc.from_buffer_copy(d)
+            b.precision = prec
+            out.append(b)
+    return tuple(out)
 
 
 def _st():
@@ -164,6 +191,7 @@ class _Conv(Function):
         d = ConvDesc(B, Hi, Wi, Ci, Ho, Wo, Co, R, S, stride, pad, 1 if transposed else 0, act, slope, prec)
         _conv_fwd_raw(d, x, w, b, y, transposed)
         ctx.d = d
+        ctx.d_dg, ctx.d_wg = _bwd_descs(d)
         ctx.transposed = transposed
         ctx.has_bias = b is not None and not dead_bias
         ctx.save_for_backward(x, w, b, y if act != L.ACT_NONE else None)
@@ -196,17 +224,17 @@ class _Conv(Function):
                 # the optimiser: run them on a side stream, concurrently with the data-gradient chain on the main stream
                 side.wait_stream(torch.cuda.current_stream())
                 with torch.cuda.stream(side):
-                    call('hoig_conv2d_bwd_weight', ctypes.byref(d), _p(x), _p(g), _p(dw), _p(db), _st())
+                    call('hoig_conv2d_bwd_weight', ctypes.byref(ctx.d_wg), _p(x), _p(g), _p(dw), _p(db), _st())
                 x.record_stream(side)
                 g.record_stream(side)
                 _wgrad_hold(side, (x, g))
             else:
-                call('hoig_conv2d_bwd_weight', ctypes.byref(d), _p(x), _p(g), _p(dw), _p(db), _st())
+                call('hoig_conv2d_bwd_weight', ctypes.byref(ctx.d_wg), _p(x), _p(g), _p(dw), _p(db), _st())
             dw_ret = dw if ret_w else None
         dx = None
         if ctx.needs_input_grad[0]:
             dx = torch.empty_like(x)
-            _conv_dgrad_raw(d, g, w, dx, ctx.transposed)
+            _conv_dgrad_raw(ctx.d_dg, g, w, dx, ctx.transposed)
         return dx, dw_ret, db_ret, None, None, None, None, None, None, None, None
 
 
@@ -234,14 +262,13 @@ class _ConvCat2(Function):
         hi, lo = _packed_planes(w, False, False)
         L.check(L.lib.hoig_conv2d_cat_fwd_packed(ctypes.byref(d), _p(x1), C1, _p(x2), _p(hi), _p(lo), None, _p(y), _st()),
                 'hoig_conv2d_cat_fwd_packed')
-        ctx.d = d
+        ctx.d_dg, ctx.d_wg = _bwd_descs(d)
         ctx.save_for_backward(x1, x2, w)
         return y
 
     @staticmethod
     def backward(ctx, dy):
         x1, x2, w = ctx.saved_tensors
-        d = ctx.d
         C1 = x1.shape[-1]
         dy = dy.contiguous()
         dw, ret_w = _grad_target(w)
@@ -249,15 +276,15 @@ class _ConvCat2(Function):
         if side is not None:
             side.wait_stream(torch.cuda.current_stream())
             with torch.cuda.stream(side):
-                call('hoig_conv2d_cat_bwd_weight', ctypes.byref(d), _p(x1), C1, _p(x2), _p(dy), _p(dw), None, _st())
+                call('hoig_conv2d_cat_bwd_weight', ctypes.byref(ctx.d_wg), _p(x1), C1, _p(x2), _p(dy), _p(dw), None, _st())
             for t in (x1, x2, dy):
                 t.record_stream(side)
             _wgrad_hold(side, (x1, x2, dy))
         else:
-            call('hoig_conv2d_cat_bwd_weight', ctypes.byref(d), _p(x1), C1, _p(x2), _p(dy), _p(dw), None, _st())
+            call('hoig_conv2d_cat_bwd_weight', ctypes.byref(ctx.d_wg), _p(x1), C1, _p(x2), _p(dy), _p(dw), None, _st())
         dx1, dx2 = torch.empty_like(x1), torch.empty_like(x2)
         hi, lo = _packed_planes(w, False, True)
-        L.check(L.lib.hoig_conv2d_cat_bwd_data_packed(ctypes.byref(d), _p(dy), _p(hi), _p(lo), _p(dx1), C1, _p(dx2), _st()),
+        L.check(L.lib.hoig_conv2d_cat_bwd_data_packed(ctypes.byref(ctx.d_dg), _p(dy), _p(hi), _p(lo), _p(dx1), C1, _p(dx2), _st()),
                 'hoig_conv2d_cat_bwd_data_packed')
         return dx1, dx2, (dw if ret_w else None), None
 
@@ -586,73 +613,77 @@ def _conv_dgrad_raw(d, g, w, dx, transposed=False):
 
 
 class _LocalAttn(Function):
-    """ExtractorAttn.forward (extract_attn.py:23-29) as: replicate-pad(target) -> conv5x5 ; K1-sample(source) -> conv1x1 ;
-    + bias ; LeakyReLU ; conv1x1 128->25 ; softmax ; (1/25) sum_q a_q S_q.  `wt` (128,C,5,5) and `ws` (128,25C,1,1) are
-    the two halves of the reference's (128,2C,5,5) weight (hoig_amd.nn.split_attn_weight)."""
+    """ExtractorAttn.forward (extract_attn.py:23-29) without any 25x-sized tensor (hoig_amd/csrc/attn.hip):
+    Gt = conv5x5(replicate_pad(target, 2), wt) + b1 ; Gs = conv5x5(replicate_pad(source, 4), ws) on the grid [-2, H+1]^2 ;
+    hidden = Gt + bilinear(Gs at pixel + flow) ; LeakyReLU ; conv1x1 128->25 ; softmax ; (1/25) sum_q a_q S_q read from the
+    source's 6x6 footprint.  `wt`, `ws` (128,C,5,5) are the two halves of the reference's (128,2C,5,5) weight
+    (hoig_amd.nn.split_attn_weight)."""
 
     @staticmethod
     def forward(ctx, source, target, flow, wt, ws, b1, w2, b2, prec):
         for t in (source, target, flow, wt, ws, b1, w2, b2):
             _chk(t)
         B, H, W, C = source.shape
-        assert tuple(wt.shape) == (128, C, 5, 5) and tuple(wt.stride()) == packed_strides(wt.shape, False)
-        assert tuple(ws.shape) == (128, 25 * C, 1, 1) and tuple(ws.stride()) == packed_strides(ws.shape, False)
+        for w in (wt, ws):
+            assert tuple(w.shape) == (128, C, 5, 5) and tuple(w.stride()) == packed_strides(w.shape, False)
         M = B * H * W
         dev, dt = source.device, source.dtype
         tpad = torch.empty((B, H + 4, W + 4, C), dtype=dt, device=dev)
         call('hoig_replicate_pad_fwd', _p(target), _p(tpad), B, H, W, C, 2, _st())
-        S = torch.empty((B, H, W, 25 * C), dtype=dt, device=dev)
-        call('hoig_attn_sample_fwd', _p(source), _p(flow), _p(S), B, H, W, C, _st())
+        spad = torch.empty((B, H + 8, W + 8, C), dtype=dt, device=dev)
+        call('hoig_replicate_pad_fwd', _p(source), _p(spad), B, H, W, C, 4, _st())
         d_t = ConvDesc(B, H + 4, W + 4, C, H, W, 128, 5, 5, 1, 0, 0, L.ACT_NONE, 0.0, prec)
-        d_s = ConvDesc(B, H, W, 25 * C, H, W, 128, 1, 1, 1, 0, 0, L.ACT_NONE, 0.0, prec)
-        h1 = torch.empty((M, 128), dtype=dt, device=dev)
-        h2 = torch.empty_like(h1)
-        _conv_fwd_raw(d_t, tpad, wt, b1, h1)
-        _conv_fwd_raw(d_s, S, ws, None, h2)
-        hidden = torch.empty_like(h1)
-        call('hoig_add', _p(h1), _p(h2), _p(hidden), hidden.numel(), _st())
+        d_s = ConvDesc(B, H + 8, W + 8, C, H + 4, W + 4, 128, 5, 5, 1, 0, 0, L.ACT_NONE, 0.0, prec)
+        gt = torch.empty((M, 128), dtype=dt, device=dev)
+        gs = torch.empty((B, H + 4, W + 4, 128), dtype=dt, device=dev)
+        _conv_fwd_raw(d_t, tpad, wt, b1, gt)
+        _conv_fwd_raw(d_s, spad, ws, None, gs)
+        hidden = torch.empty_like(gt)
         attn = torch.empty((M, 25), dtype=dt, device=dev)
         out = torch.empty_like(source)
-        call('hoig_attn_pixel_fwd', _p(hidden), _p(w2), _p(b2), _p(S), _p(attn), _p(out), M, C, _st())
-        ctx.save_for_backward(flow, wt, ws, b1, w2, b2, tpad, S, hidden, attn)
-        ctx.descs = (d_t, d_s)
+        call('hoig_attn_pixel_fwd', _p(gt), _p(gs), _p(flow), _p(w2), _p(b2), _p(source), _p(hidden), _p(attn), _p(out),
+             B, H, W, C, _st())
+        ctx.save_for_backward(source, flow, wt, ws, b1, w2, b2, tpad, spad, hidden, attn)
+        ctx.descs = _bwd_descs(d_t) + _bwd_descs(d_s)
         ctx.shape = (B, H, W, C)
         return out
 
     @staticmethod
     def backward(ctx, dout):
-        flow, wt, ws, b1, w2, b2, tpad, S, hidden, attn = ctx.saved_tensors
-        d_t, d_s = ctx.descs
+        source, flow, wt, ws, b1, w2, b2, tpad, spad, hidden, attn = ctx.saved_tensors
+        dt_dg, dt_wg, ds_dg, ds_wg = ctx.descs
         B, H, W, C = ctx.shape
-        M = B * H * W
         dout = dout.contiguous()
         gs = [_grad_target(p) for p in (wt, ws, b1, w2, b2)]
-        dhid = torch.empty_like(hidden)
-        call('hoig_attn_pixel_bwd', _p(hidden), _p(attn), _p(w2), _p(S), _p(dout), _p(dhid), _p(gs[3][0]), _p(gs[4][0]),
-             M, C, _st())
+        dhid = torch.empty_like(hidden)                       # = dGt
+        call('hoig_attn_pixel_bwd', _p(hidden), _p(attn), _p(w2), _p(source), _p(flow), _p(dout), _p(dhid), _p(gs[3][0]),
+             _p(gs[4][0]), B, H, W, C, _st())
+        dgs = torch.zeros((B, H + 4, W + 4, 128), dtype=dout.dtype, device=dout.device)
+        call('hoig_attn_gs_scatter', _p(dhid), _p(flow), _p(dgs), B, H, W, _st())
         side = _wgrad_side_stream(dout.device) if not any(r for _, r in gs) else None
         if side is not None:          # (see _Conv.backward)
             side.wait_stream(torch.cuda.current_stream())
             with torch.cuda.stream(side):
-                call('hoig_conv2d_bwd_weight', ctypes.byref(d_t), _p(tpad), _p(dhid), _p(gs[0][0]), _p(gs[2][0]), _st())
-                call('hoig_conv2d_bwd_weight', ctypes.byref(d_s), _p(S), _p(dhid), _p(gs[1][0]), None, _st())
-            for t in (tpad, S, dhid):
+                call('hoig_conv2d_bwd_weight', ctypes.byref(dt_wg), _p(tpad), _p(dhid), _p(gs[0][0]), _p(gs[2][0]), _st())
+                call('hoig_conv2d_bwd_weight', ctypes.byref(ds_wg), _p(spad), _p(dgs), _p(gs[1][0]), None, _st())
+            for t in (tpad, spad, dhid, dgs):
                 t.record_stream(side)
-            _wgrad_hold(side, (tpad, S, dhid))
+            _wgrad_hold(side, (tpad, spad, dhid, dgs))
         else:
-            call('hoig_conv2d_bwd_weight', ctypes.byref(d_t), _p(tpad), _p(dhid), _p(gs[0][0]), _p(gs[2][0]), _st())
-            call('hoig_conv2d_bwd_weight', ctypes.byref(d_s), _p(S), _p(dhid), _p(gs[1][0]), None, _st())
+            call('hoig_conv2d_bwd_weight', ctypes.byref(dt_wg), _p(tpad), _p(dhid), _p(gs[0][0]), _p(gs[2][0]), _st())
+            call('hoig_conv2d_bwd_weight', ctypes.byref(ds_wg), _p(spad), _p(dgs), _p(gs[1][0]), None, _st())
         dtgt = dsrc = None
         if ctx.needs_input_grad[1]:
             dtpad = torch.empty_like(tpad)
-            _conv_dgrad_raw(d_t, dhid, wt, dtpad)
+            _conv_dgrad_raw(dt_dg, dhid, wt, dtpad)
             dtgt = torch.empty((B, H, W, C), dtype=dout.dtype, device=dout.device)
             call('hoig_replicate_pad_bwd', _p(dtpad), _p(dtgt), B, H, W, C, 2, _st())
         if ctx.needs_input_grad[0]:
-            dS = torch.empty_like(S)
-            _conv_dgrad_raw(d_s, dhid, ws, dS)
-            dsrc = torch.zeros((B, H, W, C), dtype=dout.dtype, device=dout.device)
-            call('hoig_attn_sample_bwd', _p(flow), _p(dS), _p(attn), _p(dout), _p(dsrc), B, H, W, C, _st())
+            dspad = torch.empty_like(spad)
+            _conv_dgrad_raw(ds_dg, dgs, ws, dspad)
+            dsrc = torch.empty((B, H, W, C), dtype=dout.dtype, device=dout.device)
+            call('hoig_replicate_pad_bwd', _p(dspad), _p(dsrc), B, H, W, C, 4, _st())            # (writes every element)
+            call('hoig_attn_sample_bwd', _p(flow), _p(attn), _p(dout), _p(dsrc), B, H, W, C, _st())   # += the weighted average's part
         rets = [g if r else None for g, r in gs]
         return dsrc, dtgt, None, rets[0], rets[1], rets[2], rets[3], rets[4], None
 

@@ -39,9 +39,12 @@ enum { HOIG_ACT_NONE = 0, HOIG_ACT_RELU = 1, HOIG_ACT_LRELU = 2, HOIG_ACT_TANH =
 
 /* arithmetic of the MFMA contraction (accumulation is always fp32):
  *   F32    v_mfma_f32_32x32x2_f32, exact fp32 products (parity mode)
- *   BF16X3 operands split hi+lo bf16, 3 x v_mfma_f32_32x32x16_bf16 (~2^-16 rel.)
- *   BF16   one v_mfma_f32_32x32x16_bf16 per k-step (~2^-8 rel. per operand) */
-enum { HOIG_PREC_F32 = 0, HOIG_PREC_BF16X3 = 1, HOIG_PREC_BF16 = 2 };
+ *   BF16X3 both operands split hi+lo into 16-bit halves, 3 MFMAs per k-step (hi*hi + lo*hi + hi*lo): forward launches split
+ *          on fp16 (v_mfma_f32_32x32x16_f16, products to ~2^-21), backward launches on bf16 (~2^-16)
+ *   F16X2  the gathered operand (activations / dy) split hi+lo, the other one (weights; x in the weight gradient) rounded
+ *          to ONE 16-bit value: 2 MFMAs per k-step (hi*hi + lo*hi), ~2^-12 (fp16 forward) / ~2^-9 (bf16 backward) per product
+ *   BF16   one MFMA per k-step, both operands rounded to 16 bits (fp16 forward, bf16 backward) */
+enum { HOIG_PREC_F32 = 0, HOIG_PREC_BF16X3 = 1, HOIG_PREC_BF16 = 2, HOIG_PREC_F16X2 = 3 };
 
 /* One convolution problem.  NHWC activations, weights [Co][R][S][Ci].
  * transposed=0: y = conv2d(x, w, stride, pad)            x:[B,Hi,Wi,Ci] y:[B,Ho,Wo,Co]
@@ -67,7 +70,7 @@ int hoig_conv2d_bwd_data(const hoig_conv_desc *d, const float *dy, const float *
 int hoig_conv2d_bwd_weight(const hoig_conv_desc *d, const float *x, const float *dy, float *dw, float *dbias,
                            hoig_stream_t stream);
 
-/* 16-bit-operand fast path (HOIG_PREC_BF16X3 / HOIG_PREC_BF16): weights are pre-split once per optimiser step into
+/* 16-bit-operand fast path (HOIG_PREC_BF16X3 / HOIG_PREC_F16X2 / HOIG_PREC_BF16): weights are pre-split once per optimiser step into
  * 16-bit planes hi and lo of n rows x K reduction indices: the FORWARD planes (for_dgrad=0) hold fp16(256*w) and
  * fp16(256*w - hi) -- forward launches split their operands on fp16 and scale the accumulator by 1/256 -- the
  * DATA-GRADIENT planes (for_dgrad=1) hold bf16(w) and bf16(w - hi).  for_dgrad=0: n = co, k = (r*S+s)*Ci + ci
@@ -134,27 +137,33 @@ int hoig_inorm_bwd(const float *x, const float *mean, const float *rstd, int mod
 
 /* ---- local attention warping: ExtractorAttn (extract_attn.py:23-29) = K1 block extraction of source (with flow)
  *      and target (zero flow) + conv k5/s5 + LeakyReLU(0.01) + conv1x1 + softmax(25) + K3 reshape + weighted 5x5 average.
- *      Composition (host: hoig_amd/ops.py::_LocalAttn): the target half of the k5/s5 conv is a 5x5 convolution of the
- *      REPLICATE-padded target, the source half a 1x1 convolution over the sampled tensor S[m][q][c] (q = 25 taps);
- *      both run on hoig_conv2d_*.  These entry points are the pieces around those GEMMs.
- *      flow: [B,2,H,W] (ch0 = x, ch1 = y, PIXEL units as K1 reads them, block_extractor_kernel.cu:62-67). ---- */
+ *      Composition (host: hoig_amd/ops.py::_LocalAttn), no 25x-sized tensor anywhere: the taps of a pixel share their
+ *      bilinear fractions and each corner is border-clamped on its own, so the sampling commutes with the linear map over
+ *      the taps -- the target half of the k5/s5 conv is a 5x5 valid convolution Gt of replicate_pad(target, 2), the source
+ *      half a BILINEAR READ (at pixel + flow) of the 5x5 valid convolution Gs of replicate_pad(source, 4), both on
+ *      hoig_conv2d_*; the weighted average reads the source's 6x6 footprint.  These entry points are the pieces around the
+ *      two convolutions.  flow: [B,2,H,W] (ch0 = x, ch1 = y, PIXEL units as K1 reads them,
+ *      block_extractor_kernel.cu:62-67); it carries no gradient on the path (it is data: generator.py:481-488). ---- */
 /* y[b, py, px] = x[b, clamp(py-pad), clamp(px-pad)]  ([B,H,W,C] -> [B,H+2pad,W+2pad,C]) and its adjoint */
 int hoig_replicate_pad_fwd(const float *x, float *y, int B, int H, int W, int C, int pad, hoig_stream_t stream);
 int hoig_replicate_pad_bwd(const float *dy, float *dx, int B, int H, int W, int C, int pad, hoig_stream_t stream);
-/* sampled[b,y,x,q,c] = K1 bilinear sample of source at (y,x) + flow + tap offset (clamped taps, raw weights) */
-int hoig_attn_sample_fwd(const float *source, const float *flow, float *sampled, int B, int H, int W, int C,
+/* hidden[m] = gt[m] + bilinear(gs; m + flow(m))            gt: [B,H,W,128] (bias included), gs: [B,H+4,W+4,128] = Gs on the
+ *                                                          grid [-2,H+1] x [-2,W+1], hidden: [M,128] pre-activation (out)
+ * attn[m]   = softmax_25(w2 . leaky_0.01(hidden[m]) + b2)  w2: [25][128]
+ * out[m][c] = (1/25) sum_q attn[m][q] * S[m][q][c]         S = K1's border-clamped bilinear samples of `source` [B,H,W,C],
+ *                                                          evaluated over the pixel's 6x6 footprint, never stored */
+int hoig_attn_pixel_fwd(const float *gt, const float *gs, const float *flow, const float *w2, const float *b2,
+                        const float *source, float *hidden, float *attn, float *out, int B, int H, int W, int C,
+                        hoig_stream_t stream);
+/* given dout: dhidden (overwritten; it is also dGt), dw2 / db2 (accumulated) */
+int hoig_attn_pixel_bwd(const float *hidden, const float *attn, const float *w2, const float *source, const float *flow,
+                        const float *dout, float *dhidden, float *dw2, float *db2, int B, int H, int W, int C,
+                        hoig_stream_t stream);
+/* dgs += bilinear^T(dhidden)  (dgs: [B,H+4,W+4,128], caller-zeroed) */
+int hoig_attn_gs_scatter(const float *dhidden, const float *flow, float *dgs, int B, int H, int W, hoig_stream_t stream);
+/* dsource += bilinear^T( attn[m][q]/25 * dout[m][c] ): the source gradient of the weighted average (accumulates) */
+int hoig_attn_sample_bwd(const float *flow, const float *attn, const float *dout, float *dsource, int B, int H, int W, int C,
                          hoig_stream_t stream);
-/* dsource += bilinear^T( dsampled[m][q][c] + attn[m][q]/25 * dout[m][c] ); dsampled nullable; dsource caller-zeroed.
- * The flow carries no gradient on the path (it is data: generator.py:481-488). */
-int hoig_attn_sample_bwd(const float *flow, const float *dsampled, const float *attn, const float *dout, float *dsource,
-                         int B, int H, int W, int C, hoig_stream_t stream);
-/* attn[m] = softmax_25(w2 . leaky_0.01(hidden[m]) + b2); out[m][c] = (1/25) sum_q attn[m][q] sampled[m][q][c].
- * hidden: [M,128] pre-activation, w2: [25][128], M = B*H*W */
-int hoig_attn_pixel_fwd(const float *hidden, const float *w2, const float *b2, const float *sampled, float *attn,
-                        float *out, int M, int C, hoig_stream_t stream);
-/* dhidden (overwritten), dw2 / db2 (accumulated) */
-int hoig_attn_pixel_bwd(const float *hidden, const float *attn, const float *w2, const float *sampled, const float *dout,
-                        float *dhidden, float *dw2, float *db2, int M, int C, hoig_stream_t stream);
 
 /* Stand-alone drop-ins for the reference's two pybind ops, same argument meaning, contiguous NCHW fp32,
  * caller zero-fills outputs: block_extractor_cuda.forward/backward (block_extractor_cuda.cc:5-33) and
