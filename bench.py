@@ -28,7 +28,8 @@ sys.path.insert(0, ROOT)          # the product package only; tests/ + oracle/ a
 GFLOP_PER_PAIR_TRAIN_256 = 2555.2      # BASELINE.md §2 / SURVEY.md §8d (3*G + 3*VGG + 9*D), generator_spade_attn
 PMC_FILES = ['r02_pmc_dominant_conv.json', 'r01_pmc_dominant_conv.json']      # newest first
 PEAK_F32, PEAK_16 = 157.3, 2500.0          # TFLOP/s dense MFMA (fp32 / fp16-bf16), MI355X_MICROARCH.md
-DTYPE_NAMES = {'bf16x3': 'f16x3 fwd / bf16x3 bwd (both operands split hi+lo in 16-bit halves, 3 MFMAs per product, f32 accumulate)',
+DTYPE_NAMES = {'bf16x3:f16x2': 'f16x3 fwd (both operands split hi+lo on fp16, 3 MFMAs per product) / bf16x2 bwd (dy split hi+lo, weights and x single bf16, 2 MFMAs per product), f32 accumulate',
+               'bf16x3': 'f16x3 fwd / bf16x3 bwd (both operands split hi+lo in 16-bit halves, 3 MFMAs per product, f32 accumulate)',
                'f16x2': 'f16x2 fwd / bf16x2 bwd (gathered operand split hi+lo, weights single 16-bit, 2 MFMAs per product, f32 accumulate)',
                'bf16': 'f16 fwd / bf16 bwd (single-pass 16-bit operands, f32 accumulate)', 'f32': 'f32 (v_mfma_f32_32x32x2_f32)'}
 MFMA_TERMS = {'f32': 1, 'bf16x3': 3, 'f16x3': 3, 'f16x2': 2, 'bf16x2': 2, 'bf16': 1, 'f16': 1}      # issued MFMAs per algorithmic one
@@ -257,7 +258,8 @@ def main():
     ap.add_argument('--side', type=int, default=256)
     ap.add_argument('--gen_name', default='generator_spade_attn')
     ap.add_argument('--dataset', default='hov3', choices=['hov3', 'dexycb'], help='channel configuration (config C4 = dexycb at --side 512 --batch 4)')
-    ap.add_argument('--precision', default=os.environ.get('HOIG_PRECISION', 'bf16x3'))
+    ap.add_argument('--precision', default=os.environ.get('HOIG_PRECISION', 'bf16x3:f16x2'),
+                    help="'<forward>[:<data gradient>[:<weight gradient>]]' of f32 | bf16x3 | f16x2 | bf16 (hoig_amd/ops.py set_precision)")
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-gen-fwd', action='store_true')
     ap.add_argument('--fwd-batch', type=int, default=32, help='batch of the generator-forward latency leg')

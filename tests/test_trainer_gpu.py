@@ -9,6 +9,15 @@ from gpu_util import rel_err, rel_l2
 
 pytestmark = pytest.mark.gpu
 TOL = 1e-3
+# Loss terms: north_star's 1e-3 relative.  Measured (tools/precision_frontier.py, profiles/r02_precision_frontier.txt): with
+# the 3-term forward the seven loss terms of the FIRST step agree with the oracle to 3e-7 .. 5e-6 at 64 / 128 / 256 pixels (the
+# exact-fp32 mode: 5e-7 .. 5e-6), so the first step is held to 1e-4; later steps run on weights that Adam has moved by
+# lr * sign-like updates on both sides (rounding-level gradient elements may flip) and are held to north_star's 1e-3.
+LOSS_TOL_FIRST, LOSS_TOL = 1e-4, 1e-3
+
+
+def _loss_bound(want, step=0):
+    return (LOSS_TOL_FIRST if step == 0 else LOSS_TOL) * max(abs(want), 1e-2)
 # Gradients: the oracle itself is an fp32 computation; back-propagating through ~45 conv + instance-norm layers
 # amplifies summation-order noise, and the exact-fp32 MFMA mode already differs from torch-CPU by up to ~5e-3 in
 # relative L2 on the smallest gradient tensors (printed by the test).  The split-bf16 mode must stay in that class.
@@ -27,7 +36,7 @@ GOLDEN = [('generator_spade_attn', 'hov3_spade_attn_64.npz'), ('generator_spade'
           ('generator_spade_attn', 'dexycb_spade_attn_64.npz')]
 
 
-@pytest.mark.parametrize('precision', ['f32', 'bf16x3'])
+@pytest.mark.parametrize('precision', ['f32', 'bf16x3', 'bf16x3:f16x2'])
 @pytest.mark.parametrize('gen_name,fname', GOLDEN)
 def test_trainer_matches_reference_golden(gen_name, fname, precision):
     """Both shipped arithmetic modes (exact-fp32 MFMA and split-bf16 MFMA) must meet the same 1e-3 bound, on every generator
@@ -50,7 +59,8 @@ def test_trainer_matches_reference_golden(gen_name, fname, precision):
         m.optimize_parameters()
         e = m.get_current_errors()
         got, want = np.array([e[k] for k in keys]), g['errors'][s]
-        assert np.all(np.abs(got - want) <= 2e-3 * np.maximum(np.abs(want), 1e-2)), (s, got, want)
+        print('step %d loss rel. errors: %s' % (s, ' '.join('%.1e' % (abs(a - b) / max(abs(b), 1e-2)) for a, b in zip(got, want))))
+        assert all(abs(a - b) <= _loss_bound(b, s) for a, b in zip(got, want)), (s, got, want)
         if s == 0:
             for k in g.files:
                 if k.startswith('grad_G_'):
@@ -74,7 +84,7 @@ def test_trainer_matches_reference_golden(gen_name, fname, precision):
             assert abs(got - want) <= 1e-3 * want, name
 
 
-@pytest.mark.parametrize('precision', ['f32', 'bf16x3'])
+@pytest.mark.parametrize('precision', ['f32', 'bf16x3', 'bf16x3:f16x2'])
 def test_trainer_vs_oracle_128(precision):
     """128x128, batch 1 (D's instance norms see >= 7x7 maps): forward, all 7 loss terms and every gradient tensor of G
     and D against the CPU oracle."""
@@ -90,7 +100,7 @@ def test_trainer_vs_oracle_128(precision):
     m.optimize_parameters()
     eo, ep = ot.get_current_errors(), m.get_current_errors()
     for k in eo:
-        assert abs(eo[k] - ep[k]) <= 2e-3 * max(abs(eo[k]), 1e-2), (k, eo[k], ep[k])
+        assert abs(eo[k] - ep[k]) <= _loss_bound(eo[k]), (k, eo[k], ep[k])
     errs = []
     for net_o, net_p in ((ot.G, m._G), (ot.D, m._D)):
         grads = net_p.export_dict(net_p.flat_grad)            # reference names / shapes
@@ -113,7 +123,7 @@ def test_trainer_vs_oracle_128(precision):
     # worst 5.7e-3..1.2e-2 -- the same floor.  (With a bf16-split FORWARD it was median 1.1e-2: the gradient is that
     # sensitive to the forward point; the backward arithmetic was shown not to matter)
     # limits = ~1.5-2x the largest value seen in either mode (the spread is chaotic, not Gaussian)
-    lim = dict(f32=(1e-2, 2e-2, 3e-2), bf16x3=(1e-2, 2e-2, 3e-2))[precision]
+    lim = (1e-2, 2e-2, 3e-2)
     assert vals[len(vals) // 2] < lim[0]
     assert vals[int(0.95 * len(vals))] < lim[1]
     assert worst < lim[2], worst_name
@@ -131,7 +141,7 @@ def test_trainer_vs_oracle_dexycb_channels():
     m.optimize_parameters()
     eo, ep = ot.get_current_errors(), m.get_current_errors()
     for k in eo:
-        assert abs(eo[k] - ep[k]) <= 2e-3 * max(abs(eo[k]), 1e-2), (k, eo[k], ep[k])
+        assert abs(eo[k] - ep[k]) <= _loss_bound(eo[k]), (k, eo[k], ep[k])
 
 
 def test_api_surface_and_checkpoint_roundtrip(tmp_path):
