@@ -63,6 +63,8 @@ _SIGS = {
     'hoig_inorm_apply': [_vp, _vp, _vp, _i, _vp, _vp, _i, _f, _vp, _vp, _i, _i, _i, _vp],
     'hoig_inorm_apply_ld': [_vp, _vp, _vp, _i, _vp, _vp, _i, _i, _f, _vp, _vp, _i, _i, _i, _vp],
     'hoig_inorm_bwd_ld': [_vp, _vp, _vp, _i, _vp, _vp, _i, _vp, _vp, _i, _f, _vp, _vp, _vp, _i, _i, _i, _vp, _vp],
+    'hoig_inorm_fwd_fused': [_vp, _i, _vp, _vp, _i, _i, _f, _vp, _f, _vp, _vp, _vp, _i, _i, _i, _vp],
+    'hoig_inorm_bwd_fused': [_vp, _vp, _vp, _i, _vp, _vp, _i, _vp, _vp, _i, _f, _vp, _vp, _vp, _i, _i, _i, _vp],
     'hoig_inorm_bwd': [_vp, _vp, _vp, _i, _vp, _vp, _vp, _vp, _i, _f, _vp, _vp, _vp, _i, _i, _i, _vp, _vp],
     'hoig_replicate_pad_fwd': [_vp, _vp, _i, _i, _i, _i, _i, _vp],
     'hoig_replicate_pad_bwd': [_vp, _vp, _i, _i, _i, _i, _i, _vp],

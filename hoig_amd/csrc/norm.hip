@@ -5,6 +5,7 @@
 // apply  : y = act((x-mean)*rstd*scale+shift) (+ residual)       scale/shift = 1/0 | weight/bias[c] | 1+gamma/beta
 // bwd    : dx = rstd*(g' - mean(g') - xhat*mean(g'*xhat)),  g' = dy*act'(y)*scale ; affine / SPADE parameter grads
 #include "common.h"
+#include <cstdlib>
 
 namespace {
 
@@ -234,6 +235,184 @@ __global__ __launch_bounds__(NT) void inorm_bwd_apply_kernel(const float *__rest
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------------------
+// Small maps (H*W <= 1024: the 32x32 bottleneck, where 2/3 of the norm launches of a step live, and everything below it):
+// ONE launch per norm.  A 512-thread workgroup owns a (sample, 32-channel group) slab -- at most 1024 x 32 fp32 = 128 KB --
+// and holds it in REGISTERS (<= 16 float4 per thread; lanes = 8 channel vectors x 64 pixel rows, so every access is a 128-B
+// row segment): statistics by a two-pass (mean, then centred squares) reduction over the registers, then normalise /
+// modulate / activate (+ residual) straight from them.  x is read once and y written once (the three-kernel path reads x
+// twice and pays three dependent launches of 10-15 us each on these 17-33 MB tensors).  The backward keeps x and dy slabs
+// in registers the same way: one read of each instead of two.
+constexpr int TNT = 512, TCG = 32, TEPT = 16, TPL = TNT / (TCG / 4);      // 64 pixel lanes
+__device__ __forceinline__ float4 tile_reduce(float4 v, float *red, int cq, int pl) {
+    // sum over the 64 pixel lanes of each channel vector: red is [TPL][TCG] floats
+    *reinterpret_cast<float4 *>(red + pl * TCG + cq * 4) = v;
+    __syncthreads();
+    float s = 0.f;
+    const int c = threadIdx.x % TCG, part = threadIdx.x / TCG;           // 16 partial sums of 4 lanes each per channel
+#pragma unroll
+    for (int k = 0; k < TPL / (TNT / TCG); ++k) s += red[(part * (TPL / (TNT / TCG)) + k) * TCG + c];
+    __syncthreads();
+    red[part * TCG + c] = s;
+    __syncthreads();
+    float4 o = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+    for (int k = 0; k < TNT / TCG; ++k) {
+        const float4 t = *reinterpret_cast<const float4 *>(red + k * TCG + cq * 4);
+        o.x += t.x; o.y += t.y; o.z += t.z; o.w += t.w;
+    }
+    __syncthreads();
+    return o;
+}
+
+__global__ __launch_bounds__(TNT) void inorm_tile_fwd_kernel(const float *__restrict__ x, int mode, const float *__restrict__ p0,
+                                                             const float *__restrict__ p1, int ldp, int act, float slope,
+                                                             const float *__restrict__ residual, float eps,
+                                                             float *__restrict__ y, float *__restrict__ mean,
+                                                             float *__restrict__ rstd, int HW, int C) {
+    __shared__ float red[TPL * TCG];
+    const int b = blockIdx.y, c0 = blockIdx.x * TCG;
+    const int cq = threadIdx.x % (TCG / 4), pl = threadIdx.x / (TCG / 4), c = c0 + cq * 4;
+    const size_t base = (size_t)b * HW * C + c;
+    float4 v[TEPT];
+    float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+    for (int k = 0; k < TEPT; ++k) {
+        const int r = pl + k * TPL;
+        v[k] = r < HW ? *reinterpret_cast<const float4 *>(x + base + (size_t)r * C) : make_float4(0.f, 0.f, 0.f, 0.f);
+        s.x += v[k].x; s.y += v[k].y; s.z += v[k].z; s.w += v[k].w;
+    }
+    s = tile_reduce(s, red, cq, pl);
+    const float inv = 1.f / (float)HW;
+    const float4 mu = make_float4(s.x * inv, s.y * inv, s.z * inv, s.w * inv);
+    float4 q = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+    for (int k = 0; k < TEPT; ++k)
+        if (pl + k * TPL < HW) {
+            const float dx = v[k].x - mu.x, dy = v[k].y - mu.y, dz = v[k].z - mu.z, dw = v[k].w - mu.w;
+            q.x += dx * dx; q.y += dy * dy; q.z += dz * dz; q.w += dw * dw;
+        }
+    q = tile_reduce(q, red, cq, pl);
+    const float4 rs = make_float4(1.f / sqrtf(q.x * inv + eps), 1.f / sqrtf(q.y * inv + eps), 1.f / sqrtf(q.z * inv + eps),
+                                  1.f / sqrtf(q.w * inv + eps));
+    if (pl == 0) {
+        *reinterpret_cast<float4 *>(mean + (size_t)b * C + c) = mu;
+        *reinterpret_cast<float4 *>(rstd + (size_t)b * C + c) = rs;
+    }
+    float4 sc = make_float4(1, 1, 1, 1), sh = make_float4(0, 0, 0, 0);
+    if (mode == 1) {
+        sc = *reinterpret_cast<const float4 *>(p0 + c);
+        sh = *reinterpret_cast<const float4 *>(p1 + c);
+    }
+#pragma unroll
+    for (int k = 0; k < TEPT; ++k) {
+        const int r = pl + k * TPL;
+        if (r >= HW) continue;
+        if (mode == 2) {
+            const size_t po = ((size_t)b * HW + r) * ldp + c;
+            sc = *reinterpret_cast<const float4 *>(p0 + po);
+            sh = *reinterpret_cast<const float4 *>(p1 + po);
+            sc.x += 1.f; sc.y += 1.f; sc.z += 1.f; sc.w += 1.f;
+        }
+        float4 o;
+        o.x = hoig_act(fmaf((v[k].x - mu.x) * rs.x, sc.x, sh.x), act, slope);
+        o.y = hoig_act(fmaf((v[k].y - mu.y) * rs.y, sc.y, sh.y), act, slope);
+        o.z = hoig_act(fmaf((v[k].z - mu.z) * rs.z, sc.z, sh.z), act, slope);
+        o.w = hoig_act(fmaf((v[k].w - mu.w) * rs.w, sc.w, sh.w), act, slope);
+        if (residual) {
+            const float4 rr = *reinterpret_cast<const float4 *>(residual + base + (size_t)r * C);
+            o.x += rr.x; o.y += rr.y; o.z += rr.z; o.w += rr.w;
+        }
+        *reinterpret_cast<float4 *>(y + base + (size_t)r * C) = o;
+    }
+}
+
+__global__ __launch_bounds__(TNT) void inorm_tile_bwd_kernel(const float *__restrict__ x, const float *__restrict__ mean,
+                                                             const float *__restrict__ rstd, int mode,
+                                                             const float *__restrict__ p0, const float *__restrict__ p1,
+                                                             int ldp, const float *__restrict__ y, const float *__restrict__ dy,
+                                                             int act, float slope, float *__restrict__ dx,
+                                                             float *__restrict__ dp0, float *__restrict__ dp1, int HW, int C) {
+    __shared__ float red[TPL * TCG];
+    const int b = blockIdx.y, c0 = blockIdx.x * TCG;
+    const int cq = threadIdx.x % (TCG / 4), pl = threadIdx.x / (TCG / 4), c = c0 + cq * 4;
+    const size_t base = (size_t)b * HW * C + c;
+    const float4 mu = *reinterpret_cast<const float4 *>(mean + (size_t)b * C + c);
+    const float4 rs = *reinterpret_cast<const float4 *>(rstd + (size_t)b * C + c);
+    float4 aw = make_float4(1, 1, 1, 1), ab = make_float4(0, 0, 0, 0);
+    if (mode == 1) {
+        aw = *reinterpret_cast<const float4 *>(p0 + c);
+        if (p1) ab = *reinterpret_cast<const float4 *>(p1 + c);
+    }
+    float4 h[TEPT], g[TEPT];                    // xhat and g' = dy * act'(y) (* (1 + gamma) for SPADE, applied below)
+    float4 s1 = make_float4(0.f, 0.f, 0.f, 0.f), s2 = s1;
+#pragma unroll
+    for (int k = 0; k < TEPT; ++k) {
+        const int r = pl + k * TPL;
+        h[k] = g[k] = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (r >= HW) continue;
+        const size_t off = base + (size_t)r * C;
+        const float4 v = *reinterpret_cast<const float4 *>(x + off);
+        float4 gg = *reinterpret_cast<const float4 *>(dy + off);
+        float4 hh;
+        hh.x = (v.x - mu.x) * rs.x; hh.y = (v.y - mu.y) * rs.y; hh.z = (v.z - mu.z) * rs.z; hh.w = (v.w - mu.w) * rs.w;
+        if (act != HOIG_ACT_NONE) {
+            if (y) {
+                const float4 yy = *reinterpret_cast<const float4 *>(y + off);
+                gg.x *= hoig_act_grad_from_y(yy.x, act, slope);
+                gg.y *= hoig_act_grad_from_y(yy.y, act, slope);
+                gg.z *= hoig_act_grad_from_y(yy.z, act, slope);
+                gg.w *= hoig_act_grad_from_y(yy.w, act, slope);
+            } else {                        // (Leaky)ReLU after a plain / affine norm: the sign of y, recomputed as the forward did
+                gg.x *= hoig_act_grad_from_y(fmaf(hh.x, aw.x, ab.x), act, slope);
+                gg.y *= hoig_act_grad_from_y(fmaf(hh.y, aw.y, ab.y), act, slope);
+                gg.z *= hoig_act_grad_from_y(fmaf(hh.z, aw.z, ab.z), act, slope);
+                gg.w *= hoig_act_grad_from_y(fmaf(hh.w, aw.w, ab.w), act, slope);
+            }
+        }
+        if (mode == 2) {                    // dgamma = g*xhat, dbeta = g (per pixel); then g' = g * (1 + gamma)
+            const size_t po = ((size_t)b * HW + r) * ldp + c;
+            *reinterpret_cast<float4 *>(dp0 + po) = make_float4(gg.x * hh.x, gg.y * hh.y, gg.z * hh.z, gg.w * hh.w);
+            *reinterpret_cast<float4 *>(dp1 + po) = gg;
+            const float4 ga = *reinterpret_cast<const float4 *>(p0 + po);
+            gg.x *= 1.f + ga.x; gg.y *= 1.f + ga.y; gg.z *= 1.f + ga.z; gg.w *= 1.f + ga.w;
+        }
+        h[k] = hh;
+        g[k] = gg;
+        s1.x += gg.x; s1.y += gg.y; s1.z += gg.z; s1.w += gg.w;
+        s2.x += gg.x * hh.x; s2.y += gg.y * hh.y; s2.z += gg.z * hh.z; s2.w += gg.w * hh.w;
+    }
+    s1 = tile_reduce(s1, red, cq, pl);
+    s2 = tile_reduce(s2, red, cq, pl);
+    if (mode == 1 && pl == 0) {             // affine parameter gradients: dbias += sum g, dweight += sum g*xhat (g before * weight)
+        if (dp1) { atomicAdd(dp1 + c, s1.x); atomicAdd(dp1 + c + 1, s1.y); atomicAdd(dp1 + c + 2, s1.z); atomicAdd(dp1 + c + 3, s1.w); }
+        if (dp0) { atomicAdd(dp0 + c, s2.x); atomicAdd(dp0 + c + 1, s2.y); atomicAdd(dp0 + c + 2, s2.z); atomicAdd(dp0 + c + 3, s2.w); }
+    }
+    const float inv = 1.f / (float)HW;
+    float4 sc = make_float4(1, 1, 1, 1);
+    if (mode == 1) {
+        sc = aw;
+        s1.x *= sc.x; s1.y *= sc.y; s1.z *= sc.z; s1.w *= sc.w;
+        s2.x *= sc.x; s2.y *= sc.y; s2.z *= sc.z; s2.w *= sc.w;
+    }
+#pragma unroll
+    for (int k = 0; k < TEPT; ++k) {
+        const int r = pl + k * TPL;
+        if (r >= HW) continue;
+        float4 o;
+        o.x = rs.x * (g[k].x * sc.x - s1.x * inv - h[k].x * s2.x * inv);
+        o.y = rs.y * (g[k].y * sc.y - s1.y * inv - h[k].y * s2.y * inv);
+        o.z = rs.z * (g[k].z * sc.z - s1.z * inv - h[k].z * s2.z * inv);
+        o.w = rs.w * (g[k].w * sc.w - s1.w * inv - h[k].w * s2.w * inv);
+        *reinterpret_cast<float4 *>(dx + base + (size_t)r * C) = o;
+    }
+}
+
+bool tile_ok(int B, int HW, int C) {
+    static const bool off = getenv("HOIG_NORM_TILE") != nullptr && atoi(getenv("HOIG_NORM_TILE")) == 0;
+    return !off && B > 0 && HW > 0 && HW <= TEPT * TPL && C > 0 && C % TCG == 0;
+}
+
 bool shape_ok(int B, int HW, int C) {
     if (B <= 0 || HW <= 0 || C <= 0 || (C & 3)) return false;
     const int CV = C / 4;
@@ -330,6 +509,36 @@ extern "C" int hoig_inorm_bwd_ld(const float *x, const float *mean, const float 
     const int64_t n4 = (int64_t)B * HW * C / 4;
     inorm_bwd_apply_kernel<<<hoig_stream_grid(n4, NT), NT, 0, st>>>(x, mean, rstd, mode, p0, y, dy, act, slope, sums, dx,
                                                                    dp0, dp1, HW, C, n4, ld_p, p1);
+    HOIG_LAUNCH_CHECK();
+    return HOIG_OK;
+}
+
+/* Single-launch forms for maps of at most 1024 pixels and C a multiple of 32 (HOIG_EUNSUPPORTED otherwise: the caller then
+ * uses stats + apply / the three-kernel backward).  fwd: y, and mean / rstd for the backward. */
+extern "C" int hoig_inorm_fwd_fused(const float *x, int mode, const float *p0, const float *p1, int ld_p, int act, float slope,
+                                    const float *residual, float eps, float *y, float *mean, float *rstd, int B, int HW, int C,
+                                    hoig_stream_t stream) {
+    if (!x || !y || !mean || !rstd || mode < 0 || mode > 2) return HOIG_EINVAL;
+    if (mode != 0 && (!p0 || !p1)) return HOIG_EINVAL;
+    if (mode == 2 && (ld_p < C || (ld_p & 3))) return HOIG_EINVAL;
+    if (!tile_ok(B, HW, C)) return HOIG_EUNSUPPORTED;
+    inorm_tile_fwd_kernel<<<dim3(C / TCG, B), TNT, 0, (hipStream_t)stream>>>(x, mode, p0, p1, ld_p, act, slope, residual, eps, y,
+                                                                             mean, rstd, HW, C);
+    HOIG_LAUNCH_CHECK();
+    return HOIG_OK;
+}
+extern "C" int hoig_inorm_bwd_fused(const float *x, const float *mean, const float *rstd, int mode, const float *p0,
+                                    const float *p1, int ld_p, const float *y, const float *dy, int act, float slope, float *dx,
+                                    float *dp0, float *dp1, int B, int HW, int C, hoig_stream_t stream) {
+    if (!x || !mean || !rstd || !dy || !dx || mode < 0 || mode > 2) return HOIG_EINVAL;
+    if (mode == 2 && (ld_p < C || (ld_p & 3) || !dp0 || !dp1)) return HOIG_EINVAL;
+    if (act != HOIG_ACT_NONE && !y &&
+        !((act == HOIG_ACT_RELU || act == HOIG_ACT_LRELU) && (mode == 0 || (mode == 1 && p1))))
+        return HOIG_EINVAL;
+    if (mode != 0 && !p0) return HOIG_EINVAL;
+    if (!tile_ok(B, HW, C)) return HOIG_EUNSUPPORTED;
+    inorm_tile_bwd_kernel<<<dim3(C / TCG, B), TNT, 0, (hipStream_t)stream>>>(x, mean, rstd, mode, p0, p1, ld_p, y, dy, act, slope,
+                                                                             dx, dp0, dp1, HW, C);
     HOIG_LAUNCH_CHECK();
     return HOIG_OK;
 }

@@ -62,8 +62,10 @@ class Trainer(BaseModel):
         torch.cuda.set_device(self.device)
         self._dexycb = 'dex' in str(getattr(opt, 'dataset_mode', 'hov3')).lower()
         self._world = dist.get_world_size() if (use_ddp and dist.is_initialized()) else 1
-        self._side = torch.cuda.Stream(device=self.device)      # G's gradient exchange + Adam, overlapped with the D step
+        # G's gradient exchange + Adam run on a side stream beside the D step; D's run there beside the next forward of G
+        self._side = torch.cuda.Stream(device=self.device)
         self._g_ready = None
+        self._d_ready = None
 
         self._init_create_networks(use_ddp=use_ddp)
         if self._is_train:
@@ -228,6 +230,15 @@ class Trainer(BaseModel):
         if self._g_ready is not None:
             torch.cuda.current_stream().wait_event(self._g_ready)
             self._g_ready = None
+            self._net(self._G).set_pending(None)
+
+    def _wait_d(self):
+        """D's weights are next needed by the discriminator pass of the G loss, a whole generator forward after the
+        D step ended: its exchange (28 MB) + Adam have that long to finish on the side stream."""
+        if self._d_ready is not None:
+            torch.cuda.current_stream().wait_event(self._d_ready)
+            self._d_ready = None
+            self._net(self._D).set_pending(None)
 
     def forward(self, keep_data_for_visuals=False, return_estimates=False):
         self._wait_g()
@@ -264,16 +275,15 @@ class Trainer(BaseModel):
             loss_D = self._optimize_D(fake_tsf_imgs)
             self._optimizer_D.zero_grad()
             loss_D.backward()
-            self._step(self._D, self._optimizer_D, overlap=False)
             self._wait_g()                # G's update has had the whole D step to finish; later readers need no special care
+            self._step(self._D, self._optimizer_D, overlap=True, which='d')
 
-    def _step(self, net, optimizer, overlap):
-        """gradient exchange (RCCL, under DDP) + fused Adam; for G both run on the side stream, overlapped with the D step
-        that follows on the main stream."""
+    def _step(self, net, optimizer, overlap, which='g'):
+        """gradient exchange (RCCL, under DDP) + fused Adam.  With `overlap` both run on the side stream: G's beside the D step
+        that follows on the main stream (which never touches G's parameters: 734 MB of exchange, 5 GB of Adam traffic), D's
+        beside the next generator forward; the next reader of the network waits for the event (_wait_g / _wait_d)."""
         ddp = isinstance(net, FlatDDP) and net.sync.active
         if overlap:
-            # the D step that follows never touches G's parameters: G's exchange + Adam (HBM-bound, 5 GB of traffic) run on
-            # the side stream beside it; forward() waits for the event before the next use of G
             main = torch.cuda.current_stream()
             self._side.wait_stream(main)
             with torch.cuda.stream(self._side):
@@ -281,10 +291,14 @@ class Trainer(BaseModel):
                     optimizer.step(grad_scale=1.0 / net.sync.world, ready=net.sync.iter_all_reduce())
                 else:
                     optimizer.step()
-                self._g_ready = torch.cuda.Event()
-                self._g_ready.record(self._side)
+                ev = torch.cuda.Event()
+                ev.record(self._side)
+            self._net(net).set_pending(ev)       # anyone who reads the network through its own API waits too
+            if which == 'g':
+                self._g_ready = ev
+            else:
+                self._d_ready = ev
         elif ddp:
-            self._wait_g()
             optimizer.step(grad_scale=1.0 / net.sync.world, ready=net.sync.iter_all_reduce())
         else:
             optimizer.step()
@@ -294,6 +308,7 @@ class Trainer(BaseModel):
         o, n = self._opt, self._n
         fake_src, fake_tsf = to_nhwc(fake_src_imgs), to_nhwc(fake_tsf_imgs)
         mbg, mh = to_nhwc(fake_masks_bg), to_nhwc(fake_masks_hand)
+        self._wait_d()
         d_fake = self._D.forward_nhwc(ops.cat_channels([fake_tsf, n['tsf_cond']]))
         self._loss_g_adv = ops.lsgan_loss(d_fake, 0.0, o.lambda_D_prob)
         self._loss_g_rec = ops.l1_loss(fake_src, n['real_src'], o.lambda_rec)
@@ -311,6 +326,7 @@ class Trainer(BaseModel):
         fake_tsf = to_nhwc(fake_tsf_imgs).detach()
         # the reference runs D twice (trainer.py:464-465); instance norm is per sample, so one stacked pass is identical
         nb = fake_tsf.shape[0]
+        self._wait_d()
         d_both = self._D.forward_nhwc(torch.cat([ops.cat_channels([n['real_tsf'], n['tsf_cond']]),
                                                  ops.cat_channels([fake_tsf, n['tsf_cond']])], dim=0))
         d_real, d_fake = d_both[:nb], d_both[nb:]
@@ -405,6 +421,7 @@ class Trainer(BaseModel):
     # ------------------------------------------------------------------ checkpoints / schedule (trainer.py:553-591)
     def save(self, label):
         self._wait_g()
+        self._wait_d()
         torch.cuda.synchronize()
         self._save_network(self._G, 'G', label)
         self._save_network(self._D, 'D', label)

@@ -109,6 +109,7 @@ class ParamTree(nn.Module):
                 v._hoig_flat, v._hoig_transposed, v._hoig_owner = True, False, self
                 self.F[key] = v
 
+        self._pending = None      # event of an optimiser step still running on a side stream (Trainer._step)
         self._plane_bufs = None
         self._plane_version = -1
         self._plane_flags = {}
@@ -137,6 +138,10 @@ class ParamTree(nn.Module):
         return rows
 
     def refresh_planes(self):
+        self.wait_pending()
+        self._refresh_planes()
+
+    def _refresh_planes(self):
         """Split the current weights into bf16 planes (one launch) if they changed since the last split.  Called lazily by
         packed_planes(); a forward that forks onto several streams calls it FIRST, on the main stream, so that no branch
         races the split."""
@@ -167,6 +172,15 @@ class ParamTree(nn.Module):
         hi, lo = (self._plane_bufs[2], self._plane_bufs[3]) if for_dgrad else (self._plane_bufs[0], self._plane_bufs[1])
         return hi[off:off + n], lo[off:off + n]
 
+    def set_pending(self, event):
+        """An update of this network's buffers is in flight on another stream; readers call wait_pending() first."""
+        self._pending = event
+
+    def wait_pending(self):
+        ev, self._pending = self._pending, None
+        if ev is not None:
+            torch.cuda.current_stream().wait_event(ev)
+
     def _register(self, dotted, p):
         parts = dotted.split('.')
         mod = self
@@ -189,6 +203,7 @@ class ParamTree(nn.Module):
 
     # --- reference-compatible (de)serialisation of any flat buffer (weights, Adam moments)
     def export_dict(self, flat, prefix=''):
+        self.wait_pending()
         v = self.views_of(flat)
         out = OrderedDict()
         for name in self._ref_shapes:
@@ -204,6 +219,7 @@ class ParamTree(nn.Module):
         unexpected = [k for k in sd if k not in self._ref_shapes]
         if strict and (missing or unexpected):
             raise RuntimeError('load_state_dict: missing %s unexpected %s' % (missing[:5], unexpected[:5]))
+        self.wait_pending()
         v = self.views_of(flat)
         with torch.no_grad():
             for name, shp in self._ref_shapes.items():

@@ -42,6 +42,8 @@ set_precision(os.environ.get('HOIG_PRECISION', 'f32'))
 def _bwd_descs(d):
     """(data-gradient, weight-gradient) descriptors of a convolution: same problem, the backward arithmetic modes.  An
     exact-fp32 forward keeps its backward exact (first-layer convolutions are routed to f32 per call)."""
+    if d.precision != precision:          # a per-call precision override: the backward follows the forward
+        return d, d
     out = []
     for prec in (precision_dgrad, precision_wgrad):
         if d.precision == prec or d.precision == L.PREC_F32:
@@ -339,15 +341,21 @@ class _INorm(Function):
         assert x.is_contiguous()
         B, H, W, C = x.shape
         HW = H * W
-        ws = _norm_workspace(L.lib.hoig_inorm_workspace_bytes(B, HW, C) // 4, x.device)
-        mean = torch.empty(B * C, dtype=torch.float32, device=x.device)
-        rstd = torch.empty_like(mean)
-        call('hoig_inorm_stats', _p(x), B, HW, C, eps, _p(mean), _p(rstd), _p(ws), _st())
-        y = torch.empty_like(x)
         if act != L.ACT_NONE and residual is not None:
             raise ValueError('activation + residual in one instance-norm epilogue is not defined')
-        call('hoig_inorm_apply', _p(x), _p(mean), _p(rstd), mode, _p(p0), _p(p1), act, slope, _p(residual), _p(y),
-             B, HW, C, _st())
+        mean = torch.empty(B * C, dtype=torch.float32, device=x.device)
+        rstd = torch.empty_like(mean)
+        y = torch.empty_like(x)
+        # maps of <= 1024 pixels: statistics + apply in one launch from one read of x
+        rc = L.lib.hoig_inorm_fwd_fused(_p(x), mode, _p(p0), _p(p1), C, act, slope, _p(residual), eps, _p(y), _p(mean), _p(rstd),
+                                        B, HW, C, _st())
+        if rc == L.EUNSUPPORTED:
+            ws = _norm_workspace(L.lib.hoig_inorm_workspace_bytes(B, HW, C) // 4, x.device)
+            call('hoig_inorm_stats', _p(x), B, HW, C, eps, _p(mean), _p(rstd), _p(ws), _st())
+            call('hoig_inorm_apply', _p(x), _p(mean), _p(rstd), mode, _p(p0), _p(p1), act, slope, _p(residual), _p(y),
+                 B, HW, C, _st())
+        else:
+            L.check(rc, 'hoig_inorm_fwd_fused')
         ctx.cfg = (mode, act, slope, B, HW, C, residual is not None)
         # (Leaky)ReLU after a plain / affine norm: the backward recomputes the activation mask from x instead of reading y
         y_free = act in (L.ACT_RELU, L.ACT_LRELU) and mode in (0, 1) and not _NORM_KEEP_Y
@@ -359,7 +367,6 @@ class _INorm(Function):
         x, mean, rstd, p0, p1, y = ctx.saved_tensors
         mode, act, slope, B, HW, C, has_res = ctx.cfg
         dy = dy.contiguous()
-        ws = _norm_workspace(L.lib.hoig_inorm_workspace_bytes(B, HW, C) // 4, x.device)
         dx = torch.empty_like(x)
         dp0 = dp1 = r0 = r1 = None
         if mode == 1:
@@ -369,8 +376,14 @@ class _INorm(Function):
         elif mode == 2:
             dp0, dp1 = torch.empty_like(x), torch.empty_like(x)
             r0, r1 = dp0, dp1
-        call('hoig_inorm_bwd', _p(x), _p(mean), _p(rstd), mode, _p(p0), _p(p1) if mode == 1 else None, _p(y), _p(dy), act,
-             slope, _p(dx), _p(dp0), _p(dp1), B, HW, C, _p(ws), _st())
+        rc = L.lib.hoig_inorm_bwd_fused(_p(x), _p(mean), _p(rstd), mode, _p(p0), _p(p1) if mode == 1 else None, C, _p(y), _p(dy),
+                                        act, slope, _p(dx), _p(dp0), _p(dp1), B, HW, C, _st())
+        if rc == L.EUNSUPPORTED:
+            ws = _norm_workspace(L.lib.hoig_inorm_workspace_bytes(B, HW, C) // 4, x.device)
+            call('hoig_inorm_bwd', _p(x), _p(mean), _p(rstd), mode, _p(p0), _p(p1) if mode == 1 else None, _p(y), _p(dy), act,
+                 slope, _p(dx), _p(dp0), _p(dp1), B, HW, C, _p(ws), _st())
+        else:
+            L.check(rc, 'hoig_inorm_bwd_fused')
         return dx, r0, r1, None, None, None, (dy if has_res else None), None
 
 
@@ -395,13 +408,18 @@ class _SpadeFused(Function):
         B, H, W, C = x.shape
         assert gb.shape[-1] == 2 * C
         HW = H * W
-        ws = _norm_workspace(L.lib.hoig_inorm_workspace_bytes(B, HW, C) // 4, x.device)
         mean = torch.empty(B * C, dtype=torch.float32, device=x.device)
         rstd = torch.empty_like(mean)
-        call('hoig_inorm_stats', _p(x), B, HW, C, eps, _p(mean), _p(rstd), _p(ws), _st())
         y = torch.empty_like(x)
-        call('hoig_inorm_apply_ld', _p(x), _p(mean), _p(rstd), 2, _p(gb), gb.data_ptr() + 4 * C, 2 * C, act, slope, None,
-             _p(y), B, HW, C, _st())
+        rc = L.lib.hoig_inorm_fwd_fused(_p(x), 2, _p(gb), gb.data_ptr() + 4 * C, 2 * C, act, slope, None, eps, _p(y), _p(mean),
+                                        _p(rstd), B, HW, C, _st())
+        if rc == L.EUNSUPPORTED:
+            ws = _norm_workspace(L.lib.hoig_inorm_workspace_bytes(B, HW, C) // 4, x.device)
+            call('hoig_inorm_stats', _p(x), B, HW, C, eps, _p(mean), _p(rstd), _p(ws), _st())
+            call('hoig_inorm_apply_ld', _p(x), _p(mean), _p(rstd), 2, _p(gb), gb.data_ptr() + 4 * C, 2 * C, act, slope, None,
+                 _p(y), B, HW, C, _st())
+        else:
+            L.check(rc, 'hoig_inorm_fwd_fused')
         ctx.cfg = (act, slope, B, HW, C)
         ctx.save_for_backward(x, mean, rstd, gb, y if act != L.ACT_NONE else None)
         return y
@@ -411,11 +429,16 @@ class _SpadeFused(Function):
         x, mean, rstd, gb, y = ctx.saved_tensors
         act, slope, B, HW, C = ctx.cfg
         dy = dy.contiguous()
-        ws = _norm_workspace(L.lib.hoig_inorm_workspace_bytes(B, HW, C) // 4, x.device)
         dx = torch.empty_like(x)
         dgb = torch.empty_like(gb)
-        call('hoig_inorm_bwd_ld', _p(x), _p(mean), _p(rstd), 2, _p(gb), None, 2 * C, _p(y), _p(dy), act, slope, _p(dx), _p(dgb),
-             dgb.data_ptr() + 4 * C, B, HW, C, _p(ws), _st())
+        rc = L.lib.hoig_inorm_bwd_fused(_p(x), _p(mean), _p(rstd), 2, _p(gb), None, 2 * C, _p(y), _p(dy), act, slope, _p(dx),
+                                        _p(dgb), dgb.data_ptr() + 4 * C, B, HW, C, _st())
+        if rc == L.EUNSUPPORTED:
+            ws = _norm_workspace(L.lib.hoig_inorm_workspace_bytes(B, HW, C) // 4, x.device)
+            call('hoig_inorm_bwd_ld', _p(x), _p(mean), _p(rstd), 2, _p(gb), None, 2 * C, _p(y), _p(dy), act, slope, _p(dx),
+                 _p(dgb), dgb.data_ptr() + 4 * C, B, HW, C, _p(ws), _st())
+        else:
+            L.check(rc, 'hoig_inorm_bwd_fused')
         return dx, dgb, None, None, None
 
 

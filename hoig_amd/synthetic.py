@@ -49,7 +49,18 @@ def make_inputs(batch, side, seed=8, dataset='hov3'):
         for side_name in ('src', 'tsf'):
             rgb = g.uniform(-1.0, 1.0, size=(3, S, S)).astype(np.float32)
             hand, (cy, cx, r) = _blob(g, S, 0.12, 0.2)
-            objm, _ = _blob(g, S, 0.10, 0.18)
+            objm, (oy, ox, orad) = _blob(g, S, 0.10, 0.18)
+            if not (objm * (1.0 - hand)).any():
+                # the object disk fell entirely inside the hand disk: a hand-object pair always shows some of the object, and an
+                # all-zero object image makes obj_model's input spatially constant -- its instance norms then normalise pure
+                # rounding noise (variance 0 + eps), an ill-conditioned case in the reference too.  Slide the object along the
+                # line of centres until it sticks out (no random numbers consumed: every other sample stays bit-identical).
+                dy_, dx_ = oy - cy, ox - cx
+                nrm = float(np.hypot(dy_, dx_))
+                dy_, dx_ = (dy_ / nrm, dx_ / nrm) if nrm > 1e-6 else (0.0, 1.0)
+                oy, ox = cy + dy_ * (r + 0.5 * orad), cx + dx_ * (r + 0.5 * orad)
+                yy, xx = np.mgrid[0:S, 0:S].astype(np.float32)
+                objm = ((yy - oy) ** 2 + (xx - ox) ** 2 <= orad * orad).astype(np.float32)
             fg = np.maximum(hand, objm)
             bgm = 1.0 - fg                           # background = outside hand-object region
             # 15x15 erosion of the background mask (trainer.py:136 feeds the eroded mask)

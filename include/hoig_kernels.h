@@ -125,6 +125,18 @@ int hoig_inorm_apply_ld(const float *x, const float *mean, const float *rstd, in
 int hoig_inorm_bwd_ld(const float *x, const float *mean, const float *rstd, int mode, const float *p0, const float *p1,
                       int ld_p, const float *y, const float *dy, int act, float slope, float *dx, float *dp0, float *dp1, int B,
                       int HW, int C, void *workspace, hoig_stream_t stream);
+/* Single-launch instance norm for maps of at most 1024 pixels with C % 32 == 0 (the 32x32 bottleneck and below): a workgroup
+ * keeps a (sample, 32-channel) slab in registers -- statistics (two-pass), normalise / modulate / activate (+ residual) from
+ * one read of x; the backward likewise from one read of x and dy.  Same argument meaning as hoig_inorm_stats +
+ * hoig_inorm_apply_ld / hoig_inorm_bwd_ld; mode-1 parameter gradients accumulate atomically, no workspace.
+ * HOIG_EUNSUPPORTED for other shapes: the caller then uses the streaming kernels above. */
+int hoig_inorm_fwd_fused(const float *x, int mode, const float *p0, const float *p1, int ld_p, int act, float slope,
+                         const float *residual /*nullable*/, float eps, float *y, float *mean, float *rstd, int B, int HW,
+                         int C, hoig_stream_t stream);
+int hoig_inorm_bwd_fused(const float *x, const float *mean, const float *rstd, int mode, const float *p0, const float *p1,
+                         int ld_p, const float *y /*nullable, see hoig_inorm_bwd_ld*/, const float *dy, int act, float slope,
+                         float *dx, float *dp0, float *dp1, int B, int HW, int C, hoig_stream_t stream);
+
 /* backward of hoig_inorm_apply(+stats).  dy is d/d(y) ; y is the forward output (for the activation mask; pass
  * the pre-residual activation output, or NULL when act==NONE).  For ReLU / LeakyReLU after a plain (mode 0) or affine
  * (mode 1, p1 = its bias) norm, y may also be NULL: the mask is recomputed from x, one tensor less to read per pass.

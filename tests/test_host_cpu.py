@@ -123,6 +123,11 @@ def test_synthetic_inputs_deterministic_and_in_range():
     assert tuple(d['input_G_src_hand'].shape) == (1, 12, 32, 32) and 'armask_src' not in d
     c = synthetic.make_inputs(2, 32, seed=9)
     assert not torch.equal(a['real_src'], c['real_src'])
+    # every pair shows some of its object in both views (an all-zero object image is an ill-conditioned input: the instance
+    # norms of obj_model would normalise rounding noise)
+    big = synthetic.make_inputs(32, 64, seed=8)
+    for k in ('input_G_src_obj', 'input_G_tsf_obj'):
+        assert bool((big[k][:, 6:].flatten(1).sum(1) > 0).all()), k
 
 
 def test_eval_writer_matches_reference_layout(tmp_path):

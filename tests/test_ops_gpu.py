@@ -373,7 +373,7 @@ def test_conv_bf16x3_fast_path(B, Ci, Co, H, k, stride, pad, transposed, mode):
     ef, ed, ew = rel_err(nchw_cpu(y), yr), rel_err(nchw_cpu(xd.grad), xr.grad), rel_err(wd.grad, wr.grad)
     print('%s: fwd %.2e dgrad %.2e wgrad %.2e' % (mode, ef, ed, ew))
     assert ef < bf and ed < bd and ew < bw
-    if mode == 'f16x2':
+    if mode == 'f16x2' and Ci > 32 and Co > 32:          # (<= 32 gathered channels: that launch runs on the exact-fp32 kernels)
         assert ef > 2e-5 and ed > 1e-4, 'the two-term kernels did not run (error is at the three-term level)'
 
 
