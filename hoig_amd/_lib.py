@@ -68,10 +68,11 @@ _SIGS = {
     'hoig_inorm_bwd': [_vp, _vp, _vp, _i, _vp, _vp, _vp, _vp, _i, _f, _vp, _vp, _vp, _i, _i, _i, _vp, _vp],
     'hoig_replicate_pad_fwd': [_vp, _vp, _i, _i, _i, _i, _i, _vp],
     'hoig_replicate_pad_bwd': [_vp, _vp, _i, _i, _i, _i, _i, _vp],
-    'hoig_attn_sample_bwd': [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp],
-    'hoig_attn_pixel_fwd': [_vp] * 9 + [_i, _i, _i, _i, _vp],
-    'hoig_attn_pixel_bwd': [_vp] * 9 + [_i, _i, _i, _i, _vp],
-    'hoig_attn_gs_scatter': [_vp, _vp, _vp, _i, _i, _i, _vp],
+    'hoig_attn_pixel_fwd': [_vp] * 10 + [_i, _i, _i, _i, _vp],
+    'hoig_attn_pixel_bwd': [_vp] * 10 + [_i, _i, _i, _i, _vp],
+    'hoig_attn_build_index': [_vp, _vp, _i, _i, _i, _vp],
+    'hoig_attn_src_gather': [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp],
+    'hoig_attn_gs_gather': [_vp, _vp, _vp, _vp, _i, _i, _i, _vp],
     'hoig_block_extractor_forward': [_vp, _vp, _vp] + [_i] * 7 + [_vp],
     'hoig_block_extractor_backward': [_vp] * 5 + [_i] * 7 + [_vp],
     'hoig_local_attn_reshape_forward': [_vp, _vp] + [_i] * 4 + [_vp],
@@ -117,6 +118,8 @@ def _load():
         fn.restype = ctypes.c_int
     lib.hoig_inorm_workspace_bytes.argtypes = [_i, _i, _i]
     lib.hoig_inorm_workspace_bytes.restype = ctypes.c_int64
+    lib.hoig_attn_index_ints.argtypes = [_i, _i, _i]
+    lib.hoig_attn_index_ints.restype = ctypes.c_int64
     lib.hoig_rasterize_workspace_bytes.restype = ctypes.c_size_t
     lib.hoig_rasterize_workspace_bytes.argtypes = [ctypes.c_int, ctypes.c_int]
     lib.hoig_version.argtypes = []

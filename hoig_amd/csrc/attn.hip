@@ -80,139 +80,6 @@ __global__ void replicate_pad_bwd_kernel(const float *__restrict__ dy, float *__
     }
 }
 
-// ---------------------------------------------------------------------------------------------- source gradient scatter
-// dsource += bilinear^T( attn[m][q]/25 * dout[m][c] )   -- the source gradient of out[m] = (1/25) sum_q a_q S[m][q].
-// The 25 taps of a pixel sample a regular 5x5 grid shifted by the pixel's flow, all with the SAME bilinear fractions, so
-// their 100 (tap, corner) contributions collapse to a 6x6 footprint: out[i][j] = sum_{a,b in {0,1}} w_ab * v[i-a][j-b]
-// (a 2x2 "full" correlation done in registers).
-// LDS float atomics run at ~0.5 lane/clk/CU on gfx950 (measured: they were 80 % of this kernel), so the footprints are
-// accumulated WITHOUT atomics: a workgroup is ONE wave that owns 32 channels of a TILE x TILE pixel tile and walks its
-// pixels one after the other; lanes = 32 channels x 2 footprint halves (rows 0-2 / 3-5), i.e. the 64 lanes of one
-// instruction always touch 64 distinct patch words, and LDS operations of one wave execute in order, so a plain
-// read / add / write per cell is exact.  The patch is indexed by UNCLAMPED image coordinates (tile +- PRAD); K1's
-// border clamp is applied when the patch is flushed to dsource with global atomics.  Pixels whose footprint leaves the
-// patch (|flow| > ~PRAD-3) scatter straight to global memory.
-constexpr int PCH = 32;
-template <int TILE, int PRAD>
-__global__ __launch_bounds__(64) void attn_sample_bwd_kernel(const float *__restrict__ flow,
-                                                             const float *__restrict__ attn, const float *__restrict__ dout,
-                                                             float *__restrict__ dsrc, int B, int H, int W, int C) {
-    constexpr int PS = TILE + 2 * PRAD;
-    __shared__ float patch[PS * PS * PCH];
-    const int tiles_x = (W + TILE - 1) / TILE, tiles_y = (H + TILE - 1) / TILE;
-    int t = blockIdx.x;
-    const int bx = t % tiles_x;
-    t /= tiles_x;
-    const int by = t % tiles_y, b = t / tiles_y;
-    const int c0 = blockIdx.y * PCH;
-    const int hw = H * W;
-    // patch origin (unclamped image coordinates), one cell further up-left than centred: the footprint of a pixel starts at
-    // floor(flow) - 2, and off-hand pixels carry flow = -2 - identity in (-3, -1] (generator.py:484-488 on the -2 sentinel,
-    // treated as PIXELS by K1) -- centred, the first row / column of every tile fell off the patch onto the atomic path
-    constexpr int shift = 1;
-    const int py0 = by * TILE - PRAD - shift, px0 = bx * TILE - PRAD - shift;
-    const int lane = threadIdx.x, c = lane & 31, h = lane >> 5;
-    for (int i = lane; i < PS * PS * PCH; i += 64) patch[i] = 0.f;
-    __syncthreads();
-    float *dimg = dsrc + (size_t)b * hw * C + c0 + c;
-    const int rb = h ? 2 : 0;                                   // first tap row this half reads
-    // (explicit software pipelining of the next pixels' loads -- 1 or 4 pixels ahead -- measured slower than letting five
-    // one-wave workgroups per CU interleave)
-    struct Pix {
-        float v[3][KS];
-        float fx, fy;
-        int y, x;
-    };
-    auto load_pix = [&](int pl, Pix &P) {
-        P.y = by * TILE + pl / TILE;
-        P.x = bx * TILE + pl % TILE;
-        if (pl >= TILE * TILE || P.y >= H || P.x >= W) {
-            P.y = -1;
-            return;
-        }
-        const int rem = P.y * W + P.x;
-        const size_t m = (size_t)b * hw + rem;
-        P.fx = flow[((size_t)b * 2 + 0) * hw + rem];
-        P.fy = flow[((size_t)b * 2 + 1) * hw + rem];
-        const float go = dout[m * C + c0 + c] * (1.f / NTAP);
-        const float *am = attn + m * NTAP;
-#pragma unroll
-        for (int k = 0; k < 3; ++k)
-#pragma unroll
-            for (int q = 0; q < KS; ++q) {
-                const int tap = (rb + k) * KS + q;
-                P.v[k][q] = am[tap] * go;
-            }
-    };
-    auto scatter = [&](const Pix &P) {
-        if (P.y < 0) return;
-        int by0, bx0;
-        float wy1, wx1;
-        k1_frame(P.fy, P.y, by0, wy1);
-        k1_frame(P.fx, P.x, bx0, wx1);
-        by0 -= KS / 2;                                              // tap (0,0)
-        bx0 -= KS / 2;
-        const float wy0 = 1.f - wy1, wx0 = 1.f - wx1;
-        // x pass: xr[k][j] = wx0 * v[k][j] + wx1 * v[k][j-1], j = 0..5
-        float xr[3][KS + 1];
-#pragma unroll
-        for (int k = 0; k < 3; ++k) {
-            xr[k][0] = wx0 * P.v[k][0];
-#pragma unroll
-            for (int j = 1; j < KS; ++j) xr[k][j] = wx0 * P.v[k][j] + wx1 * P.v[k][j - 1];
-            xr[k][KS] = wx1 * P.v[k][KS - 1];
-        }
-        // y pass for this half's three footprint rows i = 3h + k:
-        //   h = 0 (v rows 0,1,2): o_k = wy0 * xr[k]   + wy1 * xr[k-1]      h = 1 (v rows 2,3,4): o_k = wy0 * xr[k+1] + wy1 * xr[k]
-        float o[3][KS + 1];
-#pragma unroll
-        for (int k = 0; k < 3; ++k)
-#pragma unroll
-            for (int j = 0; j <= KS; ++j) {
-                const float up = h ? (k < 2 ? xr[k + 1][j] : 0.f) : xr[k][j];
-                const float dn = h ? xr[k][j] : (k > 0 ? xr[k - 1][j] : 0.f);
-                o[k][j] = wy0 * up + wy1 * dn;
-            }
-        const int ly0 = by0 - py0, lx0 = bx0 - px0;
-        if (ly0 >= 0 && ly0 + KS < PS && lx0 >= 0 && lx0 + KS < PS) {
-            float *cell = patch + ((ly0 + 3 * h) * PS + lx0) * PCH + c;
-            float old[3][KS + 1];
-#pragma unroll
-            for (int k = 0; k < 3; ++k)
-#pragma unroll
-                for (int j = 0; j <= KS; ++j) old[k][j] = cell[(k * PS + j) * PCH];
-#pragma unroll
-            for (int k = 0; k < 3; ++k)
-#pragma unroll
-                for (int j = 0; j <= KS; ++j) cell[(k * PS + j) * PCH] = old[k][j] + o[k][j];
-        } else {
-#pragma unroll
-            for (int k = 0; k < 3; ++k) {
-                const int yy = max(min(by0 + 3 * h + k, H - 1), 0);
-#pragma unroll
-                for (int j = 0; j <= KS; ++j) {
-                    const int xx = max(min(bx0 + j, W - 1), 0);
-                    atomicAdd(dimg + ((size_t)yy * W + xx) * C, o[k][j]);
-                }
-            }
-        }
-    };
-#pragma unroll 2
-    for (int pl = 0; pl < TILE * TILE; ++pl) {
-        Pix P;
-        load_pix(pl, P);
-        scatter(P);
-    }
-    __syncthreads();
-    for (int cell = h; cell < PS * PS; cell += 2) {
-        const float v = patch[cell * PCH + c];
-        if (v != 0.f) {
-            const int yy = max(min(py0 + cell / PS, H - 1), 0), xx = max(min(px0 + cell % PS, W - 1), 0);
-            atomicAdd(dimg + ((size_t)yy * W + xx) * C, v);
-        }
-    }
-}
-
 // ---------------------------------------------------------------------------------------------- per-pixel softmax
 // Gs lives on the extended grid p in [-2, H+1] x [-2, W+1] (array index p + 2); beyond it every tap reads the border pixel,
 // so a clamped read is exact for any flow.
@@ -235,7 +102,8 @@ __global__ __launch_bounds__(256) void attn_pixel_fwd_kernel(const float *__rest
                                                              const float *__restrict__ flow, const float *__restrict__ w2,
                                                              const float *__restrict__ b2, const float *__restrict__ src,
                                                              float *__restrict__ hidden, float *__restrict__ attn,
-                                                             float *__restrict__ out, int B, int H, int W, int C) {
+                                                             float *__restrict__ out, float *__restrict__ kfout, int B, int H,
+                                                             int W, int C) {
     constexpr int PIX = 8;
     __shared__ float hs[PIX][NH];
     __shared__ float w2s[NTAP][NH + 1];
@@ -306,6 +174,7 @@ __global__ __launch_bounds__(256) void attn_pixel_fwd_kernel(const float *__rest
                     k += (a ? f.wy1 : 1.f - f.wy1) * (bb ? f.wx1 : 1.f - f.wx1) * as[p][ty * KS + tx];
             }
         kf[p][c] = k;
+        if (kfout && m0 + p < M) kfout[(size_t)(m0 + p) * NFP + c] = k;      // saved for the source-gradient gather
     }
     __syncthreads();
     const int CV = C >> 2;
@@ -335,6 +204,103 @@ __global__ __launch_bounds__(256) void attn_pixel_fwd_kernel(const float *__rest
     }
 }
 
+// E[m][i*6+j] = <dout[m], source cell (i,j) of pixel m's footprint> (36 dot products of length C per pixel).  One wave per
+// pixel, lane = footprint cell: every lane streams ITS cell's channel row (a whole 128-B line per step, so nothing relies on
+// L1 keeping 36 x #waves lines alive) against the pixel's dout row (wave-uniform loads); no cross-lane reduction at all.
+// (Round 1 read the 25 x C sampled tensor here; the first S-free version reduced each cell across the lanes of a wave, 216
+// shuffles per pixel, two pixels per wave in sequence: 200 us per launch.)
+__global__ __launch_bounds__(256) void attn_edots_kernel(const float *__restrict__ src, const float *__restrict__ flow,
+                                                         const float *__restrict__ dout, float *__restrict__ E, int B, int H,
+                                                         int W, int C) {
+    const int hw = H * W, M = B * hw;
+    const int m = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    if (m >= M) return;
+    const int b = m / hw, rem = m - b * hw;
+    const Frame f = pixel_frame(flow, b, rem, hw, rem / W, rem % W);
+    const int cell = lane < NFP ? lane : NFP - 1;
+    const int yy = clampi(f.by - KS / 2 + cell / FP, 0, H - 1), xx = clampi(f.bx - KS / 2 + cell % FP, 0, W - 1);
+    const float *sp = src + (((size_t)b * H + yy) * W + xx) * C;
+    const float *gp = dout + (size_t)m * C;
+    float acc = 0.f;
+    for (int c = 0; c < C; c += 32) {
+        float4 sv[8], gv[8];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            const bool ok = c + k * 4 < C;
+            sv[k] = ok ? *reinterpret_cast<const float4 *>(sp + c + k * 4) : make_float4(0.f, 0.f, 0.f, 0.f);
+            gv[k] = ok ? *reinterpret_cast<const float4 *>(gp + c + k * 4) : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+#pragma unroll
+        for (int k = 0; k < 8; ++k) acc += gv[k].x * sv[k].x + gv[k].y * sv[k].y + gv[k].z * sv[k].z + gv[k].w * sv[k].w;
+    }
+    if (lane < NFP) E[(size_t)m * NFP + lane] = acc;
+}
+
+// The same dot products with the lanes along the CHANNELS (every load a contiguous 512 B - 1 KB run of one source row): a
+// pixel is served by LPP = 64 (C = 256, 512) or 32 (C = 128) lanes that keep 36 partial dots in registers, and the 36 sums
+// over the lanes are taken by a halving butterfly -- at each step a lane keeps one half of its values and hands the other
+// half to its partner: 18 + 9 + 5 + 3 + 2 + 1 = 38 shuffles per wave instead of 36 x 6.
+template <int LPP, int VPL>
+__global__ __launch_bounds__(256) void attn_edots_ch_kernel(const float *__restrict__ src, const float *__restrict__ flow,
+                                                            const float *__restrict__ dout, float *__restrict__ E, int B, int H,
+                                                            int W) {
+    constexpr int C = LPP * VPL * 4, PPW = 64 / LPP;               // pixels per wave
+    const int hw = H * W, M = B * hw;
+    const int lane = threadIdx.x & 63, sub = lane / LPP, cl = lane % LPP;
+    const int m = (blockIdx.x * 4 + (threadIdx.x >> 6)) * PPW + sub;
+    const bool live = m < M;
+    const int mm = live ? m : M - 1;
+    const int b = mm / hw, rem = mm - b * hw;
+    const Frame f = pixel_frame(flow, b, rem, hw, rem / W, rem % W);
+    float4 go[VPL];
+#pragma unroll
+    for (int k = 0; k < VPL; ++k) go[k] = *reinterpret_cast<const float4 *>(dout + (size_t)mm * C + (cl + k * LPP) * 4);
+    const float *sb = src + (size_t)b * hw * C + cl * 4;
+    float v[NFP];
+#pragma unroll
+    for (int r = 0; r < FP; ++r) {
+        const float *row = sb + (size_t)clampi(f.by - KS / 2 + r, 0, H - 1) * W * C;
+        float4 sv[FP][VPL];
+#pragma unroll
+        for (int j = 0; j < FP; ++j) {
+            const float *sp = row + (size_t)clampi(f.bx - KS / 2 + j, 0, W - 1) * C;
+#pragma unroll
+            for (int k = 0; k < VPL; ++k) sv[j][k] = *reinterpret_cast<const float4 *>(sp + k * LPP * 4);
+        }
+#pragma unroll
+        for (int j = 0; j < FP; ++j) {
+            float a = 0.f;
+#pragma unroll
+            for (int k = 0; k < VPL; ++k) a += go[k].x * sv[j][k].x + go[k].y * sv[j][k].y + go[k].z * sv[j][k].z + go[k].w * sv[j][k].w;
+            v[r * FP + j] = a;
+        }
+    }
+    // halving butterfly over the LPP lanes of the pixel: after the step with partner distance o the lane holds the sums over
+    // its 2o-aligned group... of the index interval [lo, lo + n)
+    int lo = 0, cnt = NFP;                     // the lane's live values are v[0 .. cnt) = sums of the indices [lo, lo + cnt)
+#define HOIG_BFLY(N, O)                                                                                   \
+    {                                                                                                      \
+        constexpr int HALF = ((N) + 1) / 2;                                                                \
+        const bool up = (cl & (O)) != 0;                                                                   \
+        _Pragma("unroll") for (int j = 0; j < HALF; ++j) {                                                 \
+            const float hi = (HALF + j < (N)) ? v[HALF + j] : 0.f;                                         \
+            const float keep = up ? hi : v[j], send = up ? v[j] : hi;                                      \
+            v[j] = keep + __shfl_xor(send, (O), 64);                                                       \
+        }                                                                                                  \
+        lo += up ? HALF : 0;                                                                               \
+        cnt = up ? max(cnt - HALF, 0) : min(cnt, HALF);                                                    \
+    }
+    if (LPP == 64) {
+        HOIG_BFLY(36, 32) HOIG_BFLY(18, 16) HOIG_BFLY(9, 8) HOIG_BFLY(5, 4) HOIG_BFLY(3, 2) HOIG_BFLY(2, 1)
+        if (live && cnt > 0) E[(size_t)m * NFP + lo] = v[0];
+    } else {
+        HOIG_BFLY(36, 16) HOIG_BFLY(18, 8) HOIG_BFLY(9, 4) HOIG_BFLY(5, 2) HOIG_BFLY(3, 1)
+        if (live && cnt > 0) E[(size_t)m * NFP + lo] = v[0];
+        if (live && cnt > 1) E[(size_t)m * NFP + lo + 1] = v[1];
+    }
+#undef HOIG_BFLY
+}
+
 // da_q = (1/25) <dout[m], S[m][q]> = (1/25) sum_ab w_ab E[ty+a][tx+b], E[i][j] = <dout[m], source cell (i,j) of the footprint>;
 // dlogit = a*(da - <a,da>); dW2 += dlogit (x) leaky(h); db2 += dlogit; dhidden = (W2^T dlogit) * leaky'(h).
 // (The source gradient a_q/25*dout is attn_sample_bwd; the source gradient through `hidden` runs through dGs.)
@@ -343,8 +309,8 @@ __global__ __launch_bounds__(256) void attn_pixel_fwd_kernel(const float *__rest
 // workgroups on the same addresses, were a third of the kernel.
 constexpr int APB_NT = 1024, APB_PIX = APB_NT / 32, APB_ITEMS = (NTAP * NH + APB_NT - 1) / APB_NT;
 __global__ __launch_bounds__(APB_NT) void attn_pixel_bwd_kernel(const float *__restrict__ hidden, const float *__restrict__ attn,
-                                                                const float *__restrict__ w2, const float *__restrict__ src,
-                                                                const float *__restrict__ flow, const float *__restrict__ dout,
+                                                                const float *__restrict__ w2, const float *__restrict__ E,
+                                                                const float *__restrict__ flow,
                                                                 float *__restrict__ dhidden, float *__restrict__ dw2,
                                                                 float *__restrict__ db2, int B, int H, int W, int C, int nit) {
     constexpr int PIX = APB_PIX;
@@ -354,12 +320,12 @@ __global__ __launch_bounds__(APB_NT) void attn_pixel_bwd_kernel(const float *__r
     __shared__ float ef[PIX][NFP + 4];                   // footprint dot products E[i][j]
     __shared__ Frame fr[PIX];
     __shared__ float hl[PIX][NH];                        // leaky(hidden) of the group's pixels (read 25 times each for dW2)
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, hw = H * W, M = B * hw;
+    const int tid = threadIdx.x, hw = H * W, M = B * hw;
     for (int i = tid; i < NTAP * NH; i += APB_NT) w2s[i / NH][i % NH] = w2[i];
     float w2acc[APB_ITEMS], b2acc = 0.f;
 #pragma unroll
     for (int k = 0; k < APB_ITEMS; ++k) w2acc[k] = 0.f;
-    const int CV = C >> 2;
+    (void)C;
     for (int it = 0; it < nit; ++it) {
         const int m0 = (blockIdx.x * nit + it) * PIX;
         if (m0 >= M) break;                              // (uniform)
@@ -369,39 +335,9 @@ __global__ __launch_bounds__(APB_NT) void attn_pixel_bwd_kernel(const float *__r
             fr[tid] = pixel_frame(flow, b, rem, hw, rem / W, rem % W);
         }
         __syncthreads();
-        // E: a wave takes two pixels; its lanes split into G groups of LPP lanes, a group reduces one footprint cell at a time
-        for (int pp = 0; pp < 2; ++pp) {
-            const int p = wave * 2 + pp, m = m0 + p;
-            if (m >= M) continue;
-            const int b = m / hw;
-            const Frame f = fr[p];
-            const int LPP = CV >= 64 ? 64 : (CV >= 32 ? 32 : 16), G = 64 / LPP, ts = lane / LPP, cl = lane % LPP;
-            const float *sb = src + (size_t)b * hw * C;
-            for (int c0 = 0; c0 < NFP; c0 += 6 * G) {
-                float part[6];
-#pragma unroll
-                for (int u = 0; u < 6; ++u) {
-                    const int cell = c0 + u * G + ts;
-                    float acc = 0.f;
-                    if (cell < NFP) {
-                        const int yy = clampi(f.by - KS / 2 + cell / FP, 0, H - 1), xx = clampi(f.bx - KS / 2 + cell % FP, 0, W - 1);
-                        const float *sp = sb + ((size_t)yy * W + xx) * C;
-                        for (int cv = cl; cv < CV; cv += LPP) {
-                            const float4 go = *reinterpret_cast<const float4 *>(dout + (size_t)m * C + cv * 4);
-                            const float4 sv = *reinterpret_cast<const float4 *>(sp + cv * 4);
-                            acc += go.x * sv.x + go.y * sv.y + go.z * sv.z + go.w * sv.w;
-                        }
-                    }
-                    part[u] = acc;
-                }
-#pragma unroll
-                for (int u = 0; u < 6; ++u) {
-                    float v = part[u];
-                    for (int o = LPP >> 1; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
-                    const int cell = c0 + u * G + ts;
-                    if (cl == 0 && cell < NFP) ef[p][cell] = v;
-                }
-            }
+        for (int i = tid; i < PIX * NFP; i += APB_NT) {
+            const int p = i / NFP, cell = i % NFP;
+            ef[p][cell] = m0 + p < M ? E[(size_t)(m0 + p) * NFP + cell] : 0.f;
         }
         __syncthreads();
         {
@@ -460,32 +396,206 @@ __global__ __launch_bounds__(APB_NT) void attn_pixel_bwd_kernel(const float *__r
     if (tid < NTAP) atomicAdd(&db2[tid], b2acc);
 }
 
-// dGs[b][clamp(P + (a,b))][j] += w_ab(m) * dhidden[m][j]: the transpose of the bilinear read of Gs in attn_pixel_fwd.
-// One thread per (pixel, 4 channels); fp32 atomics (fire-and-forget) into the caller-zeroed [B, H+4, W+4, 128] tensor.
-__global__ __launch_bounds__(256) void attn_gs_scatter_kernel(const float *__restrict__ dhidden, const float *__restrict__ flow,
-                                                              float *__restrict__ dgs, int B, int H, int W) {
-    const int hw = H * W, Hg = H + 2 * GPAD, Wg = W + 2 * GPAD;
-    const int64_t n = (int64_t)B * hw * (NH / 4);
+// ---------------------------------------------------------------------------------------------- backward: gathers
+// The two source-side gradients of the layer are transposes of gathers through the pixels' sampling frames:
+//   dsource[cell] += sum_m kf(m)[cell - (P(m) - 2)] * dout[m]            (the weighted average; 6x6 footprint)
+//   dGs[cell]      = sum_m w_ab(m) * dhidden[m],  cell = P(m) + (a,b)     (the bilinear read of Gs; 2x2 footprint)
+// Round 1 scattered them with atomics (through LDS patches flushed with one global atomic per patch cell: the flush alone
+// was 4x the tensor's size in atomics).  Here the pixels are first BUCKETED by their frame cell P(m), clamped to
+// [-3, H+1] x [-3, W+1] (beyond that range every footprint cell clamps to the border anyway, so the clamped frame gives the
+// same result) -- a counting sort: count, scan, fill; the flow of a resolution is shared by all its attention layers, so the
+// host builds the index once per resolution and step -- and every output cell then GATHERS from the few buckets whose
+// footprints reach it: no atomics, every cell written once, exact for any flow.
+constexpr int BLO = 3;                       // bucket grid: P in [-BLO, H+1] -> (H + BLO + 2) rows
+__device__ __forceinline__ int bucket_dim(int n) { return n + BLO + 2; }
+
+__global__ void attn_bucket_count_kernel(const float *__restrict__ flow, int *__restrict__ counts, int *__restrict__ bucket_of,
+                                         int B, int H, int W) {
+    const int hw = H * W, M = B * hw;
+    const int m = blockIdx.x * 256 + threadIdx.x;
+    if (m >= M) return;
+    const int b = m / hw, rem = m - b * hw;
+    const Frame f = pixel_frame(flow, b, rem, hw, rem / W, rem % W);
+    const int py = clampi(f.by, -BLO, H + 1) + BLO, px = clampi(f.bx, -BLO, W + 1) + BLO;
+    const int bk = (b * bucket_dim(H) + py) * bucket_dim(W) + px;
+    bucket_of[m] = bk;
+    atomicAdd(&counts[bk], 1);
+}
+
+// exclusive scan of n ints in three small launches: per-1024 block scan, scan of the block totals (n <= 1M), offset add
+__global__ __launch_bounds__(1024) void scan_block_kernel(const int *__restrict__ in, int *__restrict__ out,
+                                                          int *__restrict__ totals, int n) {
+    __shared__ int buf[1024];
+    const int i = blockIdx.x * 1024 + threadIdx.x;
+    const int v = i < n ? in[i] : 0;
+    buf[threadIdx.x] = v;
+    __syncthreads();
+    for (int o = 1; o < 1024; o <<= 1) {
+        const int t = threadIdx.x >= o ? buf[threadIdx.x - o] : 0;
+        __syncthreads();
+        buf[threadIdx.x] += t;
+        __syncthreads();
+    }
+    if (i < n) out[i] = buf[threadIdx.x] - v;
+    if (threadIdx.x == 1023 && totals) totals[blockIdx.x] = buf[1023];
+}
+__global__ void scan_add_kernel(int *__restrict__ out, const int *__restrict__ block_off, int n) {
+    const int i = blockIdx.x * 1024 + threadIdx.x;
+    if (i < n) out[i] += block_off[blockIdx.x];
+}
+__global__ void attn_bucket_fill_kernel(const int *__restrict__ bucket_of, const int *__restrict__ offsets,
+                                        int *__restrict__ cursor, int *__restrict__ items, int M, int bw) {
+    const int m = blockIdx.x * 256 + threadIdx.x;
+    if (m >= M) return;
+    const int bk = bucket_of[m];
+    items[offsets[bk] + atomicAdd(&cursor[bk], 1)] = m | ((bk % bw) << 20);        // pixel | bucket column
+}
+
+// footprint index range [lo, hi] of frame row `p` (cells p - 2 + i, i = 0..5, border-clamped) that lands on cell `y`
+__device__ __forceinline__ void fp_range(int p, int y, int n, int span, int org, int &lo, int &hi) {
+    // cells q = p - org + i, i in [0, span); clamp(q, 0, n-1) == y
+    const int i0 = y - p + org;
+    lo = (y == 0) ? 0 : i0;
+    hi = (y == n - 1) ? span - 1 : i0;
+    if (y == 0) hi = min(hi, i0);            // q <= 0
+    if (y == n - 1) lo = max(lo, i0);        // q >= n-1
+    if (y == 0 && y == n - 1) { lo = 0; hi = span - 1; }
+    lo = max(lo, 0);
+    hi = min(hi, span - 1);
+}
+
+// dsource[b][y][x][c4] += sum over the buckets whose 6x6 footprint reaches cell (y, x).
+// The candidate frames of a cell are ALWAYS a 6 x 6 window of buckets (rows y-3 .. y+2; at the borders -3 .. 2 and
+// H-4 .. H+1, where several footprint rows clamp onto the cell), and the buckets of one row are consecutive, so their
+// pixels are ONE contiguous range of `items` (an item = pixel | bucket column << 20): per window row two offsets, then a
+// short list (~6-9 pixels).  A workgroup = a 4 x 4 patch of cells x 16 channel vectors (256 B per pixel row; the patch's cells
+// share most of their candidates, whose dout rows then come from L1).  The 16 lanes of a cell first build the cell's
+// (pixel, weight) list in LDS TOGETHER -- the index arithmetic and the kf lookups are per (cell, pixel), not per channel --
+// and then every lane walks the list: two LDS reads, one 16-B load and four FMAs per entry.
+constexpr int SG_ROWCAP = 16;                 // list slots per window row (a row with more pixels takes the slow path)
+__global__ __launch_bounds__(256) void attn_src_gather_kernel(const int *__restrict__ offsets, const int *__restrict__ items,
+                                                              const float *__restrict__ kfbuf, const float *__restrict__ dout,
+                                                              float *__restrict__ dsrc, int B, int H, int W, int C) {
+    __shared__ int lm[16][FP * SG_ROWCAP];
+    __shared__ float lw[16][FP * SG_ROWCAP];
+    const int CV = C >> 2, CVC = CV / 16;
+    const int bh = bucket_dim(H), bw = bucket_dim(W);
+    const int tiles_x = (W + 3) >> 2, tiles_y = (H + 3) >> 2;
+    int t = blockIdx.x;
+    const int cc = t % CVC;
+    t /= CVC;
+    const int tx = t % tiles_x;
+    t /= tiles_x;
+    const int ty = t % tiles_y, b = t / tiles_y;
+    const int cell = threadIdx.x >> 4, l16 = threadIdx.x & 15, cv = cc * 16 + l16;
+    const int y = ty * 4 + (cell >> 2), x = tx * 4 + (cell & 3);
+    const bool live = y < H && x < W;
+    const int py0 = y == 0 ? -BLO : (y == H - 1 ? H - 4 : y - 3);          // first of the six window rows / columns
+    const int px0 = x == 0 ? -BLO : (x == W - 1 ? W - 4 : x - 3);
+    int e0[FP], e1[FP];
+    float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+    for (int r = 0; r < FP; ++r) {
+        e0[r] = e1[r] = 0;
+        if (live) {
+            const int row = (b * bh + py0 + r + BLO) * bw + BLO;
+            e0[r] = offsets[row + px0];
+            e1[r] = offsets[row + px0 + FP];
+        }
+    }
+    auto weight_of = [&](int item, int ilo, int ihi) -> float {
+        const int m = item & 0xFFFFF, px = (item >> 20) - BLO;
+        int jlo, jhi;
+        fp_range(px, x, W, FP, KS / 2, jlo, jhi);
+        float ws = 0.f;
+        const float *kf = kfbuf + (size_t)m * NFP;
+        for (int ii = ilo; ii <= ihi; ++ii)
+            for (int jj = jlo; jj <= jhi; ++jj) ws += kf[ii * FP + jj];
+        return ws;
+    };
+#pragma unroll
+    for (int r = 0; r < FP; ++r) {
+        int ilo, ihi;
+        fp_range(py0 + r, y, H, FP, KS / 2, ilo, ihi);
+        const int cnt = (live && ilo <= ihi) ? e1[r] - e0[r] : 0;
+        // slots of this row: lane l fills slot l (SG_ROWCAP == 16 lanes)
+        int mm = -1;
+        float ww = 0.f;
+        if (l16 < cnt) {
+            const int item = items[e0[r] + l16];
+            mm = item & 0xFFFFF;
+            ww = weight_of(item, ilo, ihi);
+        }
+        lm[cell][r * SG_ROWCAP + l16] = mm;
+        lw[cell][r * SG_ROWCAP + l16] = ww;
+        // overflow (more than 16 pixels framed on one window row: strongly convergent flow): every lane walks the rest itself
+        for (int e = e0[r] + SG_ROWCAP; e < e0[r] + cnt; ++e) {
+            const int item = items[e];
+            const float w = weight_of(item, ilo, ihi);
+            const float4 g = *reinterpret_cast<const float4 *>(dout + (size_t)(item & 0xFFFFF) * C + cv * 4);
+            acc.x += w * g.x; acc.y += w * g.y; acc.z += w * g.z; acc.w += w * g.w;
+        }
+    }
+    __syncthreads();
+    if (!live) return;
+#pragma unroll
+    for (int r = 0; r < FP; ++r) {
+        const int cnt = min(e1[r] - e0[r], SG_ROWCAP);
+        for (int k0 = 0; k0 < cnt; k0 += 4) {
+            float4 g[4];
+            float w[4];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const int mm = k0 + k < cnt ? lm[cell][r * SG_ROWCAP + k0 + k] : -1;
+                w[k] = mm >= 0 ? lw[cell][r * SG_ROWCAP + k0 + k] : 0.f;
+                g[k] = mm >= 0 ? *reinterpret_cast<const float4 *>(dout + (size_t)mm * C + cv * 4) : make_float4(0.f, 0.f, 0.f, 0.f);
+            }
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                acc.x += w[k] * g[k].x; acc.y += w[k] * g[k].y; acc.z += w[k] * g[k].z; acc.w += w[k] * g[k].w;
+            }
+        }
+    }
+    float4 *dst = reinterpret_cast<float4 *>(dsrc + (((size_t)b * H + y) * W + x) * C + cv * 4);
+    float4 o = *dst;
+    o.x += acc.x; o.y += acc.y; o.z += acc.z; o.w += acc.w;
+    *dst = o;
+}
+
+// dGs[b][gy][gx][j4] = sum_m w_ab(m) * dhidden[m][j4] over the pixels whose frame corner (a,b) (clamped to [-2, H+1]) is the cell
+__global__ __launch_bounds__(256) void attn_gs_gather_kernel(const int *__restrict__ offsets, const int *__restrict__ items,
+                                                             const float *__restrict__ flow, const float *__restrict__ dhidden,
+                                                             float *__restrict__ dgs, int B, int H, int W) {
+    const int Hg = H + 2 * GPAD, Wg = W + 2 * GPAD, hw = H * W;
+    const int64_t n = (int64_t)B * Hg * Wg * (NH / 4);
+    const int bh = bucket_dim(H), bw = bucket_dim(W);
     for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
         const int jv = (int)(i % (NH / 4));
-        const int m = (int)(i / (NH / 4));
-        const int b = m / hw, rem = m - b * hw;
-        const Frame f = pixel_frame(flow, b, rem, hw, rem / W, rem % W);
-        const float4 d = *reinterpret_cast<const float4 *>(dhidden + (size_t)m * NH + jv * 4);
-        const int ys[2] = {clampi(f.by, -GPAD, H + GPAD - 1) + GPAD, clampi(f.by + 1, -GPAD, H + GPAD - 1) + GPAD};
-        const int xs[2] = {clampi(f.bx, -GPAD, W + GPAD - 1) + GPAD, clampi(f.bx + 1, -GPAD, W + GPAD - 1) + GPAD};
-        const float wy[2] = {1.f - f.wy1, f.wy1}, wx[2] = {1.f - f.wx1, f.wx1};
-#pragma unroll
-        for (int a = 0; a < 2; ++a)
-#pragma unroll
-            for (int bb = 0; bb < 2; ++bb) {
-                const float w = wx[bb] * wy[a];
-                float *g = dgs + (((size_t)b * Hg + ys[a]) * Wg + xs[bb]) * NH + jv * 4;
-                atomicAdd(g + 0, w * d.x);
-                atomicAdd(g + 1, w * d.y);
-                atomicAdd(g + 2, w * d.z);
-                atomicAdd(g + 3, w * d.w);
+        int64_t t = i / (NH / 4);
+        const int gx = (int)(t % Wg) - GPAD;
+        t /= Wg;
+        const int gy = (int)(t % Hg) - GPAD, b = (int)(t / Hg);
+        float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+        // frame rows p with clamp(p + a, -2, H+1) == gy for a in {0,1}: p in {gy-1, gy}, plus p = -3 for the first row
+        for (int py = max(gy - 1, -BLO); py <= min(gy, H + 1); ++py)
+            for (int px = max(gx - 1, -BLO); px <= min(gx, W + 1); ++px) {
+                const int bk = (b * bh + py + BLO) * bw + px + BLO;
+                const int e0 = offsets[bk], e1 = offsets[bk + 1];
+                for (int e = e0; e < e1; ++e) {
+                    const int m = items[e] & 0xFFFFF;
+                    const int rem = m - b * hw;
+                    const Frame f = pixel_frame(flow, b, rem, hw, rem / W, rem % W);
+                    float wy = 0.f, wx = 0.f;          // total weight of this pixel's corners that clamp onto the cell
+                    if (clampi(f.by, -GPAD, H + GPAD - 1) == gy) wy += 1.f - f.wy1;
+                    if (clampi(f.by + 1, -GPAD, H + GPAD - 1) == gy) wy += f.wy1;
+                    if (clampi(f.bx, -GPAD, W + GPAD - 1) == gx) wx += 1.f - f.wx1;
+                    if (clampi(f.bx + 1, -GPAD, W + GPAD - 1) == gx) wx += f.wx1;
+                    const float w = wy * wx;
+                    const float4 d = *reinterpret_cast<const float4 *>(dhidden + (size_t)m * NH + jv * 4);
+                    acc.x += w * d.x; acc.y += w * d.y; acc.z += w * d.z; acc.w += w * d.w;
+                }
             }
+        *reinterpret_cast<float4 *>(dgs + (((size_t)b * Hg + gy + GPAD) * Wg + gx + GPAD) * NH + jv * 4) = acc;
     }
 }
 
@@ -507,49 +617,74 @@ extern "C" int hoig_replicate_pad_bwd(const float *dy, float *dx, int B, int H, 
     HOIG_LAUNCH_CHECK();
     return HOIG_OK;
 }
-extern "C" int hoig_attn_sample_bwd(const float *flow, const float *attn, const float *dout, float *dsource, int B, int H,
-                                    int W, int C, hoig_stream_t stream) {
-    if (!flow || !attn || !dout || !dsource || (C % PCH)) return HOIG_EINVAL;
-    // 8x8 tiles (32 KB patch, 4-5 one-wave workgroups per CU) unless that leaves too few pixels per flush: 16x16 tiles for
-    // the large maps
-    static const int force = getenv("HOIG_ASB_TILE") ? atoi(getenv("HOIG_ASB_TILE")) : 0;
-    const bool big = force ? force == 16 : (int64_t)B * hoig_cdiv(H, 8) * hoig_cdiv(W, 8) * (C / PCH) > 8192;
-    if (big) {
-        const int tiles = B * (int)hoig_cdiv(H, 16) * (int)hoig_cdiv(W, 16);
-        attn_sample_bwd_kernel<16, 4><<<dim3(tiles, C / PCH), 64, 0, ST>>>(flow, attn, dout, dsource, B, H, W, C);
-    } else {
-        const int tiles = B * (int)hoig_cdiv(H, 8) * (int)hoig_cdiv(W, 8);
-        attn_sample_bwd_kernel<8, 4><<<dim3(tiles, C / PCH), 64, 0, ST>>>(flow, attn, dout, dsource, B, H, W, C);
-    }
+// workspace of the pixel index: [counts / offsets: nb + 1][cursor: nb][bucket_of: M][items: M][block totals: 2048] ints
+extern "C" int64_t hoig_attn_index_ints(int B, int H, int W) {
+    const int64_t nb = (int64_t)B * (H + BLO + 2) * (W + BLO + 2);
+    return 2 * (nb + 1) + 2 * (int64_t)B * H * W + 2048 + 8;
+}
+extern "C" int hoig_attn_build_index(const float *flow, int *index, int B, int H, int W, hoig_stream_t stream) {
+    if (!flow || !index || B <= 0 || H <= 0 || W <= 0) return HOIG_EINVAL;
+    const int64_t nb64 = (int64_t)B * (H + BLO + 2) * (W + BLO + 2);
+    const int M = B * H * W;
+    if (nb64 + 1 > 1024 * 1024 || M >= (1 << 20) || W + BLO + 2 >= 2048) return HOIG_EUNSUPPORTED;      // item = pixel | column << 20
+    const int nb = (int)nb64, n = nb + 1;
+    int *offsets = index, *cursor = index + n, *bucket_of = cursor + nb + 1, *items = bucket_of + M, *totals = items + M;
+    hipStream_t st = (hipStream_t)stream;
+    if (hipMemsetAsync(index, 0, (size_t)(2 * n + 1) * sizeof(int), st) != hipSuccess) return HOIG_ELAUNCH;   // counts, cursor
+    attn_bucket_count_kernel<<<(M + 255) / 256, 256, 0, st>>>(flow, offsets, bucket_of, B, H, W);
+    const int nblk = (n + 1023) / 1024;
+    scan_block_kernel<<<nblk, 1024, 0, st>>>(offsets, offsets, totals, n);
+    scan_block_kernel<<<1, 1024, 0, st>>>(totals, totals + 1024, nullptr, nblk);
+    scan_add_kernel<<<nblk, 1024, 0, st>>>(offsets, totals + 1024, n);
+    attn_bucket_fill_kernel<<<(M + 255) / 256, 256, 0, st>>>(bucket_of, offsets, cursor, items, M, W + BLO + 2);
+    HOIG_LAUNCH_CHECK();
+    return HOIG_OK;
+}
+extern "C" int hoig_attn_src_gather(const int *index, const float *kf, const float *dout, float *dsource, int B, int H, int W,
+                                    int C, hoig_stream_t stream) {
+    if (!index || !kf || !dout || !dsource || (C & 3) || B <= 0) return HOIG_EINVAL;
+    const int n = B * (H + BLO + 2) * (W + BLO + 2) + 1, M = B * H * W;
+    const int *items = index + 2 * n + M;
+    if (C % 64) return HOIG_EUNSUPPORTED;
+    const int64_t blocks = (int64_t)B * ((H + 3) / 4) * ((W + 3) / 4) * (C / 64);
+    attn_src_gather_kernel<<<(unsigned)blocks, 256, 0, ST>>>(index, items, kf, dout, dsource, B, H, W, C);
+    HOIG_LAUNCH_CHECK();
+    return HOIG_OK;
+}
+extern "C" int hoig_attn_gs_gather(const int *index, const float *flow, const float *dhidden, float *dgs, int B, int H, int W,
+                                   hoig_stream_t stream) {
+    if (!index || !flow || !dhidden || !dgs || B <= 0) return HOIG_EINVAL;
+    const int n = B * (H + BLO + 2) * (W + BLO + 2) + 1, M = B * H * W;
+    const int *items = index + 2 * n + M;
+    attn_gs_gather_kernel<<<hoig_stream_grid((int64_t)B * (H + 2 * GPAD) * (W + 2 * GPAD) * (NH / 4), 256), 256, 0, ST>>>(
+        index, items, flow, dhidden, dgs, B, H, W);
     HOIG_LAUNCH_CHECK();
     return HOIG_OK;
 }
 extern "C" int hoig_attn_pixel_fwd(const float *gt, const float *gs, const float *flow, const float *w2, const float *b2,
-                                   const float *source, float *hidden, float *attn, float *out, int B, int H, int W, int C,
-                                   hoig_stream_t stream) {
+                                   const float *source, float *hidden, float *attn, float *out, float *kf, int B, int H, int W,
+                                   int C, hoig_stream_t stream) {
     if (!gt || !gs || !flow || !w2 || !b2 || !source || !hidden || !attn || !out || (C & 3) || B <= 0 || H <= 0 || W <= 0)
         return HOIG_EINVAL;
     const int M = B * H * W;
-    attn_pixel_fwd_kernel<<<(M + 7) / 8, 256, 0, ST>>>(gt, gs, flow, w2, b2, source, hidden, attn, out, B, H, W, C);
+    attn_pixel_fwd_kernel<<<(M + 7) / 8, 256, 0, ST>>>(gt, gs, flow, w2, b2, source, hidden, attn, out, kf, B, H, W, C);
     HOIG_LAUNCH_CHECK();
     return HOIG_OK;
 }
 extern "C" int hoig_attn_pixel_bwd(const float *hidden, const float *attn, const float *w2, const float *source,
-                                   const float *flow, const float *dout, float *dhidden, float *dw2, float *db2, int B, int H,
-                                   int W, int C, hoig_stream_t stream) {
-    if (!hidden || !attn || !w2 || !source || !flow || !dout || !dhidden || !dw2 || !db2 || (C & 3) || B <= 0) return HOIG_EINVAL;
+                                   const float *flow, const float *dout, float *dhidden, float *dw2, float *db2, float *e_ws,
+                                   int B, int H, int W, int C, hoig_stream_t stream) {
+    if (!hidden || !attn || !w2 || !source || !flow || !dout || !dhidden || !dw2 || !db2 || !e_ws || (C & 3) || B <= 0)
+        return HOIG_EINVAL;
     const int M = B * H * W;
+    if (C == 512) attn_edots_ch_kernel<64, 2><<<(M + 3) / 4, 256, 0, ST>>>(source, flow, dout, e_ws, B, H, W);
+    else if (C == 256) attn_edots_ch_kernel<64, 1><<<(M + 3) / 4, 256, 0, ST>>>(source, flow, dout, e_ws, B, H, W);
+    else if (C == 128) attn_edots_ch_kernel<32, 1><<<(M + 7) / 8, 256, 0, ST>>>(source, flow, dout, e_ws, B, H, W);
+    else attn_edots_kernel<<<(M + 3) / 4, 256, 0, ST>>>(source, flow, dout, e_ws, B, H, W, C);
     const int groups = (M + APB_PIX - 1) / APB_PIX;
     const int nit = groups >= 2048 ? (groups / 1024 > 8 ? 8 : groups / 1024) : 1;      // ~1024 workgroups on the large maps
-    attn_pixel_bwd_kernel<<<(groups + nit - 1) / nit, APB_NT, 0, ST>>>(hidden, attn, w2, source, flow, dout, dhidden, dw2, db2,
-                                                                      B, H, W, C, nit);
-    HOIG_LAUNCH_CHECK();
-    return HOIG_OK;
-}
-extern "C" int hoig_attn_gs_scatter(const float *dhidden, const float *flow, float *dgs, int B, int H, int W,
-                                    hoig_stream_t stream) {
-    if (!dhidden || !flow || !dgs || B <= 0 || H <= 0 || W <= 0) return HOIG_EINVAL;
-    attn_gs_scatter_kernel<<<hoig_stream_grid((int64_t)B * H * W * (NH / 4), 256), 256, 0, ST>>>(dhidden, flow, dgs, B, H, W);
+    attn_pixel_bwd_kernel<<<(groups + nit - 1) / nit, APB_NT, 0, ST>>>(hidden, attn, w2, e_ws, flow, dhidden, dw2, db2, B, H, W, C,
+                                                                      nit);
     HOIG_LAUNCH_CHECK();
     return HOIG_OK;
 }

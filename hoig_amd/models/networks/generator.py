@@ -187,6 +187,7 @@ class Generator(ParamTree):
                      src_armask=None, tsf_armask=None):
         c = self.cfg
         self._seg_cache = {}
+        ops.attn_index_clear()
         src_bg_in = [bg, src_hand_c] + ([src_armask] if src_armask is not None else [])
         tsf_bg_in = [bg, tsf_hand_c] + ([tsf_armask] if tsf_armask is not None else [])
         # bg_model runs on the src and tsf inputs with SHARED weights (generator.py:367-369): one pass over the two

@@ -635,6 +635,26 @@ def _conv_dgrad_raw(d, g, w, dx, transposed=False):
     call('hoig_conv2d_bwd_data', ctypes.byref(d), _p(g), _p(w), _p(dx), _st())
 
 
+_attn_index = {}
+
+
+def attn_index_clear():
+    """Forget the pixel indices of the previous forward (called when a new forward starts: flows change per batch)."""
+    _attn_index.clear()
+
+
+def _attn_pixel_index(flow, B, H, W):
+    """The bucket index of a flow field (hoig_attn_build_index), built once per flow tensor: every attention layer of a
+    resolution shares its flow (generator.py:480-491), and the backward of each needs the same index."""
+    key = (flow.data_ptr(), B, H, W, torch.cuda.current_stream().cuda_stream)
+    hit = _attn_index.get(key)
+    if hit is None:
+        idx = torch.empty(L.lib.hoig_attn_index_ints(B, H, W), dtype=torch.int32, device=flow.device)
+        call('hoig_attn_build_index', _p(flow), _p(idx), B, H, W, _st())
+        hit = _attn_index[key] = (idx, flow)           # (the flow is held so that its address is not reused meanwhile)
+    return hit[0]
+
+
 class _LocalAttn(Function):
     """ExtractorAttn.forward (extract_attn.py:23-29) without any 25x-sized tensor (hoig_amd/csrc/attn.hip):
     Gt = conv5x5(replicate_pad(target, 2), wt) + b1 ; Gs = conv5x5(replicate_pad(source, 4), ws) on the grid [-2, H+1]^2 ;
@@ -664,25 +684,28 @@ class _LocalAttn(Function):
         hidden = torch.empty_like(gt)
         attn = torch.empty((M, 25), dtype=dt, device=dev)
         out = torch.empty_like(source)
+        kf = torch.empty((M, 36), dtype=dt, device=dev) if source.requires_grad else None
         call('hoig_attn_pixel_fwd', _p(gt), _p(gs), _p(flow), _p(w2), _p(b2), _p(source), _p(hidden), _p(attn), _p(out),
-             B, H, W, C, _st())
-        ctx.save_for_backward(source, flow, wt, ws, b1, w2, b2, tpad, spad, hidden, attn)
+             _p(kf), B, H, W, C, _st())
+        ctx.save_for_backward(source, flow, wt, ws, b1, w2, b2, tpad, spad, hidden, attn, kf)
         ctx.descs = _bwd_descs(d_t) + _bwd_descs(d_s)
         ctx.shape = (B, H, W, C)
         return out
 
     @staticmethod
     def backward(ctx, dout):
-        source, flow, wt, ws, b1, w2, b2, tpad, spad, hidden, attn = ctx.saved_tensors
+        source, flow, wt, ws, b1, w2, b2, tpad, spad, hidden, attn, kf = ctx.saved_tensors
         dt_dg, dt_wg, ds_dg, ds_wg = ctx.descs
         B, H, W, C = ctx.shape
         dout = dout.contiguous()
         gs = [_grad_target(p) for p in (wt, ws, b1, w2, b2)]
         dhid = torch.empty_like(hidden)                       # = dGt
+        e_ws = torch.empty((B * H * W, 36), dtype=dout.dtype, device=dout.device)
         call('hoig_attn_pixel_bwd', _p(hidden), _p(attn), _p(w2), _p(source), _p(flow), _p(dout), _p(dhid), _p(gs[3][0]),
-             _p(gs[4][0]), B, H, W, C, _st())
-        dgs = torch.zeros((B, H + 4, W + 4, 128), dtype=dout.dtype, device=dout.device)
-        call('hoig_attn_gs_scatter', _p(dhid), _p(flow), _p(dgs), B, H, W, _st())
+             _p(gs[4][0]), _p(e_ws), B, H, W, C, _st())
+        index = _attn_pixel_index(flow, B, H, W)
+        dgs = torch.empty((B, H + 4, W + 4, 128), dtype=dout.dtype, device=dout.device)
+        call('hoig_attn_gs_gather', _p(index), _p(flow), _p(dhid), _p(dgs), B, H, W, _st())
         side = _wgrad_side_stream(dout.device) if not any(r for _, r in gs) else None
         if side is not None:          # (see _Conv.backward)
             side.wait_stream(torch.cuda.current_stream())
@@ -706,7 +729,7 @@ class _LocalAttn(Function):
             _conv_dgrad_raw(ds_dg, dgs, ws, dspad)
             dsrc = torch.empty((B, H, W, C), dtype=dout.dtype, device=dout.device)
             call('hoig_replicate_pad_bwd', _p(dspad), _p(dsrc), B, H, W, C, 4, _st())            # (writes every element)
-            call('hoig_attn_sample_bwd', _p(flow), _p(attn), _p(dout), _p(dsrc), B, H, W, C, _st())   # += the weighted average's part
+            call('hoig_attn_src_gather', _p(index), _p(kf), _p(dout), _p(dsrc), B, H, W, C, _st())   # += the weighted average's part
         rets = [g if r else None for g, r in gs]
         return dsrc, dtgt, None, rets[0], rets[1], rets[2], rets[3], rets[4], None
 

@@ -165,17 +165,27 @@ int hoig_replicate_pad_bwd(const float *dy, float *dx, int B, int H, int W, int 
  * out[m][c] = (1/25) sum_q attn[m][q] * S[m][q][c]         S = K1's border-clamped bilinear samples of `source` [B,H,W,C],
  *                                                          evaluated over the pixel's 6x6 footprint, never stored */
 int hoig_attn_pixel_fwd(const float *gt, const float *gs, const float *flow, const float *w2, const float *b2,
-                        const float *source, float *hidden, float *attn, float *out, int B, int H, int W, int C,
-                        hoig_stream_t stream);
-/* given dout: dhidden (overwritten; it is also dGt), dw2 / db2 (accumulated) */
+                        const float *source, float *hidden, float *attn, float *out, float *kf /*nullable*/, int B, int H,
+                        int W, int C, hoig_stream_t stream);
+/* kf (training only): [M][36] weights of the pixel's 6x6 source footprint in `out`, k[i][j] = (1/25) sum_ab w_ab attn[i-a][j-b],
+ * kept for hoig_attn_src_gather */
+/* given dout: dhidden (overwritten; it is also dGt), dw2 / db2 (accumulated); e_ws: M*36 floats of scratch (the dot products
+ * of dout[m] with the 36 source cells of pixel m's footprint) */
 int hoig_attn_pixel_bwd(const float *hidden, const float *attn, const float *w2, const float *source, const float *flow,
-                        const float *dout, float *dhidden, float *dw2, float *db2, int B, int H, int W, int C,
+                        const float *dout, float *dhidden, float *dw2, float *db2, float *e_ws, int B, int H, int W, int C,
                         hoig_stream_t stream);
-/* dgs += bilinear^T(dhidden)  (dgs: [B,H+4,W+4,128], caller-zeroed) */
-int hoig_attn_gs_scatter(const float *dhidden, const float *flow, float *dgs, int B, int H, int W, hoig_stream_t stream);
-/* dsource += bilinear^T( attn[m][q]/25 * dout[m][c] ): the source gradient of the weighted average (accumulates) */
-int hoig_attn_sample_bwd(const float *flow, const float *attn, const float *dout, float *dsource, int B, int H, int W, int C,
+/* The two source-side gradients are transposes of gathers through the pixels' sampling frames P(m) = floor(m + flow(m)).
+ * Instead of scattering with atomics (K2, block_extractor_kernel.cu:158-161) the pixels are bucketed by their frame cell
+ * (counting sort: `index`, hoig_attn_index_ints(B,H,W) ints of caller memory; depends on the flow only, so one index serves
+ * every attention layer of a resolution) and each output cell gathers from the buckets whose footprints reach it. */
+int64_t hoig_attn_index_ints(int B, int H, int W);
+int hoig_attn_build_index(const float *flow, int32_t *index, int B, int H, int W, hoig_stream_t stream);
+/* dsource[cell] += sum_m kf[m][cell's position in m's 6x6 footprint] * dout[m]   (the weighted average's source gradient) */
+int hoig_attn_src_gather(const int32_t *index, const float *kf, const float *dout, float *dsource, int B, int H, int W, int C,
                          hoig_stream_t stream);
+/* dgs = bilinear^T(dhidden)  (dgs: [B,H+4,W+4,128], every element written) */
+int hoig_attn_gs_gather(const int32_t *index, const float *flow, const float *dhidden, float *dgs, int B, int H, int W,
+                        hoig_stream_t stream);
 
 /* Stand-alone drop-ins for the reference's two pybind ops, same argument meaning, contiguous NCHW fp32,
  * caller zero-fills outputs: block_extractor_cuda.forward/backward (block_extractor_cuda.cc:5-33) and

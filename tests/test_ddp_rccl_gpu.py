@@ -53,12 +53,15 @@ def _run(use_ddp, port, q):
     if use_ddp:
         assert dist.get_backend() == 'nccl' and m._G.sync.active and m._D.sync.active and len(m._G.sync.slices) > 4
     errs = []
-    for _ in range(STEPS):
+    g = m._net(m._G)
+    mom = None
+    for s in range(STEPS):
         m.optimize_parameters()
         errs.append(dict(m.get_current_errors()))
+        if s == 0:            # Adam's first moment after ONE step = (1 - beta1) * (exchanged) gradient of the seeded weights
+            torch.cuda.synchronize()
+            mom = {k: v.clone() for k, v in g.export_dict(m._optimizer_G.exp_avg).items() if k in PROBE}
     torch.cuda.synchronize()
-    g = m._net(m._G)
-    mom = g.export_dict(m._optimizer_G.exp_avg)
     sd = g.state_dict()
     dsum = float(m._net(m._D).flat.double().abs().sum().item())
     q.put((errs, {k: mom[k].cpu().numpy().copy() for k in PROBE}, {k: sd[k].cpu().numpy().copy() for k in PROBE}, dsum, calls))
@@ -95,9 +98,10 @@ def test_rccl_exchange_path_equals_plain_step_and_oracle():
             assert abs(e_ddp[s][k] - e_one[s][k]) <= 5e-4 * max(abs(want), 1e-2), (s, k, e_ddp[s][k], e_one[s][k])
     for k in PROBE:
         rel = np.linalg.norm(mom_ddp[k] - mom_one[k]) / np.linalg.norm(mom_one[k])
-        print('rccl(world 1, forced) vs plain  %-44s Adam-moment rel-L2 %.2e' % (k, rel))
+        print('rccl(world 1, forced) vs plain  %-44s first-step gradient rel-L2 %.2e' % (k, rel))
         assert rel < 2e-2, (k, rel)            # fp32-atomic summation order differs from run to run; same floor as two plain runs
         assert np.isfinite(w_ddp[k]).all()
-        # Adam's step is ~lr*sign(g): rounding-level gradient elements may flip; the bulk must move identically
-        assert np.mean(np.abs(w_ddp[k] - w_one[k]) <= 1e-6) > 0.9, k
+        # after two Adam steps of ~lr*sign(g) each (rounding-level gradient elements may flip) no weight is further than
+        # 2 steps from the plain run's
+        assert np.abs(w_ddp[k] - w_one[k]).max() <= 2.2 * STEPS * 2e-4, k
     assert abs(dsum_ddp - dsum_one) <= 1e-3 * dsum_one
