@@ -89,6 +89,7 @@ _SIGS = {
     'hoig_copy_channels': [_vp, _vp, _i64, _i, _i, _i, _i, _i, _i, _vp],
     'hoig_cat2_channels': [_vp, _i, _vp, _i, _vp, _i64, _vp],
     'hoig_add': [_vp, _vp, _vp, _i64, _vp],
+    'hoig_add_act': [_vp, _vp, _vp, _i, _f, _i64, _vp],
     'hoig_act_bwd': [_vp, _vp, _vp, _i, _f, _i64, _vp],
     'hoig_act_bwd_colsum': [_vp, _vp, _vp, _vp, _i, _f, _i64, _i, _vp],
     'hoig_colsum_accum': [_vp, _vp, _i64, _i, _vp],

@@ -1997,6 +1997,8 @@ struct WHaloArgs {
     float *DW, *DB;            // DB (nullable): bias gradient = column sums of dy, taken from the dy tiles as they are staged
     int Bn, H, W, Co, Ci;     // H, W: output (= dy) size
     int Hin, Win, pad;         // input (= x) size and padding
+    int tout;                  // 1: the accumulator tile is [DY channel][X channel] but DW is laid out [X channel][tap][DY channel]
+                               // (ConvTranspose2d stride 2: the plain operand is x, the gathered one dy -- roles swapped)
     int tiles_x, tiles_y, n_mtiles, mt_per_split;
     int nblk_ci, nblk;
 #ifdef HOIG_STAMP
@@ -2008,14 +2010,21 @@ struct WHaloArgs {
 // target (input (H+4) x (W+4), pad 0): ten waves = co half x tap row, five taps each.
 // CM = 2: 128 output channels per workgroup on twice the waves (wave = co quarter x tap row): the same work per wave, but the x
 // halo is loaded and split once for twice the MFMAs -- the kernel is short of VALU issue slots, not of clock.
-template <int NSX, int KS, int CM>
+// S2: Conv2d stride 2, pad 1 (KS = 3): the output tile's 2 x 32 pixels read x at (2y + r - 1, 2x + s - 1), a 5 x 65 halo.  It is
+// stored split by COLUMN PARITY -- row index ((hy * 2 + (hx & 1)) * 33 + (hx >> 1)) -- so that tap (r, s) reads sixteen
+// consecutive output pixels at sixteen consecutive rows again (parity s & 1, first row (s >> 1)): the transpose reads stay
+// unit-stride and conflict-free, exactly as for stride 1.
+template <int NSX, int KS, int CM, bool S2 = false>
 __global__ __launch_bounds__(128 * KS * CM) void wgrad_halo_bf16_kernel(const WHaloArgs p) {
     constexpr int NS = NSX == 1 ? 1 : 2, NB = NSX == 2 ? 2 : 1;      // operand planes: A (activations / dy), B (weights / x)
     constexpr int TH = 2, TW = 32, BM = 64 * CM, BC = 32, NT = 128 * KS * CM;
     constexpr int CQ = 2 * CM, C4 = 16 * CM;               // 32-channel groups / float4s of a dy pixel row
-    constexpr int HH = TH + KS - 1, HWID = TW + KS - 1, HPIX = HH * HWID;     // 4 x 34 halo pixels
+    constexpr int SD = S2 ? 2 : 1;
+    constexpr int HH = SD * (TH - 1) + KS, HWID = SD * (TW - 1) + KS, HPIX = HH * HWID;     // 4 x 34 (stride 2: 5 x 65) halo pixels
+    constexpr int HWP = (HWID + 1) / 2;                    // stride 2: pixels per column-parity run
+    constexpr int HROWS = S2 ? HH * 2 * HWP : HPIX;        // rows of the LDS halo image
     constexpr int PSTR = 128 * CM + 64, QSTR = 64;         // (192 / 320 B: four consecutive rows cover the 64 banks once)
-    constexpr int PLANE_P = TH * TW * PSTR, PLANE_Q = ((HPIX * QSTR + 255) / 256) * 256;
+    constexpr int PLANE_P = TH * TW * PSTR, PLANE_Q = ((HROWS * QSTR + 255) / 256) * 256;
     __shared__ __attribute__((aligned(16))) unsigned char smem[NS * PLANE_P + NB * PLANE_Q];
     unsigned char *Ph = smem, *Pl = smem + PLANE_P;
     unsigned char *Qh = smem + NS * PLANE_P, *Ql = Qh + PLANE_Q;
@@ -2061,7 +2070,7 @@ __global__ __launch_bounds__(128 * KS * CM) void wgrad_halo_bf16_kernel(const WH
             if (idx < HPIX * 8) {
                 const int hp = idx >> 3, c4 = idx & 7;
                 const int hy = hp / HWID, hx = hp - hy * HWID;
-                const int gy = y0 - p.pad + hy, gx = x0 - p.pad + hx;
+                const int gy = y0 * SD - p.pad + hy, gx = x0 * SD - p.pad + hx;
                 if (gy >= 0 && gy < p.Hin && gx >= 0 && gx < p.Win)
                     v = *reinterpret_cast<const float4 *>(xb + ((size_t)gy * p.Win + gx) * ldx + c4 * 4);
             }
@@ -2086,8 +2095,13 @@ __global__ __launch_bounds__(128 * KS * CM) void wgrad_halo_bf16_kernel(const WH
             if (idx < HPIX * 8) {
                 uint2 hi, lo;
                 split4(rq[i], hi, lo);
-                *reinterpret_cast<uint2 *>(Qh + idx * 8) = hi;
-                if (NB == 2) *reinterpret_cast<uint2 *>(Ql + idx * 8) = lo;
+                int st = idx * 8;
+                if (S2) {
+                    const int hp = idx >> 3, hy = hp / HWID, hx = hp - hy * HWID;
+                    st = ((hy * 2 + (hx & 1)) * HWP + (hx >> 1)) * QSTR + (idx & 7) * 8;
+                }
+                *reinterpret_cast<uint2 *>(Qh + st) = hi;
+                if (NB == 2) *reinterpret_cast<uint2 *>(Ql + st) = lo;
             }
         }
     };
@@ -2095,7 +2109,7 @@ __global__ __launch_bounds__(128 * KS * CM) void wgrad_halo_bf16_kernel(const WH
     // transpose-read addressing (see wgrad_bf16_kernel): 16-lane group g, lane 4q+c -> row 8*(g>>1)+q, channels 16*(g&1)+4c
     const int grp = lane >> 4, li = lane & 15;
     const int trow = (grp >> 1) * 8 + (li >> 2), tch = ((grp & 1) * 16 + (li & 3) * 4) * 2;
-    const int trP = trow * PSTR + tch + cb * 64, trQ = (trow + tr * HWID) * QSTR + tch;
+    const int trP = trow * PSTR + tch + cb * 64, trQ = (trow + (S2 ? 0 : tr * HWID)) * QSTR + tch;
     typedef short s4_t __attribute__((ext_vector_type(4)));
     auto frag = [&](const unsigned char *a, int stride4) -> bf16x8 {
         const s4_t lo4 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s4_t *)a);
@@ -2136,12 +2150,12 @@ __global__ __launch_bounds__(128 * KS * CM) void wgrad_halo_bf16_kernel(const WH
 #pragma unroll
         for (int kk = 0; kk < TH * 2; ++kk) {              // 16 consecutive pixels of one tile row per k-step
             const int prow0 = kk * 16;
-            const int qrow0 = (kk >> 1) * HWID + (kk & 1) * 16;
+            const int qrow0 = S2 ? (kk & 1) * 16 : (kk >> 1) * HWID + (kk & 1) * 16;
             bf16x8 ah = frag(Ph + trP + prow0 * PSTR, 4 * PSTR), al;
             if (NS == 2) al = frag(Pl + trP + prow0 * PSTR, 4 * PSTR);
 #pragma unroll
             for (int t = 0; t < KS; ++t) {
-                const int qoff = trQ + (qrow0 + t) * QSTR;
+                const int qoff = trQ + (S2 ? ((2 * (kk >> 1) + tr) * 2 + (t & 1)) * HWP + qrow0 + (t >> 1) : qrow0 + t) * QSTR;
                 const bf16x8 bh = frag(Qh + qoff, 4 * QSTR);
                 if (NS == 2) acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, bh, acc[t], 0, 0, 0);
                     if (NB == 2) {
@@ -2176,13 +2190,36 @@ __global__ __launch_bounds__(128 * KS * CM) void wgrad_halo_bf16_kernel(const WH
         if (tid < BM) atomicAdd(&p.DB[c0 + tid], red[tid]);
     }
     const int l31 = lane & 31, lh = lane >> 5;
-    const int K = KS * KS * p.Ci;
+    if (!p.tout) {
+        const int K = KS * KS * p.Ci;
 #pragma unroll
-    for (int r = 0; r < 16; ++r) {
-        const int co = c0 + cb * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
-        float *row = p.DW + (size_t)co * K + (tr * KS) * p.Ci + ci0 + l31;
+        for (int r = 0; r < 16; ++r) {
+            const int co = c0 + cb * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+            float *row = p.DW + (size_t)co * K + (tr * KS) * p.Ci + ci0 + l31;
 #pragma unroll
-        for (int t = 0; t < KS; ++t) atomicAdd(row + t * p.Ci, acc[t][r]);
+            for (int t = 0; t < KS; ++t) atomicAdd(row + t * p.Ci, acc[t][r]);
+        }
+    } else {
+        // packed [gathered channel q][tap][plain channel pc]: the accumulator has q on the lanes, so adding it as it stands
+        // would spread every atomic instruction over 32 rows of DW (K * 4 bytes apart).  Each wave turns its 32 x 32 tile
+        // through LDS first (the operand tiles are dead: the loop ended with a barrier; the bias path is not used here), so
+        // that the lanes of an atomic instruction cover two contiguous 128-B runs of plain channels.
+        const int K = KS * KS * p.Co;
+        float *tile = reinterpret_cast<float *>(smem) + wave * (32 * 33);
+#pragma unroll
+        for (int t = 0; t < KS; ++t) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) tile[((r & 3) + 8 * (r >> 2) + 4 * lh) * 33 + l31] = acc[t][r];
+            __builtin_amdgcn_s_waitcnt(0xc07f);                // lgkmcnt(0): this wave's LDS writes have landed (no other wave reads them)
+            __builtin_amdgcn_wave_barrier();
+            const int pc = c0 + cb * 32 + l31;
+#pragma unroll
+            for (int k = 0; k < 16; ++k) {
+                const int q = 2 * k + lh;
+                atomicAdd(p.DW + (size_t)(ci0 + q) * K + (tr * KS + t) * p.Co + pc, tile[l31 * 33 + q]);
+            }
+            __builtin_amdgcn_wave_barrier();
+        }
     }
 #ifdef HOIG_STAMP
     if (p.dbg && lane == 0) {
@@ -2200,12 +2237,20 @@ int launch_wgrad_halo(const hoig_conv_desc *d, const float *x, const float *dy, 
     a.DY = dy; a.X = x; a.DW = dw; a.DB = dbias; a.X2 = x2; a.ci1 = ci1;
     a.Bn = d->B; a.H = d->Ho; a.W = d->Wo; a.Co = d->Co; a.Ci = d->Ci;
     a.Hin = d->Hi; a.Win = d->Wi; a.pad = d->pad;
+    a.tout = 0;
+    if (d->transposed) {       // dW[ci][co][r][s] = sum_i x[i] dy[2i - 1 + (r,s)]: x is the plain operand, dy the gathered one
+        a.DY = x; a.X = dy; a.DB = nullptr;
+        a.H = d->Hi; a.W = d->Wi; a.Co = d->Ci; a.Ci = d->Co;
+        a.Hin = d->Ho; a.Win = d->Wo;
+        a.tout = 1;
+    }
+    const bool s2 = d->stride == 2;
     a.tiles_x = a.W / 32;
     a.tiles_y = a.H / 2;
     a.n_mtiles = a.Bn * a.tiles_x * a.tiles_y;
     a.nblk_ci = a.Ci / 32;
     static const int cm_env = getenv("HOIG_WGRAD_HALO_CM") ? atoi(getenv("HOIG_WGRAD_HALO_CM")) : 2;
-    const int cm = (d->R == 3 && cm_env == 2 && a.Co % 128 == 0) ? 2 : 1;
+    const int cm = (d->R == 3 && cm_env == 2 && a.Co % 128 == 0) ? 2 : 1;      // (a.Co: channels of the plain operand)
     a.nblk = (a.Co / (64 * cm)) * a.nblk_ci;
     static const int target_blocks = getenv("HOIG_WGRAD_HALO_BLOCKS") ? atoi(getenv("HOIG_WGRAD_HALO_BLOCKS")) : 512;
     // 5x5: a workgroup owns 25 taps x 64 x 32 outputs, so every pixel split costs 2.8x the atomics of a 3x3 one: 256 (measured)
@@ -2218,7 +2263,9 @@ int launch_wgrad_halo(const hoig_conv_desc *d, const float *x, const float *dy, 
 #ifdef HOIG_STAMP
     a.dbg = g_stamp_buf;
 #endif
-    if (d->R == 5) HOIG_NS_SWITCH(ns, wgrad_halo_bf16_kernel<NSX, 5, 1><<<grid, 640, 0, st>>>(a));
+    if (s2 && cm == 2) HOIG_NS_SWITCH(ns, wgrad_halo_bf16_kernel<NSX, 3, 2, true><<<grid, 768, 0, st>>>(a));
+    else if (s2) HOIG_NS_SWITCH(ns, wgrad_halo_bf16_kernel<NSX, 3, 1, true><<<grid, 384, 0, st>>>(a));
+    else if (d->R == 5) HOIG_NS_SWITCH(ns, wgrad_halo_bf16_kernel<NSX, 5, 1><<<grid, 640, 0, st>>>(a));
     else if (cm == 2) HOIG_NS_SWITCH(ns, wgrad_halo_bf16_kernel<NSX, 3, 2><<<grid, 768, 0, st>>>(a));
     else HOIG_NS_SWITCH(ns, wgrad_halo_bf16_kernel<NSX, 3, 1><<<grid, 384, 0, st>>>(a));
     HOIG_LAUNCH_CHECK();
@@ -2229,8 +2276,15 @@ int launch_wgrad_halo(const hoig_conv_desc *d, const float *x, const float *dy, 
 
 bool hoig_conv_bf16_wgrad_fuses_bias(const hoig_conv_desc *d) {
     static const bool no_halo = getenv("HOIG_NO_WGRAD_HALO") != nullptr;
-    if (no_halo || d->precision == HOIG_PREC_F32 || d->transposed || d->stride != 1 || d->R != d->S) return false;
+    if (no_halo || d->precision == HOIG_PREC_F32 || d->R != d->S) return false;
+    static const bool no_s2 = getenv("HOIG_NO_WGRAD_HALO_S2") != nullptr;
+    if (d->transposed)           // ConvTranspose2d 3x3 stride 2 pad 1 output_padding 1: the same kernel with x and dy swapped
+        return !no_s2 && d->stride == 2 && d->R == 3 && d->pad == 1 && d->Ho == 2 * d->Hi && d->Wo == 2 * d->Wi &&
+               d->Wi % 32 == 0 && d->Hi % 2 == 0 && d->Co % 32 == 0 && d->Ci % 64 == 0;
     if (d->Wo % 32 || d->Ho % 2 || d->Ci % 32 || d->Co % 64) return false;
+    if (d->stride == 2)          // Conv2d 3x3 stride 2 pad 1 on the column-parity halo (the generator's down-sampling layers)
+        return !no_s2 && d->R == 3 && d->pad == 1 && d->Hi == 2 * d->Ho && d->Wi == 2 * d->Wo;
+    if (d->stride != 1) return false;
     if (d->R == 3) return d->pad == 1 && d->Hi == d->Ho && d->Wi == d->Wo;
     return d->R == 5 && d->pad == 0 && d->Hi == d->Ho + 4 && d->Wi == d->Wo + 4;      // the attention's valid 5x5
 }

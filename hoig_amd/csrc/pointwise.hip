@@ -105,6 +105,12 @@ __global__ void add_kernel(const float *__restrict__ a, const float *__restrict_
         y[i] = a[i] + b[i];
 }
 
+__global__ void add_act_kernel(const float *__restrict__ a, const float *__restrict__ b, float *__restrict__ y, int act,
+                               float slope, int64_t n) {
+    for (int64_t i = (int64_t)blockIdx.x * NT + threadIdx.x; i < n; i += (int64_t)gridDim.x * NT)
+        y[i] = hoig_act(a[i] + b[i], act, slope);
+}
+
 __global__ void act_bwd_kernel(const float *__restrict__ y, const float *__restrict__ dy, float *__restrict__ dx,
                                int act, float slope, int64_t n) {
     for (int64_t i = (int64_t)blockIdx.x * NT + threadIdx.x; i < n; i += (int64_t)gridDim.x * NT)
@@ -440,6 +446,12 @@ extern "C" int hoig_cat2_channels(const float *x1, int C1, const float *x2, int 
 extern "C" int hoig_add(const float *a, const float *b, float *y, int64_t n, hoig_stream_t stream) {
     if (!a || !b || !y) return HOIG_EINVAL;
     add_kernel<<<hoig_stream_grid(n / 4 + 1, NT), NT, 0, ST>>>(a, b, y, n);
+    HOIG_LAUNCH_CHECK();
+    return HOIG_OK;
+}
+extern "C" int hoig_add_act(const float *a, const float *b, float *y, int act, float slope, int64_t n, hoig_stream_t stream) {
+    if (!a || !b || !y) return HOIG_EINVAL;
+    add_act_kernel<<<hoig_stream_grid(n, NT), NT, 0, ST>>>(a, b, y, act, slope, n);
     HOIG_LAUNCH_CHECK();
     return HOIG_OK;
 }

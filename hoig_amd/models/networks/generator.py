@@ -38,7 +38,11 @@ class Generator(ParamTree):
         self.cfg = GeneratorConfig(gen_name, bg_dim, img_dim, obj_dim, img_cond_dim, obj_cond_dim, conv_dim, repeat_num)
         sch = generator_schema(self.cfg)
         device = device if device is not None else torch.device('cuda', torch.cuda.current_device())
+        # weights stored as the two halves of their input channels (hoig_amd.nn): the attention's first conv ([target | source],
+        # two 5x5 convolutions over different tensors) and the background-mask heads over cat[x, obj features]
+        # (generator.py:315: evaluated as conv(x) + conv(y), which needs no concatenated 128-channel full-resolution tensor)
         split = ['attn_%d.fully_connect_layer.0.weight' % l for l in self.cfg.attn_layers]
+        split += ['%s.attetion_reg_bg.0.weight' % m for m in ('src_model', 'tsf_model')]
         super().__init__(sch.shapes, device, sch.transposed, split)
         self._name = 'generator'
         self._seg_cache = {}
@@ -250,7 +254,8 @@ class Generator(ParamTree):
         def regress(x, y, p):                                              # generator.py:311-315
             img = self._conv(x, p + '.img_reg.0', pad=3, act=ACT_TANH)
             mh = self._conv(x, p + '.attetion_reg_hand.0', pad=3, act=ACT_SIGMOID)
-            mb = self._conv(ops.cat_channels([x, y]), p + '.attetion_reg_bg.0', pad=3, act=ACT_SIGMOID)
+            mb = ops.add_act(ops.conv2d(x, self.P[p + '.attetion_reg_bg.0.weight#t'], None, 1, 3),
+                             ops.conv2d(y, self.P[p + '.attetion_reg_bg.0.weight#s'], None, 1, 3), ACT_SIGMOID)
             return img, mh, mb
 
         src_hand_o, src_mask_hand, src_mask_bg = regress(sx, sy, 'src_model')

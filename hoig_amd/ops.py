@@ -465,6 +465,32 @@ def add(a, b):
     return _Add.apply(a, b)
 
 
+class _AddAct(Function):
+    """act(a + b) -- the epilogue of a convolution evaluated as the sum of two convolutions over the halves of its input."""
+
+    @staticmethod
+    def forward(ctx, a, b, act, slope):
+        _chk(a); _chk(b)
+        assert a.shape == b.shape and a.is_contiguous() and b.is_contiguous()
+        y = torch.empty_like(a)
+        call('hoig_add_act', _p(a), _p(b), _p(y), act, slope, a.numel(), _st())
+        ctx.cfg = (act, slope)
+        ctx.save_for_backward(y)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        y, = ctx.saved_tensors
+        act, slope = ctx.cfg
+        g = torch.empty_like(y)
+        call('hoig_act_bwd', _p(y), _p(dy.contiguous()), _p(g), act, slope, y.numel(), _st())
+        return g, g, None, None
+
+
+def add_act(a, b, act, slope=0.0):
+    return _AddAct.apply(a, b, act, slope)
+
+
 def _copy_channels(x, y, x_off, y_off, n, accumulate=False):
     npix = x.numel() // x.shape[-1]
     call('hoig_copy_channels', _p(x), _p(y), npix, x.shape[-1], x_off, y.shape[-1], y_off, n, 1 if accumulate else 0,
@@ -734,8 +760,13 @@ class _LocalAttn(Function):
         return dsrc, dtgt, None, rets[0], rets[1], rets[2], rets[3], rets[4], None
 
 
+_ATTN_PREC = os.environ.get('HOIG_ATTN_PREC')          # experiment switch: arithmetic of the attention's two 5x5 convolutions
+
+
 def local_attention(source, target, flow, wt, ws, b1, w2, b2, prec=None):
-    return _LocalAttn.apply(source, target, flow.contiguous(), wt, ws, b1, w2, b2, precision if prec is None else prec)
+    if prec is None:
+        prec = _PREC[_ATTN_PREC] if (_ATTN_PREC and precision != L.PREC_F32) else precision
+    return _LocalAttn.apply(source, target, flow.contiguous(), wt, ws, b1, w2, b2, prec)
 
 
 # stand-alone equivalents of the reference's two extension modules (NCHW, caller-visible semantics of

@@ -231,6 +231,8 @@ int hoig_copy_channels(const float *x, float *y, int64_t npix, int Cx, int x_off
 int hoig_cat2_channels(const float *x1, int C1, const float *x2, int C2, float *y, int64_t npix, hoig_stream_t stream);
 /* y = a + b (n elements) ; y = act_bwd: dx = dy * act'(y) */
 int hoig_add(const float *a, const float *b, float *y, int64_t n, hoig_stream_t stream);
+/* y = act(a + b): the activation of a convolution that was split over two input tensors (conv(cat[x1, x2]) = conv(x1) + conv(x2)) */
+int hoig_add_act(const float *a, const float *b, float *y, int act, float slope, int64_t n, hoig_stream_t stream);
 int hoig_act_bwd(const float *y, const float *dy, float *dx, int act, float slope, int64_t n, hoig_stream_t stream);
 /* the same, fused with the bias gradient of the convolution that produced y [rows][C]: g = dy * act'(y), dbias[c] += sum_rows g */
 int hoig_act_bwd_colsum(const float *y, const float *dy, float *g, float *dbias, int act, float slope, int64_t rows, int C,
