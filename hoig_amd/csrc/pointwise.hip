@@ -51,6 +51,42 @@ __global__ void copy_channels_kernel(const float *__restrict__ x, float *__restr
 // y[p][0:C1] = x1[p][:], y[p][C1:C1+C2] = x2[p][:] in ONE pass that walks y linearly: the destination is written as fully
 // coalesced runs even when its row length is odd (the 19-channel discriminator input: 3 image + 16 condition channels --
 // two strided partial-row copies into 76-B rows took 390 us each)
+// Odd row lengths (the 19-channel discriminator input) without per-element index division: a workgroup owns 256 consecutive
+// pixels, whose output rows are ONE contiguous run of 256 * (C1 + C2) floats.  Each thread gathers its pixel's channels into
+// LDS (16-B loads where a source row is a multiple of 4 floats), then the run leaves as coalesced 16-B stores.
+__global__ __launch_bounds__(256) void cat2_rows_kernel(const float *__restrict__ x1, int C1, const float *__restrict__ x2, int C2,
+                                                        float *__restrict__ y, int64_t npix) {
+    extern __shared__ float rows[];                       // [256][Cy]
+    const int Cy = C1 + C2;
+    const int64_t p0 = (int64_t)blockIdx.x * 256, p = p0 + threadIdx.x;
+    if (p < npix) {
+        float *r = rows + threadIdx.x * Cy;
+        const float *a = x1 + p * C1, *b = x2 + p * C2;
+        if ((C1 & 3) == 0)
+            for (int c = 0; c < C1; c += 4) {
+                const float4 v = *reinterpret_cast<const float4 *>(a + c);
+                r[c] = v.x; r[c + 1] = v.y; r[c + 2] = v.z; r[c + 3] = v.w;
+            }
+        else
+            for (int c = 0; c < C1; ++c) r[c] = a[c];
+        r += C1;
+        if ((C2 & 3) == 0)
+            for (int c = 0; c < C2; c += 4) {
+                const float4 v = *reinterpret_cast<const float4 *>(b + c);
+                r[c] = v.x; r[c + 1] = v.y; r[c + 2] = v.z; r[c + 3] = v.w;
+            }
+        else
+            for (int c = 0; c < C2; ++c) r[c] = b[c];
+    }
+    __syncthreads();
+    const int64_t left = npix - p0;
+    const int n = (int)(left < 256 ? left : 256) * Cy;        // floats of this workgroup's run (starts 16-B aligned: 256 * Cy * 4)
+    float *dst = y + p0 * Cy;
+    for (int i = threadIdx.x * 4; i + 3 < n; i += 256 * 4)
+        *reinterpret_cast<float4 *>(dst + i) = make_float4(rows[i], rows[i + 1], rows[i + 2], rows[i + 3]);
+    for (int i = (n & ~3) + threadIdx.x; i < n; i += 256) dst[i] = rows[i];
+}
+
 template <int VEC>
 __global__ void cat2_kernel(const float *__restrict__ x1, int C1, const float *__restrict__ x2, int C2,
                             float *__restrict__ y, int64_t npix) {
@@ -438,6 +474,8 @@ extern "C" int hoig_cat2_channels(const float *x1, int C1, const float *x2, int 
     if (!x1 || !x2 || !y || C1 <= 0 || C2 <= 0) return HOIG_EINVAL;
     if (((C1 | C2) & 3) == 0)
         cat2_kernel<4><<<hoig_stream_grid(npix * ((C1 + C2) >> 2), NT), NT, 0, ST>>>(x1, C1, x2, C2, y, npix);
+    else if (C1 + C2 <= 96)
+        cat2_rows_kernel<<<(unsigned)hoig_cdiv(npix, 256), 256, (size_t)256 * (C1 + C2) * sizeof(float), ST>>>(x1, C1, x2, C2, y, npix);
     else
         cat2_kernel<1><<<hoig_stream_grid(npix * (C1 + C2), NT), NT, 0, ST>>>(x1, C1, x2, C2, y, npix);
     HOIG_LAUNCH_CHECK();

@@ -280,6 +280,12 @@ def test_pointwise_and_losses():
     a, b = torch.randn(2, 5, 4, 4, generator=g), torch.randn(2, 7, 4, 4, generator=g)
     c = ops.cat_channels([nhwc_cuda(a), nhwc_cuda(b)])
     assert torch.equal(nchw_cpu(c), torch.cat([a, b], 1))
+    # the discriminator input (3 image + 16 condition channels; 24 for DexYCB) and other odd / mixed widths, pixel counts that
+    # are not a multiple of the 256-pixel workgroup; wide rows take the element-wise kernel
+    for c1, c2, hw in ((3, 16, 33), (3, 21, 32), (13, 9, 17), (4, 9, 16), (64, 37, 8)):
+        a, b = torch.randn(3, c1, hw, hw, generator=g), torch.randn(3, c2, hw, hw, generator=g)
+        c = ops.cat_channels([nhwc_cuda(a), nhwc_cuda(b)])
+        assert torch.equal(nchw_cpu(c), torch.cat([a, b], 1)), (c1, c2, hw)
 
 
 def test_fused_adam_matches_torch():
