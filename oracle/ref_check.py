@@ -25,7 +25,7 @@ SEEDS = dict(G=8, D=9, VGG=10, inputs=8)
 
 
 def main(gen_name, copy, side=64, batch=1, steps=2):
-    torch.set_num_threads(4)
+    torch.set_num_threads(int(os.environ.get('HOIG_REF_CHECK_THREADS', '4')))
     cfg = O.make_cfg(gen_name, copy)
     sdG = O.make_weights(O.gen_param_shapes(cfg), seed=SEEDS['G'], mode='random')
     sdD = O.make_weights(O.disc_param_shapes(cfg), seed=SEEDS['D'], mode='random')

@@ -18,14 +18,26 @@ CASES = [('generator_base', 'hov3'), ('generator_spade', 'hov3'), ('generator_sp
          ('generator_spade_attn_tiny', 'hov3'), ('generator_spade_attn', 'dexycb'), ('generator_spade', 'dexycb')]
 
 
+_procs = {}
+
+
+def _start_all():
+    """All six comparisons run concurrently (one process per case: one reference copy per process), two torch threads each."""
+    if _procs:
+        return
+    env = dict(os.environ, PYTHONDONTWRITEBYTECODE='1', HOIG_REF_CHECK_THREADS='2')
+    for gen_name, copy in CASES:
+        _procs[(gen_name, copy)] = subprocess.Popen([sys.executable, '-m', 'oracle.ref_check', gen_name, copy, '64', '1', '2'],
+                                                    cwd=ROOT, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True)
+
+
 @pytest.mark.skipif(not os.path.isdir(os.path.join(REF, 'HOIG_HOv3', 'models')), reason='reference tree not present')
 @pytest.mark.parametrize('gen_name,copy', CASES)
 def test_oracle_equals_reference_python(gen_name, copy):
-    env = dict(os.environ, PYTHONDONTWRITEBYTECODE='1')
-    out = subprocess.run([sys.executable, '-m', 'oracle.ref_check', gen_name, copy, '64', '1', '2'], cwd=ROOT, env=env,
-                         stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=600)
-    assert out.returncode == 0, out.stderr[-2000:]
-    r = json.loads(out.stdout.strip().splitlines()[-1])
+    _start_all()
+    out, err = _procs[(gen_name, copy)].communicate(timeout=900)
+    assert _procs[(gen_name, copy)].returncode == 0, err[-2000:]
+    r = json.loads(out.strip().splitlines()[-1])
     print(r)
     assert r['fwd_max_abs'] <= 1e-6, r
     assert r['loss_max_rel'] <= 1e-5, r
