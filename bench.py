@@ -26,13 +26,14 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)          # the product package only; tests/ + oracle/ are reachable from the cpu-baseline child alone
 
 GFLOP_PER_PAIR_TRAIN_256 = 2555.2      # BASELINE.md §2 / SURVEY.md §8d (3*G + 3*VGG + 9*D), generator_spade_attn
-PMC_FILES = ['r02_pmc_dominant_conv.json', 'r01_pmc_dominant_conv.json']      # newest first
+PMC_FILES = ['r02_pmc_dominant_conv_f6.json', 'r02_pmc_dominant_conv.json', 'r01_pmc_dominant_conv.json']      # newest first
 PEAK_F32, PEAK_16 = 157.3, 2500.0          # TFLOP/s dense MFMA (fp32 / fp16-bf16), MI355X_MICROARCH.md
-DTYPE_NAMES = {'bf16x3:f16x2': 'f16x3 fwd (both operands split hi+lo on fp16, 3 MFMAs per product) / bf16x2 bwd (dy split hi+lo, weights and x single bf16, 2 MFMAs per product), f32 accumulate',
+DTYPE_NAMES = {'f16f6': 'fwd: fp16 hi*hi + the two cross terms of the hi/lo split on block-scaled fp6 MFMA (1.6 bf16-MFMA units per product; layers outside that kernel: three fp16 terms) / bwd: bf16x2 (dy split hi+lo, weights and x single bf16), f32 accumulate',
+               'bf16x3:f16x2': 'f16x3 fwd (both operands split hi+lo on fp16, 3 MFMAs per product) / bf16x2 bwd (dy split hi+lo, weights and x single bf16, 2 MFMAs per product), f32 accumulate',
                'bf16x3': 'f16x3 fwd / bf16x3 bwd (both operands split hi+lo in 16-bit halves, 3 MFMAs per product, f32 accumulate)',
                'f16x2': 'f16x2 fwd / bf16x2 bwd (gathered operand split hi+lo, weights single 16-bit, 2 MFMAs per product, f32 accumulate)',
                'bf16': 'f16 fwd / bf16 bwd (single-pass 16-bit operands, f32 accumulate)', 'f32': 'f32 (v_mfma_f32_32x32x2_f32)'}
-MFMA_TERMS = {'f32': 1, 'bf16x3': 3, 'f16x3': 3, 'f16x2': 2, 'bf16x2': 2, 'bf16': 1, 'f16': 1}      # issued MFMAs per algorithmic one
+MFMA_TERMS = {'f16f6': 1.6, 'f32': 1, 'bf16x3': 3, 'f16x3': 3, 'f16x2': 2, 'bf16x2': 2, 'bf16': 1, 'f16': 1}      # issued MFMAs per algorithmic one
 
 
 def dominant_kernel_roofline(batch, side, precision, iters=50):
@@ -64,12 +65,14 @@ def dominant_kernel_roofline(batch, side, precision, iters=50):
     # share a pass); the committed summary is attached when it was taken on the same kernel and shape
     traffic, traffic_source = None, None
     fwd_prec = precision.partition(':')[0]
+    want = 'conv_halo3_f6_kernel' if fwd_prec == 'f16f6' else ('conv_halo3_bf16_kernel' if fwd_prec in ('bf16x3', 'f16x3') else None)
     for fn in PMC_FILES:
         try:
             pmc = json.load(open(os.path.join(ROOT, 'profiles', fn)))
         except Exception:
             continue
-        if pmc.get('precision', 'bf16x3') == fwd_prec and batch == pmc.get('images', 16) and side == 256:
+        if want and pmc.get('kernel_filter', 'conv_halo3_bf16_kernel') == want and batch == 16 and side == 256 and \
+                'traffic_bytes_per_launch' in pmc:
             traffic = pmc['traffic_bytes_per_launch']
             traffic_source = ('profiles/%s: separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes over this kernel and shape, '
                               'committed; NOT measured in this run (counters cannot be read from inside the process)' % fn)
@@ -77,7 +80,8 @@ def dominant_kernel_roofline(batch, side, precision, iters=50):
     achieved = flops / (ms * 1e-3) / 1e12
     fwd = precision.partition(':')[0]
     peak = PEAK_F32 if fwd == 'f32' else PEAK_16
-    kname = 'igemm_f32_kernel' if fwd == 'f32' else 'conv_halo3_bf16_kernel<%d,4,2,128,2,true>' % {3: 2, 2: 3, 1: 1}[MFMA_TERMS[fwd]]
+    kname = ('igemm_f32_kernel' if fwd == 'f32' else 'conv_halo3_f6_kernel' if fwd == 'f16f6' else
+             'conv_halo3_bf16_kernel<%d,4,2,128,2,true>' % {3: 2, 2: 3, 1: 1}[MFMA_TERMS[fwd]])
     return dict(bound='mfma', kernel='%s (conv3x3 s1 512->512 @%dx%d, %d images = src+tsf stacked)' % (kname, h, h, batch),
                 achieved=round(achieved, 2), peak=peak, unit='TFLOP/s', mfma_terms_per_product=MFMA_TERMS[fwd],
                 frac=round(achieved / peak, 4), traffic=traffic, traffic_source=traffic_source, avg_launch_ms=round(ms, 4),
@@ -258,8 +262,8 @@ def main():
     ap.add_argument('--side', type=int, default=256)
     ap.add_argument('--gen_name', default='generator_spade_attn')
     ap.add_argument('--dataset', default='hov3', choices=['hov3', 'dexycb'], help='channel configuration (config C4 = dexycb at --side 512 --batch 4)')
-    ap.add_argument('--precision', default=os.environ.get('HOIG_PRECISION', 'bf16x3:f16x2'),
-                    help="'<forward>[:<data gradient>[:<weight gradient>]]' of f32 | bf16x3 | f16x2 | bf16 (hoig_amd/ops.py set_precision)")
+    ap.add_argument('--precision', default=os.environ.get('HOIG_PRECISION', 'f16f6'),
+                    help="'<forward>[:<data gradient>[:<weight gradient>]]' of f32 | bf16x3 | f16x2 | bf16; f16f6 = forward on fp16 + block-scaled fp6 terms, backward f16x2 (hoig_amd/ops.py set_precision)")
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-gen-fwd', action='store_true')
     ap.add_argument('--fwd-batch', type=int, default=32, help='batch of the generator-forward latency leg')

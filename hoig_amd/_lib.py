@@ -15,7 +15,7 @@ HEADER_PATH = os.path.join(os.path.dirname(_HERE), 'include', 'hoig_kernels.h')
 
 OK, EINVAL, ELAUNCH, EUNSUPPORTED = 0, -1, -2, -3
 ACT_NONE, ACT_RELU, ACT_LRELU, ACT_TANH, ACT_SIGMOID = 0, 1, 2, 3, 4
-PREC_F32, PREC_BF16X3, PREC_BF16, PREC_F16X2 = 0, 1, 2, 3
+PREC_F32, PREC_BF16X3, PREC_BF16, PREC_F16X2, PREC_F16F6 = 0, 1, 2, 3, 4
 LOSS_L1, LOSS_MSE, LOSS_BCE = 0, 1, 2
 _ERR = {EINVAL: 'invalid argument', ELAUNCH: 'kernel launch failed', EUNSUPPORTED: 'unsupported shape'}
 
@@ -56,6 +56,8 @@ _SIGS = {
     'hoig_pack_conv_weights_bf16_all': [_vp, _vp, _i, _i64, _vp, _vp, _vp, _vp, _vp],
     'hoig_conv2d_fwd_packed': [ctypes.POINTER(ConvDesc), _vp, _vp, _vp, _vp, _vp, _vp],
     'hoig_conv2d_bwd_data_packed': [ctypes.POINTER(ConvDesc), _vp, _vp, _vp, _vp, _vp],
+    'hoig_pack_conv_weight_f6': [_vp, _i, _i, _i, _vp, _vp, _vp],
+    'hoig_conv2d_fwd_f6': [ctypes.POINTER(ConvDesc), _vp, _vp, _vp, _vp, _vp, _vp, _vp],
     'hoig_conv2d_cat_fwd_packed': [ctypes.POINTER(ConvDesc), _vp, _i, _vp, _vp, _vp, _vp, _vp, _vp],
     'hoig_conv2d_cat_bwd_data_packed': [ctypes.POINTER(ConvDesc), _vp, _vp, _vp, _vp, _i, _vp, _vp],
     'hoig_conv2d_cat_bwd_weight': [ctypes.POINTER(ConvDesc), _vp, _i, _vp, _vp, _vp, _vp, _vp],
@@ -119,6 +121,10 @@ def _load():
         fn.restype = ctypes.c_int
     lib.hoig_inorm_workspace_bytes.argtypes = [_i, _i, _i]
     lib.hoig_inorm_workspace_bytes.restype = ctypes.c_int64
+    lib.hoig_set_f6_min_tiles.argtypes = [_i]
+    lib.hoig_set_f6_min_tiles.restype = ctypes.c_int
+    lib.hoig_f6_plane_bytes.argtypes = [_i, _i, _i]
+    lib.hoig_f6_plane_bytes.restype = ctypes.c_int64
     lib.hoig_attn_index_ints.argtypes = [_i, _i, _i]
     lib.hoig_attn_index_ints.restype = ctypes.c_int64
     lib.hoig_rasterize_workspace_bytes.restype = ctypes.c_size_t

@@ -558,7 +558,7 @@ int dispatch_igemm(IgemmArgs a, bool ncontig, hipStream_t st) {
 int check_desc(const hoig_conv_desc *d) {
     if (!d || d->B <= 0 || d->Ci <= 0 || d->Co <= 0 || d->R <= 0 || d->S <= 0 || d->stride <= 0) return HOIG_EINVAL;
     if (d->precision != HOIG_PREC_F32 && d->precision != HOIG_PREC_BF16X3 && d->precision != HOIG_PREC_BF16 &&
-        d->precision != HOIG_PREC_F16X2)
+        d->precision != HOIG_PREC_F16X2 && d->precision != HOIG_PREC_F16F6)
         return HOIG_EINVAL;
     if (!d->transposed) {
         if ((d->Hi + 2 * d->pad - d->R) / d->stride + 1 != d->Ho) return HOIG_EINVAL;

@@ -20,7 +20,7 @@ from ._lib import call, ConvDesc
 # arithmetic of the MFMA contractions (include/hoig_kernels.h HOIG_PREC_*).  'f16x3' is the name of what 'bf16x3' has always
 # been in the forward (fp16 halves; the backward splits on bf16); 'f16' / 'bf16' likewise name the single-pass mode.
 _PREC = {'f32': L.PREC_F32, 'bf16x3': L.PREC_BF16X3, 'f16x3': L.PREC_BF16X3, 'f16x2': L.PREC_F16X2, 'bf16x2': L.PREC_F16X2,
-         'bf16': L.PREC_BF16, 'f16': L.PREC_BF16}
+         'bf16': L.PREC_BF16, 'f16': L.PREC_BF16, 'f16f6': L.PREC_F16F6}
 precision = precision_dgrad = precision_wgrad = L.PREC_F32
 
 
@@ -32,6 +32,10 @@ def set_precision(name):
     if len(parts) > 3:
         raise ValueError('precision %r' % name)
     precision = _PREC[parts[0]]
+    if precision == L.PREC_F16F6 and len(parts) == 1:
+        parts = [parts[0], 'f16x2']                      # a forward-only arithmetic: the backward defaults to two bf16 terms
+    if L.PREC_F16F6 in [_PREC[q] for q in parts[1:]]:
+        raise ValueError('f16f6 is a forward arithmetic')
     precision_dgrad = _PREC[parts[1]] if len(parts) > 1 else precision
     precision_wgrad = _PREC[parts[2]] if len(parts) > 2 else precision_dgrad
 
@@ -42,11 +46,12 @@ set_precision(os.environ.get('HOIG_PRECISION', 'f32'))
 def _bwd_descs(d):
     """(data-gradient, weight-gradient) descriptors of a convolution: same problem, the backward arithmetic modes.  An
     exact-fp32 forward keeps its backward exact (first-layer convolutions are routed to f32 per call)."""
-    if d.precision != precision:          # a per-call precision override: the backward follows the forward
+    same = d.precision == precision or (precision == L.PREC_F16F6 and d.precision == L.PREC_BF16X3)   # (an f16f6 launch that ran as x3)
+    if not same:                          # a per-call precision override: the backward follows the forward
         return d, d
     out = []
     for prec in (precision_dgrad, precision_wgrad):
-        if d.precision == prec or d.precision == L.PREC_F32:
+        if (d.precision == prec and prec != L.PREC_F16F6) or d.precision == L.PREC_F32:
             out.append(d)
         else:
             b = ConvDesc.from_buffer_copy(d)
@@ -259,7 +264,7 @@ class _ConvCat2(Function):
         C2 = x2.shape[-1]
         Co = w.shape[0]
         assert tuple(w.stride()) == packed_strides(w.shape, False), 'conv weight is not in packed layout'
-        d = ConvDesc(B, H, W_, C1 + C2, H, W_, Co, 3, 3, 1, 1, 0, L.ACT_NONE, 0.0, prec)
+        d = _x3(ConvDesc(B, H, W_, C1 + C2, H, W_, Co, 3, 3, 1, 1, 0, L.ACT_NONE, 0.0, prec))
         y = torch.empty((B, H, W_, Co), dtype=x1.dtype, device=x1.device)
         hi, lo = _packed_planes(w, False, False)
         L.check(L.lib.hoig_conv2d_cat_fwd_packed(ctypes.byref(d), _p(x1), C1, _p(x2), _p(hi), _p(lo), None, _p(y), _st()),
@@ -640,8 +645,57 @@ def grid_sample(x, grid):
     return _GridSample.apply(x, grid.contiguous())
 
 
+_f6_cache = {}
+
+
+def set_f6_min_tiles(n):
+    """Launches of the f16f6 forward with fewer workgroups than `n` run as three fp16 terms (default 192: they would not fill
+    the chip).  Returns the previous value.  Parity tests and tools pass 1 to exercise the fp6 kernel at small sizes."""
+    return L.lib.hoig_set_f6_min_tiles(int(n))
+
+
+def _f6_planes(w):
+    """fp6 records of a 3x3 conv weight's hi / lo halves (hoig_pack_conv_weight_f6), re-made when the owner's weights change."""
+    co, ci, r, s = w.shape
+    owner = getattr(w, '_hoig_owner', None)
+    ver = owner.version if owner is not None else None
+    key = (w.data_ptr(), tuple(w.shape))
+    hit = _f6_cache.get(key)
+    if hit is not None and ver is not None and hit[0] == ver:
+        return hit[1], hit[2]
+    if hit is not None:
+        qh, ql = hit[1], hit[2]
+    else:
+        n = L.lib.hoig_f6_plane_bytes(co, r * s, ci)
+        qh = torch.empty(n, dtype=torch.uint8, device=w.device)
+        ql = torch.empty(n, dtype=torch.uint8, device=w.device)
+    call('hoig_pack_conv_weight_f6', _p(w), co, r * s, ci, _p(qh), _p(ql), _st())
+    if ver is not None:
+        _f6_cache[key] = (ver, qh, ql)
+    return qh, ql
+
+
+def _x3(d):
+    """The descriptor of a launch that the fp6 forward kernel does not cover: the same arithmetic on three fp16 terms."""
+    if d.precision != L.PREC_F16F6:
+        return d
+    c = ConvDesc.from_buffer_copy(d)
+    c.precision = L.PREC_BF16X3
+    return c
+
+
 def _conv_fwd_raw(d, x, w, b, y, transposed=False):
     """y = conv(x, w) (+bias, activation) on the kernel the precision mode selects."""
+    if d.precision == L.PREC_F16F6:
+        if (not transposed and d.R == 3 and d.S == 3 and d.stride == 1 and d.pad == 1 and d.Ci % 64 == 0 and d.Co % 128 == 0
+                and d.Hi % 8 == 0 and d.Wi % 32 == 0):
+            hi, _ = _packed_planes(w, False, False)
+            qh, ql = _f6_planes(w)
+            rc = L.lib.hoig_conv2d_fwd_f6(ctypes.byref(d), _p(x), _p(hi), _p(qh), _p(ql), _p(b), _p(y), _st())
+            if rc != L.EUNSUPPORTED:
+                L.check(rc, 'hoig_conv2d_fwd_f6')
+                return
+        d = _x3(d)
     if d.precision != L.PREC_F32 and d.Ci % 32 == 0 and d.Co % 32 == 0 and d.Co > 32:
         hi, lo = _packed_planes(w, transposed, False)
         rc = L.lib.hoig_conv2d_fwd_packed(ctypes.byref(d), _p(x), _p(hi), _p(lo), _p(b), _p(y), _st())

@@ -43,8 +43,11 @@ enum { HOIG_ACT_NONE = 0, HOIG_ACT_RELU = 1, HOIG_ACT_LRELU = 2, HOIG_ACT_TANH =
  *          on fp16 (v_mfma_f32_32x32x16_f16, products to ~2^-21), backward launches on bf16 (~2^-16)
  *   F16X2  the gathered operand (activations / dy) split hi+lo, the other one (weights; x in the weight gradient) rounded
  *          to ONE 16-bit value: 2 MFMAs per k-step (hi*hi + lo*hi), ~2^-12 (fp16 forward) / ~2^-9 (bf16 backward) per product
- *   BF16   one MFMA per k-step, both operands rounded to 16 bits (fp16 forward, bf16 backward) */
-enum { HOIG_PREC_F32 = 0, HOIG_PREC_BF16X3 = 1, HOIG_PREC_BF16 = 2, HOIG_PREC_F16X2 = 3 };
+ *   BF16   one MFMA per k-step, both operands rounded to 16 bits (fp16 forward, bf16 backward)
+ *   F16F6  FORWARD only (hoig_conv2d_fwd_f6): hi*hi on fp16, the two cross terms of the split on block-scaled e2m3 (fp6)
+ *          v_mfma_scale_f32_32x32x64_f8f6f4 (one E8M0 scale per 32 channels): BF16X3's three terms at 1.6 instead of 3 MFMA
+ *          units per product; shapes outside that kernel run as BF16X3 */
+enum { HOIG_PREC_F32 = 0, HOIG_PREC_BF16X3 = 1, HOIG_PREC_BF16 = 2, HOIG_PREC_F16X2 = 3, HOIG_PREC_F16F6 = 4 };
 
 /* One convolution problem.  NHWC activations, weights [Co][R][S][Ci].
  * transposed=0: y = conv2d(x, w, stride, pad)            x:[B,Hi,Wi,Ci] y:[B,Ho,Wo,Co]
@@ -91,6 +94,19 @@ int hoig_conv2d_fwd_packed(const hoig_conv_desc *d, const float *x, const uint16
                            const float *bias /*nullable*/, float *y, hoig_stream_t stream);
 int hoig_conv2d_bwd_data_packed(const hoig_conv_desc *d, const float *dy, const uint16_t *wt_hi, const uint16_t *wt_lo,
                                 float *dx, hoig_stream_t stream);
+
+/* fp16 + block-scaled fp6 forward of 3x3 stride-1 pad-1 convolutions (hoig_amd/csrc/conv_f6.hip).  q_hi / q_lo: fp6 records of
+ * the hi / lo fp16 halves of 256*w, hoig_f6_plane_bytes(Co, 9, Ci) bytes each, made by hoig_pack_conv_weight_f6 once per
+ * optimiser step: [(tap * Ci/64 + ci/64)][co] records of 56 B = 2 x 24 B of e2m3 elements (32 channels each, element j in bits
+ * [6j, 6j+6)) + the two E8M0 scale bytes.  w_hi: the forward hi plane of hoig_pack_conv_weight_bf16.  HOIG_EUNSUPPORTED unless
+ * Ci % 64 == 0, Co % 128 == 0, H % 8 == 0, W % 32 == 0 and the launch has enough 8x32-pixel tiles to fill the chip. */
+int64_t hoig_f6_plane_bytes(int Co, int RS, int Ci);
+int hoig_pack_conv_weight_f6(const float *w, int Co, int RS, int Ci, uint8_t *q_hi, uint8_t *q_lo, hoig_stream_t stream);
+int hoig_conv2d_fwd_f6(const hoig_conv_desc *d, const float *x, const uint16_t *w_hi, const uint8_t *q_hi, const uint8_t *q_lo,
+                       const float *bias /*nullable*/, float *y, hoig_stream_t stream);
+/* launches with fewer workgroups than this run as three fp16 terms (default 192; returns the previous value; n <= 0: query).
+ * Parity tests set 1 so that the fp6 kernel is exercised at their small sizes. */
+int hoig_set_f6_min_tiles(int n);
 
 /* conv(cat[x1, x2] along channels) without materialising the concatenation (the decoder's skip convolutions,
  * generator.py:305-306): 3x3 stride-1 "same" convolutions on the fast path only -- every other shape returns

@@ -484,3 +484,46 @@ def test_conv_over_two_tensors_equals_conv_of_cat(B, C1, C2, Co, H, W):
     assert rel_err(ya, yb) < 1e-6
     assert rel_err(a1.grad, b1.grad) < 1e-6 and rel_err(a2.grad, b2.grad) < 1e-6
     assert rel_err(wa.grad, wb.grad) < 1e-5
+
+
+@pytest.mark.parametrize('B,Ci,Co,H,bias,min_tiles,runs_f6', [
+    (16, 512, 512, 32, False, 192, True),       # the dominant launch of the step: 128-channel tiles
+    (8, 512, 512, 32, False, 192, True),        # src_model / tsf_model: 64-channel tiles (twice the workgroups)
+    (8, 128, 1024, 32, True, 192, True),        # SPADE gamma|beta
+    (16, 64, 128, 64, False, 192, True),
+    (3, 256, 256, 64, True, 192, True),
+    (1, 128, 128, 32, True, 192, False),        # 8 workgroups: left to the three-term kernels ...
+    (1, 128, 128, 32, True, 1, True),           # ... unless the threshold is lowered (what the parity tests do)
+    (2, 64, 384, 64, False, 1, True)])          # three 128-channel tiles -> six 64-channel ones
+def test_conv_f16f6_forward(B, Ci, Co, H, bias, min_tiles, runs_f6):
+    """hoig_conv2d_fwd_f6 (hi*hi on fp16 + the two cross terms of the split on block-scaled fp6 MFMAs) against torch fp32:
+    per layer the cross-term quantisation (4 significant bits on terms that carry 2^-11 of the product) must leave ~2^-15 of
+    relative error -- bound 2e-4 -- and MORE than the three-fp16-term kernel's ~1e-6, which proves the fp6 kernel ran; the
+    backward of the mode (two bf16 terms) within the f16x2 bounds."""
+    ops = _ops()
+    from hoig_amd import _lib as L
+    g = torch.Generator().manual_seed(13)
+    x = torch.randn(B, Ci, H, H, generator=g) * torch.rand(B, Ci, 1, 1, generator=g) * 3.0      # per-channel magnitudes differ
+    w = torch.randn(Co, Ci, 3, 3, generator=g) * 0.05
+    bv = torch.randn(Co, generator=g) if bias else None
+    xr, wr = x.clone().requires_grad_(True), w.clone().requires_grad_(True)
+    yr = F.conv2d(xr, wr, bv, stride=1, padding=1)
+    gy = torch.randn(yr.shape, generator=g)
+    yr.backward(gy)
+    ops.set_precision('f16f6')
+    old = ops.set_f6_min_tiles(min_tiles)
+    try:
+        xd = nhwc_cuda(x).requires_grad_(True)
+        wd = ops.pack_weight(w.cuda()).requires_grad_(True)
+        y = ops.conv2d(xd, wd, bv.cuda() if bias else None, 1, 1)
+        y.backward(nhwc_cuda(gy))
+    finally:
+        ops.set_precision('f32')
+        ops.set_f6_min_tiles(old)
+    ef, ed, ew = rel_err(nchw_cpu(y), yr), rel_err(nchw_cpu(xd.grad), xr.grad), rel_err(wd.grad, wr.grad)
+    print('f16f6: fwd %.2e dgrad %.2e wgrad %.2e' % (ef, ed, ew))
+    assert ef < 2e-4 and ed < 8e-3 and ew < 8e-3
+    if runs_f6:
+        assert ef > 5e-6, 'the fp6 kernel did not run (error at the three-fp16-term level)'
+    else:                       # too few 8x32 tiles to fill the chip: the launch runs as three fp16 terms
+        assert ef < 5e-6
