@@ -37,7 +37,8 @@ constexpr int REC = 56;                       // bytes of an fp6 record: 2 x 24 
 constexpr float W_SCALE = 256.f;
 
 struct F6Args {
-    const float *A;
+    const float *A, *A2;                      // A2 (nullable): the input is [A | A2] along channels, A holding the first cg1 (% 32)
+    int cg1;
     const unsigned short *Wh;                 // fp16 hi plane of w * 2^8, blocked 32(n) x 32(k) (plane_index of conv_igemm_bf16.hip)
     const unsigned char *Qh, *Ql;             // fp6 records of hi / lo: [(tap * ncb64 + cb64)][n][REC]
     const float *bias;
@@ -196,7 +197,10 @@ __global__ __launch_bounds__(NT) void conv_halo3_f6_kernel(const F6Args p) {
             const int hy = pix / HW, hx = pix - hy * HW;
             const int gy = y0 - 1 + hy, gx = x0 - 1 + hx;
             if (gy >= 0 && gy < p.H && gx >= 0 && gx < p.W) {
-                const float *src = p.A + (((size_t)b * p.H + gy) * p.W + gx) * p.Cg + cb * 64 + kb * 32;
+                const int c0 = cb * 64 + kb * 32;
+                const bool second = p.A2 != nullptr && c0 >= p.cg1;
+                const int ld = p.A2 ? (second ? p.Cg - p.cg1 : p.cg1) : p.Cg;
+                const float *src = (second ? p.A2 : p.A) + (((size_t)b * p.H + gy) * p.W + gx) * ld + (second ? c0 - p.cg1 : c0);
 #pragma unroll
                 for (int k = 0; k < 8; ++k) hr[k] = *reinterpret_cast<const float4 *>(src + k * 4);
             }
@@ -359,21 +363,21 @@ extern "C" int hoig_pack_conv_weight_f6(const float *w, int Co, int RS, int Ci, 
 
 // forward 3x3 stride-1 pad-1 convolution; HOIG_EUNSUPPORTED for every shape outside this kernel's tiling (the caller then uses
 // hoig_conv2d_fwd_packed with HOIG_PREC_BF16X3)
-extern "C" int hoig_conv2d_fwd_f6(const hoig_conv_desc *d, const float *x, const uint16_t *w_hi, const uint8_t *q_hi,
-                                  const uint8_t *q_lo, const float *bias, float *y, hoig_stream_t stream) {
-    if (!d || !x || !w_hi || !q_hi || !q_lo || !y) return HOIG_EINVAL;
+static int launch_f6(const hoig_conv_desc *d, const float *x, const float *x2, int cg1, const uint16_t *w_hi, const uint8_t *q_hi,
+                     const uint8_t *q_lo, const float *bias, float *y, hipStream_t st) {
     if (d->transposed || d->stride != 1 || d->R != 3 || d->S != 3 || d->pad != 1 || d->Hi != d->Ho || d->Wi != d->Wo)
         return HOIG_EUNSUPPORTED;
-    if ((d->Ci & 63) || (d->Co & 127) || (d->Hi & 7) || (d->Wi & 31)) return HOIG_EUNSUPPORTED;      // (Co % 128: the record arrays are read in 128- or 64-row tiles)
+    if ((d->Ci & 63) || (d->Co & 63) || (d->Hi & 7) || (d->Wi & 31)) return HOIG_EUNSUPPORTED;
+    if (x2 && (cg1 <= 0 || cg1 >= d->Ci || (cg1 & 31))) return HOIG_EINVAL;
     F6Args a;
-    a.A = x; a.Wh = w_hi; a.Qh = q_hi; a.Ql = q_lo; a.bias = bias; a.C = y;
+    a.A = x; a.A2 = x2; a.cg1 = cg1; a.Wh = w_hi; a.Qh = q_hi; a.Ql = q_lo; a.bias = bias; a.C = y;
     a.Bn = d->B; a.H = d->Hi; a.W = d->Wi; a.Cg = d->Ci; a.N = d->Co; a.K = 9 * d->Ci;
     a.act = d->act; a.slope = d->slope;
     a.tiles_x = a.W / TW; a.tiles_y = a.H / TH;
     const int ptiles = a.Bn * a.tiles_x * a.tiles_y;
     // 128-channel tiles when they fill the chip, 64-channel tiles (twice the workgroups) otherwise; launches that stay below
     // g_f6_min_tiles workgroups even so are left to the 4-row variants of the three-term path
-    const bool n64 = ptiles * (a.N / 128) < 192;
+    const bool n64 = (a.N & 127) != 0 || ptiles * (a.N / 128) < 192;
     a.nblk_n = a.N / (n64 ? 64 : 128);
     a.nblk = ptiles * a.nblk_n;
     if (a.nblk < g_f6_min_tiles) return HOIG_EUNSUPPORTED;
@@ -386,10 +390,25 @@ extern "C" int hoig_conv2d_fwd_f6(const hoig_conv_desc *d, const float *x, const
             return HOIG_ELAUNCH;
         once = true;
     }
-    if (n64) conv_halo3_f6_kernel<64><<<a.nblk, NT, BTile<64>::SMEM, (hipStream_t)stream>>>(a);
-    else conv_halo3_f6_kernel<128><<<a.nblk, NT, BTile<128>::SMEM, (hipStream_t)stream>>>(a);
+    if (n64) conv_halo3_f6_kernel<64><<<a.nblk, NT, BTile<64>::SMEM, st>>>(a);
+    else conv_halo3_f6_kernel<128><<<a.nblk, NT, BTile<128>::SMEM, st>>>(a);
     HOIG_LAUNCH_CHECK();
     return HOIG_OK;
+}
+
+// forward 3x3 stride-1 pad-1 convolution; HOIG_EUNSUPPORTED for every shape outside this kernel's tiling (the caller then uses
+// hoig_conv2d_fwd_packed with HOIG_PREC_BF16X3)
+extern "C" int hoig_conv2d_fwd_f6(const hoig_conv_desc *d, const float *x, const uint16_t *w_hi, const uint8_t *q_hi,
+                                  const uint8_t *q_lo, const float *bias, float *y, hoig_stream_t stream) {
+    if (!d || !x || !w_hi || !q_hi || !q_lo || !y) return HOIG_EINVAL;
+    return launch_f6(d, x, nullptr, 0, w_hi, q_hi, q_lo, bias, y, (hipStream_t)stream);
+}
+// the same over the channel concatenation [x1 | x2] without materialising it (the decoder's skip convolutions)
+extern "C" int hoig_conv2d_cat_fwd_f6(const hoig_conv_desc *d, const float *x1, int C1, const float *x2, const uint16_t *w_hi,
+                                      const uint8_t *q_hi, const uint8_t *q_lo, const float *bias, float *y,
+                                      hoig_stream_t stream) {
+    if (!d || !x1 || !x2 || !w_hi || !q_hi || !q_lo || !y) return HOIG_EINVAL;
+    return launch_f6(d, x1, x2, C1, w_hi, q_hi, q_lo, bias, y, (hipStream_t)stream);
 }
 
 extern "C" int hoig_set_f6_min_tiles(int n) {

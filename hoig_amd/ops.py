@@ -264,11 +264,17 @@ class _ConvCat2(Function):
         C2 = x2.shape[-1]
         Co = w.shape[0]
         assert tuple(w.stride()) == packed_strides(w.shape, False), 'conv weight is not in packed layout'
-        d = _x3(ConvDesc(B, H, W_, C1 + C2, H, W_, Co, 3, 3, 1, 1, 0, L.ACT_NONE, 0.0, prec))
+        d = ConvDesc(B, H, W_, C1 + C2, H, W_, Co, 3, 3, 1, 1, 0, L.ACT_NONE, 0.0, prec)
         y = torch.empty((B, H, W_, Co), dtype=x1.dtype, device=x1.device)
         hi, lo = _packed_planes(w, False, False)
-        L.check(L.lib.hoig_conv2d_cat_fwd_packed(ctypes.byref(d), _p(x1), C1, _p(x2), _p(hi), _p(lo), None, _p(y), _st()),
-                'hoig_conv2d_cat_fwd_packed')
+        rc = L.EUNSUPPORTED
+        if prec == L.PREC_F16F6 and (C1 + C2) % 64 == 0 and Co % 64 == 0 and H % 8 == 0:
+            qh, ql = _f6_planes(w)
+            rc = L.lib.hoig_conv2d_cat_fwd_f6(ctypes.byref(d), _p(x1), C1, _p(x2), _p(hi), _p(qh), _p(ql), None, _p(y), _st())
+        d = _x3(d)
+        if rc == L.EUNSUPPORTED:
+            rc = L.lib.hoig_conv2d_cat_fwd_packed(ctypes.byref(d), _p(x1), C1, _p(x2), _p(hi), _p(lo), None, _p(y), _st())
+        L.check(rc, 'hoig_conv2d_cat_fwd')
         ctx.d_dg, ctx.d_wg = _bwd_descs(d)
         ctx.save_for_backward(x1, x2, w)
         return y
@@ -687,7 +693,7 @@ def _x3(d):
 def _conv_fwd_raw(d, x, w, b, y, transposed=False):
     """y = conv(x, w) (+bias, activation) on the kernel the precision mode selects."""
     if d.precision == L.PREC_F16F6:
-        if (not transposed and d.R == 3 and d.S == 3 and d.stride == 1 and d.pad == 1 and d.Ci % 64 == 0 and d.Co % 128 == 0
+        if (not transposed and d.R == 3 and d.S == 3 and d.stride == 1 and d.pad == 1 and d.Ci % 64 == 0 and d.Co % 64 == 0
                 and d.Hi % 8 == 0 and d.Wi % 32 == 0):
             hi, _ = _packed_planes(w, False, False)
             qh, ql = _f6_planes(w)

@@ -99,11 +99,15 @@ int hoig_conv2d_bwd_data_packed(const hoig_conv_desc *d, const float *dy, const 
  * the hi / lo fp16 halves of 256*w, hoig_f6_plane_bytes(Co, 9, Ci) bytes each, made by hoig_pack_conv_weight_f6 once per
  * optimiser step: [(tap * Ci/64 + ci/64)][co] records of 56 B = 2 x 24 B of e2m3 elements (32 channels each, element j in bits
  * [6j, 6j+6)) + the two E8M0 scale bytes.  w_hi: the forward hi plane of hoig_pack_conv_weight_bf16.  HOIG_EUNSUPPORTED unless
- * Ci % 64 == 0, Co % 128 == 0, H % 8 == 0, W % 32 == 0 and the launch has enough 8x32-pixel tiles to fill the chip. */
+ * Ci % 64 == 0, Co % 64 == 0, H % 8 == 0, W % 32 == 0 and the launch has enough 8x32-pixel tiles to fill the chip.
+ * hoig_conv2d_cat_fwd_f6: the same over [x1 | x2] along channels (C1 % 32 == 0) without the concatenated tensor. */
 int64_t hoig_f6_plane_bytes(int Co, int RS, int Ci);
 int hoig_pack_conv_weight_f6(const float *w, int Co, int RS, int Ci, uint8_t *q_hi, uint8_t *q_lo, hoig_stream_t stream);
 int hoig_conv2d_fwd_f6(const hoig_conv_desc *d, const float *x, const uint16_t *w_hi, const uint8_t *q_hi, const uint8_t *q_lo,
                        const float *bias /*nullable*/, float *y, hoig_stream_t stream);
+int hoig_conv2d_cat_fwd_f6(const hoig_conv_desc *d, const float *x1, int C1, const float *x2, const uint16_t *w_hi,
+                           const uint8_t *q_hi, const uint8_t *q_lo, const float *bias /*nullable*/, float *y,
+                           hoig_stream_t stream);
 /* launches with fewer workgroups than this run as three fp16 terms (default 192; returns the previous value; n <= 0: query).
  * Parity tests set 1 so that the fp6 kernel is exercised at their small sizes. */
 int hoig_set_f6_min_tiles(int n);

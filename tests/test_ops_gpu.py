@@ -527,3 +527,24 @@ def test_conv_f16f6_forward(B, Ci, Co, H, bias, min_tiles, runs_f6):
         assert ef > 5e-6, 'the fp6 kernel did not run (error at the three-fp16-term level)'
     else:                       # too few 8x32 tiles to fill the chip: the launch runs as three fp16 terms
         assert ef < 5e-6
+
+
+@pytest.mark.parametrize('B,C1,C2,Co,H', [(8, 64, 64, 64, 64), (4, 128, 128, 128, 64), (2, 256, 256, 256, 32)])
+def test_conv_cat_f16f6_forward(B, C1, C2, Co, H):
+    """The decoder's skip convolution over [skip | up] (generator.py:305-306) on the fp16 + fp6 forward kernel reading the two
+    tensors directly, against torch's conv2d of the concatenation."""
+    ops = _ops()
+    g = torch.Generator().manual_seed(17)
+    x1, x2 = torch.randn(B, C1, H, H, generator=g), torch.randn(B, C2, H, H, generator=g) * 2.0
+    w = torch.randn(Co, C1 + C2, 3, 3, generator=g) * 0.05
+    yr = F.conv2d(torch.cat([x1, x2], 1), w, None, stride=1, padding=1)
+    ops.set_precision('f16f6')
+    old = ops.set_f6_min_tiles(1)
+    try:
+        y = ops.conv2d_cat2(nhwc_cuda(x1), nhwc_cuda(x2), ops.pack_weight(w.cuda()))
+    finally:
+        ops.set_precision('f32')
+        ops.set_f6_min_tiles(old)
+    e = rel_err(nchw_cpu(y), yr)
+    print('cat f16f6 fwd %.2e' % e)
+    assert 5e-6 < e < 2e-4
