@@ -24,6 +24,13 @@
 #include "common.h"
 #include <cstdlib>
 
+// tools/f6_knockout.cpp builds this file with HOIG_F6_KO != 0 to time the kernel with parts removed (results are then wrong):
+// 1 no halo split/store after the first block, 2 no fp6 terms, 4 no fp16 term, 8 no halo loads after the first block,
+// 16 no weight loads/stores after the prologue, 32 no per-step barrier
+#ifndef HOIG_F6_KO
+#define HOIG_F6_KO 0
+#endif
+
 namespace {
 
 typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
@@ -113,6 +120,42 @@ __global__ void pack_f6_kernel(const float *__restrict__ w, int Co, int RS, int 
         }
         qh[rec + 48 + (kb & 1)] = (unsigned char)s.sh;
         ql[rec + 48 + (kb & 1)] = (unsigned char)s.sl;
+    }
+}
+
+// Every eligible weight of a network in ONE launch (the per-weight kernel above is the stand-alone form): `rows` holds (offset
+// into the flat parameter buffer, Co, RS, Ci, byte offset of the weight's records, first task) per weight; a task = one
+// (output channel, tap, 32-channel block) half record.
+__global__ void pack_f6_all_kernel(const float *__restrict__ flat, const int64_t *__restrict__ rows, int nrows, int64_t ntasks,
+                                   unsigned char *__restrict__ qh, unsigned char *__restrict__ ql) {
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < ntasks; i += (int64_t)gridDim.x * blockDim.x) {
+        int lo_s = 0, hi_s = nrows - 1;
+        while (lo_s < hi_s) {                 // last row whose first task <= i
+            const int mid = (lo_s + hi_s + 1) >> 1;
+            if (rows[(int64_t)mid * 6 + 5] <= i) lo_s = mid; else hi_s = mid - 1;
+        }
+        const int64_t *rw = rows + (int64_t)lo_s * 6;
+        const int Co = (int)rw[1], RS = (int)rw[2], Ci = (int)rw[3];
+        unsigned char *oh = qh + rw[4], *ol = ql + rw[4];
+        const int64_t t0 = i - rw[5];
+        const int nkb = Ci >> 5;
+        const int kb = (int)(t0 % nkb);
+        const int64_t t = t0 / nkb;
+        const int rs = (int)(t % RS), co = (int)(t / RS);
+        const float *src = flat + rw[0] + ((size_t)co * RS + rs) * Ci + kb * 32;
+        float4 v[8];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) v[k] = *reinterpret_cast<const float4 *>(src + k * 4);
+        const Split32 s = split32(v, W_SCALE);
+        const size_t rec = ((size_t)(rs * (nkb >> 1) + (kb >> 1)) * Co + co) * REC;
+        unsigned *dh = reinterpret_cast<unsigned *>(oh + rec + (kb & 1) * 24), *dl = reinterpret_cast<unsigned *>(ol + rec + (kb & 1) * 24);
+#pragma unroll
+        for (int k = 0; k < 6; ++k) {
+            dh[k] = s.qh[k];
+            dl[k] = s.ql[k];
+        }
+        oh[rec + 48 + (kb & 1)] = (unsigned char)s.sh;
+        ol[rec + 48 + (kb & 1)] = (unsigned char)s.sl;
     }
 }
 
@@ -267,6 +310,7 @@ __global__ __launch_bounds__(NT) void conv_halo3_f6_kernel(const F6Args p) {
             sbl[j] = rl[48 + lh];
         }
         // the two cross terms: lo(a) * hi(w) and hi(a) * lo(w), e2m3 x e2m3 (cbsz = blgp = 2), K = 64
+        if (!(HOIG_F6_KO & 2))
 #pragma unroll
         for (int i = 0; i < TM; ++i)
 #pragma unroll
@@ -275,6 +319,7 @@ __global__ __launch_bounds__(NT) void conv_halo3_f6_kernel(const F6Args p) {
                 acc[i][j] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(aqh[i], bql[j], acc[i][j], 2, 2, 0, sah[i], 0, sbl[j]);
             }
         // hi * hi on fp16, four k-steps of 16 channels
+        if (!(HOIG_F6_KO & 4))
 #pragma unroll
         for (int ks = 0; ks < 4; ++ks) {
             f16x8 ah[TM], bh[TN];
@@ -304,17 +349,19 @@ __global__ __launch_bounds__(NT) void conv_halo3_f6_kernel(const F6Args p) {
         const int cb = step / 9, tap = step - cb * 9;
         const bool more = step + 1 < T;
         const bool boundary = more && tap == 8;
-        if (more) store_b(bbuf ^ 1);                      // weights of step+1 (registers loaded during the previous step)
-        if (step + 2 < T) load_b(step + 2);
-        if (tap == 7 && cb + 1 < ncb) halo_load(cb + 1, 0, hreg0);                  // next block's halo: first half of the tasks ...
-        if (boundary) halo_load(cb + 1, 1, hreg1);                                   // ... second half
+        if (more && !(HOIG_F6_KO & 16)) store_b(bbuf ^ 1);   // weights of step+1 (registers loaded during the previous step)
+        if (step + 2 < T && !(HOIG_F6_KO & 16)) load_b(step + 2);
+        if (!(HOIG_F6_KO & 8)) {
+            if (tap == 7 && cb + 1 < ncb) halo_load(cb + 1, 0, hreg0);              // next block's halo: first half of the tasks ...
+            if (boundary) halo_load(cb + 1, 1, hreg1);                               // ... second half
+        }
         compute(tap, bbuf);
-        if (boundary) {
+        if (boundary && !(HOIG_F6_KO & 1)) {
             __syncthreads();                              // every wave is done with the halo
             halo_store(0, hreg0);
             halo_store(1, hreg1);
         }
-        __syncthreads();
+        if (!(HOIG_F6_KO & 32)) __syncthreads();
         bbuf ^= 1;
     }
 
@@ -409,6 +456,14 @@ extern "C" int hoig_conv2d_cat_fwd_f6(const hoig_conv_desc *d, const float *x1, 
                                       hoig_stream_t stream) {
     if (!d || !x1 || !x2 || !w_hi || !q_hi || !q_lo || !y) return HOIG_EINVAL;
     return launch_f6(d, x1, x2, C1, w_hi, q_hi, q_lo, bias, y, (hipStream_t)stream);
+}
+
+extern "C" int hoig_pack_conv_weights_f6_all(const float *flat, const int64_t *rows, int nrows, int64_t ntasks, uint8_t *q_hi,
+                                             uint8_t *q_lo, hoig_stream_t stream) {
+    if (!flat || !rows || nrows <= 0 || ntasks <= 0 || !q_hi || !q_lo) return HOIG_EINVAL;
+    pack_f6_all_kernel<<<hoig_stream_grid(ntasks, 256), 256, 0, (hipStream_t)stream>>>(flat, rows, nrows, ntasks, q_hi, q_lo);
+    HOIG_LAUNCH_CHECK();
+    return HOIG_OK;
 }
 
 extern "C" int hoig_set_f6_min_tiles(int n) {

@@ -110,6 +110,7 @@ class ParamTree(nn.Module):
                 self.F[key] = v
 
         self._pending = None      # event of an optimiser step still running on a side stream (Trainer._step)
+        self._f6 = None
         self._plane_bufs = None
         self._plane_version = -1
         self._plane_flags = {}
@@ -140,6 +141,9 @@ class ParamTree(nn.Module):
     def refresh_planes(self):
         self.wait_pending()
         self._refresh_planes()
+        from . import ops
+        if ops.precision == L.PREC_F16F6:       # (a forward that forks onto several streams: the fp6 records too, here)
+            self._refresh_f6()
 
     def _refresh_planes(self):
         """Split the current weights into bf16 planes (one launch) if they changed since the last split.  Called lazily by
@@ -171,6 +175,57 @@ class ParamTree(nn.Module):
         n = w.numel()
         hi, lo = (self._plane_bufs[2], self._plane_bufs[3]) if for_dgrad else (self._plane_bufs[0], self._plane_bufs[1])
         return hi[off:off + n], lo[off:off + n]
+
+    # --- fp6 records of the 3x3 weights (ops._f6_planes): all of the network's in one launch per weight version
+    def _build_f6_table(self):
+        used = [(self._offsets[n], self._internal[n][0]) for n in self._offsets
+                if len(self._internal[n][0]) == 4 and not self._internal[n][1] and not (
+                    ('.mlp_gamma.' in n or '.mlp_beta.' in n)
+                    and n.replace('.mlp_gamma.', '.mlp_gb.').replace('.mlp_beta.', '.mlp_gb.') in self.F)]
+        used += [(v.storage_offset(), tuple(v.shape)) for v in self.F.values() if v.dim() == 4]
+        rows, byte_off, task0, where = [], 0, 0, {}
+        for off, (co, ci, r, s_) in used:
+            if r != 3 or s_ != 3 or ci % 64 or co % 64:
+                continue
+            nbytes = L.lib.hoig_f6_plane_bytes(co, 9, ci)
+            rows.append([off, co, 9, ci, byte_off, task0])
+            where[off] = (byte_off, nbytes)
+            byte_off += (nbytes + 255) // 256 * 256
+            task0 += co * 9 * (ci // 32)
+        return rows, byte_off, task0, where
+
+    def _refresh_f6(self):
+        if self._f6 is None:
+            rows, nbytes, ntasks, where = self._build_f6_table()
+            self._f6 = dict(where=where, ntasks=ntasks, version=-1, bufs=None, nbytes=nbytes,
+                            table=torch.tensor(rows, dtype=torch.int64, device=self.flat.device) if rows else None)
+        f = self._f6
+        if f['table'] is None:
+            return f
+        if f['bufs'] is None:
+            f['bufs'] = (torch.empty(f['nbytes'], dtype=torch.uint8, device=self.flat.device),
+                         torch.empty(f['nbytes'], dtype=torch.uint8, device=self.flat.device))
+        if f['version'] != self.version:
+            self.wait_pending()
+            L.call('hoig_pack_conv_weights_f6_all', _p(self.flat), _p(f['table']), f['table'].shape[0], f['ntasks'],
+                   _p(f['bufs'][0]), _p(f['bufs'][1]), _st())
+            f['version'] = self.version
+        return f
+
+    def packed_f6(self, w):
+        """(q_hi, q_lo) fp6 record arrays of conv weight `w` (a view of self.flat; hoig_pack_conv_weights_f6_all), or None if
+        `w` is not a 3x3 weight with Ci, Co multiples of 64."""
+        off = w.storage_offset()
+        f = self._f6
+        if f is not None and (f['table'] is None or off not in f['where']):
+            return None
+        if w.data_ptr() != self.flat.data_ptr() + 4 * off:
+            return None
+        f = self._refresh_f6()
+        if f['table'] is None or off not in f['where']:
+            return None
+        a, n = f['where'][off]
+        return f['bufs'][0][a:a + n], f['bufs'][1][a:a + n]
 
     def set_pending(self, event):
         """An update of this network's buffers is in flight on another stream; readers call wait_pending() first."""

@@ -664,6 +664,10 @@ def _f6_planes(w):
     """fp6 records of a 3x3 conv weight's hi / lo halves (hoig_pack_conv_weight_f6), re-made when the owner's weights change."""
     co, ci, r, s = w.shape
     owner = getattr(w, '_hoig_owner', None)
+    if owner is not None and hasattr(owner, 'packed_f6'):
+        planes = owner.packed_f6(w)          # all weights of the network in one launch per optimiser step
+        if planes is not None:
+            return planes
     ver = owner.version if owner is not None else None
     key = (w.data_ptr(), tuple(w.shape))
     hit = _f6_cache.get(key)

@@ -108,6 +108,11 @@ int hoig_conv2d_fwd_f6(const hoig_conv_desc *d, const float *x, const uint16_t *
 int hoig_conv2d_cat_fwd_f6(const hoig_conv_desc *d, const float *x1, int C1, const float *x2, const uint16_t *w_hi,
                            const uint8_t *q_hi, const uint8_t *q_lo, const float *bias /*nullable*/, float *y,
                            hoig_stream_t stream);
+/* all eligible weights of a flat parameter buffer in one launch: rows = int64[nrows][6] = (offset of the weight in `flat`, Co,
+ * RS, Ci, byte offset of its records in q_hi / q_lo (a multiple of 4), index of its first task); a task = one (output channel,
+ * tap, 32 input channels) half record: Co*RS*Ci/32 per weight */
+int hoig_pack_conv_weights_f6_all(const float *flat, const int64_t *rows, int nrows, int64_t ntasks, uint8_t *q_hi, uint8_t *q_lo,
+                                  hoig_stream_t stream);
 /* launches with fewer workgroups than this run as three fp16 terms (default 192; returns the previous value; n <= 0: query).
  * Parity tests set 1 so that the fp6 kernel is exercised at their small sizes. */
 int hoig_set_f6_min_tiles(int n);

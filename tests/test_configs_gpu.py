@@ -40,8 +40,10 @@ def _loss_tol(want):
 def test_config5_eval_forward_b32_hipgraph_replay():
     """configs[4]: eval.py's generator-only inference (eval.py:59-65: set_eval, forward under no_grad), 256x256, batch 32,
     captured in a hipGraph.  The replay must reproduce the eager forward (same kernels, same order; fp32 atomics in the
-    instance-norm statistics and split-K epilogues make two runs agree to rounding, not bitwise: measured 3e-5 through the 45
-    conv + norm layers, bound 2e-4), must re-read its static
+    instance-norm statistics and split-K epilogues make two runs agree to rounding, not bitwise; in the f16f6 arithmetic a
+    last-bit difference of an activation can move an fp6 rounding of a cross term, so two runs differ by up to that arithmetic's
+    own error against fp32 -- measured 3e-5 ... 2e-4 through the 45 conv + norm layers at 32 images, bound 5e-4; the parity
+    statement is the oracle comparison below at TOL), must re-read its static
     input buffers (new inputs -> new outputs without re-capture), and its first two samples must match the ORACLE's forward
     of those two samples."""
     from hoig_amd import synthetic
@@ -61,7 +63,7 @@ def test_config5_eval_forward_b32_hipgraph_replay():
         r2 = [o.clone() for o in outs]
     for e, a, b in zip(eager, r1, r2):
         assert torch.isfinite(a).all()
-        assert rel_err(a, e) < 2e-4 and rel_err(b, a) < 2e-4
+        assert rel_err(a, e) < 5e-4 and rel_err(b, a) < 5e-4
     ot = oracle_trainer('generator_spade_attn', 2, S)          # same per-sample seeds: samples 0,1 of the batch of 32
     with torch.no_grad():
         want = ot.forward()

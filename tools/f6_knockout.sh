@@ -1,0 +1,14 @@
+#!/bin/bash
+# Builds (here) / runs (on the GPU box) the knock-out variants of the fp6 forward kernel.  usage: f6_knockout.sh build|run
+cd "$(dirname "$0")/.."
+KOS="0 1 2 4 6 8 9 16 32 25 57"
+if [ "$1" = build ]; then
+  for k in $KOS; do
+    /opt/rocm/bin/hipcc -O3 -std=c++17 --offload-arch=gfx950 -DHOIG_F6_KO=$k -DHOIG_F6_KO_VALUE=$k -Iinclude -Ihoig_amd/csrc -Wno-unused-result \
+      tools/f6_knockout.cpp hoig_amd/csrc/conv_f6.hip -o tools/_build/f6_ko_$k &
+  done
+  wait
+else
+  for k in $KOS; do tools/_build/f6_ko_$k 16; done
+  tools/_build/f6_ko_0 8
+fi

@@ -4,6 +4,7 @@ set -u
 cd /root/repo
 O=/root/repo/gpurun_out
 TAG=${1:-r02}
+python -c "from hoig_amd import _lib; _lib.lib" || { echo "library does not load: stale snapshot?"; exit 9; }
 python -m pytest tests -m gpu -q 2>&1 | tail -15 > $O/${TAG}_pytest.log
 python bench.py > $O/${TAG}_bench.json 2> $O/${TAG}_bench.err
 export TMPDIR=/tmp
