@@ -1,7 +1,7 @@
 #!/bin/bash
 # Builds (here) / runs (on the GPU box) the knock-out variants of the fp6 forward kernel.  usage: f6_knockout.sh build|run
 cd "$(dirname "$0")/.."
-KOS="0 1 2 4 6 8 9 16 32 25 57"
+KOS=${KOS:-"0 57 63 121 123 125"}
 if [ "$1" = build ]; then
   for k in $KOS; do
     /opt/rocm/bin/hipcc -O3 -std=c++17 --offload-arch=gfx950 -DHOIG_F6_KO=$k -DHOIG_F6_KO_VALUE=$k -Iinclude -Ihoig_amd/csrc -Wno-unused-result \
