@@ -26,7 +26,7 @@
 
 // tools/f6_knockout.cpp builds this file with HOIG_F6_KO != 0 to time the kernel with parts removed (results are then wrong):
 // 1 no halo split/store after the first block, 2 no fp6 terms, 4 no fp16 term, 8 no halo loads after the first block,
-// 16 no weight loads/stores after the prologue, 32 no per-step barrier, 64 no LDS fragment reads (MFMAs on register garbage)
+// 16 no weight loads/stores after the prologue, 32 no per-step barrier
 #ifndef HOIG_F6_KO
 #define HOIG_F6_KO 0
 #endif
@@ -97,30 +97,6 @@ __device__ __forceinline__ Split32 split32(const float4 (&v)[8], float pre) {
     return o;
 }
 
-// weight records (3x3): record (32-channel block kb, tap pair pr = tap / 2, output channel) = 24 B of tap 2 pr | 24 B of tap
-// 2 pr + 1 | their two scale bytes; the ninth tap's partner is zero (elements 0, scale byte 0 = 2^-127)
-constexpr int NPAIR = 5;
-__device__ __forceinline__ void write_weight_rec(unsigned char *qh, unsigned char *ql, size_t rec, int rs, const Split32 &s) {
-    const int half = rs & 1;
-    unsigned *dh = reinterpret_cast<unsigned *>(qh + rec + half * 24), *dl = reinterpret_cast<unsigned *>(ql + rec + half * 24);
-#pragma unroll
-    for (int k = 0; k < 6; ++k) {
-        dh[k] = s.qh[k];
-        dl[k] = s.ql[k];
-    }
-    qh[rec + 48 + half] = (unsigned char)s.sh;
-    ql[rec + 48 + half] = (unsigned char)s.sl;
-    if (rs == 8) {
-#pragma unroll
-        for (int k = 0; k < 6; ++k) {
-            dh[6 + k] = 0u;
-            dl[6 + k] = 0u;
-        }
-        qh[rec + 49] = 0;
-        ql[rec + 49] = 0;
-    }
-}
-
 // weights: one thread per (output channel, tap, 32-channel block)
 __global__ void pack_f6_kernel(const float *__restrict__ w, int Co, int RS, int Ci, unsigned char *__restrict__ qh,
                                unsigned char *__restrict__ ql) {
@@ -135,7 +111,15 @@ __global__ void pack_f6_kernel(const float *__restrict__ w, int Co, int RS, int 
 #pragma unroll
         for (int k = 0; k < 8; ++k) v[k] = *reinterpret_cast<const float4 *>(src + k * 4);
         const Split32 s = split32(v, W_SCALE);
-        write_weight_rec(qh, ql, ((size_t)(kb * NPAIR + (rs >> 1)) * Co + co) * REC, rs, s);
+        const size_t rec = ((size_t)(rs * (nkb >> 1) + (kb >> 1)) * Co + co) * REC;
+        unsigned *dh = reinterpret_cast<unsigned *>(qh + rec + (kb & 1) * 24), *dl = reinterpret_cast<unsigned *>(ql + rec + (kb & 1) * 24);
+#pragma unroll
+        for (int k = 0; k < 6; ++k) {
+            dh[k] = s.qh[k];
+            dl[k] = s.ql[k];
+        }
+        qh[rec + 48 + (kb & 1)] = (unsigned char)s.sh;
+        ql[rec + 48 + (kb & 1)] = (unsigned char)s.sl;
     }
 }
 
@@ -163,17 +147,26 @@ __global__ void pack_f6_all_kernel(const float *__restrict__ flat, const int64_t
 #pragma unroll
         for (int k = 0; k < 8; ++k) v[k] = *reinterpret_cast<const float4 *>(src + k * 4);
         const Split32 s = split32(v, W_SCALE);
-        write_weight_rec(oh, ol, ((size_t)(kb * NPAIR + (rs >> 1)) * Co + co) * REC, rs, s);
+        const size_t rec = ((size_t)(rs * (nkb >> 1) + (kb >> 1)) * Co + co) * REC;
+        unsigned *dh = reinterpret_cast<unsigned *>(oh + rec + (kb & 1) * 24), *dl = reinterpret_cast<unsigned *>(ol + rec + (kb & 1) * 24);
+#pragma unroll
+        for (int k = 0; k < 6; ++k) {
+            dh[k] = s.qh[k];
+            dl[k] = s.ql[k];
+        }
+        oh[rec + 48 + (kb & 1)] = (unsigned char)s.sh;
+        ol[rec + 48 + (kb & 1)] = (unsigned char)s.sl;
     }
 }
 
-constexpr int WM = 4, TH = 8, TW = 32, KS = 3, TM = 2;
+constexpr int WM = 4, WN = 2, TH = 8, TW = 32, KS = 3, NT = 512;
 constexpr int HH = TH + KS - 1, HW = TW + KS - 1, HPIX = HH * HW;              // 10 x 34 = 340 halo pixels
-constexpr int AROW = 80;                                                         // fp16 plane: 32 channels = 64 B + 16 B pad
-constexpr int A_HI = HPIX * AROW, A_Q = HPIX * REC, A_BUF = A_HI + A_Q;          // 27200 + 19040 = 46240 B per block buffer
-template <int BN, int WN> struct BTile {                                        // BN = 128: 16384 + 2 * 7168 = 30720 B per stage
-    static constexpr int HI = 2 * BN * 64, Q = BN * REC, STAGE = HI + 2 * Q, SMEM = 2 * A_BUF + 2 * STAGE, TN = BN / (32 * WN),
-                         NT = 64 * WM * WN;
+constexpr int AROW = 144;                                                        // fp16 plane: 64 channels = 128 B + 16 B pad
+constexpr int A_HI = HPIX * AROW, A_Q = ((HPIX * REC + 15) / 16) * 16;           // 48960, 19040
+constexpr int A_BYTES = A_HI + 2 * A_Q;
+constexpr int TM = 2;
+template <int BN> struct BTile {                                                 // BN = 128: 16384 + 2 * 7168 = 30720 B per stage
+    static constexpr int HI = 2 * BN * 64, Q = BN * REC, STAGE = HI + 2 * Q, SMEM = A_BYTES + 2 * STAGE, TN = BN / (32 * WN);
 };
 
 __device__ __forceinline__ i32x8 read_rec(const unsigned char *p) {
@@ -184,27 +177,13 @@ __device__ __forceinline__ i32x8 read_rec(const unsigned char *p) {
     return r;
 }
 
-// One workgroup = 8 x 32 pixels x BN output channels, 8 waves (4 along the rows x 2 along the channels), each wave 2 rows x
-// BN/2 channels = TM x TN MFMA blocks of 32 x 32.  The reduction runs over 32-channel blocks; within a block a STEP covers two
-// taps: the block-scaled fp6 MFMA contracts K = 64 = (tap a, 32 channels | tap b, 32 channels) -- lanes 0-31 read the records of
-// the pixel shifted by tap a, lanes 32-63 those of tap b -- and the fp16 term issues 2 x K = 16 per tap.  The ninth tap pairs
-// with zero weights (1/9 of the fp6 issue slots, 4 % of the MFMA time) -- the price of 32-channel blocks, which halve the halo
-// image so that TWO of them fit: the next block's halo is split and stored while the current one is being read, and no
-// barrier other than the one per step is needed.
-// Software pipeline of a step s (weight stage b = s & 1), registers named by what they hold:
-//   P1  store weights(s+1) -> stage b^1, load weights(s+2) -> registers;  read fp16 fragments of tap a;  fp6 MFMAs (F6(s))
-//   P2  read fp16 fragments of tap b;                                      fp16 MFMAs of tap a
-//   --- barrier (stage b^1 and a freshly split halo block become visible; every read of stage b has returned) ---
-//   P3  read F6(s+1) (stage b^1, and the next halo block when s ends a block); fp16 MFMAs of tap b
-// so every LDS read is issued one phase before the MFMAs that consume it.
-template <int BN, int WN>
-__global__ __launch_bounds__(64 * WM * WN) void conv_halo3_f6_kernel(const F6Args p) {
-    using BT = BTile<BN, WN>;
-    constexpr int B_HI = BT::HI, B_Q = BT::Q, B_STAGE = BT::STAGE, TN = BT::TN, NT = BT::NT;
+// BN = 64: the same tile with half the output channels (twice the workgroups: launches with too few 8x32 pixel tiles for BN = 128)
+template <int BN>
+__global__ __launch_bounds__(NT) void conv_halo3_f6_kernel(const F6Args p) {
+    constexpr int B_HI = BTile<BN>::HI, B_Q = BTile<BN>::Q, B_STAGE = BTile<BN>::STAGE, TN = BTile<BN>::TN;
     constexpr int QCHUNKS = B_Q / 16;                     // 16-B chunks of one fp6 record array
-    constexpr int HU = (BN * 4 + NT - 1) / NT, QU = (QCHUNKS + NT - 1) / NT, SLOTS = (HPIX + NT - 1) / NT;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    unsigned char *Bbase = smem + 2 * A_BUF;
+    unsigned char *Ah = smem, *Aqh = smem + A_HI, *Aql = Aqh + A_Q, *Bbase = smem + A_BYTES;
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int l31 = lane & 31, lh = lane >> 5;
@@ -217,88 +196,75 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_halo3_f6_kernel(const F6Arg
     mt /= p.tiles_x;
     const int ty_ = mt % p.tiles_y, b = mt / p.tiles_y;
     const int y0 = ty_ * TH, x0 = tx_ * TW;
-    const int ncb = p.Cg >> 5, T = ncb * NPAIR;
+    const int ncb = p.Cg >> 6, T = ncb * KS * KS;
 
-    // ---- weight stage of a step: two fp16 32-k blocked tiles (tap a, tap b: BN rows x 4 chunks of 16 B each) + fp6 records
-    const unsigned short *wrow[HU];
-    int boff[HU];
-#pragma unroll
-    for (int u = 0; u < HU; ++u) {
-        const int task = tid + u * NT, brow = task >> 2, bchunk = task & 3;
-        wrow[u] = p.Wh + plane_index(n0 + (brow < BN ? brow : 0), bchunk * 8, p.K);
-        boff[u] = brow * 64 + ((bchunk ^ ((brow >> 2) & 3)) << 4);
-    }
-    uint4 rbh0[HU], rbh1[HU], rbq0[QU], rbq1[QU];
+    // ---- weight tile of a step: fp16 plane (two 32-k blocked tiles: one 16-B chunk per thread each) + fp6 records (linear copy)
+    const int brow = tid >> 2, bchunk = tid & 3;            // 128 rows x 4 chunks (BN = 64: the first 256 threads)
+    const bool bload = brow < BN;
+    const unsigned short *wrow = p.Wh + plane_index(n0 + (bload ? brow : 0), bchunk * 8, p.K);
+    const int boff = brow * 64 + ((bchunk ^ ((brow >> 2) & 3)) << 4);
+    uint4 rbh0 = make_uint4(0, 0, 0, 0), rbh1 = rbh0, rbq0 = rbh0, rbq1 = rbh0;
     auto load_b = [&](int step) {
-        const int cb = step / NPAIR, pr = step - cb * NPAIR;
-        const size_t koff = (size_t)(2 * pr * p.Cg + cb * 32) * 32;       // k-block index * 1024 elements (tap a = 2 pr)
-#pragma unroll
-        for (int u = 0; u < HU; ++u)
-            if (tid + u * NT < BN * 4) {
-                rbh0[u] = *reinterpret_cast<const uint4 *>(wrow[u] + koff);
-                rbh1[u] = pr < 4 ? *reinterpret_cast<const uint4 *>(wrow[u] + koff + (size_t)p.Cg * 32) : make_uint4(0, 0, 0, 0);
-            }
-        const size_t rec0 = ((size_t)step * p.N + n0) * REC;             // BN records (BN = 128: 7168 B = 448 chunks per array)
-#pragma unroll
-        for (int u = 0; u < QU; ++u)
-            if (tid + u * NT < QCHUNKS) {
-                rbq0[u] = *reinterpret_cast<const uint4 *>(p.Qh + rec0 + (size_t)(tid + u * NT) * 16);
-                rbq1[u] = *reinterpret_cast<const uint4 *>(p.Ql + rec0 + (size_t)(tid + u * NT) * 16);
-            }
+        const int cb = step / 9, tap = step - cb * 9;
+        const size_t koff = (size_t)(tap * p.Cg + cb * 64) * 32;           // k-block index * 1024 elements
+        if (bload) {
+            rbh0 = *reinterpret_cast<const uint4 *>(wrow + koff);
+            rbh1 = *reinterpret_cast<const uint4 *>(wrow + koff + 1024);
+        }
+        const size_t rec0 = ((size_t)(tap * ncb + cb) * p.N + n0) * REC;   // BN records (BN = 128: 7168 B = 448 chunks per plane)
+        if (tid < QCHUNKS) {
+            rbq0 = *reinterpret_cast<const uint4 *>(p.Qh + rec0 + (size_t)tid * 16);
+            rbq1 = *reinterpret_cast<const uint4 *>(p.Ql + rec0 + (size_t)tid * 16);
+        }
     };
     auto store_b = [&](int buf) {
         unsigned char *B = Bbase + buf * B_STAGE;
-#pragma unroll
-        for (int u = 0; u < HU; ++u)
-            if (tid + u * NT < BN * 4) {
-                *reinterpret_cast<uint4 *>(B + boff[u]) = rbh0[u];
-                *reinterpret_cast<uint4 *>(B + BN * 64 + boff[u]) = rbh1[u];
-            }
-#pragma unroll
-        for (int u = 0; u < QU; ++u)
-            if (tid + u * NT < QCHUNKS) {
-                *reinterpret_cast<uint4 *>(B + B_HI + (tid + u * NT) * 16) = rbq0[u];
-                *reinterpret_cast<uint4 *>(B + B_HI + B_Q + (tid + u * NT) * 16) = rbq1[u];
-            }
+        if (bload) {
+            *reinterpret_cast<uint4 *>(B + boff) = rbh0;
+            *reinterpret_cast<uint4 *>(B + BN * 64 + boff) = rbh1;
+        }
+        if (tid < QCHUNKS) {
+            *reinterpret_cast<uint4 *>(B + B_HI + tid * 16) = rbq0;
+            *reinterpret_cast<uint4 *>(B + B_HI + B_Q + tid * 16) = rbq1;
+        }
     };
 
-    // ---- halo of a 32-channel block: one thread per halo pixel (340 tasks)
-    float4 hreg[SLOTS][8];
-    auto halo_load = [&](int cb) {
+    // ---- halo: task = (halo pixel, 32-channel block); 680 tasks over 512 threads
+    float4 hreg0[8], hreg1[8];
+    auto halo_load = [&](int cb, int slot, float4 (&hr)[8]) {
+        const int task = tid + slot * NT;
 #pragma unroll
-        for (int u = 0; u < SLOTS; ++u) {
-            const int task = tid + u * NT;
-            const int hy = task / HW, hx = task - hy * HW;
+        for (int k = 0; k < 8; ++k) hr[k] = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (task < HPIX * 2) {
+            const int pix = task >> 1, kb = task & 1;
+            const int hy = pix / HW, hx = pix - hy * HW;
             const int gy = y0 - 1 + hy, gx = x0 - 1 + hx;
-#pragma unroll
-            for (int k = 0; k < 8; ++k) hreg[u][k] = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (task < HPIX && gy >= 0 && gy < p.H && gx >= 0 && gx < p.W) {
-                const int c0 = cb * 32;
+            if (gy >= 0 && gy < p.H && gx >= 0 && gx < p.W) {
+                const int c0 = cb * 64 + kb * 32;
                 const bool second = p.A2 != nullptr && c0 >= p.cg1;
                 const int ld = p.A2 ? (second ? p.Cg - p.cg1 : p.cg1) : p.Cg;
                 const float *src = (second ? p.A2 : p.A) + (((size_t)b * p.H + gy) * p.W + gx) * ld + (second ? c0 - p.cg1 : c0);
 #pragma unroll
-                for (int k = 0; k < 8; ++k) hreg[u][k] = *reinterpret_cast<const float4 *>(src + k * 4);
+                for (int k = 0; k < 8; ++k) hr[k] = *reinterpret_cast<const float4 *>(src + k * 4);
             }
         }
     };
-    auto halo_store = [&](unsigned char *Abuf) {
+    auto halo_store = [&](int slot, const float4 (&hr)[8]) {
+        const int task = tid + slot * NT;
+        if (task < HPIX * 2) {
+            const int pix = task >> 1, kb = task & 1;
+            const Split32 s = split32(hr, 1.f);
+            uint4 *dh = reinterpret_cast<uint4 *>(Ah + pix * AROW + kb * 64);
 #pragma unroll
-        for (int u = 0; u < SLOTS; ++u) {
-            const int task = tid + u * NT;
-            if (task < HPIX) {
-                const Split32 s = split32(hreg[u], 1.f);
-                uint4 *dh = reinterpret_cast<uint4 *>(Abuf + task * AROW);
+            for (int k = 0; k < 4; ++k) dh[k] = s.hi[k];
+            unsigned char *rh = Aqh + pix * REC + kb * 24, *rl = Aql + pix * REC + kb * 24;
 #pragma unroll
-                for (int k = 0; k < 4; ++k) dh[k] = s.hi[k];
-                unsigned char *rec = Abuf + A_HI + task * REC;        // hi record 24 B | residual record 24 B | the two scale bytes
-#pragma unroll
-                for (int k = 0; k < 3; ++k) {
-                    *reinterpret_cast<uint2 *>(rec + k * 8) = make_uint2(s.qh[2 * k], s.qh[2 * k + 1]);
-                    *reinterpret_cast<uint2 *>(rec + 24 + k * 8) = make_uint2(s.ql[2 * k], s.ql[2 * k + 1]);
-                }
-                *reinterpret_cast<unsigned short *>(rec + 48) = (unsigned short)(s.sh | (s.sl << 8));
+            for (int k = 0; k < 3; ++k) {
+                *reinterpret_cast<uint2 *>(rh + k * 8) = make_uint2(s.qh[2 * k], s.qh[2 * k + 1]);
+                *reinterpret_cast<uint2 *>(rl + k * 8) = make_uint2(s.ql[2 * k], s.ql[2 * k + 1]);
             }
+            Aqh[pix * REC + 48 + kb] = (unsigned char)s.sh;
+            Aql[pix * REC + 48 + kb] = (unsigned char)s.sl;
         }
     };
 
@@ -310,117 +276,93 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_halo3_f6_kernel(const F6Arg
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
-    int bread[TN], brec[TN];
+    int bread[TN];
 #pragma unroll
     for (int j = 0; j < TN; ++j) {
         const int row = wn * (TN * 32) + j * 32 + l31;
         bread[j] = row * 64 + ((lh ^ ((row >> 2) & 3)) << 4);
-        brec[j] = B_HI + row * REC + lh * 24;
     }
-    const int arow0 = (wm * TM) * HW + l31;                 // halo pixel of (the wave's first row, tap (0, 0))
 
-    // fp6 fragments of a step: lanes 0-31 tap a = 2 pr, lanes 32-63 tap b = 2 pr + 1 (pr = 4: tap 8 again -- finite values
-    // against zero weights)
-    i32x8 aqh[TM], aql[TM], bqh[TN], bql[TN];
-    int sah[TM], sal[TM], sbh[TN], sbl[TN];
-    auto read_f6 = [&](int pr, const unsigned char *Abuf, const unsigned char *B) {
-        const int tap = pr < 4 ? 2 * pr + lh : 8;
-        const int r = tap / 3, s_ = tap - 3 * r;
+    auto compute = [&](int tap, int bbuf) {
+        const int r = tap / 3, s_ = tap - r * 3;
+        const unsigned char *B = Bbase + bbuf * B_STAGE;
+        int apix[TM];
+#pragma unroll
+        for (int i = 0; i < TM; ++i) apix[i] = (wm * TM + i + r) * HW + l31 + s_;
+        // fp6 fragments + scales
+        i32x8 aqh[TM], aql[TM], bqh[TN], bql[TN];
+        int sah[TM], sal[TM], sbh[TN], sbl[TN];
 #pragma unroll
         for (int i = 0; i < TM; ++i) {
-            const unsigned char *rec = Abuf + A_HI + (arow0 + (i + r) * HW + s_) * REC;
-            aqh[i] = read_rec(rec);
-            aql[i] = read_rec(rec + 24);
-            sah[i] = rec[48];
-            sal[i] = rec[49];
+            const unsigned char *rh = Aqh + apix[i] * REC, *rl = Aql + apix[i] * REC;
+            aqh[i] = read_rec(rh + lh * 24);
+            aql[i] = read_rec(rl + lh * 24);
+            sah[i] = rh[48 + lh];
+            sal[i] = rl[48 + lh];
         }
 #pragma unroll
         for (int j = 0; j < TN; ++j) {
-            const unsigned char *rh = B + brec[j], *rl = rh + B_Q;
-            bqh[j] = read_rec(rh);
-            bql[j] = read_rec(rl);
-            sbh[j] = rh[48 - lh * 23];                      // byte 48 + lh of the record (rh points lh * 24 into it)
-            sbl[j] = rl[48 - lh * 23];
+            const int nrow = wn * (TN * 32) + j * 32 + l31;
+            const unsigned char *rh = B + B_HI + nrow * REC, *rl = B + B_HI + B_Q + nrow * REC;
+            bqh[j] = read_rec(rh + lh * 24);
+            bql[j] = read_rec(rl + lh * 24);
+            sbh[j] = rh[48 + lh];
+            sbl[j] = rl[48 + lh];
         }
-    };
-    auto mma_f6 = [&]() {                                   // lo(a) * hi(w) and hi(a) * lo(w), e2m3 x e2m3 (cbsz = blgp = 2), K = 64
-        if (HOIG_F6_KO & 2) return;
+        // the two cross terms: lo(a) * hi(w) and hi(a) * lo(w), e2m3 x e2m3 (cbsz = blgp = 2), K = 64
+        if (!(HOIG_F6_KO & 2))
 #pragma unroll
         for (int i = 0; i < TM; ++i)
 #pragma unroll
-            for (int j = 0; j < TN; ++j)
+            for (int j = 0; j < TN; ++j) {
                 acc[i][j] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(aql[i], bqh[j], acc[i][j], 2, 2, 0, sal[i], 0, sbh[j]);
+                acc[i][j] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(aqh[i], bql[j], acc[i][j], 2, 2, 0, sah[i], 0, sbl[j]);
+            }
+        // hi * hi on fp16, four k-steps of 16 channels
+        if (!(HOIG_F6_KO & 4))
 #pragma unroll
-        for (int i = 0; i < TM; ++i)
+        for (int ks = 0; ks < 4; ++ks) {
+            f16x8 ah[TM], bh[TN];
+#pragma unroll
+            for (int i = 0; i < TM; ++i) ah[i] = *reinterpret_cast<const f16x8 *>(Ah + apix[i] * AROW + ks * 32 + lh * 16);
 #pragma unroll
             for (int j = 0; j < TN; ++j)
-                acc[i][j] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(aqh[i], bql[j], acc[i][j], 2, 2, 0, sah[i], 0, sbl[j]);
-    };
-    // fp16 fragments of one tap (two k-steps of 16 channels) and their MFMAs
-    auto read_h = [&](f16x8 (&ah)[TM][2], f16x8 (&bh)[TN][2], int tap, int tsel, const unsigned char *Abuf, const unsigned char *B) {
-        const int r = tap / 3, s_ = tap - 3 * r;
-#pragma unroll
-        for (int i = 0; i < TM; ++i)
-#pragma unroll
-            for (int ks = 0; ks < 2; ++ks)
-                ah[i][ks] = *reinterpret_cast<const f16x8 *>(Abuf + (arow0 + (i + r) * HW + s_) * AROW + ks * 32 + lh * 16);
-#pragma unroll
-        for (int j = 0; j < TN; ++j)
-#pragma unroll
-            for (int ks = 0; ks < 2; ++ks)
-                bh[j][ks] = *reinterpret_cast<const f16x8 *>(B + tsel * (BN * 64) + (bread[j] ^ (ks << 5)));
-    };
-    auto mma_h = [&](const f16x8 (&ah)[TM][2], const f16x8 (&bh)[TN][2]) {
-        if (HOIG_F6_KO & 4) return;
-#pragma unroll
-        for (int ks = 0; ks < 2; ++ks)
+                bh[j] = *reinterpret_cast<const f16x8 *>(B + (ks >> 1) * (BN * 64) + (bread[j] ^ ((ks & 1) << 5)));
 #pragma unroll
             for (int i = 0; i < TM; ++i)
 #pragma unroll
-                for (int j = 0; j < TN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[i][ks], bh[j][ks], acc[i][j], 0, 0, 0);
+                for (int j = 0; j < TN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[i], bh[j], acc[i][j], 0, 0, 0);
+        }
     };
 
-    // ---- prologue: block 0's halo, weight stages 0 (LDS) and 1 (registers), F6(0)
-    halo_load(0);
+    halo_load(0, 0, hreg0);
+    halo_load(0, 1, hreg1);
     load_b(0);
-    halo_store(smem);
+    halo_store(0, hreg0);
+    halo_store(1, hreg1);
     store_b(0);
     if (T > 1) load_b(1);
     __syncthreads();
-    read_f6(0, smem, Bbase);
-
-    f16x8 ahA[TM][2], bhA[TN][2], ahB[TM][2], bhB[TN][2];
-    int step = 0;
+    int bbuf = 0;
 #pragma unroll 1
-    for (int cb = 0; cb < ncb; ++cb) {
-        const unsigned char *Acur = smem + (cb & 1) * A_BUF;
-        unsigned char *Anext = smem + ((cb + 1) & 1) * A_BUF;
-        const bool more_blocks = cb + 1 < ncb;
-#pragma unroll
-        for (int pr = 0; pr < NPAIR; ++pr, ++step) {
-            const int bbuf = step & 1;
-            const unsigned char *B = Bbase + bbuf * B_STAGE, *Bn = Bbase + (bbuf ^ 1) * B_STAGE;
-            const bool more = pr + 1 < NPAIR || more_blocks;
-            // P1
-            if (more && !(HOIG_F6_KO & 16)) store_b(bbuf ^ 1);
-            if (step + 2 < T && !(HOIG_F6_KO & 16)) load_b(step + 2);
-            if (pr == 0 && more_blocks && !(HOIG_F6_KO & 8)) halo_load(cb + 1);
-            read_h(ahA, bhA, 2 * pr, 0, Acur, B);
-            mma_f6();
-            __builtin_amdgcn_sched_barrier(0);
-            // P2 (the fp6 fragments are dead here: the phase with room for the halo split's temporaries)
-            if (pr < 4) {
-                read_h(ahB, bhB, 2 * pr + 1, 1, Acur, B);
-                mma_h(ahA, bhA);
-            }
-            if (pr == 2 && more_blocks && !(HOIG_F6_KO & 1)) halo_store(Anext);
-            __builtin_amdgcn_sched_barrier(0);
-            if (!(HOIG_F6_KO & 32)) __syncthreads();
-            // P3
-            if (more) read_f6(pr + 1 < NPAIR ? pr + 1 : 0, pr + 1 < NPAIR ? Acur : Anext, Bn);
-            if (pr < 4) mma_h(ahB, bhB);
-            else mma_h(ahA, bhA);
+    for (int step = 0; step < T; ++step) {
+        const int cb = step / 9, tap = step - cb * 9;
+        const bool more = step + 1 < T;
+        const bool boundary = more && tap == 8;
+        if (more && !(HOIG_F6_KO & 16)) store_b(bbuf ^ 1);   // weights of step+1 (registers loaded during the previous step)
+        if (step + 2 < T && !(HOIG_F6_KO & 16)) load_b(step + 2);
+        if (!(HOIG_F6_KO & 8)) {
+            if (tap == 7 && cb + 1 < ncb) halo_load(cb + 1, 0, hreg0);              // next block's halo: first half of the tasks ...
+            if (boundary) halo_load(cb + 1, 1, hreg1);                               // ... second half
         }
+        compute(tap, bbuf);
+        if (boundary && !(HOIG_F6_KO & 1)) {
+            __syncthreads();                              // every wave is done with the halo
+            halo_store(0, hreg0);
+            halo_store(1, hreg1);
+        }
+        if (!(HOIG_F6_KO & 32)) __syncthreads();
+        bbuf ^= 1;
     }
 
     const float nslope = p.act == HOIG_ACT_NONE ? 1.f : (p.act == HOIG_ACT_RELU ? 0.f : p.slope);
@@ -453,13 +395,13 @@ int g_f6_min_tiles = 192;
 }  // namespace
 
 extern "C" int64_t hoig_f6_plane_bytes(int Co, int RS, int Ci) {
-    if (Co <= 0 || RS != 9 || Ci <= 0 || (Ci & 31)) return 0;
-    return (int64_t)NPAIR * (Ci >> 5) * Co * REC;
+    if (Co <= 0 || RS <= 0 || Ci <= 0 || (Ci & 63)) return 0;
+    return (int64_t)RS * (Ci >> 6) * Co * REC;
 }
 
 extern "C" int hoig_pack_conv_weight_f6(const float *w, int Co, int RS, int Ci, uint8_t *q_hi, uint8_t *q_lo, hoig_stream_t stream) {
     if (!w || !q_hi || !q_lo || Co <= 0 || RS <= 0) return HOIG_EINVAL;
-    if ((Ci & 31) || RS != 9) return HOIG_EUNSUPPORTED;
+    if (Ci & 63) return HOIG_EUNSUPPORTED;
     const int64_t n = (int64_t)Co * RS * (Ci >> 5);
     pack_f6_kernel<<<hoig_stream_grid(n, 256), 256, 0, (hipStream_t)stream>>>(w, Co, RS, Ci, q_hi, q_lo);
     HOIG_LAUNCH_CHECK();
@@ -486,27 +428,17 @@ static int launch_f6(const hoig_conv_desc *d, const float *x, const float *x2, i
     a.nblk_n = a.N / (n64 ? 64 : 128);
     a.nblk = ptiles * a.nblk_n;
     if (a.nblk < g_f6_min_tiles) return HOIG_EUNSUPPORTED;
-    static const int wn_env = getenv("HOIG_F6_WN") ? atoi(getenv("HOIG_F6_WN")) : 2;
     static bool once = false;
     if (!once) {
-        if (hipFuncSetAttribute(reinterpret_cast<const void *>(&conv_halo3_f6_kernel<128, 2>), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                BTile<128, 2>::SMEM) != hipSuccess ||
-            hipFuncSetAttribute(reinterpret_cast<const void *>(&conv_halo3_f6_kernel<128, 1>), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                BTile<128, 1>::SMEM) != hipSuccess ||
-            hipFuncSetAttribute(reinterpret_cast<const void *>(&conv_halo3_f6_kernel<64, 1>), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                BTile<64, 1>::SMEM) != hipSuccess ||
-            hipFuncSetAttribute(reinterpret_cast<const void *>(&conv_halo3_f6_kernel<64, 2>), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                BTile<64, 2>::SMEM) != hipSuccess)
+        if (hipFuncSetAttribute(reinterpret_cast<const void *>(&conv_halo3_f6_kernel<128>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                BTile<128>::SMEM) != hipSuccess ||
+            hipFuncSetAttribute(reinterpret_cast<const void *>(&conv_halo3_f6_kernel<64>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                BTile<64>::SMEM) != hipSuccess)
             return HOIG_ELAUNCH;
         once = true;
     }
-    if (n64) {
-        if (wn_env == 1) conv_halo3_f6_kernel<64, 1><<<a.nblk, 256, BTile<64, 1>::SMEM, st>>>(a);
-        else conv_halo3_f6_kernel<64, 2><<<a.nblk, 512, BTile<64, 2>::SMEM, st>>>(a);
-    } else {
-        if (wn_env == 1) conv_halo3_f6_kernel<128, 1><<<a.nblk, 256, BTile<128, 1>::SMEM, st>>>(a);
-        else conv_halo3_f6_kernel<128, 2><<<a.nblk, 512, BTile<128, 2>::SMEM, st>>>(a);
-    }
+    if (n64) conv_halo3_f6_kernel<64><<<a.nblk, NT, BTile<64>::SMEM, st>>>(a);
+    else conv_halo3_f6_kernel<128><<<a.nblk, NT, BTile<128>::SMEM, st>>>(a);
     HOIG_LAUNCH_CHECK();
     return HOIG_OK;
 }

@@ -1,7 +1,8 @@
 #!/bin/bash
-# Builds (here) / runs (on the GPU box) the knock-out variants of the fp6 forward kernel.  usage: f6_knockout.sh build|run
+# Builds (here) / runs (on the GPU box) the knock-out variants of the fp6 forward kernel.
+# usage: [KOS="0 57 ..."] f6_knockout.sh build | run [batch] [0 = zero operands]
 cd "$(dirname "$0")/.."
-KOS=${KOS:-"0 57 63 121 123 125"}
+KOS=${KOS:-"0 1 9 25 57"}
 if [ "$1" = build ]; then
   for k in $KOS; do
     /opt/rocm/bin/hipcc -O3 -std=c++17 --offload-arch=gfx950 -DHOIG_F6_KO=$k -DHOIG_F6_KO_VALUE=$k -Iinclude -Ihoig_amd/csrc -Wno-unused-result \
@@ -9,6 +10,5 @@ if [ "$1" = build ]; then
   done
   wait
 else
-  for k in $KOS; do tools/_build/f6_ko_$k 16; done
-  tools/_build/f6_ko_0 8
+  for k in $KOS; do tools/_build/f6_ko_$k ${2:-16} ${3:-1}; done
 fi
