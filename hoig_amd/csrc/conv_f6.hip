@@ -30,6 +30,12 @@
 #ifndef HOIG_F6_KO
 #define HOIG_F6_KO 0
 #endif
+// 1: the weight stages go global -> LDS by LDS-DMA (global_load_lds_dwordx4; no staging registers, no ds_write); 0: through
+// registers, one step ahead.  Both are parity-tested; measured on the dominant launch 170.4 us (DMA) against 164.3 us (registers),
+// 117.5 against 113.6 us at 8 images (profiles/r02_f6_knockout.txt): the 28 us that staging costs are not the registers' doing.
+#ifndef HOIG_F6_DMA
+#define HOIG_F6_DMA 0
+#endif
 
 namespace {
 
@@ -217,6 +223,29 @@ __global__ __launch_bounds__(NT) void conv_halo3_f6_kernel(const F6Args p) {
             rbq1 = *reinterpret_cast<const uint4 *>(p.Ql + rec0 + (size_t)tid * 16);
         }
     };
+    // The same stage by LDS-DMA: the fp16 planes are stored in HBM in exactly the LDS image (plane_index carries the XOR), so a
+    // 32-row x 32-k block is 2 KB contiguous on both sides, and so are the record arrays: lane t moves bytes [16 t, 16 t + 16) of
+    // each piece; a wave-instruction fills 1 KB of LDS at M0 = the wave's uniform base.  Issued at the top of step s for stage
+    // s + 1, awaited (vmcnt) before the barrier that ends step s.
+    auto dma_b = [&](int step, int buf) {
+        const int cb = step / 9, tap = step - cb * 9;
+        const size_t koff = (size_t)(tap * p.Cg + cb * 64) * 32;
+        const size_t rec0 = ((size_t)(tap * ncb + cb) * p.N + n0) * REC;
+        unsigned char *B = Bbase + buf * B_STAGE + wave * 1024;
+        typedef const __attribute__((address_space(1))) void *gptr;
+        typedef __attribute__((address_space(3))) void *lptr;
+        if (wave * 16 < BN) {                                   // 16 rows of 64 B per wave-instruction
+            const unsigned short *src = p.Wh + ((size_t)((n0 >> 5) + (tid >> 7)) * (p.K >> 5)) * 1024 + koff + (tid & 127) * 8;
+            __builtin_amdgcn_global_load_lds((gptr)src, (lptr)B, 16, 0, 0);
+            __builtin_amdgcn_global_load_lds((gptr)(src + 1024), (lptr)(B + BN * 64), 16, 0, 0);
+        }
+        if (wave * 1024 < B_Q) {                                // 7168 B = 7 wave-instructions per record array (BN = 64: 3.5)
+            if (tid < QCHUNKS) {
+                __builtin_amdgcn_global_load_lds((gptr)(p.Qh + rec0 + (size_t)tid * 16), (lptr)(B + B_HI), 16, 0, 0);
+                __builtin_amdgcn_global_load_lds((gptr)(p.Ql + rec0 + (size_t)tid * 16), (lptr)(B + B_HI + B_Q), 16, 0, 0);
+            }
+        }
+    };
     auto store_b = [&](int buf) {
         unsigned char *B = Bbase + buf * B_STAGE;
         if (bload) {
@@ -337,11 +366,15 @@ __global__ __launch_bounds__(NT) void conv_halo3_f6_kernel(const F6Args p) {
 
     halo_load(0, 0, hreg0);
     halo_load(0, 1, hreg1);
-    load_b(0);
+    if (HOIG_F6_DMA) dma_b(0, 0);
+    else load_b(0);
     halo_store(0, hreg0);
     halo_store(1, hreg1);
-    store_b(0);
-    if (T > 1) load_b(1);
+    if (HOIG_F6_DMA) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    else {
+        store_b(0);
+        if (T > 1) load_b(1);
+    }
     __syncthreads();
     int bbuf = 0;
 #pragma unroll 1
@@ -349,8 +382,12 @@ __global__ __launch_bounds__(NT) void conv_halo3_f6_kernel(const F6Args p) {
         const int cb = step / 9, tap = step - cb * 9;
         const bool more = step + 1 < T;
         const bool boundary = more && tap == 8;
-        if (more && !(HOIG_F6_KO & 16)) store_b(bbuf ^ 1);   // weights of step+1 (registers loaded during the previous step)
-        if (step + 2 < T && !(HOIG_F6_KO & 16)) load_b(step + 2);
+        if (HOIG_F6_DMA) {
+            if (more && !(HOIG_F6_KO & 16)) dma_b(step + 1, bbuf ^ 1);          // stage s + 1: free since the previous barrier
+        } else {
+            if (more && !(HOIG_F6_KO & 16)) store_b(bbuf ^ 1);   // weights of step+1 (registers loaded during the previous step)
+            if (step + 2 < T && !(HOIG_F6_KO & 16)) load_b(step + 2);
+        }
         if (!(HOIG_F6_KO & 8)) {
             if (tap == 7 && cb + 1 < ncb) halo_load(cb + 1, 0, hreg0);              // next block's halo: first half of the tasks ...
             if (boundary) halo_load(cb + 1, 1, hreg1);                               // ... second half
@@ -361,6 +398,7 @@ __global__ __launch_bounds__(NT) void conv_halo3_f6_kernel(const F6Args p) {
             halo_store(0, hreg0);
             halo_store(1, hreg1);
         }
+        if (HOIG_F6_DMA) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // stage s + 1 has landed (and this wave's halo loads)
         if (!(HOIG_F6_KO & 32)) __syncthreads();
         bbuf ^= 1;
     }
