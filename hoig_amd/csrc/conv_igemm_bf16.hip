@@ -15,6 +15,13 @@
 // exact-fp32 kernels of conv_igemm.hip.
 #include "common.h"
 #include <cstdlib>
+
+// tools/wgrad_knockout.cpp builds this file with HOIG_WG_KO != 0 to time wgrad_halo_bf16_kernel with parts removed (results are
+// then wrong): 1 no hi/lo split (bit moves only), 2 no global loads after the first tile, 4 no LDS stores after the first tile,
+// 8 no atomic epilogue, 16 no LDS fragment reads (MFMAs on register garbage), 32 no MFMAs of the lo plane
+#ifndef HOIG_WG_KO
+#define HOIG_WG_KO 0
+#endif
 #ifndef HOIG_HALO_BSTAGES
 #define HOIG_HALO_BSTAGES 1
 #endif
@@ -2083,7 +2090,12 @@ __global__ __launch_bounds__(128 * KS * CM) void wgrad_halo_bf16_kernel(const WH
             const int idx = tid + NT * i;
             if (idx < TH * TW * C4) {
                 uint2 hi, lo;
-                split4(rp[i], hi, lo);
+                if (HOIG_WG_KO & 1) {
+                    hi = make_uint2(__float_as_uint(rp[i].x) >> 16 | (__float_as_uint(rp[i].y) & 0xffff0000u),
+                                    __float_as_uint(rp[i].z) >> 16 | (__float_as_uint(rp[i].w) & 0xffff0000u));
+                    lo = make_uint2(0u, 0u);
+                } else
+                    split4(rp[i], hi, lo);
                 const int off = (idx / C4) * PSTR + (idx % C4) * 8;
                 *reinterpret_cast<uint2 *>(Ph + off) = hi;
                 if (NS == 2) *reinterpret_cast<uint2 *>(Pl + off) = lo;
@@ -2094,7 +2106,12 @@ __global__ __launch_bounds__(128 * KS * CM) void wgrad_halo_bf16_kernel(const WH
             const int idx = tid + NT * i;
             if (idx < HPIX * 8) {
                 uint2 hi, lo;
-                split4(rq[i], hi, lo);
+                if (HOIG_WG_KO & 1) {
+                    hi = make_uint2(__float_as_uint(rq[i].x) >> 16 | (__float_as_uint(rq[i].y) & 0xffff0000u),
+                                    __float_as_uint(rq[i].z) >> 16 | (__float_as_uint(rq[i].w) & 0xffff0000u));
+                    lo = make_uint2(0u, 0u);
+                } else
+                    split4(rq[i], hi, lo);
                 int st = idx * 8;
                 if (S2) {
                     const int hp = idx >> 3, hy = hp / HWID, hx = hp - hy * HWID;
@@ -2145,19 +2162,28 @@ __global__ __launch_bounds__(128 * KS * CM) void wgrad_halo_bf16_kernel(const WH
     __syncthreads();
     for (int mt = mt_begin; mt < mt_end; ++mt) {
         const bool nxt = mt + 1 < mt_end;
-        if (nxt) load_tiles(mt + 1);
+        if (nxt && !(HOIG_WG_KO & 2)) load_tiles(mt + 1);
         WSTAMP(w_issue)
 #pragma unroll
         for (int kk = 0; kk < TH * 2; ++kk) {              // 16 consecutive pixels of one tile row per k-step
             const int prow0 = kk * 16;
             const int qrow0 = S2 ? (kk & 1) * 16 : (kk >> 1) * HWID + (kk & 1) * 16;
-            bf16x8 ah = frag(Ph + trP + prow0 * PSTR, 4 * PSTR), al;
-            if (NS == 2) al = frag(Pl + trP + prow0 * PSTR, 4 * PSTR);
+            bf16x8 ah, al;
+            if (HOIG_WG_KO & 16) {
+                for (int q = 0; q < 8; ++q) { ah[q] = (short)(0x3f80 + lane + q); al[q] = (short)(0x3c00 + lane * 3 + q); }
+            } else {
+                ah = frag(Ph + trP + prow0 * PSTR, 4 * PSTR);
+                if (NS == 2) al = frag(Pl + trP + prow0 * PSTR, 4 * PSTR);
+            }
 #pragma unroll
             for (int t = 0; t < KS; ++t) {
                 const int qoff = trQ + (S2 ? ((2 * (kk >> 1) + tr) * 2 + (t & 1)) * HWP + qrow0 + (t >> 1) : qrow0 + t) * QSTR;
-                const bf16x8 bh = frag(Qh + qoff, 4 * QSTR);
-                if (NS == 2) acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, bh, acc[t], 0, 0, 0);
+                bf16x8 bh;
+                if (HOIG_WG_KO & 16) {
+                    for (int q = 0; q < 8; ++q) bh[q] = (short)(0x3f00 + lane * 5 + q + t);
+                } else
+                    bh = frag(Qh + qoff, 4 * QSTR);
+                if (NS == 2 && !(HOIG_WG_KO & 32)) acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, bh, acc[t], 0, 0, 0);
                     if (NB == 2) {
                     const bf16x8 bl = frag(Ql + qoff, 4 * QSTR);
                     acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bl, acc[t], 0, 0, 0);
@@ -2168,7 +2194,7 @@ __global__ __launch_bounds__(128 * KS * CM) void wgrad_halo_bf16_kernel(const WH
         WSTAMP(w_comp)
         __syncthreads();                      // every wave is done reading the stage
         WSTAMP(w_b1)
-        if (nxt) store_tiles();
+        if (nxt && !(HOIG_WG_KO & 4)) store_tiles();
         WSTAMP(w_st)
         __syncthreads();
         WSTAMP(w_b2)
@@ -2190,6 +2216,7 @@ __global__ __launch_bounds__(128 * KS * CM) void wgrad_halo_bf16_kernel(const WH
         if (tid < BM) atomicAdd(&p.DB[c0 + tid], red[tid]);
     }
     const int l31 = lane & 31, lh = lane >> 5;
+    if ((HOIG_WG_KO & 8) && acc[0][0] != 12345.f) return;
     if (!p.tout) {
         const int K = KS * KS * p.Ci;
 #pragma unroll
