@@ -2164,31 +2164,54 @@ __global__ __launch_bounds__(128 * KS * CM) void wgrad_halo_bf16_kernel(const WH
         const bool nxt = mt + 1 < mt_end;
         if (nxt && !(HOIG_WG_KO & 2)) load_tiles(mt + 1);
         WSTAMP(w_issue)
-#pragma unroll
-        for (int kk = 0; kk < TH * 2; ++kk) {              // 16 consecutive pixels of one tile row per k-step
+        // the fragments of k-step kk + 1 are read before the MFMAs of k-step kk are issued (fences: the compiler would sink the reads
+        // below the MFMAs to shorten live ranges, and every k-step would then start with an exposed LDS round trip)
+        struct KFrag { bf16x8 ah, al, bh[KS], bl[KS]; };
+        auto read_k = [&](KFrag &f, int kk) {
             const int prow0 = kk * 16;
             const int qrow0 = S2 ? (kk & 1) * 16 : (kk >> 1) * HWID + (kk & 1) * 16;
-            bf16x8 ah, al;
             if (HOIG_WG_KO & 16) {
-                for (int q = 0; q < 8; ++q) { ah[q] = (short)(0x3f80 + lane + q); al[q] = (short)(0x3c00 + lane * 3 + q); }
-            } else {
-                ah = frag(Ph + trP + prow0 * PSTR, 4 * PSTR);
-                if (NS == 2) al = frag(Pl + trP + prow0 * PSTR, 4 * PSTR);
+                for (int q = 0; q < 8; ++q) { f.ah[q] = (short)(0x3f80 + lane + q); f.al[q] = (short)(0x3c00 + lane * 3 + q); }
+                for (int t = 0; t < KS; ++t)
+                    for (int q = 0; q < 8; ++q) f.bh[t][q] = f.bl[t][q] = (short)(0x3f00 + lane * 5 + q + t);
+                return;
             }
+            f.ah = frag(Ph + trP + prow0 * PSTR, 4 * PSTR);
+            if (NS == 2) f.al = frag(Pl + trP + prow0 * PSTR, 4 * PSTR);
 #pragma unroll
             for (int t = 0; t < KS; ++t) {
                 const int qoff = trQ + (S2 ? ((2 * (kk >> 1) + tr) * 2 + (t & 1)) * HWP + qrow0 + (t >> 1) : qrow0 + t) * QSTR;
-                bf16x8 bh;
-                if (HOIG_WG_KO & 16) {
-                    for (int q = 0; q < 8; ++q) bh[q] = (short)(0x3f00 + lane * 5 + q + t);
-                } else
-                    bh = frag(Qh + qoff, 4 * QSTR);
-                if (NS == 2 && !(HOIG_WG_KO & 32)) acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, bh, acc[t], 0, 0, 0);
-                    if (NB == 2) {
-                    const bf16x8 bl = frag(Ql + qoff, 4 * QSTR);
-                    acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bl, acc[t], 0, 0, 0);
-                }
-                acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bh, acc[t], 0, 0, 0);
+                f.bh[t] = frag(Qh + qoff, 4 * QSTR);
+                if (NB == 2) f.bl[t] = frag(Ql + qoff, 4 * QSTR);
+            }
+        };
+        auto mma_k = [&](const KFrag &f) {
+#pragma unroll
+            for (int t = 0; t < KS; ++t) {
+                if (NS == 2 && !(HOIG_WG_KO & 32)) acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f.al, f.bh[t], acc[t], 0, 0, 0);
+                if (NB == 2) acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f.ah, f.bl[t], acc[t], 0, 0, 0);
+                acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f.ah, f.bh[t], acc[t], 0, 0, 0);
+            }
+        };
+        constexpr bool AHEAD = KS == 3 && NB == 1;         // (5x5, and x split too: two fragment sets do not fit the registers)
+        KFrag f0, f1;
+        if (AHEAD) read_k(f0, 0);
+#pragma unroll
+        for (int kk = 0; kk < TH * 2; kk += 2) {           // 16 consecutive pixels of one tile row per k-step
+            if (AHEAD) {
+                read_k(f1, kk + 1);
+                __builtin_amdgcn_sched_barrier(0);
+                mma_k(f0);
+                __builtin_amdgcn_sched_barrier(0);
+                if (kk + 2 < TH * 2) read_k(f0, kk + 2);
+                __builtin_amdgcn_sched_barrier(0);
+                mma_k(f1);
+                __builtin_amdgcn_sched_barrier(0);
+            } else {
+                read_k(f0, kk);
+                mma_k(f0);
+                read_k(f0, kk + 1);
+                mma_k(f0);
             }
         }
         WSTAMP(w_comp)
