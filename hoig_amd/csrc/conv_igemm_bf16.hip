@@ -2021,10 +2021,12 @@ struct WHaloArgs {
 // stored split by COLUMN PARITY -- row index ((hy * 2 + (hx & 1)) * 33 + (hx >> 1)) -- so that tap (r, s) reads sixteen
 // consecutive output pixels at sixteen consecutive rows again (parity s & 1, first row (s >> 1)): the transpose reads stay
 // unit-stride and conflict-free, exactly as for stride 1.
-template <int NSX, int KS, int CM, bool S2 = false>
+// TH_ = 4: pixel tiles of 4 x 32 (one workgroup per CU, 94 KB of dynamic LDS): half the barriers, staging rounds and read ramps per
+// MFMA, and a 6-row halo for 4 rows instead of two 4-row halos.
+template <int NSX, int KS, int CM, bool S2 = false, int TH_ = 2>
 __global__ __launch_bounds__(128 * KS * CM) void wgrad_halo_bf16_kernel(const WHaloArgs p) {
     constexpr int NS = NSX == 1 ? 1 : 2, NB = NSX == 2 ? 2 : 1;      // operand planes: A (activations / dy), B (weights / x)
-    constexpr int TH = 2, TW = 32, BM = 64 * CM, BC = 32, NT = 128 * KS * CM;
+    constexpr int TH = TH_, TW = 32, BM = 64 * CM, BC = 32, NT = 128 * KS * CM;
     constexpr int CQ = 2 * CM, C4 = 16 * CM;               // 32-channel groups / float4s of a dy pixel row
     constexpr int SD = S2 ? 2 : 1;
     constexpr int HH = SD * (TH - 1) + KS, HWID = SD * (TW - 1) + KS, HPIX = HH * HWID;     // 4 x 34 (stride 2: 5 x 65) halo pixels
@@ -2032,7 +2034,10 @@ __global__ __launch_bounds__(128 * KS * CM) void wgrad_halo_bf16_kernel(const WH
     constexpr int HROWS = S2 ? HH * 2 * HWP : HPIX;        // rows of the LDS halo image
     constexpr int PSTR = 128 * CM + 64, QSTR = 64;         // (192 / 320 B: four consecutive rows cover the 64 banks once)
     constexpr int PLANE_P = TH * TW * PSTR, PLANE_Q = ((HROWS * QSTR + 255) / 256) * 256;
-    __shared__ __attribute__((aligned(16))) unsigned char smem[NS * PLANE_P + NB * PLANE_Q];
+    constexpr int LDS_BYTES = NS * PLANE_P + NB * PLANE_Q;
+    __shared__ __attribute__((aligned(16))) unsigned char smem_static[TH_ > 2 ? 16 : LDS_BYTES];
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_dynamic[];
+    unsigned char *smem = TH_ > 2 ? smem_dynamic : smem_static;
     unsigned char *Ph = smem, *Pl = smem + PLANE_P;
     unsigned char *Qh = smem + NS * PLANE_P, *Ql = Qh + PLANE_Q;
 
@@ -2186,12 +2191,17 @@ __global__ __launch_bounds__(128 * KS * CM) void wgrad_halo_bf16_kernel(const WH
             }
         };
         auto mma_k = [&](const KFrag &f) {
+            // term-major: the KS accumulators take turns, so no MFMA waits on the one issued just before it
+            if (NS == 2 && !(HOIG_WG_KO & 32)) {
 #pragma unroll
-            for (int t = 0; t < KS; ++t) {
-                if (NS == 2 && !(HOIG_WG_KO & 32)) acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f.al, f.bh[t], acc[t], 0, 0, 0);
-                if (NB == 2) acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f.ah, f.bl[t], acc[t], 0, 0, 0);
-                acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f.ah, f.bh[t], acc[t], 0, 0, 0);
+                for (int t = 0; t < KS; ++t) acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f.al, f.bh[t], acc[t], 0, 0, 0);
             }
+            if (NB == 2) {
+#pragma unroll
+                for (int t = 0; t < KS; ++t) acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f.ah, f.bl[t], acc[t], 0, 0, 0);
+            }
+#pragma unroll
+            for (int t = 0; t < KS; ++t) acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f.ah, f.bh[t], acc[t], 0, 0, 0);
         };
         constexpr bool AHEAD = KS == 3 && NB == 1;         // (5x5, and x split too: two fragment sets do not fit the registers)
         KFrag f0, f1;
@@ -2295,13 +2305,17 @@ int launch_wgrad_halo(const hoig_conv_desc *d, const float *x, const float *dy, 
         a.tout = 1;
     }
     const bool s2 = d->stride == 2;
-    a.tiles_x = a.W / 32;
-    a.tiles_y = a.H / 2;
-    a.n_mtiles = a.Bn * a.tiles_x * a.tiles_y;
     a.nblk_ci = a.Ci / 32;
     static const int cm_env = getenv("HOIG_WGRAD_HALO_CM") ? atoi(getenv("HOIG_WGRAD_HALO_CM")) : 2;
     const int cm = (d->R == 3 && cm_env == 2 && a.Co % 128 == 0) ? 2 : 1;      // (a.Co: channels of the plain operand)
     a.nblk = (a.Co / (64 * cm)) * a.nblk_ci;
+    // 4-row pixel tiles for the stride-1 3x3 layers on 128-channel workgroups, where every workgroup still gets >= 8 of them
+    static const int th_env = getenv("HOIG_WGRAD_HALO_TH") ? atoi(getenv("HOIG_WGRAD_HALO_TH")) : 4;
+    const bool th4 = th_env == 4 && cm == 2 && d->R == 3 && !s2 && !d->transposed && ns != 2 && a.H % 4 == 0 &&
+                     (int64_t)a.Bn * (a.W / 32) * (a.H / 4) * a.nblk >= 8 * 256;
+    a.tiles_x = a.W / 32;
+    a.tiles_y = a.H / (th4 ? 4 : 2);
+    a.n_mtiles = a.Bn * a.tiles_x * a.tiles_y;
     static const int target_blocks = getenv("HOIG_WGRAD_HALO_BLOCKS") ? atoi(getenv("HOIG_WGRAD_HALO_BLOCKS")) : 512;
     // 5x5: a workgroup owns 25 taps x 64 x 32 outputs, so every pixel split costs 2.8x the atomics of a 3x3 one: 256 (measured)
     int splits = (int)hoig_cdiv((d->R == 5 ? target_blocks / 2 : target_blocks) / cm, a.nblk);
@@ -2313,7 +2327,20 @@ int launch_wgrad_halo(const hoig_conv_desc *d, const float *x, const float *dy, 
 #ifdef HOIG_STAMP
     a.dbg = g_stamp_buf;
 #endif
-    if (s2 && cm == 2) HOIG_NS_SWITCH(ns, wgrad_halo_bf16_kernel<NSX, 3, 2, true><<<grid, 768, 0, st>>>(a));
+    if (th4) {
+        constexpr int LDS4 = 2 * (4 * 32 * 320) + (((6 * 34 * 64) + 255) / 256) * 256;      // dy hi, lo | x hi
+        static bool once = false;
+        if (!once) {
+            if (hipFuncSetAttribute(reinterpret_cast<const void *>(&wgrad_halo_bf16_kernel<1, 3, 2, false, 4>),
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, LDS4) != hipSuccess ||
+                hipFuncSetAttribute(reinterpret_cast<const void *>(&wgrad_halo_bf16_kernel<3, 3, 2, false, 4>),
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, LDS4) != hipSuccess)
+                return HOIG_ELAUNCH;
+            once = true;
+        }
+        if (ns == 3) wgrad_halo_bf16_kernel<3, 3, 2, false, 4><<<grid, 768, LDS4, st>>>(a);
+        else wgrad_halo_bf16_kernel<1, 3, 2, false, 4><<<grid, 768, LDS4, st>>>(a);
+    } else if (s2 && cm == 2) HOIG_NS_SWITCH(ns, wgrad_halo_bf16_kernel<NSX, 3, 2, true><<<grid, 768, 0, st>>>(a));
     else if (s2) HOIG_NS_SWITCH(ns, wgrad_halo_bf16_kernel<NSX, 3, 1, true><<<grid, 384, 0, st>>>(a));
     else if (d->R == 5) HOIG_NS_SWITCH(ns, wgrad_halo_bf16_kernel<NSX, 5, 1><<<grid, 640, 0, st>>>(a));
     else if (cm == 2) HOIG_NS_SWITCH(ns, wgrad_halo_bf16_kernel<NSX, 3, 2><<<grid, 768, 0, st>>>(a));
