@@ -10,7 +10,7 @@ import torch
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
-from hoig_amd._lib import ConvDesc, ACT_NONE, PREC_BF16X3      # noqa: E402 (structure layout only)
+from hoig_amd._lib import ConvDesc, ACT_NONE, PREC_BF16X3, PREC_F16X2      # noqa: E402 (structure layout only)
 
 B = int(sys.argv[1]) if len(sys.argv) > 1 else 16
 level = sys.argv[2] if len(sys.argv) > 2 else '1'
@@ -21,8 +21,9 @@ dy = torch.randn(B, H, H, C, device='cuda')
 dw = torch.zeros(C, 3, 3, C, device='cuda')
 st = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
 vp = ctypes.c_void_p
-d = ConvDesc(B, H, H, C, H, H, C, 3, 3, 1, 1, 0, ACT_NONE, 0.0, PREC_BF16X3)
-nwg, waves = (C // 64) * (C // 32) * 4, 6
+prec = PREC_BF16X3 if len(sys.argv) > 3 and sys.argv[3] == 'x3' else PREC_F16X2          # the shipped weight-gradient arithmetic: two terms
+d = ConvDesc(B, H, H, C, H, H, C, 3, 3, 1, 1, 0, ACT_NONE, 0.0, prec)
+nwg, waves = 4096, 16                                   # (an upper bound: unstamped rows stay zero and are dropped)
 dbg = torch.zeros(nwg * waves * 8, dtype=torch.int64, device='cuda')
 
 
@@ -52,5 +53,8 @@ print('B=%d: %.1f us per launch (%.0f TF/s); %d stamped waves; kernel cycles per
          np.median(t[:, 6] / t[:, 7]) * 0.1))
 for i, n in enumerate(['issue', 'compute', 'barrier1', 'publish', 'barrier2']):
     print('  %-9s %5.1f %% of the loop' % (n, 100 * np.median(t[:, i] / t[:, 5])))
-mt = B * (H // 2) // 4
-print('  per pixel tile: %.0f cycles per wave; MFMA floor per SIMD with 18 waves per CU: %d' % (np.median(t[:, 5]) / mt, 36 * 32 * 18 // 4))
+th = int(os.environ.get('HOIG_WGRAD_HALO_TH', '4'))
+mt = B * (H // th) // 4                                 # pixel tiles per workgroup (four pixel splits)
+nm = (2 if prec == PREC_F16X2 else 3) * 3 * 2 * th     # MFMAs per wave and pixel tile
+print('  per pixel tile: %.0f cycles per wave; %d MFMAs per wave and tile = %d cycles per SIMD with 12 waves per CU'
+      % (np.median(t[:, 5]) / mt, nm, nm * 32 * 3))
