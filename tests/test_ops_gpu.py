@@ -486,6 +486,51 @@ def test_conv_over_two_tensors_equals_conv_of_cat(B, C1, C2, Co, H, W):
     assert rel_err(wa.grad, wb.grad) < 1e-5
 
 
+@pytest.mark.parametrize('B,C1,C2,Co,H,W', [
+    (8, 512, 0, 256, 16, 64),        # two tile columns
+    (8, 512, 0, 512, 20, 32),        # five tile rows: ten tiles per workgroup
+    (8, 256, 256, 256, 32, 32),      # the decoder's skip convolution: x is [skip | up]
+    (8, 512, 0, 512, 18, 32)])       # H % 4 != 0: stays on 2-row tiles
+def test_wgrad_four_row_tiles(B, C1, C2, Co, H, W):
+    """Weight (and bias) gradient of 3x3 stride-1 layers in the two-term arithmetic on wgrad_halo_bf16_kernel<.., TH = 4> (4 x 32
+    pixel tiles, dynamic LDS; launch_wgrad_halo picks it when every workgroup keeps >= 8 tiles) against torch fp32 at the f16x2
+    bound, on maps whose tile grid is not square / not a power of two, and over a two-tensor input."""
+    ops = _ops()
+    from hoig_amd import _lib as L
+    g = torch.Generator().manual_seed(41)
+    Ci = C1 + C2
+    x = torch.randn(B, Ci, H, W, generator=g)
+    w = torch.randn(Co, Ci, 3, 3, generator=g) * 0.05
+    bias = torch.randn(Co, generator=g)
+    xr, wr, br = x.clone().requires_grad_(True), w.clone().requires_grad_(True), bias.clone().requires_grad_(True)
+    yr = F.conv2d(xr, wr, br, stride=1, padding=1)
+    gy = torch.randn(yr.shape, generator=g)
+    yr.backward(gy)
+    ops.set_precision('f16x2')
+    try:
+        wd = ops.pack_weight(w.cuda()).requires_grad_(True)
+        bd = bias.cuda().requires_grad_(True)
+        if C2:
+            xn = nhwc_cuda(x)
+            x1, x2 = xn[..., :C1].contiguous().requires_grad_(True), xn[..., C1:].contiguous().requires_grad_(True)
+            y = ops.conv2d_cat2(x1, x2, wd) + bd
+        else:
+            xd = nhwc_cuda(x).requires_grad_(True)
+            y = ops.conv2d(xd, wd, bd, 1, 1)
+        y.backward(nhwc_cuda(gy))
+    finally:
+        ops.set_precision('f32')
+    bf, bdg, bw = PREC_BOUNDS['f16x2']
+    assert rel_err(nchw_cpu(y), yr) < bf
+    assert rel_err(wd.grad, wr.grad) < bw
+    assert rel_err(bd.grad.cpu(), br.grad) < 1e-4
+    if C2:
+        dx = torch.cat([x1.grad, x2.grad], -1)
+    else:
+        dx = xd.grad
+    assert rel_err(nchw_cpu(dx), xr.grad) < bdg
+
+
 @pytest.mark.parametrize('B,Ci,Co,H,bias,min_tiles,runs_f6', [
     (16, 512, 512, 32, False, 192, True),       # the dominant launch of the step: 128-channel tiles
     (8, 512, 512, 32, False, 192, True),        # src_model / tsf_model: 64-channel tiles (twice the workgroups)
