@@ -163,3 +163,20 @@ def test_eval_writer_matches_reference_layout(tmp_path):
     assert len(crops_of(vis['14_batch_real_img'], B, side)) == B
     with pytest.raises(ValueError):
         crops_of(vis['14_batch_real_img'], rows * nrow + 1, side)
+
+
+def test_bench_refuses_mislabelled_multi_gpu_runs():
+    """bench.py --gpus N must never report a smaller job under the N-GPU label (`--gpus 8` ran one rank):
+    with fewer visible GPUs than N it exits 2 before any GPU call; under a launcher whose WORLD_SIZE differs from N it errors."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ('WORLD_SIZE', 'RANK', 'LOCAL_RANK')}
+    r = subprocess.run([sys.executable, os.path.join(root, 'bench.py'), '--gpus', '2', '--steps', '1', '--warmup', '0'],
+                       env=env, capture_output=True, text=True, timeout=300)
+    assert r.returncode == 2 and 'refusing' in r.stderr + r.stdout
+    assert not (r.stdout.strip().startswith('{'))                       # no JSON line for a job that did not run
+    env.update(WORLD_SIZE='4', RANK='0', LOCAL_RANK='0')
+    r = subprocess.run([sys.executable, os.path.join(root, 'bench.py'), '--gpus', '2', '--steps', '1', '--warmup', '0'],
+                       env=env, capture_output=True, text=True, timeout=300)
+    assert r.returncode != 0 and 'WORLD_SIZE=4' in r.stderr + r.stdout
