@@ -189,7 +189,7 @@ class ParamTree(nn.Module):
                 continue
             nbytes = L.lib.hoig_f6_plane_bytes(co, 9, ci)
             rows.append([off, co, 9, ci, byte_off, task0])
-            where[off] = (byte_off, nbytes)
+            where[off] = (byte_off, nbytes, (co, ci))
             byte_off += (nbytes + 255) // 256 * 256
             task0 += co * 9 * (ci // 32)
         return rows, byte_off, task0, where
@@ -224,7 +224,9 @@ class ParamTree(nn.Module):
         f = self._refresh_f6()
         if f['table'] is None or off not in f['where']:
             return None
-        a, n = f['where'][off]
+        a, n, shp = f['where'][off]
+        if tuple(w.shape[:2]) != shp:                 # (mlp_gamma alone starts where the fused gamma|beta weight does)
+            return None
         return f['bufs'][0][a:a + n], f['bufs'][1][a:a + n]
 
     def set_pending(self, event):

@@ -224,3 +224,45 @@ def test_visuals_match_reference_golden():
             d = np.abs(v.astype(np.int16) - want.astype(np.int16))
             assert d.max() <= 1, (k, int(d.max()))
             assert (d > 0).mean() < 0.02, (k, float((d > 0).mean()))
+
+
+def test_batched_fp6_weight_records_equal_per_weight_packing():
+    """ParamTree.packed_f6 (hoig_pack_conv_weights_f6_all: every eligible 3x3 weight of the generator in ONE launch per weight
+    version, incl. the fused SPADE gamma|beta views) must produce byte for byte the records of the per-weight entry point
+    hoig_pack_conv_weight_f6, must cover exactly the 3x3 weights with Ci, Co multiples of 64, and must be re-made after an
+    optimiser step (new version) but not before."""
+    import ctypes
+    from hoig_amd import _lib as L
+    m = product_trainer('generator_spade_attn', 2, 64)
+    G = m._G
+    st = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+    checked = 0
+    weights = list(G.P.items()) + list(G.F.items())
+    for name, w in weights:
+        if w.dim() != 4:
+            continue
+        planes = G.packed_f6(w)
+        co, ci, r, s = w.shape
+        eligible = (r == 3 and s == 3 and ci % 64 == 0 and co % 64 == 0 and not getattr(w, '_hoig_transposed', False)
+                    and not (('.mlp_gamma.' in name or '.mlp_beta.' in name)
+                             and name.replace('.mlp_gamma.', '.mlp_gb.').replace('.mlp_beta.', '.mlp_gb.') in G.F))
+        assert (planes is not None) == eligible, name
+        if planes is None:
+            continue
+        n = L.lib.hoig_f6_plane_bytes(co, 9, ci)
+        qh = torch.empty(n, dtype=torch.uint8, device='cuda')
+        ql = torch.empty(n, dtype=torch.uint8, device='cuda')
+        rc = L.lib.hoig_pack_conv_weight_f6(ctypes.c_void_p(w.data_ptr()), co, 9, ci, ctypes.c_void_p(qh.data_ptr()),
+                                            ctypes.c_void_p(ql.data_ptr()), st)
+        assert rc == 0
+        assert planes[0].numel() == n and n % 56 == 0
+        for got, want in ((planes[0], qh), (planes[1], ql)):         # a record: 48 B of elements, 2 scale bytes, 6 B never written
+            assert torch.equal(got.view(-1, 56)[:, :50], want.view(-1, 56)[:, :50]), name
+        checked += 1
+    assert checked >= 20
+    name, w = next((k, v) for k, v in G.P.items() if v.dim() == 4 and G.packed_f6(v) is not None)
+    before = G.packed_f6(w)[1].clone()                    # (the residual's records: a 2e-4 step rarely moves the 4-bit hi ones)
+    m.optimize_parameters()                               # Adam moved the weights: new version -> new records on the next request
+    after = G.packed_f6(w)[1]
+    assert not torch.equal(before.view(-1, 56)[:, :50], after.view(-1, 56)[:, :50])
+    assert after.data_ptr() == G.packed_f6(w)[1].data_ptr()
