@@ -139,3 +139,32 @@ def test_config2_256_forward_and_step():
     del m, ot
     torch.cuda.empty_cache()
     _step_is_mean_of_halves(8, S, 'hov3')
+
+
+def test_bench_line_contract():
+    """bench.py's ONE JSON line (the driver's contract): the keys, the timed-step bookkeeping, the roofline object of the dominant
+    kernel measured live, and the gen-fwd leg -- on a short run (2 timed steps, no CPU-baseline child)."""
+    import json
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ('WORLD_SIZE', 'RANK', 'LOCAL_RANK')}
+    r = subprocess.run([sys.executable, os.path.join(root, 'bench.py'), '--steps', '2', '--warmup', '1', '--no-cpu-baseline',
+                        '--fwd-batch', '8'], env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith('{')]
+    assert len(lines) == 1, r.stdout[-2000:]
+    d = json.loads(lines[0])
+    assert d['metric'].startswith('HOGAN train images/sec at 256') and d['unit'] == 'images/s'
+    assert d['n_gpus'] == 1 and d['steps'] == 2 and d['warmup'] == 1 and d['higher_is_better'] is True
+    assert d['scaling'] == 'weak' and d['vs_baseline'] is None and d['data'] == 'synthetic'
+    assert abs(d['value'] - 8 / (d['ms_per_step'] * 1e-3)) < 0.02 * d['value']            # batch 8 pairs per step on one GPU
+    assert 30 < d['value'] < 400
+    assert 'workload' in d['config'] and 'model' not in d['config']
+    rf = d['roofline']
+    assert rf['bound'] == 'mfma' and rf['unit'] == 'TFLOP/s' and rf['peak'] == 2500.0
+    assert abs(rf['frac'] - rf['achieved'] / rf['peak']) < 1e-3 and 0.05 < rf['frac'] < 0.625
+    assert 'conv_halo3_f6_kernel' in rf['kernel'] and rf['traffic_source']                  # counters come from a committed pass
+    assert d['gen_fwd']['finite'] and d['gen_fwd']['batch'] == 8 and d['losses_finite'] is True
+    assert 'cpu_baseline' not in d or d['cpu_baseline'] is None or isinstance(d['cpu_baseline'], dict)
