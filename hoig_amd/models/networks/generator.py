@@ -32,6 +32,11 @@ def as_nchw(t):
 _FORK_STREAMS = os.environ.get('HOIG_G_STREAMS', '1') == '1'
 
 
+def forks_streams():
+    """True if Generator.forward runs bg_model / obj_model on branch streams (their backward then runs there too)."""
+    return _FORK_STREAMS
+
+
 class Generator(ParamTree):
     def __init__(self, bg_dim, img_dim, obj_dim, img_cond_dim=0, obj_cond_dim=0, conv_dim=64, repeat_num=6,
                  gen_name='generator_spade_attn', device=None):

@@ -25,7 +25,7 @@ from ..ddp import FlatDDP
 from ..nn import FusedAdam
 from .base_model import BaseModel
 from .networks import NetworksFactory
-from .networks.generator import to_nhwc, as_nchw
+from .networks.generator import to_nhwc, as_nchw, forks_streams as generator_forks_streams
 from .networks.vgg19 import Vgg19, VGGLoss
 
 PREPARED_KEYS = ['input_G_bg', 'input_G_src_obj', 'input_G_tsf_obj', 'input_G_src_hand', 'input_G_tsf_hand', 'T',
@@ -267,7 +267,9 @@ class Trainer(BaseModel):
         netD.set_requires_grad(False)       # the reference computes D grads here and zeroes them at :432
         loss_G = self._optimize_G(fake_src_imgs, fake_tsf_imgs, fake_masks_bg, fake_masks_hand)
         self._optimizer_G.zero_grad()
+        ops.pause_wgrad_side(generator_forks_streams())     # G's backward is three concurrent chains already
         loss_G.backward()
+        ops.pause_wgrad_side(False)
         netD.set_requires_grad(True)
         self._step(self._G, self._optimizer_G, overlap=trainable)
 

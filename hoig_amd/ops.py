@@ -140,11 +140,22 @@ def _packed_planes(w, transposed, for_dgrad):
 
 
 _wgrad_streams = {}
-_WGRAD_SIDE = os.environ.get('HOIG_WGRAD_STREAM', '1') == '1'
+# weight gradients on a side stream, beside the data-gradient chain: '1' always, '0' never, 'auto' (default) wherever the
+# backward is ONE chain -- the generator's backward already runs as three concurrent chains (its forward forks onto branch
+# streams, HOIG_G_STREAMS), and a fourth stream of one-workgroup-per-CU kernels beside them costs 1 % (measured)
+_WGRAD_MODE = os.environ.get('HOIG_WGRAD_STREAM', 'auto')
+_WGRAD_SIDE = _WGRAD_MODE != '0'
+_wgrad_side_paused = False
+
+
+def pause_wgrad_side(paused):
+    """Trainer: True around a backward that already runs on several streams (only honoured in 'auto' mode)."""
+    global _wgrad_side_paused
+    _wgrad_side_paused = bool(paused) and _WGRAD_MODE == 'auto'
 
 
 def _wgrad_side_stream(device):
-    if not _WGRAD_SIDE:
+    if not _WGRAD_SIDE or _wgrad_side_paused:
         return None
     s = _wgrad_streams.get(device)
     if s is None:
