@@ -32,6 +32,9 @@ def as_nchw(t):
 _FORK_STREAMS = os.environ.get('HOIG_G_STREAMS', '1') == '1'
 
 
+_FORK_SRC = os.environ.get('HOIG_SRC_STREAM', '1') == '1'
+
+
 def forks_streams():
     """True if Generator.forward runs bg_model / obj_model on branch streams (their backward then runs there too)."""
     return _FORK_STREAMS
@@ -58,7 +61,7 @@ class Generator(ParamTree):
 
     def _branch_streams(self, device):
         if getattr(self, '_streams', None) is None:
-            self._streams = (torch.cuda.Stream(device=device), torch.cuda.Stream(device=device))
+            self._streams = tuple(torch.cuda.Stream(device=device) for _ in range(3))
         return self._streams
 
     # ---- building blocks -------------------------------------------------------------------
@@ -214,9 +217,10 @@ class Generator(ParamTree):
         obj_in = torch.cat([src_obj, tsf_obj], dim=0)
         obj_c = torch.cat([src_obj_c, tsf_obj_c], dim=0)
         if fork:
-            s_bg, s_obj = self._branch_streams(bg.device)
+            s_bg, s_obj, s_src = self._branch_streams(bg.device)
             s_bg.wait_stream(main)
             s_obj.wait_stream(main)
+            s_src.wait_stream(main)
             with torch.cuda.stream(s_bg):
                 bg_both = self._bg_net(bg_in)
             with torch.cuda.stream(s_obj):
@@ -227,20 +231,39 @@ class Generator(ParamTree):
         else:
             bg_both = self._bg_net(bg_in)
 
-        # infer_front (generator.py:379-464)
-        sx = self._conv_in_relu(src_hand, 'src_model.encoders.0', pad=3)
+        # infer_front (generator.py:379-464).  src_model never reads tsf_model's features, so it runs AHEAD on a stream of its own
+        # (HOIG_SRC_STREAM=0: on the main stream); tsf_model waits, level by level, for the src features it warps in.
+        import contextlib
+        fork_src = fork and _FORK_SRC
+        on_src = (lambda: torch.cuda.stream(s_src)) if fork_src else contextlib.nullcontext
+
+        keep = []                                            # (capture: record_stream is not available in a graph's private pool,
+                                                             # so tensors that cross streams stay referenced until the join)
+        def src_ready(t_):                                   # the main stream may read a tensor made on the src stream
+            if fork_src:
+                main.wait_stream(s_src)
+                if capturing:
+                    keep.append(t_)
+                else:
+                    t_.record_stream(main)
+            return t_
+
+        with on_src():
+            sx = self._conv_in_relu(src_hand, 'src_model.encoders.0', pad=3)
         tx = self._conv_in_relu(tsf_hand, 'tsf_model.encoders.0', pad=3)
         s_enc, t_enc = [sx], [tx]
         for i in range(1, c.n_down + 1):
-            sx = self._enc_level(sx, src_hand_c, 'src_model', i)
+            with on_src():
+                sx = self._enc_level(sx, src_hand_c, 'src_model', i)
             tx = self._enc_level(tx, tsf_hand_c, 'tsf_model', i)
-            tx = ops.add(tx, self._transform(sx, T, i, y=tx))
+            tx = ops.add(tx, self._transform(src_ready(sx), T, i, y=tx))
             s_enc.append(sx)
             t_enc.append(tx)
         for i in range(c.repeat_num):
-            sx = self._resnet(sx, src_hand_c, 'src_model', i)
+            with on_src():
+                sx = self._resnet(sx, src_hand_c, 'src_model', i)
             tx = self._resnet(tx, tsf_hand_c, 'tsf_model', i)
-            tx = ops.add(tx, self._transform(sx, T, i + c.n_down + 1, y=tx))
+            tx = ops.add(tx, self._transform(src_ready(sx), T, i + c.n_down + 1, y=tx))
 
         # obj_model likewise serves both the src and the tsf object (generator.py:449-450): one stacked pass
         if fork:
@@ -253,7 +276,12 @@ class Generator(ParamTree):
             obj_both = self._unet(obj_in, obj_c, 'obj_model')
         src_img_bg, tsf_img_bg = bg_both[:nb], bg_both[nb:]
         sy, ty = obj_both[:nb], obj_both[nb:]
-        sx = self._decode(sx, s_enc, src_hand_c, 'src_model')
+        if fork_src:
+            s_src.wait_stream(s_obj)                         # the src heads read the object branch's output
+            if not capturing:
+                obj_both.record_stream(s_src)
+        with on_src():
+            sx = self._decode(sx, s_enc, src_hand_c, 'src_model')
         tx = self._decode(tx, t_enc, tsf_hand_c, 'tsf_model')
 
         def regress(x, y, p):                                              # generator.py:311-315
@@ -263,8 +291,15 @@ class Generator(ParamTree):
                              ops.conv2d(y, self.P[p + '.attetion_reg_bg.0.weight#s'], None, 1, 3), ACT_SIGMOID)
             return img, mh, mb
 
-        src_hand_o, src_mask_hand, src_mask_bg = regress(sx, sy, 'src_model')
+        with on_src():
+            src_hand_o, src_mask_hand, src_mask_bg = regress(sx, sy, 'src_model')
         tsf_hand_o, tsf_mask_hand, tsf_mask_bg = regress(tx, ty, 'tsf_model')
+        if fork_src:
+            main.wait_stream(s_src)
+            if not capturing:
+                for t_ in (src_hand_o, src_mask_hand, src_mask_bg):
+                    t_.record_stream(main)
+            keep.clear()
         obj_o = self._conv(obj_both, 'obj_model.img_reg.0', pad=3, act=ACT_TANH)
         src_obj_o, tsf_obj_o = obj_o[:nb], obj_o[nb:]
         self._seg_cache = {}
