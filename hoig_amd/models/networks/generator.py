@@ -169,7 +169,14 @@ class Generator(ParamTree):
             self._seg_cache[key] = ops.resize_bilinear_ac(T, h, h)         # resize_trans: size=(h, h)
         return self._seg_cache[key]
 
-    def _transform(self, x, T, layer, y=None):
+    def _attn_source(self, x, layer):
+        """The source half of layer `layer`'s attention (ops.attn_source_conv), or None where the layer warps by grid_sample:
+        evaluated by the caller on src_model's stream, right after the source features exist."""
+        if layer not in self.cfg.attn_layers:
+            return None
+        return ops.attn_source_conv(x, self.P['attn_%d.fully_connect_layer.0.weight#s' % layer])
+
+    def _transform(self, x, T, layer, y=None, gs=None):
         h = x.shape[1]
         ts = self._tscale(T, h)
         if layer in self.cfg.attn_layers:
@@ -178,7 +185,7 @@ class Generator(ParamTree):
                 self._seg_cache[key] = ops.attn_flow(ts)
             p = 'attn_%d.fully_connect_layer' % layer
             return ops.local_attention(x, y, self._seg_cache[key], self.P[p + '.0.weight#t'], self.P[p + '.0.weight#s'],
-                                       self.P[p + '.0.bias'], self.P[p + '.2.weight'], self.P[p + '.2.bias'])
+                                       self.P[p + '.0.bias'], self.P[p + '.2.weight'], self.P[p + '.2.bias'], gs=gs)
         return ops.grid_sample(x, ts)
 
     # ---- public forward: reference signature (generator.py:347-376), NCHW in / NCHW-shaped out ---
@@ -255,15 +262,17 @@ class Generator(ParamTree):
         for i in range(1, c.n_down + 1):
             with on_src():
                 sx = self._enc_level(sx, src_hand_c, 'src_model', i)
+                gs = self._attn_source(sx, i)               # (the attention's source convolution rides on the src stream too)
             tx = self._enc_level(tx, tsf_hand_c, 'tsf_model', i)
-            tx = ops.add(tx, self._transform(src_ready(sx), T, i, y=tx))
+            tx = ops.add(tx, self._transform(src_ready(sx), T, i, y=tx, gs=None if gs is None else src_ready(gs)))
             s_enc.append(sx)
             t_enc.append(tx)
         for i in range(c.repeat_num):
             with on_src():
                 sx = self._resnet(sx, src_hand_c, 'src_model', i)
+                gs = self._attn_source(sx, i + c.n_down + 1)
             tx = self._resnet(tx, tsf_hand_c, 'tsf_model', i)
-            tx = ops.add(tx, self._transform(src_ready(sx), T, i + c.n_down + 1, y=tx))
+            tx = ops.add(tx, self._transform(src_ready(sx), T, i + c.n_down + 1, y=tx, gs=None if gs is None else src_ready(gs)))
 
         # obj_model likewise serves both the src and the tsf object (generator.py:449-450): one stacked pass
         if fork:

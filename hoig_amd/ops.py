@@ -756,92 +756,144 @@ def _attn_pixel_index(flow, B, H, W):
     return hit[0]
 
 
-class _LocalAttn(Function):
-    """ExtractorAttn.forward (extract_attn.py:23-29) without any 25x-sized tensor (hoig_amd/csrc/attn.hip):
-    Gt = conv5x5(replicate_pad(target, 2), wt) + b1 ; Gs = conv5x5(replicate_pad(source, 4), ws) on the grid [-2, H+1]^2 ;
-    hidden = Gt + bilinear(Gs at pixel + flow) ; LeakyReLU ; conv1x1 128->25 ; softmax ; (1/25) sum_q a_q S_q read from the
-    source's 6x6 footprint.  `wt`, `ws` (128,C,5,5) are the two halves of the reference's (128,2C,5,5) weight
-    (hoig_amd.nn.split_attn_weight)."""
+class _AttnSourceConv(Function):
+    """The source half of ExtractorAttn's first layer: Gs = conv5x5(replicate_pad(source, 4), ws) on the grid [-2, H+1]^2 (see
+    _LocalAttn).  A Function of its own because it depends on the SOURCE features only: the generator evaluates it on the
+    stream of src_model, ahead of the tsf chain that consumes it."""
 
     @staticmethod
-    def forward(ctx, source, target, flow, wt, ws, b1, w2, b2, prec):
-        for t in (source, target, flow, wt, ws, b1, w2, b2):
+    def forward(ctx, source, ws, prec):
+        _chk(source)
+        _chk(ws)
+        B, H, W, C = source.shape
+        assert tuple(ws.shape) == (128, C, 5, 5) and tuple(ws.stride()) == packed_strides(ws.shape, False)
+        spad = torch.empty((B, H + 8, W + 8, C), dtype=source.dtype, device=source.device)
+        call('hoig_replicate_pad_fwd', _p(source), _p(spad), B, H, W, C, 4, _st())
+        d_s = ConvDesc(B, H + 8, W + 8, C, H + 4, W + 4, 128, 5, 5, 1, 0, 0, L.ACT_NONE, 0.0, prec)
+        gs = torch.empty((B, H + 4, W + 4, 128), dtype=source.dtype, device=source.device)
+        _conv_fwd_raw(d_s, spad, ws, None, gs)
+        ctx.save_for_backward(ws, spad)
+        ctx.descs = _bwd_descs(d_s)
+        ctx.shape = (B, H, W, C)
+        return gs
+
+    @staticmethod
+    def backward(ctx, dgs):
+        ws, spad = ctx.saved_tensors
+        ds_dg, ds_wg = ctx.descs
+        B, H, W, C = ctx.shape
+        dgs = dgs.contiguous()
+        gw, ret_w = _grad_target(ws)
+        side = _wgrad_side_stream(dgs.device) if not ret_w else None
+        if side is not None:          # (see _Conv.backward)
+            side.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(side):
+                call('hoig_conv2d_bwd_weight', ctypes.byref(ds_wg), _p(spad), _p(dgs), _p(gw), None, _st())
+            for t in (spad, dgs):
+                t.record_stream(side)
+            _wgrad_hold(side, (spad, dgs))
+        else:
+            call('hoig_conv2d_bwd_weight', ctypes.byref(ds_wg), _p(spad), _p(dgs), _p(gw), None, _st())
+        dsrc = None
+        if ctx.needs_input_grad[0]:
+            dspad = torch.empty_like(spad)
+            _conv_dgrad_raw(ds_dg, dgs, ws, dspad)
+            dsrc = torch.empty((B, H, W, C), dtype=dgs.dtype, device=dgs.device)
+            call('hoig_replicate_pad_bwd', _p(dspad), _p(dsrc), B, H, W, C, 4, _st())            # (writes every element)
+        return dsrc, (gw if ret_w else None), None
+
+
+class _LocalAttn(Function):
+    """ExtractorAttn.forward (extract_attn.py:23-29) without any 25x-sized tensor (hoig_amd/csrc/attn.hip):
+    Gt = conv5x5(replicate_pad(target, 2), wt) + b1 ; Gs = conv5x5(replicate_pad(source, 4), ws) on the grid [-2, H+1]^2
+    (_AttnSourceConv, passed in) ; hidden = Gt + bilinear(Gs at pixel + flow) ; LeakyReLU ; conv1x1 128->25 ; softmax ;
+    (1/25) sum_q a_q S_q read from the source's 6x6 footprint.  `wt`, `ws` (128,C,5,5) are the two halves of the reference's
+    (128,2C,5,5) weight (hoig_amd.nn.split_attn_weight)."""
+
+    @staticmethod
+    def forward(ctx, source, target, flow, gs, wt, b1, w2, b2, prec):
+        for t in (source, target, flow, gs, wt, b1, w2, b2):
             _chk(t)
         B, H, W, C = source.shape
-        for w in (wt, ws):
-            assert tuple(w.shape) == (128, C, 5, 5) and tuple(w.stride()) == packed_strides(w.shape, False)
+        assert tuple(wt.shape) == (128, C, 5, 5) and tuple(wt.stride()) == packed_strides(wt.shape, False)
+        assert tuple(gs.shape) == (B, H + 4, W + 4, 128)
         M = B * H * W
         dev, dt = source.device, source.dtype
         tpad = torch.empty((B, H + 4, W + 4, C), dtype=dt, device=dev)
         call('hoig_replicate_pad_fwd', _p(target), _p(tpad), B, H, W, C, 2, _st())
-        spad = torch.empty((B, H + 8, W + 8, C), dtype=dt, device=dev)
-        call('hoig_replicate_pad_fwd', _p(source), _p(spad), B, H, W, C, 4, _st())
         d_t = ConvDesc(B, H + 4, W + 4, C, H, W, 128, 5, 5, 1, 0, 0, L.ACT_NONE, 0.0, prec)
-        d_s = ConvDesc(B, H + 8, W + 8, C, H + 4, W + 4, 128, 5, 5, 1, 0, 0, L.ACT_NONE, 0.0, prec)
         gt = torch.empty((M, 128), dtype=dt, device=dev)
-        gs = torch.empty((B, H + 4, W + 4, 128), dtype=dt, device=dev)
         _conv_fwd_raw(d_t, tpad, wt, b1, gt)
-        _conv_fwd_raw(d_s, spad, ws, None, gs)
         hidden = torch.empty_like(gt)
         attn = torch.empty((M, 25), dtype=dt, device=dev)
         out = torch.empty_like(source)
         kf = torch.empty((M, 36), dtype=dt, device=dev) if source.requires_grad else None
         call('hoig_attn_pixel_fwd', _p(gt), _p(gs), _p(flow), _p(w2), _p(b2), _p(source), _p(hidden), _p(attn), _p(out),
              _p(kf), B, H, W, C, _st())
-        ctx.save_for_backward(source, flow, wt, ws, b1, w2, b2, tpad, spad, hidden, attn, kf)
-        ctx.descs = _bwd_descs(d_t) + _bwd_descs(d_s)
+        ctx.save_for_backward(source, flow, wt, b1, w2, b2, tpad, hidden, attn, kf)
+        ctx.descs = _bwd_descs(d_t)
         ctx.shape = (B, H, W, C)
         return out
 
     @staticmethod
     def backward(ctx, dout):
-        source, flow, wt, ws, b1, w2, b2, tpad, spad, hidden, attn, kf = ctx.saved_tensors
-        dt_dg, dt_wg, ds_dg, ds_wg = ctx.descs
+        source, flow, wt, b1, w2, b2, tpad, hidden, attn, kf = ctx.saved_tensors
+        dt_dg, dt_wg = ctx.descs
         B, H, W, C = ctx.shape
         dout = dout.contiguous()
-        gs = [_grad_target(p) for p in (wt, ws, b1, w2, b2)]
+        gs = [_grad_target(p) for p in (wt, b1, w2, b2)]
         dhid = torch.empty_like(hidden)                       # = dGt
         e_ws = torch.empty((B * H * W, 36), dtype=dout.dtype, device=dout.device)
-        call('hoig_attn_pixel_bwd', _p(hidden), _p(attn), _p(w2), _p(source), _p(flow), _p(dout), _p(dhid), _p(gs[3][0]),
-             _p(gs[4][0]), _p(e_ws), B, H, W, C, _st())
+        call('hoig_attn_pixel_bwd', _p(hidden), _p(attn), _p(w2), _p(source), _p(flow), _p(dout), _p(dhid), _p(gs[2][0]),
+             _p(gs[3][0]), _p(e_ws), B, H, W, C, _st())
         index = _attn_pixel_index(flow, B, H, W)
-        dgs = torch.empty((B, H + 4, W + 4, 128), dtype=dout.dtype, device=dout.device)
-        call('hoig_attn_gs_gather', _p(index), _p(flow), _p(dhid), _p(dgs), B, H, W, _st())
+        dgs = None
+        if ctx.needs_input_grad[3]:
+            dgs = torch.empty((B, H + 4, W + 4, 128), dtype=dout.dtype, device=dout.device)
+            call('hoig_attn_gs_gather', _p(index), _p(flow), _p(dhid), _p(dgs), B, H, W, _st())
         side = _wgrad_side_stream(dout.device) if not any(r for _, r in gs) else None
         if side is not None:          # (see _Conv.backward)
             side.wait_stream(torch.cuda.current_stream())
             with torch.cuda.stream(side):
-                call('hoig_conv2d_bwd_weight', ctypes.byref(dt_wg), _p(tpad), _p(dhid), _p(gs[0][0]), _p(gs[2][0]), _st())
-                call('hoig_conv2d_bwd_weight', ctypes.byref(ds_wg), _p(spad), _p(dgs), _p(gs[1][0]), None, _st())
-            for t in (tpad, spad, dhid, dgs):
+                call('hoig_conv2d_bwd_weight', ctypes.byref(dt_wg), _p(tpad), _p(dhid), _p(gs[0][0]), _p(gs[1][0]), _st())
+            for t in (tpad, dhid):
                 t.record_stream(side)
-            _wgrad_hold(side, (tpad, spad, dhid, dgs))
+            _wgrad_hold(side, (tpad, dhid))
         else:
-            call('hoig_conv2d_bwd_weight', ctypes.byref(dt_wg), _p(tpad), _p(dhid), _p(gs[0][0]), _p(gs[2][0]), _st())
-            call('hoig_conv2d_bwd_weight', ctypes.byref(ds_wg), _p(spad), _p(dgs), _p(gs[1][0]), None, _st())
+            call('hoig_conv2d_bwd_weight', ctypes.byref(dt_wg), _p(tpad), _p(dhid), _p(gs[0][0]), _p(gs[1][0]), _st())
         dtgt = dsrc = None
         if ctx.needs_input_grad[1]:
             dtpad = torch.empty_like(tpad)
             _conv_dgrad_raw(dt_dg, dhid, wt, dtpad)
             dtgt = torch.empty((B, H, W, C), dtype=dout.dtype, device=dout.device)
             call('hoig_replicate_pad_bwd', _p(dtpad), _p(dtgt), B, H, W, C, 2, _st())
-        if ctx.needs_input_grad[0]:
-            dspad = torch.empty_like(spad)
-            _conv_dgrad_raw(ds_dg, dgs, ws, dspad)
-            dsrc = torch.empty((B, H, W, C), dtype=dout.dtype, device=dout.device)
-            call('hoig_replicate_pad_bwd', _p(dspad), _p(dsrc), B, H, W, C, 4, _st())            # (writes every element)
-            call('hoig_attn_src_gather', _p(index), _p(kf), _p(dout), _p(dsrc), B, H, W, C, _st())   # += the weighted average's part
+        if ctx.needs_input_grad[0]:                           # the weighted average's part (Gs's part comes from _AttnSourceConv)
+            dsrc = torch.zeros((B, H, W, C), dtype=dout.dtype, device=dout.device)
+            call('hoig_attn_src_gather', _p(index), _p(kf), _p(dout), _p(dsrc), B, H, W, C, _st())
         rets = [g if r else None for g, r in gs]
-        return dsrc, dtgt, None, rets[0], rets[1], rets[2], rets[3], rets[4], None
+        return dsrc, dtgt, None, dgs, rets[0], rets[1], rets[2], rets[3], None
 
 
 _ATTN_PREC = os.environ.get('HOIG_ATTN_PREC')          # experiment switch: arithmetic of the attention's two 5x5 convolutions
 
 
-def local_attention(source, target, flow, wt, ws, b1, w2, b2, prec=None):
+def _attn_prec(prec):
     if prec is None:
         prec = _PREC[_ATTN_PREC] if (_ATTN_PREC and precision != L.PREC_F32) else precision
-    return _LocalAttn.apply(source, target, flow.contiguous(), wt, ws, b1, w2, b2, prec)
+    return prec
+
+
+def attn_source_conv(source, ws, prec=None):
+    """Gs of local_attention(): the part that depends on the source features and the source half of the weight only."""
+    return _AttnSourceConv.apply(source, ws, _attn_prec(prec))
+
+
+def local_attention(source, target, flow, wt, ws, b1, w2, b2, prec=None, gs=None):
+    """`gs`: attn_source_conv(source, ws) if the caller has evaluated it already (on another stream)."""
+    prec = _attn_prec(prec)
+    if gs is None:
+        gs = _AttnSourceConv.apply(source, ws, prec)
+    return _LocalAttn.apply(source, target, flow.contiguous(), gs, wt, b1, w2, b2, prec)
 
 
 # stand-alone equivalents of the reference's two extension modules (NCHW, caller-visible semantics of
