@@ -72,10 +72,21 @@ class VGGLoss(object):
     def cuda(self, *a, **k):
         return self
 
-    def forward_nhwc(self, x, y, scale=1.0):
-        fx = self.vgg.forward_nhwc(x)
-        with torch.no_grad():
-            fy = self.vgg.forward_nhwc(y)
+    def forward_nhwc(self, x, y, scale=1.0, side=None):
+        """`side`: a stream on which the (gradient-free) features of the target `y` are evaluated beside those of `x`."""
+        if side is not None and x.is_cuda:
+            main = torch.cuda.current_stream()
+            side.wait_stream(main)
+            with torch.cuda.stream(side), torch.no_grad():
+                fy = self.vgg.forward_nhwc(y)
+            fx = self.vgg.forward_nhwc(x)
+            main.wait_stream(side)
+            for t in fy:
+                t.record_stream(main)
+        else:
+            fx = self.vgg.forward_nhwc(x)
+            with torch.no_grad():
+                fy = self.vgg.forward_nhwc(y)
         loss = 0
         for w, a, b in zip(self.weights, fx, fy):
             loss = loss + ops.l1_loss(a, b, scale=w * scale)

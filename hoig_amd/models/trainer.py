@@ -28,6 +28,8 @@ from .networks import NetworksFactory
 from .networks.generator import to_nhwc, as_nchw, forks_streams as generator_forks_streams
 from .networks.vgg19 import Vgg19, VGGLoss
 
+_LOSS_STREAMS = os.environ.get('HOIG_LOSS_STREAMS', '1') == '1'
+
 PREPARED_KEYS = ['input_G_bg', 'input_G_src_obj', 'input_G_tsf_obj', 'input_G_src_hand', 'input_G_tsf_hand', 'T',
                  'real_src', 'real_tsf', 'bg_mask', 'hand_mask']
 RASTER_KEYS = ['src_img', 'ref_img', 'src_faces', 'src_fim', 'src_wim', 'ref_fim', 'ref_wim', 'tables']
@@ -64,6 +66,7 @@ class Trainer(BaseModel):
         self._world = dist.get_world_size() if (use_ddp and dist.is_initialized()) else 1
         # G's gradient exchange + Adam run on a side stream beside the D step; D's run there beside the next forward of G
         self._side = torch.cuda.Stream(device=self.device)
+        self._loss_streams = None
         self._g_ready = None
         self._d_ready = None
 
@@ -310,12 +313,32 @@ class Trainer(BaseModel):
         o, n = self._opt, self._n
         fake_src, fake_tsf = to_nhwc(fake_src_imgs), to_nhwc(fake_tsf_imgs)
         mbg, mh = to_nhwc(fake_masks_bg), to_nhwc(fake_masks_hand)
-        self._wait_d()
-        d_fake = self._D.forward_nhwc(ops.cat_channels([fake_tsf, n['tsf_cond']]))
-        self._loss_g_adv = ops.lsgan_loss(d_fake, 0.0, o.lambda_D_prob)
+        # The adversarial term (D on the fake) and the perceptual term (VGG on the fake, VGG on the target) do not read each other:
+        # three chains on three streams, like the generator's sub-networks (their backward replays there too); HOIG_LOSS_STREAMS=0:
+        # one after the other on the caller's stream.
+        fork = _LOSS_STREAMS and fake_tsf.is_cuda and generator_forks_streams()
+        if fork:
+            main = torch.cuda.current_stream()
+            if self._loss_streams is None:
+                self._loss_streams = (torch.cuda.Stream(device=self.device), torch.cuda.Stream(device=self.device))
+            s_adv, s_vgg = self._loss_streams
+            s_adv.wait_stream(main)
+            with torch.cuda.stream(s_adv):
+                self._wait_d()
+                d_fake = self._D.forward_nhwc(ops.cat_channels([fake_tsf, n['tsf_cond']]))
+                self._loss_g_adv = ops.lsgan_loss(d_fake, 0.0, o.lambda_D_prob)
+            fake_tsf.record_stream(s_adv)
+        else:
+            s_vgg = None
+            self._wait_d()
+            d_fake = self._D.forward_nhwc(ops.cat_channels([fake_tsf, n['tsf_cond']]))
+            self._loss_g_adv = ops.lsgan_loss(d_fake, 0.0, o.lambda_D_prob)
         self._loss_g_rec = ops.l1_loss(fake_src, n['real_src'], o.lambda_rec)
         # the reference uses self._crt_tsf in both branches of `if use_vgg` (:443-446); it only exists with --use_vgg
-        self._loss_g_tsf = self._crt_tsf.forward_nhwc(fake_tsf, n['real_tsf'], o.lambda_tsf)
+        self._loss_g_tsf = self._crt_tsf.forward_nhwc(fake_tsf, n['real_tsf'], o.lambda_tsf, side=s_vgg)
+        if fork:
+            main.wait_stream(s_adv)
+            self._loss_g_adv.record_stream(main)
         crt = ops.bce_loss if o.mask_bce else ops.mse_loss
         self._loss_g_mask = crt(mbg, n['bg_mask'], o.lambda_mask) + crt(mh, n['hand_mask'], o.lambda_mask)
         if o.lambda_mask_smooth != 0:
