@@ -29,6 +29,7 @@ from .networks.generator import to_nhwc, as_nchw, forks_streams as generator_for
 from .networks.vgg19 import Vgg19, VGGLoss
 
 _LOSS_STREAMS = os.environ.get('HOIG_LOSS_STREAMS', '1') == '1'
+_D_STREAM = os.environ.get('HOIG_D_STREAM', '1') == '1'
 
 PREPARED_KEYS = ['input_G_bg', 'input_G_src_obj', 'input_G_tsf_obj', 'input_G_src_hand', 'input_G_tsf_hand', 'T',
                  'real_src', 'real_tsf', 'bg_mask', 'hand_mask']
@@ -67,6 +68,7 @@ class Trainer(BaseModel):
         # G's gradient exchange + Adam run on a side stream beside the D step; D's run there beside the next forward of G
         self._side = torch.cuda.Stream(device=self.device)
         self._loss_streams = None
+        self._d_stream = None
         self._g_ready = None
         self._d_ready = None
 
@@ -265,6 +267,10 @@ class Trainer(BaseModel):
             return
         _, _, fake_src_imgs, fake_tsf_imgs, fake_masks_bg, fake_masks_hand = \
             self.forward(keep_data_for_visuals=keep_data_for_visuals)
+        ev_fwd = None
+        if fake_tsf_imgs.is_cuda:
+            ev_fwd = torch.cuda.Event()
+            ev_fwd.record(torch.cuda.current_stream())
 
         netD = self._net(self._D)
         netD.set_requires_grad(False)       # the reference computes D grads here and zeroes them at :432
@@ -277,11 +283,29 @@ class Trainer(BaseModel):
         self._step(self._G, self._optimizer_G, overlap=trainable)
 
         if trainable:
-            loss_D = self._optimize_D(fake_tsf_imgs)
-            self._optimizer_D.zero_grad()
-            loss_D.backward()
-            self._wait_g()                # G's update has had the whole D step to finish; later readers need no special care
-            self._step(self._D, self._optimizer_D, overlap=True, which='d')
+            # The D step reads the fake image and D's weights, nothing of G's backward: it runs on a stream of its own that only
+            # waits for the generator's forward, i.e. BESIDE G's backward chains (HOIG_D_STREAM=0: after them, on the caller's
+            # stream).  D's Adam still follows G's backward through D: it is queued on the side stream behind G's step, which waited
+            # for every backward stream.
+            d_fork = _D_STREAM and ev_fwd is not None
+            if d_fork:
+                main = torch.cuda.current_stream()
+                if self._d_stream is None:
+                    self._d_stream = torch.cuda.Stream(device=self.device)
+                self._d_stream.wait_event(ev_fwd)
+                fake_tsf_imgs.record_stream(self._d_stream)
+                with torch.cuda.stream(self._d_stream):
+                    self._d_step(fake_tsf_imgs)
+                main.wait_stream(self._d_stream)
+            else:
+                self._d_step(fake_tsf_imgs)
+
+    def _d_step(self, fake_tsf_imgs):
+        loss_D = self._optimize_D(fake_tsf_imgs)
+        self._optimizer_D.zero_grad()
+        loss_D.backward()
+        self._wait_g()                # G's update has had the whole D step to finish; later readers need no special care
+        self._step(self._D, self._optimizer_D, overlap=True, which='d')
 
     def _step(self, net, optimizer, overlap, which='g'):
         """gradient exchange (RCCL, under DDP) + fused Adam.  With `overlap` both run on the side stream: G's beside the D step
