@@ -30,6 +30,7 @@ from .networks.vgg19 import Vgg19, VGGLoss
 
 _LOSS_STREAMS = os.environ.get('HOIG_LOSS_STREAMS', '1') == '1'
 _D_STREAM = os.environ.get('HOIG_D_STREAM', '1') == '1'
+_PACK_WITH_STEP = os.environ.get('HOIG_PACK_WITH_STEP', '1') == '1'
 
 PREPARED_KEYS = ['input_G_bg', 'input_G_src_obj', 'input_G_tsf_obj', 'input_G_src_hand', 'input_G_tsf_hand', 'T',
                  'real_src', 'real_tsf', 'bg_mask', 'hand_mask']
@@ -320,6 +321,8 @@ class Trainer(BaseModel):
                     optimizer.step(grad_scale=1.0 / net.sync.world, ready=net.sync.iter_all_reduce())
                 else:
                     optimizer.step()
+                if _PACK_WITH_STEP:        # the operand planes of the new weights too: off the next forward's critical path
+                    self._net(net).refresh_planes()
                 ev = torch.cuda.Event()
                 ev.record(self._side)
             self._net(net).set_pending(ev)       # anyone who reads the network through its own API waits too
