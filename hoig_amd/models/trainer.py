@@ -288,7 +288,7 @@ class Trainer(BaseModel):
             # waits for the generator's forward, i.e. BESIDE G's backward chains (HOIG_D_STREAM=0: after them, on the caller's
             # stream).  D's Adam still follows G's backward through D: it is queued on the side stream behind G's step, which waited
             # for every backward stream.
-            d_fork = _D_STREAM and ev_fwd is not None
+            d_fork = _D_STREAM and ev_fwd is not None and generator_forks_streams()     # (HOIG_G_STREAMS=0: one stream for everything)
             if d_fork:
                 main = torch.cuda.current_stream()
                 if self._d_stream is None:
