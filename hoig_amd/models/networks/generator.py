@@ -33,6 +33,7 @@ _FORK_STREAMS = os.environ.get('HOIG_G_STREAMS', '1') == '1'
 
 
 _FORK_SRC = os.environ.get('HOIG_SRC_STREAM', '1') == '1'
+_INTERLEAVE = os.environ.get('HOIG_INTERLEAVE', '1') == '1'
 
 
 def forks_streams():
@@ -111,20 +112,33 @@ class Generator(ParamTree):
         h = self._conv(x, name + '.conv', stride=2, to_norm=True) if down else self._convT(x, name + '.conv')
         return self._spade(h, seg, name + '.norm', ACT_RELU)
 
-    def _bg_net(self, x):                                                  # generator.py:93-135
+    def _bg_net_steps(self, x, out):                                       # generator.py:93-135
+        """bg_model as a Python generator that yields after every level / block (out[0] = the result): forward_nhwc advances
+        the sub-networks round-robin, so that the host issues -- and autograd later replays -- the concurrent chains interleaved
+        instead of one whole chain after the other."""
         c, p = self.cfg, 'bg_model.model'
         x = self._in(self._conv(x, p + '.0', pad=3, to_norm=True), p + '.1', act=ACT_RELU)
+        yield
         idx = 3
         for _ in range(c.n_down):
             x = self._in(self._conv(x, p + '.%d' % idx, stride=2, to_norm=True), p + '.%d' % (idx + 1), act=ACT_RELU)
             idx += 3
+            yield
         for _ in range(c.repeat_num):
             x = self._resblock(x, p + '.%d' % idx)
             idx += 1
+            yield
         for _ in range(c.n_down):
             x = self._in(self._convT(x, p + '.%d' % idx), p + '.%d' % (idx + 1), act=ACT_RELU)
             idx += 3
-        return self._conv(x, p + '.%d' % idx, pad=3, act=ACT_TANH)
+            yield
+        out[0] = self._conv(x, p + '.%d' % idx, pad=3, act=ACT_TANH)
+
+    def _bg_net(self, x):
+        out = [None]
+        for _ in self._bg_net_steps(x, out):
+            pass
+        return out[0]
 
     def _enc_level(self, x, seg, p, i):
         if self.cfg.spade_layers[0]:
@@ -137,30 +151,45 @@ class Generator(ParamTree):
             return self._spade_resblock(x, seg, p + '.resnets.%d' % i)
         return self._resblock(x, p + '.resnets.%d' % i)
 
-    def _decode(self, x, enc, seg, p):                                     # generator.py:298-309
+    def _decode_level(self, x, enc, seg, p, i):                            # generator.py:298-309
         nd = self.cfg.n_down
-        for i in range(nd):
-            if self.cfg.spade_layers[3]:
-                x = self._spade_block(x, seg, p + '.decoders.%d' % i, False)
-            else:
-                x = self._conv_in_relu(x, p + '.decoders.%d' % i, transposed=True)
-            # cat[skip, up] -> conv3x3 -> IN -> ReLU: the convolution reads the two tensors directly (ops.conv2d_cat2)
-            name = p + '.skippers.%d' % i
-            if self.P.get(name + '.0.bias') is None:
-                x = self._in(ops.conv2d_cat2(enc[nd - 1 - i], x, self.P[name + '.0.weight']), name + '.1', act=ACT_RELU)
-            else:
-                x = self._conv_in_relu(ops.cat_channels([enc[nd - 1 - i], x]), name)
+        if self.cfg.spade_layers[3]:
+            x = self._spade_block(x, seg, p + '.decoders.%d' % i, False)
+        else:
+            x = self._conv_in_relu(x, p + '.decoders.%d' % i, transposed=True)
+        # cat[skip, up] -> conv3x3 -> IN -> ReLU: the convolution reads the two tensors directly (ops.conv2d_cat2)
+        name = p + '.skippers.%d' % i
+        if self.P.get(name + '.0.bias') is None:
+            return self._in(ops.conv2d_cat2(enc[nd - 1 - i], x, self.P[name + '.0.weight']), name + '.1', act=ACT_RELU)
+        return self._conv_in_relu(ops.cat_channels([enc[nd - 1 - i], x]), name)
+
+    def _decode(self, x, enc, seg, p):
+        for i in range(self.cfg.n_down):
+            x = self._decode_level(x, enc, seg, p, i)
         return x
 
-    def _unet(self, x, seg, p):                                            # generator.py:261-283
+    def _unet_steps(self, x, seg, p, out):                                 # generator.py:261-283 (see _bg_net_steps)
         e = self._conv_in_relu(x, p + '.encoders.0', pad=3)
+        yield
         enc = [e]
         for i in range(1, self.cfg.n_down + 1):
             e = self._enc_level(e, seg, p, i)
             enc.append(e)
+            yield
         for i in range(self.cfg.repeat_num):
             e = self._resnet(e, seg, p, i)
-        return self._decode(e, enc, seg, p)
+            yield
+        for i in range(self.cfg.n_down):
+            e = self._decode_level(e, enc, seg, p, i)
+            if i + 1 < self.cfg.n_down:
+                yield
+        out[0] = e
+
+    def _unet(self, x, seg, p):
+        out = [None]
+        for _ in self._unet_steps(x, seg, p, out):
+            pass
+        return out[0]
 
     # ---- feature warping (generator.py:466-491) ------------------------------------------------
     def _tscale(self, T, h):
@@ -228,15 +257,26 @@ class Generator(ParamTree):
             s_bg.wait_stream(main)
             s_obj.wait_stream(main)
             s_src.wait_stream(main)
-            with torch.cuda.stream(s_bg):
-                bg_both = self._bg_net(bg_in)
-            with torch.cuda.stream(s_obj):
-                obj_both = self._unet(obj_in, obj_c, 'obj_model')
+            bg_out, obj_out = [None], [None]
+            branches = [(self._bg_net_steps(bg_in, bg_out), s_bg), (self._unet_steps(obj_in, obj_c, 'obj_model', obj_out), s_obj)]
             if not capturing:
                 for t_, st_ in ((bg_in, s_bg), (obj_in, s_obj), (obj_c, s_obj)):
                     t_.record_stream(st_)
         else:
+            branches = []
             bg_both = self._bg_net(bg_in)
+
+        def advance(all_the_way=False):                      # one level / block of bg_model and obj_model on their streams
+            for gen, st_ in branches:
+                with torch.cuda.stream(st_):
+                    if all_the_way:
+                        for _ in gen:
+                            pass
+                    else:
+                        next(gen, None)
+
+        if not _INTERLEAVE:
+            advance(True)
 
         # infer_front (generator.py:379-464).  src_model never reads tsf_model's features, so it runs AHEAD on a stream of its own
         # (HOIG_SRC_STREAM=0: on the main stream); tsf_model waits, level by level, for the src features it warps in.
@@ -258,6 +298,7 @@ class Generator(ParamTree):
         with on_src():
             sx = self._conv_in_relu(src_hand, 'src_model.encoders.0', pad=3)
         tx = self._conv_in_relu(tsf_hand, 'tsf_model.encoders.0', pad=3)
+        advance()
         s_enc, t_enc = [sx], [tx]
         for i in range(1, c.n_down + 1):
             with on_src():
@@ -267,12 +308,17 @@ class Generator(ParamTree):
             tx = ops.add(tx, self._transform(src_ready(sx), T, i, y=tx, gs=None if gs is None else src_ready(gs)))
             s_enc.append(sx)
             t_enc.append(tx)
+            advance()
         for i in range(c.repeat_num):
             with on_src():
                 sx = self._resnet(sx, src_hand_c, 'src_model', i)
                 gs = self._attn_source(sx, i + c.n_down + 1)
             tx = self._resnet(tx, tsf_hand_c, 'tsf_model', i)
             tx = ops.add(tx, self._transform(src_ready(sx), T, i + c.n_down + 1, y=tx, gs=None if gs is None else src_ready(gs)))
+            advance()
+        advance(True)                                        # (their decoders: issued before the join below)
+        if fork:
+            bg_both, obj_both = bg_out[0], obj_out[0]
 
         # obj_model likewise serves both the src and the tsf object (generator.py:449-450): one stacked pass
         if fork:

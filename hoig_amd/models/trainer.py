@@ -346,6 +346,10 @@ class Trainer(BaseModel):
         fork = _LOSS_STREAMS and fake_tsf.is_cuda and generator_forks_streams()
         if fork:
             main = torch.cuda.current_stream()
+            # operand planes are (re)made lazily by whoever asks first: make D's and VGG's here, on the caller's stream, so that
+            # the chains below only read them (VGG's weights never change: this matters on the first step and after a load)
+            self._net(self._D).refresh_planes()
+            self._crt_tsf.vgg.refresh_planes()
             if self._loss_streams is None:
                 self._loss_streams = (torch.cuda.Stream(device=self.device), torch.cuda.Stream(device=self.device))
             s_adv, s_vgg = self._loss_streams

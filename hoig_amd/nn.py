@@ -139,11 +139,25 @@ class ParamTree(nn.Module):
         return rows
 
     def refresh_planes(self):
+        """Make the operand planes of the current weights on the CURRENT stream (creating the buffers on first use): a forward
+        that forks onto several streams calls this first, so that no chain makes them under another chain's feet."""
         self.wait_pending()
-        self._refresh_planes()
         from . import ops
-        if ops.precision == L.PREC_F16F6:       # (a forward that forks onto several streams: the fp6 records too, here)
+        if ops.precision != L.PREC_F32:
+            self._ensure_plane_bufs()
+        self._refresh_planes()
+        if ops.precision == L.PREC_F16F6:       # (the fp6 records too)
             self._refresh_f6()
+
+    def _ensure_plane_bufs(self):
+        if self._plane_bufs is None:
+            rows = self._build_plane_table()
+            if not rows:
+                self._plane_bufs = ()
+                return
+            self._plane_table = torch.tensor(rows, dtype=torch.int64, device=self.flat.device)
+            self._plane_bufs = tuple(torch.empty(self.flat.numel(), dtype=torch.int16, device=self.flat.device)
+                                     for _ in range(4))
 
     def _refresh_planes(self):
         """Split the current weights into bf16 planes (one launch) if they changed since the last split.  Called lazily by
@@ -158,14 +172,7 @@ class ParamTree(nn.Module):
     def packed_planes(self, w, for_dgrad):
         """(hi, lo) bf16 planes of conv weight `w` (a view of self.flat) for the forward (for_dgrad=False) or data-
         gradient GEMM, or None if `w` is not in the table (hoig_pack_conv_weights_bf16_all, include/hoig_kernels.h)."""
-        if self._plane_bufs is None:
-            rows = self._build_plane_table()
-            if not rows:
-                self._plane_bufs = ()
-                return None
-            self._plane_table = torch.tensor(rows, dtype=torch.int64, device=self.flat.device)
-            self._plane_bufs = tuple(torch.empty(self.flat.numel(), dtype=torch.int16, device=self.flat.device)
-                                     for _ in range(4))
+        self._ensure_plane_bufs()
         if not self._plane_bufs:
             return None
         off = w.storage_offset()
