@@ -102,7 +102,7 @@ def gen_forward_latency(opt, batch, side, iters=10):
     BaseModel.__init__(model, opt)
     model._name = 'Trainer'
     model.device = torch.device('cuda', torch.cuda.current_device())
-    model._dexycb, model._world, model._side, model._g_ready = False, 1, None, None
+    model._dexycb, model._world, model._side = False, 1, None
     with contextlib.redirect_stdout(sys.stderr):       # 'Network ... was created' banners: keep stdout to the JSON line
         model._init_create_networks(use_ddp=False)
     model._init_prefetch_inputs()
@@ -121,8 +121,9 @@ def gen_forward_latency(opt, batch, side, iters=10):
         torch.cuda.synchronize()
         out['eager_ms_per_img'] = round(s.elapsed_time(e) / iters / batch, 4)
         try:
+            from hoig_amd import ops
             graph = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(graph):
+            with ops.graph_capture(graph):
                 res = model.forward()
             graph.replay()
             torch.cuda.synchronize()
@@ -265,6 +266,8 @@ def main():
     ap.add_argument('--precision', default=os.environ.get('HOIG_PRECISION', 'f16f6'),
                     help="'<forward>[:<data gradient>[:<weight gradient>]]' of f32 | bf16x3 | f16x2 | bf16; f16f6 = forward on fp16 + block-scaled fp6 terms, backward f16x2 (hoig_amd/ops.py set_precision)")
     ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--no-graph', action='store_true', help='issue every step kernel by kernel instead of replaying the captured hipGraph')
+    ap.add_argument('--eager-steps', type=int, default=20, help='steps of the eager (uncaptured) comparison leg; 0 = skip')
     ap.add_argument('--no-gen-fwd', action='store_true')
     ap.add_argument('--fwd-batch', type=int, default=32, help='batch of the generator-forward latency leg')
     ap.add_argument('--cpu-baseline-worker', type=int, default=0, help=argparse.SUPPRESS)
@@ -293,7 +296,8 @@ def main():
     from hoig_amd.options import opt_namespace
     ops.set_precision(args.precision)
 
-    opt = opt_namespace(gen_name=args.gen_name, local_rank=local_rank, image_size=args.side, dataset_mode=args.dataset)
+    opt = opt_namespace(gen_name=args.gen_name, local_rank=local_rank, image_size=args.side, dataset_mode=args.dataset,
+                        hip_graph=not args.no_graph)
     torch.manual_seed(8)
     with contextlib.redirect_stdout(sys.stderr):       # the reference-style construction banners go to stderr
         model = ModelsFactory.get_by_name('trainer', opt, use_ddp=ddp)
@@ -306,6 +310,11 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    # untimed and not counted as warm-up: the eager iterations the trainer runs before it captures the step, and the capture
+    from hoig_amd.models import trainer as trainer_mod
+    if not args.no_graph:
+        for _ in range(trainer_mod._GRAPH_WARMUP + 1):
+            model.optimize_parameters()
     for _ in range(args.warmup):
         model.optimize_parameters()
     barrier()
@@ -319,6 +328,20 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
     errors = model.get_current_errors()
+    captured = bool(model._graphs) and all(g['graphs'] is not None for g in model._graphs.values())
+
+    eager_ms = None
+    if captured and args.eager_steps > 0:          # the same step issued kernel by kernel (what rounds 1-2 measured)
+        model._use_graph = False
+        for _ in range(3):
+            model.optimize_parameters()
+        barrier()
+        t1 = time.perf_counter()
+        for _ in range(args.eager_steps):
+            model.optimize_parameters()
+        barrier()
+        eager_ms = (time.perf_counter() - t1) / args.eager_steps * 1e3
+        model._use_graph = True
 
     if rank == 0:
         ms = dt / args.steps * 1e3
@@ -335,6 +358,8 @@ def main():
                                                            args.batch, args.gen_name),
                        'global_batch': world * args.batch, 'parallelism': 'dp%d' % world},
             'step_tflops': round(GFLOP_PER_PAIR_TRAIN_256 * (args.side / 256.0) ** 2 * value / 1e3, 2),
+            'hipgraph': {'captured_step': captured, 'eager_ms_per_step': None if eager_ms is None else round(eager_ms, 3),
+                         'eager_value': None if eager_ms is None else round(world * args.batch / (eager_ms * 1e-3), 3)},
             'roofline': roof,
             'losses_finite': all(v == v and abs(v) != float('inf') for v in errors.values()),
         }

@@ -103,6 +103,8 @@ _SIGS = {
     'hoig_tv_fwd_bwd': [_vp, _f, _f, _vp, _vp, _i, _i, _i, _vp],
     'hoig_sum': [_vp, _vp, _i64, _vp],
     'hoig_adam_step': [_vp, _vp, _vp, _vp, _i64, _d, _d, _d, _d, _i, _f, _vp],
+    'hoig_adam_tick': [_vp, _vp, _vp],
+    'hoig_adam_step_dev': [_vp, _vp, _vp, _vp, _i64, _vp, _f, _vp],
     'hoig_tensor2im_u8': [_vp, _vp] + [_i] * 6 + [_vp],
     'hoig_prep_texture': [_vp] * 9,
     'hoig_prep_lookup': [_vp] * 5 + [_i] + [_vp] * 8,

@@ -424,6 +424,58 @@ __global__ __launch_bounds__(NT) void adam_kernel(float *__restrict__ p, const f
     }
 }
 
+// Adam with its schedule in DEVICE memory, so that an optimiser step is a pure function of device state and can sit inside a
+// captured hipGraph: `state` = {lr, beta1, beta2, eps, step} (doubles; the host only rewrites lr), `derived` = the six fp32
+// scalars adam_kernel takes by value.  One thread: advance the step count and evaluate the bias corrections in double, as
+// hoig_adam_step does on the host.
+__global__ void adam_tick_kernel(double *__restrict__ state, float *__restrict__ derived) {
+    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    const double lr = state[0], b1 = state[1], b2 = state[2], eps = state[3];
+    const double step = state[4] + 1.0;
+    state[4] = step;
+    const double bc1 = 1.0 - pow(b1, step), bc2 = 1.0 - pow(b2, step);
+    derived[0] = (float)(lr / bc1);
+    derived[1] = (float)(1.0 - b1);
+    derived[2] = (float)b2;
+    derived[3] = (float)(1.0 - b2);
+    derived[4] = (float)eps;
+    derived[5] = (float)sqrt(bc2);
+}
+
+__global__ __launch_bounds__(NT) void adam_dev_kernel(float *__restrict__ p, const float *__restrict__ g, float *__restrict__ m,
+                                                      float *__restrict__ v, int64_t n, const float *__restrict__ derived,
+                                                      float gscale) {
+    const float step_size = derived[0], omb1 = derived[1], b2 = derived[2], omb2 = derived[3], eps = derived[4],
+                bc2_sqrt = derived[5];
+    const int64_t n4 = n >> 2;
+    for (int64_t i = (int64_t)blockIdx.x * NT + threadIdx.x; i < n4; i += (int64_t)gridDim.x * NT) {
+        float4 pp = reinterpret_cast<float4 *>(p)[i];
+        const float4 gg = reinterpret_cast<const float4 *>(g)[i];
+        float4 mm = reinterpret_cast<float4 *>(m)[i], vv = reinterpret_cast<float4 *>(v)[i];
+        float *pe = &pp.x, *me = &mm.x, *ve = &vv.x;
+        const float *ge = &gg.x;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const float gk = ge[k] * gscale;
+            me[k] = me[k] + (gk - me[k]) * omb1;
+            ve[k] = ve[k] * b2 + omb2 * (gk * gk);
+            const float denom = sqrtf(ve[k]) / bc2_sqrt + eps;
+            pe[k] = pe[k] - step_size * (me[k] / denom);
+        }
+        reinterpret_cast<float4 *>(p)[i] = pp;
+        reinterpret_cast<float4 *>(m)[i] = mm;
+        reinterpret_cast<float4 *>(v)[i] = vv;
+    }
+    for (int64_t i = (n4 << 2) + (int64_t)blockIdx.x * NT + threadIdx.x; i < n; i += (int64_t)gridDim.x * NT) {
+        const float gk = g[i] * gscale;
+        const float mk = m[i] + (gk - m[i]) * omb1;
+        const float vk = v[i] * b2 + omb2 * (gk * gk);
+        m[i] = mk;
+        v[i] = vk;
+        p[i] = p[i] - step_size * (mk / (sqrtf(vk) / bc2_sqrt + eps));
+    }
+}
+
 __global__ void tensor2im_kernel(const float *__restrict__ x, uint8_t *__restrict__ out, int B, int H, int W, int C,
                                  int ncol, int nrw, int unnorm) {
     // out: [C][nrw*H][ncol*W] uint8 ; x NHWC
@@ -607,6 +659,19 @@ extern "C" int hoig_adam_step(float *param, const float *grad, float *exp_avg, f
     adam_kernel<<<hoig_stream_grid(n / 4 + 1, NT), NT, 0, ST>>>(param, grad, exp_avg, exp_avg_sq, n, step_size,
                                                                (float)(1.0 - beta1), (float)beta2, (float)(1.0 - beta2),
                                                                (float)eps, bc2_sqrt, grad_scale);
+    HOIG_LAUNCH_CHECK();
+    return HOIG_OK;
+}
+extern "C" int hoig_adam_tick(double *state, float *derived, hoig_stream_t stream) {
+    if (!state || !derived) return HOIG_EINVAL;
+    adam_tick_kernel<<<1, 64, 0, ST>>>(state, derived);
+    HOIG_LAUNCH_CHECK();
+    return HOIG_OK;
+}
+extern "C" int hoig_adam_step_dev(float *param, const float *grad, float *exp_avg, float *exp_avg_sq, int64_t n,
+                                  const float *derived, float grad_scale, hoig_stream_t stream) {
+    if (!param || !grad || !exp_avg || !exp_avg_sq || !derived) return HOIG_EINVAL;
+    adam_dev_kernel<<<hoig_stream_grid(n / 4 + 1, NT), NT, 0, ST>>>(param, grad, exp_avg, exp_avg_sq, n, derived, grad_scale);
     HOIG_LAUNCH_CHECK();
     return HOIG_OK;
 }

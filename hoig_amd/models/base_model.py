@@ -1,107 +1,106 @@
-"""Model API base + checkpoint helpers (reference: models/base_model.py:7-147).  File names and formats are the
-reference's: ``net_epoch_<label>_id_<G|D>.pth`` = torch.save(state_dict) with NCHW fp32 tensors under the
-reference parameter names, ``opt_epoch_<label>_id_<G|D>.pth`` = torch.optim.Adam-layout state."""
+"""What the reference's drivers expect of any model object (models/base_model.py:7-147), written for the flat-buffer networks.
+
+Only the NAMES are contract here: ``name`` / ``is_train``, the per-iteration verbs a driver calls, and the checkpoint helpers
+``_save_network / _load_network / _save_optimizer / _load_optimizer / _load_params``.  Checkpoint files keep the reference's
+naming scheme and payload -- ``net_epoch_<label>_id_<G|D>.pth`` is ``torch.save(state_dict)`` of NCHW fp32 tensors under the
+reference's parameter names, ``opt_epoch_<label>_id_<G|D>.pth`` a ``torch.optim.Adam``-layout state -- so runs can be resumed
+across the two implementations (hoig_amd/nn.py produces both layouts from the flat buffers).
+"""
 import os
-from collections import OrderedDict
 
 import torch
+
+_DDP_PREFIX = 'module.'
+# verbs a concrete model has to provide itself (the reference's stubs `assert False`; a typed error names the class instead)
+_REQUIRED = ('set_input', 'set_train', 'set_eval', 'forward', 'test', 'optimize_parameters', 'save', 'load')
+
+
+class CheckpointDir(object):
+    """<checkpoints_dir>/<name>/{net,opt}_epoch_<label>_id_<ident>.pth"""
+
+    def __init__(self, root):
+        self.root = root
+
+    def file(self, kind, label, ident):
+        return os.path.join(self.root, '{}_epoch_{}_id_{}.pth'.format(kind, label, ident))
+
+    def write(self, payload, kind, label, ident):
+        os.makedirs(self.root, exist_ok=True)
+        path = self.file(kind, label, ident)
+        torch.save(payload, path)
+        return path
+
+    def read(self, path):
+        if not os.path.isfile(path):
+            raise FileNotFoundError('checkpoint %s does not exist (nothing has been trained / saved under %s yet)'
+                                    % (path, self.root))
+        return torch.load(path, map_location='cpu')
+
+
+def strip_ddp_prefix(state):
+    """Keys saved through a DistributedDataParallel wrapper carry 'module.'; a bare network wants them without
+    (base_model.py:108-116 strips seven characters off every key that mentions 'module')."""
+    return type(state)((k[len(_DDP_PREFIX):] if k.startswith(_DDP_PREFIX) else k, v) for k, v in state.items())
+
+
+def _missing(verb):
+    def stub(self, *args, **kwargs):
+        raise NotImplementedError('%s.%s()' % (type(self).__name__, verb))
+    stub.__name__ = verb
+    return stub
 
 
 class BaseModel(object):
     def __init__(self, opt, use_ddp=False):
-        self._name = 'BaseModel'
+        self._name = type(self).__name__
         self._opt = opt
-        self._gpu_ids = opt.gpu_ids
-        self._is_train = opt.is_train
-        self._use_ddp = use_ddp
+        self._use_ddp = bool(use_ddp)
+        self._is_train = bool(opt.is_train)
+        self._gpu_ids = getattr(opt, 'gpu_ids', None)
         self._save_dir = os.path.join(opt.checkpoints_dir, opt.name)
-        self._G_cond_nc = self._D_cond_nc = getattr(opt, 'cond_nc', 2)
+        self._ckpt = CheckpointDir(self._save_dir)
+        cond_nc = getattr(opt, 'cond_nc', 2)
+        self._G_cond_nc, self._D_cond_nc = cond_nc, cond_nc
 
-    @property
-    def name(self):
-        return self._name
+    name = property(lambda self: self._name)
+    is_train = property(lambda self: self._is_train)
 
-    @property
-    def is_train(self):
-        return self._is_train
-
-    def set_input(self, input):
-        assert False, "set_input not implemented"
-
-    def set_train(self):
-        assert False, "set_train not implemented"
-
-    def set_eval(self):
-        assert False, "set_eval not implemented"
-
-    def forward(self, *input):
-        assert False, "forward not implemented"
-
-    def test(self):
-        assert False, "test not implemented"
-
+    # reporting hooks: empty unless the model has something to say
     def get_image_paths(self):
         return {}
 
-    def optimize_parameters(self):
-        assert False, "optimize_parameters not implemented"
-
-    def get_current_visuals(self):
-        return {}
-
-    def get_current_errors(self):
-        return {}
-
-    def get_current_scalars(self):
-        return {}
-
-    def save(self, label):
-        assert False, "save not implemented"
-
-    def load(self):
-        assert False, "load not implemented"
+    get_current_visuals = get_current_errors = get_current_scalars = get_image_paths
 
     def update_learning_rate(self):
-        pass
+        return None
 
-    # ---- checkpoint files -------------------------------------------------------------------
-    def _path(self, kind, label, ident):
-        return os.path.join(self._save_dir, '%s_epoch_%s_id_%s.pth' % (kind, label, ident))
+    # ---- checkpoints
+    def _save_network(self, network, network_label, epoch_label):
+        print('saved net: %s' % self._ckpt.write(network.state_dict(), 'net', epoch_label, network_label))
 
     def _save_optimizer(self, optimizer, optimizer_label, epoch_label):
-        os.makedirs(self._save_dir, exist_ok=True)
-        torch.save(optimizer.state_dict(), self._path('opt', epoch_label, optimizer_label))
-
-    def _load_optimizer(self, optimizer, optimizer_label, epoch_label):
-        load_path = self._path('opt', epoch_label, optimizer_label)
-        assert os.path.exists(load_path), 'Weights file not found. %s ' \
-                                          'Have you trained a model!? We are not providing one' % load_path
-        optimizer.load_state_dict(torch.load(load_path, map_location='cpu'))
-        print('loaded optimizer: %s' % load_path)
-
-    def _save_network(self, network, network_label, epoch_label):
-        os.makedirs(self._save_dir, exist_ok=True)
-        save_path = self._path('net', epoch_label, network_label)
-        torch.save(network.state_dict(), save_path)
-        print('saved net: %s' % save_path)
+        self._ckpt.write(optimizer.state_dict(), 'opt', epoch_label, optimizer_label)
 
     def _load_network(self, network, network_label, epoch_label, need_module=False):
-        self._load_params(network, self._path('net', epoch_label, network_label), need_module)
+        self._load_params(network, self._ckpt.file('net', epoch_label, network_label), need_module)
 
     def _load_params(self, network, load_path, need_module=False):
-        assert os.path.exists(load_path), \
-            'Weights file not found. Have you trained a model!? We are not providing one %s' % load_path
-        save_data = torch.load(load_path, map_location='cpu')
-        if need_module:
-            network.load_state_dict(save_data)
-        else:
-            state_dict = OrderedDict()
-            for k, v in save_data.items():
-                state_dict[k[7:] if 'module' in k else k] = v      # strip DDP's 'module.' (base_model.py:108-116)
-            network.load_state_dict(state_dict)
+        """need_module=True hands the file's keys to the network untouched (the HOIG_DexYCB copy loads into its DDP wrappers
+        that way, HOIG_DexYCB/models/trainer.py:562,566); otherwise a 'module.' prefix is removed first."""
+        state = self._ckpt.read(load_path)
+        network.load_state_dict(state if need_module else strip_ddp_prefix(state))
         print('Loading net: %s' % load_path)
 
+    def _load_optimizer(self, optimizer, optimizer_label, epoch_label):
+        path = self._ckpt.file('opt', epoch_label, optimizer_label)
+        optimizer.load_state_dict(self._ckpt.read(path))
+        print('loaded optimizer: %s' % path)
+
     def print_network(self, network):
-        num_params = sum(p.numel() for p in network.parameters())
         print(network)
-        print('Total number of parameters: %d' % num_params)
+        print('Total number of parameters: %d' % sum(p.numel() for p in network.parameters()))
+
+
+for _verb in _REQUIRED:
+    setattr(BaseModel, _verb, _missing(_verb))
+del _verb

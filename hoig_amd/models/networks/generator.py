@@ -29,15 +29,14 @@ def as_nchw(t):
     return t.permute(0, 3, 1, 2)
 
 
-_FORK_STREAMS = os.environ.get('HOIG_G_STREAMS', '1') == '1'
-
-
-_FORK_SRC = os.environ.get('HOIG_SRC_STREAM', '1') == '1'
-_INTERLEAVE = os.environ.get('HOIG_INTERLEAVE', '1') == '1'
+# HOIG_STREAMS=0 (alias HOIG_G_STREAMS=0): every chain of the step on the caller's stream -- per-kernel profiles only add up that
+# way.  Default: the sub-networks that do not read each other run on HIP streams of their own ('Concurrent
+# chains'); inside a captured step those forks are the hipGraph's parallel branches.
+_FORK_STREAMS = os.environ.get('HOIG_STREAMS', os.environ.get('HOIG_G_STREAMS', '1')) == '1'
 
 
 def forks_streams():
-    """True if Generator.forward runs bg_model / obj_model on branch streams (their backward then runs there too)."""
+    """True if Generator.forward runs bg_model / obj_model / src_model on branch streams (their backward then runs there too)."""
     return _FORK_STREAMS
 
 
@@ -247,7 +246,6 @@ class Generator(ParamTree):
         # backward on its own stream too).  The weight split is refreshed first, on the main stream.
         main = torch.cuda.current_stream()
         fork = _FORK_STREAMS and bg.is_cuda
-        capturing = fork and torch.cuda.is_current_stream_capturing()      # graph memory is private: no record_stream
         self.refresh_planes()
         bg_in = torch.cat([ops.cat_channels(src_bg_in), ops.cat_channels(tsf_bg_in)], dim=0)
         obj_in = torch.cat([src_obj, tsf_obj], dim=0)
@@ -259,9 +257,8 @@ class Generator(ParamTree):
             s_src.wait_stream(main)
             bg_out, obj_out = [None], [None]
             branches = [(self._bg_net_steps(bg_in, bg_out), s_bg), (self._unet_steps(obj_in, obj_c, 'obj_model', obj_out), s_obj)]
-            if not capturing:
-                for t_, st_ in ((bg_in, s_bg), (obj_in, s_obj), (obj_c, s_obj)):
-                    t_.record_stream(st_)
+            for t_, st_ in ((bg_in, s_bg), (obj_in, s_obj), (obj_c, s_obj)):
+                ops.cross_stream(t_, st_)
         else:
             branches = []
             bg_both = self._bg_net(bg_in)
@@ -275,24 +272,16 @@ class Generator(ParamTree):
                     else:
                         next(gen, None)
 
-        if not _INTERLEAVE:
-            advance(True)
-
         # infer_front (generator.py:379-464).  src_model never reads tsf_model's features, so it runs AHEAD on a stream of its own
         # (HOIG_SRC_STREAM=0: on the main stream); tsf_model waits, level by level, for the src features it warps in.
         import contextlib
-        fork_src = fork and _FORK_SRC
+        fork_src = fork
         on_src = (lambda: torch.cuda.stream(s_src)) if fork_src else contextlib.nullcontext
 
-        keep = []                                            # (capture: record_stream is not available in a graph's private pool,
-                                                             # so tensors that cross streams stay referenced until the join)
         def src_ready(t_):                                   # the main stream may read a tensor made on the src stream
             if fork_src:
                 main.wait_stream(s_src)
-                if capturing:
-                    keep.append(t_)
-                else:
-                    t_.record_stream(main)
+                ops.cross_stream(t_, main)
             return t_
 
         with on_src():
@@ -324,17 +313,15 @@ class Generator(ParamTree):
         if fork:
             main.wait_stream(s_bg)
             main.wait_stream(s_obj)
-            if not capturing:
-                bg_both.record_stream(main)
-                obj_both.record_stream(main)
+            ops.cross_stream(bg_both, main)
+            ops.cross_stream(obj_both, main)
         else:
             obj_both = self._unet(obj_in, obj_c, 'obj_model')
         src_img_bg, tsf_img_bg = bg_both[:nb], bg_both[nb:]
         sy, ty = obj_both[:nb], obj_both[nb:]
         if fork_src:
             s_src.wait_stream(s_obj)                         # the src heads read the object branch's output
-            if not capturing:
-                obj_both.record_stream(s_src)
+            ops.cross_stream(obj_both, s_src)
         with on_src():
             sx = self._decode(sx, s_enc, src_hand_c, 'src_model')
         tx = self._decode(tx, t_enc, tsf_hand_c, 'tsf_model')
@@ -351,10 +338,8 @@ class Generator(ParamTree):
         tsf_hand_o, tsf_mask_hand, tsf_mask_bg = regress(tx, ty, 'tsf_model')
         if fork_src:
             main.wait_stream(s_src)
-            if not capturing:
-                for t_ in (src_hand_o, src_mask_hand, src_mask_bg):
-                    t_.record_stream(main)
-            keep.clear()
+            for t_ in (src_hand_o, src_mask_hand, src_mask_bg):
+                ops.cross_stream(t_, main)
         obj_o = self._conv(obj_both, 'obj_model.img_reg.0', pad=3, act=ACT_TANH)
         src_obj_o, tsf_obj_o = obj_o[:nb], obj_o[nb:]
         self._seg_cache = {}

@@ -82,7 +82,7 @@ class VGGLoss(object):
             fx = self.vgg.forward_nhwc(x)
             main.wait_stream(side)
             for t in fy:
-                t.record_stream(main)
+                ops.cross_stream(t, main)
         else:
             fx = self.vgg.forward_nhwc(x)
             with torch.no_grad():

@@ -28,9 +28,13 @@ from .networks import NetworksFactory
 from .networks.generator import to_nhwc, as_nchw, forks_streams as generator_forks_streams
 from .networks.vgg19 import Vgg19, VGGLoss
 
-_LOSS_STREAMS = os.environ.get('HOIG_LOSS_STREAMS', '1') == '1'
-_D_STREAM = os.environ.get('HOIG_D_STREAM', '1') == '1'
-_PACK_WITH_STEP = os.environ.get('HOIG_PACK_WITH_STEP', '1') == '1'
+# HOIG_GRAPH=0: never capture the training step in a hipGraph (every step issued kernel by kernel, as in rounds 1-2)
+_GRAPH = os.environ.get('HOIG_GRAPH', '1') == '1'
+_GRAPH_WARMUP = 2         # eager steps per input signature before the capture (lazily made buffers and planes then exist)
+_GRAPH_MAX_SIGNATURES = 3
+# test hook (tests/test_trainer_gpu.py): cycles the optimiser side stream idles before each step's exchange + Adam, so that a
+# reader stream that is not ordered behind it shows up as a parity failure instead of hiding behind timing
+_TEST_SIDE_DELAY = 0
 
 PREPARED_KEYS = ['input_G_bg', 'input_G_src_obj', 'input_G_tsf_obj', 'input_G_src_hand', 'input_G_tsf_hand', 'T',
                  'real_src', 'real_tsf', 'bg_mask', 'hand_mask']
@@ -54,6 +58,10 @@ def _labelcolormap(n):
 
 
 class Trainer(BaseModel):
+    _use_graph = False
+    _static_inputs = None
+    _sig = None
+
     def __init__(self, opt, use_ddp=False):
         super(Trainer, self).__init__(opt, use_ddp)
         self._name = 'Trainer'
@@ -70,8 +78,11 @@ class Trainer(BaseModel):
         self._side = torch.cuda.Stream(device=self.device)
         self._loss_streams = None
         self._d_stream = None
-        self._g_ready = None
-        self._d_ready = None
+        self._use_graph = bool(getattr(opt, 'hip_graph', _GRAPH))
+        self._graphs = {}                # (trainable, input signature, arithmetic) -> captured step
+        self._graph_pool = None
+        self._static_inputs = {}         # input signature -> the staged tensors a captured step reads
+        self._sig = None
 
         self._init_create_networks(use_ddp=use_ddp)
         if self._is_train:
@@ -211,6 +222,7 @@ class Trainer(BaseModel):
                     n['%s_%s_cond' % (side, part)] = ops.slice_channels(full, 3, full.shape[-1])
             cond = [n['tsf_obj_cond'], n['tsf_hand_cond']] + ([n['armask_tsf']] if 'armask_tsf' in n else [])
             n['tsf_cond'] = ops.cat_channels(cond)                                            # trainer.py:437,460
+            n = self._n = self._stage_static(n)
             # reference-named NCHW views
             self._input_G_bg = as_nchw(n['input_G_bg'])
             self._input_G_src_obj, self._input_G_tsf_obj = as_nchw(n['input_G_src_obj']), as_nchw(n['input_G_tsf_obj'])
@@ -221,6 +233,23 @@ class Trainer(BaseModel):
             self._bg_mask, self._hand_mask = as_nchw(n['bg_mask']), as_nchw(n['hand_mask'])
             if 'armask_src' in n:
                 self._armask_src, self._armask_tsf = as_nchw(n['armask_src']), as_nchw(n['armask_tsf'])
+
+    def _stage_static(self, n):
+        """A captured step reads its inputs from fixed addresses: the first batch of a shape becomes that shape's staging set
+        (cloned: some entries may alias the caller's tensors), later batches are copied into it (46 MB at 256x256, batch 8)."""
+        sig = tuple(sorted((k, tuple(v.shape)) for k, v in n.items()))
+        self._sig = sig
+        if not (self._use_graph and self._is_train):
+            return n
+        st = self._static_inputs.get(sig)
+        if st is None:
+            if len(self._static_inputs) >= _GRAPH_MAX_SIGNATURES:
+                return n
+            st = self._static_inputs[sig] = {k: v.clone() for k, v in n.items()}
+        else:
+            for k, v in n.items():
+                st[k].copy_(v)
+        return st
 
     def set_train(self):
         self._G.train()
@@ -233,18 +262,13 @@ class Trainer(BaseModel):
 
     # ------------------------------------------------------------------ forward (trainer.py:373-415)
     def _wait_g(self):
-        if self._g_ready is not None:
-            torch.cuda.current_stream().wait_event(self._g_ready)
-            self._g_ready = None
-            self._net(self._G).set_pending(None)
+        """G's previous optimiser step (exchange + Adam + operand planes on the side stream) before the current stream reads G."""
+        self._net(self._G).wait_pending()
 
     def _wait_d(self):
         """D's weights are next needed by the discriminator pass of the G loss, a whole generator forward after the
         D step ended: its exchange (28 MB) + Adam have that long to finish on the side stream."""
-        if self._d_ready is not None:
-            torch.cuda.current_stream().wait_event(self._d_ready)
-            self._d_ready = None
-            self._net(self._D).set_pending(None)
+        self._net(self._D).wait_pending()
 
     def forward(self, keep_data_for_visuals=False, return_estimates=False):
         self._wait_g()
@@ -264,76 +288,180 @@ class Trainer(BaseModel):
 
     # ------------------------------------------------------------------ one GAN iteration (trainer.py:417-434)
     def optimize_parameters(self, trainable=True, keep_data_for_visuals=False):
+        """forward -> G loss -> zero / backward / Adam(G) -> if `trainable`: D loss -> zero / backward / Adam(D).  After
+        _GRAPH_WARMUP eager iterations on a batch shape the whole iteration is captured in a hipGraph and replayed from then on
+        (one host call per step instead of ~1 500 launches); iterations that keep data for visuals run eagerly."""
         if not self._is_train:
             return
+        if self._use_graph and not keep_data_for_visuals:
+            self._graph_step(bool(trainable))
+        else:
+            self._eager_step(trainable, keep_data_for_visuals)
+
+    def _sync_active(self):
+        return isinstance(self._G, FlatDDP) and self._G.sync.active
+
+    def _eager_step(self, trainable=True, keep_data_for_visuals=False):
+        fake_tsf_imgs, ev_fwd = self._phase_g(keep_data_for_visuals)
+        self._step(self._G, self._optimizer_G, overlap=trainable)
+        if trainable:
+            self._phase_d(fake_tsf_imgs, ev_fwd)
+            self._wait_g()            # G's update has had the whole D step to finish; later readers need no special care
+            self._step(self._D, self._optimizer_D, overlap=True)
+
+    def _phase_g(self, keep_data_for_visuals=False):
+        """Forward, the G loss and its backward (trainer.py:419-427).  Returns the fake target image and the event that marks the
+        end of the forward (what the D step waits for)."""
         _, _, fake_src_imgs, fake_tsf_imgs, fake_masks_bg, fake_masks_hand = \
             self.forward(keep_data_for_visuals=keep_data_for_visuals)
-        ev_fwd = None
-        if fake_tsf_imgs.is_cuda:
-            ev_fwd = torch.cuda.Event()
-            ev_fwd.record(torch.cuda.current_stream())
-
+        ev_fwd = torch.cuda.Event()
+        ev_fwd.record(torch.cuda.current_stream())
         netD = self._net(self._D)
         netD.set_requires_grad(False)       # the reference computes D grads here and zeroes them at :432
         loss_G = self._optimize_G(fake_src_imgs, fake_tsf_imgs, fake_masks_bg, fake_masks_hand)
         self._optimizer_G.zero_grad()
-        ops.pause_wgrad_side(generator_forks_streams())     # G's backward is three concurrent chains already
+        ops.pause_wgrad_side(generator_forks_streams())     # G's backward is several concurrent chains already
         loss_G.backward()
         ops.pause_wgrad_side(False)
         netD.set_requires_grad(True)
-        self._step(self._G, self._optimizer_G, overlap=trainable)
+        return fake_tsf_imgs, ev_fwd
 
-        if trainable:
-            # The D step reads the fake image and D's weights, nothing of G's backward: it runs on a stream of its own that only
-            # waits for the generator's forward, i.e. BESIDE G's backward chains (HOIG_D_STREAM=0: after them, on the caller's
-            # stream).  D's Adam still follows G's backward through D: it is queued on the side stream behind G's step, which waited
-            # for every backward stream.
-            d_fork = _D_STREAM and ev_fwd is not None and generator_forks_streams()     # (HOIG_G_STREAMS=0: one stream for everything)
-            if d_fork:
-                main = torch.cuda.current_stream()
-                if self._d_stream is None:
-                    self._d_stream = torch.cuda.Stream(device=self.device)
-                self._d_stream.wait_event(ev_fwd)
-                fake_tsf_imgs.record_stream(self._d_stream)
-                with torch.cuda.stream(self._d_stream):
-                    self._d_step(fake_tsf_imgs)
-                main.wait_stream(self._d_stream)
-            else:
-                self._d_step(fake_tsf_imgs)
+    def _phase_d(self, fake_tsf_imgs, ev_fwd=None):
+        """The D loss and its backward (trainer.py:429-433).  It reads the fake image and D's weights, nothing of G's backward:
+        given the forward's event it runs on a stream of its own that only waits for the generator's forward, i.e. BESIDE G's
+        backward chains.  D's Adam still follows G's backward through D: it is queued on the side stream behind G's step, which
+        waited for every backward stream."""
+        if ev_fwd is not None and generator_forks_streams():
+            main = torch.cuda.current_stream()
+            if self._d_stream is None:
+                self._d_stream = torch.cuda.Stream(device=self.device)
+            self._d_stream.wait_event(ev_fwd)
+            ops.cross_stream(fake_tsf_imgs, self._d_stream)
+            with torch.cuda.stream(self._d_stream):
+                self._d_backward(fake_tsf_imgs)
+            main.wait_stream(self._d_stream)
+        else:
+            self._d_backward(fake_tsf_imgs)
 
-    def _d_step(self, fake_tsf_imgs):
-        loss_D = self._optimize_D(fake_tsf_imgs)
+    def _d_backward(self, fake_tsf_imgs):
+        loss_D = self._optimize_D(fake_tsf_imgs)          # (waits for D's previous update on THIS stream: _wait_d)
         self._optimizer_D.zero_grad()
         loss_D.backward()
-        self._wait_g()                # G's update has had the whole D step to finish; later readers need no special care
-        self._step(self._D, self._optimizer_D, overlap=True, which='d')
 
-    def _step(self, net, optimizer, overlap, which='g'):
-        """gradient exchange (RCCL, under DDP) + fused Adam.  With `overlap` both run on the side stream: G's beside the D step
-        that follows on the main stream (which never touches G's parameters: 734 MB of exchange, 5 GB of Adam traffic), D's
-        beside the next generator forward; the next reader of the network waits for the event (_wait_g / _wait_d)."""
+    def _step(self, net, optimizer, overlap):
+        """gradient exchange (RCCL, under DDP) + fused Adam + the operand planes of the new weights.  With `overlap` they run on
+        the side stream: G's beside the D step that follows on the main stream (which never touches G's parameters: 734 MB of
+        exchange, 5 GB of Adam traffic), D's beside the next generator forward; every later reader of the network waits for the
+        event (ParamTree.wait_pending, _wait_g / _wait_d)."""
         ddp = isinstance(net, FlatDDP) and net.sync.active
-        if overlap:
-            main = torch.cuda.current_stream()
-            self._side.wait_stream(main)
-            with torch.cuda.stream(self._side):
-                if ddp:           # Adam of slice i runs while slices i+1.. are still being exchanged
-                    optimizer.step(grad_scale=1.0 / net.sync.world, ready=net.sync.iter_all_reduce())
-                else:
-                    optimizer.step()
-                if _PACK_WITH_STEP:        # the operand planes of the new weights too: off the next forward's critical path
-                    self._net(net).refresh_planes()
-                ev = torch.cuda.Event()
-                ev.record(self._side)
-            self._net(net).set_pending(ev)       # anyone who reads the network through its own API waits too
-            if which == 'g':
-                self._g_ready = ev
+        tree = self._net(net)
+
+        def run():
+            if ddp:           # Adam of slice i runs while slices i+1.. are still being exchanged
+                optimizer.step(grad_scale=1.0 / net.sync.world, ready=net.sync.iter_all_reduce())
             else:
-                self._d_ready = ev
-        elif ddp:
-            optimizer.step(grad_scale=1.0 / net.sync.world, ready=net.sync.iter_all_reduce())
+                optimizer.step()
+            tree.refresh_planes()      # off the next forward's critical path
+
+        if not overlap:
+            tree.wait_pending()
+            return run()
+        main = torch.cuda.current_stream()
+        self._side.wait_stream(main)
+        with torch.cuda.stream(self._side):
+            if _TEST_SIDE_DELAY and not ops.capturing():
+                torch.cuda._sleep(int(_TEST_SIDE_DELAY))
+            tree.set_pending(None)     # (this stream IS the writer: the previous step ran here too)
+            run()
+            ev = torch.cuda.Event()
+            ev.record(self._side)
+        tree.set_pending(ev)
+
+    # ------------------------------------------------------------------ the captured step
+    def _graph_key(self, trainable):
+        return (trainable, self._sig, ops.precision, ops.precision_dgrad, ops.precision_wgrad, self._sync_active())
+
+    def _graph_step(self, trainable):
+        key = self._graph_key(trainable)
+        st = self._graphs.get(key)
+        if st is None:
+            if len(self._graphs) >= _GRAPH_MAX_SIGNATURES or self._static_inputs.get(self._sig) is not self._n:
+                return self._eager_step(trainable)
+            st = self._graphs[key] = dict(seen=0, graphs=None)
+        if st['graphs'] is None:
+            if st['seen'] < _GRAPH_WARMUP:
+                st['seen'] += 1
+                return self._eager_step(trainable)
+            self._capture_step(st, trainable)
+        self._replay_step(st, trainable)
+
+    def _quiesce(self):
+        """Nothing of a previous step may still be in flight when a capture starts (events recorded outside a capture cannot be
+        waited for inside it)."""
+        self._wait_g()
+        self._wait_d()
+        torch.cuda.synchronize(self.device)
+        self._net(self._G).set_pending(None)
+        self._net(self._D).set_pending(None)
+
+    def _capture(self, body):
+        graph = torch.cuda.CUDAGraph()
+        with ops.graph_capture(graph, pool=self._graph_pool):
+            out = body()
+        if self._graph_pool is None:
+            self._graph_pool = graph.pool()
+        return graph, out
+
+    def _capture_step(self, st, trainable):
+        """Single GPU: the whole iteration is ONE graph (its streams become the graph's parallel branches; the optimiser steps run
+        inside it from device-resident schedules).  Under DDP the RCCL exchange stays outside: graph 1 = forward + G loss + G
+        backward, then G's exchange + Adam eagerly on the side stream, beside graph 2 = the D loss and backward, then D's."""
+        self._quiesce()
+        opts = (self._optimizer_G, self._optimizer_D)
+        for o in opts:
+            o.sync_state()
+        before = [o.step_count for o in opts]
+        if not self._sync_active():
+            def body():
+                self._eager_step(trainable)
+                if trainable:         # (the optimiser side stream forked into the capture: join it back)
+                    torch.cuda.current_stream().wait_stream(self._side)
+            graph, _ = self._capture(body)
+            st['graphs'] = (graph,)
+            # the capture ran the host side of one step without executing it: the replay that follows does
+            for o, b in zip(opts, before):
+                o.step_count = b
+                o._on_device = o._on_device[:4] + (float(b),)
         else:
-            optimizer.step()
+            g1, fake = self._capture(lambda: self._phase_g()[0])
+            g2 = self._capture(lambda: self._phase_d(fake))[0] if trainable else None
+            st['graphs'] = (g1, g2)
+            st['fake'] = fake
+        self._net(self._G).set_pending(None)
+        self._net(self._D).set_pending(None)
+
+    def _replay_step(self, st, trainable):
+        for tree in (self._net(self._G), self._net(self._D), self._crt_tsf.vgg if self._opt.use_vgg else None):
+            if tree is not None:
+                tree.refresh_planes()        # (a no-op unless weights were loaded since the last step)
+        if len(st['graphs']) == 1:
+            self._optimizer_G.sync_state()
+            if trainable:
+                self._optimizer_D.sync_state()
+            st['graphs'][0].replay()
+            self._optimizer_G.replayed()
+            if trainable:
+                self._optimizer_D.replayed()
+            return
+        g1, g2 = st['graphs']
+        self._wait_g()
+        self._wait_d()
+        g1.replay()
+        self._step(self._G, self._optimizer_G, overlap=trainable)
+        if trainable:
+            g2.replay()
+            self._wait_g()
+            self._step(self._D, self._optimizer_D, overlap=True)
 
     def _optimize_G(self, fake_src_imgs, fake_tsf_imgs, fake_masks_bg, fake_masks_hand):
         """trainer.py:436-457."""
@@ -343,7 +471,7 @@ class Trainer(BaseModel):
         # The adversarial term (D on the fake) and the perceptual term (VGG on the fake, VGG on the target) do not read each other:
         # three chains on three streams, like the generator's sub-networks (their backward replays there too); HOIG_LOSS_STREAMS=0:
         # one after the other on the caller's stream.
-        fork = _LOSS_STREAMS and fake_tsf.is_cuda and generator_forks_streams()
+        fork = fake_tsf.is_cuda and generator_forks_streams()
         if fork:
             main = torch.cuda.current_stream()
             # operand planes are (re)made lazily by whoever asks first: make D's and VGG's here, on the caller's stream, so that
@@ -358,7 +486,7 @@ class Trainer(BaseModel):
                 self._wait_d()
                 d_fake = self._D.forward_nhwc(ops.cat_channels([fake_tsf, n['tsf_cond']]))
                 self._loss_g_adv = ops.lsgan_loss(d_fake, 0.0, o.lambda_D_prob)
-            fake_tsf.record_stream(s_adv)
+            ops.cross_stream(fake_tsf, s_adv)
         else:
             s_vgg = None
             self._wait_d()
@@ -369,7 +497,7 @@ class Trainer(BaseModel):
         self._loss_g_tsf = self._crt_tsf.forward_nhwc(fake_tsf, n['real_tsf'], o.lambda_tsf, side=s_vgg)
         if fork:
             main.wait_stream(s_adv)
-            self._loss_g_adv.record_stream(main)
+            ops.cross_stream(self._loss_g_adv, main)
         crt = ops.bce_loss if o.mask_bce else ops.mse_loss
         self._loss_g_mask = crt(mbg, n['bg_mask'], o.lambda_mask) + crt(mh, n['hand_mask'], o.lambda_mask)
         if o.lambda_mask_smooth != 0:

@@ -44,6 +44,23 @@ def merge_attn_weight(wt, ws):
     return torch.cat([wt, ws], dim=1)
 
 
+class PendingUpdate(object):
+    """An optimiser step of a network (gradient exchange, Adam, operand packing) queued on a side stream.  EVERY stream that
+    touches the network's buffers afterwards waits for it -- once per stream: the object remembers who has -- and it stays in
+    place until the next step replaces it (a one-shot event, cleared by whichever stream asked first, left the other reader
+    streams unordered)."""
+
+    def __init__(self, event):
+        self.event = event
+        self._waited = set()
+
+    def wait(self, stream=None):
+        stream = torch.cuda.current_stream() if stream is None else stream
+        if stream.cuda_stream not in self._waited:
+            stream.wait_event(self.event)
+            self._waited.add(stream.cuda_stream)
+
+
 class ParamTree(nn.Module):
     """A module tree generated from dotted parameter names; parameters are views of flat buffers."""
 
@@ -237,13 +254,12 @@ class ParamTree(nn.Module):
         return f['bufs'][0][a:a + n], f['bufs'][1][a:a + n]
 
     def set_pending(self, event):
-        """An update of this network's buffers is in flight on another stream; readers call wait_pending() first."""
-        self._pending = event
+        """An update of this network's buffers is in flight on another stream (None: no longer); readers call wait_pending()."""
+        self._pending = PendingUpdate(event) if event is not None else None
 
-    def wait_pending(self):
-        ev, self._pending = self._pending, None
-        if ev is not None:
-            torch.cuda.current_stream().wait_event(ev)
+    def wait_pending(self, stream=None):
+        if self._pending is not None:
+            self._pending.wait(stream)
 
     def _register(self, dotted, p):
         parts = dotted.split('.')
@@ -349,7 +365,12 @@ class FusedAdam(object):
     """torch.optim.Adam semantics (lr, betas, eps=1e-8, no weight decay / amsgrad: trainer.py:275-278) as ONE
     kernel over the network's flat buffers.  ``state_dict()`` / ``load_state_dict()`` use torch.optim.Adam's
     per-parameter layout over the REFERENCE parameter list so optimiser checkpoints interoperate
-    (base_model.py:78-90)."""
+    (base_model.py:78-90).
+
+    The schedule lives in DEVICE memory ({lr, beta1, beta2, eps, step}: hoig_adam_tick advances the step count and derives the
+    bias corrections there), so a step is a pure function of device state and can be captured in a hipGraph
+    (Trainer._graph_step).  ``param_groups`` / ``step_count`` are the host's view: a change made on the host (a new learning
+    rate, a loaded checkpoint) is uploaded before the next step; a replayed step is reported with ``replayed()``."""
 
     def __init__(self, tree, lr, betas=(0.9, 0.999), eps=1e-8):
         self.tree = tree
@@ -358,23 +379,48 @@ class FusedAdam(object):
         self.exp_avg = torch.zeros_like(tree.flat)
         self.exp_avg_sq = torch.zeros_like(tree.flat)
         self.step_count = 0
+        self._state = torch.zeros(5, dtype=torch.float64, device=tree.flat.device)
+        self._derived = torch.zeros(8, dtype=torch.float32, device=tree.flat.device)
+        self._on_device = None          # the host values self._state was last written from
 
     def zero_grad(self, set_to_none=False):
         join_wgrad_streams()
         self.tree.flat_grad.zero_()
 
+    def _host_state(self):
+        g = self.param_groups[0]
+        return (float(g['lr']), float(g['betas'][0]), float(g['betas'][1]), float(g['eps']), float(self.step_count))
+
+    def sync_state(self):
+        """Upload the host's schedule if it differs from what the device holds (construction, update_learning_rate, a loaded
+        checkpoint).  Never inside a capture: a captured step must start from the steady state."""
+        want = self._host_state()
+        if want != self._on_device:
+            from . import ops
+            if ops.capturing():
+                raise RuntimeError('FusedAdam: the optimiser schedule changed while a hipGraph was being captured')
+            self._state.copy_(torch.tensor(want, dtype=torch.float64))
+            self._on_device = want
+
+    def replayed(self):
+        """A captured step of this optimiser has been replayed: the device advanced its step count, follow it."""
+        self.step_count += 1
+        self._on_device = self._on_device[:4] + (float(self.step_count),)
+        # (tree.version stays: it only keys the operand-plane caches, which the captured step re-packs itself)
+
     def step(self, grad_scale=1.0, ready=None):
         """One Adam step over the flat buffers.  `ready` (DDP): an iterator of (begin, end) element ranges whose gradients
         have just been exchanged -- the update of a range is launched as soon as it is yielded, so Adam pipelines behind
         the sliced all-reduce instead of waiting for the last slice (GradSync.iter_all_reduce)."""
-        g = self.param_groups[0]
-        self.step_count += 1
+        self.sync_state()
         join_wgrad_streams()
+        L.call('hoig_adam_tick', _p(self._state), _p(self._derived), _st())
+        self.step_count += 1
+        self._on_device = self._on_device[:4] + (float(self.step_count),)
         fl, gr, m, v = self.tree.flat, self.tree.flat_grad, self.exp_avg, self.exp_avg_sq
         for a, b in (ready if ready is not None else [(0, fl.numel())]):
-            L.call('hoig_adam_step', fl.data_ptr() + 4 * a, gr.data_ptr() + 4 * a, m.data_ptr() + 4 * a,
-                   v.data_ptr() + 4 * a, b - a, g['lr'], g['betas'][0], g['betas'][1], g['eps'], self.step_count,
-                   grad_scale, _st())
+            L.call('hoig_adam_step_dev', fl.data_ptr() + 4 * a, gr.data_ptr() + 4 * a, m.data_ptr() + 4 * a,
+                   v.data_ptr() + 4 * a, b - a, _p(self._derived), grad_scale, _st())
         self.tree.version += 1
 
     def state_dict(self):

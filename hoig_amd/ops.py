@@ -160,10 +160,76 @@ def _wgrad_side_stream(device):
     s = _wgrad_streams.get(device)
     if s is None:
         s = _wgrad_streams[device] = torch.cuda.Stream(device=device)
+    if _capture_depth:
+        _capture_forked.add(s)
     return s
 
 
 _wgrad_pending = collections.deque()
+
+# --- hipGraph capture (Trainer._graph_step): while a step is being CAPTURED nothing executes, memory comes from the graph's
+# private pool (no record_stream there) and events may not be queried.  A tensor that is used on a stream other than the one it
+# was allocated on is then simply kept referenced until the capture ends: the pool never hands its block to another tensor of
+# the capture, which is what record_stream() guarantees in eager mode.
+_capture_depth = 0
+_capture_hold = []
+
+
+_capture_forked = set()        # weight-gradient side streams that have joined the capture (and must be joined back before it ends)
+
+
+def capturing():
+    """True while a hipGraph is being captured -- through graph_capture() below, or by a caller's own torch.cuda.graph()."""
+    return _capture_depth > 0 or torch.cuda.is_current_stream_capturing()
+
+
+def begin_capture():
+    global _capture_depth
+    _capture_depth += 1
+
+
+def end_capture():
+    global _capture_depth
+    _capture_depth -= 1
+    if _capture_depth == 0:
+        _capture_hold.clear()
+        _capture_forked.clear()
+        _wgrad_pending.clear()
+
+
+class graph_capture(object):
+    """``with ops.graph_capture(graph, pool=None):`` = ``torch.cuda.graph`` plus this module's capture bookkeeping."""
+
+    def __init__(self, graph, pool=None):
+        self._ctx = torch.cuda.graph(graph, pool=pool)
+
+    def __enter__(self):
+        begin_capture()
+        try:
+            return self._ctx.__enter__()
+        except BaseException:
+            end_capture()
+            raise
+
+    def __exit__(self, *exc):
+        try:
+            if exc[0] is None:
+                join_wgrad_streams()
+            return self._ctx.__exit__(*exc)
+        finally:
+            end_capture()
+
+
+def cross_stream(t, stream):
+    """Tensor `t`, allocated on another stream, is (about to be) used on `stream`: keep its memory out of the allocator's hands
+    until that use has run."""
+    if t is None:
+        return t
+    if capturing():
+        _capture_hold.append(t)
+    else:
+        t.record_stream(stream)
+    return t
 
 
 def _wgrad_hold(side, tensors):
@@ -173,6 +239,11 @@ def _wgrad_hold(side, tensors):
     buffer, and once the convolution's backward has returned, the accumulation may overwrite dy while the side stream is
     still reading it.  A live reference keeps the accumulation out of place; record_stream() alone only guards reuse after
     free."""
+    if capturing():                     # (a captured event cannot be queried; the references live until the capture ends)
+        _capture_hold.append(tensors)
+        return
+    for t in tensors:
+        t.record_stream(side)
     ev = torch.cuda.Event()
     ev.record(side)
     _wgrad_pending.append((ev, tensors))
@@ -183,6 +254,11 @@ def _wgrad_hold(side, tensors):
 def join_wgrad_streams():
     """Make the current stream wait for every weight gradient launched on a side stream (called before anything reads a
     flat gradient buffer: the optimiser step, the gradient all-reduce)."""
+    if capturing():                 # only streams that forked INTO the capture may be waited for inside it
+        for s in list(_capture_forked):
+            torch.cuda.current_stream(s.device).wait_stream(s)
+        _capture_forked.clear()
+        return
     for s in _wgrad_streams.values():
         torch.cuda.current_stream(s.device).wait_stream(s)
     _wgrad_pending.clear()          # later work on this stream is ordered after the side stream's reads
@@ -243,8 +319,6 @@ class _Conv(Function):
                 side.wait_stream(torch.cuda.current_stream())
                 with torch.cuda.stream(side):
                     call('hoig_conv2d_bwd_weight', ctypes.byref(ctx.d_wg), _p(x), _p(g), _p(dw), _p(db), _st())
-                x.record_stream(side)
-                g.record_stream(side)
                 _wgrad_hold(side, (x, g))
             else:
                 call('hoig_conv2d_bwd_weight', ctypes.byref(ctx.d_wg), _p(x), _p(g), _p(dw), _p(db), _st())
@@ -301,8 +375,6 @@ class _ConvCat2(Function):
             side.wait_stream(torch.cuda.current_stream())
             with torch.cuda.stream(side):
                 call('hoig_conv2d_cat_bwd_weight', ctypes.byref(ctx.d_wg), _p(x1), C1, _p(x2), _p(dy), _p(dw), None, _st())
-            for t in (x1, x2, dy):
-                t.record_stream(side)
             _wgrad_hold(side, (x1, x2, dy))
         else:
             call('hoig_conv2d_cat_bwd_weight', ctypes.byref(ctx.d_wg), _p(x1), C1, _p(x2), _p(dy), _p(dw), None, _st())
@@ -789,8 +861,6 @@ class _AttnSourceConv(Function):
             side.wait_stream(torch.cuda.current_stream())
             with torch.cuda.stream(side):
                 call('hoig_conv2d_bwd_weight', ctypes.byref(ds_wg), _p(spad), _p(dgs), _p(gw), None, _st())
-            for t in (spad, dgs):
-                t.record_stream(side)
             _wgrad_hold(side, (spad, dgs))
         else:
             call('hoig_conv2d_bwd_weight', ctypes.byref(ds_wg), _p(spad), _p(dgs), _p(gw), None, _st())
@@ -856,8 +926,6 @@ class _LocalAttn(Function):
             side.wait_stream(torch.cuda.current_stream())
             with torch.cuda.stream(side):
                 call('hoig_conv2d_bwd_weight', ctypes.byref(dt_wg), _p(tpad), _p(dhid), _p(gs[0][0]), _p(gs[1][0]), _st())
-            for t in (tpad, dhid):
-                t.record_stream(side)
             _wgrad_hold(side, (tpad, dhid))
         else:
             call('hoig_conv2d_bwd_weight', ctypes.byref(dt_wg), _p(tpad), _p(dhid), _p(gs[0][0]), _p(gs[1][0]), _st())

@@ -290,6 +290,14 @@ int hoig_sum(const float *x, float *out, int64_t n, hoig_stream_t stream);
 int hoig_adam_step(float *param, const float *grad, float *exp_avg, float *exp_avg_sq, int64_t n, double lr,
                    double beta1, double beta2, double eps, int step, float grad_scale, hoig_stream_t stream);
 
+/* The same update with the schedule in DEVICE memory (an optimiser step that can be captured in a hipGraph):
+ * `state` = {lr, beta1, beta2, eps, step} as doubles (the host only ever rewrites lr: Trainer.update_learning_rate,
+ * trainer.py:574-591); hoig_adam_tick advances state[4] by one and writes the six fp32 scalars of this step into `derived`
+ * (bias corrections evaluated in double, as hoig_adam_step does on the host); hoig_adam_step_dev applies them to a slice. */
+int hoig_adam_tick(double *state, float *derived, hoig_stream_t stream);
+int hoig_adam_step_dev(float *param, const float *grad, float *exp_avg, float *exp_avg_sq, int64_t n, const float *derived,
+                       float grad_scale, hoig_stream_t stream);
+
 /* eval.py output stage (utils/util.py:249-264): uint8 = (x+1)/2*255 truncated, NHWC fp32 -> CHW uint8 grid tile */
 int hoig_tensor2im_u8(const float *x, uint8_t *out, int B, int H, int W, int C, int nrow, int unnormalize,
                       hoig_stream_t stream);
