@@ -323,8 +323,21 @@ class Trainer(BaseModel):
         ops.pause_wgrad_side(generator_forks_streams())     # G's backward is several concurrent chains already
         loss_G.backward()
         ops.pause_wgrad_side(False)
+        self._join_backward_streams()
         netD.set_requires_grad(True)
         return fake_tsf_imgs, ev_fwd
+
+    def _join_backward_streams(self):
+        """Autograd replays every chain's backward on the stream of its forward and, when it returns, has synchronised the
+        caller's stream only with the streams of gradient-accumulation LEAVES.  This path has none (weight gradients are
+        accumulated by the kernels themselves, the inputs need no gradient), so the tails of the branch chains -- the first
+        layers' weight gradients on the bg / obj / src streams, VGG's and D's data gradients on the loss streams -- would be
+        ordered before nothing: join them, so that zero_grad / the optimiser step (and the end of a captured graph) follow
+        them."""
+        main = torch.cuda.current_stream()
+        streams = list(getattr(self._net(self._G), '_streams', None) or ()) + list(self._loss_streams or ())
+        for st in streams:
+            main.wait_stream(st)
 
     def _phase_d(self, fake_tsf_imgs, ev_fwd=None):
         """The D loss and its backward (trainer.py:429-433).  It reads the fake image and D's weights, nothing of G's backward:
