@@ -47,6 +47,38 @@ def _dev(t, dtype, name):
     return t.to(dtype).contiguous()
 
 
+def _check_ranges(rng, n_faces):
+    for i, nf in enumerate(n_faces):
+        for name, lo, hi in (('src_fim', rng[i][0], rng[i][1]), ('ref_fim', rng[i][2], rng[i][3])):
+            if lo < -1 or hi >= nf:
+                raise IndexError('%s[%d] holds face indices in [%d, %d]; the sample has %d faces' % (name, i, lo, hi, nf))
+
+
+_range_checks = []
+
+
+def _deferred_range_check(rng, n_faces):
+    """validate='deferred' (the training loop, Trainer.set_rasterised_input): the batch's index ranges go to pinned host memory
+    with an asynchronous copy and are examined when the NEXT batch is prepared (or by flush_range_checks()), by which time the
+    copy has long finished -- the host never waits for the device inside the step.  An out-of-range index is still reported,
+    one batch late, as the IndexError the reference's indexing would raise."""
+    flush_range_checks(wait=False)
+    host = torch.empty(tuple(rng.shape), dtype=rng.dtype, pin_memory=True)
+    host.copy_(rng, non_blocking=True)
+    ev = torch.cuda.Event()
+    ev.record()
+    _range_checks.append((ev, host, n_faces))
+
+
+def flush_range_checks(wait=True):
+    """Examine the index ranges of batches prepared with validate='deferred' (all of them if `wait`, else those whose copy
+    has completed)."""
+    while _range_checks and (wait or _range_checks[0][0].query()):
+        ev, host, n_faces = _range_checks.pop(0)
+        ev.synchronize()
+        _check_ranges(host.tolist(), n_faces)
+
+
 def prepare_inputs(src_img, ref_img, src_faces, src_fim, src_wim, ref_fim, ref_wim, tables, bg_both=False, dexycb=False,
                    validate=True):
     """trainer.py:46-145 after the rasteriser.  src_img / ref_img (B,3,256,256); src_faces (B,F,3,3) as returned by
@@ -54,8 +86,9 @@ def prepare_inputs(src_img, ref_img, src_faces, src_fim, src_wim, ref_fim, ref_w
     *_wim (B,256,256,3); tables: one ObjectTables per sample; dexycb: the DexYCB copy's hand inputs (12 channels: + the six
     hand-part one-hots, HOIG_DexYCB/models/trainer.py:131,135); validate (default on): check that every face index addresses
     its sample's tables, as the reference's indexing would raise IndexError (the kernels index unchecked: an out-of-range face
-    would be a device memory fault) -- one small reduction and one host read per batch; pass False only for inputs that come
-    straight from hoig_amd.raster, whose indices are in range by construction.
+    would be a device memory fault) -- one small reduction and one host read per batch; 'deferred': the same check without the
+    host waiting for the device (reported when the next batch is prepared; _deferred_range_check); False only for inputs
+    that come straight from hoig_amd.raster, whose indices are in range by construction.
     Returns (input_G_src_bg, input_G_tsf_bg | None, input_G_src_obj, input_G_tsf_obj, input_G_src_hand, input_G_ref_hand,
     T_hand, src_crop_mask_bg, ref_crop_mask_bg, src_crop_mask_hand, ref_crop_mask_hand, None)."""
     B = int(src_img.shape[0])
@@ -68,14 +101,18 @@ def prepare_inputs(src_img, ref_img, src_faces, src_fim, src_wim, ref_fim, ref_w
     src_fim, ref_fim = _dev(src_fim, torch.int32, 'src_fim'), _dev(ref_fim, torch.int32, 'ref_fim')
     src_wim, ref_wim = _dev(src_wim, torch.float32, 'src_wim'), _dev(ref_wim, torch.float32, 'ref_wim')
     if validate:
-        # one reduction + one host read for the whole batch: [B,4] = (min, max) of the two index maps of every sample
+        # one reduction for the whole batch: [B,4] = (min, max) of the two index maps of every sample
         rng = torch.stack([src_fim.amin(dim=(1, 2)), src_fim.amax(dim=(1, 2)), ref_fim.amin(dim=(1, 2)),
-                           ref_fim.amax(dim=(1, 2))], dim=1).cpu().tolist()
-        for i, tb in enumerate(tables):
-            for name, lo, hi in (('src_fim', rng[i][0], rng[i][1]), ('ref_fim', rng[i][2], rng[i][3])):
-                if lo < -1 or hi >= tb.n_faces:
-                    raise IndexError('%s[%d] holds face indices in [%d, %d]; the sample has %d faces' % (name, i, lo, hi,
-                                                                                                      tb.n_faces))
+                           ref_fim.amax(dim=(1, 2))], dim=1)
+        n_faces = [tb.n_faces for tb in tables]
+        if validate == 'deferred':
+            _deferred_range_check(rng, n_faces)
+            # the kernels index unchecked: until the report arrives, keep a bad index from becoming a memory fault
+            top = torch.tensor(n_faces, dtype=torch.int32).to(src_fim.device, non_blocking=True).view(B, 1, 1) - 1
+            src_fim = torch.minimum(src_fim, top).clamp_min_(-1)
+            ref_fim = torch.minimum(ref_fim, top).clamp_min_(-1)
+        else:
+            _check_ranges(rng.cpu().tolist(), n_faces)
     dev = src_img.device
     new = lambda *shape: torch.empty(shape, dtype=torch.float32, device=dev)
     st = torch.cuda.current_stream().cuda_stream

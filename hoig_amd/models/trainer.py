@@ -195,7 +195,8 @@ class Trainer(BaseModel):
             t = {k: (v.to(dev, non_blocking=True) if torch.is_tensor(v) else v) for k, v in inp.items()}
             tabs = [tb if isinstance(tb, IP.ObjectTables) else IP.ObjectTables(tb, dev) for tb in t['tables']]
             out = IP.prepare_inputs(t['src_img'], t['ref_img'], t['src_faces'], t['src_fim'], t['src_wim'], t['ref_fim'],
-                                    t['ref_wim'], tabs, bg_both=bool(getattr(self._opt, 'bg_both', False)), dexycb=self._dexycb)
+                                    t['ref_wim'], tabs, bg_both=bool(getattr(self._opt, 'bg_both', False)), dexycb=self._dexycb,
+                                    validate='deferred')        # (no host wait inside the training loop)
             return self.set_prepared_input(IP.to_prepared(out, t['src_img'].float(), t['ref_img'].float(),
                                                           t.get('maskA'), t.get('maskB')))
 
@@ -626,25 +627,34 @@ class Trainer(BaseModel):
         self._save_optimizer(self._optimizer_D, 'D', label)
 
     def load(self):
+        """HOIG_HOv3/models/trainer.py:562-575; the HOIG_DexYCB copy (its trainer.py:558-573) differs twice: it hands the file's
+        keys to the (DDP-wrapped) networks as saved (`need_module=True`), and after restoring the optimisers it REPLAYS the
+        linear learning-rate decay from the initial rate for the epochs past `nepochs_no_decay` (the rate in the optimiser
+        file is overridden)."""
         load_epoch = self._opt.load_epoch
-        self._load_network(self._G, 'G', load_epoch, need_module=False)
+        need_module = self._dexycb
+        self._load_network(self._G, 'G', load_epoch, need_module=need_module)
         if self._is_train:
-            self._load_network(self._D, 'D', load_epoch, need_module=False)
+            self._load_network(self._D, 'D', load_epoch, need_module=need_module)
             self._load_optimizer(self._optimizer_G, 'G', load_epoch)
             self._load_optimizer(self._optimizer_D, 'D', load_epoch)
+            no_decay = getattr(self._opt, 'nepochs_no_decay', None)
+            if self._dexycb and no_decay is not None and load_epoch > no_decay:
+                for _ in range(no_decay, load_epoch):
+                    self.update_learning_rate()
 
     def update_learning_rate(self):
-        final_lr = self._opt.final_lr
-        lr_decay_G = (self._opt.lr_G - final_lr) / self._opt.nepochs_decay
-        self._current_lr_G -= lr_decay_G
-        for param_group in self._optimizer_G.param_groups:
-            param_group['lr'] = self._current_lr_G
-        print('update G learning rate: %f -> %f' % (self._current_lr_G + lr_decay_G, self._current_lr_G))
-        lr_decay_D = (self._opt.lr_D - final_lr) / self._opt.nepochs_decay
-        self._current_lr_D -= lr_decay_D
-        for param_group in self._optimizer_D.param_groups:
-            param_group['lr'] = self._current_lr_D
-        print('update D learning rate: %f -> %f' % (self._current_lr_D + lr_decay_D, self._current_lr_D))
+        """One linear decay step towards final_lr for both optimisers (trainer.py:577-591).  The new rates reach the device-
+        resident schedules before the next step (FusedAdam.sync_state); rank 0 reports."""
+        quiet = dist.is_available() and dist.is_initialized() and dist.get_rank() != 0
+        for tag, optimizer, lr0 in (('G', self._optimizer_G, self._opt.lr_G), ('D', self._optimizer_D, self._opt.lr_D)):
+            old = getattr(self, '_current_lr_' + tag)
+            new = old - (lr0 - self._opt.final_lr) / self._opt.nepochs_decay
+            setattr(self, '_current_lr_' + tag, new)
+            for group in optimizer.param_groups:
+                group['lr'] = new
+            if not quiet:
+                print('update %s learning rate: %f -> %f' % (tag, old, new))
 
 
 HOGANModel = Trainer

@@ -888,6 +888,11 @@ class _LocalAttn(Function):
         assert tuple(wt.shape) == (128, C, 5, 5) and tuple(wt.stride()) == packed_strides(wt.shape, False)
         assert tuple(gs.shape) == (B, H + 4, W + 4, 128)
         M = B * H * W
+        # the backward's gather kernels (hoig_attn_src_gather / hoig_attn_build_index) cover less than the forward does: say so
+        # here, before a forward that could not be differentiated (the reference's layers have C = 256 / 512, M <= 131072)
+        if source.requires_grad and (C % 64 or M >= (1 << 20) or W + 8 >= 2048):
+            raise NotImplementedError('local_attention: the backward needs C %% 64 == 0, fewer than 2^20 pixels per batch and '
+                                      'W < 2040 (got C=%d, B*H*W=%d, W=%d)' % (C, M, W))
         dev, dt = source.device, source.dtype
         tpad = torch.empty((B, H + 4, W + 4, C), dtype=dt, device=dev)
         call('hoig_replicate_pad_fwd', _p(target), _p(tpad), B, H, W, C, 2, _st())

@@ -9,7 +9,7 @@ def opt_namespace(**over):
              local_rank=0, gen_name='generator_spade_attn', use_spade=True, repeat_num=6, norm_type='instance',
              image_size=256, tex_size=3, bg_both=False, use_vgg=True, mask_bce=True, lr_G=2e-4, lr_D=2e-4,
              G_adam_b1=0.5, G_adam_b2=0.999, D_adam_b1=0.5, D_adam_b2=0.999, lambda_D_prob=1.0, lambda_rec=10.0,
-             lambda_tsf=10.0, lambda_mask=1.0, lambda_mask_smooth=1.0, final_lr=2e-6, nepochs_decay=15,
+             lambda_tsf=10.0, lambda_mask=1.0, lambda_mask_smooth=1.0, final_lr=2e-6, nepochs_no_decay=15, nepochs_decay=15,
              load_path='None', load_epoch=-1, dataset_mode='hov3',
              # not a reference option: ImageNet VGG19 weights are not vendored and there is no network, so benchmarks and
              # parity tests opt in to deterministic surrogate weights (hoig_amd/models/trainer.py:_init_losses)

@@ -1,7 +1,8 @@
 """The gradient-exchange path ON RCCL: a `nccl` process group of ONE rank on cuda:0 with the exchange forced on
 (HOIG_DDP_FORCE=1, hoig_amd/ddp.py), so that everything an 8-GPU run executes -- the flat-buffer broadcast, one RCCL
 all-reduce per 64 MiB slice submitted from the side HIP stream, `wait()` ordering that stream behind each collective,
-the sliced Adam pipelined behind the exchange, D's exchange on the main stream -- runs on the single-GPU box.  A SUM over
+the sliced Adam pipelined behind the exchange, D's exchange on that side stream too (beside the next generator forward) --
+runs on the single-GPU box.  A SUM over
 one rank leaves the gradients unchanged, so the result must equal the plain (non-DDP) step and the oracle's.
 Reference: train_ddp.py:28 (`init_process_group(backend='nccl')`), models/trainer.py:237-252 (the two DDP wrappers)."""
 import os

@@ -116,6 +116,12 @@ def test_rejects_cpu_tensors_and_wrong_size():
     with pytest.raises(IndexError):
         IP.prepare_inputs(r['src_img'].cuda(), r['ref_img'].cuda(), r['src_faces'].cuda(), bad.cuda(), r['src_wim'].cuda(),
                           r['ref_fim'].cuda(), r['ref_wim'].cuda(), tabs, validate=True)
+    # 'deferred' (the training loop's mode): no host wait; the bad index is clamped for the kernels and reported afterwards
+    IP.prepare_inputs(r['src_img'].cuda(), r['ref_img'].cuda(), r['src_faces'].cuda(), bad.cuda(), r['src_wim'].cuda(),
+                      r['ref_fim'].cuda(), r['ref_wim'].cuda(), tabs, validate='deferred')
+    with pytest.raises(IndexError):
+        IP.flush_range_checks()
+    IP.flush_range_checks()                                  # reported once
     with pytest.raises(ValueError):
         IP.prepare_inputs(r['src_img'][:, :, :128, :128].cuda(), r['ref_img'].cuda(), r['src_faces'].cuda(),
                           r['src_fim'].cuda(), r['src_wim'].cuda(), r['ref_fim'].cuda(), r['ref_wim'].cuda(), tabs)

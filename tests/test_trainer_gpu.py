@@ -183,6 +183,47 @@ def test_api_surface_and_checkpoint_roundtrip(tmp_path):
         m.set_input({'imageA': torch.zeros(1)})
 
 
+def test_dexycb_resume_replays_the_learning_rate_decay(tmp_path):
+    """The HOIG_DexYCB copy's `load` (HOIG_DexYCB/models/trainer.py:558-573): networks loaded with need_module=True, and for
+    load_epoch > nepochs_no_decay the linear decay is replayed from the INITIAL rate -- (load_epoch - nepochs_no_decay) steps --
+    whatever rate the optimiser file carries.  The HOv3 copy resumes with the optimiser file's rate (trainer.py:562-575)."""
+    from hoig_amd.models import ModelsFactory
+    from common import opt_namespace
+    lr0, final, nd = 2e-4, 2e-6, 15
+    step = (lr0 - final) / nd
+    for dataset, epochs_past in (('dexycb', 3), ('hov3', 3)):
+        d = tmp_path / dataset
+        m = product_trainer('generator_spade_attn', 1, 64, dataset=dataset, checkpoints_dir=str(d))
+        m.optimize_parameters()
+        m.update_learning_rate()                      # the saved optimiser files carry lr0 - step
+        m.save(18)
+        m2 = ModelsFactory.get_by_name('trainer', opt_namespace(checkpoints_dir=str(d), load_epoch=15 + epochs_past,
+                                                                 dataset_mode=dataset, nepochs_no_decay=15, nepochs_decay=nd))
+        for k, v in m._G.state_dict().items():
+            assert torch.equal(v, m2._G.state_dict()[k]), k
+        assert m2._optimizer_G.step_count == 1 and m2._optimizer_D.step_count == 1
+        lr = m2._optimizer_G.param_groups[0]['lr']
+        if dataset == 'dexycb':
+            assert abs(lr - (lr0 - epochs_past * step)) < 1e-12 and abs(m2.get_current_scalars()['lr_D'] - lr) < 1e-12
+        else:
+            assert abs(lr - (lr0 - step)) < 1e-12 and m2.get_current_scalars()['lr_G'] == lr0
+        # the restored rate is the one the next step runs with (device-resident schedule)
+        m2._crt_tsf.vgg.load_state_dict(m._crt_tsf.vgg.state_dict())
+        from hoig_amd import synthetic
+        from common import SEEDS
+        m2.set_input(synthetic.make_inputs(1, 64, seed=SEEDS['inputs'], dataset=dataset))
+        m2.optimize_parameters()
+        torch.cuda.synchronize()
+        assert abs(float(m2._optimizer_G._state[0]) - lr) < 1e-15 and float(m2._optimizer_G._state[4]) == 2.0
+        del m, m2
+        torch.cuda.empty_cache()
+    # a bare (non-DDP) network refuses 'module.'-prefixed keys under need_module=True, as nn.Module.load_state_dict would
+    from hoig_amd.models.base_model import strip_ddp_prefix
+    from collections import OrderedDict
+    sd = OrderedDict(('module.' + k, v) for k, v in [('a', 1), ('b', 2)])
+    assert list(strip_ddp_prefix(sd)) == ['a', 'b']
+
+
 def test_visuals_match_reference_golden():
     """The f2 output stage (eval.py:61-67 reads `14/15/16_batch_*`): the 18 uint8 visuals against those of the REFERENCE's own
     `forward(keep_data_for_visuals=True)` (utils/util.py:249-272 tensor2im / tensor2maskim, util.py:22-74 Colorize;
