@@ -17,7 +17,7 @@ TOL = 1e-3                      # north_star: 1e-3 relative fp32 on the outputs
 @pytest.fixture(autouse=True)
 def _precision():
     from hoig_amd import ops
-    ops.set_precision('f16f6')              # the benchmarked arithmetic (forward: fp16 + fp6 terms; backward: two bf16 terms)
+    ops.set_precision('bf16x3:f16x2')       # the benchmarked arithmetic (forward: three fp16 terms; backward: two bf16 terms)
     yield
     ops.set_precision('f32')
 
@@ -52,8 +52,9 @@ def test_config5_eval_forward_b32_hipgraph_replay():
     m.set_eval()
     with torch.no_grad():
         eager = [o.clone() for o in m.forward()]
+        from hoig_amd import ops
         graph = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(graph):
+        with ops.graph_capture(graph):
             outs = m.forward()
         graph.replay()
         torch.cuda.synchronize()
@@ -151,7 +152,7 @@ def test_bench_line_contract():
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     env = {k: v for k, v in os.environ.items() if k not in ('WORLD_SIZE', 'RANK', 'LOCAL_RANK')}
     r = subprocess.run([sys.executable, os.path.join(root, 'bench.py'), '--steps', '2', '--warmup', '1', '--no-cpu-baseline',
-                        '--fwd-batch', '8'], env=env, capture_output=True, text=True, timeout=900)
+                        '--fwd-batch', '8', '--eager-steps', '2'], env=env, capture_output=True, text=True, timeout=900)
     assert r.returncode == 0, r.stderr[-2000:]
     lines = [l for l in r.stdout.splitlines() if l.startswith('{')]
     assert len(lines) == 1, r.stdout[-2000:]
@@ -164,7 +165,58 @@ def test_bench_line_contract():
     assert 'workload' in d['config'] and 'model' not in d['config']
     rf = d['roofline']
     assert rf['bound'] == 'mfma' and rf['unit'] == 'TFLOP/s' and rf['peak'] == 2500.0
-    assert abs(rf['frac'] - rf['achieved'] / rf['peak']) < 1e-3 and 0.05 < rf['frac'] < 0.625
-    assert 'conv_halo3_f6_kernel' in rf['kernel'] and rf['traffic_source']                  # counters come from a committed pass
+    assert abs(rf['frac'] - rf['achieved'] / rf['peak']) < 1e-3 and 0.05 < rf['frac'] < 0.334
+    assert 'conv_halo3_bf16_kernel' in rf['kernel'] and rf['traffic_source']                # counters come from a committed pass
+    assert d['hipgraph']['captured_step'] is True and d['hipgraph']['eager_ms_per_step'] > 0
     assert d['gen_fwd']['finite'] and d['gen_fwd']['batch'] == 8 and d['losses_finite'] is True
     assert 'cpu_baseline' not in d or d['cpu_baseline'] is None or isinstance(d['cpu_baseline'], dict)
+
+
+def test_config2_gradients_256_against_oracle():
+    """One G+D step at the bench resolution (256x256, batch 1: the oracle's step takes seconds): every gradient tensor of G and D
+    against the CPU oracle, in the benchmarked arithmetic.  Measured (tools/grad_parity.py, profiles/r03_grad_parity_256.txt,
+    4 runs): median 6.4e-3..6.6e-3, p95 8.5e-3..8.7e-3, worst 1.7e-2..2.2e-2 (an attention layer's 25-element bias); limits = the
+    ones of the 128x128 test.  The opt-in 'f16f6' forward (fp6 cross terms on every eligible layer) is asserted on its OUTPUTS
+    (1e-3) here and reported for its gradients: median 1.5e-2, p95 2.0e-2..2.4e-2, worst 2.7e-2..4.3e-2 -- beyond 3e-2, which is
+    why it is not the default."""
+    from hoig_amd import ops
+    sys_path_tools()
+    from precision_frontier import oracle_side
+    ofwd, oerr, ograd = oracle_side(256, 1)
+    for mode, limits in (('bf16x3:f16x2', (1e-2, 2e-2, 3e-2)), ('f16f6', None)):
+        ops.set_precision(mode)
+        old = ops.set_f6_min_tiles(1)
+        try:
+            m = product_trainer('generator_spade_attn', 1, 256)
+            with torch.no_grad():
+                fwd = m.forward()
+            for a, b in zip(fwd, ofwd):
+                assert rel_err(a, b) < TOL, mode
+            m.optimize_parameters()
+            e = m.get_current_errors()
+            for k in oerr:
+                assert abs(e[k] - oerr[k]) <= 1e-4 * max(abs(oerr[k]), 1e-2), (mode, k, e[k], oerr[k])
+            vals = []
+            for tag, net in (('G', m._G), ('D', m._D)):
+                for k, v in net.export_dict(net.flat_grad).items():
+                    if (tag, k) in ograd:
+                        vals.append(float((v.detach().float().cpu() - ograd[(tag, k)]).norm() / ograd[(tag, k)].norm()))
+            vals.sort()
+            med, p95, worst = vals[len(vals) // 2], vals[int(0.95 * len(vals))], vals[-1]
+            print('%s: gradient rel-L2 over %d tensors: median %.2e p95 %.2e worst %.2e' % (mode, len(vals), med, p95, worst))
+            if limits is not None:
+                assert med < limits[0] and p95 < limits[1] and worst < limits[2], (mode, med, p95, worst)
+            else:
+                assert med < 3e-2 and worst < 8e-2, (mode, med, worst)          # (sanity only: see the docstring)
+            del m
+            torch.cuda.empty_cache()
+        finally:
+            ops.set_f6_min_tiles(old)
+
+
+def sys_path_tools():
+    import os
+    import sys
+    p = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), 'tools')
+    if p not in sys.path:
+        sys.path.insert(0, p)

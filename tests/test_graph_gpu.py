@@ -17,7 +17,7 @@ LR = 2e-4
 def _precision():
     from hoig_amd import ops
     old = ops.set_f6_min_tiles(1)
-    ops.set_precision('f16f6')              # the benchmarked arithmetic
+    ops.set_precision('bf16x3:f16x2')       # the benchmarked arithmetic
     yield
     ops.set_precision('f32')
     ops.set_f6_min_tiles(old)
@@ -47,7 +47,7 @@ def _copy_state(src, dst):
     torch.cuda.synchronize()
 
 
-@pytest.mark.parametrize('precision', ['f16f6', 'bf16x3'])
+@pytest.mark.parametrize('precision', ['bf16x3:f16x2', 'f16f6'])
 def test_captured_step_matches_eager_step_and_oracle(precision):
     from hoig_amd import ops
     from hoig_amd.models import trainer as T

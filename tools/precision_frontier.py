@@ -34,7 +34,7 @@ def oracle_side(side, batch):
 
 def main():
     modes = sys.argv[1:] or ['f32', 'bf16x3', 'bf16']
-    ops.set_f6_min_tiles(1)          # 'f16f6': the fp6 forward kernel on every eligible layer, also at these small sizes
+    ops.set_f6_min_tiles(int(os.environ.get('F6_MIN_TILES', '1')))          # 'f16f6': the fp6 forward kernel on every eligible layer, also at these small sizes
     print('%-8s %5s | %-10s | %-10s | %-28s | %s' % ('mode', 'side', 'fwd max', 'loss max', 'grad rel-L2 med/p95/worst', 'worst loss term'))
     for side, batch in ((64, 2), (128, 1), (256, 1)):
         ofwd, oerr, ograd = oracle_side(side, batch)

@@ -12,9 +12,9 @@ lo, hi = adam[-3], adam[-1]            # D-adam of step n-1 .. D-adam of step n
 win = ks[lo + 1:hi + 1]
 t0, t1 = win[0][0], max(k[1] for k in win)
 def short(n):
-    n = re.sub(r'\(.*', '', n)
+    n = n.replace('(anonymous namespace)::', '').replace('at::native::', '')
     n = re.sub(r'^void ', '', n)
-    n = re.sub(r'at::native::', '', n)
+    n = re.sub(r'\(.*', '', n)
     return n[:44]
 # sweep
 ev = []

@@ -13,7 +13,7 @@ steps, side, batch = int(sys.argv[1]), int(sys.argv[2]), int(sys.argv[3])
 modes = sys.argv[4:]
 marks = sorted(set([1, 2, 5, 10, 20, 35, 50, 75, 100, steps]))
 res = {}
-ops.set_f6_min_tiles(1)          # 'f16f6': the fp6 forward kernel on every eligible layer, also at this small size
+ops.set_f6_min_tiles(int(os.environ.get('F6_MIN_TILES', '1')))          # 'f16f6': the fp6 forward kernel on every eligible layer, also at this small size
 for mode in modes:
     ops.set_precision(mode.split('#')[0])
     m = product_trainer('generator_spade_attn', batch, side)
