@@ -21,6 +21,7 @@
 // multiplied, then written to LDS.  Block ids are remapped so that the n-tiles of one m-tile share an XCD (L2 reuse of
 // the gathered rows).
 #include "common.h"
+#include <cstdlib>
 
 namespace {
 
@@ -583,6 +584,14 @@ int hoig_conv_small_dgrad(const hoig_conv_desc *d, const float *dy, const float 
 int hoig_conv_small_ci_fwd(const hoig_conv_desc *d, const float *x, const float *w, const float *bias, float *y,
                            hipStream_t st);
 int hoig_conv_dot_fwd(const hoig_conv_desc *d, const float *x, const float *w, const float *bias, float *y, hipStream_t st);
+// conv_thin.hip: stride-1 'same' convolutions with <= 8 (3x3: 16) channels on one side, taps in place of the missing channels
+int hoig_conv_thin_fwd(const hoig_conv_desc *d, const float *x, const float *w, const float *bias, float *y, hipStream_t st);
+int hoig_conv_thin_dgrad(const hoig_conv_desc *d, const float *dy, const float *w, float *dx, int accumulate, hipStream_t st);
+int hoig_conv_thin_wgrad(const hoig_conv_desc *d, const float *x, const float *dy, float *dw, hipStream_t st);
+static bool thin_enabled() {
+    static const bool on = getenv("HOIG_NO_THIN") == nullptr;            // A/B switch: back to the fp32 VALU / generic kernels
+    return on;
+}
 
 extern "C" int hoig_conv2d_fwd(const hoig_conv_desc *d, const float *x, const float *w, const float *bias, float *y,
                                hoig_stream_t stream) {
@@ -591,6 +600,7 @@ extern "C" int hoig_conv2d_fwd(const hoig_conv_desc *d, const float *x, const fl
     if (!x || !w || !y) return HOIG_EINVAL;
     hipStream_t st = (hipStream_t)stream;
     rc = hoig_conv_small_fwd(d, x, w, bias, y, st);           // 7x7 heads with <= 4 output channels: direct fp32 kernel
+    if (rc == HOIG_EUNSUPPORTED && thin_enabled()) rc = hoig_conv_thin_fwd(d, x, w, bias, y, st);      // thin-input convs on MFMA
     if (rc == HOIG_EUNSUPPORTED) rc = hoig_conv_small_ci_fwd(d, x, w, bias, y, st);    // 7x7 stems with <= 8 input channels
     if (rc == HOIG_EUNSUPPORTED) rc = hoig_conv_dot_fwd(d, x, w, bias, y, st);         // <= 4 outputs over >= 1024 products
     if (rc != HOIG_EUNSUPPORTED) return rc;
@@ -612,7 +622,8 @@ extern "C" int hoig_conv2d_bwd_data(const hoig_conv_desc *d, const float *dy, co
     if (rc) return rc;
     if (!dy || !w || !dx) return HOIG_EINVAL;
     hipStream_t st = (hipStream_t)stream;
-    rc = hoig_conv_small_dgrad(d, dy, w, dx, st);              // 7x7 heads with <= 4 output channels: direct fp32 kernel
+    rc = thin_enabled() ? hoig_conv_thin_dgrad(d, dy, w, dx, 0, st) : HOIG_EUNSUPPORTED;     // thin-output convs (heads) on MFMA
+    if (rc == HOIG_EUNSUPPORTED) rc = hoig_conv_small_dgrad(d, dy, w, dx, st);     // ... or the direct fp32 kernel (HOIG_PREC_F32)
     if (rc != HOIG_EUNSUPPORTED) return rc;
     if (d->precision != HOIG_PREC_F32) {
         rc = hoig_conv_bf16_fwd_like(d, dy, w, nullptr, dx, true, st);
@@ -664,7 +675,8 @@ extern "C" int hoig_conv2d_bwd_weight(const hoig_conv_desc *d, const float *x, c
         rc = hoig_colsum_accum(dy, dbias, (int64_t)d->B * d->Ho * d->Wo, d->Co, stream);
         if (rc) return rc;
     }
-    rc = hoig_conv_small_wgrad(d, x, dy, dw, st);
+    rc = thin_enabled() ? hoig_conv_thin_wgrad(d, x, dy, dw, st) : HOIG_EUNSUPPORTED;      // thin-input / thin-output convs on MFMA
+    if (rc == HOIG_EUNSUPPORTED) rc = hoig_conv_small_wgrad(d, x, dy, dw, st);
     if (rc != HOIG_EUNSUPPORTED) return rc;
     if (d->precision != HOIG_PREC_F32) {
         rc = hoig_conv_bf16_wgrad(d, x, dy, dw, fused_bias ? dbias : nullptr, st);

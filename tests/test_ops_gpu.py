@@ -383,6 +383,63 @@ def test_conv_bf16x3_fast_path(B, Ci, Co, H, k, stride, pad, transposed, mode):
         assert ef > 2e-5 and ed > 1e-4, 'the two-term kernels did not run (error is at the three-term level)'
 
 
+THIN_CASES = [
+    # B, Ci, Co, H, W, k, bias, act       (stride 1, 'same' padding)
+    (2, 3, 64, 32, 32, 7, False, 'none'),      # the 7x7 stems (generator.py:100,153)
+    (1, 8, 64, 8, 64, 7, True, 'none'),
+    (2, 3, 128, 32, 32, 3, True, 'relu'),      # SPADE's shared conv over the 3-channel condition map (spade.py:18)
+    (1, 12, 128, 16, 32, 3, True, 'relu'),     # ... over obj_model's 12-channel one
+    (1, 3, 64, 64, 64, 3, True, 'relu'),       # VGG19's first layer
+    (2, 64, 1, 32, 32, 7, True, 'sigmoid'),    # the mask heads (generator.py:219-235)
+    (2, 64, 3, 16, 64, 7, True, 'tanh'),       # the image heads
+    (1, 128, 1, 32, 32, 7, False, 'none'),     # (two 64-channel groups)
+]
+
+
+@pytest.mark.parametrize('mode', ['bf16x3', 'f16x2'])
+@pytest.mark.parametrize('B,Ci,Co,H,W,k,bias,act', THIN_CASES)
+def test_conv_thin_channels_on_mfma(B, Ci, Co, H, W, k, bias, act, mode):
+    """conv_thin.hip: convolutions with a few channels on one side, taps standing in for the missing channels on the MFMA --
+    forward + weight gradient of thin-input layers, data + weight gradient of thin-output layers (their forward stays on the
+    fp32 VALU kernel) -- against torch fp32, in the three-term and the two-term arithmetic."""
+    ops = _ops()
+    from hoig_amd import _lib as L
+    prec = {'bf16x3': L.PREC_BF16X3, 'f16x2': L.PREC_F16X2}[mode]
+    bf, bd, bw = PREC_BOUNDS[mode]
+    acts = {'none': (L.ACT_NONE, lambda t: t), 'relu': (L.ACT_RELU, torch.relu), 'tanh': (L.ACT_TANH, torch.tanh),
+            'sigmoid': (L.ACT_SIGMOID, torch.sigmoid)}
+    code, fn = acts[act]
+    ops.set_precision(mode)
+    g = torch.Generator().manual_seed(21)
+    x = torch.randn(B, Ci, H, W, generator=g)
+    w = torch.randn(Co, Ci, k, k, generator=g) * 0.05
+    b = torch.randn(Co, generator=g) if bias else None
+    xr, wr = x.clone().requires_grad_(True), w.clone().requires_grad_(True)
+    yr = fn(F.conv2d(xr, wr, b, stride=1, padding=k // 2))
+    gy = torch.randn(yr.shape, generator=g)
+    yr.backward(gy)
+    xd = nhwc_cuda(x).requires_grad_(True)
+    wd = ops.pack_weight(w.cuda()).requires_grad_(True)
+    try:
+        y = ops.conv2d(xd, wd, b.cuda() if bias else None, 1, k // 2, act=code, prec=prec)
+        y.backward(nhwc_cuda(gy))
+        torch.cuda.synchronize()
+    finally:
+        ops.set_precision('f32')
+    ef, ed, ew = rel_err(nchw_cpu(y), yr), rel_err(nchw_cpu(xd.grad), xr.grad), rel_err(wd.grad, wr.grad)
+    print('thin %s: fwd %.2e dgrad %.2e wgrad %.2e' % (mode, ef, ed, ew))
+    assert ef < bf and ew < bw
+    # (a thin-input layer's data gradient is never needed on the path -- its input is an image or a label map -- and behind a
+    # ReLU it is not a fair test either: a forward error of 1e-4 flips the mask of outputs that close to zero, 1 % of dx each)
+    assert ed < bd or (Ci <= 16 and act == 'relu')
+    if mode == 'f16x2':          # the two-term MFMA kernels really ran (the fp32 VALU / generic kernels sit at 1e-6)
+        assert ew > 2e-5
+        if Ci <= 16:
+            assert ef > 1e-5
+        else:
+            assert ed > 2e-5
+
+
 def test_batched_weight_split_matches_per_weight_split():
     """hoig_pack_conv_weights_bf16_all (one launch over a network's flat buffer, LDS-tiled transpose for the data-gradient
     planes) must produce exactly the planes hoig_pack_conv_weight_bf16 produces weight by weight, including for the fused
