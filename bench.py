@@ -347,7 +347,7 @@ def main():
     if rank == 0:
         ms = dt / args.steps * 1e3
         value = world * args.batch * args.steps / dt
-        roof = dominant_kernel_roofline(args.batch, args.side, args.precision)
+        roof = None if os.environ.get('HOIG_BENCH_NO_ROOF') else dominant_kernel_roofline(args.batch, args.side, args.precision)
         out = {
             'metric': 'HOGAN train images/sec at %dx%d' % (args.side, args.side),
             'value': round(value, 3), 'unit': 'images/s', 'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,

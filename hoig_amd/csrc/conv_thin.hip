@@ -18,6 +18,8 @@
 // bf16 halves; HOIG_PREC_BF16X3 = three terms (both operands split hi + lo), HOIG_PREC_F16X2 = the gathered / gradient operand
 // split, the other one single, HOIG_PREC_BF16 = one term; fp32 accumulate.
 #include "common.h"
+#include <map>
+#include <mutex>
 
 namespace {
 
@@ -31,6 +33,7 @@ struct ThinArgs {
     const float *D;          // wgrad: dense tensor [B][H][W][CD];  gemm: the packed fp32 conv weight
     const float *bias;       // gemm forward: per dense channel (nullable)
     float *Out;              // gemm: [B][H][W][CD];  wgrad: dW, accumulated with atomics
+    float *Ws;               // wgrad: per-workgroup partials [gridDim.y][gridDim.x][64][NP] (nullable: atomics straight into dW)
     int Bn, H, W, F, CD, KS, pad;
     int flip;                // taps mirrored: the thin tensor is a gradient (thin-OUTPUT convolutions)
     int sj, st, sf;          // weight / dW element index = j * sj + tap * st + f * sf   (j dense channel, f thin channel)
@@ -62,23 +65,51 @@ __device__ __forceinline__ f32x16 mfma16(const bf16x8 a, const bf16x8 b, const f
     return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0);
 }
 
-// The halo image of one tile of the thin tensor: planes [NT][F][HR][CW] of 16-bit values, zero outside the picture.
-template <bool FP16, int NT>
-__device__ __forceinline__ void stage_thin_halo(const ThinArgs &p, int b, int y0, int x0, unsigned short *Tl) {
+// The halo image of one tile of the thin tensor: planes [NT][F][HR][CW] of 16-bit values, zero outside the picture.  Loaded into
+// registers one tile ahead (HMAX values per thread cover the largest image: 10 x 38 pixels x 8 channels) and written to LDS
+// when the tile's turn comes, so that the load latency hides behind the previous tile's MFMAs.
+constexpr int HMAX = 12;
+struct HaloRegs {
+    float v[HMAX];
+};
+__device__ __forceinline__ void halo_load(const ThinArgs &p, int b, int y0, int x0, HaloRegs &h) {
     const int wr = TW + p.KS - 1;                          // halo pixels per row
     const int row_elems = wr * p.F;                        // contiguous in memory: (x0 - pad .. x0 - pad + wr) x F
+    const int total = p.HR * row_elems;
+#pragma unroll
+    for (int it = 0; it < HMAX; ++it) {
+        const int i = threadIdx.x + it * NTHR;
+        h.v[it] = 0.f;
+        if (it * NTHR < total) {                           // (uniform)
+            if (i < total) {
+                const int hy = i / row_elems, e = i - hy * row_elems;
+                const int hx = e / p.F, f = e - hx * p.F;
+                const int gy = y0 - p.pad + hy, gx = x0 - p.pad + hx;
+                if (gy >= 0 && gy < p.H && gx >= 0 && gx < p.W) h.v[it] = p.T[(((size_t)b * p.H + gy) * p.W + gx) * p.F + f];
+            }
+        }
+    }
+}
+template <bool FP16, int NT>
+__device__ __forceinline__ void halo_store(const ThinArgs &p, const HaloRegs &h, unsigned short *Tl) {
+    const int wr = TW + p.KS - 1;
+    const int row_elems = wr * p.F;
+    const int total = p.HR * row_elems;
     const int plane = p.F * p.HR * p.CW;
-    for (int i = threadIdx.x; i < p.HR * row_elems; i += NTHR) {
-        const int hy = i / row_elems, e = i - hy * row_elems;
-        const int hx = e / p.F, f = e - hx * p.F;
-        const int gy = y0 - p.pad + hy, gx = x0 - p.pad + hx;
-        float v = 0.f;
-        if (gy >= 0 && gy < p.H && gx >= 0 && gx < p.W) v = p.T[(((size_t)b * p.H + gy) * p.W + gx) * p.F + f];
-        unsigned short hi, lo;
-        split16<FP16>(v, hi, lo);
-        const int o = (f * p.HR + hy) * p.CW + hx;
-        Tl[o] = hi;
-        if (NT == 2) Tl[plane + o] = lo;
+#pragma unroll
+    for (int it = 0; it < HMAX; ++it) {
+        const int i = threadIdx.x + it * NTHR;
+        if (it * NTHR < total) {
+            if (i < total) {
+                const int hy = i / row_elems, e = i - hy * row_elems;
+                const int hx = e / p.F, f = e - hx * p.F;
+                unsigned short hi, lo;
+                split16<FP16>(h.v[it], hi, lo);
+                const int o = (f * p.HR + hy) * p.CW + hx;
+                Tl[o] = hi;
+                if (NT == 2) Tl[plane + o] = lo;
+            }
+        }
     }
 }
 
@@ -105,18 +136,32 @@ __global__ __launch_bounds__(NTHR) void thin_gemm_kernel(const ThinArgs p) {
     const int KK = p.KS * p.KS;
     const int tplane = p.F * p.HR * p.CW;
 
-    for (int i = tid; i < 64 * p.KP; i += NTHR) {
-        const int n = i / p.KP, k = i - n * p.KP;
-        float v = 0.f;
-        if (k < p.K) {
-            const int tap = k / p.F, f = k - tap * p.F;
-            const int tw = p.flip ? KK - 1 - tap : tap;
-            v = p.D[(size_t)(cbase + n) * p.sj + (size_t)tw * p.st + (size_t)f * p.sf] * p.wscale;
+    for (int i0 = tid; i0 < 64 * p.KP; i0 += 4 * NTHR) {                  // (four independent loads in flight per thread)
+        float v[4];
+        int dst[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int i = i0 + u * NTHR;
+            v[u] = 0.f;
+            dst[u] = -1;
+            if (i < 64 * p.KP) {
+                const int n = i / p.KP, k = i - n * p.KP;
+                dst[u] = n * wstride + k;
+                if (k < p.K) {
+                    const int tap = k / p.F, f = k - tap * p.F;
+                    const int tw = p.flip ? KK - 1 - tap : tap;
+                    v[u] = p.D[(size_t)(cbase + n) * p.sj + (size_t)tw * p.st + (size_t)f * p.sf];
+                }
+            }
         }
-        unsigned short hi, lo;
-        split16<FP16>(v, hi, lo);
-        Wl[n * wstride + k] = hi;
-        if (NW == 2) Wl[64 * wstride + n * wstride + k] = lo;
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+            if (dst[u] >= 0) {
+                unsigned short hi, lo;
+                split16<FP16>(v[u] * p.wscale, hi, lo);
+                Wl[dst[u]] = hi;
+                if (NW == 2) Wl[64 * wstride + dst[u]] = lo;
+            }
     }
     for (int k = tid; k < p.KP; k += NTHR) {
         const int kc = k < p.K ? k : p.K - 1;                            // (padding: any valid address, the weight is zero)
@@ -135,12 +180,23 @@ __global__ __launch_bounds__(NTHR) void thin_gemm_kernel(const ThinArgs p) {
     const int pix = wave * p.CW + l31;                                   // this lane's pixel inside the halo image (tap 0,0)
 
     const int t_end = min(p.ntiles, (int)(blockIdx.x + 1) * p.strip);
+    HaloRegs hreg;
+    {
+        int b, y0, x0;
+        tile_coords(p, blockIdx.x * p.strip, b, y0, x0);
+        halo_load(p, b, y0, x0, hreg);
+    }
     for (int t = blockIdx.x * p.strip; t < t_end; ++t) {
         int b, y0, x0;
         tile_coords(p, t, b, y0, x0);
         __syncthreads();                                                 // the previous tile's reads (and the tables) are done
-        stage_thin_halo<FP16, NT>(p, b, y0, x0, Tl);
+        halo_store<FP16, NT>(p, hreg, Tl);
         __syncthreads();
+        if (t + 1 < t_end) {                                             // the next tile's halo flies during this tile's MFMAs
+            int b2, y2, x2;
+            tile_coords(p, t + 1, b2, y2, x2);
+            halo_load(p, b2, y2, x2, hreg);
+        }
         f32x16 acc[2];
 #pragma unroll
         for (int j = 0; j < 2; ++j)
@@ -260,15 +316,24 @@ __global__ __launch_bounds__(NTHR) void thin_wgrad_kernel(const ThinArgs p) {
     };
 
     int t = blockIdx.x;
-    if (t < p.ntiles) load_d(t);
-    for (; t < p.ntiles; t += gridDim.x) {
+    HaloRegs hreg;
+    if (t < p.ntiles) {
         int b, y0, x0;
         tile_coords(p, t, b, y0, x0);
+        load_d(t);
+        halo_load(p, b, y0, x0, hreg);
+    }
+    for (; t < p.ntiles; t += gridDim.x) {
         __syncthreads();                                                  // the previous tile has been consumed
         store_d();
-        stage_thin_halo<false, NT>(p, b, y0, x0, Tl);
+        halo_store<false, NT>(p, hreg, Tl);
         __syncthreads();
-        if (t + (int)gridDim.x < p.ntiles) load_d(t + gridDim.x);         // the next tile's loads fly during the MFMAs
+        if (t + (int)gridDim.x < p.ntiles) {                              // the next tile's loads fly during the MFMAs
+            int b, y0, x0;
+            tile_coords(p, t + gridDim.x, b, y0, x0);
+            load_d(t + gridDim.x);
+            halo_load(p, b, y0, x0, hreg);
+        }
 #pragma unroll 1
         for (int ks = wk; ks < KSTEPS; ks += WK) {
             const int prow = ks >> 1, pcol = (ks & 1) * 16;               // sixteen pixels of row `prow`, from column `pcol`
@@ -320,6 +385,12 @@ __global__ __launch_bounds__(NTHR) void thin_wgrad_kernel(const ThinArgs p) {
                 }
         }
     __syncthreads();
+    if (p.Ws) {          // hundreds of workgroups adding into the same few KB of dW serialise at the memory-side atomic units
+                         // (measured: 78 us for the 64 -> 1 heads, 73 of them atomics): plain stores here, thin_reduce_kernel adds
+        float *dst = p.Ws + ((size_t)blockIdx.y * gridDim.x + blockIdx.x) * 64 * p.NP;
+        for (int i = tid; i < 64 * p.NP; i += NTHR) dst[i] = Gl[i];
+        return;
+    }
     if (p.sj == 1) {                                                      // dW[f][tap][j]: consecutive threads along j
         for (int i = tid; i < 64 * p.N; i += NTHR) {
             const int n = i >> 6, m = i & 63;
@@ -333,6 +404,63 @@ __global__ __launch_bounds__(NTHR) void thin_wgrad_kernel(const ThinArgs p) {
             atomicAdd(p.Out + (size_t)(cbase + m) * p.sj + (size_t)tap * p.st + (size_t)f * p.sf, Gl[m * p.NP + n]);
         }
     }
+}
+
+// dW += sum over the workgroups' partials (one thread per dW element of this 64-channel group, coalesced over the partials)
+__global__ __launch_bounds__(NTHR) void thin_reduce_kernel(const ThinArgs p, int nwg) {
+    const int cbase = blockIdx.y * 64;
+    const float *src = p.Ws + (size_t)blockIdx.y * nwg * 64 * p.NP;
+    const int i = blockIdx.x * NTHR + threadIdx.x;
+    if (i >= 64 * p.N) return;
+    const int m = i / p.N, n = i - m * p.N;                // (threads along n: the partials are read in contiguous runs)
+    // blockIdx.z: a chunk of the partials (a thread sums at most 32 of them, four loads in flight; <= 16 atomics per element)
+    const int wper = (nwg + (int)gridDim.z - 1) / (int)gridDim.z;
+    const int w0 = blockIdx.z * wper, w1 = min(nwg, w0 + wper);
+    const size_t step = (size_t)64 * p.NP;
+    const float *col = src + m * p.NP + n + (size_t)w0 * step;
+    float v0 = 0.f, v1 = 0.f, v2 = 0.f, v3 = 0.f;
+    int w = w0;
+    for (; w + 3 < w1; w += 4, col += 4 * step) {
+        v0 += col[0];
+        v1 += col[step];
+        v2 += col[2 * step];
+        v3 += col[3 * step];
+    }
+    for (; w < w1; ++w, col += step) v0 += col[0];
+    const float v = (v0 + v1) + (v2 + v3);
+    const int tap = n / p.F, f = n - tap * p.F;
+    atomicAdd(p.Out + (size_t)(cbase + m) * p.sj + (size_t)tap * p.st + (size_t)f * p.sf, v);
+}
+
+// Workspace for the partials: a pool of slots, one per stream that ever launches a thin weight gradient (launches of one
+// stream are ordered, so they share their slot).  Allocated on the first use -- never while a stream is being captured
+// (the trainer's eager warm-up steps come first); without a slot the kernel falls back to atomics.
+constexpr size_t WS_SLOT_BYTES = (size_t)16 << 20;
+constexpr int WS_SLOTS = 24;
+float *thin_workspace(hipStream_t st, size_t bytes) {
+    static std::mutex mu;
+    static float *base = nullptr;
+    static std::map<hipStream_t, int> owner;
+    static int next = 0;
+    std::lock_guard<std::mutex> lock(mu);
+    if (bytes > WS_SLOT_BYTES) return nullptr;
+    if (!base) {
+        hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
+        if (hipStreamIsCapturing(st, &cs) != hipSuccess || cs != hipStreamCaptureStatusNone) return nullptr;
+        if (hipMalloc(reinterpret_cast<void **>(&base), WS_SLOT_BYTES * WS_SLOTS) != hipSuccess) {
+            base = nullptr;
+            (void)hipGetLastError();
+            return nullptr;
+        }
+    }
+    auto it = owner.find(st);
+    int slot;
+    if (it != owner.end()) slot = it->second;
+    else {
+        if (next >= WS_SLOTS) return nullptr;
+        slot = owner[st] = next++;
+    }
+    return base + (size_t)slot * (WS_SLOT_BYTES / sizeof(float));
 }
 
 bool thin_geometry(const hoig_conv_desc *d) {
@@ -350,7 +478,7 @@ void fill_common(ThinArgs &a, const hoig_conv_desc *d, int F, int CD) {
     a.ntiles = d->B * a.tiles_x * a.tiles_y;
     a.HR = TH + d->R - 1;
     a.CW = (TW + d->R - 1 + 8 + 1) & ~1;            // (+8: a fragment's eight-pixel run may start in the last columns)
-    a.bias = nullptr; a.act = HOIG_ACT_NONE; a.slope = 0.f; a.accumulate = 0; a.wscale = 1.f; a.strip = 1;
+    a.bias = nullptr; a.act = HOIG_ACT_NONE; a.slope = 0.f; a.accumulate = 0; a.wscale = 1.f; a.strip = 1; a.Ws = nullptr;
 }
 
 template <bool FP16>
@@ -404,7 +532,7 @@ int launch_wgrad_t(const ThinArgs &a, int nt, int nd, dim3 grid, size_t smem, hi
 
 // forward of a thin-INPUT convolution (Ci <= 8, Co % 64 == 0); HOIG_EUNSUPPORTED otherwise
 int hoig_conv_thin_fwd(const hoig_conv_desc *d, const float *x, const float *w, const float *bias, float *y, hipStream_t st) {
-    if (d->precision == HOIG_PREC_F32 || !thin_geometry(d) || d->Ci > (d->R <= 3 ? 16 : 8) || d->Ci < 1 || (d->Co % 64)) return HOIG_EUNSUPPORTED;
+    if (d->precision == HOIG_PREC_F32 || !thin_geometry(d) || d->Ci > (d->R <= 3 ? 12 : 8) || d->Ci < 1 || (d->Co % 64)) return HOIG_EUNSUPPORTED;
     ThinArgs a;
     fill_common(a, d, d->Ci, d->Co);
     a.T = x; a.D = w; a.bias = bias; a.Out = y;
@@ -432,7 +560,7 @@ int hoig_conv_thin_dgrad(const hoig_conv_desc *d, const float *dy, const float *
 // weight gradient of a thin-input (Ci <= 8, Co % 64 == 0) or thin-output (Co <= 8, Ci % 64 == 0) convolution
 int hoig_conv_thin_wgrad(const hoig_conv_desc *d, const float *x, const float *dy, float *dw, hipStream_t st) {
     if (d->precision == HOIG_PREC_F32 || !thin_geometry(d)) return HOIG_EUNSUPPORTED;
-    const bool thin_in = d->Ci <= (d->R <= 3 ? 16 : 8) && (d->Co % 64) == 0, thin_out = d->Co <= 8 && (d->Ci % 64) == 0;
+    const bool thin_in = d->Ci <= (d->R <= 3 ? 12 : 8) && (d->Co % 64) == 0, thin_out = d->Co <= 8 && (d->Ci % 64) == 0;
     if (!thin_in && !thin_out) return HOIG_EUNSUPPORTED;
     ThinArgs a;
     int nt, nd;                                  // 16-bit planes of the thin / dense operand
@@ -459,10 +587,18 @@ int hoig_conv_thin_wgrad(const hoig_conv_desc *d, const float *x, const float *d
     int nwg = 512;                               // persistent workgroups: each adds its 64 x N partial once (fp32 atomics)
     if (smem > 80 * 1024 || a.N >= 128) nwg = 256;
     if (nwg > a.ntiles) nwg = a.ntiles;
-    dim3 grid(nwg, a.CD / 64);
-    if (nfr == 1) return launch_wgrad_t<1, 1>(a, nt, nd, grid, smem, st);
-    if (nfr == 2) return launch_wgrad_t<2, 1>(a, nt, nd, grid, smem, st);
-    if (nfr <= 4) return launch_wgrad_t<2, 2>(a, nt, nd, grid, smem, st);
-    if (nfr <= 8) return launch_wgrad_t<2, 4>(a, nt, nd, grid, smem, st);
-    return launch_wgrad_t<4, 4>(a, nt, nd, grid, smem, st);
+    const int groups = a.CD / 64;
+    while (nwg > 64 && (size_t)nwg * groups * 64 * a.NP * 4 > WS_SLOT_BYTES) nwg >>= 1;
+    dim3 grid(nwg, groups);
+    a.Ws = nwg > 8 ? thin_workspace(st, (size_t)nwg * groups * 64 * a.NP * 4) : nullptr;
+    int rc;
+    if (nfr == 1) rc = launch_wgrad_t<1, 1>(a, nt, nd, grid, smem, st);
+    else if (nfr == 2) rc = launch_wgrad_t<2, 1>(a, nt, nd, grid, smem, st);
+    else if (nfr <= 4) rc = launch_wgrad_t<2, 2>(a, nt, nd, grid, smem, st);
+    else if (nfr <= 8) rc = launch_wgrad_t<2, 4>(a, nt, nd, grid, smem, st);
+    else rc = launch_wgrad_t<4, 4>(a, nt, nd, grid, smem, st);
+    if (rc != HOIG_OK || !a.Ws) return rc;
+    thin_reduce_kernel<<<dim3((unsigned)hoig_cdiv(64 * a.N, NTHR), groups, (unsigned)hoig_cdiv(nwg, 32)), NTHR, 0, st>>>(a, nwg);
+    HOIG_LAUNCH_CHECK();
+    return HOIG_OK;
 }

@@ -87,6 +87,35 @@ __global__ __launch_bounds__(256) void cat2_rows_kernel(const float *__restrict_
     for (int i = (n & ~3) + threadIdx.x; i < n; i += 256) dst[i] = rows[i];
 }
 
+// The same without LDS: a thread produces four consecutive floats of the output stream (one integer division per thread, then a
+// running (pixel, channel) pair); the scalar source reads of a wave cover a contiguous span of x1 and of x2.
+__global__ __launch_bounds__(NT) void cat2_flat_kernel(const float *__restrict__ x1, int C1, const float *__restrict__ x2, int C2,
+                                                       float *__restrict__ y, int64_t ntotal) {
+    const int Cy = C1 + C2;
+    const int64_t n4 = ntotal >> 2;
+    for (int64_t i = (int64_t)blockIdx.x * NT + threadIdx.x; i < n4; i += (int64_t)gridDim.x * NT) {
+        const int64_t e0 = i << 2;
+        int64_t pix = e0 / Cy;
+        int c = (int)(e0 - pix * Cy);
+        float v[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            v[k] = c < C1 ? x1[pix * C1 + c] : x2[pix * C2 + (c - C1)];
+            if (++c == Cy) {
+                c = 0;
+                ++pix;
+            }
+        }
+        reinterpret_cast<float4 *>(y)[i] = make_float4(v[0], v[1], v[2], v[3]);
+    }
+    if (blockIdx.x == 0 && threadIdx.x < (ntotal & 3)) {
+        const int64_t e = (n4 << 2) + threadIdx.x;
+        const int64_t pix = e / Cy;
+        const int c = (int)(e - pix * Cy);
+        y[e] = c < C1 ? x1[pix * C1 + c] : x2[pix * C2 + (c - C1)];
+    }
+}
+
 template <int VEC>
 __global__ void cat2_kernel(const float *__restrict__ x1, int C1, const float *__restrict__ x2, int C2,
                             float *__restrict__ y, int64_t npix) {
@@ -526,10 +555,8 @@ extern "C" int hoig_cat2_channels(const float *x1, int C1, const float *x2, int 
     if (!x1 || !x2 || !y || C1 <= 0 || C2 <= 0) return HOIG_EINVAL;
     if (((C1 | C2) & 3) == 0)
         cat2_kernel<4><<<hoig_stream_grid(npix * ((C1 + C2) >> 2), NT), NT, 0, ST>>>(x1, C1, x2, C2, y, npix);
-    else if (C1 + C2 <= 96)
-        cat2_rows_kernel<<<(unsigned)hoig_cdiv(npix, 256), 256, (size_t)256 * (C1 + C2) * sizeof(float), ST>>>(x1, C1, x2, C2, y, npix);
     else
-        cat2_kernel<1><<<hoig_stream_grid(npix * (C1 + C2), NT), NT, 0, ST>>>(x1, C1, x2, C2, y, npix);
+        cat2_flat_kernel<<<hoig_stream_grid(npix * (C1 + C2) / 4 + 1, NT), NT, 0, ST>>>(x1, C1, x2, C2, y, npix * (C1 + C2));
     HOIG_LAUNCH_CHECK();
     return HOIG_OK;
 }

@@ -59,7 +59,7 @@ def call(name, *a):
 
 ops._conv_fwd_raw, ops._conv_dgrad_raw, ops.call = fwd, dgrad, call
 
-opt = opt_namespace(gen_name='generator_spade_attn', local_rank=0, image_size=side)
+opt = opt_namespace(gen_name='generator_spade_attn', local_rank=0, image_size=side, hip_graph=False)
 torch.manual_seed(8)
 model = ModelsFactory.get_by_name('trainer', opt, use_ddp=False)
 model.set_train()
@@ -90,7 +90,7 @@ tot = sum(r[0] for r in rows)
 print('total conv time %.2f ms over %d launches (%s, batch %d, %d^2)' % (tot, len(records), prec, batch, side))
 print('%-6s %-52s %5s %9s %8s %7s' % ('kind', 'B Hi Wi Ci -> Ho Wo Co  RxR s p T', 'calls', 'ms', 'TF/s', 'cum%'))
 cum = 0.0
-for ms, kind, key, n, flop in rows[:70]:
+for ms, kind, key, n, flop in rows[:int(os.environ.get('ROWS', '70'))]:
     cum += ms
     B, Hi, Wi, Ci, Ho, Wo, Co, R, stride, pad, tr = key
     desc = '%d %dx%d %d -> %dx%d %d  %dx%d s%d p%d %s' % (B, Hi, Wi, Ci, Ho, Wo, Co, R, R, stride, pad, 'T' if tr else '')
