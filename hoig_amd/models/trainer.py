@@ -35,6 +35,16 @@ _GRAPH_MAX_SIGNATURES = 3
 # test hook (tests/test_trainer_gpu.py): cycles the optimiser side stream idles before each step's exchange + Adam, so that a
 # reader stream that is not ordered behind it shows up as a parity failure instead of hiding behind timing
 _TEST_SIDE_DELAY = 0
+# test hook (tests/test_ddp_rccl_gpu.py): a list that receives (tag, timing event) marks of the step's phases, to check that G's
+# exchange + Adam on the side stream really finish inside the D step they are meant to hide behind
+_TEST_TRACE = None
+
+
+def _mark(tag, stream=None):
+    if _TEST_TRACE is not None and not ops.capturing():
+        ev = torch.cuda.Event(enable_timing=True)
+        ev.record(stream if stream is not None else torch.cuda.current_stream())
+        _TEST_TRACE.append((tag, ev))
 
 PREPARED_KEYS = ['input_G_bg', 'input_G_src_obj', 'input_G_tsf_obj', 'input_G_src_hand', 'input_G_tsf_hand', 'T',
                  'real_src', 'real_tsf', 'bg_mask', 'hand_mask']
@@ -102,12 +112,13 @@ class Trainer(BaseModel):
         self._hdr = None          # HandRecoveryFlow: out of scope (needs MANO assets + neural_renderer)
         self._G = self._create_generator()
         self._G.init_weights()
+        payload = getattr(self._opt, 'ddp_payload', None)        # None: HOIG_DDP_PAYLOAD / fp32 (hoig_amd/ddp.py)
         if use_ddp:
-            self._G = FlatDDP(self._G)
+            self._G = FlatDDP(self._G, payload=payload)
         self._D = self._create_discriminator()
         self._D.init_weights()
         if use_ddp:
-            self._D = FlatDDP(self._D)
+            self._D = FlatDDP(self._D, payload=payload)
 
     def _create_generator(self):
         if not self._opt.use_spade:
@@ -306,7 +317,9 @@ class Trainer(BaseModel):
         fake_tsf_imgs, ev_fwd = self._phase_g(keep_data_for_visuals)
         self._step(self._G, self._optimizer_G, overlap=trainable)
         if trainable:
+            _mark('d_phase_begin')
             self._phase_d(fake_tsf_imgs, ev_fwd)
+            _mark('d_phase_end')
             self._wait_g()            # G's update has had the whole D step to finish; later readers need no special care
             self._step(self._D, self._optimizer_D, overlap=True)
 
@@ -382,11 +395,14 @@ class Trainer(BaseModel):
             return run()
         main = torch.cuda.current_stream()
         self._side.wait_stream(main)
+        which = 'g' if net is self._G else 'd'
         with torch.cuda.stream(self._side):
             if _TEST_SIDE_DELAY and not ops.capturing():
                 torch.cuda._sleep(int(_TEST_SIDE_DELAY))
             tree.set_pending(None)     # (this stream IS the writer: the previous step ran here too)
+            _mark('step_%s_begin' % which)
             run()
+            _mark('step_%s_end' % which)
             ev = torch.cuda.Event()
             ev.record(self._side)
         tree.set_pending(ev)
@@ -473,7 +489,9 @@ class Trainer(BaseModel):
         g1.replay()
         self._step(self._G, self._optimizer_G, overlap=trainable)
         if trainable:
+            _mark('d_phase_begin')
             g2.replay()
+            _mark('d_phase_end')
             self._wait_g()
             self._step(self._D, self._optimizer_D, overlap=True)
 

@@ -178,9 +178,17 @@ _capture_hold = []
 _capture_forked = set()        # weight-gradient side streams that have joined the capture (and must be joined back before it ends)
 
 
+_has_gpu = None
+
+
 def capturing():
     """True while a hipGraph is being captured -- through graph_capture() below, or by a caller's own torch.cuda.graph()."""
-    return _capture_depth > 0 or torch.cuda.is_current_stream_capturing()
+    global _has_gpu
+    if _capture_depth > 0:
+        return True
+    if _has_gpu is None:
+        _has_gpu = torch.cuda.is_available()          # (hoig_amd.ddp's exchange also runs on CPU tensors over gloo)
+    return _has_gpu and torch.cuda.is_current_stream_capturing()
 
 
 def begin_capture():

@@ -38,6 +38,47 @@ def _worker(rank, world, port, q):
     dist.destroy_process_group()
 
 
+def _worker_bf16(rank, world, port, q):
+    os.environ['MASTER_ADDR'] = '127.0.0.1'
+    os.environ['MASTER_PORT'] = str(port)
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    from hoig_amd.ddp import GradSync
+    g = torch.Generator().manual_seed(7 + rank)
+    grad = torch.randn(5000, generator=g) * (10.0 ** torch.randint(-6, 2, (5000,), generator=g).float())
+    param = torch.zeros(5000)
+    sync = GradSync(param, grad, bucket_bytes=4096, payload='bf16')
+    assert len(sync.slices) > 1 and sync.active
+    mine = grad.clone()
+    got = [ab for ab in sync.iter_all_reduce()]                 # the sliced form the optimiser consumes
+    assert got == sync.slices
+    q.put((rank, mine.numpy().copy(), grad.numpy().copy()))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_bf16_gradient_payload_world2():
+    """HOIG_DDP_PAYLOAD=bf16 / GradSync(payload='bf16'): the gradients travel as bf16 (half the bytes per link); both ranks end
+    with the SAME fp32 buffer, equal to the sum of the two gradients to bf16 rounding (8 significant bits: 2^-8 per rounding; one of
+    each addend, one of the sum)."""
+    world, port = 2, _free_port()
+    ctx = mp.get_context('spawn')
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_worker_bf16, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = sorted([q.get(timeout=120) for _ in range(world)], key=lambda t: t[0])
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    import numpy as np
+    (_, a0, s0), (_, a1, s1) = res
+    assert np.array_equal(s0, s1)
+    want = a0.astype(np.float64) + a1.astype(np.float64)
+    tol = 2 * 2.0 ** -8 * (np.abs(a0) + np.abs(a1)) + 1e-30
+    assert (np.abs(s0 - want) <= tol).all()
+    assert np.abs(s0 - want).max() > 0                          # (it really was rounded)
+
+
 def test_flat_ddp_broadcast_and_allreduce_world2():
     world, port = 2, _free_port()
     ctx = mp.get_context('spawn')

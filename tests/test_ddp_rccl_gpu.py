@@ -27,6 +27,78 @@ def _free_port():
     return p
 
 
+def _run_graph(port, q, payload):
+    """world-1 RCCL group, exchange forced on, the step CAPTURED: under DDP the trainer keeps the collectives outside the graphs
+    (graph 1 = forward + G loss + G backward | eager: G's exchange + Adam on the side stream | graph 2 = D loss + backward |
+    eager: D's exchange + Adam).  Returns the losses of every step, the first moments after the last one and phase timings."""
+    import torch.distributed as dist
+    from common import product_trainer
+    from hoig_amd import ops
+    from hoig_amd.models import trainer as T
+    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), HOIG_DDP_FORCE='1',
+                      HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get('HSA_ENABLE_IPC_MODE_LEGACY', '0'))
+    torch.cuda.set_device(0)
+    dist.init_process_group('nccl', rank=0, world_size=1, device_id=torch.device('cuda', 0))
+    ops.set_precision('bf16x3')
+    m = product_trainer('generator_spade_attn', BATCH, SIDE, use_ddp=True, hip_graph=True, ddp_payload=payload)
+    assert m._G.sync.active and m._G.sync.payload == payload
+    errs = []
+    steps = T._GRAPH_WARMUP + 3
+    T._TEST_TRACE = trace = []
+    for s in range(steps):
+        del trace[:]
+        m.optimize_parameters()
+        errs.append(dict(m.get_current_errors()))
+    torch.cuda.synchronize()
+    captured = [k for k, g in m._graphs.items() if g['graphs'] is not None]
+    two_graphs = bool(captured) and len(m._graphs[captured[0]]['graphs']) == 2
+    marks = dict(trace)                                  # the last (replayed) step
+    t0 = marks['step_g_begin']
+    rel = {k: t0.elapsed_time(v) for k, v in marks.items()}
+    g = m._net(m._G)
+    mom = {k: v.cpu().numpy().copy() for k, v in g.export_dict(m._optimizer_G.exp_avg).items() if k in PROBE}
+    q.put((errs, mom, two_graphs, rel, m._optimizer_G.step_count, float(m._optimizer_G._state[4])))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def _spawn_graph(payload):
+    ctx = mp.get_context('spawn')
+    q = ctx.Queue()
+    p = ctx.Process(target=_run_graph, args=(_free_port(), q, payload))
+    p.start()
+    res = q.get(timeout=900)
+    p.join(timeout=120)
+    assert p.exitcode == 0
+    return res
+
+
+def test_rccl_exchange_with_captured_step_and_bf16_payload():
+    """(1) The captured DDP step (two graphs, collectives between them) follows the eager DDP step's losses; (2) G's exchange +
+    Adam, queued on the side stream when graph 1 ends, finish before the D phase does (they are hidden behind it: with one rank
+    the exchange is a local copy, so this checks the stream choreography, not link speed); (3) with the bf16 payload the run
+    stays on the fp32-payload run's losses and its gradients differ by bf16 rounding only."""
+    from hoig_amd.models import trainer as T
+    e32, m32, two32, rel32, steps32, dev32 = _spawn_graph('f32')
+    e16, m16, two16, rel16, _, _ = _spawn_graph('bf16')
+    assert two32 and two16
+    assert steps32 == T._GRAPH_WARMUP + 3 == int(dev32)
+    for rel in (rel32, rel16):
+        print('phase marks (ms after G exchange start): %s' % {k: round(v, 3) for k, v in rel.items()})
+        assert rel['step_g_end'] > 0
+        assert rel['step_g_end'] <= rel['d_phase_end'] + 0.05, rel      # hidden behind the D phase
+        assert rel['d_phase_begin'] < rel['step_g_end']                 # ... and really beside it, not before it
+    e_eager, _, _, _, _ = _spawn(True)                                   # the eager DDP run of the test above (2 steps)
+    for s in range(len(e_eager)):
+        for k, want in e_eager[s].items():
+            assert abs(e32[s][k] - want) <= 1e-3 * max(abs(want), 1e-2), (s, k, e32[s][k], want)
+            assert abs(e16[s][k] - want) <= 2e-3 * max(abs(want), 1e-2), (s, k, e16[s][k], want)
+    for s in range(len(e32)):
+        assert all(np.isfinite(v) for v in e32[s].values()) and all(np.isfinite(v) for v in e16[s].values())
+    for k in PROBE:
+        assert np.isfinite(m16[k]).all() and np.linalg.norm(m16[k]) > 0
+
+
 def _run(use_ddp, port, q):
     import torch.distributed as dist
     from common import product_trainer
