@@ -267,8 +267,8 @@ def main():
                     help="'<forward>[:<data gradient>[:<weight gradient>]]' of f32 | bf16x3 | f16x2 | bf16; f16f6 = forward on fp16 + block-scaled fp6 terms, backward f16x2: "
                          "faster, outputs inside 1e-3, but its worst gradient tensor exceeds 3e-2 at 256x256 (profiles/r03_grad_parity_256.txt), so it is opt-in (hoig_amd/ops.py set_precision)")
     ap.add_argument('--no-cpu-baseline', action='store_true')
-    ap.add_argument('--no-graph', action='store_true', help='issue every step kernel by kernel instead of replaying the captured hipGraph')
-    ap.add_argument('--eager-steps', type=int, default=20, help='steps of the eager (uncaptured) comparison leg; 0 = skip')
+    ap.add_argument('--graph', action='store_true', help='time the step as a replayed hipGraph (default: issued kernel by kernel on its streams, which is faster on this ROCm: DESIGN.md section 3c)')
+    ap.add_argument('--graph-steps', type=int, default=20, help='steps of the comparison leg in the OTHER form (captured if the main run is eager, and vice versa); 0 = skip')
     ap.add_argument('--no-gen-fwd', action='store_true')
     ap.add_argument('--fwd-batch', type=int, default=32, help='batch of the generator-forward latency leg')
     ap.add_argument('--cpu-baseline-worker', type=int, default=0, help=argparse.SUPPRESS)
@@ -298,7 +298,7 @@ def main():
     ops.set_precision(args.precision)
 
     opt = opt_namespace(gen_name=args.gen_name, local_rank=local_rank, image_size=args.side, dataset_mode=args.dataset,
-                        hip_graph=not args.no_graph)
+                        hip_graph=bool(args.graph))
     torch.manual_seed(8)
     with contextlib.redirect_stdout(sys.stderr):       # the reference-style construction banners go to stderr
         model = ModelsFactory.get_by_name('trainer', opt, use_ddp=ddp)
@@ -313,7 +313,7 @@ def main():
 
     # untimed and not counted as warm-up: the eager iterations the trainer runs before it captures the step, and the capture
     from hoig_amd.models import trainer as trainer_mod
-    if not args.no_graph:
+    if args.graph:
         for _ in range(trainer_mod._GRAPH_WARMUP + 1):
             model.optimize_parameters()
     for _ in range(args.warmup):
@@ -329,20 +329,30 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
     errors = model.get_current_errors()
-    captured = bool(model._graphs) and all(g['graphs'] is not None for g in model._graphs.values())
+    is_captured = lambda: bool(model._graphs) and all(g['graphs'] is not None for g in model._graphs.values())
+    main_captured = is_captured()
 
-    eager_ms = None
-    if captured and args.eager_steps > 0:          # the same step issued kernel by kernel (what rounds 1-2 measured)
-        model._use_graph = False
-        for _ in range(3):
+    other_ms, other_host_ms = None, None
+    if args.graph_steps > 0:                       # the same step in the other form, same process, same weights
+        model._use_graph = not args.graph
+        for _ in range(trainer_mod._GRAPH_WARMUP + 2):
             model.optimize_parameters()
         barrier()
         t1 = time.perf_counter()
-        for _ in range(args.eager_steps):
+        for _ in range(args.graph_steps):
             model.optimize_parameters()
         barrier()
-        eager_ms = (time.perf_counter() - t1) / args.eager_steps * 1e3
-        model._use_graph = True
+        other_ms = (time.perf_counter() - t1) / args.graph_steps * 1e3
+        t1 = time.perf_counter()                   # host time of ONE step issued on an idle device (pure issue cost)
+        model.optimize_parameters()
+        other_host_ms = (time.perf_counter() - t1) * 1e3
+        barrier()
+        other_captured = is_captured()
+        model._use_graph = bool(args.graph)
+    t1 = time.perf_counter()
+    model.optimize_parameters()
+    main_host_ms = (time.perf_counter() - t1) * 1e3
+    barrier()
 
     if rank == 0:
         ms = dt / args.steps * 1e3
@@ -359,8 +369,13 @@ def main():
                                                            args.batch, args.gen_name),
                        'global_batch': world * args.batch, 'parallelism': 'dp%d' % world},
             'step_tflops': round(GFLOP_PER_PAIR_TRAIN_256 * (args.side / 256.0) ** 2 * value / 1e3, 2),
-            'hipgraph': {'captured_step': captured, 'eager_ms_per_step': None if eager_ms is None else round(eager_ms, 3),
-                         'eager_value': None if eager_ms is None else round(world * args.batch / (eager_ms * 1e-3), 3)},
+            'step_form': 'captured hipGraph replay' if main_captured else 'eager: kernels issued on the step\'s HIP streams',
+            'host_ms_per_step_idle_device': round(main_host_ms, 2),
+            'hipgraph': None if other_ms is None else {
+                'form': 'eager' if args.graph else 'captured hipGraph replay',
+                'captured_step': bool(other_captured) if not args.graph else main_captured,
+                'ms_per_step': round(other_ms, 3), 'value': round(world * args.batch / (other_ms * 1e-3), 3),
+                'host_ms_per_step_idle_device': round(other_host_ms, 2)},
             'roofline': roof,
             'losses_finite': all(v == v and abs(v) != float('inf') for v in errors.values()),
         }

@@ -28,8 +28,11 @@ from .networks import NetworksFactory
 from .networks.generator import to_nhwc, as_nchw, forks_streams as generator_forks_streams
 from .networks.vgg19 import Vgg19, VGGLoss
 
-# HOIG_GRAPH=0: never capture the training step in a hipGraph (every step issued kernel by kernel, as in rounds 1-2)
-_GRAPH = os.environ.get('HOIG_GRAPH', '1') == '1'
+# HOIG_GRAPH=1 (or opt.hip_graph=True): replay the training step as a captured hipGraph after two eager iterations per batch shape.
+# Off by default: on this ROCm the replay costs the host 4 ms instead of 28 ms per step, but the graph's internal stream mapping
+# overlaps the chains less than the eager streams do -- 80.2 / 81.7 ms per replayed step against 74.8 / 79.5 ms eager, two boxes
+#  -- and the step is GPU-bound either way.
+_GRAPH = os.environ.get('HOIG_GRAPH', '0') == '1'
 _GRAPH_WARMUP = 2         # eager steps per input signature before the capture (lazily made buffers and planes then exist)
 _GRAPH_MAX_SIGNATURES = 3
 # test hook (tests/test_trainer_gpu.py): cycles the optimiser side stream idles before each step's exchange + Adam, so that a
@@ -300,9 +303,10 @@ class Trainer(BaseModel):
 
     # ------------------------------------------------------------------ one GAN iteration (trainer.py:417-434)
     def optimize_parameters(self, trainable=True, keep_data_for_visuals=False):
-        """forward -> G loss -> zero / backward / Adam(G) -> if `trainable`: D loss -> zero / backward / Adam(D).  After
-        _GRAPH_WARMUP eager iterations on a batch shape the whole iteration is captured in a hipGraph and replayed from then on
-        (one host call per step instead of ~1 500 launches); iterations that keep data for visuals run eagerly."""
+        """forward -> G loss -> zero / backward / Adam(G) -> if `trainable`: D loss -> zero / backward / Adam(D).  With
+        opt.hip_graph / HOIG_GRAPH=1: after _GRAPH_WARMUP eager iterations on a batch shape the whole iteration is captured in a
+        hipGraph and replayed from then on (one host call per step instead of ~1 500 launches); iterations that keep data for
+        visuals run eagerly."""
         if not self._is_train:
             return
         if self._use_graph and not keep_data_for_visuals:

@@ -209,7 +209,11 @@ class graph_capture(object):
     """``with ops.graph_capture(graph, pool=None):`` = ``torch.cuda.graph`` plus this module's capture bookkeeping."""
 
     def __init__(self, graph, pool=None):
-        self._ctx = torch.cuda.graph(graph, pool=pool)
+        # thread-local error mode: the capture still records every launch into the capturing streams (the autograd thread's
+        # included), but a HIP call made by ANOTHER thread meanwhile -- ProcessGroupNCCL's watchdog polling the events of earlier
+        # collectives -- is not an error that takes the process down (measured: 'operation not permitted when stream is capturing'
+        # from the watchdog thread under the default global mode)
+        self._ctx = torch.cuda.graph(graph, pool=pool, capture_error_mode='thread_local')
 
     def __enter__(self):
         begin_capture()

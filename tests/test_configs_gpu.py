@@ -152,7 +152,7 @@ def test_bench_line_contract():
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     env = {k: v for k, v in os.environ.items() if k not in ('WORLD_SIZE', 'RANK', 'LOCAL_RANK')}
     r = subprocess.run([sys.executable, os.path.join(root, 'bench.py'), '--steps', '2', '--warmup', '1', '--no-cpu-baseline',
-                        '--fwd-batch', '8', '--eager-steps', '2'], env=env, capture_output=True, text=True, timeout=900)
+                        '--fwd-batch', '8', '--graph-steps', '2'], env=env, capture_output=True, text=True, timeout=900)
     assert r.returncode == 0, r.stderr[-2000:]
     lines = [l for l in r.stdout.splitlines() if l.startswith('{')]
     assert len(lines) == 1, r.stdout[-2000:]
@@ -167,7 +167,7 @@ def test_bench_line_contract():
     assert rf['bound'] == 'mfma' and rf['unit'] == 'TFLOP/s' and rf['peak'] == 2500.0
     assert abs(rf['frac'] - rf['achieved'] / rf['peak']) < 1e-3 and 0.05 < rf['frac'] < 0.334
     assert 'conv_halo3_bf16_kernel' in rf['kernel'] and rf['traffic_source']                # counters come from a committed pass
-    assert d['hipgraph']['captured_step'] is True and d['hipgraph']['eager_ms_per_step'] > 0
+    assert d['hipgraph']['captured_step'] is True and d['hipgraph']['ms_per_step'] > 0 and d['step_form'].startswith('eager')
     assert d['gen_fwd']['finite'] and d['gen_fwd']['batch'] == 8 and d['losses_finite'] is True
     assert 'cpu_baseline' not in d or d['cpu_baseline'] is None or isinstance(d['cpu_baseline'], dict)
 

@@ -1,6 +1,6 @@
 mkdir -p gpurun_out/r3b
 timeout 900 python -m pytest tests/test_graph_gpu.py -x -q 2>&1 | tail -30 > gpurun_out/r3b/pytest_graph.log
-B="python bench.py --steps 20 --warmup 3 --no-cpu-baseline --no-gen-fwd --eager-steps 0"
+B="python bench.py --steps 20 --warmup 3 --no-cpu-baseline --no-gen-fwd --graph-steps 0"
 run() { name=$1; shift; env "$@" timeout 300 $B 2>/dev/null | python -c "import sys,json; d=json.loads(sys.stdin.read()); print('$name', d['ms_per_step'], d['value'])" >> gpurun_out/r3b/sweep.txt 2>&1; }
 run base X=1
 run q2 DEBUG_HIP_FORCE_GRAPH_QUEUES=2
