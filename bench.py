@@ -303,7 +303,8 @@ def main():
     with contextlib.redirect_stdout(sys.stderr):       # the reference-style construction banners go to stderr
         model = ModelsFactory.get_by_name('trainer', opt, use_ddp=ddp)
     model.set_train()
-    model.set_input(synthetic.make_inputs(args.batch, args.side, seed=8 + rank, dataset=args.dataset))
+    inputs = synthetic.make_inputs(args.batch, args.side, seed=8 + rank, dataset=args.dataset)
+    model.set_input(inputs)
     torch.cuda.synchronize()
 
     def barrier():
@@ -335,6 +336,7 @@ def main():
     other_ms, other_host_ms = None, None
     if args.graph_steps > 0:                       # the same step in the other form, same process, same weights
         model._use_graph = not args.graph
+        model.set_input(inputs)                    # (a captured step reads its inputs from staging buffers made by set_input)
         for _ in range(trainer_mod._GRAPH_WARMUP + 2):
             model.optimize_parameters()
         barrier()
