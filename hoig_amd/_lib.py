@@ -51,6 +51,7 @@ _vp, _i, _i64, _f, _d = ctypes.c_void_p, ctypes.c_int, ctypes.c_int64, ctypes.c_
 _SIGS = {
     'hoig_conv2d_fwd': [ctypes.POINTER(ConvDesc), _vp, _vp, _vp, _vp, _vp],
     'hoig_conv2d_bwd_data': [ctypes.POINTER(ConvDesc), _vp, _vp, _vp, _vp],
+    'hoig_conv2d_fwd_heads': [ctypes.POINTER(ConvDesc), _vp, _vp, _vp, _vp, ctypes.c_uint64, _vp],
     'hoig_conv2d_bwd_weight': [ctypes.POINTER(ConvDesc), _vp, _vp, _vp, _vp, _vp],
     'hoig_pack_conv_weight_bf16': [_vp, _i, _i, _i, _i, _vp, _vp, _vp],
     'hoig_pack_conv_weights_bf16_all': [_vp, _vp, _i, _i64, _vp, _vp, _vp, _vp, _vp],

@@ -584,10 +584,19 @@ int hoig_conv_small_dgrad(const hoig_conv_desc *d, const float *dy, const float 
 int hoig_conv_small_ci_fwd(const hoig_conv_desc *d, const float *x, const float *w, const float *bias, float *y,
                            hipStream_t st);
 int hoig_conv_dot_fwd(const hoig_conv_desc *d, const float *x, const float *w, const float *bias, float *y, hipStream_t st);
+int hoig_conv_small_fwd_acts(const hoig_conv_desc *d, const float *x, const float *w, const float *bias, float *y,
+                             unsigned long long acts, hipStream_t st);
 // conv_thin.hip: stride-1 'same' convolutions with <= 8 (3x3: 16) channels on one side, taps in place of the missing channels
 int hoig_conv_thin_fwd(const hoig_conv_desc *d, const float *x, const float *w, const float *bias, float *y, hipStream_t st);
 int hoig_conv_thin_dgrad(const hoig_conv_desc *d, const float *dy, const float *w, float *dx, int accumulate, hipStream_t st);
 int hoig_conv_thin_wgrad(const hoig_conv_desc *d, const float *x, const float *dy, float *dw, hipStream_t st);
+int hoig_conv_thin_out(const hoig_conv_desc *d, const float *x, const float *w, const float *bias, float *y,
+                       unsigned long long acts, int dgrad, hipStream_t st);
+static unsigned long long uniform_acts(int act) {
+    unsigned long long a = 0;
+    for (int f = 0; f < 16; ++f) a |= (unsigned long long)(act & 15) << (4 * f);
+    return a;
+}
 static bool thin_enabled() {
     static const bool on = getenv("HOIG_NO_THIN") == nullptr;            // A/B switch: back to the fp32 VALU / generic kernels
     return on;
@@ -600,6 +609,7 @@ extern "C" int hoig_conv2d_fwd(const hoig_conv_desc *d, const float *x, const fl
     if (!x || !w || !y) return HOIG_EINVAL;
     hipStream_t st = (hipStream_t)stream;
     rc = hoig_conv_small_fwd(d, x, w, bias, y, st);           // 7x7 heads with <= 4 output channels: direct fp32 kernel
+    if (rc == HOIG_EUNSUPPORTED && thin_enabled()) rc = hoig_conv_thin_out(d, x, w, bias, y, uniform_acts(d->act), 0, st);   // 3x3, <= 16 outputs
     if (rc == HOIG_EUNSUPPORTED && thin_enabled()) rc = hoig_conv_thin_fwd(d, x, w, bias, y, st);      // thin-input convs on MFMA
     if (rc == HOIG_EUNSUPPORTED) rc = hoig_conv_small_ci_fwd(d, x, w, bias, y, st);    // 7x7 stems with <= 8 input channels
     if (rc == HOIG_EUNSUPPORTED) rc = hoig_conv_dot_fwd(d, x, w, bias, y, st);         // <= 4 outputs over >= 1024 products
@@ -616,6 +626,18 @@ extern "C" int hoig_conv2d_fwd(const hoig_conv_desc *d, const float *x, const fl
     return dispatch_igemm(a, false, st);
 }
 
+// forward of a convolution with <= 16 output channels and a different activation per output channel (the generator's fused
+// image / mask heads: tanh | sigmoid | none): `acts` holds the HOIG_ACT_* code of channel f in bits [4f, 4f+4)
+extern "C" int hoig_conv2d_fwd_heads(const hoig_conv_desc *d, const float *x, const float *w, const float *bias, float *y,
+                                     uint64_t acts, hoig_stream_t stream) {
+    int rc = check_desc(d);
+    if (rc) return rc;
+    if (!x || !w || !y) return HOIG_EINVAL;
+    rc = hoig_conv_small_fwd_acts(d, x, w, bias, y, acts, (hipStream_t)stream);          // 7x7, <= 5 outputs: fp32 VALU (every mode)
+    if (rc == HOIG_EUNSUPPORTED) rc = hoig_conv_thin_out(d, x, w, bias, y, acts, 0, (hipStream_t)stream);
+    return rc;
+}
+
 extern "C" int hoig_conv2d_bwd_data(const hoig_conv_desc *d, const float *dy, const float *w, float *dx,
                                     hoig_stream_t stream) {
     int rc = check_desc(d);
@@ -623,6 +645,7 @@ extern "C" int hoig_conv2d_bwd_data(const hoig_conv_desc *d, const float *dy, co
     if (!dy || !w || !dx) return HOIG_EINVAL;
     hipStream_t st = (hipStream_t)stream;
     rc = thin_enabled() ? hoig_conv_thin_dgrad(d, dy, w, dx, 0, st) : HOIG_EUNSUPPORTED;     // thin-output convs (heads) on MFMA
+    if (rc == HOIG_EUNSUPPORTED && thin_enabled()) rc = hoig_conv_thin_out(d, dy, w, nullptr, dx, 0, 1, st);   // thin-INPUT convs (VGG conv1_1)
     if (rc == HOIG_EUNSUPPORTED) rc = hoig_conv_small_dgrad(d, dy, w, dx, st);     // ... or the direct fp32 kernel (HOIG_PREC_F32)
     if (rc != HOIG_EUNSUPPORTED) return rc;
     if (d->precision != HOIG_PREC_F32) {

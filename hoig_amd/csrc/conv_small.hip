@@ -26,8 +26,8 @@ constexpr int F4_TW = 64, F4_TH = 16, F4_ROW = 80, F4_CC = 8;
 template <int CO>
 __global__ __launch_bounds__(256) void conv_small_fwd4_kernel(const float *__restrict__ x, const float *__restrict__ w,
                                                               const float *__restrict__ bias, float *__restrict__ y,
-                                                              int B, int H, int W, int Ci, int pad, int act, float slope,
-                                                              int CoReal) {
+                                                              int B, int H, int W, int Ci, int pad, unsigned long long acts,
+                                                              float slope, int CoReal) {
     constexpr int HT = F4_TH + KS - 1, WT = F4_TW + KS - 1;          // 22 x 70 halo pixels
     constexpr int PLANE = HT * F4_ROW;                               // float4 slots per plane
     __shared__ float4 xs[2 * PLANE];                                 // 56 KB
@@ -135,7 +135,7 @@ __global__ __launch_bounds__(256) void conv_small_fwd4_kernel(const float *__res
                 float *o = y + (((size_t)b * H + oy) * W + ox) * CoReal;
 #pragma unroll
                 for (int n = 0; n < CO; ++n)
-                    o[n] = hoig_act(acc[j][n].x + acc[j][n].y + (bias ? bias[n] : 0.f), act, slope);
+                    o[n] = hoig_act(acc[j][n].x + acc[j][n].y + (bias ? bias[n] : 0.f), (int)((acts >> (4 * n)) & 15), slope);
             }
         }
     }
@@ -341,23 +341,31 @@ __global__ __launch_bounds__(256) void conv_small_wgrad_kernel(const float *__re
 }  // namespace
 
 // returns HOIG_EUNSUPPORTED when the problem is not a small-Co stride-1 "same" convolution
-int hoig_conv_small_fwd(const hoig_conv_desc *d, const float *x, const float *w, const float *bias, float *y,
-                        hipStream_t st) {
-    if (d->transposed || d->stride != 1 || d->Co > 4 || (d->Ci % CC) || d->R != KS || d->S != KS) return HOIG_EUNSUPPORTED;
+// `acts`: the HOIG_ACT_* code of output channel n in bits [4n, 4n+4) (one activation per head of a fused launch)
+int hoig_conv_small_fwd_acts(const hoig_conv_desc *d, const float *x, const float *w, const float *bias, float *y,
+                             unsigned long long acts, hipStream_t st) {
+    if (d->transposed || d->stride != 1 || d->Co > 5 || (d->Ci % CC) || d->R != KS || d->S != KS) return HOIG_EUNSUPPORTED;
     if (d->Ho != d->Hi || d->Wo != d->Wi || 2 * d->pad != d->R - 1 || d->R != d->S) return HOIG_EUNSUPPORTED;
     const int tiles = d->B * (int)hoig_cdiv(d->Hi, F4_TH) * (int)hoig_cdiv(d->Wi, F4_TW);
 #define HOIG_SMALL_FWD(N)                                                                                          \
-    conv_small_fwd4_kernel<N><<<tiles, 256, 0, st>>>(x, w, bias, y, d->B, d->Hi, d->Wi, d->Ci, d->pad, d->act, d->slope, \
-                                                     d->Co)
+    conv_small_fwd4_kernel<N><<<tiles, 256, 0, st>>>(x, w, bias, y, d->B, d->Hi, d->Wi, d->Ci, d->pad, acts, d->slope, d->Co)
     switch (d->Co) {
         case 1: HOIG_SMALL_FWD(1); break;
         case 2: HOIG_SMALL_FWD(2); break;
         case 3: HOIG_SMALL_FWD(3); break;
-        default: HOIG_SMALL_FWD(4); break;
+        case 4: HOIG_SMALL_FWD(4); break;
+        default: HOIG_SMALL_FWD(5); break;
     }
 #undef HOIG_SMALL_FWD
     HOIG_LAUNCH_CHECK();
     return HOIG_OK;
+}
+int hoig_conv_small_fwd(const hoig_conv_desc *d, const float *x, const float *w, const float *bias, float *y,
+                        hipStream_t st) {
+    if (d->Co > 4) return HOIG_EUNSUPPORTED;
+    unsigned long long acts = 0;
+    for (int n = 0; n < 16; ++n) acts |= (unsigned long long)(d->act & 15) << (4 * n);
+    return hoig_conv_small_fwd_acts(d, x, w, bias, y, acts, st);
 }
 
 // forward of 7x7 stride-1 "same" convs with few INPUT channels (3, 8: the stems) and Co % 16 == 0: groups of <= 4 input

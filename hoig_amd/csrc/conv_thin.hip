@@ -463,6 +463,170 @@ float *thin_workspace(hipStream_t st, size_t bytes) {
     return base + (size_t)slot * (WS_SLOT_BYTES / sizeof(float));
 }
 
+// ------------------------------------------------------------------------------------------------------------ thin OUTPUT
+// out[p][f] = sum_tap sum_j D[p + off(tap)][j] * W[f][tap][j]  with F <= 16 output channels: the FORWARD of the image / mask heads
+// (64 -> 1 | 3 | 5 fused, 7x7) and the data gradient of a thin-input layer (VGG conv1_1: 64 -> 3, 3x3, taps mirrored).  The
+// 16x16x32 MFMA keeps N at 16 (the 32-wide form would waste twice as much): a wave owns two 16-pixel row segments, A fragments
+// are read from the 16-bit halo image of D (32 channels per pass, 80-B pixel rows) at the tap's offset, B fragments from the
+// LDS-resident weights [f][tap][64]; lanes n >= F multiply zeros.  Per-channel activations (tanh image | sigmoid mask | none)
+// come as 4-bit codes.
+typedef float f32x4v __attribute__((ext_vector_type(4)));
+
+struct ThinOutArgs {
+    const float *D, *Wt, *bias;
+    float *Out;
+    int Bn, H, W, F, CD, KS, pad, flip;
+    int sf, st, sj;          // weight element index = f * sf + tap * st + j * sj
+    unsigned long long acts; // activation code of output channel f in bits [4f, 4f+4)
+    float slope, wscale;
+    int tiles_x, tiles_y, ntiles, strip, HR, HWc;
+};
+
+template <bool FP16>
+__device__ __forceinline__ f32x4v mfma16x16(const bf16x8 a, const bf16x8 b, const f32x4v c) {
+    if (FP16) return __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, a), __builtin_bit_cast(f16x8, b), c, 0, 0, 0);
+    return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0);
+}
+
+template <bool FP16, int ND, int NW>
+__global__ __launch_bounds__(NTHR) void thin_out_kernel(const ThinOutArgs p) {
+    constexpr int PROW = 80, WROW = 144;                                  // bytes per halo pixel (32 ch + pad) / weight row (64 ch + pad)
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int KK = p.KS * p.KS, hpix = p.HR * p.HWc;
+    unsigned char *Wl = smem;                                             // [NW][CD / 64][F][KK][WROW]
+    unsigned char *Dl = smem + (size_t)NW * (p.CD >> 6) * p.F * KK * WROW;        // [ND][hpix][PROW]
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int l15 = lane & 15, kg = lane >> 4;
+    const int wplane = p.F * KK * WROW;
+
+    for (int i0 = tid; i0 < p.F * KK * p.CD; i0 += 4 * NTHR) {            // weights -> 16-bit planes (four loads in flight)
+        float v[4];
+        int dst[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int i = i0 + u * NTHR;
+            v[u] = 0.f;
+            dst[u] = -1;
+            if (i < p.F * KK * p.CD) {
+                const int j = i % p.CD, ft = i / p.CD;
+                const int tap = ft % KK, f = ft / KK;
+                const int tw = p.flip ? KK - 1 - tap : tap;
+                v[u] = p.Wt[(size_t)f * p.sf + (size_t)tw * p.st + (size_t)j * p.sj];
+                dst[u] = ((j >> 6) * p.F * KK + f * KK + tap) * WROW + (j & 63) * 2;      // (64-channel groups one after the other)
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+            if (dst[u] >= 0) {
+                unsigned short hi, lo;
+                split16<FP16>(v[u] * p.wscale, hi, lo);
+                *reinterpret_cast<unsigned short *>(Wl + dst[u]) = hi;
+                if (NW == 2) *reinterpret_cast<unsigned short *>(Wl + (size_t)(p.CD >> 6) * wplane + dst[u]) = lo;
+            }
+    }
+
+    // this wave's two 16-pixel segments: segment g = 2 * wave + i -> tile row g >> 1, columns 16 * (g & 1) ..
+    int apix[2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const int g = 2 * wave + i;
+        apix[i] = ((g >> 1) * p.HWc + 16 * (g & 1) + l15) * PROW + kg * 16;
+    }
+    const bool nvalid = l15 < p.F;
+    const int wrow0 = l15 * KK * WROW + kg * 16;
+    const float inv = 1.f / p.wscale;
+    const int act_n = (int)((p.acts >> (4 * l15)) & 15);
+    const float bias_n = (p.bias && nvalid) ? p.bias[l15] : 0.f;
+
+    constexpr int HT = 12;                                                // float4 loads per thread: 10 x 38 pixels x 8 quads / 256
+    float4 hreg[HT];
+    auto halo_load = [&](int t, int kh) {
+        int b, y0, x0;
+        const int tx = t % p.tiles_x, r1 = t / p.tiles_x;
+        b = r1 / p.tiles_y;
+        y0 = (r1 % p.tiles_y) * TH;
+        x0 = tx * TW;
+#pragma unroll
+        for (int it = 0; it < HT; ++it) {
+            const int i = tid + it * NTHR;
+            hreg[it] = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (it * NTHR < hpix * 8 && i < hpix * 8) {
+                const int px = i >> 3, c4 = i & 7;
+                const int hy = px / p.HWc, hx = px - hy * p.HWc;
+                const int gy = y0 - p.pad + hy, gx = x0 - p.pad + hx;
+                if (gy >= 0 && gy < p.H && gx >= 0 && gx < p.W)
+                    hreg[it] = *reinterpret_cast<const float4 *>(p.D + (((size_t)b * p.H + gy) * p.W + gx) * p.CD + kh * 32 + c4 * 4);
+            }
+        }
+    };
+    auto halo_store = [&]() {
+#pragma unroll
+        for (int it = 0; it < HT; ++it) {
+            const int i = tid + it * NTHR;
+            if (it * NTHR < hpix * 8 && i < hpix * 8) {
+                const int px = i >> 3, c4 = i & 7;
+                const float v[4] = {hreg[it].x, hreg[it].y, hreg[it].z, hreg[it].w};
+                unsigned short h[4], l[4];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) split16<FP16>(v[e], h[e], l[e]);
+                *reinterpret_cast<uint2 *>(Dl + px * PROW + c4 * 8) = make_uint2(h[0] | ((unsigned)h[1] << 16), h[2] | ((unsigned)h[3] << 16));
+                if (ND == 2)
+                    *reinterpret_cast<uint2 *>(Dl + hpix * PROW + px * PROW + c4 * 8) =
+                        make_uint2(l[0] | ((unsigned)l[1] << 16), l[2] | ((unsigned)l[3] << 16));
+            }
+        }
+    };
+
+    const int nkh = p.CD >> 5;
+    const int t_begin = blockIdx.x * p.strip, t_end = min(p.ntiles, t_begin + p.strip);
+    if (t_begin < t_end) halo_load(t_begin, 0);
+    for (int t = t_begin; t < t_end; ++t) {
+        f32x4v acc[2];
+#pragma unroll
+        for (int i = 0; i < 2; ++i) acc[i] = (f32x4v){0.f, 0.f, 0.f, 0.f};
+        for (int kh = 0; kh < nkh; ++kh) {
+            __syncthreads();                                              // the previous image (and the weights) are done / ready
+            halo_store();
+            __syncthreads();
+            if (kh + 1 < nkh) halo_load(t, kh + 1);                       // the next image flies during the MFMAs
+            else if (t + 1 < t_end) halo_load(t + 1, 0);
+            const unsigned char *wbase = Wl + (size_t)(kh >> 1) * wplane + wrow0 + (kh & 1) * 64;
+#pragma unroll 1
+            for (int tap = 0; tap < KK; ++tap) {
+                const int r = tap / p.KS, s_ = tap - r * p.KS;
+                const int toff = (r * p.HWc + s_) * PROW;
+                bf16x8 bh = {0, 0, 0, 0, 0, 0, 0, 0}, bl = bh;
+                if (nvalid) {
+                    bh = *reinterpret_cast<const bf16x8 *>(wbase + tap * WROW);
+                    if (NW == 2) bl = *reinterpret_cast<const bf16x8 *>(wbase + (size_t)(p.CD >> 6) * wplane + tap * WROW);
+                }
+#pragma unroll
+                for (int i = 0; i < 2; ++i) {
+                    const unsigned char *ap = Dl + apix[i] + toff;
+                    const bf16x8 ah = *reinterpret_cast<const bf16x8 *>(ap);
+                    if (ND == 2) acc[i] = mfma16x16<FP16>(*reinterpret_cast<const bf16x8 *>(ap + hpix * PROW), bh, acc[i]);
+                    if (NW == 2) acc[i] = mfma16x16<FP16>(ah, bl, acc[i]);
+                    acc[i] = mfma16x16<FP16>(ah, bh, acc[i]);
+                }
+            }
+        }
+        if (nvalid) {
+            const int tx = t % p.tiles_x, r1 = t / p.tiles_x;
+            const int b = r1 / p.tiles_y, y0 = (r1 % p.tiles_y) * TH, x0 = tx * TW;
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                const int g = 2 * wave + i;
+                const int oy = y0 + (g >> 1), oxb = x0 + 16 * (g & 1) + 4 * kg;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const float v = acc[i][e] * inv + bias_n;
+                    p.Out[(((size_t)b * p.H + oy) * p.W + oxb + e) * p.F + l15] = hoig_act(v, act_n, p.slope);
+                }
+            }
+        }
+    }
+}
+
 bool thin_geometry(const hoig_conv_desc *d) {
     return !d->transposed && d->stride == 1 && d->R == d->S && (d->R & 1) && d->R <= 7 && 2 * d->pad == d->R - 1 &&
            d->Ho == d->Hi && d->Wo == d->Wi && (d->Hi % TH) == 0 && (d->Wi % TW) == 0;
@@ -599,6 +763,57 @@ int hoig_conv_thin_wgrad(const hoig_conv_desc *d, const float *x, const float *d
     else rc = launch_wgrad_t<4, 4>(a, nt, nd, grid, smem, st);
     if (rc != HOIG_OK || !a.Ws) return rc;
     thin_reduce_kernel<<<dim3((unsigned)hoig_cdiv(64 * a.N, NTHR), groups, (unsigned)hoig_cdiv(nwg, 32)), NTHR, 0, st>>>(a, nwg);
+    HOIG_LAUNCH_CHECK();
+    return HOIG_OK;
+}
+
+// forward of a thin-OUTPUT convolution (Co <= 16, Ci % 64 == 0) with per-channel activation codes (4 bits per output channel;
+// HOIG_ACT_*), or -- dgrad != 0 -- the data gradient of a thin-INPUT convolution (Ci <= 16 outputs, Co % 64 == 0 gathered)
+int hoig_conv_thin_out(const hoig_conv_desc *d, const float *x, const float *w, const float *bias, float *y,
+                       unsigned long long acts, int dgrad, hipStream_t st) {
+    if (d->precision == HOIG_PREC_F32 || !thin_geometry(d)) return HOIG_EUNSUPPORTED;
+    const int F = dgrad ? d->Ci : d->Co, CD = dgrad ? d->Co : d->Ci;
+    if (F < 1 || F > 16 || (CD % 64)) return HOIG_EUNSUPPORTED;
+    // Every A fragment feeds ONE 16-wide MFMA here, so the kernel is bound by LDS reads, not by the matrix pipe: measured on the
+    // 7x7 heads 228 / 362 us (64 -> 1 / 3, 8 images at 256x256) against 120 / 190 us on the fp32 VALU kernel, whose LDS reads
+    // each feed 7 taps x Co FMAs -- but 84 against 299 us on the 3x3 data gradient of VGG conv1_1.  Small kernels only.
+    if (d->R > 3) return HOIG_EUNSUPPORTED;
+    ThinOutArgs a;
+    a.D = x; a.Wt = w; a.bias = bias; a.Out = y;
+    a.Bn = d->B; a.H = d->Hi; a.W = d->Wi; a.F = F; a.CD = CD; a.KS = d->R; a.pad = d->pad;
+    const int KK = d->R * d->S;
+    if (!dgrad) { a.flip = 0; a.sf = KK * CD; a.st = CD; a.sj = 1; a.wscale = 256.f; }       // w[f][tap][j]
+    else { a.flip = 1; a.sf = 1; a.st = F; a.sj = KK * F; a.wscale = 1.f; }                 // w[j][tap][f]
+    a.acts = acts; a.slope = d->slope;
+    a.tiles_x = d->Wi / TW; a.tiles_y = d->Hi / TH; a.ntiles = d->B * a.tiles_x * a.tiles_y;
+    a.strip = a.ntiles >= 2048 ? 8 : (a.ntiles >= 512 ? 2 : 1);
+    a.HR = TH + d->R - 1; a.HWc = TW + d->R - 1;
+    if (a.HR * a.HWc * 8 > 12 * NTHR) return HOIG_EUNSUPPORTED;
+    const int nd = d->precision == HOIG_PREC_BF16 ? 1 : 2, nw = d->precision == HOIG_PREC_BF16X3 ? 2 : 1;
+    const size_t smem = (size_t)nw * (CD / 64) * F * KK * 144 + (size_t)nd * a.HR * a.HWc * 80;
+    if (smem > 160 * 1024) return HOIG_EUNSUPPORTED;
+    const unsigned grid = (unsigned)hoig_cdiv(a.ntiles, a.strip);
+#define HOIG_THIN_OUT(FP16_, ND_, NW_)                                                                                   \
+    do {                                                                                                                 \
+        static bool attr = false;                                                                                        \
+        if (!attr) {                                                                                                     \
+            if (hipFuncSetAttribute(reinterpret_cast<const void *>(&thin_out_kernel<FP16_, ND_, NW_>),                   \
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess)               \
+                return HOIG_ELAUNCH;                                                                                     \
+            attr = true;                                                                                                 \
+        }                                                                                                                \
+        thin_out_kernel<FP16_, ND_, NW_><<<grid, NTHR, smem, st>>>(a);                                                   \
+    } while (0)
+    if (!dgrad) {
+        if (nd == 2 && nw == 2) HOIG_THIN_OUT(true, 2, 2);
+        else if (nd == 2) HOIG_THIN_OUT(true, 2, 1);
+        else HOIG_THIN_OUT(true, 1, 1);
+    } else {
+        if (nd == 2 && nw == 2) HOIG_THIN_OUT(false, 2, 2);
+        else if (nd == 2) HOIG_THIN_OUT(false, 2, 1);
+        else HOIG_THIN_OUT(false, 1, 1);
+    }
+#undef HOIG_THIN_OUT
     HOIG_LAUNCH_CHECK();
     return HOIG_OK;
 }

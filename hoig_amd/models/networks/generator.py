@@ -35,6 +35,9 @@ def as_nchw(t):
 _FORK_STREAMS = os.environ.get('HOIG_STREAMS', os.environ.get('HOIG_G_STREAMS', '1')) == '1'
 
 
+_FUSE_HEADS = os.environ.get('HOIG_FUSE_HEADS', '1') == '1'      # A/B switch: the three x-side heads as separate convolutions
+
+
 def forks_streams():
     """True if Generator.forward runs bg_model / obj_model / src_model on branch streams (their backward then runs there too)."""
     return _FORK_STREAMS
@@ -54,6 +57,12 @@ class Generator(ParamTree):
         super().__init__(sch.shapes, device, sch.transposed, split)
         self._name = 'generator'
         self._seg_cache = {}
+        # the three heads that read the decoder's last feature map -- img_reg (3), attetion_reg_hand (1) and the x half of
+        # attetion_reg_bg (1) -- are registered one after the other (generator.py:219-235), so their packed weights are ONE
+        # (5, C, 7, 7) block of the flat store: evaluate them as one convolution (ops.conv_heads)
+        for m in ('src_model', 'tsf_model'):
+            names = [m + '.img_reg.0.weight', m + '.attetion_reg_hand.0.weight', m + '.attetion_reg_bg.0.weight#t']
+            self.fuse_conv_weights(m + '.heads_x.weight', names)
 
     @property
     def name(self):
@@ -230,13 +239,21 @@ class Generator(ParamTree):
                                  to_nhwc(tsf_hand_conds), to_nhwc(src_armask), to_nhwc(tsf_armask))
         return tuple(as_nchw(o) for o in outs)
 
+    @staticmethod
+    def stack_inputs(bg, src_obj, tsf_obj, src_hand_c, tsf_hand_c, src_obj_c, tsf_obj_c, src_armask=None, tsf_armask=None):
+        """The batch-stacked inputs of the two shared-weight sub-networks (bg_model over [src | tsf] backgrounds, obj_model over
+        [src | tsf] objects and their condition maps).  They depend on the batch only, so a caller that steps several times on a
+        batch -- or stages its inputs once per iteration (Trainer.set_input) -- makes them once and passes them as `stacked`."""
+        src_bg_in = [bg, src_hand_c] + ([src_armask] if src_armask is not None else [])
+        tsf_bg_in = [bg, tsf_hand_c] + ([tsf_armask] if tsf_armask is not None else [])
+        return (torch.cat([ops.cat_channels(src_bg_in), ops.cat_channels(tsf_bg_in)], dim=0),
+                torch.cat([src_obj, tsf_obj], dim=0), torch.cat([src_obj_c, tsf_obj_c], dim=0))
+
     def forward_nhwc(self, bg, src_obj, tsf_obj, src_hand, tsf_hand, T, src_obj_c, src_hand_c, tsf_obj_c, tsf_hand_c,
-                     src_armask=None, tsf_armask=None):
+                     src_armask=None, tsf_armask=None, stacked=None):
         c = self.cfg
         self._seg_cache = {}
         ops.attn_index_clear()
-        src_bg_in = [bg, src_hand_c] + ([src_armask] if src_armask is not None else [])
-        tsf_bg_in = [bg, tsf_hand_c] + ([tsf_armask] if tsf_armask is not None else [])
         # bg_model runs on the src and tsf inputs with SHARED weights (generator.py:367-369): one pass over the two
         # batches stacked (instance norm is per sample, so the result is identical) -> twice the tiles per launch at the
         # 32x32 bottleneck and one weight-gradient accumulation instead of two
@@ -247,9 +264,9 @@ class Generator(ParamTree):
         main = torch.cuda.current_stream()
         fork = _FORK_STREAMS and bg.is_cuda
         self.refresh_planes()
-        bg_in = torch.cat([ops.cat_channels(src_bg_in), ops.cat_channels(tsf_bg_in)], dim=0)
-        obj_in = torch.cat([src_obj, tsf_obj], dim=0)
-        obj_c = torch.cat([src_obj_c, tsf_obj_c], dim=0)
+        if stacked is None:
+            stacked = self.stack_inputs(bg, src_obj, tsf_obj, src_hand_c, tsf_hand_c, src_obj_c, tsf_obj_c, src_armask, tsf_armask)
+        bg_in, obj_in, obj_c = stacked
         if fork:
             s_bg, s_obj, s_src = self._branch_streams(bg.device)
             s_bg.wait_stream(main)
@@ -327,10 +344,14 @@ class Generator(ParamTree):
         tx = self._decode(tx, t_enc, tsf_hand_c, 'tsf_model')
 
         def regress(x, y, p):                                              # generator.py:311-315
-            img = self._conv(x, p + '.img_reg.0', pad=3, act=ACT_TANH)
-            mh = self._conv(x, p + '.attetion_reg_hand.0', pad=3, act=ACT_SIGMOID)
-            mb = ops.add_act(ops.conv2d(x, self.P[p + '.attetion_reg_bg.0.weight#t'], None, 1, 3),
-                             ops.conv2d(y, self.P[p + '.attetion_reg_bg.0.weight#s'], None, 1, 3), ACT_SIGMOID)
+            fused = self.F.get(p + '.heads_x.weight')
+            if fused is not None and _FUSE_HEADS and x.is_cuda:
+                img, mh, mbt = ops.conv_heads(x, fused, (3, 1, 1), (ACT_TANH, ACT_SIGMOID, ACT_NONE))
+            else:
+                img = self._conv(x, p + '.img_reg.0', pad=3, act=ACT_TANH)
+                mh = self._conv(x, p + '.attetion_reg_hand.0', pad=3, act=ACT_SIGMOID)
+                mbt = ops.conv2d(x, self.P[p + '.attetion_reg_bg.0.weight#t'], None, 1, 3)
+            mb = ops.add_act(mbt, ops.conv2d(y, self.P[p + '.attetion_reg_bg.0.weight#s'], None, 1, 3), ACT_SIGMOID)
             return img, mh, mb
 
         with on_src():

@@ -237,6 +237,12 @@ class Trainer(BaseModel):
                     n['%s_%s_cond' % (side, part)] = ops.slice_channels(full, 3, full.shape[-1])
             cond = [n['tsf_obj_cond'], n['tsf_hand_cond']] + ([n['armask_tsf']] if 'armask_tsf' in n else [])
             n['tsf_cond'] = ops.cat_channels(cond)                                            # trainer.py:437,460
+            # everything that depends on the batch only is made here, once per batch, not once per step: the stacked inputs of
+            # the shared-weight sub-networks and the discriminator's REAL input (trainer.py:460-464)
+            n['bg_in'], n['obj_in'], n['obj_c'] = self._net(self._G).stack_inputs(
+                n['input_G_bg'], n['src_obj_rgb'], n['tsf_obj_rgb'], n['src_hand_cond'], n['tsf_hand_cond'], n['src_obj_cond'],
+                n['tsf_obj_cond'], n.get('armask_src'), n.get('armask_tsf'))
+            n['d_real_in'] = ops.cat_channels([n['real_tsf'], n['tsf_cond']])
             n = self._n = self._stage_static(n)
             # reference-named NCHW views
             self._input_G_bg = as_nchw(n['input_G_bg'])
@@ -290,7 +296,8 @@ class Trainer(BaseModel):
         n = self._n
         outs = self._G.forward_nhwc(n['input_G_bg'], n['src_obj_rgb'], n['tsf_obj_rgb'], n['src_hand_rgb'],
                                     n['tsf_hand_rgb'], n['T'], n['src_obj_cond'], n['src_hand_cond'],
-                                    n['tsf_obj_cond'], n['tsf_hand_cond'], n.get('armask_src'), n.get('armask_tsf'))
+                                    n['tsf_obj_cond'], n['tsf_hand_cond'], n.get('armask_src'), n.get('armask_tsf'),
+                                    stacked=(n['bg_in'], n['obj_in'], n['obj_c']))
         (src_bg, tsf_bg, src_obj, src_hand, src_mbg, src_mh, tsf_obj, tsf_hand, tsf_mbg, tsf_mh) = outs
         fake_src = ops.compose(src_bg, src_obj, src_hand, src_mbg, src_mh)
         fake_tsf = ops.compose(tsf_bg, tsf_obj, tsf_hand, tsf_mbg, tsf_mh)
@@ -547,8 +554,7 @@ class Trainer(BaseModel):
         # the reference runs D twice (trainer.py:464-465); instance norm is per sample, so one stacked pass is identical
         nb = fake_tsf.shape[0]
         self._wait_d()
-        d_both = self._D.forward_nhwc(torch.cat([ops.cat_channels([n['real_tsf'], n['tsf_cond']]),
-                                                 ops.cat_channels([fake_tsf, n['tsf_cond']])], dim=0))
+        d_both = self._D.forward_nhwc(torch.cat([n['d_real_in'], ops.cat_channels([fake_tsf, n['tsf_cond']])], dim=0))
         d_real, d_fake = d_both[:nb], d_both[nb:]
         loss_real = ops.lsgan_loss(d_real, 1.0, o.lambda_D_prob)
         loss_fake = ops.lsgan_loss(d_fake, -1.0, o.lambda_D_prob)

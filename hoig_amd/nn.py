@@ -125,7 +125,30 @@ class ParamTree(nn.Module):
                 v.grad = self.flat_grad.as_strided(sh, st, o)
                 v._hoig_flat, v._hoig_transposed, v._hoig_owner = True, False, self
                 self.F[key] = v
+        self._init_runtime_state()
 
+    def fuse_conv_weights(self, key, names):
+        """A (sum Co, Ci, R, S) view over conv weights that sit back to back in the flat store (same Ci, R, S; none transposed):
+        registered in self.F like the fused SPADE gamma|beta weight, with the matching gradient view.  Returns False -- and
+        registers nothing -- when the members are not adjacent."""
+        shapes = [self._internal[n][0] for n in names]
+        if any(self._internal[n][1] for n in names) or len({tuple(sh[1:]) for sh in shapes}) != 1:
+            return False
+        off = self._offsets[names[0]]
+        nxt = off
+        for n, sh in zip(names, shapes):
+            if self._offsets[n] != nxt:
+                return False
+            nxt += _numel(sh)
+        shp = (sum(sh[0] for sh in shapes),) + tuple(shapes[0][1:])
+        st = packed_strides(shp, False)
+        v = nn.Parameter(self.flat.as_strided(shp, st, off), requires_grad=True)
+        v.grad = self.flat_grad.as_strided(shp, st, off)
+        v._hoig_flat, v._hoig_transposed, v._hoig_owner = True, False, self
+        self.F[key] = v
+        return True
+
+    def _init_runtime_state(self):
         self._pending = None      # event of an optimiser step still running on a side stream (Trainer._step)
         self._f6 = None
         self._plane_bufs = None

@@ -416,6 +416,75 @@ def conv2d_cat2(x1, x2, w, prec=None):
     return _ConvCat2.apply(x1, x2, w, prec)
 
 
+class _ConvHeads(Function):
+    """The generator's image / mask heads over ONE feature map as one 7x7 convolution with a per-channel activation
+    (generator.py:311-315: img_reg -> tanh, attetion_reg_hand -> sigmoid, and the x half of attetion_reg_bg, whose sigmoid
+    follows the sum with its y half): `w` is the fused (Co_total, Ci, 7, 7) view of the heads' adjacent weights, `splits` the
+    channel counts and `acts` the activation of each head.  One read of x forward; backward ONE weight-gradient and ONE
+    data-gradient launch over the concatenated head gradients (three of each, and two full-resolution gradient sums, before)."""
+
+    @staticmethod
+    def forward(ctx, x, w, splits, acts, prec):
+        _chk(x, 'x'); _chk(w, 'w')
+        assert x.is_contiguous() and tuple(w.stride()) == packed_strides(w.shape, False)
+        B, H, W_, Ci = x.shape
+        Co, _, R, S = w.shape
+        assert sum(splits) == Co and len(splits) == len(acts)
+        d = ConvDesc(B, H, W_, Ci, H, W_, Co, R, S, 1, R // 2, 0, L.ACT_NONE, 0.0, prec)
+        codes, ch = 0, 0
+        for n, a in zip(splits, acts):
+            for _ in range(n):
+                codes |= (a & 15) << (4 * ch)
+                ch += 1
+        y = torch.empty((B, H, W_, Co), dtype=x.dtype, device=x.device)
+        call('hoig_conv2d_fwd_heads', ctypes.byref(d), _p(x), _p(w), None, _p(y), codes, _st())
+        outs, off = [], 0
+        for n in splits:
+            o = torch.empty((B, H, W_, n), dtype=x.dtype, device=x.device)
+            _copy_channels(y, o, off, 0, n)
+            outs.append(o)
+            off += n
+        ctx.d_dg, ctx.d_wg = _bwd_descs(_x3(d))
+        ctx.cfg = (tuple(splits), tuple(acts))
+        ctx.save_for_backward(x, w, *[o if a != L.ACT_NONE else None for o, a in zip(outs, acts)])
+        return tuple(outs)
+
+    @staticmethod
+    def backward(ctx, *douts):
+        x, w = ctx.saved_tensors[:2]
+        ys = ctx.saved_tensors[2:]
+        splits, acts = ctx.cfg
+        B, H, W_, _ = x.shape
+        Co = w.shape[0]
+        g = torch.empty((B, H, W_, Co), dtype=x.dtype, device=x.device)
+        off = 0
+        for n, a, yv, dy in zip(splits, acts, ys, douts):
+            if dy is None:
+                dy = torch.zeros((B, H, W_, n), dtype=x.dtype, device=x.device)
+            dy = dy.contiguous()
+            if a != L.ACT_NONE:
+                t = torch.empty_like(dy)
+                call('hoig_act_bwd', _p(yv), _p(dy), _p(t), a, 0.0, dy.numel(), _st())
+                dy = t
+            _copy_channels(dy, g, 0, off, n)
+            off += n
+        dw_ret = None
+        if ctx.needs_input_grad[1]:
+            dw, ret_w = _grad_target(w)
+            call('hoig_conv2d_bwd_weight', ctypes.byref(ctx.d_wg), _p(x), _p(g), _p(dw), None, _st())
+            dw_ret = dw if ret_w else None
+        dx = None
+        if ctx.needs_input_grad[0]:
+            dx = torch.empty_like(x)
+            _conv_dgrad_raw(ctx.d_dg, g, w, dx)
+        return dx, dw_ret, None, None, None
+
+
+def conv_heads(x, w, splits, acts, prec=None):
+    """-> one tensor per head (len(splits) of them), activations applied."""
+    return _ConvHeads.apply(x, w, tuple(splits), tuple(acts), precision if prec is None else prec)
+
+
 def conv_transpose2d(x, w, stride=2, pad=1, output_padding=1, prec=None):
     """nn.ConvTranspose2d(k, stride, padding, output_padding, bias=False) (generator.py:118,201)."""
     B, Hi, Wi, _ = x.shape

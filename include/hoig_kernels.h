@@ -73,6 +73,14 @@ int hoig_conv2d_bwd_data(const hoig_conv_desc *d, const float *dy, const float *
 int hoig_conv2d_bwd_weight(const hoig_conv_desc *d, const float *x, const float *dy, float *dw, float *dbias,
                            hoig_stream_t stream);
 
+/* Forward of a stride-1 'same' convolution with <= 16 output channels over Ci % 64 == 0 inputs and ONE activation PER OUTPUT
+ * CHANNEL (acts: the HOIG_ACT_* code of channel f in bits [4f, 4f+4)): the generator's image / mask heads (generator.py:219-235,
+ * 311-315: tanh image, sigmoid masks) evaluated as one convolution over the decoder's last feature map.  7x7 with <= 5
+ * outputs: exact fp32 (VALU kernel) in every precision mode; 3x3 with <= 16 outputs: 16-bit MFMA arithmetic of d->precision;
+ * HOIG_EUNSUPPORTED otherwise. */
+int hoig_conv2d_fwd_heads(const hoig_conv_desc *d, const float *x, const float *w, const float *bias /*nullable*/, float *y,
+                          uint64_t acts, hoig_stream_t stream);
+
 /* 16-bit-operand fast path (HOIG_PREC_BF16X3 / HOIG_PREC_F16X2 / HOIG_PREC_BF16): weights are pre-split once per optimiser step into
  * 16-bit planes hi and lo of n rows x K reduction indices: the FORWARD planes (for_dgrad=0) hold fp16(256*w) and
  * fp16(256*w - hi) -- forward launches split their operands on fp16 and scale the accumulator by 1/256 -- the
