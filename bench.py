@@ -26,7 +26,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)          # the product package only; tests/ + oracle/ are reachable from the cpu-baseline child alone
 
 GFLOP_PER_PAIR_TRAIN_256 = 2555.2      # BASELINE.md §2 / SURVEY.md §8d (3*G + 3*VGG + 9*D), generator_spade_attn
-PMC_FILES = ['r03_pmc_dominant_conv.json', 'r02_pmc_dominant_conv_f6.json', 'r02_pmc_dominant_conv.json', 'r01_pmc_dominant_conv.json']      # newest first
+PMC_FILES = ['r03_pmc_dominant_conv.json', 'r02_pmc_dominant_conv_f6.json', 'r02_pmc_dominant_conv.json', 'r01_pmc_dominant_conv.json']      # newest first (matched by kernel name below)
 PEAK_F32, PEAK_16 = 157.3, 2500.0          # TFLOP/s dense MFMA (fp32 / fp16-bf16), MI355X_MICROARCH.md
 DTYPE_NAMES = {'f16f6': 'fwd: fp16 hi*hi + the two cross terms of the hi/lo split on block-scaled fp6 MFMA (1.6 bf16-MFMA units per product; layers outside that kernel: three fp16 terms) / bwd: bf16x2 (dy split hi+lo, weights and x single bf16), f32 accumulate',
                'bf16x3:f16x2': 'f16x3 fwd (both operands split hi+lo on fp16, 3 MFMAs per product) / bf16x2 bwd (dy split hi+lo, weights and x single bf16, 2 MFMAs per product), f32 accumulate',

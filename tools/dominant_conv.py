@@ -8,7 +8,7 @@ import torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from hoig_amd import ops
 
-prec = sys.argv[1] if len(sys.argv) > 1 else 'f16f6'
+prec = sys.argv[1] if len(sys.argv) > 1 else 'bf16x3'
 ops.set_precision(prec)
 x = torch.randn(16, 32, 32, 512, device='cuda')
 w = ops.pack_weight(torch.randn(512, 512, 3, 3, device='cuda') * 0.02)

@@ -5,5 +5,5 @@ sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, 'tests'))
 import bench
 from common import opt_namespace
 from hoig_amd import ops
-ops.set_precision(os.environ.get('HOIG_PRECISION', 'f16f6'))
+ops.set_precision(os.environ.get('HOIG_PRECISION', 'bf16x3:f16x2'))
 print(bench.gen_forward_latency(opt_namespace(), int(os.environ.get('B', 32)), 256, iters=3))
