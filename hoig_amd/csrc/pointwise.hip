@@ -712,4 +712,20 @@ extern "C" int hoig_tensor2im_u8(const float *x, uint8_t *out, int B, int H, int
     HOIG_LAUNCH_CHECK();
     return HOIG_OK;
 }
+// A HIP stream of the library's own (non-blocking).  PyTorch hands out its side streams round-robin from a pool of 32 per
+// device, so the 33rd torch.cuda.Stream() of a process ALIASES the first: two roles of the step then share one HIP stream, and a
+// stream that forks from / joins itself inside a capture sends hip::Stream::EndCapture() into unbounded recursion (ROCm 7.2,
+// seen as a segfault after ~10 Trainer objects in one process).  The step's long-lived streams are therefore created here and
+// wrapped with torch.cuda.ExternalStream (hoig_amd/ops.py new_stream).
+extern "C" int hoig_stream_create(hoig_stream_t *out) {
+    if (!out) return HOIG_EINVAL;
+    hipStream_t s = nullptr;
+    if (hipStreamCreateWithFlags(&s, hipStreamNonBlocking) != hipSuccess) return HOIG_ELAUNCH;
+    *out = (hoig_stream_t)s;
+    return HOIG_OK;
+}
+extern "C" int hoig_stream_destroy(hoig_stream_t stream) {
+    if (!stream) return HOIG_EINVAL;
+    return hipStreamDestroy((hipStream_t)stream) == hipSuccess ? HOIG_OK : HOIG_ELAUNCH;
+}
 extern "C" const char *hoig_version(void) { return "hoig-hip 0.1 (gfx950)"; }

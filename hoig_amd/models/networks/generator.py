@@ -70,7 +70,7 @@ class Generator(ParamTree):
 
     def _branch_streams(self, device):
         if getattr(self, '_streams', None) is None:
-            self._streams = tuple(torch.cuda.Stream(device=device) for _ in range(3))
+            self._streams = tuple(ops.new_stream(device) for _ in range(3))
         return self._streams
 
     # ---- building blocks -------------------------------------------------------------------

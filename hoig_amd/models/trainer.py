@@ -88,7 +88,7 @@ class Trainer(BaseModel):
         self._dexycb = 'dex' in str(getattr(opt, 'dataset_mode', 'hov3')).lower()
         self._world = dist.get_world_size() if (use_ddp and dist.is_initialized()) else 1
         # G's gradient exchange + Adam run on a side stream beside the D step; D's run there beside the next forward of G
-        self._side = torch.cuda.Stream(device=self.device)
+        self._side = ops.new_stream(self.device)
         self._loss_streams = None
         self._d_stream = None
         self._use_graph = bool(getattr(opt, 'hip_graph', _GRAPH))
@@ -372,7 +372,7 @@ class Trainer(BaseModel):
         if ev_fwd is not None and generator_forks_streams():
             main = torch.cuda.current_stream()
             if self._d_stream is None:
-                self._d_stream = torch.cuda.Stream(device=self.device)
+                self._d_stream = ops.new_stream(self.device)
             self._d_stream.wait_event(ev_fwd)
             ops.cross_stream(fake_tsf_imgs, self._d_stream)
             with torch.cuda.stream(self._d_stream):
@@ -522,7 +522,7 @@ class Trainer(BaseModel):
             self._net(self._D).refresh_planes()
             self._crt_tsf.vgg.refresh_planes()
             if self._loss_streams is None:
-                self._loss_streams = (torch.cuda.Stream(device=self.device), torch.cuda.Stream(device=self.device))
+                self._loss_streams = (ops.new_stream(self.device), ops.new_stream(self.device))
             s_adv, s_vgg = self._loss_streams
             s_adv.wait_stream(main)
             with torch.cuda.stream(s_adv):

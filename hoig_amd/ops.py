@@ -139,6 +139,23 @@ def _packed_planes(w, transposed, for_dgrad):
     return hi, lo
 
 
+_own_streams = []
+
+
+def new_stream(device=None):
+    """A HIP stream that no other stream object of the process aliases.  torch.cuda.Stream() takes its streams round-robin from
+    a pool of 32 per device: in a process that has created more than that (a test session with a dozen Trainers) two roles of
+    the step end up on ONE HIP stream, and a stream that waits for itself inside a capture crashes hipStreamEndCapture (ROCm
+    7.2: unbounded recursion over the capture's parallel streams).  The library creates the stream, torch wraps it."""
+    dev = torch.device('cuda', torch.cuda.current_device()) if device is None else torch.device(device)
+    with torch.cuda.device(dev):
+        h = ctypes.c_void_p()
+        call('hoig_stream_create', ctypes.byref(h))
+        s = torch.cuda.ExternalStream(h.value, device=dev)
+    _own_streams.append((h.value, s))          # (kept for the life of the process: a handful per Trainer)
+    return s
+
+
 _wgrad_streams = {}
 # weight gradients on a side stream, beside the data-gradient chain: '1' always, '0' never, 'auto' (default) wherever the
 # backward is ONE chain -- the generator's backward already runs as three concurrent chains (its forward forks onto branch
@@ -159,7 +176,7 @@ def _wgrad_side_stream(device):
         return None
     s = _wgrad_streams.get(device)
     if s is None:
-        s = _wgrad_streams[device] = torch.cuda.Stream(device=device)
+        s = _wgrad_streams[device] = new_stream(device)
     if _capture_depth:
         _capture_forked.add(s)
     return s

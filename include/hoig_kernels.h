@@ -306,6 +306,11 @@ int hoig_adam_tick(double *state, float *derived, hoig_stream_t stream);
 int hoig_adam_step_dev(float *param, const float *grad, float *exp_avg, float *exp_avg_sq, int64_t n, const float *derived,
                        float grad_scale, hoig_stream_t stream);
 
+/* A non-blocking HIP stream owned by the library (the step's side streams: see hoig_amd/ops.py new_stream for why they are not
+ * taken from PyTorch's round-robin stream pool). */
+int hoig_stream_create(hoig_stream_t *out);
+int hoig_stream_destroy(hoig_stream_t stream);
+
 /* eval.py output stage (utils/util.py:249-264): uint8 = (x+1)/2*255 truncated, NHWC fp32 -> CHW uint8 grid tile */
 int hoig_tensor2im_u8(const float *x, uint8_t *out, int B, int H, int W, int C, int nrow, int unnormalize,
                       hoig_stream_t stream);
