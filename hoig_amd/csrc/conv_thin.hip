@@ -54,8 +54,10 @@ __device__ __forceinline__ void split16(float x, unsigned short &hi, unsigned sh
         hi = __builtin_bit_cast(unsigned short, h);
         lo = __builtin_bit_cast(unsigned short, l);
     } else {
-        hi = hoig_f2bf(x);
-        lo = hoig_f2bf(x - hoig_bf2f(hi));
+        const __bf16 h = (__bf16)x;                        // v_cvt_pk_bf16_f32 (round to nearest even)
+        hi = __builtin_bit_cast(unsigned short, h);
+        const __bf16 l = (__bf16)(x - hoig_bf2f(hi));
+        lo = __builtin_bit_cast(unsigned short, l);
     }
 }
 
@@ -68,49 +70,57 @@ __device__ __forceinline__ f32x16 mfma16(const bf16x8 a, const bf16x8 b, const f
 // The halo image of one tile of the thin tensor: planes [NT][F][HR][CW] of 16-bit values, zero outside the picture.  Loaded into
 // registers one tile ahead (HMAX values per thread cover the largest image: 10 x 38 pixels x 8 channels) and written to LDS
 // when the tile's turn comes, so that the load latency hides behind the previous tile's MFMAs.
+// Which element of the halo image a thread moves in round `it` does not depend on the tile: the (row, column, channel) of every
+// round is worked out ONCE per kernel (HaloMap: the integer divisions cost more than the tile's MFMAs when redone per tile).
 constexpr int HMAX = 12;
 struct HaloRegs {
     float v[HMAX];
 };
-__device__ __forceinline__ void halo_load(const ThinArgs &p, int b, int y0, int x0, HaloRegs &h) {
+struct HaloMap {
+    int lds[HMAX];                 // element offset in the LDS plane, -1: no element in this round
+    int rc[HMAX];                  // halo row | column << 8 | channel << 16
+    int rounds;
+};
+__device__ __forceinline__ void halo_map(const ThinArgs &p, HaloMap &m) {
     const int wr = TW + p.KS - 1;                          // halo pixels per row
     const int row_elems = wr * p.F;                        // contiguous in memory: (x0 - pad .. x0 - pad + wr) x F
     const int total = p.HR * row_elems;
+    m.rounds = (total + NTHR - 1) / NTHR;
 #pragma unroll
     for (int it = 0; it < HMAX; ++it) {
         const int i = threadIdx.x + it * NTHR;
+        m.lds[it] = -1;
+        m.rc[it] = 0;
+        if (i < total) {
+            const int hy = i / row_elems, e = i - hy * row_elems;
+            const int hx = e / p.F, f = e - hx * p.F;
+            m.lds[it] = (f * p.HR + hy) * p.CW + hx;
+            m.rc[it] = hy | (hx << 8) | (f << 16);
+        }
+    }
+}
+__device__ __forceinline__ void halo_load(const ThinArgs &p, const HaloMap &m, int b, int y0, int x0, HaloRegs &h) {
+    const float *img = p.T + (size_t)b * p.H * p.W * p.F;
+#pragma unroll
+    for (int it = 0; it < HMAX; ++it) {
         h.v[it] = 0.f;
-        if (it * NTHR < total) {                           // (uniform)
-            if (i < total) {
-                const int hy = i / row_elems, e = i - hy * row_elems;
-                const int hx = e / p.F, f = e - hx * p.F;
-                const int gy = y0 - p.pad + hy, gx = x0 - p.pad + hx;
-                if (gy >= 0 && gy < p.H && gx >= 0 && gx < p.W) h.v[it] = p.T[(((size_t)b * p.H + gy) * p.W + gx) * p.F + f];
-            }
+        if (it < m.rounds && m.lds[it] >= 0) {             // (first test uniform)
+            const int gy = y0 - p.pad + (m.rc[it] & 255), gx = x0 - p.pad + ((m.rc[it] >> 8) & 255);
+            if (gy >= 0 && gy < p.H && gx >= 0 && gx < p.W) h.v[it] = img[((size_t)gy * p.W + gx) * p.F + (m.rc[it] >> 16)];
         }
     }
 }
 template <bool FP16, int NT>
-__device__ __forceinline__ void halo_store(const ThinArgs &p, const HaloRegs &h, unsigned short *Tl) {
-    const int wr = TW + p.KS - 1;
-    const int row_elems = wr * p.F;
-    const int total = p.HR * row_elems;
+__device__ __forceinline__ void halo_store(const ThinArgs &p, const HaloMap &m, const HaloRegs &h, unsigned short *Tl) {
     const int plane = p.F * p.HR * p.CW;
 #pragma unroll
-    for (int it = 0; it < HMAX; ++it) {
-        const int i = threadIdx.x + it * NTHR;
-        if (it * NTHR < total) {
-            if (i < total) {
-                const int hy = i / row_elems, e = i - hy * row_elems;
-                const int hx = e / p.F, f = e - hx * p.F;
-                unsigned short hi, lo;
-                split16<FP16>(h.v[it], hi, lo);
-                const int o = (f * p.HR + hy) * p.CW + hx;
-                Tl[o] = hi;
-                if (NT == 2) Tl[plane + o] = lo;
-            }
+    for (int it = 0; it < HMAX; ++it)
+        if (it < m.rounds && m.lds[it] >= 0) {
+            unsigned short hi, lo;
+            split16<FP16>(h.v[it], hi, lo);
+            Tl[m.lds[it]] = hi;
+            if (NT == 2) Tl[plane + m.lds[it]] = lo;
         }
-    }
 }
 
 __device__ __forceinline__ void tile_coords(const ThinArgs &p, int t, int &b, int &y0, int &x0) {
@@ -181,21 +191,23 @@ __global__ __launch_bounds__(NTHR) void thin_gemm_kernel(const ThinArgs p) {
 
     const int t_end = min(p.ntiles, (int)(blockIdx.x + 1) * p.strip);
     HaloRegs hreg;
+    HaloMap hmap;
+    halo_map(p, hmap);
     {
         int b, y0, x0;
         tile_coords(p, blockIdx.x * p.strip, b, y0, x0);
-        halo_load(p, b, y0, x0, hreg);
+        halo_load(p, hmap, b, y0, x0, hreg);
     }
     for (int t = blockIdx.x * p.strip; t < t_end; ++t) {
         int b, y0, x0;
         tile_coords(p, t, b, y0, x0);
         __syncthreads();                                                 // the previous tile's reads (and the tables) are done
-        halo_store<FP16, NT>(p, hreg, Tl);
+        halo_store<FP16, NT>(p, hmap, hreg, Tl);
         __syncthreads();
         if (t + 1 < t_end) {                                             // the next tile's halo flies during this tile's MFMAs
             int b2, y2, x2;
             tile_coords(p, t + 1, b2, y2, x2);
-            halo_load(p, b2, y2, x2, hreg);
+            halo_load(p, hmap, b2, y2, x2, hreg);
         }
         f32x16 acc[2];
 #pragma unroll
@@ -304,11 +316,19 @@ __global__ __launch_bounds__(NTHR) void thin_wgrad_kernel(const ThinArgs p) {
                                 dreg[i][1].x, dreg[i][1].y, dreg[i][1].z, dreg[i][1].w};
             bf16x8 hi, lo;
 #pragma unroll
-            for (int e = 0; e < 8; ++e) {
-                unsigned short h, l;
-                split16<false>(v[e], h, l);
-                hi[e] = (short)h;
-                lo[e] = (short)l;
+            for (int e = 0; e < 8; e += 2) {               // two values per v_cvt_pk_bf16_f32
+                typedef float f2v __attribute__((ext_vector_type(2)));
+                typedef __bf16 b2v __attribute__((ext_vector_type(2)));
+                const f2v x2 = {v[e], v[e + 1]};
+                const unsigned hp = __builtin_bit_cast(unsigned, __builtin_convertvector(x2, b2v));
+                hi[e] = (short)(hp & 0xffffu);
+                hi[e + 1] = (short)(hp >> 16);
+                if (ND == 2) {
+                    const f2v r2 = {v[e] - __uint_as_float(hp << 16), v[e + 1] - __uint_as_float(hp & 0xffff0000u)};
+                    const unsigned lp = __builtin_bit_cast(unsigned, __builtin_convertvector(r2, b2v));
+                    lo[e] = (short)(lp & 0xffffu);
+                    lo[e + 1] = (short)(lp >> 16);
+                }
             }
             *reinterpret_cast<bf16x8 *>(Dl + px * DROW + c8 * 16) = hi;
             if (ND == 2) *reinterpret_cast<bf16x8 *>(Dl + NPIX * DROW + px * DROW + c8 * 16) = lo;
@@ -317,22 +337,24 @@ __global__ __launch_bounds__(NTHR) void thin_wgrad_kernel(const ThinArgs p) {
 
     int t = blockIdx.x;
     HaloRegs hreg;
+    HaloMap hmap;
+    halo_map(p, hmap);
     if (t < p.ntiles) {
         int b, y0, x0;
         tile_coords(p, t, b, y0, x0);
         load_d(t);
-        halo_load(p, b, y0, x0, hreg);
+        halo_load(p, hmap, b, y0, x0, hreg);
     }
     for (; t < p.ntiles; t += gridDim.x) {
         __syncthreads();                                                  // the previous tile has been consumed
         store_d();
-        halo_store<false, NT>(p, hreg, Tl);
+        halo_store<false, NT>(p, hmap, hreg, Tl);
         __syncthreads();
         if (t + (int)gridDim.x < p.ntiles) {                              // the next tile's loads fly during the MFMAs
             int b, y0, x0;
             tile_coords(p, t + gridDim.x, b, y0, x0);
             load_d(t + gridDim.x);
-            halo_load(p, b, y0, x0, hreg);
+            halo_load(p, hmap, b, y0, x0, hreg);
         }
 #pragma unroll 1
         for (int ks = wk; ks < KSTEPS; ks += WK) {

@@ -720,7 +720,8 @@ extern "C" int hoig_tensor2im_u8(const float *x, uint8_t *out, int B, int H, int
 extern "C" int hoig_stream_create(hoig_stream_t *out) {
     if (!out) return HOIG_EINVAL;
     hipStream_t s = nullptr;
-    if (hipStreamCreateWithFlags(&s, hipStreamNonBlocking) != hipSuccess) return HOIG_ELAUNCH;
+    // the same call PyTorch's stream pool makes (non-blocking, default priority 0)
+    if (hipStreamCreateWithPriority(&s, hipStreamNonBlocking, 0) != hipSuccess) return HOIG_ELAUNCH;
     *out = (hoig_stream_t)s;
     return HOIG_OK;
 }

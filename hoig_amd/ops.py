@@ -140,6 +140,8 @@ def _packed_planes(w, transposed, for_dgrad):
 
 
 _own_streams = []
+_stream_banks = {}
+_QUEUE_OF_ROLE = [int(v) for v in os.environ.get('HOIG_STREAM_MAP', '3,1,3,1,2,2,2,2').split(',')]
 
 
 def new_stream(device=None):
@@ -148,11 +150,36 @@ def new_stream(device=None):
     the step end up on ONE HIP stream, and a stream that waits for itself inside a capture crashes hipStreamEndCapture (ROCm
     7.2: unbounded recursion over the capture's parallel streams).  The library creates the stream, torch wraps it."""
     dev = torch.device('cuda', torch.cuda.current_device()) if device is None else torch.device(device)
-    with torch.cuda.device(dev):
-        h = ctypes.c_void_p()
-        call('hoig_stream_create', ctypes.byref(h))
-        s = torch.cuda.ExternalStream(h.value, device=dev)
-    _own_streams.append((h.value, s))          # (kept for the life of the process: a handful per Trainer)
+    if os.environ.get('HOIG_POOL_STREAMS') == '1':          # A/B switch: PyTorch's pooled streams, as in rounds 1-2
+        return torch.cuda.Stream(device=dev)
+    bank = _stream_banks.get(dev)
+    if bank is None:
+        # A bank of 32 streams created back to back.  The runtime gives every new stream the least-used of its (four) hardware
+        # queues, so bank entry k sits on queue k mod 4 (class 0 = the queue of the caller's default stream), and WHICH roles of
+        # the step share a hardware queue is worth up to 20 % of the step time (profiles/r03_stream_queue_map.txt, one box: the
+        # three branch chains on three different queues 77-78 ms, every side role on one queue 79-88 ms, the assignment below
+        # 72.9 ms = what PyTorch's pooled streams happened to get in rounds 1-2): kernels of different queues interleave at
+        # workgroup granularity, and four heavy chains doing that to each other are slower than two pairs.  _QUEUE_OF_ROLE is the
+        # queue class of the n-th stream a process asks for -- the order is fixed by the code: optimiser side stream (3), bg /
+        # obj / src branch streams (1 / 3 / 1), the two loss streams, the D stream, the weight-gradient stream (2).
+        bank = _stream_banks[dev] = {'free': [[], [], [], []], 'n': 0}
+        with torch.cuda.device(dev):
+            for k in range(32):
+                h = ctypes.c_void_p()
+                call('hoig_stream_create', ctypes.byref(h))
+                bank['free'][k % 4].append(h.value)
+    role = bank['n']
+    bank['n'] += 1
+    q = _QUEUE_OF_ROLE[role % len(_QUEUE_OF_ROLE)]
+    if not bank['free'][q]:                     # (a long session: more streams, same queue classes)
+        with torch.cuda.device(dev):
+            for k in range(32):
+                h = ctypes.c_void_p()
+                call('hoig_stream_create', ctypes.byref(h))
+                bank['free'][k % 4].append(h.value)
+    h = bank['free'][q].pop(0)
+    s = torch.cuda.ExternalStream(h, device=dev)
+    _own_streams.append((h, s))                # (kept for the life of the process: a handful per Trainer)
     return s
 
 
