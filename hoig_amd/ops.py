@@ -902,8 +902,30 @@ def _x3(d):
     return c
 
 
+_F6_SCOPE = tuple(p for p in os.environ.get('HOIG_F6_SCOPE', '').split(',') if p)      # experiment: f16f6 only in these sub-networks
+
+
+def _f6_in_scope(w):
+    """With HOIG_F6_SCOPE=<prefix>,<prefix> the fp6 forward is used only for weights of those sub-networks (by parameter-name
+    prefix, e.g. bg_model,obj_model); everything else of an 'f16f6' run stays on three fp16 terms."""
+    if not _F6_SCOPE:
+        return True
+    owner = getattr(w, '_hoig_owner', None)
+    if owner is None or not hasattr(owner, '_offsets'):
+        return False
+    rng = getattr(owner, '_f6_scope_ranges', None)
+    if rng is None:
+        names = list(owner._offsets.items())
+        ends = [o for _, o in names[1:]] + [owner.flat.numel()]
+        rng = owner._f6_scope_ranges = [(o, e) for (n, o), e in zip(names, ends) if n.startswith(_F6_SCOPE)]
+    off = w.storage_offset()
+    return any(a <= off < b for a, b in rng)
+
+
 def _conv_fwd_raw(d, x, w, b, y, transposed=False):
     """y = conv(x, w) (+bias, activation) on the kernel the precision mode selects."""
+    if d.precision == L.PREC_F16F6 and not _f6_in_scope(w):
+        d = _x3(d)
     if d.precision == L.PREC_F16F6:
         if (not transposed and d.R == 3 and d.S == 3 and d.stride == 1 and d.pad == 1 and d.Ci % 64 == 0 and d.Co % 64 == 0
                 and d.Hi % 8 == 0 and d.Wi % 32 == 0):
