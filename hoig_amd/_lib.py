@@ -57,6 +57,7 @@ _SIGS = {
     'hoig_pack_conv_weights_bf16_all': [_vp, _vp, _i, _i64, _vp, _vp, _vp, _vp, _vp],
     'hoig_conv2d_fwd_packed': [ctypes.POINTER(ConvDesc), _vp, _vp, _vp, _vp, _vp, _vp],
     'hoig_conv2d_bwd_data_packed': [ctypes.POINTER(ConvDesc), _vp, _vp, _vp, _vp, _vp],
+    'hoig_conv2d_bwd_data_packed_add': [ctypes.POINTER(ConvDesc), _vp, _vp, _vp, _vp, _vp, _vp],
     'hoig_pack_conv_weight_f6': [_vp, _i, _i, _i, _vp, _vp, _vp],
     'hoig_conv2d_fwd_f6': [ctypes.POINTER(ConvDesc), _vp, _vp, _vp, _vp, _vp, _vp, _vp],
     'hoig_pack_conv_weights_f6_all': [_vp, _vp, _i, _i64, _vp, _vp, _vp],

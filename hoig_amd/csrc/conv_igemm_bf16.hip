@@ -572,6 +572,8 @@ struct HaloArgs {
     int cg1;
     float *C2;
     int n1;
+    const float *addend;       // same shape as C (single-output launches only): C = conv + addend -- the data gradient that lands in
+                               // a tensor with a second consumer adds that consumer's gradient itself (ops.conv2d_fork)
 #ifdef HOIG_STAMP
     unsigned long long *dbg;   // diagnostic build only (tools/stamp_halo.py): per-wave cycle sums of the step phases
 #endif
@@ -770,7 +772,9 @@ __global__ __launch_bounds__(128 * WN) void conv_halo_bf16_kernel(const HaloArgs
                 if (n < p.N) {
                     float v = acc[i][j][r] * p.oscale;
                     v += bias_r[j];
-                    p.C[pix * p.N + n] = fast_act(v, nslope, special, p.act, p.slope);
+                    v = fast_act(v, nslope, special, p.act, p.slope);
+                    if (p.addend) v += p.addend[pix * p.N + n];
+                    p.C[pix * p.N + n] = v;
                 }
             }
         }
@@ -1088,6 +1092,7 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_halo3_bf16_kernel(const Hal
                     float v = acc[i][j][r] * p.oscale;
                     v += bias_r[j];
                     v = fast_act(v, nslope, special, p.act, p.slope);
+                    if (p.addend) v += p.addend[pix * p.N + n];
                     if (!p.C2) p.C[pix * p.N + n] = v;
                     else if (n < p.n1) p.C[pix * p.n1 + n] = v;                  // (a whole 32-column group goes one way)
                     else p.C2[pix * (p.N - p.n1) + (n - p.n1)] = v;
@@ -1596,7 +1601,8 @@ int launch_dgrad_thin(const float *dy, const unsigned short *wh, const unsigned 
 }
 
 int run(const hoig_conv_desc *d, const float *a, const unsigned short *wh, const unsigned short *wl, const float *bias,
-        float *c, bool dgrad, hipStream_t st, const float *a2 = nullptr, int cg1 = 0, float *c2 = nullptr, int n1 = 0) {
+        float *c, bool dgrad, hipStream_t st, const float *a2 = nullptr, int cg1 = 0, float *c2 = nullptr, int n1 = 0,
+        const float *addend = nullptr) {
     Args p;
     p.A = a; p.Wh = wh; p.Wl = wl; p.bias = bias; p.C = c;
     p.f16 = dgrad ? 0 : 1;                       // forward: fp16-split operands over the 2^8-scaled forward planes
@@ -1624,7 +1630,7 @@ int run(const hoig_conv_desc *d, const float *a, const unsigned short *wh, const
     if (p.N <= 32 || p.N % 32 != 0) return HOIG_EUNSUPPORTED;
     static const bool no_thin = getenv("HOIG_NO_THIN_DGRAD") != nullptr;
     if (!no_thin && dgrad && !d->transposed && d->R == 1 && d->S == 1 && d->stride == 1 && d->pad == 0 && g.Cg == 128 &&
-        p.N >= 1024 && p.N % 64 == 0 && p.M % 128 == 0 && !a2 && !c2)
+        p.N >= 1024 && p.N % 64 == 0 && p.M % 128 == 0 && !a2 && !c2 && !addend)
         return launch_dgrad_thin(a, wh, wl, c, p.M, p.N, ns, st);
     // stride-1 "same" convolutions (and their data gradients): LDS-resident input halo, weights streamed per tap
     if (!d->transposed && d->stride == 1 && d->R == d->S && 2 * d->pad == d->R - 1 && (d->R == 1 || d->R == 3 || d->R == 5) &&
@@ -1633,6 +1639,8 @@ int run(const hoig_conv_desc *d, const float *a, const unsigned short *wh, const
         HaloArgs h;
         h.A = a; h.Wh = wh; h.Wl = wl; h.bias = bias; h.C = c;
         h.A2 = a2; h.cg1 = cg1; h.C2 = c2; h.n1 = n1;
+        h.addend = addend;
+        if (addend && c2) return HOIG_EUNSUPPORTED;
         if ((a2 || c2) && d->R != 3) return HOIG_EUNSUPPORTED;
         if (a2 && (cg1 % 32 || cg1 <= 0 || cg1 >= g.Cg)) return HOIG_EINVAL;
         if (c2 && (n1 % 64 || n1 <= 0 || n1 >= p.N)) return HOIG_EINVAL;
@@ -1645,7 +1653,7 @@ int run(const hoig_conv_desc *d, const float *a, const unsigned short *wh, const
         if (d->R == 3) return launch_halo3(h, ns, st);
         return launch_halo<5>(h, ns, st);
     }
-    if (a2 || c2) return HOIG_EUNSUPPORTED;
+    if (a2 || c2 || addend) return HOIG_EUNSUPPORTED;
     // stride-2 3x3 pad-1 layers on the parity-phase halo kernel.  gather: Conv2d forward / ConvTranspose2d data gradient;
     // scatter: ConvTranspose2d forward / Conv2d data gradient
     static const bool no_s2 = getenv("HOIG_NO_HALO_S2") != nullptr;
@@ -1659,7 +1667,7 @@ int run(const hoig_conv_desc *d, const float *a, const unsigned short *wh, const
             h.A = a; h.Wh = wh; h.Wl = wl; h.bias = bias; h.C = c;
             h.Bn = d->B; h.Cg = g.Cg; h.N = p.N; h.K = p.K;
             h.pad = 1; h.flip = 0;
-            h.A2 = nullptr; h.cg1 = 0; h.C2 = nullptr; h.n1 = 0;
+            h.A2 = nullptr; h.cg1 = 0; h.C2 = nullptr; h.n1 = 0; h.addend = nullptr;
             h.act = p.act; h.slope = p.slope;
             h.f16 = p.f16; h.oscale = p.oscale;
             const bool gather = !g.gatherT;      // the operand is read at 2*o - 1 + tap (fine grid) -> gather mode
@@ -1722,6 +1730,14 @@ extern "C" int hoig_conv2d_bwd_data_packed(const hoig_conv_desc *d, const float 
     if (!d || !dy || !wt_hi || !dx) return HOIG_EINVAL;
     if (!is_16bit_precision(d->precision)) return HOIG_EINVAL;
     return run(d, dy, wt_hi, wt_lo, nullptr, dx, true, (hipStream_t)stream);
+}
+
+// dx = data gradient + addend (HOIG_EUNSUPPORTED where the layer's kernel has no such epilogue: the caller adds separately)
+extern "C" int hoig_conv2d_bwd_data_packed_add(const hoig_conv_desc *d, const float *dy, const uint16_t *wt_hi,
+                                               const uint16_t *wt_lo, const float *addend, float *dx, hoig_stream_t stream) {
+    if (!d || !dy || !wt_hi || !dx || !addend) return HOIG_EINVAL;
+    if (!is_16bit_precision(d->precision)) return HOIG_EINVAL;
+    return run(d, dy, wt_hi, wt_lo, nullptr, dx, true, (hipStream_t)stream, nullptr, 0, nullptr, 0, addend);
 }
 
 // conv(cat[x1, x2]) and its data gradient [dx1 | dx2] without materialising the concatenation (3x3 stride-1 "same" only)

@@ -54,7 +54,10 @@ class Generator(ParamTree):
         # (generator.py:315: evaluated as conv(x) + conv(y), which needs no concatenated 128-channel full-resolution tensor)
         split = ['attn_%d.fully_connect_layer.0.weight' % l for l in self.cfg.attn_layers]
         split += ['%s.attetion_reg_bg.0.weight' % m for m in ('src_model', 'tsf_model')]
-        super().__init__(sch.shapes, device, sch.transposed, split)
+        # obj_model's last feature map feeds its own image head and the y halves of BOTH background-mask heads (generator.py:
+        # 311-315, 449-456): the three 7x7 weights are kept back to back so they can run as one convolution (heads_y, below)
+        heads_y = ['obj_model.img_reg.0.weight'] + ['%s.attetion_reg_bg.0.weight#s' % m for m in ('src_model', 'tsf_model')]
+        super().__init__(sch.shapes, device, sch.transposed, split, adjacent=[heads_y])
         self._name = 'generator'
         self._seg_cache = {}
         # the three heads that read the decoder's last feature map -- img_reg (3), attetion_reg_hand (1) and the x half of
@@ -63,6 +66,7 @@ class Generator(ParamTree):
         for m in ('src_model', 'tsf_model'):
             names = [m + '.img_reg.0.weight', m + '.attetion_reg_hand.0.weight', m + '.attetion_reg_bg.0.weight#t']
             self.fuse_conv_weights(m + '.heads_x.weight', names)
+        self.fuse_conv_weights('obj_model.heads_y.weight', heads_y)
 
     @property
     def name(self):
@@ -108,7 +112,9 @@ class Generator(ParamTree):
         return self._in(h, name + '.1', act=ACT_RELU)
 
     def _resblock(self, x, name):                                          # generator.py:9-32
-        h = self._in(self._conv(x, name + '.main.0', to_norm=True), name + '.main.1', act=ACT_RELU)
+        # (x has two readers, the first conv and the skip: conv2d_fork routes the skip's gradient through the conv's backward)
+        h, x = ops.conv2d_fork(x, self.P[name + '.main.0.weight'], self.P.get(name + '.main.0.bias'), 1, 1, dead_bias=True)
+        h = self._in(h, name + '.main.1', act=ACT_RELU)
         return self._in(self._conv(h, name + '.main.3', to_norm=True), name + '.main.4', residual=x)
 
     def _spade_resblock(self, x, seg, name):                               # generator.py:63-71
@@ -327,13 +333,26 @@ class Generator(ParamTree):
             bg_both, obj_both = bg_out[0], obj_out[0]
 
         # obj_model likewise serves both the src and the tsf object (generator.py:449-450): one stacked pass
+        if not fork:
+            obj_both = self._unet(obj_in, obj_c, 'obj_model')
+        # The object branch's feature map has THREE readers -- its image head over both halves, and the y half of the src / tsf
+        # background-mask head over one half each.  Fused: one 5-channel 7x7 convolution over the stacked map (the mask columns of
+        # the other half are computed and dropped: 2 of 5 columns of a convolution that is bound by reading its input), so the
+        # backward is ONE data gradient instead of three plus two full-resolution zero-padded slice gradients and their sums.
+        # It runs where the map was made (the object branch's stream), ahead of the joins below.
+        fused_y = self.F.get('obj_model.heads_y.weight') if (_FUSE_HEADS and obj_both.is_cuda) else None
+        if fused_y is not None:
+            with (torch.cuda.stream(s_obj) if fork else contextlib.nullcontext()):
+                obj_o, my_src, my_tsf = ops.conv_heads(obj_both, fused_y, (3, 1, 1), (ACT_TANH, ACT_NONE, ACT_NONE))
         if fork:
             main.wait_stream(s_bg)
             main.wait_stream(s_obj)
             ops.cross_stream(bg_both, main)
             ops.cross_stream(obj_both, main)
-        else:
-            obj_both = self._unet(obj_in, obj_c, 'obj_model')
+            if fused_y is not None:
+                ops.cross_stream(obj_o, main)
+                ops.cross_stream(my_tsf, main)
+                ops.cross_stream(my_src, s_src)
         src_img_bg, tsf_img_bg = bg_both[:nb], bg_both[nb:]
         sy, ty = obj_both[:nb], obj_both[nb:]
         if fork_src:
@@ -343,6 +362,9 @@ class Generator(ParamTree):
             sx = self._decode(sx, s_enc, src_hand_c, 'src_model')
         tx = self._decode(tx, t_enc, tsf_hand_c, 'tsf_model')
 
+        if fused_y is not None:
+            my = {'src_model': my_src[:nb], 'tsf_model': my_tsf[nb:]}
+
         def regress(x, y, p):                                              # generator.py:311-315
             fused = self.F.get(p + '.heads_x.weight')
             if fused is not None and _FUSE_HEADS and x.is_cuda:
@@ -351,7 +373,8 @@ class Generator(ParamTree):
                 img = self._conv(x, p + '.img_reg.0', pad=3, act=ACT_TANH)
                 mh = self._conv(x, p + '.attetion_reg_hand.0', pad=3, act=ACT_SIGMOID)
                 mbt = ops.conv2d(x, self.P[p + '.attetion_reg_bg.0.weight#t'], None, 1, 3)
-            mb = ops.add_act(mbt, ops.conv2d(y, self.P[p + '.attetion_reg_bg.0.weight#s'], None, 1, 3), ACT_SIGMOID)
+            mby = my[p] if fused_y is not None else ops.conv2d(y, self.P[p + '.attetion_reg_bg.0.weight#s'], None, 1, 3)
+            mb = ops.add_act(mbt, mby, ACT_SIGMOID)
             return img, mh, mb
 
         with on_src():
@@ -361,7 +384,8 @@ class Generator(ParamTree):
             main.wait_stream(s_src)
             for t_ in (src_hand_o, src_mask_hand, src_mask_bg):
                 ops.cross_stream(t_, main)
-        obj_o = self._conv(obj_both, 'obj_model.img_reg.0', pad=3, act=ACT_TANH)
+        if fused_y is None:
+            obj_o = self._conv(obj_both, 'obj_model.img_reg.0', pad=3, act=ACT_TANH)
         src_obj_o, tsf_obj_o = obj_o[:nb], obj_o[nb:]
         self._seg_cache = {}
         return (src_img_bg, tsf_img_bg, src_obj_o, src_hand_o, src_mask_bg, src_mask_hand,

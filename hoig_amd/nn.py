@@ -64,7 +64,7 @@ class PendingUpdate(object):
 class ParamTree(nn.Module):
     """A module tree generated from dotted parameter names; parameters are views of flat buffers."""
 
-    def __init__(self, shapes, device, transposed_names=(), split_names=()):
+    def __init__(self, shapes, device, transposed_names=(), split_names=(), adjacent=()):
         super().__init__()
         self._ref_shapes = OrderedDict(shapes)            # reference names -> reference shapes
         self._split = set(split_names)
@@ -89,6 +89,13 @@ class ParamTree(nn.Module):
                 fused.append(pre)
             elif n.endswith('.mlp_gamma.bias'):
                 order.insert(order.index(n) + 1, n.replace('.mlp_gamma.', '.mlp_beta.'))
+        # ... and `adjacent` groups of (internal) names, which the caller wants back to back behind the group's first member
+        # (conv weights of different modules that read the same tensor: fuse_conv_weights)
+        for group in adjacent:
+            for n in group[1:]:
+                order.remove(n)
+            at = order.index(group[0]) + 1
+            order[at:at] = list(group[1:])
         assert sorted(order) == sorted(internal), 'allocation order lost a parameter'
         total = 0
         self._offsets = OrderedDict()

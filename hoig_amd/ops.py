@@ -322,7 +322,7 @@ def join_wgrad_streams():
 
 class _Conv(Function):
     @staticmethod
-    def forward(ctx, x, w, b, stride, pad, transposed, act, slope, out_hw, prec, dead_bias=False):
+    def forward(ctx, x, w, b, stride, pad, transposed, act, slope, out_hw, prec, dead_bias=False, fork=False):
         _chk(x, 'x'); _chk(w, 'w'); _chk(b, 'bias')
         assert x.is_contiguous() and x.dim() == 4
         B, Hi, Wi, Ci = x.shape
@@ -345,12 +345,21 @@ class _Conv(Function):
         ctx.transposed = transposed
         ctx.has_bias = b is not None and not dead_bias
         ctx.save_for_backward(x, w, b, y if act != L.ACT_NONE else None)
+        ctx.fork = fork
+        if fork:
+            # (y, x): the caller hands this second output to x's OTHER consumer, so that autograd sees x consumed once -- by
+            # this node, whose backward receives both gradients and lets the data-gradient kernel add the other one in its
+            # epilogue, instead of the engine summing two full tensors in a pass of its own
+            ctx.set_materialize_grads(False)
+            return y, x
         return y
 
     @staticmethod
-    def backward(ctx, dy):
+    def backward(ctx, dy, dxr=None):
         x, w, b, y = ctx.saved_tensors
         d = ctx.d
+        if dy is None:                      # (fork: only the pass-through output was used)
+            return (dxr,) + (None,) * 11
         dy = dy.contiguous()
         dw_ret = db_ret = None
         db, ret_b = None, False
@@ -382,8 +391,8 @@ class _Conv(Function):
         dx = None
         if ctx.needs_input_grad[0]:
             dx = torch.empty_like(x)
-            _conv_dgrad_raw(ctx.d_dg, g, w, dx, ctx.transposed)
-        return dx, dw_ret, db_ret, None, None, None, None, None, None, None, None
+            _conv_dgrad_raw(ctx.d_dg, g, w, dx, ctx.transposed, addend=dxr.contiguous() if dxr is not None else None)
+        return dx, dw_ret, db_ret, None, None, None, None, None, None, None, None, None
 
 
 def conv2d(x, w, b=None, stride=1, pad=0, act=L.ACT_NONE, slope=0.0, prec=None, dead_bias=False):
@@ -391,6 +400,18 @@ def conv2d(x, w, b=None, stride=1, pad=0, act=L.ACT_NONE, slope=0.0, prec=None, 
     gradient exactly zero in exact arithmetic (the reference computes ~1e-10 rounding noise there); the column sum of dy
     is skipped and the bias gradient left at zero."""
     return _Conv.apply(x, w, b, stride, pad, False, act, slope, None, precision if prec is None else prec, dead_bias)
+
+
+_FORK = os.environ.get('HOIG_CONV_FORK', '1') == '1'      # A/B switch: 0 = autograd sums the gradients of a fanned-out tensor itself
+
+
+def conv2d_fork(x, w, b=None, stride=1, pad=0, act=L.ACT_NONE, slope=0.0, prec=None, dead_bias=False):
+    """-> (conv2d(x, ...), x') for a tensor x with a SECOND consumer (the skip of a residual block: generator.py:29-32).  x' is
+    x; the second consumer must read x' so that its gradient comes back through this node, which adds it in the epilogue of its
+    data-gradient kernel (hoig_conv2d_bwd_data_packed_add) -- one extra read instead of the autograd engine's three-pass sum."""
+    if not _FORK or not x.requires_grad:
+        return conv2d(x, w, b, stride, pad, act, slope, prec, dead_bias), x
+    return _Conv.apply(x, w, b, stride, pad, False, act, slope, None, precision if prec is None else prec, dead_bias, True)
 
 
 class _ConvCat2(Function):
@@ -945,14 +966,24 @@ def _conv_fwd_raw(d, x, w, b, y, transposed=False):
     call('hoig_conv2d_fwd', ctypes.byref(d), _p(x), _p(w), _p(b), _p(y), _st())
 
 
-def _conv_dgrad_raw(d, g, w, dx, transposed=False):
-    if d.precision != L.PREC_F32 and d.Co % 32 == 0 and d.Ci % 32 == 0 and d.Ci > 32:
+def _conv_dgrad_raw(d, g, w, dx, transposed=False, addend=None):
+    """dx = data gradient (+ addend: in the kernel's epilogue where it has one, by a separate add otherwise)."""
+    packed = d.precision != L.PREC_F32 and d.Co % 32 == 0 and d.Ci % 32 == 0 and d.Ci > 32
+    if packed:
         hi, lo = _packed_planes(w, transposed, True)
-        rc = L.lib.hoig_conv2d_bwd_data_packed(ctypes.byref(d), _p(g), _p(hi), _p(lo), _p(dx), _st())
-        if rc != L.EUNSUPPORTED:
-            L.check(rc, 'hoig_conv2d_bwd_data_packed')
-            return
-    call('hoig_conv2d_bwd_data', ctypes.byref(d), _p(g), _p(w), _p(dx), _st())
+        if addend is not None:
+            rc = L.lib.hoig_conv2d_bwd_data_packed_add(ctypes.byref(d), _p(g), _p(hi), _p(lo), _p(addend), _p(dx), _st())
+            if rc != L.EUNSUPPORTED:
+                L.check(rc, 'hoig_conv2d_bwd_data_packed_add')
+                return
+    out = dx if addend is None else torch.empty_like(dx)
+    rc = L.lib.hoig_conv2d_bwd_data_packed(ctypes.byref(d), _p(g), _p(hi), _p(lo), _p(out), _st()) if packed else L.EUNSUPPORTED
+    if rc == L.EUNSUPPORTED:
+        call('hoig_conv2d_bwd_data', ctypes.byref(d), _p(g), _p(w), _p(out), _st())
+    else:
+        L.check(rc, 'hoig_conv2d_bwd_data_packed')
+    if addend is not None:
+        call('hoig_add', _p(out), _p(addend), _p(dx), dx.numel(), _st())
 
 
 _attn_index = {}

@@ -102,6 +102,12 @@ int hoig_conv2d_fwd_packed(const hoig_conv_desc *d, const float *x, const uint16
                            const float *bias /*nullable*/, float *y, hoig_stream_t stream);
 int hoig_conv2d_bwd_data_packed(const hoig_conv_desc *d, const float *dy, const uint16_t *wt_hi, const uint16_t *wt_lo,
                                 float *dx, hoig_stream_t stream);
+/* dx = data gradient + addend (addend: the gradient that reaches the same tensor through its OTHER consumer, e.g. the skip path of
+ * a residual block, generator.py:29-32 `x + self.main(x)`; torch's autograd engine sums the two in a separate pass).  Returns
+ * HOIG_EUNSUPPORTED for layers whose kernel has no such epilogue (everything but stride-1 "same" 1x1/3x3/5x5 on the halo kernels): the
+ * caller then adds separately. */
+int hoig_conv2d_bwd_data_packed_add(const hoig_conv_desc *d, const float *dy, const uint16_t *wt_hi, const uint16_t *wt_lo,
+                                    const float *addend, float *dx, hoig_stream_t stream);
 
 /* fp16 + block-scaled fp6 forward of 3x3 stride-1 pad-1 convolutions (hoig_amd/csrc/conv_f6.hip).  q_hi / q_lo: fp6 records of
  * the hi / lo fp16 halves of 256*w, hoig_f6_plane_bytes(Co, 9, Ci) bytes each, made by hoig_pack_conv_weight_f6 once per

@@ -383,6 +383,52 @@ def test_conv_bf16x3_fast_path(B, Ci, Co, H, k, stride, pad, transposed, mode):
         assert ef > 2e-5 and ed > 1e-4, 'the two-term kernels did not run (error is at the three-term level)'
 
 
+@pytest.mark.parametrize('mode', ['f32', 'bf16x3', 'f16x2'])
+@pytest.mark.parametrize('B,C,Co,H,W,k,stride', [(8, 512, 512, 32, 32, 3, 1),      # the residual blocks: addend epilogue of the 3x3 kernel
+                                                 (8, 128, 64, 64, 64, 3, 1),       # ... its 64-column variant
+                                                 (8, 64, 64, 64, 64, 1, 1),        # 1x1 on the halo kernel
+                                                 (2, 128, 128, 16, 32, 3, 1),      # few tiles: split-K kernel, separate add
+                                                 (2, 128, 128, 16, 16, 3, 2),      # no such epilogue: separate add
+                                                 (2, 16, 64, 8, 8, 3, 1)])         # thin input
+def test_conv_fork_adds_the_other_consumers_gradient(B, C, Co, H, W, k, stride, mode):
+    """ops.conv2d_fork(x, w) -> (conv(x), x'): the gradient of x must be dgrad + (gradient that arrived through x'), whichever
+    kernel adds it -- and equal to what autograd computes when it sums the two consumers itself (generator.py:29-32)."""
+    ops = _ops()
+    g = torch.Generator().manual_seed(5)
+    x = torch.randn(B, C, H, W, generator=g)
+    w = torch.randn(Co, C, k, k, generator=g) * 0.05
+    ops.set_precision(mode)
+    try:
+        res = []
+        for fork in (False, True):
+            xd = nhwc_cuda(x).requires_grad_(True)
+            wd = ops.pack_weight(w.cuda()).requires_grad_(True)
+            x1 = ops.add(xd, xd)                               # a non-leaf (leaves accumulate into .grad anyway)
+            if fork:
+                y, x2 = ops.conv2d_fork(x1, wd, None, stride, k // 2)
+                assert x2.data_ptr() == x1.data_ptr()
+            else:
+                y, x2 = ops.conv2d(x1, wd, None, stride, k // 2), x1
+            gy = torch.randn(y.shape, generator=torch.Generator().manual_seed(6)).cuda()
+            gx = torch.randn(x1.shape, generator=torch.Generator().manual_seed(7)).cuda()
+            ((y * gy).sum() + (x2 * gx).sum()).backward()
+            torch.cuda.synchronize()
+            res.append((y.detach().clone(), xd.grad.clone(), wd.grad.clone()))
+        # only the pass-through output used: the gradient passes through untouched
+        xd = nhwc_cuda(x).requires_grad_(True)
+        _, x2 = ops.conv2d_fork(ops.add(xd, xd), ops.pack_weight(w.cuda()).requires_grad_(True), None, stride, k // 2)
+        (x2 * gx).sum().backward()
+        assert torch.equal(xd.grad, 2 * gx)
+    finally:
+        ops.set_precision('f32')
+    (y0, dx0, dw0), (y1, dx1, dw1) = res
+    assert float((y0 - y1).abs().max()) <= 1e-5 * float(y0.abs().max())         # (split-K launches: fp32 atomics)
+    assert float((dx0 - dx1).abs().max()) <= 1e-5 * float(dx0.abs().max())      # same products, one rounding apart
+    assert float((dw0 - dw1).abs().max()) <= 1e-4 * float(dw0.abs().max())      # (fp32 atomics)
+    # the fork must not have dropped either part: dx = 2 * (dgrad + gx)
+    assert rel_err(dx1 - 2 * gx, dx0 - 2 * gx) < 1e-4 and float((dx1 - 2 * gx).abs().max()) > 0
+
+
 THIN_CASES = [
     # B, Ci, Co, H, W, k, bias, act       (stride 1, 'same' padding)
     (2, 3, 64, 32, 32, 7, False, 'none'),      # the 7x7 stems (generator.py:100,153)

@@ -14,7 +14,7 @@ from hoig_amd import ops, synthetic                       # noqa: E402
 from hoig_amd.options import opt_namespace                # noqa: E402
 from hoig_amd.models import ModelsFactory                 # noqa: E402
 
-ops.set_precision('f16f6')
+ops.set_precision(os.environ.get('HOIG_PRECISION', 'bf16x3:f16x2'))
 opt = opt_namespace(gen_name='generator_spade_attn')
 m = ModelsFactory.get_by_name('trainer', opt, use_ddp=False)
 m.set_input(synthetic.make_inputs(8, 256, seed=1))
