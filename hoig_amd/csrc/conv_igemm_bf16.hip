@@ -1422,7 +1422,9 @@ __global__ __launch_bounds__(256) void conv_halo_s2_bf16_kernel(const HaloArgs p
                 if (n < p.N) {
                     float v = acc[i][j][r] * p.oscale;
                     v += bias_r[j];
-                    p.C[pix * p.N + n] = fast_act(v, nslope, special, p.act, p.slope);
+                    v = fast_act(v, nslope, special, p.act, p.slope);
+                    if (p.addend) v += p.addend[pix * p.N + n];
+                    p.C[pix * p.N + n] = v;
                 }
             }
         }
@@ -1653,7 +1655,7 @@ int run(const hoig_conv_desc *d, const float *a, const unsigned short *wh, const
         if (d->R == 3) return launch_halo3(h, ns, st);
         return launch_halo<5>(h, ns, st);
     }
-    if (a2 || c2 || addend) return HOIG_EUNSUPPORTED;
+    if (a2 || c2) return HOIG_EUNSUPPORTED;
     // stride-2 3x3 pad-1 layers on the parity-phase halo kernel.  gather: Conv2d forward / ConvTranspose2d data gradient;
     // scatter: ConvTranspose2d forward / Conv2d data gradient
     static const bool no_s2 = getenv("HOIG_NO_HALO_S2") != nullptr;
@@ -1667,7 +1669,7 @@ int run(const hoig_conv_desc *d, const float *a, const unsigned short *wh, const
             h.A = a; h.Wh = wh; h.Wl = wl; h.bias = bias; h.C = c;
             h.Bn = d->B; h.Cg = g.Cg; h.N = p.N; h.K = p.K;
             h.pad = 1; h.flip = 0;
-            h.A2 = nullptr; h.cg1 = 0; h.C2 = nullptr; h.n1 = 0; h.addend = nullptr;
+            h.A2 = nullptr; h.cg1 = 0; h.C2 = nullptr; h.n1 = 0; h.addend = addend;
             h.act = p.act; h.slope = p.slope;
             h.f16 = p.f16; h.oscale = p.oscale;
             const bool gather = !g.gatherT;      // the operand is read at 2*o - 1 + tap (fine grid) -> gather mode
@@ -1679,6 +1681,7 @@ int run(const hoig_conv_desc *d, const float *a, const unsigned short *wh, const
             return launch_halo_s2<true>(h, ns, st);
         }
     }
+    if (addend) return HOIG_EUNSUPPORTED;
     if (p.N <= 64) {
         if (t128 >= 512) return launch<128, 64, 2, 2>(p, ns, st);
         return launch<64, 64, 2, 2>(p, ns, st);

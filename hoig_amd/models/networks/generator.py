@@ -107,13 +107,20 @@ class Generator(ParamTree):
         beta = self._conv(actv, name + '.mlp_beta')
         return ops.spade_norm(x, gamma, beta, act=act)
 
-    def _conv_in_relu(self, x, name, stride=1, pad=1, transposed=False):
+    def _conv_fork(self, x, name, stride=1, pad=1):
+        """-> (conv(x), x'): x has a second reader (a skip connection), which must read x' (ops.conv2d_fork)."""
+        return ops.conv2d_fork(x, self.P[name + '.weight'], self.P.get(name + '.bias'), stride, pad, dead_bias=True)
+
+    def _conv_in_relu(self, x, name, stride=1, pad=1, transposed=False, fork=False):
+        if fork:
+            h, x = self._conv_fork(x, name + '.0', stride, pad)
+            return self._in(h, name + '.1', act=ACT_RELU), x
         h = self._convT(x, name + '.0') if transposed else self._conv(x, name + '.0', stride, pad, to_norm=True)
         return self._in(h, name + '.1', act=ACT_RELU)
 
     def _resblock(self, x, name):                                          # generator.py:9-32
         # (x has two readers, the first conv and the skip: conv2d_fork routes the skip's gradient through the conv's backward)
-        h, x = ops.conv2d_fork(x, self.P[name + '.main.0.weight'], self.P.get(name + '.main.0.bias'), 1, 1, dead_bias=True)
+        h, x = self._conv_fork(x, name + '.main.0')
         h = self._in(h, name + '.main.1', act=ACT_RELU)
         return self._in(self._conv(h, name + '.main.3', to_norm=True), name + '.main.4', residual=x)
 
@@ -122,7 +129,10 @@ class Generator(ParamTree):
         dx = self._conv(self._spade(dx, seg, name + '.norm_1', ACT_RELU), name + '.conv_1')
         return ops.add(x, dx)
 
-    def _spade_block(self, x, seg, name, down):                            # generator.py:74-90
+    def _spade_block(self, x, seg, name, down, fork=False):                # generator.py:74-90
+        if fork:
+            h, x = self._conv_fork(x, name + '.conv', stride=2)
+            return self._spade(h, seg, name + '.norm', ACT_RELU), x
         h = self._conv(x, name + '.conv', stride=2, to_norm=True) if down else self._convT(x, name + '.conv')
         return self._spade(h, seg, name + '.norm', ACT_RELU)
 
@@ -155,9 +165,10 @@ class Generator(ParamTree):
         return out[0]
 
     def _enc_level(self, x, seg, p, i):
+        """-> (encoder level i of x, x'): x is also the skip connection of a decoder level, which must read x'."""
         if self.cfg.spade_layers[0]:
-            return self._spade_block(x, seg, p + '.encoders.%d' % i, True)
-        return self._conv_in_relu(x, p + '.encoders.%d' % i, stride=2)
+            return self._spade_block(x, seg, p + '.encoders.%d' % i, True, fork=True)
+        return self._conv_in_relu(x, p + '.encoders.%d' % i, stride=2, fork=True)
 
     def _resnet(self, x, seg, p, i):
         c = self.cfg
@@ -187,7 +198,7 @@ class Generator(ParamTree):
         yield
         enc = [e]
         for i in range(1, self.cfg.n_down + 1):
-            e = self._enc_level(e, seg, p, i)
+            e, enc[-1] = self._enc_level(e, seg, p, i)
             enc.append(e)
             yield
         for i in range(self.cfg.repeat_num):
@@ -314,9 +325,9 @@ class Generator(ParamTree):
         s_enc, t_enc = [sx], [tx]
         for i in range(1, c.n_down + 1):
             with on_src():
-                sx = self._enc_level(sx, src_hand_c, 'src_model', i)
+                sx, s_enc[-1] = self._enc_level(sx, src_hand_c, 'src_model', i)
                 gs = self._attn_source(sx, i)               # (the attention's source convolution rides on the src stream too)
-            tx = self._enc_level(tx, tsf_hand_c, 'tsf_model', i)
+            tx, t_enc[-1] = self._enc_level(tx, tsf_hand_c, 'tsf_model', i)
             tx = ops.add(tx, self._transform(src_ready(sx), T, i, y=tx, gs=None if gs is None else src_ready(gs)))
             s_enc.append(sx)
             t_enc.append(tx)

@@ -104,7 +104,7 @@ int hoig_conv2d_bwd_data_packed(const hoig_conv_desc *d, const float *dy, const 
                                 float *dx, hoig_stream_t stream);
 /* dx = data gradient + addend (addend: the gradient that reaches the same tensor through its OTHER consumer, e.g. the skip path of
  * a residual block, generator.py:29-32 `x + self.main(x)`; torch's autograd engine sums the two in a separate pass).  Returns
- * HOIG_EUNSUPPORTED for layers whose kernel has no such epilogue (everything but stride-1 "same" 1x1/3x3/5x5 on the halo kernels): the
+ * HOIG_EUNSUPPORTED for layers whose kernel has no such epilogue (everything but stride-1 "same" 1x1/3x3/5x5 and stride-2 3x3 on the halo kernels): the
  * caller then adds separately. */
 int hoig_conv2d_bwd_data_packed_add(const hoig_conv_desc *d, const float *dy, const uint16_t *wt_hi, const uint16_t *wt_lo,
                                     const float *addend, float *dx, hoig_stream_t stream);

@@ -388,6 +388,7 @@ def test_conv_bf16x3_fast_path(B, Ci, Co, H, k, stride, pad, transposed, mode):
                                                  (8, 128, 64, 64, 64, 3, 1),       # ... its 64-column variant
                                                  (8, 64, 64, 64, 64, 1, 1),        # 1x1 on the halo kernel
                                                  (2, 128, 128, 16, 32, 3, 1),      # few tiles: split-K kernel, separate add
+                                                 (4, 64, 128, 64, 64, 3, 2),       # encoder level: the stride-2 kernel's epilogue
                                                  (2, 128, 128, 16, 16, 3, 2),      # no such epilogue: separate add
                                                  (2, 16, 64, 8, 8, 3, 1)])         # thin input
 def test_conv_fork_adds_the_other_consumers_gradient(B, C, Co, H, W, k, stride, mode):
