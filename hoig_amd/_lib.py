@@ -71,13 +71,16 @@ _SIGS = {
     'hoig_inorm_bwd_ld': [_vp, _vp, _vp, _i, _vp, _vp, _i, _vp, _vp, _i, _f, _vp, _vp, _vp, _i, _i, _i, _vp, _vp],
     'hoig_inorm_fwd_fused': [_vp, _i, _vp, _vp, _i, _i, _f, _vp, _f, _vp, _vp, _vp, _i, _i, _i, _vp],
     'hoig_inorm_bwd_fused': [_vp, _vp, _vp, _i, _vp, _vp, _i, _vp, _vp, _i, _f, _vp, _vp, _vp, _i, _i, _i, _vp],
+    'hoig_inorm_bwd_add_ld': [_vp, _vp, _vp, _i, _vp, _vp, _i, _vp, _vp, _i, _f, _vp, _vp, _vp, _vp, _i, _i, _i, _vp, _vp],
+    'hoig_inorm_bwd_fused_add': [_vp, _vp, _vp, _i, _vp, _vp, _i, _vp, _vp, _i, _f, _vp, _vp, _vp, _vp, _i, _i, _i, _vp],
     'hoig_inorm_bwd': [_vp, _vp, _vp, _i, _vp, _vp, _vp, _vp, _i, _f, _vp, _vp, _vp, _i, _i, _i, _vp, _vp],
     'hoig_replicate_pad_fwd': [_vp, _vp, _i, _i, _i, _i, _i, _vp],
     'hoig_replicate_pad_bwd': [_vp, _vp, _i, _i, _i, _i, _i, _vp],
+    'hoig_replicate_pad_bwd_add': [_vp, _vp, _vp, _i, _i, _i, _i, _i, _vp],
     'hoig_attn_pixel_fwd': [_vp] * 10 + [_i, _i, _i, _i, _vp],
     'hoig_attn_pixel_bwd': [_vp] * 10 + [_i, _i, _i, _i, _vp],
     'hoig_attn_build_index': [_vp, _vp, _i, _i, _i, _vp],
-    'hoig_attn_src_gather': [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp],
+    'hoig_attn_src_gather': [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp],
     'hoig_attn_gs_gather': [_vp, _vp, _vp, _vp, _i, _i, _i, _vp],
     'hoig_block_extractor_forward': [_vp, _vp, _vp] + [_i] * 7 + [_vp],
     'hoig_block_extractor_backward': [_vp] * 5 + [_i] * 7 + [_vp],
@@ -103,7 +106,10 @@ _SIGS = {
     'hoig_compose_bwd': [_vp] * 11 + [_i64, _i, _vp],
     'hoig_loss_fwd_bwd': [_i, _vp, _vp, _f, _f, _vp, _vp, _i64, _vp],
     'hoig_tv_fwd_bwd': [_vp, _f, _f, _vp, _vp, _i, _i, _i, _vp],
+    'hoig_loss_accumulate': [_i, _vp, _vp, _f, _f, _vp, _vp, _i64, _vp],
+    'hoig_tv_accumulate': [_vp, _f, _f, _vp, _vp, _i, _i, _i, _vp],
     'hoig_sum': [_vp, _vp, _i64, _vp],
+    'hoig_sum_scaled': [_vp, _f, _vp, _i64, _vp],
     'hoig_adam_step': [_vp, _vp, _vp, _vp, _i64, _d, _d, _d, _d, _i, _f, _vp],
     'hoig_adam_tick': [_vp, _vp, _vp],
     'hoig_adam_step_dev': [_vp, _vp, _vp, _vp, _i64, _vp, _f, _vp],

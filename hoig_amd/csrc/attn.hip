@@ -59,7 +59,7 @@ __global__ void replicate_pad_fwd_kernel(const float *__restrict__ x, float *__r
 
 // dx[y][x] = sum of dy over the padded cells that replicate (y,x)  (gather form: no atomics)
 __global__ void replicate_pad_bwd_kernel(const float *__restrict__ dy, float *__restrict__ dx, int B, int H, int W, int C,
-                                         int p) {
+                                         int p, const float *__restrict__ addend) {
     const int Hp = H + 2 * p, Wp = W + 2 * p, CV = C >> 2;
     const int64_t n = (int64_t)B * H * W * CV;
     for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
@@ -76,6 +76,10 @@ __global__ void replicate_pad_bwd_kernel(const float *__restrict__ dy, float *__
                 const float4 v = *reinterpret_cast<const float4 *>(dy + (((size_t)b * Hp + py) * Wp + px) * C + cv * 4);
                 s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
             }
+        if (addend) {                       // the gradient that reached the unpadded tensor through another consumer
+            const float4 a = reinterpret_cast<const float4 *>(addend)[i];
+            s.x += a.x; s.y += a.y; s.z += a.z; s.w += a.w;
+        }
         reinterpret_cast<float4 *>(dx)[i] = s;
     }
 }
@@ -475,7 +479,8 @@ __device__ __forceinline__ void fp_range(int p, int y, int n, int span, int org,
 constexpr int SG_ROWCAP = 16;                 // list slots per window row (a row with more pixels takes the slow path)
 __global__ __launch_bounds__(256) void attn_src_gather_kernel(const int *__restrict__ offsets, const int *__restrict__ items,
                                                               const float *__restrict__ kfbuf, const float *__restrict__ dout,
-                                                              float *__restrict__ dsrc, int B, int H, int W, int C) {
+                                                              float *__restrict__ dsrc, int B, int H, int W, int C,
+                                                              const float *__restrict__ init) {
     __shared__ int lm[16][FP * SG_ROWCAP];
     __shared__ float lw[16][FP * SG_ROWCAP];
     const int CV = C >> 2, CVC = CV / 16;
@@ -556,10 +561,13 @@ __global__ __launch_bounds__(256) void attn_src_gather_kernel(const int *__restr
             }
         }
     }
-    float4 *dst = reinterpret_cast<float4 *>(dsrc + (((size_t)b * H + y) * W + x) * C + cv * 4);
-    float4 o = *dst;
-    o.x += acc.x; o.y += acc.y; o.z += acc.z; o.w += acc.w;
-    *dst = o;
+    // every (pixel, channel) is written exactly once: dsource = init (another consumer's gradient; nothing if NULL) + the gather
+    const size_t di = (((size_t)b * H + y) * W + x) * C + cv * 4;
+    if (init) {
+        const float4 o = *reinterpret_cast<const float4 *>(init + di);
+        acc.x += o.x; acc.y += o.y; acc.z += o.z; acc.w += o.w;
+    }
+    *reinterpret_cast<float4 *>(dsrc + di) = acc;
 }
 
 // dGs[b][gy][gx][j4] = sum_m w_ab(m) * dhidden[m][j4] over the pixels whose frame corner (a,b) (clamped to [-2, H+1]) is the cell
@@ -610,12 +618,16 @@ extern "C" int hoig_replicate_pad_fwd(const float *x, float *y, int B, int H, in
     HOIG_LAUNCH_CHECK();
     return HOIG_OK;
 }
-extern "C" int hoig_replicate_pad_bwd(const float *dy, float *dx, int B, int H, int W, int C, int pad, hoig_stream_t stream) {
+extern "C" int hoig_replicate_pad_bwd_add(const float *dy, const float *addend, float *dx, int B, int H, int W, int C, int pad,
+                                          hoig_stream_t stream) {
     if (!dy || !dx || pad < 0 || (C & 3)) return HOIG_EINVAL;
     const int64_t n = (int64_t)B * H * W * (C / 4);
-    replicate_pad_bwd_kernel<<<hoig_stream_grid(n, 256), 256, 0, ST>>>(dy, dx, B, H, W, C, pad);
+    replicate_pad_bwd_kernel<<<hoig_stream_grid(n, 256), 256, 0, ST>>>(dy, dx, B, H, W, C, pad, addend);
     HOIG_LAUNCH_CHECK();
     return HOIG_OK;
+}
+extern "C" int hoig_replicate_pad_bwd(const float *dy, float *dx, int B, int H, int W, int C, int pad, hoig_stream_t stream) {
+    return hoig_replicate_pad_bwd_add(dy, nullptr, dx, B, H, W, C, pad, stream);
 }
 // workspace of the pixel index: [counts / offsets: nb + 1][cursor: nb][bucket_of: M][items: M][block totals: 2048] ints
 extern "C" int64_t hoig_attn_index_ints(int B, int H, int W) {
@@ -640,14 +652,14 @@ extern "C" int hoig_attn_build_index(const float *flow, int *index, int B, int H
     HOIG_LAUNCH_CHECK();
     return HOIG_OK;
 }
-extern "C" int hoig_attn_src_gather(const int *index, const float *kf, const float *dout, float *dsource, int B, int H, int W,
-                                    int C, hoig_stream_t stream) {
+extern "C" int hoig_attn_src_gather(const int *index, const float *kf, const float *dout, const float *init, float *dsource,
+                                    int B, int H, int W, int C, hoig_stream_t stream) {
     if (!index || !kf || !dout || !dsource || (C & 3) || B <= 0) return HOIG_EINVAL;
     const int n = B * (H + BLO + 2) * (W + BLO + 2) + 1, M = B * H * W;
     const int *items = index + 2 * n + M;
     if (C % 64) return HOIG_EUNSUPPORTED;
     const int64_t blocks = (int64_t)B * ((H + 3) / 4) * ((W + 3) / 4) * (C / 64);
-    attn_src_gather_kernel<<<(unsigned)blocks, 256, 0, ST>>>(index, items, kf, dout, dsource, B, H, W, C);
+    attn_src_gather_kernel<<<(unsigned)blocks, 256, 0, ST>>>(index, items, kf, dout, dsource, B, H, W, C, init);
     HOIG_LAUNCH_CHECK();
     return HOIG_OK;
 }

@@ -180,7 +180,8 @@ __global__ __launch_bounds__(NT) void inorm_bwd_apply_kernel(const float *__rest
                                                              const float *__restrict__ dy, int act, float slope,
                                                              const float *__restrict__ sums, float *__restrict__ dx,
                                                              float *__restrict__ dp0, float *__restrict__ dp1, int HW,
-                                                             int C, int64_t n4, int ldp, const float *__restrict__ p1) {
+                                                             int C, int64_t n4, int ldp, const float *__restrict__ p1,
+                                                             const float *__restrict__ addend) {
     const int CV = C >> 2;
     const float inv = 1.f / (float)HW;
     for (int64_t i = (int64_t)blockIdx.x * NT + threadIdx.x; i < n4; i += (int64_t)gridDim.x * NT) {
@@ -231,6 +232,10 @@ __global__ __launch_bounds__(NT) void inorm_bwd_apply_kernel(const float *__rest
         o.y = rs.y * (g.y * sc.y - s1.y * inv - h.y * s2.y * inv);
         o.z = rs.z * (g.z * sc.z - s1.z * inv - h.z * s2.z * inv);
         o.w = rs.w * (g.w * sc.w - s1.w * inv - h.w * s2.w * inv);
+        if (addend) {                           // the gradient that reached x through its other consumer (a residual add)
+            const float4 a = reinterpret_cast<const float4 *>(addend)[i];
+            o.x += a.x; o.y += a.y; o.z += a.z; o.w += a.w;
+        }
         reinterpret_cast<float4 *>(dx)[i] = o;
     }
 }
@@ -332,7 +337,8 @@ __global__ __launch_bounds__(TNT) void inorm_tile_bwd_kernel(const float *__rest
                                                              const float *__restrict__ p0, const float *__restrict__ p1,
                                                              int ldp, const float *__restrict__ y, const float *__restrict__ dy,
                                                              int act, float slope, float *__restrict__ dx,
-                                                             float *__restrict__ dp0, float *__restrict__ dp1, int HW, int C) {
+                                                             float *__restrict__ dp0, float *__restrict__ dp1, int HW, int C,
+                                                             const float *__restrict__ addend) {
     __shared__ float red[TPL * TCG];
     const int b = blockIdx.y, c0 = blockIdx.x * TCG;
     const int cq = threadIdx.x % (TCG / 4), pl = threadIdx.x / (TCG / 4), c = c0 + cq * 4;
@@ -404,6 +410,10 @@ __global__ __launch_bounds__(TNT) void inorm_tile_bwd_kernel(const float *__rest
         o.y = rs.y * (g[k].y * sc.y - s1.y * inv - h[k].y * s2.y * inv);
         o.z = rs.z * (g[k].z * sc.z - s1.z * inv - h[k].z * s2.z * inv);
         o.w = rs.w * (g[k].w * sc.w - s1.w * inv - h[k].w * s2.w * inv);
+        if (addend) {
+            const float4 a = *reinterpret_cast<const float4 *>(addend + base + (size_t)r * C);
+            o.x += a.x; o.y += a.y; o.z += a.z; o.w += a.w;
+        }
         *reinterpret_cast<float4 *>(dx + base + (size_t)r * C) = o;
     }
 }
@@ -475,17 +485,25 @@ extern "C" int hoig_inorm_apply_ld(const float *x, const float *mean, const floa
     return HOIG_OK;
 }
 
+extern "C" int hoig_inorm_bwd_add_ld(const float *x, const float *mean, const float *rstd, int mode, const float *p0,
+                                     const float *p1, int ld_p, const float *y, const float *dy, int act, float slope,
+                                     const float *addend, float *dx, float *dp0, float *dp1, int B, int HW, int C,
+                                     void *workspace, hoig_stream_t stream);
 extern "C" int hoig_inorm_bwd_ld(const float *x, const float *mean, const float *rstd, int mode, const float *p0,
                                  const float *p1, int ld_p, const float *y, const float *dy, int act, float slope, float *dx,
-                                 float *dp0, float *dp1, int B, int HW, int C, void *workspace, hoig_stream_t stream);
+                                 float *dp0, float *dp1, int B, int HW, int C, void *workspace, hoig_stream_t stream) {
+    return hoig_inorm_bwd_add_ld(x, mean, rstd, mode, p0, p1, ld_p, y, dy, act, slope, nullptr, dx, dp0, dp1, B, HW, C, workspace,
+                                 stream);
+}
 extern "C" int hoig_inorm_bwd(const float *x, const float *mean, const float *rstd, int mode, const float *p0,
                               const float *p1, const float *y, const float *dy, int act, float slope, float *dx, float *dp0,
                               float *dp1, int B, int HW, int C, void *workspace, hoig_stream_t stream) {
     return hoig_inorm_bwd_ld(x, mean, rstd, mode, p0, p1, C, y, dy, act, slope, dx, dp0, dp1, B, HW, C, workspace, stream);
 }
-extern "C" int hoig_inorm_bwd_ld(const float *x, const float *mean, const float *rstd, int mode, const float *p0,
-                                 const float *p1, int ld_p, const float *y, const float *dy, int act, float slope, float *dx,
-                                 float *dp0, float *dp1, int B, int HW, int C, void *workspace, hoig_stream_t stream) {
+extern "C" int hoig_inorm_bwd_add_ld(const float *x, const float *mean, const float *rstd, int mode, const float *p0,
+                                     const float *p1, int ld_p, const float *y, const float *dy, int act, float slope,
+                                     const float *addend, float *dx, float *dp0, float *dp1, int B, int HW, int C,
+                                     void *workspace, hoig_stream_t stream) {
     if (mode == 2 && (ld_p < C || (ld_p & 3))) return HOIG_EINVAL;
     if (!x || !mean || !rstd || !dy || !dx || !workspace || mode < 0 || mode > 2) return HOIG_EINVAL;
     // y may be NULL for (Leaky)ReLU after a plain or affine instance norm: the sign of y is recomputed from x (for the
@@ -508,7 +526,7 @@ extern "C" int hoig_inorm_bwd_ld(const float *x, const float *mean, const float 
     HOIG_LAUNCH_CHECK();
     const int64_t n4 = (int64_t)B * HW * C / 4;
     inorm_bwd_apply_kernel<<<hoig_stream_grid(n4, NT), NT, 0, st>>>(x, mean, rstd, mode, p0, y, dy, act, slope, sums, dx,
-                                                                   dp0, dp1, HW, C, n4, ld_p, p1);
+                                                                   dp0, dp1, HW, C, n4, ld_p, p1, addend);
     HOIG_LAUNCH_CHECK();
     return HOIG_OK;
 }
@@ -527,9 +545,19 @@ extern "C" int hoig_inorm_fwd_fused(const float *x, int mode, const float *p0, c
     HOIG_LAUNCH_CHECK();
     return HOIG_OK;
 }
+extern "C" int hoig_inorm_bwd_fused_add(const float *x, const float *mean, const float *rstd, int mode, const float *p0,
+                                        const float *p1, int ld_p, const float *y, const float *dy, int act, float slope,
+                                        const float *addend, float *dx, float *dp0, float *dp1, int B, int HW, int C,
+                                        hoig_stream_t stream);
 extern "C" int hoig_inorm_bwd_fused(const float *x, const float *mean, const float *rstd, int mode, const float *p0,
                                     const float *p1, int ld_p, const float *y, const float *dy, int act, float slope, float *dx,
                                     float *dp0, float *dp1, int B, int HW, int C, hoig_stream_t stream) {
+    return hoig_inorm_bwd_fused_add(x, mean, rstd, mode, p0, p1, ld_p, y, dy, act, slope, nullptr, dx, dp0, dp1, B, HW, C, stream);
+}
+extern "C" int hoig_inorm_bwd_fused_add(const float *x, const float *mean, const float *rstd, int mode, const float *p0,
+                                        const float *p1, int ld_p, const float *y, const float *dy, int act, float slope,
+                                        const float *addend, float *dx, float *dp0, float *dp1, int B, int HW, int C,
+                                        hoig_stream_t stream) {
     if (!x || !mean || !rstd || !dy || !dx || mode < 0 || mode > 2) return HOIG_EINVAL;
     if (mode == 2 && (ld_p < C || (ld_p & 3) || !dp0 || !dp1)) return HOIG_EINVAL;
     if (act != HOIG_ACT_NONE && !y &&
@@ -538,7 +566,7 @@ extern "C" int hoig_inorm_bwd_fused(const float *x, const float *mean, const flo
     if (mode != 0 && !p0) return HOIG_EINVAL;
     if (!tile_ok(B, HW, C)) return HOIG_EUNSUPPORTED;
     inorm_tile_bwd_kernel<<<dim3(C / TCG, B), TNT, 0, (hipStream_t)stream>>>(x, mean, rstd, mode, p0, p1, ld_p, y, dy, act, slope,
-                                                                             dx, dp0, dp1, HW, C);
+                                                                             dx, dp0, dp1, HW, C, addend);
     HOIG_LAUNCH_CHECK();
     return HOIG_OK;
 }

@@ -311,7 +311,7 @@ __global__ void compose_bwd_kernel(const float *__restrict__ bg, const float *__
 
 __global__ __launch_bounds__(NT) void loss_kernel(int kind, const float *__restrict__ pred,
                                                   const float *__restrict__ target, float tconst, float gscale,
-                                                  float *__restrict__ out, float *__restrict__ dpred, int64_t n) {
+                                                  float *__restrict__ out, float *__restrict__ dpred, int64_t n, float oscale) {
     float acc = 0.f;
     for (int64_t i = (int64_t)blockIdx.x * NT + threadIdx.x; i < n; i += (int64_t)gridDim.x * NT) {
         const float p = pred[i], t = target ? target[i] : tconst;
@@ -333,11 +333,12 @@ __global__ __launch_bounds__(NT) void loss_kernel(int kind, const float *__restr
         if (dpred) dpred[i] = g * gscale;
     }
     const float s = block_sum(acc);
-    if (threadIdx.x == 0) atomicAdd(out, s);
+    if (threadIdx.x == 0) atomicAdd(out, s * oscale);
 }
 
+// `one`: both sums go to out[0], scaled by gx / gy (a term of an objective: hoig_tv_accumulate)
 __global__ __launch_bounds__(NT) void tv_kernel(const float *__restrict__ m, float gx, float gy, float *__restrict__ out,
-                                                float *__restrict__ dm, int B, int H, int W) {
+                                                float *__restrict__ dm, int B, int H, int W, bool one) {
     const int64_t n = (int64_t)B * H * W;
     float ax = 0.f, ay = 0.f;
     for (int64_t i = (int64_t)blockIdx.x * NT + threadIdx.x; i < n; i += (int64_t)gridDim.x * NT) {
@@ -367,16 +368,20 @@ __global__ __launch_bounds__(NT) void tv_kernel(const float *__restrict__ m, flo
     const float sx = block_sum(ax);
     const float sy = block_sum(ay);
     if (threadIdx.x == 0) {
-        atomicAdd(&out[0], sx);
-        atomicAdd(&out[1], sy);
+        if (one) {
+            atomicAdd(&out[0], sx * gx + sy * gy);
+        } else {
+            atomicAdd(&out[0], sx);
+            atomicAdd(&out[1], sy);
+        }
     }
 }
 
-__global__ __launch_bounds__(NT) void sum_kernel(const float *__restrict__ x, float *__restrict__ out, int64_t n) {
+__global__ __launch_bounds__(NT) void sum_kernel(const float *__restrict__ x, float *__restrict__ out, int64_t n, float scale) {
     float acc = 0.f;
     for (int64_t i = (int64_t)blockIdx.x * NT + threadIdx.x; i < n; i += (int64_t)gridDim.x * NT) acc += x[i];
     const float s = block_sum(acc);
-    if (threadIdx.x == 0) atomicAdd(out, s);
+    if (threadIdx.x == 0) atomicAdd(out, s * scale);
 }
 
 __global__ void maxpool_fwd_kernel(const float *__restrict__ x, float *__restrict__ y, int B, int H, int W, int C) {
@@ -640,7 +645,16 @@ extern "C" int hoig_loss_fwd_bwd(int kind, const float *pred, const float *targe
     if (!pred || !out || kind < 0 || kind > 2) return HOIG_EINVAL;
     int g = hoig_stream_grid(n, NT);
     if (g > 512) g = 512;
-    loss_kernel<<<g, NT, 0, ST>>>(kind, pred, target, target_const, gscale, out, dpred, n);
+    loss_kernel<<<g, NT, 0, ST>>>(kind, pred, target, target_const, gscale, out, dpred, n, 1.f);
+    HOIG_LAUNCH_CHECK();
+    return HOIG_OK;
+}
+extern "C" int hoig_loss_accumulate(int kind, const float *pred, const float *target, float target_const, float gscale,
+                                    float *term, float *dpred, int64_t n, hoig_stream_t stream) {
+    if (!pred || !term || kind < 0 || kind > 2) return HOIG_EINVAL;
+    int g = hoig_stream_grid(n, NT);
+    if (g > 512) g = 512;
+    loss_kernel<<<g, NT, 0, ST>>>(kind, pred, target, target_const, gscale, term, dpred, n, gscale);
     HOIG_LAUNCH_CHECK();
     return HOIG_OK;
 }
@@ -649,7 +663,16 @@ extern "C" int hoig_tv_fwd_bwd(const float *m, float gx, float gy, float *out, f
     if (!m || !out) return HOIG_EINVAL;
     int g = hoig_stream_grid((int64_t)B * H * W, NT);
     if (g > 512) g = 512;
-    tv_kernel<<<g, NT, 0, ST>>>(m, gx, gy, out, dm, B, H, W);
+    tv_kernel<<<g, NT, 0, ST>>>(m, gx, gy, out, dm, B, H, W, false);
+    HOIG_LAUNCH_CHECK();
+    return HOIG_OK;
+}
+extern "C" int hoig_tv_accumulate(const float *m, float gx, float gy, float *term, float *dm, int B, int H, int W,
+                                  hoig_stream_t stream) {
+    if (!m || !term) return HOIG_EINVAL;
+    int g = hoig_stream_grid((int64_t)B * H * W, NT);
+    if (g > 512) g = 512;
+    tv_kernel<<<g, NT, 0, ST>>>(m, gx, gy, term, dm, B, H, W, true);
     HOIG_LAUNCH_CHECK();
     return HOIG_OK;
 }
@@ -657,7 +680,15 @@ extern "C" int hoig_sum(const float *x, float *out, int64_t n, hoig_stream_t str
     if (!x || !out) return HOIG_EINVAL;
     int g = hoig_stream_grid(n, NT);
     if (g > 512) g = 512;
-    sum_kernel<<<g, NT, 0, ST>>>(x, out, n);
+    sum_kernel<<<g, NT, 0, ST>>>(x, out, n, 1.f);
+    HOIG_LAUNCH_CHECK();
+    return HOIG_OK;
+}
+extern "C" int hoig_sum_scaled(const float *x, float scale, float *out, int64_t n, hoig_stream_t stream) {
+    if (!x || !out) return HOIG_EINVAL;
+    int g = hoig_stream_grid(n, NT);
+    if (g > 512) g = 512;
+    sum_kernel<<<g, NT, 0, ST>>>(x, out, n, scale);
     HOIG_LAUNCH_CHECK();
     return HOIG_OK;
 }

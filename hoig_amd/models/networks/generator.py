@@ -94,18 +94,20 @@ class Generator(ParamTree):
             self._seg_cache[key] = ops.resize_nearest(seg, h, w)          # spade.py:30
         return self._seg_cache[key]
 
-    def _spade(self, x, seg, name, act):
-        """spade.py:25-38 (+ the ReLU that always follows it, generator.py:66-67,88)."""
+    def _spade(self, x, seg, name, act, fork=False):
+        """spade.py:25-38 (+ the ReLU that always follows it, generator.py:66-67,88).  fork=True -> (y, x') for an x that has a
+        second reader, which must read x' (ops.spade_norm_fused)."""
         s = self._seg_at(seg, x.shape[1], x.shape[2])
         actv = self._conv(s, name + '.mlp_shared.0', act=ACT_RELU)
         if name + '.mlp_gb.weight' in self.F:
             # mlp_gamma and mlp_beta are two 3x3 convs over the same activation (spade.py:33-34): run them as ONE conv with
             # 2C outputs (their weights sit back to back in the flat store) and modulate from the [.,2C] result in place
             gb = ops.conv2d(actv, self.F[name + '.mlp_gb.weight'], self.F[name + '.mlp_gb.bias'], 1, 1)
-            return ops.spade_norm_fused(x, gb, act=act)
+            return ops.spade_norm_fused(x, gb, act=act, fork=fork)
         gamma = self._conv(actv, name + '.mlp_gamma')
         beta = self._conv(actv, name + '.mlp_beta')
-        return ops.spade_norm(x, gamma, beta, act=act)
+        y = ops.spade_norm(x, gamma, beta, act=act)
+        return (y, x) if fork else y
 
     def _conv_fork(self, x, name, stride=1, pad=1):
         """-> (conv(x), x'): x has a second reader (a skip connection), which must read x' (ops.conv2d_fork)."""
@@ -125,7 +127,8 @@ class Generator(ParamTree):
         return self._in(self._conv(h, name + '.main.3', to_norm=True), name + '.main.4', residual=x)
 
     def _spade_resblock(self, x, seg, name):                               # generator.py:63-71
-        dx = self._conv(self._spade(x, seg, name + '.norm_0', ACT_RELU), name + '.conv_0', to_norm=True)
+        h, x = self._spade(x, seg, name + '.norm_0', ACT_RELU, fork=True)      # (the skip below reads x through the norm's fork)
+        dx = self._conv(h, name + '.conv_0', to_norm=True)
         dx = self._conv(self._spade(dx, seg, name + '.norm_1', ACT_RELU), name + '.conv_1')
         return ops.add(x, dx)
 
@@ -223,14 +226,20 @@ class Generator(ParamTree):
             self._seg_cache[key] = ops.resize_bilinear_ac(T, h, h)         # resize_trans: size=(h, h)
         return self._seg_cache[key]
 
+    # The source features of a level have up to four readers (the next src level, the skip, the attention's source convolution
+    # and its weighted average) and the target features two (the attention and the sum that follows it).  Each reader but the
+    # last hands the tensor on as a pass-through output (ops.conv2d_fork), so autograd sees a CHAIN of single consumers and every
+    # backward kernel adds the gradient that arrived behind it -- no gradient sums by the autograd engine.
     def _attn_source(self, x, layer):
-        """The source half of layer `layer`'s attention (ops.attn_source_conv), or None where the layer warps by grid_sample:
-        evaluated by the caller on src_model's stream, right after the source features exist."""
+        """-> (Gs, x'): the source half of layer `layer`'s attention (ops.attn_source_conv; None where the layer warps by
+        grid_sample), evaluated by the caller on src_model's stream right after the source features exist, and the source
+        features for their later readers."""
         if layer not in self.cfg.attn_layers:
-            return None
-        return ops.attn_source_conv(x, self.P['attn_%d.fully_connect_layer.0.weight#s' % layer])
+            return None, x
+        return ops.attn_source_conv(x, self.P['attn_%d.fully_connect_layer.0.weight#s' % layer], fork=True)
 
     def _transform(self, x, T, layer, y=None, gs=None):
+        """-> (x warped to the target frame, x', y'): x', y' are x and y for their later readers."""
         h = x.shape[1]
         ts = self._tscale(T, h)
         if layer in self.cfg.attn_layers:
@@ -239,8 +248,8 @@ class Generator(ParamTree):
                 self._seg_cache[key] = ops.attn_flow(ts)
             p = 'attn_%d.fully_connect_layer' % layer
             return ops.local_attention(x, y, self._seg_cache[key], self.P[p + '.0.weight#t'], self.P[p + '.0.weight#s'],
-                                       self.P[p + '.0.bias'], self.P[p + '.2.weight'], self.P[p + '.2.bias'], gs=gs)
-        return ops.grid_sample(x, ts)
+                                       self.P[p + '.0.bias'], self.P[p + '.2.weight'], self.P[p + '.2.bias'], gs=gs, fork=True)
+        return ops.grid_sample(x, ts), x, y
 
     # ---- public forward: reference signature (generator.py:347-376), NCHW in / NCHW-shaped out ---
     def forward(self, bg_inputs, src_obj_inputs, tsf_obj_inputs, src_hand_inputs, tsf_hand_inputs, T,
@@ -326,18 +335,20 @@ class Generator(ParamTree):
         for i in range(1, c.n_down + 1):
             with on_src():
                 sx, s_enc[-1] = self._enc_level(sx, src_hand_c, 'src_model', i)
-                gs = self._attn_source(sx, i)               # (the attention's source convolution rides on the src stream too)
+                gs, sx = self._attn_source(sx, i)           # (the attention's source convolution rides on the src stream too)
             tx, t_enc[-1] = self._enc_level(tx, tsf_hand_c, 'tsf_model', i)
-            tx = ops.add(tx, self._transform(src_ready(sx), T, i, y=tx, gs=None if gs is None else src_ready(gs)))
+            warped, sx, tx = self._transform(src_ready(sx), T, i, y=tx, gs=None if gs is None else src_ready(gs))
+            tx = ops.add(tx, warped)
             s_enc.append(sx)
             t_enc.append(tx)
             advance()
         for i in range(c.repeat_num):
             with on_src():
                 sx = self._resnet(sx, src_hand_c, 'src_model', i)
-                gs = self._attn_source(sx, i + c.n_down + 1)
+                gs, sx = self._attn_source(sx, i + c.n_down + 1)
             tx = self._resnet(tx, tsf_hand_c, 'tsf_model', i)
-            tx = ops.add(tx, self._transform(src_ready(sx), T, i + c.n_down + 1, y=tx, gs=None if gs is None else src_ready(gs)))
+            warped, sx, tx = self._transform(src_ready(sx), T, i + c.n_down + 1, y=tx, gs=None if gs is None else src_ready(gs))
+            tx = ops.add(tx, warped)
             advance()
         advance(True)                                        # (their decoders: issued before the join below)
         if fork:

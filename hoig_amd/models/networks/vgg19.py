@@ -42,15 +42,23 @@ class Vgg19(ParamTree):
     def forward_nhwc(self, x):
         outs, idx, sl = [], 0, 1
         for v in VGG_LAYERS:
-            if idx >= VGG_SLICE_ENDS[sl - 1]:
-                outs.append(x)
+            tap = idx >= VGG_SLICE_ENDS[sl - 1]           # x is a slice output (relu{k}_1): the loss reads it AND the next layer
+            if tap:
                 sl += 1
             if v == 'M':
+                if tap:
+                    outs.append(x)
                 x = ops.maxpool2(x)
                 idx += 1
             else:
                 p = 'slice%d.%d' % (sl, idx)
-                x = ops.conv2d(x, self.P[p + '.weight'], self.P[p + '.bias'], 1, 1, ACT_RELU)
+                if tap:
+                    # (the loss reads the feature through the convolution's pass-through output: its gradient is then added by the
+                    # convolution's data-gradient kernel, ops.conv2d_fork, instead of by the autograd engine)
+                    x, feat = ops.conv2d_fork(x, self.P[p + '.weight'], self.P[p + '.bias'], 1, 1, ACT_RELU)
+                    outs.append(feat)
+                else:
+                    x = ops.conv2d(x, self.P[p + '.weight'], self.P[p + '.bias'], 1, 1, ACT_RELU)
                 idx += 2
         outs.append(x)
         return outs
@@ -72,8 +80,9 @@ class VGGLoss(object):
     def cuda(self, *a, **k):
         return self
 
-    def forward_nhwc(self, x, y, scale=1.0, side=None):
-        """`side`: a stream on which the (gradient-free) features of the target `y` are evaluated beside those of `x`."""
+    def forward_nhwc(self, x, y, scale=1.0, side=None, into=None):
+        """`side`: a stream on which the (gradient-free) features of the target `y` are evaluated beside those of `x`.
+        `into` = ops.LossSlots.term(name): the five levels are added to that slot; returns their handles (for LossSlots.total)."""
         if side is not None and x.is_cuda:
             main = torch.cuda.current_stream()
             side.wait_stream(main)
@@ -87,6 +96,8 @@ class VGGLoss(object):
             fx = self.vgg.forward_nhwc(x)
             with torch.no_grad():
                 fy = self.vgg.forward_nhwc(y)
+        if into is not None:
+            return [ops.l1_loss(a, b, scale=w * scale, into=into) for w, a, b in zip(self.weights, fx, fy)]
         loss = 0
         for w, a, b in zip(self.weights, fx, fy):
             loss = loss + ops.l1_loss(a, b, scale=w * scale)

@@ -32,6 +32,7 @@ from .networks.vgg19 import Vgg19, VGGLoss
 # Off by default: on this ROCm the replay costs the host 4 ms instead of 28 ms per step, but the graph's internal stream mapping
 # overlaps the chains less than the eager streams do -- 80.2 / 81.7 ms per replayed step against 74.8 / 79.5 ms eager, two boxes
 #  -- and the step is GPU-bound either way.
+_LOSS_SLOTS = os.environ.get('HOIG_LOSS_SLOTS', '1') == '1'      # A/B switch: 0 = the objectives composed with torch scalar arithmetic
 _GRAPH = os.environ.get('HOIG_GRAPH', '0') == '1'
 _GRAPH_WARMUP = 2         # eager steps per input signature before the capture (lazily made buffers and planes then exist)
 _GRAPH_MAX_SIGNATURES = 3
@@ -181,6 +182,9 @@ class Trainer(BaseModel):
                   '(opt.vgg_surrogate=True)', file=sys.stderr)
         if self._opt.use_vgg:
             self._crt_tsf = VGGLoss(vgg=vgg_net)
+        # the terms of the two objectives live in device slots that the loss kernels add into (ops.LossSlots)
+        self._g_terms = ops.LossSlots(['g_adv', 'g_rec', 'g_tsf', 'g_mask', 'g_mask_smooth'], self.device) if _LOSS_SLOTS else None
+        self._d_terms = ops.LossSlots(['d'], self.device, extra=['d_real', 'd_fake']) if _LOSS_SLOTS else None
         z = lambda: torch.zeros((), device=self.device)
         self._loss_g_rec, self._loss_g_tsf, self._loss_g_adv = z(), z(), z()
         self._loss_g_smooth, self._loss_g_mask, self._loss_g_mask_smooth = z(), z(), z()
@@ -515,6 +519,10 @@ class Trainer(BaseModel):
         # three chains on three streams, like the generator's sub-networks (their backward replays there too); HOIG_LOSS_STREAMS=0:
         # one after the other on the caller's stream.
         fork = fake_tsf.is_cuda and generator_forks_streams()
+        T = self._g_terms
+        into = (lambda name: T.term(name)) if T is not None else (lambda name: None)
+        if T is not None:
+            T.begin()                      # (on the caller's stream, before the loss streams fork from it)
         if fork:
             main = torch.cuda.current_stream()
             # operand planes are (re)made lazily by whoever asks first: make D's and VGG's here, on the caller's stream, so that
@@ -528,23 +536,34 @@ class Trainer(BaseModel):
             with torch.cuda.stream(s_adv):
                 self._wait_d()
                 d_fake = self._D.forward_nhwc(ops.cat_channels([fake_tsf, n['tsf_cond']]))
-                self._loss_g_adv = ops.lsgan_loss(d_fake, 0.0, o.lambda_D_prob)
+                self._loss_g_adv = ops.lsgan_loss(d_fake, 0.0, o.lambda_D_prob, into=into('g_adv'))
             ops.cross_stream(fake_tsf, s_adv)
         else:
             s_vgg = None
             self._wait_d()
             d_fake = self._D.forward_nhwc(ops.cat_channels([fake_tsf, n['tsf_cond']]))
-            self._loss_g_adv = ops.lsgan_loss(d_fake, 0.0, o.lambda_D_prob)
-        self._loss_g_rec = ops.l1_loss(fake_src, n['real_src'], o.lambda_rec)
+            self._loss_g_adv = ops.lsgan_loss(d_fake, 0.0, o.lambda_D_prob, into=into('g_adv'))
+        self._loss_g_rec = ops.l1_loss(fake_src, n['real_src'], o.lambda_rec, into=into('g_rec'))
         # the reference uses self._crt_tsf in both branches of `if use_vgg` (:443-446); it only exists with --use_vgg
-        self._loss_g_tsf = self._crt_tsf.forward_nhwc(fake_tsf, n['real_tsf'], o.lambda_tsf, side=s_vgg)
+        tsf = self._crt_tsf.forward_nhwc(fake_tsf, n['real_tsf'], o.lambda_tsf, side=s_vgg, into=into('g_tsf'))
         if fork:
             main.wait_stream(s_adv)
-            ops.cross_stream(self._loss_g_adv, main)
+            if T is None:
+                ops.cross_stream(self._loss_g_adv, main)
         crt = ops.bce_loss if o.mask_bce else ops.mse_loss
-        self._loss_g_mask = crt(mbg, n['bg_mask'], o.lambda_mask) + crt(mh, n['hand_mask'], o.lambda_mask)
+        masks = [crt(mbg, n['bg_mask'], o.lambda_mask, into=into('g_mask')), crt(mh, n['hand_mask'], o.lambda_mask, into=into('g_mask'))]
+        smooth = []
         if o.lambda_mask_smooth != 0:
-            self._loss_g_mask_smooth = ops.tv_loss(mbg, o.lambda_mask_smooth) + ops.tv_loss(mh, o.lambda_mask_smooth)
+            smooth = [ops.tv_loss(mbg, o.lambda_mask_smooth, into=into('g_mask_smooth')),
+                      ops.tv_loss(mh, o.lambda_mask_smooth, into=into('g_mask_smooth'))]
+        if T is not None:
+            # every term already sits, scaled, in its slot: one launch sums them; the reported values are views of the slots
+            self._loss_g_tsf, self._loss_g_mask = T.value('g_tsf'), T.value('g_mask')
+            self._loss_g_mask_smooth = T.value('g_mask_smooth')
+            return T.total(self._loss_g_adv, self._loss_g_rec, *(tsf + masks + smooth))
+        self._loss_g_tsf, self._loss_g_mask = tsf, masks[0] + masks[1]
+        if smooth:
+            self._loss_g_mask_smooth = smooth[0] + smooth[1]
         return self._loss_g_adv + self._loss_g_rec + self._loss_g_tsf + self._loss_g_mask + self._loss_g_mask_smooth
 
     def _optimize_D(self, fake_tsf_imgs):
@@ -556,6 +575,15 @@ class Trainer(BaseModel):
         self._wait_d()
         d_both = self._D.forward_nhwc(torch.cat([n['d_real_in'], ops.cat_channels([fake_tsf, n['tsf_cond']])], dim=0))
         d_real, d_fake = d_both[:nb], d_both[nb:]
+        T = self._d_terms
+        if T is not None:
+            T.begin()
+            loss_real = ops.lsgan_loss(d_real, 1.0, o.lambda_D_prob, into=T.term('d'))
+            loss_fake = ops.lsgan_loss(d_fake, -1.0, o.lambda_D_prob, into=T.term('d'))
+            with torch.no_grad():
+                self._d_real = ops.mean(d_real, into=T.term('d_real'))
+                self._d_fake = ops.mean(d_fake, into=T.term('d_fake'))
+            return T.total(loss_real, loss_fake)
         loss_real = ops.lsgan_loss(d_real, 1.0, o.lambda_D_prob)
         loss_fake = ops.lsgan_loss(d_fake, -1.0, o.lambda_D_prob)
         with torch.no_grad():

@@ -642,7 +642,7 @@ class _SpadeFused(Function):
     gamma|beta convolution); the backward writes dgamma | dbeta straight into the matching [.,2C] gradient."""
 
     @staticmethod
-    def forward(ctx, x, gb, act, slope, eps):
+    def forward(ctx, x, gb, act, slope, eps, fork=False):
         _chk(x); _chk(gb)
         assert x.is_contiguous() and gb.is_contiguous()
         B, H, W, C = x.shape
@@ -662,28 +662,38 @@ class _SpadeFused(Function):
             L.check(rc, 'hoig_inorm_fwd_fused')
         ctx.cfg = (act, slope, B, HW, C)
         ctx.save_for_backward(x, mean, rstd, gb, y if act != L.ACT_NONE else None)
+        if fork:                              # (y, x): see _Conv.forward
+            ctx.set_materialize_grads(False)
+            return y, x
         return y
 
     @staticmethod
-    def backward(ctx, dy):
+    def backward(ctx, dy, dxr=None):
         x, mean, rstd, gb, y = ctx.saved_tensors
         act, slope, B, HW, C = ctx.cfg
+        if dy is None:
+            return dxr, None, None, None, None, None
         dy = dy.contiguous()
+        add = dxr.contiguous() if dxr is not None else None
         dx = torch.empty_like(x)
         dgb = torch.empty_like(gb)
-        rc = L.lib.hoig_inorm_bwd_fused(_p(x), _p(mean), _p(rstd), 2, _p(gb), None, 2 * C, _p(y), _p(dy), act, slope, _p(dx),
-                                        _p(dgb), dgb.data_ptr() + 4 * C, B, HW, C, _st())
+        rc = L.lib.hoig_inorm_bwd_fused_add(_p(x), _p(mean), _p(rstd), 2, _p(gb), None, 2 * C, _p(y), _p(dy), act, slope, _p(add),
+                                            _p(dx), _p(dgb), dgb.data_ptr() + 4 * C, B, HW, C, _st())
         if rc == L.EUNSUPPORTED:
             ws = _norm_workspace(L.lib.hoig_inorm_workspace_bytes(B, HW, C) // 4, x.device)
-            call('hoig_inorm_bwd_ld', _p(x), _p(mean), _p(rstd), 2, _p(gb), None, 2 * C, _p(y), _p(dy), act, slope, _p(dx),
-                 _p(dgb), dgb.data_ptr() + 4 * C, B, HW, C, _p(ws), _st())
+            call('hoig_inorm_bwd_add_ld', _p(x), _p(mean), _p(rstd), 2, _p(gb), None, 2 * C, _p(y), _p(dy), act, slope, _p(add),
+                 _p(dx), _p(dgb), dgb.data_ptr() + 4 * C, B, HW, C, _p(ws), _st())
         else:
-            L.check(rc, 'hoig_inorm_bwd_fused')
-        return dx, dgb, None, None, None
+            L.check(rc, 'hoig_inorm_bwd_fused_add')
+        return dx, dgb, None, None, None, None
 
 
-def spade_norm_fused(x, gb, act=L.ACT_NONE, slope=0.0, eps=1e-5):
-    return _SpadeFused.apply(x, gb, act, slope, eps)
+def spade_norm_fused(x, gb, act=L.ACT_NONE, slope=0.0, eps=1e-5, fork=False):
+    """fork=True -> (y, x') for an x with a second consumer, which must read x' (see conv2d_fork): its gradient is then added by
+    the norm's backward kernel."""
+    if fork and not (_FORK and x.requires_grad):
+        return _SpadeFused.apply(x, gb, act, slope, eps), x
+    return _SpadeFused.apply(x, gb, act, slope, eps, fork)
 
 
 # ------------------------------------------------------------------------------------------------- small ops
@@ -1012,7 +1022,7 @@ class _AttnSourceConv(Function):
     stream of src_model, ahead of the tsf chain that consumes it."""
 
     @staticmethod
-    def forward(ctx, source, ws, prec):
+    def forward(ctx, source, ws, prec, fork=False):
         _chk(source)
         _chk(ws)
         B, H, W, C = source.shape
@@ -1025,13 +1035,18 @@ class _AttnSourceConv(Function):
         ctx.save_for_backward(ws, spad)
         ctx.descs = _bwd_descs(d_s)
         ctx.shape = (B, H, W, C)
+        if fork:                              # (gs, source): see _Conv.forward
+            ctx.set_materialize_grads(False)
+            return gs, source
         return gs
 
     @staticmethod
-    def backward(ctx, dgs):
+    def backward(ctx, dgs, dsrc_r=None):
         ws, spad = ctx.saved_tensors
         ds_dg, ds_wg = ctx.descs
         B, H, W, C = ctx.shape
+        if dgs is None:
+            return dsrc_r, None, None, None
         dgs = dgs.contiguous()
         gw, ret_w = _grad_target(ws)
         side = _wgrad_side_stream(dgs.device) if not ret_w else None
@@ -1047,8 +1062,9 @@ class _AttnSourceConv(Function):
             dspad = torch.empty_like(spad)
             _conv_dgrad_raw(ds_dg, dgs, ws, dspad)
             dsrc = torch.empty((B, H, W, C), dtype=dgs.dtype, device=dgs.device)
-            call('hoig_replicate_pad_bwd', _p(dspad), _p(dsrc), B, H, W, C, 4, _st())            # (writes every element)
-        return dsrc, (gw if ret_w else None), None
+            call('hoig_replicate_pad_bwd_add', _p(dspad), _p(dsrc_r.contiguous() if dsrc_r is not None else None), _p(dsrc),
+                 B, H, W, C, 4, _st())                                                           # (writes every element)
+        return dsrc, (gw if ret_w else None), None, None
 
 
 class _LocalAttn(Function):
@@ -1059,7 +1075,7 @@ class _LocalAttn(Function):
     (128,2C,5,5) weight (hoig_amd.nn.split_attn_weight)."""
 
     @staticmethod
-    def forward(ctx, source, target, flow, gs, wt, b1, w2, b2, prec):
+    def forward(ctx, source, target, flow, gs, wt, b1, w2, b2, prec, fork=False):
         for t in (source, target, flow, gs, wt, b1, w2, b2):
             _chk(t)
         B, H, W, C = source.shape
@@ -1086,13 +1102,21 @@ class _LocalAttn(Function):
         ctx.save_for_backward(source, flow, wt, b1, w2, b2, tpad, hidden, attn, kf)
         ctx.descs = _bwd_descs(d_t)
         ctx.shape = (B, H, W, C)
+        if fork:
+            # (out, source, target): both feature maps have further readers (the next layer of their chain; the sum
+            # `target + out`), which read these pass-through outputs so that their gradients come back through this node and
+            # are added by its own kernels (see _Conv.forward)
+            ctx.set_materialize_grads(False)
+            return out, source, target
         return out
 
     @staticmethod
-    def backward(ctx, dout):
+    def backward(ctx, dout, dsrc_r=None, dtgt_r=None):
         source, flow, wt, b1, w2, b2, tpad, hidden, attn, kf = ctx.saved_tensors
         dt_dg, dt_wg = ctx.descs
         B, H, W, C = ctx.shape
+        if dout is None:
+            return (dsrc_r, dtgt_r) + (None,) * 8
         dout = dout.contiguous()
         gs = [_grad_target(p) for p in (wt, b1, w2, b2)]
         dhid = torch.empty_like(hidden)                       # = dGt
@@ -1117,12 +1141,14 @@ class _LocalAttn(Function):
             dtpad = torch.empty_like(tpad)
             _conv_dgrad_raw(dt_dg, dhid, wt, dtpad)
             dtgt = torch.empty((B, H, W, C), dtype=dout.dtype, device=dout.device)
-            call('hoig_replicate_pad_bwd', _p(dtpad), _p(dtgt), B, H, W, C, 2, _st())
+            call('hoig_replicate_pad_bwd_add', _p(dtpad), _p(dtgt_r.contiguous() if dtgt_r is not None else None), _p(dtgt),
+                 B, H, W, C, 2, _st())
         if ctx.needs_input_grad[0]:                           # the weighted average's part (Gs's part comes from _AttnSourceConv)
-            dsrc = torch.zeros((B, H, W, C), dtype=dout.dtype, device=dout.device)
-            call('hoig_attn_src_gather', _p(index), _p(kf), _p(dout), _p(dsrc), B, H, W, C, _st())
+            dsrc = torch.empty((B, H, W, C), dtype=dout.dtype, device=dout.device)
+            call('hoig_attn_src_gather', _p(index), _p(kf), _p(dout), _p(dsrc_r.contiguous() if dsrc_r is not None else None),
+                 _p(dsrc), B, H, W, C, _st())
         rets = [g if r else None for g, r in gs]
-        return dsrc, dtgt, None, dgs, rets[0], rets[1], rets[2], rets[3], None
+        return dsrc, dtgt, None, dgs, rets[0], rets[1], rets[2], rets[3], None, None
 
 
 _ATTN_PREC = os.environ.get('HOIG_ATTN_PREC')          # experiment switch: arithmetic of the attention's two 5x5 convolutions
@@ -1134,17 +1160,23 @@ def _attn_prec(prec):
     return prec
 
 
-def attn_source_conv(source, ws, prec=None):
-    """Gs of local_attention(): the part that depends on the source features and the source half of the weight only."""
-    return _AttnSourceConv.apply(source, ws, _attn_prec(prec))
+def attn_source_conv(source, ws, prec=None, fork=False):
+    """Gs of local_attention(): the part that depends on the source features and the source half of the weight only.
+    fork=True -> (Gs, source'): later readers of `source` must read source' (see conv2d_fork)."""
+    if fork and not (_FORK and source.requires_grad):
+        return _AttnSourceConv.apply(source, ws, _attn_prec(prec)), source
+    return _AttnSourceConv.apply(source, ws, _attn_prec(prec), fork)
 
 
-def local_attention(source, target, flow, wt, ws, b1, w2, b2, prec=None, gs=None):
-    """`gs`: attn_source_conv(source, ws) if the caller has evaluated it already (on another stream)."""
+def local_attention(source, target, flow, wt, ws, b1, w2, b2, prec=None, gs=None, fork=False):
+    """`gs`: attn_source_conv(source, ws) if the caller has evaluated it already (on another stream).
+    fork=True -> (out, source', target'): later readers of the two feature maps must read those (see conv2d_fork)."""
     prec = _attn_prec(prec)
     if gs is None:
         gs = _AttnSourceConv.apply(source, ws, prec)
-    return _LocalAttn.apply(source, target, flow.contiguous(), gs, wt, b1, w2, b2, prec)
+    if fork and not (_FORK and source.requires_grad and target.requires_grad):
+        return _LocalAttn.apply(source, target, flow.contiguous(), gs, wt, b1, w2, b2, prec), source, target
+    return _LocalAttn.apply(source, target, flow.contiguous(), gs, wt, b1, w2, b2, prec, fork)
 
 
 # stand-alone equivalents of the reference's two extension modules (NCHW, caller-visible semantics of
@@ -1230,72 +1262,139 @@ def compose(bg, obj, hand, mbg, mh):
     return _Compose.apply(bg, obj, hand, mbg, mh)
 
 
-class _MeanLoss(Function):
-    """scale * mean(loss(pred, target)); the kernel produces the sum and the pre-scaled gradient in one pass."""
+class LossSlots(object):
+    """The scalar terms of ONE objective (trainer.py:448-457: loss_G = g_adv + g_rec + g_tsf + g_mask + g_mask_smooth) as fp32
+    slots of one small device buffer.  The loss kernels add their scaled value straight into a slot (`into=slots.term(name)`;
+    several calls may share a slot: the five VGG levels of g_tsf), `total()` sums the slots in one launch, and differentiating the
+    total hands every term the constant 1 -- the host composes the objective without the per-term scalar multiplies, adds, fills
+    and gradient scalings torch would launch (42 of them per step).  `extra` names report-only slots (means) outside the total.
+    Usage per step: begin() -> the loss calls -> total(*handles).backward(); value(name) reads a slot (0-dim view, no launch)."""
+
+    def __init__(self, names, device, extra=()):
+        self.names = list(names)
+        self.extra = list(extra)
+        self.buf = torch.zeros(len(self.names) + 1 + len(self.extra), dtype=torch.float32, device=device)
+        self.one = torch.ones((), dtype=torch.float32, device=device)
+
+    def begin(self):
+        self.buf.zero_()
+
+    def _index(self, name):
+        return self.names.index(name) if name in self.names else len(self.names) + 1 + self.extra.index(name)
+
+    def term(self, name):
+        return (self, self._index(name))
+
+    def value(self, name):
+        return self.buf[self._index(name)]
+
+    def total(self, *handles):
+        return _LossRoot.apply(self, *handles)
+
+
+class _LossRoot(Function):
+    """Sum of a LossSlots' objective slots.  Its backward hands each term the constant 1 whatever gradient arrives: the terms
+    (`into=` losses) store their gradient pre-scaled and ignore it anyway -- the total is meant to be differentiated as it is."""
 
     @staticmethod
-    def forward(ctx, pred, target, kind, tconst, scale):
+    def forward(ctx, slots, *handles):
+        k = len(slots.names)
+        call('hoig_sum', _p(slots.buf), slots.buf.data_ptr() + 4 * k, k, _st())
+        ctx.one, ctx.n = slots.one, len(handles)
+        return slots.buf[k]
+
+    @staticmethod
+    def backward(ctx, g):
+        return (None,) + (ctx.one,) * ctx.n
+
+
+class _MeanLoss(Function):
+    """scale * mean(loss(pred, target)); the kernel produces the sum and the pre-scaled gradient in one pass.
+    `into` = LossSlots.term(name): the value is a term of that objective (see LossSlots)."""
+
+    @staticmethod
+    def forward(ctx, pred, target, kind, tconst, scale, into=None):
         _chk(pred); _chk(target)
         pred = pred.contiguous()
         n = pred.numel()
-        out = torch.zeros(1, dtype=torch.float32, device=pred.device)
         need = pred.requires_grad
         dpred = torch.empty_like(pred) if need else None
-        call('hoig_loss_fwd_bwd', kind, _p(pred), _p(target), tconst, scale / n, _p(out), _p(dpred), n, _st())
         ctx.save_for_backward(dpred)
+        ctx.term = into is not None
+        if into is not None:
+            slots, k = into
+            call('hoig_loss_accumulate', kind, _p(pred), _p(target), tconst, scale / n, slots.buf.data_ptr() + 4 * k, _p(dpred), n,
+                 _st())
+            return slots.buf[k]
+        out = torch.zeros(1, dtype=torch.float32, device=pred.device)
+        call('hoig_loss_fwd_bwd', kind, _p(pred), _p(target), tconst, scale / n, _p(out), _p(dpred), n, _st())
         return out[0] * (scale / n)
 
     @staticmethod
     def backward(ctx, g):
         dpred, = ctx.saved_tensors
-        return (dpred * g if dpred is not None else None), None, None, None, None
+        if ctx.term:
+            return dpred, None, None, None, None, None
+        return (dpred * g if dpred is not None else None), None, None, None, None, None
 
 
-def l1_loss(pred, target, scale=1.0):
-    return _MeanLoss.apply(pred, target.contiguous(), L.LOSS_L1, 0.0, scale)
+def l1_loss(pred, target, scale=1.0, into=None):
+    return _MeanLoss.apply(pred, target.contiguous(), L.LOSS_L1, 0.0, scale, into)
 
 
-def mse_loss(pred, target, scale=1.0):
-    return _MeanLoss.apply(pred, target.contiguous(), L.LOSS_MSE, 0.0, scale)
+def mse_loss(pred, target, scale=1.0, into=None):
+    return _MeanLoss.apply(pred, target.contiguous(), L.LOSS_MSE, 0.0, scale, into)
 
 
-def bce_loss(pred, target, scale=1.0):
-    return _MeanLoss.apply(pred, target.contiguous(), L.LOSS_BCE, 0.0, scale)
+def bce_loss(pred, target, scale=1.0, into=None):
+    return _MeanLoss.apply(pred, target.contiguous(), L.LOSS_BCE, 0.0, scale, into)
 
 
-def lsgan_loss(pred, target_value, scale=1.0):
+def lsgan_loss(pred, target_value, scale=1.0, into=None):
     """mean((x - y)^2) * scale with a constant target (trainer.py:476-477)."""
-    return _MeanLoss.apply(pred, None, L.LOSS_MSE, float(target_value), scale)
+    return _MeanLoss.apply(pred, None, L.LOSS_MSE, float(target_value), scale, into)
 
 
 class _TV(Function):
     """Trainer._compute_loss_smooth (trainer.py:479-481) on a single-channel NHWC map."""
 
     @staticmethod
-    def forward(ctx, m, scale):
+    def forward(ctx, m, scale, into=None):
         _chk(m)
         m = m.contiguous()
         B, H, W, C = m.shape
         assert C == 1
-        out = torch.zeros(2, dtype=torch.float32, device=m.device)
         nx, ny = B * H * (W - 1), B * (H - 1) * W
         need = m.requires_grad
         dm = torch.empty_like(m) if need else None
-        call('hoig_tv_fwd_bwd', _p(m), scale / nx, scale / ny, _p(out), _p(dm), B, H, W, _st())
         ctx.save_for_backward(dm)
+        ctx.term = into is not None
+        if into is not None:                  # a term of an objective: see LossSlots
+            slots, k = into
+            call('hoig_tv_accumulate', _p(m), scale / nx, scale / ny, slots.buf.data_ptr() + 4 * k, _p(dm), B, H, W, _st())
+            return slots.buf[k]
+        out = torch.zeros(2, dtype=torch.float32, device=m.device)
+        call('hoig_tv_fwd_bwd', _p(m), scale / nx, scale / ny, _p(out), _p(dm), B, H, W, _st())
         return out[0] * (scale / nx) + out[1] * (scale / ny)
 
     @staticmethod
     def backward(ctx, g):
         dm, = ctx.saved_tensors
-        return (dm * g if dm is not None else None), None
+        if ctx.term:
+            return dm, None, None
+        return (dm * g if dm is not None else None), None, None
 
 
-def tv_loss(m, scale=1.0):
-    return _TV.apply(m, scale)
+def tv_loss(m, scale=1.0, into=None):
+    return _TV.apply(m, scale, into)
 
 
-def mean(x):
+def mean(x, into=None):
+    """into = LossSlots.term(name) of a report-only slot: the mean is added there (no result tensor)."""
+    if into is not None:
+        slots, k = into
+        call('hoig_sum_scaled', _p(x.contiguous()), 1.0 / x.numel(), slots.buf.data_ptr() + 4 * k, x.numel(), _st())
+        return slots.buf[k]
     out = torch.zeros(1, dtype=torch.float32, device=x.device)
     call('hoig_sum', _p(x.contiguous()), _p(out), x.numel(), _st())
     return out[0] / x.numel()

@@ -175,6 +175,14 @@ int hoig_inorm_fwd_fused(const float *x, int mode, const float *p0, const float 
 int hoig_inorm_bwd_fused(const float *x, const float *mean, const float *rstd, int mode, const float *p0, const float *p1,
                          int ld_p, const float *y /*nullable, see hoig_inorm_bwd_ld*/, const float *dy, int act, float slope,
                          float *dx, float *dp0, float *dp1, int B, int HW, int C, hoig_stream_t stream);
+/* ... + addend (nullable; same shape as x): dx = norm backward + addend.  The SPADE residual block reads its input twice -- the
+ * first norm and the skip `x + dx` (generator.py:63-71) -- and the skip's gradient is added here instead of by a pass of its own. */
+int hoig_inorm_bwd_add_ld(const float *x, const float *mean, const float *rstd, int mode, const float *p0, const float *p1,
+                          int ld_p, const float *y, const float *dy, int act, float slope, const float *addend, float *dx,
+                          float *dp0, float *dp1, int B, int HW, int C, void *workspace, hoig_stream_t stream);
+int hoig_inorm_bwd_fused_add(const float *x, const float *mean, const float *rstd, int mode, const float *p0, const float *p1,
+                             int ld_p, const float *y, const float *dy, int act, float slope, const float *addend, float *dx,
+                             float *dp0, float *dp1, int B, int HW, int C, hoig_stream_t stream);
 
 /* backward of hoig_inorm_apply(+stats).  dy is d/d(y) ; y is the forward output (for the activation mask; pass
  * the pre-residual activation output, or NULL when act==NONE).  For ReLU / LeakyReLU after a plain (mode 0) or affine
@@ -198,6 +206,10 @@ int hoig_inorm_bwd(const float *x, const float *mean, const float *rstd, int mod
 /* y[b, py, px] = x[b, clamp(py-pad), clamp(px-pad)]  ([B,H,W,C] -> [B,H+2pad,W+2pad,C]) and its adjoint */
 int hoig_replicate_pad_fwd(const float *x, float *y, int B, int H, int W, int C, int pad, hoig_stream_t stream);
 int hoig_replicate_pad_bwd(const float *dy, float *dx, int B, int H, int W, int C, int pad, hoig_stream_t stream);
+/* ... + addend (nullable, [B,H,W,C]): the gradient that reached x through another consumer (tx = tx + attention(.., target = tx),
+ * generator.py:391-392,413-414), added here instead of by a pass of its own */
+int hoig_replicate_pad_bwd_add(const float *dy, const float *addend, float *dx, int B, int H, int W, int C, int pad,
+                               hoig_stream_t stream);
 /* hidden[m] = gt[m] + bilinear(gs; m + flow(m))            gt: [B,H,W,128] (bias included), gs: [B,H+4,W+4,128] = Gs on the
  *                                                          grid [-2,H+1] x [-2,W+1], hidden: [M,128] pre-activation (out)
  * attn[m]   = softmax_25(w2 . leaky_0.01(hidden[m]) + b2)  w2: [25][128]
@@ -219,9 +231,10 @@ int hoig_attn_pixel_bwd(const float *hidden, const float *attn, const float *w2,
  * every attention layer of a resolution) and each output cell gathers from the buckets whose footprints reach it. */
 int64_t hoig_attn_index_ints(int B, int H, int W);
 int hoig_attn_build_index(const float *flow, int32_t *index, int B, int H, int W, hoig_stream_t stream);
-/* dsource[cell] += sum_m kf[m][cell's position in m's 6x6 footprint] * dout[m]   (the weighted average's source gradient) */
-int hoig_attn_src_gather(const int32_t *index, const float *kf, const float *dout, float *dsource, int B, int H, int W, int C,
-                         hoig_stream_t stream);
+/* dsource[cell] = init[cell] + sum_m kf[m][cell's position in m's 6x6 footprint] * dout[m]   (the weighted average's source
+ * gradient; every element written; init (nullable = zeros): the gradient the source receives from its other consumers) */
+int hoig_attn_src_gather(const int32_t *index, const float *kf, const float *dout, const float *init, float *dsource, int B,
+                         int H, int W, int C, hoig_stream_t stream);
 /* dgs = bilinear^T(dhidden)  (dgs: [B,H+4,W+4,128], every element written) */
 int hoig_attn_gs_gather(const int32_t *index, const float *flow, const float *dhidden, float *dgs, int B, int H, int W,
                         hoig_stream_t stream);
@@ -296,8 +309,17 @@ int hoig_loss_fwd_bwd(int kind, const float *pred, const float *target, float ta
 /* TV-L1 smoothness trainer.py:479-481 on [B,H,W] single-channel maps: out[0] += sum|dx|, out[1] += sum|dy| ;
  * dm (overwritten) = gx * d(sum|dx|) + gy * d(sum|dy|) */
 int hoig_tv_fwd_bwd(const float *m, float gx, float gy, float *out, float *dm, int B, int H, int W, hoig_stream_t stream);
+/* The same two as TERMS OF AN OBJECTIVE (trainer.py:448-457: loss_G = g_adv + g_rec + g_tsf + g_mask + g_mask_smooth): *term +=
+ * gscale * sum loss(pred, target)  resp.  gx * sum|dx| + gy * sum|dy|  -- the scaled value goes straight into a caller-owned
+ * fp32 slot (several calls may share one: the five VGG levels of g_tsf), so that the host composes the objective without
+ * per-term scalar launches. */
+int hoig_loss_accumulate(int kind, const float *pred, const float *target, float target_const, float gscale, float *term,
+                         float *dpred, int64_t n, hoig_stream_t stream);
+int hoig_tv_accumulate(const float *m, float gx, float gy, float *term, float *dm, int B, int H, int W, hoig_stream_t stream);
 /* out[0] += sum x */
 int hoig_sum(const float *x, float *out, int64_t n, hoig_stream_t stream);
+/* out[0] += scale * sum x   (a mean written straight into a report slot: d_real / d_fake, trainer.py:470-471) */
+int hoig_sum_scaled(const float *x, float scale, float *out, int64_t n, hoig_stream_t stream);
 
 /* ---- fused Adam over one flat parameter buffer (torch.optim.Adam defaults of trainer.py:275-278:
  *      no weight decay, no amsgrad): step is the 1-based step count after increment ---- */

@@ -141,10 +141,39 @@ def test_instance_norm(mode, B, C, H, W):
         assert rel_err(dg, r.grad) < 5 * TOL
 
 
+@pytest.mark.parametrize('fork', [False, True])
+@pytest.mark.parametrize('B,C,H,W', [(2, 64, 16, 16), (3, 128, 15, 15), (2, 64, 48, 32)])     # one-launch and streaming kernels
+def test_spade_norm_fused_and_its_fork(B, C, H, W, fork):
+    """IN(x) * (1 + gamma) + beta -> ReLU from the [.,2C] gamma|beta tensor (spade.py:36); with fork=True the norm's backward
+    also adds the gradient of x's second reader (the SPADE residual block's skip, generator.py:63-71)."""
+    ops = _ops()
+    from hoig_amd import _lib as L
+    g = torch.Generator().manual_seed(14)
+    x = torch.randn(B, C, H, W, generator=g) * 2 + 1
+    ga, be = torch.randn(B, C, H, W, generator=g), torch.randn(B, C, H, W, generator=g)
+    xr, gar, ber = (t.clone().requires_grad_(True) for t in (x, ga, be))
+    yr = F.relu(F.instance_norm(xr, eps=1e-5) * (1 + gar) + ber)
+    gy, gx = torch.randn(yr.shape, generator=g), torch.randn(x.shape, generator=g)
+    ((yr * gy).sum() + ((xr * gx).sum() if fork else 0)).backward()
+    xd = nhwc_cuda(x).requires_grad_(True)
+    gb = torch.cat([nhwc_cuda(ga), nhwc_cuda(be)], dim=3).contiguous().requires_grad_(True)
+    if fork:
+        y, x2 = ops.spade_norm_fused(xd, gb, act=L.ACT_RELU, fork=True)
+        ((y * nhwc_cuda(gy)).sum() + (x2 * nhwc_cuda(gx)).sum()).backward()
+    else:
+        y = ops.spade_norm_fused(xd, gb, act=L.ACT_RELU)
+        y.backward(nhwc_cuda(gy))
+    assert rel_err(nchw_cpu(y), yr) < TOL
+    assert rel_err(nchw_cpu(xd.grad), xr.grad) < 5 * TOL
+    assert rel_err(nchw_cpu(gb.grad[..., :C]), gar.grad) < 5 * TOL and rel_err(nchw_cpu(gb.grad[..., C:]), ber.grad) < 5 * TOL
+
+
+@pytest.mark.parametrize('fork', [False, True])
 @pytest.mark.parametrize('B,C,h', [(2, 128, 8), (1, 256, 6), (2, 512, 4), (1, 128, 32)])
-def test_local_attention_vs_oracle(B, C, h):
+def test_local_attention_vs_oracle(B, C, h, fork):
     """Fused attention (fc1 MFMA + pixel kernel) against the oracle's materialising restatement of
-    extract_attn.py:23-29, forward and all gradients."""
+    extract_attn.py:23-29, forward and all gradients.  fork=True: source and target have later readers, whose gradients come
+    back through the attention's pass-through outputs and are added by its backward kernels (generator.py:391-392)."""
     ops = _ops()
     from oracle import hogan_oracle as O
     g = torch.Generator().manual_seed(5)
@@ -160,7 +189,8 @@ def test_local_attention_vs_oracle(B, C, h):
     sr, tr = src.clone().requires_grad_(True), tgt.clone().requires_grad_(True)
     yr = O.extractor_attn(sr, tr, flow, ref, 'a')
     gy = torch.randn(yr.shape, generator=g)
-    yr.backward(gy)
+    es, et = torch.randn(src.shape, generator=g), torch.randn(tgt.shape, generator=g)
+    ((yr * gy).sum() + (((sr * es).sum() + (tr * et).sum()) if fork else 0)).backward()
 
     from hoig_amd.nn import split_attn_weight, merge_attn_weight
     sdv, tdv = nhwc_cuda(src).requires_grad_(True), nhwc_cuda(tgt).requires_grad_(True)
@@ -170,8 +200,14 @@ def test_local_attention_vs_oracle(B, C, h):
     b1 = sd['a.fully_connect_layer.0.bias'].cuda().requires_grad_(True)
     w2 = ops.pack_weight(sd['a.fully_connect_layer.2.weight'].cuda()).requires_grad_(True)
     b2 = sd['a.fully_connect_layer.2.bias'].cuda().requires_grad_(True)
-    y = ops.local_attention(sdv, tdv, flow.cuda(), wt, ws, b1, w2, b2)
-    y.backward(nhwc_cuda(gy))
+    if fork:
+        gsv, s1 = ops.attn_source_conv(sdv, ws, fork=True)
+        y, s2, t2 = ops.local_attention(s1, tdv, flow.cuda(), wt, ws, b1, w2, b2, gs=gsv, fork=True)
+        assert s2.data_ptr() == sdv.data_ptr() and t2.data_ptr() == tdv.data_ptr()
+        ((y * nhwc_cuda(gy)).sum() + (s2 * nhwc_cuda(es)).sum() + (t2 * nhwc_cuda(et)).sum()).backward()
+    else:
+        y = ops.local_attention(sdv, tdv, flow.cuda(), wt, ws, b1, w2, b2)
+        y.backward(nhwc_cuda(gy))
     assert rel_err(nchw_cpu(y), yr) < TOL
     assert rel_err(nchw_cpu(sdv.grad), sr.grad) < 5 * TOL
     assert rel_err(nchw_cpu(tdv.grad), tr.grad) < 5 * TOL
@@ -286,6 +322,40 @@ def test_pointwise_and_losses():
         a, b = torch.randn(3, c1, hw, hw, generator=g), torch.randn(3, c2, hw, hw, generator=g)
         c = ops.cat_channels([nhwc_cuda(a), nhwc_cuda(b)])
         assert torch.equal(nchw_cpu(c), torch.cat([a, b], 1)), (c1, c2, hw)
+
+
+def test_loss_slots_compose_an_objective_like_torch_scalars():
+    """ops.LossSlots: terms added into device slots by the loss kernels, one launch for the total, unit gradients -- against the
+    same objective composed from the stand-alone losses with torch scalar arithmetic (trainer.py:448-457)."""
+    ops = _ops()
+    g = torch.Generator().manual_seed(21)
+    a, b = torch.randn(2, 16, 16, 8, generator=g).cuda(), torch.randn(2, 16, 16, 8, generator=g).cuda()
+    m, t = torch.rand(2, 16, 16, 1, generator=g).cuda(), (torch.rand(2, 16, 16, 1, generator=g) > 0.5).float().cuda()
+    d = torch.randn(2, 6, 6, 1, generator=g).cuda()
+    res = []
+    for slots in (None, ops.LossSlots(['x', 'y', 'z', 'unused'], a.device, extra=['mean_d'])):
+        ar, mr, dr = (v.clone().requires_grad_(True) for v in (a, m, d))
+        into = (lambda n: slots.term(n)) if slots is not None else (lambda n: None)
+        if slots is not None:
+            slots.buf.fill_(7.0)           # begin() must clear whatever the previous step left
+            slots.begin()
+        terms = [ops.l1_loss(ar, b, 2.0, into=into('x')), ops.l1_loss(ar * 1.0, b, 0.5, into=into('x')),     # two terms, one slot
+                 ops.bce_loss(mr, t, 3.0, into=into('y')), ops.tv_loss(mr * 1.0, 0.7, into=into('y')),
+                 ops.lsgan_loss(dr, -1.0, 0.25, into=into('z'))]
+        with torch.no_grad():
+            mean_d = ops.mean(d, into=into('mean_d'))
+        total = slots.total(*terms) if slots is not None else sum(terms)
+        total.backward()
+        torch.cuda.synchronize()
+        vals = ([float(slots.value(n)) for n in ('x', 'y', 'z')] if slots is not None
+                else [float(terms[0] + terms[1]), float(terms[2] + terms[3]), float(terms[4])])
+        res.append((float(total), vals, float(mean_d), ar.grad.clone(), mr.grad.clone(), dr.grad.clone()))
+    (t0, v0, m0, *g0), (t1, v1, m1, *g1) = res
+    assert abs(t0 - t1) <= 1e-6 * abs(t0) and abs(m0 - m1) <= 1e-6 * abs(m0) + 1e-8
+    for x, y in zip(v0, v1):
+        assert abs(x - y) <= 1e-6 * abs(x)
+    for x, y in zip(g0, g1):
+        assert torch.equal(x, y)           # the same pre-scaled gradients; the unit factor is exact
 
 
 def test_fused_adam_matches_torch():
