@@ -385,6 +385,24 @@ int hoig_rasterize_fim_wim(const float *faces, int B, int F, int image_size, flo
 
 const char *hoig_version(void);
 
+/* ---- MANO hand layer: pose / shape parameters -> skinned hand vertices, the step in front of the rasteriser.
+ *      Replaces, for this path, smplx 0.1.28's MANO layer (HOIG_HOv3/models/networks/hmr.py:55,84-85: `mano_layer_right(global_orient,
+ *      hand_pose, betas, transl).vertices`, use_pca=False, flat_hand_mean=True) and manopth's ManoLayer (HOIG_DexYCB/models/networks/
+ *      hmr.py:55-60,85-86: 45 PCA coefficients + hand mean, `+ trans`, x 1000 / 1000): linear blend skinning (smplx.lbs.lbs) in ONE
+ *      launch, one workgroup per sample.
+ * model (device, fp32): v_template [V][3], shapedirs [V][3][10], posedirs [135][V*3] (smplx's buffer layout), lbs_weights [V][16],
+ *   parents [16] (int32, parents[0] ignored), j_template [16][3] = J_regressor . v_template and j_shapedirs [16][3][10] =
+ *   J_regressor . shapedirs (the joint regression is linear in betas: folded once on the host).
+ * pose: root [B][3] axis-angle; hand [B][45] axis-angle (hands_components == NULL) or [B][ncomps] PCA coefficients expanded with
+ *   hands_components [ncomps][45]; hands_mean [45] (nullable = flat hand) is added either way.  betas [B][10], transl [B][3] (nullable).
+ * out: verts rows 0..V-1 of a [B][ld_v][3] tensor (ld_v >= V: the caller's [hand | object] vertex buffer, hmr.py:89, is written
+ *   in place), joints [B][16][3] posed joints + transl (nullable). */
+int hoig_mano_lbs(const float *v_template, const float *shapedirs, const float *posedirs, const float *j_template,
+                  const float *j_shapedirs, const float *lbs_weights, const int32_t *parents, const float *hands_mean /*nullable*/,
+                  const float *hands_components /*nullable*/, int ncomps, int V, const float *root, const float *hand,
+                  const float *betas, const float *transl /*nullable*/, float *verts, int ld_v, float *joints /*nullable*/, int B,
+                  hoig_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif
