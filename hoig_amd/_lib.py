@@ -57,6 +57,9 @@ _SIGS = {
     'hoig_pack_conv_weights_bf16_all': [_vp, _vp, _i, _i64, _vp, _vp, _vp, _vp, _vp],
     'hoig_conv2d_fwd_packed': [ctypes.POINTER(ConvDesc), _vp, _vp, _vp, _vp, _vp, _vp],
     'hoig_conv2d_bwd_data_packed': [ctypes.POINTER(ConvDesc), _vp, _vp, _vp, _vp, _vp],
+    'hoig_conv2d_fwd_packed_stats': [ctypes.POINTER(ConvDesc), _vp, _vp, _vp, _vp, _vp, _vp, _vp],
+    'hoig_conv2d_cat_fwd_packed_stats': [ctypes.POINTER(ConvDesc), _vp, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp],
+    'hoig_inorm_stats_from_sums': [_i, _i, _i, _f, _vp, _vp, _vp, _vp],
     'hoig_conv2d_bwd_data_packed_add': [ctypes.POINTER(ConvDesc), _vp, _vp, _vp, _vp, _vp, _vp],
     'hoig_pack_conv_weight_f6': [_vp, _i, _i, _i, _vp, _vp, _vp],
     'hoig_conv2d_fwd_f6': [ctypes.POINTER(ConvDesc), _vp, _vp, _vp, _vp, _vp, _vp, _vp],

@@ -574,10 +574,46 @@ struct HaloArgs {
     int n1;
     const float *addend;       // same shape as C (single-output launches only): C = conv + addend -- the data gradient that lands in
                                // a tensor with a second consumer adds that consumer's gradient itself (ops.conv2d_fork)
+    float *stats;              // (nullable) [Bn][2][N] fp32 accumulators: += per-image, per-channel sum and sum of squares of the
+                               // values written to C -- the statistics of the instance norm that reads C next
 #ifdef HOIG_STAMP
     unsigned long long *dbg;   // diagnostic build only (tools/stamp_halo.py): per-wave cycle sums of the step phases
 #endif
 };
+
+// Instance-norm statistics from a convolution's epilogue.  s1 / s2: the lane's sums of v and v*v over the pixels it stored, per
+// 32-channel column group j (channel = n0 + wn * TN * 32 + j * 32 + (lane & 31)).  The two 32-lane halves hold different pixels of
+// the same channels (one cross-lane add), the WM waves with the same wn different image rows (LDS, which is dead after the main
+// loop), and the workgroup then issues ONE atomic per (channel, moment) into the image's accumulators -- as many per address as
+// the streaming statistics kernel it replaces issued (norm.hip: one per 16 pixel rows).
+template <int TN, int WM, int WN, int NT>
+__device__ __forceinline__ void halo_stats_epilogue(float (&s1)[TN], float (&s2)[TN], unsigned char *lds, float *stats_img, int N,
+                                                    int n0, int wm, int wn, int lane) {
+    const int l31 = lane & 31, lh = lane >> 5;
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+        s1[j] += __shfl_xor(s1[j], 32);
+        s2[j] += __shfl_xor(s2[j], 32);
+    }
+    __syncthreads();                                   // every wave has left the main loop's LDS tiles
+    float *red = reinterpret_cast<float *>(lds);       // [WM][WN][TN][2][32]
+    if (lh == 0) {
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+            red[(((wm * WN + wn) * TN + j) * 2 + 0) * 32 + l31] = s1[j];
+            red[(((wm * WN + wn) * TN + j) * 2 + 1) * 32 + l31] = s2[j];
+        }
+    }
+    __syncthreads();
+    for (int e = threadIdx.x; e < WN * TN * 64; e += NT) {
+        const int l = e & 31, m = (e >> 5) & 1, j = (e >> 6) % TN, w = (e >> 6) / TN;
+        float v = 0.f;
+#pragma unroll
+        for (int k = 0; k < WM; ++k) v += red[(((k * WN + w) * TN + j) * 2 + m) * 32 + l];
+        const int n = n0 + w * (TN * 32) + j * 32 + l;
+        if (n < N) atomicAdd(&stats_img[(size_t)m * N + n], v);
+    }
+}
 
 template <int KS, int NSX, int WN, int BN, bool F16>
 __global__ __launch_bounds__(128 * WN) void conv_halo_bf16_kernel(const HaloArgs p) {
@@ -1078,6 +1114,9 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_halo3_bf16_kernel(const Hal
         const int n = n0 + wn * (TN * 32) + j * 32 + l31;
         bias_r[j] = (p.bias && n < p.N) ? p.bias[n] : 0.f;
     }
+    float st1[TN], st2[TN];
+#pragma unroll
+    for (int j = 0; j < TN; ++j) st1[j] = st2[j] = 0.f;
 #pragma unroll
     for (int i = 0; i < TM; ++i) {
         const int oy = y0 + wm * TM + i;
@@ -1093,6 +1132,8 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_halo3_bf16_kernel(const Hal
                     v += bias_r[j];
                     v = fast_act(v, nslope, special, p.act, p.slope);
                     if (p.addend) v += p.addend[pix * p.N + n];
+                    st1[j] += v;
+                    st2[j] += v * v;
                     if (!p.C2) p.C[pix * p.N + n] = v;
                     else if (n < p.n1) p.C[pix * p.n1 + n] = v;                  // (a whole 32-column group goes one way)
                     else p.C2[pix * (p.N - p.n1) + (n - p.n1)] = v;
@@ -1100,6 +1141,7 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_halo3_bf16_kernel(const Hal
             }
         }
     }
+    if (p.stats) halo_stats_epilogue<TN, WM, WN, NT>(st1, st2, smem, p.stats + (size_t)b * 2 * p.N, p.N, n0, wm, wn, lane);
 }
 
 template <int NS, int WM, int WN, int BN, int MODE>
@@ -1405,6 +1447,9 @@ __global__ __launch_bounds__(256) void conv_halo_s2_bf16_kernel(const HaloArgs p
         const int n = n0 + wn * (TN * 32) + j * 32 + l31;
         bias_r[j] = (p.bias && n < p.N) ? p.bias[n] : 0.f;
     }
+    float st1[TN], st2[TN];
+#pragma unroll
+    for (int j = 0; j < TN; ++j) st1[j] = st2[j] = 0.f;
     // output grid: gather mode = the coarse grid (tiles_y*TH x tiles_x*TW); scatter mode = twice the coarse grid, phase (P,Q)
     const int Ho = SCATTER ? 2 * p.H : p.tiles_y * TH, Wo = SCATTER ? 2 * p.W : p.tiles_x * TW;
 #pragma unroll
@@ -1424,11 +1469,14 @@ __global__ __launch_bounds__(256) void conv_halo_s2_bf16_kernel(const HaloArgs p
                     v += bias_r[j];
                     v = fast_act(v, nslope, special, p.act, p.slope);
                     if (p.addend) v += p.addend[pix * p.N + n];
+                    st1[j] += v;
+                    st2[j] += v * v;
                     p.C[pix * p.N + n] = v;
                 }
             }
         }
     }
+    if (p.stats) halo_stats_epilogue<TN, 2, WN, NT>(st1, st2, smem, p.stats + (size_t)b * 2 * p.N, p.N, n0, wm, wn, lane);
 }
 
 // a: H, W = spatial size of the GATHERED tensor (gather mode: the fine grid, output is H/2 x W/2; scatter mode: the coarse
@@ -1604,7 +1652,7 @@ int launch_dgrad_thin(const float *dy, const unsigned short *wh, const unsigned 
 
 int run(const hoig_conv_desc *d, const float *a, const unsigned short *wh, const unsigned short *wl, const float *bias,
         float *c, bool dgrad, hipStream_t st, const float *a2 = nullptr, int cg1 = 0, float *c2 = nullptr, int n1 = 0,
-        const float *addend = nullptr) {
+        const float *addend = nullptr, float *stats = nullptr) {
     Args p;
     p.A = a; p.Wh = wh; p.Wl = wl; p.bias = bias; p.C = c;
     p.f16 = dgrad ? 0 : 1;                       // forward: fp16-split operands over the 2^8-scaled forward planes
@@ -1632,7 +1680,7 @@ int run(const hoig_conv_desc *d, const float *a, const unsigned short *wh, const
     if (p.N <= 32 || p.N % 32 != 0) return HOIG_EUNSUPPORTED;
     static const bool no_thin = getenv("HOIG_NO_THIN_DGRAD") != nullptr;
     if (!no_thin && dgrad && !d->transposed && d->R == 1 && d->S == 1 && d->stride == 1 && d->pad == 0 && g.Cg == 128 &&
-        p.N >= 1024 && p.N % 64 == 0 && p.M % 128 == 0 && !a2 && !c2 && !addend)
+        p.N >= 1024 && p.N % 64 == 0 && p.M % 128 == 0 && !a2 && !c2 && !addend && !stats)
         return launch_dgrad_thin(a, wh, wl, c, p.M, p.N, ns, st);
     // stride-1 "same" convolutions (and their data gradients): LDS-resident input halo, weights streamed per tap
     if (!d->transposed && d->stride == 1 && d->R == d->S && 2 * d->pad == d->R - 1 && (d->R == 1 || d->R == 3 || d->R == 5) &&
@@ -1642,7 +1690,9 @@ int run(const hoig_conv_desc *d, const float *a, const unsigned short *wh, const
         h.A = a; h.Wh = wh; h.Wl = wl; h.bias = bias; h.C = c;
         h.A2 = a2; h.cg1 = cg1; h.C2 = c2; h.n1 = n1;
         h.addend = addend;
-        if (addend && c2) return HOIG_EUNSUPPORTED;
+        h.stats = stats;
+        if ((addend || stats) && c2) return HOIG_EUNSUPPORTED;
+        if (stats && d->R != 3) return HOIG_EUNSUPPORTED;          // (only the 3x3 kernel has the statistics epilogue)
         if ((a2 || c2) && d->R != 3) return HOIG_EUNSUPPORTED;
         if (a2 && (cg1 % 32 || cg1 <= 0 || cg1 >= g.Cg)) return HOIG_EINVAL;
         if (c2 && (n1 % 64 || n1 <= 0 || n1 >= p.N)) return HOIG_EINVAL;
@@ -1669,7 +1719,7 @@ int run(const hoig_conv_desc *d, const float *a, const unsigned short *wh, const
             h.A = a; h.Wh = wh; h.Wl = wl; h.bias = bias; h.C = c;
             h.Bn = d->B; h.Cg = g.Cg; h.N = p.N; h.K = p.K;
             h.pad = 1; h.flip = 0;
-            h.A2 = nullptr; h.cg1 = 0; h.C2 = nullptr; h.n1 = 0; h.addend = addend;
+            h.A2 = nullptr; h.cg1 = 0; h.C2 = nullptr; h.n1 = 0; h.addend = addend; h.stats = stats;
             h.act = p.act; h.slope = p.slope;
             h.f16 = p.f16; h.oscale = p.oscale;
             const bool gather = !g.gatherT;      // the operand is read at 2*o - 1 + tap (fine grid) -> gather mode
@@ -1681,7 +1731,7 @@ int run(const hoig_conv_desc *d, const float *a, const unsigned short *wh, const
             return launch_halo_s2<true>(h, ns, st);
         }
     }
-    if (addend) return HOIG_EUNSUPPORTED;
+    if (addend || stats) return HOIG_EUNSUPPORTED;
     if (p.N <= 64) {
         if (t128 >= 512) return launch<128, 64, 2, 2>(p, ns, st);
         return launch<64, 64, 2, 2>(p, ns, st);
@@ -1733,6 +1783,22 @@ extern "C" int hoig_conv2d_bwd_data_packed(const hoig_conv_desc *d, const float 
     if (!d || !dy || !wt_hi || !dx) return HOIG_EINVAL;
     if (!is_16bit_precision(d->precision)) return HOIG_EINVAL;
     return run(d, dy, wt_hi, wt_lo, nullptr, dx, true, (hipStream_t)stream);
+}
+
+// y = conv(x) and, from the same epilogue, stats[b][0/1][co] += sum / sum of squares of y over image b (HOIG_EUNSUPPORTED where the
+// layer's kernel has no such epilogue: 3x3 stride-1 "same" and 3x3 stride-2 layers on the halo kernels have it)
+extern "C" int hoig_conv2d_fwd_packed_stats(const hoig_conv_desc *d, const float *x, const uint16_t *w_hi, const uint16_t *w_lo,
+                                            const float *bias, float *y, float *stats, hoig_stream_t stream) {
+    if (!d || !x || !w_hi || !y || !stats) return HOIG_EINVAL;
+    if (!is_16bit_precision(d->precision)) return HOIG_EINVAL;
+    return run(d, x, w_hi, w_lo, bias, y, false, (hipStream_t)stream, nullptr, 0, nullptr, 0, nullptr, stats);
+}
+extern "C" int hoig_conv2d_cat_fwd_packed_stats(const hoig_conv_desc *d, const float *x1, int C1, const float *x2,
+                                                const uint16_t *w_hi, const uint16_t *w_lo, const float *bias, float *y,
+                                                float *stats, hoig_stream_t stream) {
+    if (!d || !x1 || !x2 || !w_hi || !y || !stats) return HOIG_EINVAL;
+    if (!is_16bit_precision(d->precision)) return HOIG_EINVAL;
+    return run(d, x1, w_hi, w_lo, bias, y, false, (hipStream_t)stream, x2, C1, nullptr, 0, nullptr, stats);
 }
 
 // dx = data gradient + addend (HOIG_EUNSUPPORTED where the layer's kernel has no such epilogue: the caller adds separately)

@@ -101,6 +101,7 @@ __global__ __launch_bounds__(NT) void inorm_partial_kernel(const float *__restri
     (void)chunk;
 }
 
+// x == NULL: the sums are plain (pivot 0: they come from a convolution's epilogue, hoig_conv2d_fwd_packed_stats)
 __global__ void inorm_finalize_kernel(const float *__restrict__ x, float *__restrict__ partial, int HW, int C,
                                       int nchunks, float eps, float *__restrict__ mean, float *__restrict__ rstd,
                                       int total) {
@@ -113,7 +114,7 @@ __global__ void inorm_finalize_kernel(const float *__restrict__ x, float *__rest
     const float d = s1 * inv;
     float var = s2 * inv - d * d;
     var = var > 0.f ? var : 0.f;
-    mean[i] = x[(size_t)b * HW * C + c] + d;
+    mean[i] = (x ? x[(size_t)b * HW * C + c] : 0.f) + d;
     rstd[i] = 1.f / sqrtf(var + eps);
     partial[(size_t)b * 2 * C + c] = 0.f;          // leave the accumulators zeroed for the next call (no memset launches)
     partial[(size_t)b * 2 * C + C + c] = 0.f;
@@ -445,6 +446,17 @@ constexpr int64_t ACC_POOL = 1 << 18;
 extern "C" int64_t hoig_inorm_workspace_bytes(int B, int HW, int C) {
     (void)HW;
     return (ACC_POOL + (int64_t)B * 2 * C) * (int64_t)sizeof(float);
+}
+
+extern "C" int hoig_inorm_stats_from_sums(int B, int HW, int C, float eps, float *mean, float *rstd, void *workspace,
+                                          hoig_stream_t stream) {
+    if (!mean || !rstd || !workspace) return HOIG_EINVAL;
+    if (B <= 0 || HW <= 0 || C <= 0 || (int64_t)B * 2 * C > ACC_POOL) return HOIG_EUNSUPPORTED;
+    const int total = B * C;
+    inorm_finalize_kernel<<<(total + 255) / 256, 256, 0, (hipStream_t)stream>>>(nullptr, (float *)workspace, HW, C, 0, eps, mean,
+                                                                                rstd, total);
+    HOIG_LAUNCH_CHECK();
+    return HOIG_OK;
 }
 
 extern "C" int hoig_inorm_stats(const float *x, int B, int HW, int C, float eps, float *mean, float *rstd,

@@ -83,7 +83,7 @@ class Generator(ParamTree):
         return ops.conv2d(x, self.P[name + '.weight'], self.P.get(name + '.bias'), stride, pad, act, dead_bias=to_norm)
 
     def _convT(self, x, name):
-        return ops.conv_transpose2d(x, self.P[name + '.weight'])
+        return ops.conv_transpose2d(x, self.P[name + '.weight'], norm_next=True)      # (always followed by a norm: generator.py:118,201)
 
     def _in(self, x, name, act=ACT_NONE, residual=None):
         return ops.instance_norm(x, self.P[name + '.weight'], self.P[name + '.bias'], act=act, residual=residual)
@@ -188,7 +188,7 @@ class Generator(ParamTree):
         # cat[skip, up] -> conv3x3 -> IN -> ReLU: the convolution reads the two tensors directly (ops.conv2d_cat2)
         name = p + '.skippers.%d' % i
         if self.P.get(name + '.0.bias') is None:
-            return self._in(ops.conv2d_cat2(enc[nd - 1 - i], x, self.P[name + '.0.weight']), name + '.1', act=ACT_RELU)
+            return self._in(ops.conv2d_cat2(enc[nd - 1 - i], x, self.P[name + '.0.weight'], norm_next=True), name + '.1', act=ACT_RELU)
         return self._conv_in_relu(ops.cat_channels([enc[nd - 1 - i], x]), name)
 
     def _decode(self, x, enc, seg, p):

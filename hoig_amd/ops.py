@@ -339,7 +339,7 @@ class _Conv(Function):
         Ho, Wo = out_hw
         y = torch.empty((B, Ho, Wo, Co), dtype=x.dtype, device=x.device)
         d = ConvDesc(B, Hi, Wi, Ci, Ho, Wo, Co, R, S, stride, pad, 1 if transposed else 0, act, slope, prec)
-        _conv_fwd_raw(d, x, w, b, y, transposed)
+        _conv_fwd_raw(d, x, w, b, y, transposed, norm_next=dead_bias)
         ctx.d = d
         ctx.d_dg, ctx.d_wg = _bwd_descs(d)
         ctx.transposed = transposed
@@ -421,7 +421,7 @@ class _ConvCat2(Function):
     caller concatenates."""
 
     @staticmethod
-    def forward(ctx, x1, x2, w, prec):
+    def forward(ctx, x1, x2, w, prec, norm_next=False):
         B, H, W_, C1 = x1.shape
         C2 = x2.shape[-1]
         Co = w.shape[0]
@@ -434,6 +434,12 @@ class _ConvCat2(Function):
             qh, ql = _f6_planes(w)
             rc = L.lib.hoig_conv2d_cat_fwd_f6(ctypes.byref(d), _p(x1), C1, _p(x2), _p(hi), _p(qh), _p(ql), None, _p(y), _st())
         d = _x3(d)
+        ws = _conv_stats_workspace(y) if (rc == L.EUNSUPPORTED and norm_next) else None
+        if ws is not None:          # (see _conv_fwd_raw)
+            rc = L.lib.hoig_conv2d_cat_fwd_packed_stats(ctypes.byref(d), _p(x1), C1, _p(x2), _p(hi), _p(lo), None, _p(y), _p(ws), _st())
+            if rc != L.EUNSUPPORTED:
+                L.check(rc, 'hoig_conv2d_cat_fwd_packed_stats')
+                _stats_offer(y)
         if rc == L.EUNSUPPORTED:
             rc = L.lib.hoig_conv2d_cat_fwd_packed(ctypes.byref(d), _p(x1), C1, _p(x2), _p(hi), _p(lo), None, _p(y), _st())
         L.check(rc, 'hoig_conv2d_cat_fwd')
@@ -459,15 +465,15 @@ class _ConvCat2(Function):
         hi, lo = _packed_planes(w, False, True)
         L.check(L.lib.hoig_conv2d_cat_bwd_data_packed(ctypes.byref(ctx.d_dg), _p(dy), _p(hi), _p(lo), _p(dx1), C1, _p(dx2), _st()),
                 'hoig_conv2d_cat_bwd_data_packed')
-        return dx1, dx2, (dw if ret_w else None), None
+        return dx1, dx2, (dw if ret_w else None), None, None
 
 
 _CAT_CONV = os.environ.get('HOIG_CAT_CONV', '1') == '1'
 
 
-def conv2d_cat2(x1, x2, w, prec=None):
+def conv2d_cat2(x1, x2, w, prec=None, norm_next=False):
     """conv2d(cat_channels([x1, x2]), w, None, 1, 1) (3x3, no bias); without the concatenation when the shapes are on the
-    16-bit halo path, else through cat_channels."""
+    16-bit halo path, else through cat_channels.  norm_next: the output goes straight into an instance norm (_conv_fwd_raw)."""
     prec = precision if prec is None else prec
     B, H, W_, C1 = x1.shape
     C2 = x2.shape[-1]
@@ -477,8 +483,8 @@ def conv2d_cat2(x1, x2, w, prec=None):
           B * (H // 4) * (W_ // 32) * ((Co + 127) // 128) >= 160 and B * (H // 4) * (W_ // 32) * ((C1 + C2 + 127) // 128) >= 160 and
           x1.shape[:3] == x2.shape[:3] and x1.is_contiguous() and x2.is_contiguous())
     if not ok:
-        return conv2d(cat_channels([x1, x2]), w, None, 1, 1, prec=prec)
-    return _ConvCat2.apply(x1, x2, w, prec)
+        return conv2d(cat_channels([x1, x2]), w, None, 1, 1, prec=prec, dead_bias=norm_next)
+    return _ConvCat2.apply(x1, x2, w, prec, norm_next)
 
 
 class _ConvHeads(Function):
@@ -550,12 +556,13 @@ def conv_heads(x, w, splits, acts, prec=None):
     return _ConvHeads.apply(x, w, tuple(splits), tuple(acts), precision if prec is None else prec)
 
 
-def conv_transpose2d(x, w, stride=2, pad=1, output_padding=1, prec=None):
-    """nn.ConvTranspose2d(k, stride, padding, output_padding, bias=False) (generator.py:118,201)."""
+def conv_transpose2d(x, w, stride=2, pad=1, output_padding=1, prec=None, norm_next=False):
+    """nn.ConvTranspose2d(k, stride, padding, output_padding, bias=False) (generator.py:118,201).  norm_next=True: the output goes
+    straight into an instance norm (the statistics then come from this convolution's epilogue, see _conv_fwd_raw)."""
     B, Hi, Wi, _ = x.shape
     R, S = w.shape[2], w.shape[3]
     out_hw = ((Hi - 1) * stride - 2 * pad + R + output_padding, (Wi - 1) * stride - 2 * pad + S + output_padding)
-    return _Conv.apply(x, w, None, stride, pad, True, L.ACT_NONE, 0.0, out_hw, precision if prec is None else prec)
+    return _Conv.apply(x, w, None, stride, pad, True, L.ACT_NONE, 0.0, out_hw, precision if prec is None else prec, norm_next)
 
 
 # ------------------------------------------------------------------------------------------------- instance norm
@@ -563,15 +570,41 @@ _norm_ws = {}
 _NORM_KEEP_Y = os.environ.get('HOIG_NORM_KEEP_Y', '0') == '1'      # A/B switch: read y in the backward as before
 
 
-def _norm_workspace(nfloats, device):
+_CONV_STATS = os.environ.get('HOIG_CONV_STATS', '1') == '1'   # A/B switch: 0 = every instance norm computes its statistics itself
+_stats_pending = {}     # (device, stream) -> (data_ptr, B, HW, C) of the tensor whose sums a convolution left in that workspace
+
+
+def _norm_workspace(nfloats, device, take=None):
     """One zero-initialised instance-norm workspace per (device, stream): the kernels leave their accumulators zeroed
-    (include/hoig_kernels.h), so it is never memset again."""
+    (include/hoig_kernels.h), so it is never memset again.  A convolution whose output goes straight into an instance norm may
+    have left that tensor's sums in the accumulators (_conv_fwd_raw): `take` = (data_ptr, B, HW, C) of the tensor the caller is
+    about to normalise -> (workspace, True) if they are its sums.  Sums nobody asked for (the norm took another path) are cleared
+    before anyone else uses the accumulators."""
     key = (device, torch.cuda.current_stream(device).cuda_stream)
     ws = _norm_ws.get(key)
+    pend = _stats_pending.pop(key, None)
+    if pend is not None and pend == take:
+        return ws, True
     if ws is None or ws.numel() < nfloats:
         ws = torch.zeros(max(nfloats, 1 << 20), dtype=torch.float32, device=device)
         _norm_ws[key] = ws
-    return ws
+    elif pend is not None:
+        ws[:pend[1] * 2 * pend[3]].zero_()
+    return (ws, False) if take is not None else ws
+
+
+def _conv_stats_workspace(y):
+    """Accumulators for the statistics of `y` (a convolution output about to be written), or None when its instance norm would
+    not read them: maps of <= 1024 pixels take the one-launch norm kernel, which computes its own."""
+    B, H, W_, C = y.shape
+    if not _CONV_STATS or H * W_ <= 1024 or C % 4:
+        return None
+    return _norm_workspace(L.lib.hoig_inorm_workspace_bytes(B, H * W_, C) // 4, y.device)
+
+
+def _stats_offer(y):
+    B, H, W_, C = y.shape
+    _stats_pending[(y.device, torch.cuda.current_stream(y.device).cuda_stream)] = (y.data_ptr(), B, H * W_, C)
 
 
 class _INorm(Function):
@@ -587,11 +620,14 @@ class _INorm(Function):
         rstd = torch.empty_like(mean)
         y = torch.empty_like(x)
         # maps of <= 1024 pixels: statistics + apply in one launch from one read of x
-        rc = L.lib.hoig_inorm_fwd_fused(_p(x), mode, _p(p0), _p(p1), C, act, slope, _p(residual), eps, _p(y), _p(mean), _p(rstd),
-                                        B, HW, C, _st())
+        rc = L.EUNSUPPORTED if HW > 1024 else L.lib.hoig_inorm_fwd_fused(_p(x), mode, _p(p0), _p(p1), C, act, slope, _p(residual),
+                                                                         eps, _p(y), _p(mean), _p(rstd), B, HW, C, _st())
         if rc == L.EUNSUPPORTED:
-            ws = _norm_workspace(L.lib.hoig_inorm_workspace_bytes(B, HW, C) // 4, x.device)
-            call('hoig_inorm_stats', _p(x), B, HW, C, eps, _p(mean), _p(rstd), _p(ws), _st())
+            ws, have = _norm_workspace(L.lib.hoig_inorm_workspace_bytes(B, HW, C) // 4, x.device, take=(x.data_ptr(), B, HW, C))
+            if have:              # the convolution that made x left its sums in the accumulators: no pass over x for them
+                call('hoig_inorm_stats_from_sums', B, HW, C, eps, _p(mean), _p(rstd), _p(ws), _st())
+            else:
+                call('hoig_inorm_stats', _p(x), B, HW, C, eps, _p(mean), _p(rstd), _p(ws), _st())
             call('hoig_inorm_apply', _p(x), _p(mean), _p(rstd), mode, _p(p0), _p(p1), act, slope, _p(residual), _p(y),
                  B, HW, C, _st())
         else:
@@ -651,11 +687,14 @@ class _SpadeFused(Function):
         mean = torch.empty(B * C, dtype=torch.float32, device=x.device)
         rstd = torch.empty_like(mean)
         y = torch.empty_like(x)
-        rc = L.lib.hoig_inorm_fwd_fused(_p(x), 2, _p(gb), gb.data_ptr() + 4 * C, 2 * C, act, slope, None, eps, _p(y), _p(mean),
-                                        _p(rstd), B, HW, C, _st())
+        rc = L.EUNSUPPORTED if HW > 1024 else L.lib.hoig_inorm_fwd_fused(_p(x), 2, _p(gb), gb.data_ptr() + 4 * C, 2 * C, act, slope,
+                                                                         None, eps, _p(y), _p(mean), _p(rstd), B, HW, C, _st())
         if rc == L.EUNSUPPORTED:
-            ws = _norm_workspace(L.lib.hoig_inorm_workspace_bytes(B, HW, C) // 4, x.device)
-            call('hoig_inorm_stats', _p(x), B, HW, C, eps, _p(mean), _p(rstd), _p(ws), _st())
+            ws, have = _norm_workspace(L.lib.hoig_inorm_workspace_bytes(B, HW, C) // 4, x.device, take=(x.data_ptr(), B, HW, C))
+            if have:
+                call('hoig_inorm_stats_from_sums', B, HW, C, eps, _p(mean), _p(rstd), _p(ws), _st())
+            else:
+                call('hoig_inorm_stats', _p(x), B, HW, C, eps, _p(mean), _p(rstd), _p(ws), _st())
             call('hoig_inorm_apply_ld', _p(x), _p(mean), _p(rstd), 2, _p(gb), gb.data_ptr() + 4 * C, 2 * C, act, slope, None,
                  _p(y), B, HW, C, _st())
         else:
@@ -953,10 +992,21 @@ def _f6_in_scope(w):
     return any(a <= off < b for a, b in rng)
 
 
-def _conv_fwd_raw(d, x, w, b, y, transposed=False):
-    """y = conv(x, w) (+bias, activation) on the kernel the precision mode selects."""
+def _conv_fwd_raw(d, x, w, b, y, transposed=False, norm_next=False):
+    """y = conv(x, w) (+bias, activation) on the kernel the precision mode selects.  norm_next: y goes straight into an instance
+    norm -- where the layer's kernel can, it also leaves the per-image channel sums of y in the stream's norm workspace
+    (hoig_conv2d_fwd_packed_stats) and says so (_stats_offer); the norm then skips its statistics pass."""
     if d.precision == L.PREC_F16F6 and not _f6_in_scope(w):
         d = _x3(d)
+    if norm_next and d.precision not in (L.PREC_F32, L.PREC_F16F6) and d.Ci % 32 == 0 and d.Co % 32 == 0 and d.Co > 32:
+        ws = _conv_stats_workspace(y)
+        if ws is not None:
+            hi, lo = _packed_planes(w, transposed, False)
+            rc = L.lib.hoig_conv2d_fwd_packed_stats(ctypes.byref(d), _p(x), _p(hi), _p(lo), _p(b), _p(y), _p(ws), _st())
+            if rc != L.EUNSUPPORTED:
+                L.check(rc, 'hoig_conv2d_fwd_packed_stats')
+                _stats_offer(y)
+                return
     if d.precision == L.PREC_F16F6:
         if (not transposed and d.R == 3 and d.S == 3 and d.stride == 1 and d.pad == 1 and d.Ci % 64 == 0 and d.Co % 64 == 0
                 and d.Hi % 8 == 0 and d.Wi % 32 == 0):

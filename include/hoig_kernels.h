@@ -102,6 +102,16 @@ int hoig_conv2d_fwd_packed(const hoig_conv_desc *d, const float *x, const uint16
                            const float *bias /*nullable*/, float *y, hoig_stream_t stream);
 int hoig_conv2d_bwd_data_packed(const hoig_conv_desc *d, const float *dy, const uint16_t *wt_hi, const uint16_t *wt_lo,
                                 float *dx, hoig_stream_t stream);
+/* y = conv(x) AND, from the same epilogue, the statistics of the instance norm that reads y next (generator.py:16-22 conv -> IN ->
+ * ReLU): stats[b][0][co] += sum of y over image b, stats[b][1][co] += sum of y*y (fp32 atomics, one per workgroup and
+ * channel; stats = the accumulators of an instance-norm workspace, zero on entry), consumed by hoig_inorm_stats_from_sums instead of
+ * a pass over y.  HOIG_EUNSUPPORTED where the layer's kernel has no such epilogue (it exists on the 3x3 stride-1 "same" and the 3x3
+ * stride-2 halo kernels, Conv2d and ConvTranspose2d): the caller then runs the plain convolution and hoig_inorm_stats. */
+int hoig_conv2d_fwd_packed_stats(const hoig_conv_desc *d, const float *x, const uint16_t *w_hi, const uint16_t *w_lo,
+                                 const float *bias /*nullable*/, float *y, float *stats, hoig_stream_t stream);
+int hoig_conv2d_cat_fwd_packed_stats(const hoig_conv_desc *d, const float *x1, int C1, const float *x2, const uint16_t *w_hi,
+                                     const uint16_t *w_lo, const float *bias /*nullable*/, float *y, float *stats,
+                                     hoig_stream_t stream);
 /* dx = data gradient + addend (addend: the gradient that reaches the same tensor through its OTHER consumer, e.g. the skip path of
  * a residual block, generator.py:29-32 `x + self.main(x)`; torch's autograd engine sums the two in a separate pass).  Returns
  * HOIG_EUNSUPPORTED for layers whose kernel has no such epilogue (everything but stride-1 "same" 1x1/3x3/5x5 and stride-2 3x3 on the halo kernels): the
@@ -158,6 +168,10 @@ int hoig_inorm_apply(const float *x, const float *mean, const float *rstd, int m
                      hoig_stream_t stream);
 /* same with gamma/beta rows `ld_p` floats apart (mode 2 only): lets gamma and beta live side by side in ONE [.,2C] tensor
  * (the output of the fused gamma|beta convolution), p0 = gb, p1 = gb + C, ld_p = 2C */
+/* mean / rstd from sums that a convolution's epilogue left in the workspace's accumulators (hoig_conv2d_fwd_packed_stats; plain
+ * sums: var = E[y^2] - E[y]^2 in fp32, adequate for the outputs of convolutions over normalised activations this is used for);
+ * leaves the accumulators zero like hoig_inorm_stats */
+int hoig_inorm_stats_from_sums(int B, int HW, int C, float eps, float *mean, float *rstd, void *workspace, hoig_stream_t stream);
 int hoig_inorm_apply_ld(const float *x, const float *mean, const float *rstd, int mode, const float *p0, const float *p1,
                         int ld_p, int act, float slope, const float *residual /*nullable*/, float *y, int B, int HW, int C,
                         hoig_stream_t stream);

@@ -500,6 +500,66 @@ def test_conv_fork_adds_the_other_consumers_gradient(B, C, Co, H, W, k, stride, 
     assert rel_err(dx1 - 2 * gx, dx0 - 2 * gx) < 1e-4 and float((dx1 - 2 * gx).abs().max()) > 0
 
 
+@pytest.mark.parametrize('kind,B,Ci,Co,H,W', [('s1', 8, 64, 128, 64, 64), ('s1', 4, 128, 64, 64, 128), ('s2', 4, 64, 128, 128, 128),
+                                              ('s2', 2, 128, 256, 128, 64), ('convT', 4, 128, 64, 64, 64), ('convT', 2, 256, 128, 32, 64),
+                                              ('cat2', 4, 64, 64, 64, 128), ('small', 8, 512, 512, 32, 32), ('thin', 2, 8, 64, 64, 64)])
+def test_instance_norm_statistics_from_the_convolution_epilogue(kind, B, Ci, Co, H, W):
+    """conv -> IN(+ReLU) where the convolution's epilogue leaves the per-image channel sums for the norm (SURVEY 7.4;
+    hoig_conv2d_fwd_packed_stats / hoig_inorm_stats_from_sums): same outputs and gradients as the reference ops, the hand-off really
+    happens on the layers that have the epilogue, and never leaves the workspace dirty."""
+    ops = _ops()
+    from hoig_amd import _lib as L
+    g = torch.Generator().manual_seed(31)
+    x = torch.randn(B, Ci, H, W, generator=g) + 0.5
+    x2 = torch.randn(B, Ci, H, W, generator=g) if kind == 'cat2' else None
+    ci_w = 2 * Ci if kind == 'cat2' else Ci
+    w = torch.randn(*((ci_w, Co, 3, 3) if kind == 'convT' else (Co, ci_w, 3, 3)), generator=g) * 0.05
+    aw, ab = torch.randn(Co, generator=g), torch.randn(Co, generator=g)
+    xr, wr, awr, abr = (t.clone().requires_grad_(True) for t in (x, w, aw, ab))
+    x2r = x2.clone().requires_grad_(True) if x2 is not None else None
+    if kind == 'convT':
+        hr = F.conv_transpose2d(xr, wr, None, stride=2, padding=1, output_padding=1)
+    else:
+        hr = F.conv2d(torch.cat([xr, x2r], 1) if x2 is not None else xr, wr, None, stride=2 if kind == 's2' else 1, padding=1)
+    yr = F.instance_norm(hr, weight=awr, bias=abr, eps=1e-5)     # (no activation: a ReLU mask one rounding away from the reference's
+    gy = torch.randn(yr.shape, generator=g)                      # would put isolated large errors into the max-norm of the gradients)
+    yr.backward(gy)
+    ops.set_precision('bf16x3')
+    try:
+        xd = nhwc_cuda(x).requires_grad_(True)
+        x2d = nhwc_cuda(x2).requires_grad_(True) if x2 is not None else None
+        wd = ops.pack_weight(w.cuda(), transposed=kind == 'convT').requires_grad_(True)
+        awd, abd = aw.cuda().requires_grad_(True), ab.cuda().requires_grad_(True)
+        ops._stats_pending.clear()
+        if kind == 'convT':
+            h = ops.conv_transpose2d(xd, wd, norm_next=True)
+        elif kind == 'cat2':
+            h = ops.conv2d_cat2(xd, x2d, wd, norm_next=True)
+        else:
+            h = ops.conv2d(xd, wd, None, 2 if kind == 's2' else 1, 1, dead_bias=True)
+        offered = len(ops._stats_pending) == 1
+        assert offered == (kind not in ('small', 'thin'))       # <= 1024-pixel maps and thin layers keep the norm's own statistics
+        y = ops.instance_norm(h, awd, abd)
+        assert not ops._stats_pending
+        y.backward(nhwc_cuda(gy))
+        torch.cuda.synchronize()
+        for ws in ops._norm_ws.values():                         # accumulators are left zero by whoever consumed them
+            assert float(ws[:1 << 18].abs().max()) == 0.0
+        # sums nobody consumes (the norm is never called) are cleared by the next user of the workspace
+        if offered:
+            ops.conv2d(xd, wd, None, 2 if kind == 's2' else 1, 1, dead_bias=True) if kind in ('s1', 's2') else None
+            z = ops.instance_norm(nhwc_cuda(torch.randn(2, 64, 48, 48, generator=g)))
+            torch.cuda.synchronize()
+            assert not ops._stats_pending
+            assert float(z.mean(dim=(1, 2)).abs().max()) < 1e-4
+    finally:
+        ops.set_precision('f32')
+    assert rel_err(nchw_cpu(y), yr) < 3e-4
+    assert rel_err(nchw_cpu(xd.grad), xr.grad) < 3e-3           # (bf16x3 products)
+    assert rel_err(wd.grad, wr.grad) < 3e-3
+    assert rel_err(awd.grad, awr.grad) < 3e-3 and rel_err(abd.grad, abr.grad) < 3e-3
+
+
 THIN_CASES = [
     # B, Ci, Co, H, W, k, bias, act       (stride 1, 'same' padding)
     (2, 3, 64, 32, 32, 7, False, 'none'),      # the 7x7 stems (generator.py:100,153)
