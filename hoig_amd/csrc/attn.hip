@@ -694,7 +694,9 @@ extern "C" int hoig_attn_pixel_bwd(const float *hidden, const float *attn, const
     else if (C == 128) attn_edots_ch_kernel<32, 1><<<(M + 7) / 8, 256, 0, ST>>>(source, flow, dout, e_ws, B, H, W);
     else attn_edots_kernel<<<(M + 3) / 4, 256, 0, ST>>>(source, flow, dout, e_ws, B, H, W, C);
     const int groups = (M + APB_PIX - 1) / APB_PIX;
-    const int nit = groups >= 2048 ? (groups / 1024 > 8 ? 8 : groups / 1024) : 1;      // ~1024 workgroups on the large maps
+    // <= 256 workgroups: each closes with 3225 atomics into the SAME dW2 / db2 addresses, which retire at ~25 ns per address and
+    // atomic (1024 workgroups on the 128x128 layer: a 25-us tail)
+    const int nit = (groups + 255) / 256;
     attn_pixel_bwd_kernel<<<(groups + nit - 1) / nit, APB_NT, 0, ST>>>(hidden, attn, w2, e_ws, flow, dhidden, dw2, db2, B, H, W, C,
                                                                       nit);
     HOIG_LAUNCH_CHECK();

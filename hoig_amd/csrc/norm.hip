@@ -11,11 +11,13 @@ namespace {
 
 constexpr int NT = 256;
 
-__host__ __device__ inline int inorm_chunks(int HW) {
-    // 16 pixel rows per workgroup (partials are combined with atomics, so many small chunks cost nothing extra and a
-    // 32x32 map already yields 64 workgroups per image)
+inline int inorm_chunks(int HW) {
+    // >= 16 pixel rows per workgroup (a 32x32 map already yields 64 workgroups per image), at most HOIG_NORM_CHUNKS (128) per
+    // image: every workgroup closes with one atomic per (channel, moment) into the image's accumulators, the workgroups of a
+    // launch finish together, and same-address atomics retire at ~25 ns each -- 512 chunks were a 13-us tail on every launch
+    static const int cap = getenv("HOIG_NORM_CHUNKS") ? atoi(getenv("HOIG_NORM_CHUNKS")) : 128;
     int n = (HW + 15) / 16;
-    if (n > 512) n = 512;
+    if (n > cap) n = cap;
     if (n < 1) n = 1;
     return n;
 }
