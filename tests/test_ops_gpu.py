@@ -404,6 +404,8 @@ BF16_CASES = [
     (2, 128, 64, 32, 3, 2, 1, True),       # ConvTranspose2d on it (scatter fwd, gather dgrad; 64-channel tiles)
     (1, 256, 128, 32, 3, 2, 1, True),
     (1, 512, 256, 8, 3, 2, 1, True),
+    (8, 64, 128, 256, 3, 2, 1, False),     # ... at the step's own sizes (thousands of tiles): gather fwd, scatter dgrad, 128-column tiles
+    (8, 128, 64, 64, 3, 2, 1, True),       # ... scatter fwd, gather dgrad, 64-column tiles
 ]
 
 
