@@ -108,6 +108,37 @@ def test_param_tree_state_dict_roundtrip_cpu():
     assert abs(float(tree.P['model.0.weight'].std()) - 0.02) < 5e-3 and float(tree.P['model.0.bias'].abs().max()) == 0
 
 
+def test_param_tree_adjacent_groups_and_fused_views_cpu():
+    """ParamTree(adjacent=...) moves parameters next to each other in the flat store (the object branch's three 7x7 heads that
+    read one feature map: generator.py:219-235,311-315) without changing what a checkpoint sees: names, order, shapes, values."""
+    from hoig_amd.nn import ParamTree
+    shapes = {'a.img.weight': (3, 8, 7, 7), 'a.norm.weight': (8,), 'b.mask.weight': (1, 16, 7, 7), 'b.other.weight': (4, 8, 3, 3),
+              'c.mask.weight': (1, 16, 7, 7)}
+    split = ['b.mask.weight', 'c.mask.weight']                      # stored as two halves of their input channels (#t | #s)
+    group = ['a.img.weight', 'b.mask.weight#s', 'c.mask.weight#s']
+    plain = ParamTree(shapes, torch.device('cpu'), split_names=split)
+    tree = ParamTree(shapes, torch.device('cpu'), split_names=split, adjacent=[group])
+    assert not plain.fuse_conv_weights('heads', group)              # not adjacent in the reference order: nothing registered
+    assert 'heads' not in plain.F
+    assert tree.fuse_conv_weights('heads', group)
+    offs = [tree._offsets[n] for n in group]
+    assert offs[1] == offs[0] + 3 * 8 * 49 and offs[2] == offs[1] + 8 * 49
+    g = torch.Generator().manual_seed(3)
+    sd = {k: torch.randn(v, generator=g) for k, v in shapes.items()}
+    tree.load_state_dict(sd)
+    plain.load_state_dict(sd)
+    out = tree.state_dict()
+    assert list(out.keys()) == list(shapes.keys()) == list(plain.state_dict().keys())
+    for k in sd:
+        assert torch.equal(out[k], sd[k])
+    fused = tree.F['heads']                                          # (5, 8, 7, 7) in the packed [Co][R][S][Ci] layout
+    assert tuple(fused.shape) == (5, 8, 7, 7)
+    want = torch.cat([sd['a.img.weight'], sd['b.mask.weight'][:, 8:], sd['c.mask.weight'][:, 8:]], dim=0)
+    assert torch.equal(fused.detach(), want)
+    assert fused.grad.data_ptr() == tree.flat_grad.data_ptr() + 4 * offs[0]
+    assert tree.flat.numel() == plain.flat.numel()
+
+
 def test_synthetic_inputs_deterministic_and_in_range():
     from hoig_amd import synthetic
     a = synthetic.make_inputs(2, 32, seed=8)
