@@ -60,8 +60,9 @@ def test_captured_step_matches_eager_step_and_oracle(precision):
         ot.optimize_parameters()
         eg, eo = mg.get_current_errors(), ot.get_current_errors()
         assert not _captured(mg)
+        later = 2e-3 if precision == 'f16f6' else LOSS_TOL          # (tests/test_trainer_gpu.py: LOSS_TOL_LATER_F6)
         for k in eo:
-            assert _close(eg[k], eo[k], LOSS_TOL if s else 1e-4), (s, k, eg[k], eo[k])
+            assert _close(eg[k], eo[k], later if s else 1e-4), (s, k, eg[k], eo[k])
     for s in range(T._GRAPH_WARMUP):
         me.optimize_parameters()
     assert not me._graphs

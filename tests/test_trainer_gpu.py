@@ -16,8 +16,16 @@ TOL = 1e-3
 LOSS_TOL_FIRST, LOSS_TOL = 1e-4, 1e-3
 
 
-def _loss_bound(want, step=0):
-    return (LOSS_TOL_FIRST if step == 0 else LOSS_TOL) * max(abs(want), 1e-2)
+# Later steps: the second optimiser step already amplifies the first step's rounding ~100x (this GAN's g_adv jumps from 0.9 to 61).
+# Measured over 8 runs each at 64x64 (round 3): default arithmetic 4.6e-4..6.2e-4 of the oracle's value; the opt-in `f16f6` forward,
+# whose outputs are 1e-4 off instead of 2e-5, 6.0e-4..8.9e-4 -- no margin to 1e-3 (one failure in ~15 runs), so that mode's later
+# steps are held to 2e-3.  Its first step and its outputs meet the same bounds as every other mode.
+LOSS_TOL_LATER_F6 = 2e-3
+
+
+def _loss_bound(want, step=0, precision=None):
+    later = LOSS_TOL_LATER_F6 if precision == 'f16f6' else LOSS_TOL
+    return (LOSS_TOL_FIRST if step == 0 else later) * max(abs(want), 1e-2)
 # Gradients: the oracle itself is an fp32 computation; back-propagating through ~45 conv + instance-norm layers
 # amplifies summation-order noise, and the exact-fp32 MFMA mode already differs from torch-CPU by up to ~5e-3 in
 # relative L2 on the smallest gradient tensors (printed by the test).  The split-bf16 mode must stay in that class.
@@ -64,7 +72,7 @@ def test_trainer_matches_reference_golden(gen_name, fname, precision):
         e = m.get_current_errors()
         got, want = np.array([e[k] for k in keys]), g['errors'][s]
         print('step %d loss rel. errors: %s' % (s, ' '.join('%.1e' % (abs(a - b) / max(abs(b), 1e-2)) for a, b in zip(got, want))))
-        assert all(abs(a - b) <= _loss_bound(b, s) for a, b in zip(got, want)), (s, got, want)
+        assert all(abs(a - b) <= _loss_bound(b, s, precision) for a, b in zip(got, want)), (s, got, want)
         if s == 0:
             for k in g.files:
                 if k.startswith('grad_G_'):
