@@ -147,12 +147,27 @@ def _load():
     lib.hoig_attn_index_ints.restype = ctypes.c_int64
     lib.hoig_rasterize_workspace_bytes.restype = ctypes.c_size_t
     lib.hoig_rasterize_workspace_bytes.argtypes = [ctypes.c_int, ctypes.c_int]
+    lib.hoig_set_tuning.argtypes = [ctypes.c_char_p, _i]
+    lib.hoig_set_tuning.restype = ctypes.c_int
     lib.hoig_version.argtypes = []
     lib.hoig_version.restype = ctypes.c_char_p
     return lib
 
 
 lib = _load()
+
+
+def set_tuning(key, value):
+    """hoig_set_tuning: kernel-variant choice `key` -> `value` (returns the previous value)."""
+    prev = lib.hoig_set_tuning(key.encode(), int(value))
+    if prev < 0:
+        raise KeyError('unknown tuning key %r' % key)
+    return prev
+
+
+# HOIG_TUNING="key=value,key=value": variant choices for A/B runs (bench.py and the tools set them through this one variable)
+for _kv in filter(None, os.environ.get('HOIG_TUNING', '').split(',')):
+    set_tuning(*_kv.split('='))
 
 
 def check(rc, what):

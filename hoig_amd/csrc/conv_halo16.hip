@@ -1,0 +1,350 @@
+// 3x3 stride-1 "same" convolution (forward and data gradient) on v_mfma_f32_16x16x32_{f16,bf16}: the same workgroup tile and
+// step structure as conv_halo3_bf16_kernel MODE 2 (conv_igemm_bf16.hip: 8 rows x 32 pixels x BN channels, 8 waves, the input
+// halo of a 32-channel block staged once and split to 16-bit hi / lo planes, one TAP ROW of weight tiles per step,
+// double-buffered), on the 16x16 MFMA shape, which holds a higher clock than 32x32x16 on random data (MI355X_MICROARCH.md,
+// 'DVFS give-back' item 7; cdna_hip_programming.md rule 28).
+//
+// Operand roles are swapped against the 32x32 kernel: the WEIGHTS are the A operand (rows of the result = output channels)
+// and the PIXELS the B operand (columns), so a lane ends up with FOUR CONSECUTIVE CHANNELS of one pixel (D: col = lane & 15,
+// row = 4 * (lane >> 4) + reg) and the epilogue stores 16 B per lane: 16 dwordx4 stores per wave instead of 64 dword stores.
+//
+// LDS images: both operands are stored as two "half images" of [row][32 B] -- the two 16-B k-chunks {0,1} (resp. {2,3}) of a
+// row side by side, no padding.  A ds_read_b128 of this MFMA shape has lanes 0-15 on chunk 0 of rows r..r+15, lanes 16-31 on
+// chunk 1, lanes 32-47 / 48-63 on chunks 2 / 3 (the other half image); its four bank cycles each see 8 even and 8 odd 16-B
+// slots (2 * row + chunk): conflict-free at every tap shift.  The second half image starts 64 B past a multiple of 128 B, so
+// that the staging stores (ds_write_b64 of the split halo: 2 pixels x 8 lanes; ds_write_b128 of the weight chunks: 2 rows x 4
+// lanes) fill a whole 128-B bank window per lane group.
+#include "conv_bf16_common.h"
+
+namespace hoig_detail {
+namespace {
+
+template <bool F16>
+__device__ __forceinline__ f32x4 mfma_m16(const bf16x8 a, const bf16x8 b, const f32x4 c) {
+    if constexpr (F16)
+        return __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, a), __builtin_bit_cast(f16x8, b), c, 0, 0, 0);
+    else
+        return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0);
+}
+
+constexpr int round128(int v) { return (v + 127) / 128 * 128; }
+
+template <int WM, int BN>
+struct M16Layout {
+    static constexpr int TH = 2 * WM, HW = 34, HPIX = (TH + 2) * HW;
+    static constexpr int PHALF = HPIX * 32;                       // one half image of the halo: [pixel][32 B]
+    static constexpr int P23 = round128(PHALF) + 64;              // offset of the second half image (k-chunks 2, 3)
+    static constexpr int PLANE_P = round128(P23 + PHALF);
+    static constexpr int W23 = BN * 32 + 64;
+    static constexpr int PLANE_W = round128(W23 + BN * 32);
+    static constexpr size_t bytes(int nsx) { return (size_t)ns_a(nsx) * PLANE_P + 2 * 3 * ns_b(nsx) * PLANE_W; }
+};
+
+template <int NSX, int WM, int WN, int BN, bool F16>
+__global__ __launch_bounds__(64 * WM * WN) void conv_halo3_m16_kernel(const HaloArgs p) {
+    constexpr int NS = NSX == 1 ? 1 : 2, NB = NSX == 2 ? 2 : 1;      // operand planes: pixels (activations / dy), weights
+    using LY = M16Layout<WM, BN>;
+    constexpr int KS = 3, TH = LY::TH, HW = LY::HW, HPIX = LY::HPIX;
+    constexpr int NT = 64 * WM * WN;
+    constexpr int P23 = LY::P23, PLANE_P = LY::PLANE_P, W23 = LY::W23, PLANE_W = LY::PLANE_W;
+    constexpr int RB = BN * 4 >= NT ? BN * 4 / NT : 1;     // 16-B weight chunks per thread per plane per tap
+    constexpr bool B_PART = BN * 4 < NT;                   // more threads than chunks
+    constexpr int MT = 4;                                  // pixel tiles of 16 per wave: 2 rows x 2 halves
+    constexpr int NTW = BN / (16 * WN);                    // channel tiles of 16 per wave
+    constexpr int ABUF = NS * PLANE_P, BBUF = KS * NB * PLANE_W;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];   // ABUF + 2 * BBUF
+    unsigned char *Pbase = smem;
+    unsigned char *Wbase = smem + ABUF;
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int l15 = lane & 15, lg = lane >> 4;
+    const int wm = wave / WN, wn = wave % WN;
+    const int tile = hoig_xcd_remap(blockIdx.x, p.nblk);
+    const int n_mt = p.nblk / p.nblk_n;
+    int mt_ = p.nmajor ? tile % n_mt : tile / p.nblk_n;
+    const int n0 = (p.nmajor ? tile / n_mt : tile % p.nblk_n) * BN;
+    const int tx_ = mt_ % p.tiles_x;
+    mt_ /= p.tiles_x;
+    const int ty_ = mt_ % p.tiles_y, b = mt_ / p.tiles_y;
+    const int y0 = ty_ * TH, x0 = tx_ * 32;
+
+    // weight staging: thread -> (row, position in the 64-B row of the blocked plane); the plane's position holds logical chunk
+    // pos ^ ((row >> 2) & 3) (plane_index)
+    const int brow = tid >> 2, bpos = tid & 3;
+    const unsigned short *wrow_h[RB], *wrow_l[RB];
+    int woff[RB];
+#pragma unroll
+    for (int i = 0; i < RB; ++i) {
+        const int row = brow + (NT / 4) * i;
+        const int n = n0 + row;
+        const bool ok = n < p.N && (!B_PART || row < BN);
+        const size_t o = ((size_t)(n >> 5) * (p.K >> 5)) * 1024 + (n & 31) * 32 + bpos * 8;
+        wrow_h[i] = ok ? p.Wh + o : nullptr;
+        wrow_l[i] = (NB == 2 && ok) ? p.Wl + o : nullptr;
+        const int c = bpos ^ ((row >> 2) & 3);
+        woff[i] = (c >> 1) * W23 + row * 32 + (c & 1) * 16;
+    }
+    // fragment read offsets
+    int wread[NTW], pread[MT];
+#pragma unroll
+    for (int j = 0; j < NTW; ++j) wread[j] = (lg >> 1) * W23 + (wn * (NTW * 16) + j * 16 + l15) * 32 + (lg & 1) * 16;
+#pragma unroll
+    for (int m = 0; m < MT; ++m)
+        pread[m] = (lg >> 1) * P23 + ((wm * 2 + (m >> 1)) * HW + (m & 1) * 16 + l15) * 32 + (lg & 1) * 16;
+
+    f32x4 acc[NTW][MT];
+#pragma unroll
+    for (int j = 0; j < NTW; ++j)
+#pragma unroll
+        for (int m = 0; m < MT; ++m) acc[j][m] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    uint4 rbh[KS][RB], rbl[KS][RB];
+    const int ncb = p.Cg >> 5, T = ncb * KS;               // step = (channel block, tap row)
+    auto load_b = [&](int step) {
+        const int cb = step / KS, r = step - cb * KS;
+#pragma unroll
+        for (int t = 0; t < KS; ++t) {
+            const int tap = r * KS + t;
+            const int wtap = p.flip ? (KS * KS - 1 - tap) : tap;
+            const size_t koff = (size_t)(wtap * p.Cg + cb * 32) * 32;
+#pragma unroll
+            for (int i = 0; i < RB; ++i) {
+                rbh[t][i] = wrow_h[i] ? *reinterpret_cast<const uint4 *>(wrow_h[i] + koff) : make_uint4(0, 0, 0, 0);
+                if (NB == 2)
+                    rbl[t][i] = wrow_l[i] ? *reinterpret_cast<const uint4 *>(wrow_l[i] + koff) : make_uint4(0, 0, 0, 0);
+            }
+        }
+    };
+    auto store_b = [&](int buf) {
+#pragma unroll
+        for (int t = 0; t < KS; ++t) {
+            unsigned char *Wh = Wbase + buf * BBUF + t * NB * PLANE_W, *Wl = Wh + PLANE_W;
+#pragma unroll
+            for (int i = 0; i < RB; ++i) {
+                if (B_PART && brow >= BN) continue;
+                *reinterpret_cast<uint4 *>(Wh + woff[i]) = rbh[t][i];
+                if (NB == 2) *reinterpret_cast<uint4 *>(Wl + woff[i]) = rbl[t][i];
+            }
+        }
+    };
+    constexpr int HSLICES = (HPIX * 8 + NT - 1) / NT;
+    float4 hreg[HSLICES];
+    auto halo_load = [&](int cb) {
+        const bool second = p.A2 != nullptr && cb * 32 >= p.cg1;
+        const int ld = p.A2 ? (second ? p.Cg - p.cg1 : p.cg1) : p.Cg;
+        const float *Aimg = (second ? p.A2 : p.A) + (size_t)b * p.H * p.W * ld + (second ? cb * 32 - p.cg1 : cb * 32);
+#pragma unroll
+        for (int sl = 0; sl < HSLICES; ++sl) {
+            const int i = tid + NT * sl;
+            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (i < HPIX * 8) {
+                const int pix = i >> 3, c4 = i & 7;
+                const int hy = pix / HW, hx = pix - hy * HW;
+                const int gy = y0 - p.pad + hy, gx = x0 - p.pad + hx;
+                if (gy >= 0 && gy < p.H && gx >= 0 && gx < p.W)
+                    v = *reinterpret_cast<const float4 *>(Aimg + ((size_t)gy * p.W + gx) * ld + c4 * 4);
+            }
+            hreg[sl] = v;
+        }
+    };
+    auto halo_store = [&]() {
+        unsigned char *Ph = Pbase, *Pl = Ph + PLANE_P;
+#pragma unroll
+        for (int sl = 0; sl < HSLICES; ++sl) {
+            const int i = tid + NT * sl;
+            if (i < HPIX * 8) {
+                const int pix = i >> 3, c4 = i & 7;
+                uint2 hi, lo;
+                split4t<F16>(hreg[sl], hi, lo);
+                const int off = (c4 >> 2) * P23 + pix * 32 + (c4 & 3) * 8;
+                *reinterpret_cast<uint2 *>(Ph + off) = hi;
+                if (NS == 2) *reinterpret_cast<uint2 *>(Pl + off) = lo;
+            }
+        }
+    };
+
+    // One step = the three taps of row r.  A group = (tap, channel tile): its two weight fragments (hi, lo) against the
+    // tap's eight pixel fragments (4 tiles x hi / lo, read once per tap): 12 MFMAs.  The fragments of the NEXT group -- and a
+    // quarter of the next tap's pixel fragments -- are read before the MFMAs of the current group issue.
+    struct PF {
+        bf16x8 h[MT], l[MT];
+    };
+    struct WF {
+        bf16x8 h, l;
+    };
+    auto compute = [&](int r, int bbuf) {
+        const unsigned char *Ph = Pbase, *Pl = Ph + PLANE_P;
+        const unsigned char *Wst = Wbase + bbuf * BBUF;
+        auto read_p = [&](PF &f, int t, int m) {
+            const int off = pread[m] + (r * HW + t) * 32;
+            f.h[m] = *reinterpret_cast<const bf16x8 *>(Ph + off);
+            if (NS == 2) f.l[m] = *reinterpret_cast<const bf16x8 *>(Pl + off);
+        };
+        auto read_w = [&](WF &f, int t, int j) {
+            const unsigned char *Wh = Wst + t * NB * PLANE_W, *Wl = Wh + PLANE_W;
+            f.h = *reinterpret_cast<const bf16x8 *>(Wh + wread[j]);
+            if (NB == 2) f.l = *reinterpret_cast<const bf16x8 *>(Wl + wread[j]);
+        };
+        PF pf[2];
+        WF wf[2];
+#pragma unroll
+        for (int m = 0; m < MT; ++m) read_p(pf[0], 0, m);
+        read_w(wf[0], 0, 0);
+        constexpr int NG = KS * NTW;
+        constexpr int PPG = (MT + NTW - 1) / NTW;          // pixel tiles of the next tap read per group
+#pragma unroll
+        for (int g = 0; g < NG; ++g) {
+            const int t = g / NTW, j = g % NTW;
+            if (g + 1 < NG) read_w(wf[(g + 1) & 1], (g + 1) / NTW, (g + 1) % NTW);
+            if (t + 1 < KS) {
+#pragma unroll
+                for (int q = 0; q < PPG; ++q)
+                    if (j * PPG + q < MT) read_p(pf[(t + 1) & 1], t + 1, j * PPG + q);
+            }
+            __builtin_amdgcn_sched_barrier(0);      // reads of the next group stay AHEAD of this group's MFMAs
+            const PF &pc = pf[t & 1];
+            const WF &wc = wf[g & 1];
+#pragma unroll
+            for (int m = 0; m < MT; ++m) {
+                if (NS == 2) acc[j][m] = mfma_m16<F16>(wc.h, pc.l[m], acc[j][m]);
+                if (NB == 2) acc[j][m] = mfma_m16<F16>(wc.l, pc.h[m], acc[j][m]);
+                acc[j][m] = mfma_m16<F16>(wc.h, pc.h[m], acc[j][m]);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    };
+
+    halo_load(0);
+    halo_store();
+    load_b(0);
+    store_b(0);
+    if (T > 1) load_b(1);
+    __syncthreads();
+    int bbuf = 0;
+#pragma unroll 1
+    for (int step = 0; step < T; ++step) {
+        const int cb = step / KS, r = step - cb * KS;
+        const bool more = step + 1 < T;
+        const bool boundary = more && r == KS - 1;
+        if (more) store_b(bbuf ^ 1);                  // weights of step+1 (registers loaded during the previous step)
+        if (step + 2 < T) load_b(step + 2);
+        if (boundary) halo_load(cb + 1);
+        compute(r, bbuf);
+        if (boundary) {
+            __syncthreads();                          // every wave is done with the halo
+            halo_store();
+        }
+        __syncthreads();
+        bbuf ^= 1;
+    }
+
+    // epilogue: lane -> pixel (lane & 15) of pixel tile m, channels 4 * (lane >> 4) .. + 3 of channel tile j
+    const float nslope = p.act == HOIG_ACT_NONE ? 1.f : (p.act == HOIG_ACT_RELU ? 0.f : p.slope);
+    const bool special = p.act == HOIG_ACT_TANH || p.act == HOIG_ACT_SIGMOID;
+    float4 bias_r[NTW];
+#pragma unroll
+    for (int j = 0; j < NTW; ++j) {
+        const int n = n0 + wn * (NTW * 16) + j * 16 + lg * 4;
+        bias_r[j] = (p.bias && n < p.N) ? *reinterpret_cast<const float4 *>(p.bias + n) : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+    float st1[NTW][4], st2[NTW][4];
+#pragma unroll
+    for (int j = 0; j < NTW; ++j)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) st1[j][q] = st2[j][q] = 0.f;
+#pragma unroll
+    for (int m = 0; m < MT; ++m) {
+        const int oy = y0 + wm * 2 + (m >> 1), ox = x0 + (m & 1) * 16 + l15;
+        const size_t pix = ((size_t)b * p.H + oy) * p.W + ox;
+#pragma unroll
+        for (int j = 0; j < NTW; ++j) {
+            const int n = n0 + wn * (NTW * 16) + j * 16 + lg * 4;
+            if (n < p.N) {
+                float v[4];
+                const float bq[4] = {bias_r[j].x, bias_r[j].y, bias_r[j].z, bias_r[j].w};
+#pragma unroll
+                for (int q = 0; q < 4; ++q) v[q] = fast_act(acc[j][m][q] * p.oscale + bq[q], nslope, special, p.act, p.slope);
+                if (p.addend) {
+                    const float4 ad = *reinterpret_cast<const float4 *>(p.addend + pix * p.N + n);
+                    v[0] += ad.x; v[1] += ad.y; v[2] += ad.z; v[3] += ad.w;
+                }
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    st1[j][q] += v[q];
+                    st2[j][q] += v[q] * v[q];
+                }
+                const float4 o = make_float4(v[0], v[1], v[2], v[3]);
+                if (!p.C2) *reinterpret_cast<float4 *>(p.C + pix * p.N + n) = o;
+                else if (n < p.n1) *reinterpret_cast<float4 *>(p.C + pix * p.n1 + n) = o;      // (a 64-column group goes one way)
+                else *reinterpret_cast<float4 *>(p.C2 + pix * (p.N - p.n1) + (n - p.n1)) = o;
+            }
+        }
+    }
+    if (p.stats) {
+        // instance-norm statistics of what was stored (halo_stats_epilogue of the 32x32 kernel): the 16 lanes of a channel
+        // quad hold different pixels (four xor steps), the WM waves with the same wn different rows (LDS, dead by now), then one
+        // atomic per (workgroup, channel, moment)
+#pragma unroll
+        for (int j = 0; j < NTW; ++j)
+#pragma unroll
+            for (int q = 0; q < 4; ++q)
+#pragma unroll
+                for (int o = 1; o < 16; o <<= 1) {
+                    st1[j][q] += __shfl_xor(st1[j][q], o);
+                    st2[j][q] += __shfl_xor(st2[j][q], o);
+                }
+        __syncthreads();
+        float *red = reinterpret_cast<float *>(smem);      // [WM][2][BN]
+        if (l15 == 0) {
+#pragma unroll
+            for (int j = 0; j < NTW; ++j)
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const int cl = wn * (NTW * 16) + j * 16 + lg * 4 + q;
+                    red[(wm * 2 + 0) * BN + cl] = st1[j][q];
+                    red[(wm * 2 + 1) * BN + cl] = st2[j][q];
+                }
+        }
+        __syncthreads();
+        float *stats_img = p.stats + (size_t)b * 2 * p.N;
+        for (int e = tid; e < 2 * BN; e += NT) {
+            const int mom = e / BN, cl = e - mom * BN;
+            float v = 0.f;
+#pragma unroll
+            for (int k = 0; k < WM; ++k) v += red[(k * 2 + mom) * BN + cl];
+            if (n0 + cl < p.N) atomicAdd(&stats_img[(size_t)mom * p.N + n0 + cl], v);
+        }
+    }
+}
+
+template <int NS, int BN>
+int launch_one(const HaloArgs &a, hipStream_t st) {
+    constexpr int WM = 4, WN = 2;
+    constexpr size_t shm = M16Layout<WM, BN>::bytes(NS);
+    static bool once = false;
+    if (!once) {
+        if (hipFuncSetAttribute(reinterpret_cast<const void *>(&conv_halo3_m16_kernel<NS, WM, WN, BN, true>),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm) != hipSuccess ||
+            hipFuncSetAttribute(reinterpret_cast<const void *>(&conv_halo3_m16_kernel<NS, WM, WN, BN, false>),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm) != hipSuccess)
+            return HOIG_ELAUNCH;
+        once = true;
+    }
+    if (a.f16) conv_halo3_m16_kernel<NS, WM, WN, BN, true><<<a.nblk, 64 * WM * WN, shm, st>>>(a);
+    else conv_halo3_m16_kernel<NS, WM, WN, BN, false><<<a.nblk, 64 * WM * WN, shm, st>>>(a);
+    HOIG_LAUNCH_CHECK();
+    return HOIG_OK;
+}
+
+}  // namespace
+
+// `a` arrives with the geometry of an 8-row tiling filled in (tiles_x / tiles_y / nblk_n / nblk / nmajor) for channel tiles
+// of `bn` = 128 or 64
+int launch_halo3_m16(HaloArgs a, int ns, int bn, hipStream_t st) {
+    if (a.H % 8 || a.W % 32 || a.Cg % 32 || a.N % 4) return HOIG_EUNSUPPORTED;
+    if (bn == 128) HOIG_NS_SWITCH(ns, return launch_one<NSX, 128>(a, st));
+    if (bn == 64) HOIG_NS_SWITCH(ns, return launch_one<NSX, 64>(a, st));
+    return HOIG_EUNSUPPORTED;
+}
+
+}  // namespace hoig_detail

@@ -13,7 +13,8 @@
 // 16-lane groups of ds_read_b128 hit 16 distinct slots of the 256-B bank row.
 // Shapes outside the fast path (gathered channels not a multiple of 32) return HOIG_EUNSUPPORTED and the caller uses the
 // exact-fp32 kernels of conv_igemm.hip.
-#include "common.h"
+#include "conv_bf16_common.h"
+#include "tuning.h"
 #include <cstdlib>
 
 // tools/wgrad_knockout.cpp builds this file with HOIG_WG_KO != 0 to time wgrad_halo_bf16_kernel with parts removed (results are
@@ -27,26 +28,8 @@
 #endif
 
 namespace {
+using namespace hoig_detail;
 
-// Number of 16-bit MFMA terms per algorithmic product, as the launchers' runtime `ns` and the kernels' NSX template value:
-//   1 : a*b ~= ah*bh                       one plane per operand                      (HOIG_PREC_BF16)
-//   2 : a*b ~= ah*bh + al*bh + ah*bl       both operands split hi + lo   (3 MFMAs)    (HOIG_PREC_BF16X3)
-//   3 : a*b ~= ah*bh + al*bh               A split, B = its rounded hi plane only (2 MFMAs: the B-side -- weight -- LDS image,
-//                                          its L2 stream and the ah*bl pass are dropped)                (HOIG_PREC_F16X2)
-#define HOIG_NS_SWITCH(ns, ...)                                                \
-    do {                                                                       \
-        if ((ns) == 2) { constexpr int NSX = 2; __VA_ARGS__; }                 \
-        else if ((ns) == 3) { constexpr int NSX = 3; __VA_ARGS__; }            \
-        else { constexpr int NSX = 1; __VA_ARGS__; }                           \
-    } while (0)
-__host__ __device__ constexpr int ns_a(int nsx) { return nsx == 1 ? 1 : 2; }
-__host__ __device__ constexpr int ns_b(int nsx) { return nsx == 2 ? 2 : 1; }
-inline int ns_of_precision(int precision) {
-    return precision == HOIG_PREC_BF16X3 ? 2 : (precision == HOIG_PREC_F16X2 ? 3 : 1);
-}
-inline bool is_16bit_precision(int precision) {
-    return precision == HOIG_PREC_BF16X3 || precision == HOIG_PREC_BF16 || precision == HOIG_PREC_F16X2;
-}
 
 struct Geom {
     int Bn, Hg, Wg, Cg;
@@ -111,63 +94,6 @@ __device__ __forceinline__ bool tap_alive(const Geom &g, int hp, int wp, int rs)
     return (((hp + g.pad - r) & 1) == 0) && (((wp + g.pad - s) & 1) == 0);
 }
 
-typedef __bf16 bf2_t __attribute__((ext_vector_type(2)));
-typedef float f2_t __attribute__((ext_vector_type(2)));
-// two fp32 -> packed bf16 pair (round to nearest even): one v_cvt_pk_bf16_f32
-__device__ __forceinline__ unsigned cvt2(float a, float b) {
-    f2_t v = {a, b};
-    return __builtin_bit_cast(unsigned, __builtin_convertvector(v, bf2_t));
-}
-// FORWARD operands are split on fp16 instead (11-bit mantissas: x = hi + lo to 2^-22, the three products to ~2^-21 at the
-// same MFMA rate): the error of the forward point, not the backward arithmetic, sets the gradient parity of the fast mode
-// (precision).  Forward activations are O(1)-O(100) (post-norm / images / VGG features), far inside fp16's
-// range; weights are scaled by 2^8 when they are split (exact) and the accumulator by 2^-8 in the epilogue.
-typedef _Float16 h2_t __attribute__((ext_vector_type(2)));
-typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
-constexpr float W_SCALE_F16 = 256.f;
-__device__ __forceinline__ unsigned cvt2h(float a, float b) {
-    f2_t v = {a, b};
-    return __builtin_bit_cast(unsigned, __builtin_convertvector(v, h2_t));
-}
-__device__ __forceinline__ void split4h(const float4 v, uint2 &hi, uint2 &lo) {
-    hi.x = cvt2h(v.x, v.y);
-    hi.y = cvt2h(v.z, v.w);
-    const h2_t h0 = __builtin_bit_cast(h2_t, hi.x), h1 = __builtin_bit_cast(h2_t, hi.y);
-    lo.x = cvt2h(v.x - (float)h0[0], v.y - (float)h0[1]);
-    lo.y = cvt2h(v.z - (float)h1[0], v.w - (float)h1[1]);
-}
-template <bool F16>
-__device__ __forceinline__ f32x16 mfma16(const bf16x8 a, const bf16x8 b, const f32x16 c) {
-    if constexpr (F16)
-        return __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, a), __builtin_bit_cast(f16x8, b), c, 0, 0, 0);
-    else
-        return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0);
-}
-
-// hi = bf16(x), lo = bf16(x - hi) for four values
-__device__ __forceinline__ void split4(const float4 v, uint2 &hi, uint2 &lo) {
-    hi.x = cvt2(v.x, v.y);
-    hi.y = cvt2(v.z, v.w);
-    const float r0 = v.x - __uint_as_float(hi.x << 16), r1 = v.y - __uint_as_float(hi.x & 0xFFFF0000u);
-    const float r2 = v.z - __uint_as_float(hi.y << 16), r3 = v.w - __uint_as_float(hi.y & 0xFFFF0000u);
-    lo.x = cvt2(r0, r1);
-    lo.y = cvt2(r2, r3);
-}
-template <bool F16>
-__device__ __forceinline__ void split4t(const float4 v, uint2 &hi, uint2 &lo) {
-    if constexpr (F16) split4h(v, hi, lo);
-    else split4(v, hi, lo);
-}
-
-// Layout of a packed bf16 weight plane in HBM: 32(n) x 32(k) blocks, each 2 KB contiguous, block (n/32, k/32) at
-// ((n/32) * (K/32) + k/32) * 1024.  The weight tile of one k-step (BN rows x 32 k) is then BN/32 fully used 2-KB runs
-// instead of BN half-used 128-B lines K*2 bytes apart; N and K are multiples of 32 on this path.  Inside a block, row n
-// holds its four 16-B chunks at position chunk ^ ((n >> 2) & 3): the block is byte for byte the XOR-swizzled LDS image
-// the kernels read (lds_swz<32>), so a tile can be copied to LDS linearly -- by global_load_lds, 1 KB per wave-instruction.
-__host__ __device__ __forceinline__ size_t plane_index(int n, int k, int K) {
-    return ((size_t)(n >> 5) * (K >> 5) + (k >> 5)) * 1024 + (n & 31) * 32 + (((((k & 31) >> 3) ^ ((n >> 2) & 3))) << 3) +
-           (k & 7);
-}
 
 // LDS plane = [rows][BK] bf16; the 16-B chunk index of a row is XOR-ed with a row-dependent value so that the 16-lane
 // groups of ds_read_b128 (rows r..r+3, r+12.., r+20..) fall on 16 distinct slots of the 256-B bank row:
@@ -550,36 +476,6 @@ int launch(Args a, int ns, hipStream_t st) {
 // Halo rows are 80 B apart (64 B of data + 16 B pad): any 16 consecutive rows fall on 16 distinct 16-B bank slots, so
 // ds_read_b128 stays conflict-free at every tap shift without an address-dependent swizzle.
 // Used for conv fwd (stride 1) and for the data gradient of stride-1 convs (taps walked flipped).
-struct HaloArgs {
-    const float *A;
-    const unsigned short *Wh, *Wl;
-    const float *bias;
-    float *C;
-    int Bn, H, W, Cg;       // input == output spatial size (stride 1, "same" padding), gathered channels
-    int N, K;               // output channels, KS*KS*Cg
-    int pad;                // halo origin = tile origin - pad   (dgrad: KS-1-pad)
-    int flip;               // 1: weight tap index = KS*KS-1 - (r*KS+s)   (data gradient)
-    int act;
-    float slope;
-    int nblk_n, nblk;
-    int tiles_x, tiles_y;
-    int nmajor;                // tile index = channel tile * pixel tiles + pixel tile (3x3 kernel)
-    int f16;                   // forward launch: fp16-split operands, weights pre-scaled by 2^8
-    float oscale;              // accumulator scale of the epilogue (2^-8 or 1)
-    // channel concatenation without the copy (3x3 kernel): the gathered tensor is [A | A2] along channels (A holds the
-    // first cg1 of the Cg channels), and / or the output is [C | C2] (C receives the first n1 of the N columns)
-    const float *A2;
-    int cg1;
-    float *C2;
-    int n1;
-    const float *addend;       // same shape as C (single-output launches only): C = conv + addend -- the data gradient that lands in
-                               // a tensor with a second consumer adds that consumer's gradient itself (ops.conv2d_fork)
-    float *stats;              // (nullable) [Bn][2][N] fp32 accumulators: += per-image, per-channel sum and sum of squares of the
-                               // values written to C -- the statistics of the instance norm that reads C next
-#ifdef HOIG_STAMP
-    unsigned long long *dbg;   // diagnostic build only (tools/stamp_halo.py): per-wave cycle sums of the step phases
-#endif
-};
 
 // Instance-norm statistics from a convolution's epilogue.  s1 / s2: the lane's sums of v and v*v over the pixels it stored, per
 // 32-channel column group j (channel = n0 + wn * TN * 32 + j * 32 + (lane & 31)).  The two 32-lane halves hold different pixels of
@@ -1179,16 +1075,19 @@ int launch_halo3(HaloArgs a, int ns, hipStream_t st) {
     a.nblk_n = (int)hoig_cdiv(a.N, n64 ? 64 : 128);
     a.nblk = a.Bn * a.tiles_x * a.tiles_y * a.nblk_n;
     if (n64) HOIG_NS_SWITCH(ns, return launch_halo3_one<NSX, 2, 2, 64, 0>(a, st));
+    const bool m16 = hoig_tuning(HOIG_TUNE_MFMA16) != 0;      // the 8-row tilings on v_mfma_f32_16x16x32 (conv_halo16.hip)
     if (a.H % 8 == 0 && a.nblk / 2 < 256 && a.nblk >= 192) {   // too few 8-row tiles at BN = 128: 8 rows x 64 channels
         a.tiles_y = a.H / 8;
         a.nblk_n = a.N / 64;
         a.nblk = a.Bn * a.tiles_x * a.tiles_y * a.nblk_n;
+        if (m16) return launch_halo3_m16(a, ns, 64, st);
         HOIG_NS_SWITCH(ns, return launch_halo3_one<NSX, 4, 2, 64, 2>(a, st));
     }
     // 8 x 32 pixel tiles (8 waves, weight tile shared by 256 pixels) when that still gives every CU a workgroup
     if (a.H % 8 == 0 && a.nblk / 2 >= 256) {
         a.tiles_y = a.H / 8;
         a.nblk = a.Bn * a.tiles_x * a.tiles_y * a.nblk_n;
+        if (m16) return launch_halo3_m16(a, ns, 128, st);
         HOIG_NS_SWITCH(ns, return launch_halo3_one<NSX, 4, 2, 128, 2>(a, st));
     }
     const bool wide = a.nblk < 384;

@@ -399,6 +399,12 @@ int hoig_rasterize_fim_wim(const float *faces, int B, int F, int image_size, flo
 
 const char *hoig_version(void);
 
+/* Kernel-variant choices that are tuning, not semantics (every value computes the same result up to summation order): one table
+ * instead of per-variant environment switches.  key -> value; returns the previous value, or -1 for an unknown key; value < 0 only
+ * queries.  Keys: "mfma16" (1: the 8-row 3x3 stride-1 tilings run on v_mfma_f32_16x16x32, conv_halo16.hip; 0: on 32x32x16).
+ * Process-wide, not synchronised: set before launching. */
+int hoig_set_tuning(const char *key, int value);
+
 /* ---- MANO hand layer: pose / shape parameters -> skinned hand vertices, the step in front of the rasteriser.
  *      Replaces, for this path, smplx 0.1.28's MANO layer (HOIG_HOv3/models/networks/hmr.py:55,84-85: `mano_layer_right(global_orient,
  *      hand_pose, betas, transl).vertices`, use_pca=False, flat_hand_mean=True) and manopth's ManoLayer (HOIG_DexYCB/models/networks/

@@ -1,0 +1,126 @@
+"""The 3x3 stride-1 halo kernel on v_mfma_f32_16x16x32 (hoig_amd/csrc/conv_halo16.hip, tuning key 'mfma16') against the 32x32x16
+kernels it replaces (same split arithmetic, another summation order) and against torch's fp32 convolution: forward, data gradient,
+bias / activation / addend / statistics epilogues, the two-tensor input and the two-tensor output of the decoder's skip convolution.
+Shapes are chosen so that the launcher picks the 8-row tilings (128- and 64-channel tiles) the key switches."""
+import pytest
+import torch
+import torch.nn.functional as F
+
+from gpu_util import rel_err
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture
+def tuning():
+    from hoig_amd import _lib as L
+    prev = L.set_tuning('mfma16', 0)
+    yield L
+    L.set_tuning('mfma16', prev)
+
+
+def _both(L, fn):
+    out = []
+    for v in (0, 1):
+        L.set_tuning('mfma16', v)
+        out.append(fn())
+    torch.cuda.synchronize()
+    return out
+
+
+CASES = [
+    # B, Ci, Co, H, W                   tiling the launcher picks
+    (8, 64, 256, 64, 64),       # 8 x 32 x 128
+    (16, 512, 512, 32, 32),     # 8 x 32 x 128: the step's dominant launch
+    (8, 96, 128, 64, 64),       # 8 x 32 x 64  (three channel blocks)
+    (8, 512, 512, 32, 32),      # 8 x 32 x 64: the 8-image launches of src_model / tsf_model
+    (2, 128, 512, 32, 128),     # 8 x 32 x 64, four tile columns
+]
+
+
+@pytest.mark.parametrize('mode', ['bf16x3', 'f16x2'])
+@pytest.mark.parametrize('B,Ci,Co,H,W', CASES)
+def test_m16_forward_and_data_gradient(tuning, B, Ci, Co, H, W, mode):
+    from hoig_amd import ops
+    L = tuning
+    g = torch.Generator().manual_seed(5)
+    x = (torch.randn(B, H, W, Ci, generator=g) * 1.5 + 0.3).cuda()
+    w = (torch.randn(Co, Ci, 3, 3, generator=g) * 0.05)
+    bias = torch.randn(Co, generator=g).cuda()
+    gy = torch.randn(B, H, W, Co, generator=g).cuda()
+    addend = torch.randn(B, H, W, Ci, generator=g).cuda()
+    wd = ops.pack_weight(w.cuda())
+    ops.set_precision(mode)
+    try:
+        def run():
+            xd = x.clone().requires_grad_(True)
+            x1 = ops.add(xd, xd)
+            y, x2 = ops.conv2d_fork(x1, wd.clone().requires_grad_(True), bias, 1, 1, act=L.ACT_LRELU, slope=0.2)
+            ((y * gy).sum() + (x2 * addend).sum()).backward()
+            return y.detach(), xd.grad
+        (y0, dx0), (y1, dx1) = _both(L, run)
+    finally:
+        ops.set_precision('f32')
+    # the same products in another order
+    assert rel_err(y1, y0) < 2e-6 and rel_err(dx1, dx0) < 2e-6
+    # and an independent reference: torch fp32 on the device
+    # (the activation mask is taken from the device's own output: a LeakyReLU mask one rounding away from the reference's would
+    # put isolated large errors into the max-norm of the gradient)
+    xr = (2 * x).permute(0, 3, 1, 2).clone().requires_grad_(True)
+    hr = F.conv2d(xr, w.cuda(), bias, padding=1)
+    yr = F.leaky_relu(hr, 0.2)
+    slope = torch.where(y1 > 0, torch.ones_like(y1), torch.full_like(y1, 0.2))
+    (hr * (gy * slope).permute(0, 3, 1, 2)).sum().backward()
+    dxr = 2 * (xr.grad.permute(0, 2, 3, 1) + addend)
+    bf, bd = (3e-4, 3e-4) if mode == 'bf16x3' else (1e-3, 8e-3)
+    assert rel_err(y1, yr.permute(0, 2, 3, 1)) < bf
+    assert rel_err(dx1, dxr) < bd
+
+
+@pytest.mark.parametrize('B,C1,C2,Co,H,W', [(4, 256, 256, 256, 32, 128), (8, 64, 128, 256, 64, 64)])
+def test_m16_two_tensor_input_and_output(tuning, B, C1, C2, Co, H, W):
+    """ops.conv2d_cat2: the halo loader reads [x1 | x2] by channel block, the data gradient writes [dx1 | dx2]."""
+    from hoig_amd import ops
+    L = tuning
+    g = torch.Generator().manual_seed(9)
+    x1 = torch.randn(B, H, W, C1, generator=g).cuda()
+    x2 = torch.randn(B, H, W, C2, generator=g).cuda()
+    w = ops.pack_weight((torch.randn(Co, C1 + C2, 3, 3, generator=g) * 0.05).cuda())
+    gy = torch.randn(B, H, W, Co, generator=g).cuda()
+
+    def run():
+        a1, a2 = x1.clone().requires_grad_(True), x2.clone().requires_grad_(True)
+        y = ops.conv2d_cat2(a1, a2, w.clone().requires_grad_(True), prec=L.PREC_BF16X3)
+        y.backward(gy)
+        return y.detach(), a1.grad, a2.grad
+    (y0, d10, d20), (y1, d11, d21) = _both(L, run)
+    assert rel_err(y1, y0) < 2e-6 and rel_err(d11, d10) < 2e-6 and rel_err(d21, d20) < 2e-6
+    yr = F.conv2d(torch.cat([x1, x2], 3).permute(0, 3, 1, 2), w.permute(0, 1, 2, 3).contiguous(), padding=1)
+    assert rel_err(y1, yr.permute(0, 2, 3, 1)) < 3e-4
+
+
+@pytest.mark.parametrize('B,Ci,Co,H,W', [(8, 64, 128, 64, 64), (8, 64, 256, 64, 64)])
+def test_m16_statistics_epilogue(tuning, B, Ci, Co, H, W):
+    """conv -> instance norm with the statistics taken from the convolution's epilogue (hoig_conv2d_fwd_packed_stats)."""
+    from hoig_amd import ops
+    L = tuning
+    g = torch.Generator().manual_seed(13)
+    x = (torch.randn(B, H, W, Ci, generator=g) + 0.5).cuda()
+    w = ops.pack_weight((torch.randn(Co, Ci, 3, 3, generator=g) * 0.05).cuda())
+    ops.set_precision('bf16x3')
+    try:
+        def run():
+            ops._stats_pending.clear()
+            h = ops.conv2d(x, w, None, 1, 1, dead_bias=True)
+            assert len(ops._stats_pending) == 1
+            y = ops.instance_norm(h)
+            assert not ops._stats_pending
+            return h, y
+        (h0, y0), (h1, y1) = _both(L, run)
+    finally:
+        ops.set_precision('f32')
+    assert rel_err(h1, h0) < 2e-6 and rel_err(y1, y0) < 1e-5
+    yr = F.instance_norm(h1.permute(0, 3, 1, 2), eps=1e-5).permute(0, 2, 3, 1)
+    assert rel_err(y1, yr) < 1e-4
+    for ws in ops._norm_ws.values():
+        assert float(ws[:1 << 18].abs().max()) == 0.0

@@ -1,0 +1,84 @@
+"""A/B of kernel-variant choices (hoig_set_tuning keys) on single convolution launches: interleaved rounds in ONE process on random
+data (cdna_hip_programming.md rules 24, 25), HIP events on the launch stream, median and min per variant.
+Usage: python tools/ab_conv.py "mfma16=0" "mfma16=1" [--shapes dominant] [--rounds 7] [--iters 20] [--prec bf16x3:f16x2]
+Shape sets: 'dominant' (3x3 512->512 at 32x32, 16 and 8 images), 's1' (every 3x3 stride-1 shape of the step with >= 0.2 ms)."""
+import argparse
+import ctypes
+import os
+import statistics
+import sys
+
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from hoig_amd import ops, _lib as L          # noqa: E402
+
+SHAPES = {
+    'dominant': [(16, 512, 512, 32, 32, 3), (8, 512, 512, 32, 32, 3)],
+    's1': [(16, 512, 512, 32, 32, 3), (8, 512, 512, 32, 32, 3), (8, 128, 1024, 32, 32, 3), (16, 128, 1024, 32, 32, 3),
+           (8, 256, 256, 64, 64, 3), (8, 128, 256, 128, 128, 3), (16, 128, 256, 128, 128, 3), (8, 128, 128, 128, 128, 3),
+           (8, 128, 512, 64, 64, 3), (16, 128, 512, 64, 64, 3), (8, 64, 64, 256, 256, 3), (8, 64, 128, 128, 128, 3)],
+    'attn5': [(8, 512, 128, 40, 40, 5), (8, 512, 128, 36, 36, 5), (8, 128, 128, 136, 136, 5), (8, 256, 128, 72, 72, 5)],
+}
+
+
+def parse(v):
+    return dict((k, int(x)) for k, x in (kv.split('=') for kv in v.split(',') if kv))
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('variants', nargs='+')
+    ap.add_argument('--shapes', default='dominant')
+    ap.add_argument('--rounds', type=int, default=7)
+    ap.add_argument('--iters', type=int, default=20)
+    ap.add_argument('--prec', default='bf16x3:f16x2')
+    ap.add_argument('--kinds', default='fwd,dgrad,wgrad')
+    a = ap.parse_args()
+    ops.set_precision(a.prec)
+    variants = [parse(v) for v in a.variants]
+    st = torch.cuda.current_stream().cuda_stream
+    p = lambda t: t.data_ptr()
+    print('precision %s, %d rounds x %d launches, random data' % (a.prec, a.rounds, a.iters))
+    for (B, Ci, Co, H, W, k) in SHAPES[a.shapes]:
+        pad = 1 if k == 3 else 0
+        Ho, Wo = H + 2 * pad - k + 1, W + 2 * pad - k + 1
+        x = torch.randn(B, H, W, Ci, device='cuda')
+        w = ops.pack_weight((torch.randn(Co, Ci, k, k, device='cuda') * 0.02))
+        dy = torch.randn(B, Ho, Wo, Co, device='cuda')
+        y, dx, dw = torch.empty_like(dy), torch.empty_like(x), torch.zeros_like(w)
+        d = L.ConvDesc(B, H, W, Ci, Ho, Wo, Co, k, k, 1, pad, 0, 0, 0.0, ops.precision)
+        d_dg, d_wg = ops._bwd_descs(d)
+        hi, lo = ops._packed_planes(w, False, False)
+        thi, tlo = ops._packed_planes(w, False, True)
+        fns = {
+            'fwd': lambda: L.call('hoig_conv2d_fwd_packed', ctypes.byref(d), p(x), p(hi), p(lo), None, p(y), st),
+            'dgrad': lambda: L.call('hoig_conv2d_bwd_data_packed', ctypes.byref(d_dg), p(dy), p(thi), p(tlo), p(dx), st),
+            'wgrad': lambda: L.call('hoig_conv2d_bwd_weight', ctypes.byref(d_wg), p(x), p(dy), p(dw), None, st),
+        }
+        flop = 2.0 * B * Ho * Wo * Ci * Co * k * k
+        for kind in a.kinds.split(','):
+            fn = fns[kind]
+            times = [[] for _ in variants]
+            for r in range(a.rounds + 1):
+                for vi, v in enumerate(variants):
+                    for key, val in v.items():
+                        L.set_tuning(key, val)
+                    fn()
+                    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                    e0.record()
+                    for _ in range(a.iters):
+                        fn()
+                    e1.record()
+                    torch.cuda.synchronize()
+                    if r:                      # round 0 warms up
+                        times[vi].append(e0.elapsed_time(e1) / a.iters * 1e3)
+            line = '%-5s %2d %3dx%-3d %4d->%-4d k%d |' % (kind, B, H, W, Ci, Co, k)
+            for v, t in zip(a.variants, times):
+                med, mn = statistics.median(t), min(t)
+                line += '  [%s] med %7.1f us %6.1f TF  min %7.1f us |' % (v, med, flop / med / 1e6, mn)
+            print(line, flush=True)
+
+
+if __name__ == '__main__':
+    main()
