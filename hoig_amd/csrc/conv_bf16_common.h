@@ -114,6 +114,94 @@ struct HaloArgs {
 #endif
 };
 
+// geometry and argument block of the generic implicit-GEMM kernels (igemm_bf16_kernel in conv_igemm_bf16.hip, conv_igemm16.hip)
+struct Geom {
+    int Bn, Hg, Wg, Cg;
+    int Hp, Wp;
+    int R, S, stride, pad;
+    int gatherT, phase_major, tile_skip;
+};
+
+struct Args {
+    const float *A;
+    const unsigned short *Wh;
+    const unsigned short *Wl;
+    const float *bias;
+    float *C;
+    Geom g;
+    int M, N, K;
+    int act;
+    float slope;
+    int nblk_n, nblk;
+    int ksplit, steps_per_split;   // split-K over blockIdx.y (atomic epilogue into a zeroed output)
+    int f16;                       // forward launch: fp16-split operands, weights pre-scaled by 2^8
+    float oscale;                  // accumulator scale of the epilogue (2^-8 or 1)
+};
+
+__device__ __forceinline__ void decode_m(const Geom &g, int m, int &b, int &hp, int &wp) {
+    if (!g.phase_major) {
+        const int hw = g.Hp * g.Wp;
+        b = m / hw;
+        const int rem = m - b * hw;
+        hp = rem / g.Wp;
+        wp = rem - hp * g.Wp;
+    } else {
+        const int W2 = g.Wp >> 1, q = (g.Hp >> 1) * W2, bq = g.Bn * q;
+        const int ph = m / bq;
+        const int rem = m - ph * bq;
+        b = rem / q;
+        const int r2 = rem - b * q;
+        const int h2 = r2 / W2;
+        hp = 2 * h2 + (ph >> 1);
+        wp = 2 * (r2 - h2 * W2) + (ph & 1);
+    }
+}
+__device__ __forceinline__ int row_base(const Geom &g, int p) { return g.gatherT ? p + g.pad : p * g.stride - g.pad; }
+__device__ __forceinline__ int gcoord(const Geom &g, int base, int r, int lim) {
+    if (!g.gatherT) {
+        const int c = base + r;
+        return (c >= 0 && c < lim) ? c : -1;
+    }
+    int t = base - r;
+    if (t < 0) return -1;
+    if (g.stride == 2) {
+        if (t & 1) return -1;
+        t >>= 1;
+    } else if (g.stride != 1) {
+        if (t % g.stride) return -1;
+        t /= g.stride;
+    }
+    return t < lim ? t : -1;
+}
+__device__ __forceinline__ bool tap_alive(const Geom &g, int hp, int wp, int rs) {
+    const int r = rs / g.S, s = rs - r * g.S;
+    return (((hp + g.pad - r) & 1) == 0) && (((wp + g.pad - s) & 1) == 0);
+}
+
+// conv_igemm16.hip: the generic implicit GEMM on v_mfma_f32_16x16x32 (same tiles, split-K rule and geometry handling as
+// launch<BM, BN, WM, WN> of conv_igemm_bf16.hip; `cfg` = 0: 128x128 on 4 waves, 1: 128x128 on 8 waves, 2: 64x128, 3: 128x64, 4: 64x64)
+int launch_igemm_m16(Args a, int ns, int cfg, hipStream_t st);
+
+// argument block of the weight-gradient halo kernels (wgrad_halo_bf16_kernel in conv_igemm_bf16.hip, wgrad_halo16.hip)
+struct WHaloArgs {
+    const float *DY, *X, *X2;  // X2 (nullable): the input is [X | X2] along channels, X holding the first ci1
+    int ci1;
+    float *DW, *DB;            // DB (nullable): bias gradient = column sums of dy, taken from the dy tiles as they are staged
+    int Bn, H, W, Co, Ci;     // H, W: output (= dy) size
+    int Hin, Win, pad;         // input (= x) size and padding
+    int tout;                  // 1: the accumulator tile is [DY channel][X channel] but DW is laid out [X channel][tap][DY channel]
+                               // (ConvTranspose2d stride 2: the plain operand is x, the gathered one dy -- roles swapped)
+    int tiles_x, tiles_y, n_mtiles, mt_per_split;
+    int nblk_ci, nblk;
+#ifdef HOIG_STAMP
+    unsigned long long *dbg;
+#endif
+};
+
+// wgrad_halo16.hip: the stride-1 3x3 weight gradient on v_mfma_f32_16x16x32 (`a` carries the tiling: th = 2 or 4 pixel rows per
+// tile, cm = 1 or 2 groups of 64 dy channels per workgroup); HOIG_EUNSUPPORTED for what it has no variant for
+int launch_wgrad_halo_m16(const WHaloArgs &a, int ns, int th, int cm, dim3 grid, hipStream_t st);
+
 // conv_halo16.hip: the 3x3 stride-1 halo kernel on v_mfma_f32_16x16x32 (8 rows x 32 pixels x bn channels per workgroup, bn = 128
 // or 64; `a` carries that tiling's geometry); HOIG_EUNSUPPORTED for shapes it has no tiling for
 int launch_halo3_m16(HaloArgs a, int ns, int bn, hipStream_t st);

@@ -31,70 +31,6 @@ namespace {
 using namespace hoig_detail;
 
 
-struct Geom {
-    int Bn, Hg, Wg, Cg;
-    int Hp, Wp;
-    int R, S, stride, pad;
-    int gatherT, phase_major, tile_skip;
-};
-
-struct Args {
-    const float *A;
-    const unsigned short *Wh;
-    const unsigned short *Wl;
-    const float *bias;
-    float *C;
-    Geom g;
-    int M, N, K;
-    int act;
-    float slope;
-    int nblk_n, nblk;
-    int ksplit, steps_per_split;   // split-K over blockIdx.y (atomic epilogue into a zeroed output)
-    int f16;                       // forward launch: fp16-split operands, weights pre-scaled by 2^8
-    float oscale;                  // accumulator scale of the epilogue (2^-8 or 1)
-};
-
-__device__ __forceinline__ void decode_m(const Geom &g, int m, int &b, int &hp, int &wp) {
-    if (!g.phase_major) {
-        const int hw = g.Hp * g.Wp;
-        b = m / hw;
-        const int rem = m - b * hw;
-        hp = rem / g.Wp;
-        wp = rem - hp * g.Wp;
-    } else {
-        const int W2 = g.Wp >> 1, q = (g.Hp >> 1) * W2, bq = g.Bn * q;
-        const int ph = m / bq;
-        const int rem = m - ph * bq;
-        b = rem / q;
-        const int r2 = rem - b * q;
-        const int h2 = r2 / W2;
-        hp = 2 * h2 + (ph >> 1);
-        wp = 2 * (r2 - h2 * W2) + (ph & 1);
-    }
-}
-__device__ __forceinline__ int row_base(const Geom &g, int p) { return g.gatherT ? p + g.pad : p * g.stride - g.pad; }
-__device__ __forceinline__ int gcoord(const Geom &g, int base, int r, int lim) {
-    if (!g.gatherT) {
-        const int c = base + r;
-        return (c >= 0 && c < lim) ? c : -1;
-    }
-    int t = base - r;
-    if (t < 0) return -1;
-    if (g.stride == 2) {
-        if (t & 1) return -1;
-        t >>= 1;
-    } else if (g.stride != 1) {
-        if (t % g.stride) return -1;
-        t /= g.stride;
-    }
-    return t < lim ? t : -1;
-}
-__device__ __forceinline__ bool tap_alive(const Geom &g, int hp, int wp, int rs) {
-    const int r = rs / g.S, s = rs - r * g.S;
-    return (((hp + g.pad - r) & 1) == 0) && (((wp + g.pad - s) & 1) == 0);
-}
-
-
 // LDS plane = [rows][BK] bf16; the 16-B chunk index of a row is XOR-ed with a row-dependent value so that the 16-lane
 // groups of ds_read_b128 (rows r..r+3, r+12.., r+20..) fall on 16 distinct slots of the 256-B bank row:
 //   BK = 32 (64-B rows, 4 chunks): chunk ^ ((row >> 2) & 3)      BK = 64 (128-B rows, 8 chunks): chunk ^ ((row >> 1) & 7)
@@ -1074,8 +1010,16 @@ int launch_halo3(HaloArgs a, int ns, hipStream_t st) {
     const bool n64 = (a.N % 128) != 0 || (a.C2 && a.n1 % 128 != 0);      // (a channel tile must not straddle the two outputs)
     a.nblk_n = (int)hoig_cdiv(a.N, n64 ? 64 : 128);
     a.nblk = a.Bn * a.tiles_x * a.tiles_y * a.nblk_n;
-    if (n64) HOIG_NS_SWITCH(ns, return launch_halo3_one<NSX, 2, 2, 64, 0>(a, st));
     const bool m16 = hoig_tuning(HOIG_TUNE_MFMA16) != 0;      // the 8-row tilings on v_mfma_f32_16x16x32 (conv_halo16.hip)
+    if (n64) {
+        // 64-channel layers (the full-resolution levels): 8 x 32 x 64 on the 16x16 MFMA where that leaves every CU a workgroup
+        if (m16 && a.H % 8 == 0 && a.nblk / 2 >= 256) {
+            a.tiles_y = a.H / 8;
+            a.nblk = a.Bn * a.tiles_x * a.tiles_y * a.nblk_n;
+            return launch_halo3_m16(a, ns, 64, st);
+        }
+        HOIG_NS_SWITCH(ns, return launch_halo3_one<NSX, 2, 2, 64, 0>(a, st));
+    }
     if (a.H % 8 == 0 && a.nblk / 2 < 256 && a.nblk >= 192) {   // too few 8-row tiles at BN = 128: 8 rows x 64 channels
         a.tiles_y = a.H / 8;
         a.nblk_n = a.N / 64;
@@ -1631,16 +1575,17 @@ int run(const hoig_conv_desc *d, const float *a, const unsigned short *wh, const
         }
     }
     if (addend || stats) return HOIG_EUNSUPPORTED;
+    const bool m16 = hoig_tuning(HOIG_TUNE_IGEMM16) != 0;      // on v_mfma_f32_16x16x32 (conv_igemm16.hip)
     if (p.N <= 64) {
-        if (t128 >= 512) return launch<128, 64, 2, 2>(p, ns, st);
-        return launch<64, 64, 2, 2>(p, ns, st);
+        if (t128 >= 512) return m16 ? launch_igemm_m16(p, ns, 3, st) : launch<128, 64, 2, 2>(p, ns, st);
+        return m16 ? launch_igemm_m16(p, ns, 4, st) : launch<64, 64, 2, 2>(p, ns, st);
     }
     const long n128 = hoig_cdiv(p.N, 128);
     // fewer than two 128x128 workgroups per CU: run 8 waves per workgroup so every SIMD still holds two waves and one
     // wave's bf16 split (VALU) overlaps the other's MFMAs.  (A BK = 64, double-buffered variant measured slower.)
-    if (t128 * n128 >= 512) return launch<128, 128, 2, 2>(p, ns, st);
-    if (t128 * n128 >= 128) return launch<128, 128, 2, 4>(p, ns, st);
-    return launch<64, 128, 2, 2>(p, ns, st);
+    if (t128 * n128 >= 512) return m16 ? launch_igemm_m16(p, ns, 0, st) : launch<128, 128, 2, 2>(p, ns, st);
+    if (t128 * n128 >= 128) return m16 ? launch_igemm_m16(p, ns, 1, st) : launch<128, 128, 2, 4>(p, ns, st);
+    return m16 ? launch_igemm_m16(p, ns, 2, st) : launch<64, 128, 2, 2>(p, ns, st);
 }
 
 }  // namespace
@@ -1982,20 +1927,6 @@ int launch_wgrad_bf16(WArgs a, int ns, hipStream_t st) {
 // of its row (48 accumulator registers, so three workgroups = 18 waves share a CU).
 // Both operands want pixels along k, so both are read with ds_read_b64_tr_b16; the halo rows are 64 B apart (no pad):
 // the four rows a 32-lane half reads (256 B) cover all 64 banks once for any row offset.  dy rows are 192 B apart.
-struct WHaloArgs {
-    const float *DY, *X, *X2;  // X2 (nullable): the input is [X | X2] along channels, X holding the first ci1
-    int ci1;
-    float *DW, *DB;            // DB (nullable): bias gradient = column sums of dy, taken from the dy tiles as they are staged
-    int Bn, H, W, Co, Ci;     // H, W: output (= dy) size
-    int Hin, Win, pad;         // input (= x) size and padding
-    int tout;                  // 1: the accumulator tile is [DY channel][X channel] but DW is laid out [X channel][tap][DY channel]
-                               // (ConvTranspose2d stride 2: the plain operand is x, the gathered one dy -- roles swapped)
-    int tiles_x, tiles_y, n_mtiles, mt_per_split;
-    int nblk_ci, nblk;
-#ifdef HOIG_STAMP
-    unsigned long long *dbg;
-#endif
-};
 
 // KS = 3: "same" 3x3 (pad 1, input = output size).  KS = 5: the attention's 5x5 VALID convolution over the replicate-padded
 // target (input (H+4) x (W+4), pad 0): ten waves = co half x tap row, five taps each.
@@ -2311,6 +2242,10 @@ int launch_wgrad_halo(const hoig_conv_desc *d, const float *x, const float *dy, 
 #ifdef HOIG_STAMP
     a.dbg = g_stamp_buf;
 #endif
+    if (hoig_tuning(HOIG_TUNE_WGRAD16) != 0 && d->R == 3 && !s2 && !d->transposed) {      // on v_mfma_f32_16x16x32 (wgrad_halo16.hip)
+        const int rc = launch_wgrad_halo_m16(a, ns, th4 ? 4 : 2, cm, grid, st);
+        if (rc != HOIG_EUNSUPPORTED) return rc;
+    }
     if (th4) {
         constexpr int LDS4 = 2 * (4 * 32 * 320) + (((6 * 34 * 64) + 255) / 256) * 256;      // dy hi, lo | x hi
         static bool once = false;

@@ -9,7 +9,9 @@ struct Entry {
     int value;
 };
 Entry g_table[HOIG_TUNE_COUNT] = {
-    {"mfma16", 0},
+    {"mfma16", 1},
+    {"wgrad16", 0},
+    {"igemm16", 0},
 };
 }  // namespace
 

@@ -1,0 +1,262 @@
+// Weight gradient of stride-1 "same" 3x3 convolutions on v_mfma_f32_16x16x32_bf16: the structure of wgrad_halo_bf16_kernel
+// (conv_igemm_bf16.hip) -- a workgroup owns dW[64*CM co][9 taps][32 ci], stages per pixel tile (TH x 32) the dy tile and the x
+// halo once, wave = (32-channel group of co) x (tap row) with the three taps of its row accumulated side by side -- on the
+// 16x16 MFMA shape (K = 32 pixels: one tile row per instruction), which holds a higher clock on random data than 32x32x16
+// (MI355X_MICROARCH.md 'DVFS give-back' item 7).
+//
+// Both operands want PIXELS along k and arrive channel-contiguous, so both are read with ds_read_b64_tr_b16.  LDS images: one
+// sub-image per 16-channel tile, [pixel][32 B], so that the eight pixel rows a 32-lane half reads are 256 contiguous bytes at
+// any tap shift (conflict-free).  16-lane group g of a fragment takes pixels {4g .. 4g+3} and {16+4g .. 16+4g+3} of the row:
+// the k order inside an MFMA is free as long as both operands agree.  Sub-images are skewed by 32 B (dy: four per ds_write_b64
+// lane group) / 64 B (x: two) so that the staging stores cover a whole 128-B bank window.
+//
+// Epilogue: dW[co][tap][ci] += acc.  The 16x16 result has ci on the lane (16 columns) and four co rows per register, i.e. four
+// 64-B segments per atomic instruction; one v_permlane16_swap per register pair of the two ci tiles turns them into two 128-B
+// runs in two rows, the full-rate shape of the memory-side atomic units (MI355X_MICROARCH.md 'Global float atomics').
+#include "conv_bf16_common.h"
+
+namespace hoig_detail {
+namespace {
+
+typedef short s4_t __attribute__((ext_vector_type(4)));
+typedef unsigned u2_t __attribute__((ext_vector_type(2)));
+
+__device__ __forceinline__ bf16x8 tr_frag(const unsigned char *a) {      // pixels 4g+q at a, 16+4g+q at a + 16 pixels
+    const s4_t lo4 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s4_t *)a);
+    const s4_t hi4 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s4_t *)(a + 16 * 32));
+    bf16x8 f;
+    f[0] = lo4[0]; f[1] = lo4[1]; f[2] = lo4[2]; f[3] = lo4[3];
+    f[4] = hi4[0]; f[5] = hi4[1]; f[6] = hi4[2]; f[7] = hi4[3];
+    return f;
+}
+
+template <int TH, int CM>
+struct W16Layout {
+    static constexpr int HPIX = (TH + 2) * 34;
+    static constexpr int SP = TH * 32 * 32 + 32;               // dy sub-image (16 channels): [TH*32 px][32 B], skewed by 32 B
+    static constexpr int PLANE_P = 4 * CM * SP;
+    static constexpr int SQ = (HPIX * 32 + 127) / 128 * 128 + 64;      // x sub-image: [halo px][32 B], the second 64 B past a 128-B multiple
+    static constexpr int PLANE_Q = (2 * SQ + 255) / 256 * 256;
+    static constexpr int bytes(int nsx) { return ns_a(nsx) * PLANE_P + ns_b(nsx) * PLANE_Q; }
+};
+
+template <int NSX, int CM, int TH>
+__global__ __launch_bounds__(128 * 3 * CM) void wgrad_halo_m16_kernel(const WHaloArgs p) {
+    constexpr int NS = NSX == 1 ? 1 : 2, NB = NSX == 2 ? 2 : 1;      // operand planes: dy, x
+    using LY = W16Layout<TH, CM>;
+    constexpr int KS = 3, TW = 32, BM = 64 * CM, BC = 32, NT = 128 * KS * CM;
+    constexpr int CQ = 2 * CM, C4 = 16 * CM;               // 32-channel groups / float4s of a dy pixel row
+    constexpr int HWID = 34, HPIX = LY::HPIX;
+    constexpr int SP = LY::SP, SQ = LY::SQ, PLANE_P = LY::PLANE_P, PLANE_Q = LY::PLANE_Q;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    unsigned char *Ph = smem, *Pl = smem + PLANE_P;
+    unsigned char *Qh = smem + NS * PLANE_P, *Ql = Qh + PLANE_Q;
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int cb = wave % CQ, tr = wave / CQ;              // 32-channel group of co, tap row
+    const int tile = hoig_xcd_remap(blockIdx.x, p.nblk);
+    const int c0 = (tile / p.nblk_ci) * BM, ci0 = (tile % p.nblk_ci) * BC;
+    const int mt_begin = blockIdx.y * p.mt_per_split;
+    const int mt_end = min(p.n_mtiles, mt_begin + p.mt_per_split);
+
+    constexpr int PSL = (TH * TW * C4 + NT - 1) / NT;      // dy float4s per thread
+    constexpr int QSL = (HPIX * 8 + NT - 1) / NT;          // halo float4s per thread
+    float4 rp[PSL], rq[QSL];
+    const bool do_bias = p.DB != nullptr && ci0 == 0;      // the workgroups of the first ci tile also own the bias gradient
+    float4 bsum = make_float4(0.f, 0.f, 0.f, 0.f);
+    auto load_tiles = [&](int mt) {
+        const int tx = mt % p.tiles_x;
+        const int t2 = mt / p.tiles_x;
+        const int ty = t2 % p.tiles_y, b = t2 / p.tiles_y;
+        const int y0 = ty * TH, x0 = tx * TW;
+        const float *dyb = p.DY + (((size_t)b * p.H + y0) * p.W + x0) * p.Co + c0;
+#pragma unroll
+        for (int i = 0; i < PSL; ++i) {
+            const int idx = tid + NT * i;
+            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (idx < TH * TW * C4) {
+                const int pp = idx / C4, c4 = idx % C4;    // pixel of the tile: row pp>>5, column pp&31
+                v = *reinterpret_cast<const float4 *>(dyb + ((size_t)(pp >> 5) * p.W + (pp & 31)) * p.Co + c4 * 4);
+            }
+            rp[i] = v;
+            if (do_bias) {                 // this thread always loads the same four channels (NT % C4 == 0)
+                bsum.x += v.x; bsum.y += v.y; bsum.z += v.z; bsum.w += v.w;
+            }
+        }
+        const bool second = p.X2 != nullptr && ci0 >= p.ci1;
+        const int ldx = p.X2 ? (second ? p.Ci - p.ci1 : p.ci1) : p.Ci;
+        const float *xb = (second ? p.X2 : p.X) + (size_t)b * p.Hin * p.Win * ldx + (second ? ci0 - p.ci1 : ci0);
+#pragma unroll
+        for (int i = 0; i < QSL; ++i) {
+            const int idx = tid + NT * i;
+            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (idx < HPIX * 8) {
+                const int hp = idx >> 3, c4 = idx & 7;
+                const int hy = hp / HWID, hx = hp - hy * HWID;
+                const int gy = y0 - p.pad + hy, gx = x0 - p.pad + hx;
+                if (gy >= 0 && gy < p.Hin && gx >= 0 && gx < p.Win)
+                    v = *reinterpret_cast<const float4 *>(xb + ((size_t)gy * p.Win + gx) * ldx + c4 * 4);
+            }
+            rq[i] = v;
+        }
+    };
+    auto store_tiles = [&]() {
+#pragma unroll
+        for (int i = 0; i < PSL; ++i) {
+            const int idx = tid + NT * i;
+            if (idx < TH * TW * C4) {
+                uint2 hi, lo;
+                split4(rp[i], hi, lo);
+                const int pp = idx / C4, c4 = idx % C4;
+                const int off = (c4 >> 2) * SP + pp * 32 + (c4 & 3) * 8;
+                *reinterpret_cast<uint2 *>(Ph + off) = hi;
+                if (NS == 2) *reinterpret_cast<uint2 *>(Pl + off) = lo;
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < QSL; ++i) {
+            const int idx = tid + NT * i;
+            if (idx < HPIX * 8) {
+                uint2 hi, lo;
+                split4(rq[i], hi, lo);
+                const int hp = idx >> 3, c4 = idx & 7;
+                const int off = (c4 >> 2) * SQ + hp * 32 + (c4 & 3) * 8;
+                *reinterpret_cast<uint2 *>(Qh + off) = hi;
+                if (NB == 2) *reinterpret_cast<uint2 *>(Ql + off) = lo;
+            }
+        }
+    };
+
+    // transpose-read addressing: lane 4q+c of 16-lane group g -> pixel 4g+q of the row, channels 4c .. 4c+3 of the 16-channel tile
+    const int grp = lane >> 4, li = lane & 15;
+    const int trow = grp * 4 + (li >> 2), tcol = (li & 3) * 8;
+    const int trP = (cb * 2) * SP + trow * 32 + tcol;                 // + j * SP + tile row * 1024
+    const int trQ = (tr * HWID + trow) * 32 + tcol;                   // + c * SQ + (tile row * 34 + tap) * 32
+
+    f32x4 acc[KS][2][2];                    // [tap][co tile][ci tile]
+#pragma unroll
+    for (int t = 0; t < KS; ++t)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int c = 0; c < 2; ++c) acc[t][j][c] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    if (mt_begin < mt_end) {
+        load_tiles(mt_begin);
+        store_tiles();
+    }
+    __syncthreads();
+    for (int mt = mt_begin; mt < mt_end; ++mt) {
+        const bool nxt = mt + 1 < mt_end;
+        if (nxt) load_tiles(mt + 1);
+        // A sub-step = (tile row kk, tap t of the wave's tap row): the two x fragments of the tap against the row's four dy
+        // fragments (read once per row): 8 MFMAs.  The x fragments of the NEXT sub-step -- and, during a row's middle tap, the dy
+        // fragments of the next row -- are read before the MFMAs of the current one issue (fences: the compiler would sink the
+        // reads below the MFMAs to shorten live ranges, and every sub-step would start with an exposed LDS round trip).
+        struct AF {
+            bf16x8 h[2], l[2];
+        };
+        struct BF {
+            bf16x8 h[2], l[2];
+        };
+        auto read_a = [&](AF &f, int kk) {
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                f.h[j] = tr_frag(Ph + trP + j * SP + kk * 1024);
+                if (NS == 2) f.l[j] = tr_frag(Pl + trP + j * SP + kk * 1024);
+            }
+        };
+        auto read_b = [&](BF &f, int kk, int t) {
+#pragma unroll
+            for (int c = 0; c < 2; ++c) {
+                const int off = trQ + c * SQ + (kk * HWID + t) * 32;
+                f.h[c] = tr_frag(Qh + off);
+                if (NB == 2) f.l[c] = tr_frag(Ql + off);
+            }
+        };
+        AF af[2];
+        BF bf[2];
+        read_a(af[0], 0);
+        read_b(bf[0], 0, 0);
+        constexpr int NSUB = TH * KS;
+#pragma unroll
+        for (int s_ = 0; s_ < NSUB; ++s_) {
+            const int kk = s_ / KS, t = s_ % KS;
+            if (s_ + 1 < NSUB) read_b(bf[(s_ + 1) & 1], (s_ + 1) / KS, (s_ + 1) % KS);
+            if (t == 1 && kk + 1 < TH) read_a(af[(kk + 1) & 1], kk + 1);
+            __builtin_amdgcn_sched_barrier(0);
+            const AF &a = af[kk & 1];
+            const BF &b = bf[s_ & 1];
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+#pragma unroll
+                for (int c = 0; c < 2; ++c) {
+                    if (NS == 2) acc[t][j][c] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a.l[j], b.h[c], acc[t][j][c], 0, 0, 0);
+                    if (NB == 2) acc[t][j][c] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a.h[j], b.l[c], acc[t][j][c], 0, 0, 0);
+                    acc[t][j][c] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a.h[j], b.h[c], acc[t][j][c], 0, 0, 0);
+                }
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        __syncthreads();                      // every wave is done reading the stage
+        if (nxt) store_tiles();
+        __syncthreads();
+    }
+
+    if (do_bias) {                         // the threads that hold partial sums of the same four channels combine in LDS
+        float *red = reinterpret_cast<float *>(smem);          // (the tiles are dead: the loop ended with a barrier)
+        if (tid < BM) red[tid] = 0.f;
+        __syncthreads();
+        const int ch = (tid % C4) * 4;
+        atomicAdd(&red[ch + 0], bsum.x);
+        atomicAdd(&red[ch + 1], bsum.y);
+        atomicAdd(&red[ch + 2], bsum.z);
+        atomicAdd(&red[ch + 3], bsum.w);
+        __syncthreads();
+        if (tid < BM) atomicAdd(&p.DB[c0 + tid], red[tid]);
+    }
+    // dW[co][tap][ci]: registers (ci tile 0, ci tile 1) of co rows 4g + r -> after the swap lanes 0-31 / 32-63 of the first hold
+    // ci 0..31 of rows r / 8 + r, of the second rows 4 + r / 12 + r
+    const int K = KS * KS * p.Ci;
+    const int l31 = lane & 31, lh = lane >> 5;
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int co = c0 + cb * 32 + j * 16 + r + 8 * lh;
+            float *row = p.DW + (size_t)co * K + (tr * KS) * p.Ci + ci0 + l31;
+#pragma unroll
+            for (int t = 0; t < KS; ++t) {
+                const u2_t sw = __builtin_amdgcn_permlane16_swap(__float_as_uint(acc[t][j][0][r]), __float_as_uint(acc[t][j][1][r]),
+                                                                 false, false);
+                atomicAdd(row + t * p.Ci, __uint_as_float(sw[0]));
+                atomicAdd(row + (size_t)4 * K + t * p.Ci, __uint_as_float(sw[1]));
+            }
+        }
+}
+
+template <int NSX, int CM, int TH>
+int launch_one(const WHaloArgs &a, dim3 grid, hipStream_t st) {
+    constexpr int shm = W16Layout<TH, CM>::bytes(NSX);
+    static bool once = false;
+    if (!once) {
+        if (hipFuncSetAttribute(reinterpret_cast<const void *>(&wgrad_halo_m16_kernel<NSX, CM, TH>),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, shm) != hipSuccess)
+            return HOIG_ELAUNCH;
+        once = true;
+    }
+    wgrad_halo_m16_kernel<NSX, CM, TH><<<grid, 128 * 3 * CM, shm, st>>>(a);
+    HOIG_LAUNCH_CHECK();
+    return HOIG_OK;
+}
+
+}  // namespace
+
+int launch_wgrad_halo_m16(const WHaloArgs &a, int ns, int th, int cm, dim3 grid, hipStream_t st) {
+    if (a.tout || a.W % 32 || a.Ci % 32 || a.Co % (64 * cm)) return HOIG_EUNSUPPORTED;
+    if (th == 4 && cm == 2 && ns != 2) HOIG_NS_SWITCH(ns, return launch_one<NSX == 2 ? 3 : NSX, 2, 4>(a, grid, st));
+    if (th == 2 && cm == 2) HOIG_NS_SWITCH(ns, return launch_one<NSX, 2, 2>(a, grid, st));
+    if (th == 2 && cm == 1) HOIG_NS_SWITCH(ns, return launch_one<NSX, 1, 2>(a, grid, st));
+    return HOIG_EUNSUPPORTED;
+}
+
+}  // namespace hoig_detail

@@ -28,16 +28,17 @@ class PatchDiscriminator(ParamTree):
 
     def forward_nhwc(self, x):
         P = self.P
-        x = ops.conv2d(x, P['model.0.weight'], P['model.0.bias'], 2, 1, ACT_LRELU, 0.2)
+        prec = ops.subnet_precision('d')
+        x = ops.conv2d(x, P['model.0.weight'], P['model.0.bias'], 2, 1, ACT_LRELU, 0.2, prec=prec)
         idx = 2
         for _ in range(1, self.n_layers):
-            x = ops.conv2d(x, P['model.%d.weight' % idx], P['model.%d.bias' % idx], 2, 1, dead_bias=True)
+            x = ops.conv2d(x, P['model.%d.weight' % idx], P['model.%d.bias' % idx], 2, 1, dead_bias=True, prec=prec)
             x = ops.instance_norm(x, act=ACT_LRELU, slope=0.2)
             idx += 3
-        x = ops.conv2d(x, P['model.%d.weight' % idx], P['model.%d.bias' % idx], 1, 1, dead_bias=True)
+        x = ops.conv2d(x, P['model.%d.weight' % idx], P['model.%d.bias' % idx], 1, 1, dead_bias=True, prec=prec)
         x = ops.instance_norm(x, act=ACT_LRELU, slope=0.2)
         idx += 3
-        return ops.conv2d(x, P['model.%d.weight' % idx], P['model.%d.bias' % idx], 1, 1, ACT_NONE)
+        return ops.conv2d(x, P['model.%d.weight' % idx], P['model.%d.bias' % idx], 1, 1, ACT_NONE, prec=prec)
 
     def forward(self, input):
         return as_nchw(self.forward_nhwc(to_nhwc(input)))

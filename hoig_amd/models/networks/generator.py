@@ -298,6 +298,9 @@ class Generator(ParamTree):
             s_bg.wait_stream(main)
             s_obj.wait_stream(main)
             s_src.wait_stream(main)
+            for st_, role in ((s_bg, 'g_bg'), (s_obj, 'g_obj'), (s_src, 'g_src')):      # (test hook: ops.test_delay)
+                with torch.cuda.stream(st_):
+                    ops.test_delay(role)
             bg_out, obj_out = [None], [None]
             branches = [(self._bg_net_steps(bg_in, bg_out), s_bg), (self._unet_steps(obj_in, obj_c, 'obj_model', obj_out), s_obj)]
             for t_, st_ in ((bg_in, s_bg), (obj_in, s_obj), (obj_c, s_obj)):
@@ -352,7 +355,10 @@ class Generator(ParamTree):
             advance()
         advance(True)                                        # (their decoders: issued before the join below)
         if fork:
-            bg_both, obj_both = bg_out[0], obj_out[0]
+            with torch.cuda.stream(s_bg):
+                bg_both = ops.delay_backward(bg_out[0], 'g_bg')
+            with torch.cuda.stream(s_obj):
+                obj_both = ops.delay_backward(obj_out[0], 'g_obj')
 
         # obj_model likewise serves both the src and the tsf object (generator.py:449-450): one stacked pass
         if not fork:
@@ -401,6 +407,7 @@ class Generator(ParamTree):
 
         with on_src():
             src_hand_o, src_mask_hand, src_mask_bg = regress(sx, sy, 'src_model')
+            src_hand_o = ops.delay_backward(src_hand_o, 'g_src')
         tsf_hand_o, tsf_mask_hand, tsf_mask_bg = regress(tx, ty, 'tsf_model')
         if fork_src:
             main.wait_stream(s_src)

@@ -41,6 +41,7 @@ class Vgg19(ParamTree):
 
     def forward_nhwc(self, x):
         outs, idx, sl = [], 0, 1
+        prec = ops.subnet_precision('vgg')
         for v in VGG_LAYERS:
             tap = idx >= VGG_SLICE_ENDS[sl - 1]           # x is a slice output (relu{k}_1): the loss reads it AND the next layer
             if tap:
@@ -55,10 +56,10 @@ class Vgg19(ParamTree):
                 if tap:
                     # (the loss reads the feature through the convolution's pass-through output: its gradient is then added by the
                     # convolution's data-gradient kernel, ops.conv2d_fork, instead of by the autograd engine)
-                    x, feat = ops.conv2d_fork(x, self.P[p + '.weight'], self.P[p + '.bias'], 1, 1, ACT_RELU)
+                    x, feat = ops.conv2d_fork(x, self.P[p + '.weight'], self.P[p + '.bias'], 1, 1, ACT_RELU, prec=prec)
                     outs.append(feat)
                 else:
-                    x = ops.conv2d(x, self.P[p + '.weight'], self.P[p + '.bias'], 1, 1, ACT_RELU)
+                    x = ops.conv2d(x, self.P[p + '.weight'], self.P[p + '.bias'], 1, 1, ACT_RELU, prec=prec)
                 idx += 2
         outs.append(x)
         return outs
@@ -87,6 +88,7 @@ class VGGLoss(object):
             main = torch.cuda.current_stream()
             side.wait_stream(main)
             with torch.cuda.stream(side), torch.no_grad():
+                ops.test_delay('loss_vgg')
                 fy = self.vgg.forward_nhwc(y)
             fx = self.vgg.forward_nhwc(x)
             main.wait_stream(side)

@@ -214,9 +214,19 @@ class Trainer(BaseModel):
             tabs = [tb if isinstance(tb, IP.ObjectTables) else IP.ObjectTables(tb, dev) for tb in t['tables']]
             out = IP.prepare_inputs(t['src_img'], t['ref_img'], t['src_faces'], t['src_fim'], t['src_wim'], t['ref_fim'],
                                     t['ref_wim'], tabs, bg_both=bool(getattr(self._opt, 'bg_both', False)), dexycb=self._dexycb,
-                                    validate='deferred')        # (no host wait inside the training loop)
+                                    # training: no host wait inside the loop (reported one batch late, or by
+                                    # _flush_input_checks); a single eval / test batch is checked before it runs
+                                    validate='deferred' if self._is_train else True)
             return self.set_prepared_input(IP.to_prepared(out, t['src_img'].float(), t['ref_img'].float(),
                                                           t.get('maskA'), t.get('maskB')))
+
+    @staticmethod
+    def _flush_input_checks():
+        """Face-index ranges of batches staged with validate='deferred' that nobody has looked at yet (the last batch of a run):
+        raises the IndexError the reference's indexing would have raised.  Called where the host waits for the
+        device anyway: get_current_errors, get_current_visuals, save."""
+        from .. import input_prep as IP
+        IP.flush_range_checks(wait=True)
 
     def set_prepared_input(self, inp):
         """Stage the a2 attributes (what trainer.py:346-362 assigns).  NCHW tensors (T: B,S,S,2), CPU or device."""
@@ -329,6 +339,7 @@ class Trainer(BaseModel):
         return isinstance(self._G, FlatDDP) and self._G.sync.active
 
     def _eager_step(self, trainable=True, keep_data_for_visuals=False):
+        ops.test_step_begins()
         fake_tsf_imgs, ev_fwd = self._phase_g(keep_data_for_visuals)
         self._step(self._G, self._optimizer_G, overlap=trainable)
         if trainable:
@@ -380,6 +391,7 @@ class Trainer(BaseModel):
             self._d_stream.wait_event(ev_fwd)
             ops.cross_stream(fake_tsf_imgs, self._d_stream)
             with torch.cuda.stream(self._d_stream):
+                ops.test_delay('d')
                 self._d_backward(fake_tsf_imgs)
             main.wait_stream(self._d_stream)
         else:
@@ -414,6 +426,7 @@ class Trainer(BaseModel):
         with torch.cuda.stream(self._side):
             if _TEST_SIDE_DELAY and not ops.capturing():
                 torch.cuda._sleep(int(_TEST_SIDE_DELAY))
+            ops.test_delay('opt', which)
             tree.set_pending(None)     # (this stream IS the writer: the previous step ran here too)
             _mark('step_%s_begin' % which)
             run()
@@ -534,8 +547,10 @@ class Trainer(BaseModel):
             s_adv, s_vgg = self._loss_streams
             s_adv.wait_stream(main)
             with torch.cuda.stream(s_adv):
+                ops.test_delay('loss_adv')
                 self._wait_d()
                 d_fake = self._D.forward_nhwc(ops.cat_channels([fake_tsf, n['tsf_cond']]))
+                d_fake = ops.delay_backward(d_fake, 'loss_adv')
                 self._loss_g_adv = ops.lsgan_loss(d_fake, 0.0, o.lambda_D_prob, into=into('g_adv'))
             ops.cross_stream(fake_tsf, s_adv)
         else:
@@ -602,6 +617,7 @@ class Trainer(BaseModel):
 
     # ------------------------------------------------------------------ reporting (trainer.py:483-551)
     def get_current_errors(self):
+        self._flush_input_checks()
         return OrderedDict([('g_rec', self._loss_g_rec.item()), ('g_tsf', self._loss_g_tsf.item()),
                             ('g_adv', self._loss_g_adv.item()), ('g_mask', self._loss_g_mask.item()),
                             ('g_mask_smooth', self._loss_g_mask_smooth.item()), ('d_real', self._d_real.item()),
@@ -611,6 +627,7 @@ class Trainer(BaseModel):
         return OrderedDict([('lr_G', self._current_lr_G), ('lr_D', self._current_lr_D)])
 
     def get_current_visuals(self):
+        self._flush_input_checks()
         keys = [('1_real_img', '_vis_input'), ('2_input_src_obj', '_vis_src_obj'), ('2_input_src_hand', '_vis_src_hand'),
                 ('2_input_tsf_obj', '_vis_tsf_obj'), ('2_input_tsf_hand', '_vis_tsf_hand'),
                 ('3_fake_src_bg', '_vis_fake_src_bg'), ('4_fake_tsf_bg', '_vis_fake_tsf_bg'),
@@ -674,6 +691,7 @@ class Trainer(BaseModel):
 
     # ------------------------------------------------------------------ checkpoints / schedule (trainer.py:553-591)
     def save(self, label):
+        self._flush_input_checks()
         self._wait_g()
         self._wait_d()
         torch.cuda.synchronize()

@@ -42,6 +42,30 @@ def set_precision(name):
 
 set_precision(os.environ.get('HOIG_PRECISION', 'f32'))
 
+# Forward arithmetic per sub-network: 'vgg' and 'd' do not sit inside the 45-layer generator chain whose error
+# growth forces three forward terms.  name -> HOIG_PREC_* of that sub-network's convolution FORWARDS (their backward then follows
+# the forward's arithmetic: _bwd_descs); names without an entry use the module-level `precision`.
+_subnet_prec = {}
+
+
+def set_subnet_precision(mapping):
+    """{'vgg': 'f16x2', 'd': 'f16x2'} or 'vgg=f16x2,d=f16x2' (HOIG_PRECISION_MAP); None / '' clears."""
+    _subnet_prec.clear()
+    if not mapping:
+        return
+    if isinstance(mapping, str):
+        mapping = dict(kv.split('=') for kv in mapping.split(',') if kv)
+    for k, v in mapping.items():
+        _subnet_prec[k] = _PREC[v]
+
+
+def subnet_precision(name):
+    """Forward arithmetic of sub-network `name`, or None for the module default; an exact-fp32 run keeps every sub-network exact."""
+    return None if precision == L.PREC_F32 else _subnet_prec.get(name)
+
+
+set_subnet_precision(os.environ.get('HOIG_PRECISION_MAP'))
+
 
 def _bwd_descs(d):
     """(data-gradient, weight-gradient) descriptors of a convolution: same problem, the backward arithmetic modes.  An
@@ -181,6 +205,46 @@ def new_stream(device=None):
     s = torch.cuda.ExternalStream(h, device=dev)
     _own_streams.append((h, s))                # (kept for the life of the process: a handful per Trainer)
     return s
+
+
+# ---- test hook (tests/test_stream_order_gpu.py): stream role -> cycles to idle.  A role that finds its name here sleeps that long
+# where it forks off the caller's stream and again where its backward begins (once per step each), so that a consumer that is not
+# ordered behind it reads stale data and a parity check fails instead of the bug hiding behind timing.  Roles: g_bg, g_obj, g_src
+# (the generator's branch streams), loss_adv, loss_vgg, d, wgrad (the weight-gradient side stream), opt (the optimiser side stream).
+_TEST_DELAYS = {}
+_test_fired = set()
+
+
+def test_step_begins():
+    _test_fired.clear()
+
+
+def test_delay(role, where='fwd'):
+    """Idle the CURRENT stream if `role` is being delayed (at most once per step and `where`)."""
+    cycles = _TEST_DELAYS.get(role)
+    if not cycles or (role, where) in _test_fired:
+        return
+    _test_fired.add((role, where))
+    torch.cuda._sleep(int(cycles))
+
+
+class _DelayBackward(Function):
+    @staticmethod
+    def forward(ctx, x, role):
+        ctx.role = role
+        return x.view_as(x)
+
+    @staticmethod
+    def backward(ctx, g):
+        test_delay(ctx.role, 'bwd')          # (autograd runs this on the stream of the forward: the role's own)
+        return g, None
+
+
+def delay_backward(x, role):
+    """Identity; with the test hook armed for `role`, the backward that starts at `x` begins with the role's delay."""
+    if _TEST_DELAYS.get(role) and torch.is_tensor(x) and x.requires_grad:
+        return _DelayBackward.apply(x, role)
+    return x
 
 
 _wgrad_streams = {}
@@ -383,6 +447,7 @@ class _Conv(Function):
                 # the optimiser: run them on a side stream, concurrently with the data-gradient chain on the main stream
                 side.wait_stream(torch.cuda.current_stream())
                 with torch.cuda.stream(side):
+                    test_delay('wgrad')
                     call('hoig_conv2d_bwd_weight', ctypes.byref(ctx.d_wg), _p(x), _p(g), _p(dw), _p(db), _st())
                 _wgrad_hold(side, (x, g))
             else:
@@ -457,6 +522,7 @@ class _ConvCat2(Function):
         if side is not None:
             side.wait_stream(torch.cuda.current_stream())
             with torch.cuda.stream(side):
+                test_delay('wgrad')
                 call('hoig_conv2d_cat_bwd_weight', ctypes.byref(ctx.d_wg), _p(x1), C1, _p(x2), _p(dy), _p(dw), None, _st())
             _wgrad_hold(side, (x1, x2, dy))
         else:

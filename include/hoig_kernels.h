@@ -401,7 +401,7 @@ const char *hoig_version(void);
 
 /* Kernel-variant choices that are tuning, not semantics (every value computes the same result up to summation order): one table
  * instead of per-variant environment switches.  key -> value; returns the previous value, or -1 for an unknown key; value < 0 only
- * queries.  Keys: "mfma16" (1: the 8-row 3x3 stride-1 tilings run on v_mfma_f32_16x16x32, conv_halo16.hip; 0: on 32x32x16).
+ * queries.  Keys: "mfma16" (1, the default: the 8-row 3x3 stride-1 tilings run on v_mfma_f32_16x16x32, conv_halo16.hip; 0: on 32x32x16); "wgrad16" (1: the stride-1 3x3 weight gradients on v_mfma_f32_16x16x32, wgrad_halo16.hip); "igemm16" (1: the generic implicit GEMM on v_mfma_f32_16x16x32, conv_igemm16.hip).
  * Process-wide, not synchronised: set before launching. */
 int hoig_set_tuning(const char *key, int value);
 

@@ -53,28 +53,30 @@ def test_m16_forward_and_data_gradient(tuning, B, Ci, Co, H, W, mode):
     ops.set_precision(mode)
     try:
         def run():
+            # (no activation in the differentiated pass: a LeakyReLU mask that differs between the two kernels at one output near
+            # zero would put an isolated large error into the max-norm of the gradient; the activation epilogue is checked forward)
             xd = x.clone().requires_grad_(True)
             x1 = ops.add(xd, xd)
-            y, x2 = ops.conv2d_fork(x1, wd.clone().requires_grad_(True), bias, 1, 1, act=L.ACT_LRELU, slope=0.2)
+            y, x2 = ops.conv2d_fork(x1, wd.clone().requires_grad_(True), bias, 1, 1)
             ((y * gy).sum() + (x2 * addend).sum()).backward()
-            return y.detach(), xd.grad
-        (y0, dx0), (y1, dx1) = _both(L, run)
+            with torch.no_grad():
+                ya = ops.conv2d(x1.detach(), wd, bias, 1, 1, act=L.ACT_LRELU, slope=0.2)
+            return y.detach(), xd.grad, ya
+        (y0, dx0, ya0), (y1, dx1, ya1) = _both(L, run)
     finally:
         ops.set_precision('f32')
-    # the same products in another order
-    assert rel_err(y1, y0) < 2e-6 and rel_err(dx1, dx0) < 2e-6
-    # and an independent reference: torch fp32 on the device
-    # (the activation mask is taken from the device's own output: a LeakyReLU mask one rounding away from the reference's would
-    # put isolated large errors into the max-norm of the gradient)
+    # an independent reference: torch fp32 on the device
     xr = (2 * x).permute(0, 3, 1, 2).clone().requires_grad_(True)
-    hr = F.conv2d(xr, w.cuda(), bias, padding=1)
-    yr = F.leaky_relu(hr, 0.2)
-    slope = torch.where(y1 > 0, torch.ones_like(y1), torch.full_like(y1, 0.2))
-    (hr * (gy * slope).permute(0, 3, 1, 2)).sum().backward()
+    yr = F.conv2d(xr, w.cuda(), bias, padding=1)
+    (yr * gy.permute(0, 3, 1, 2)).sum().backward()
     dxr = 2 * (xr.grad.permute(0, 2, 3, 1) + addend)
+    yr = yr.detach().permute(0, 2, 3, 1)
     bf, bd = (3e-4, 3e-4) if mode == 'bf16x3' else (1e-3, 8e-3)
-    assert rel_err(y1, yr.permute(0, 2, 3, 1)) < bf
-    assert rel_err(dx1, dxr) < bd
+    for tag, y, dx, ya in (('32x32x16', y0, dx0, ya0), ('16x16x32', y1, dx1, ya1)):
+        ef, ed, ea = rel_err(y, yr), rel_err(dx, dxr), rel_err(ya, F.leaky_relu(yr, 0.2))
+        assert ef < bf and ed < bd and ea < bf, (tag, ef, ed, ea)
+    # and the two kernels against each other: the same products in another order
+    assert rel_err(y1, y0) < 2e-6 and rel_err(ya1, ya0) < 2e-6 and rel_err(dx1, dx0) < (2e-6 if mode == 'bf16x3' else 1e-4)
 
 
 @pytest.mark.parametrize('B,C1,C2,Co,H,W', [(4, 256, 256, 256, 32, 128), (8, 64, 128, 256, 64, 64)])
@@ -124,3 +126,56 @@ def test_m16_statistics_epilogue(tuning, B, Ci, Co, H, W):
     assert rel_err(y1, yr) < 1e-4
     for ws in ops._norm_ws.values():
         assert float(ws[:1 << 18].abs().max()) == 0.0
+
+
+WGRAD_CASES = [
+    # B, C1, C2, Co, H, W                  variant of wgrad_halo_m16_kernel the launcher picks (two-term arithmetic)
+    (8, 512, 0, 512, 32, 32),       # 4-row tiles, 128 dy channels per workgroup: the step's dominant weight gradient
+    (8, 256, 256, 256, 32, 32),     # ... over a two-tensor input (the decoder's skip convolution)
+    (8, 512, 0, 512, 18, 32),       # H % 4 != 0: 2-row tiles
+    (4, 64, 0, 64, 64, 64),         # 64 dy channels per workgroup
+    (2, 96, 0, 192, 16, 64),        # three ci tiles, Co % 128 != 0
+]
+
+
+@pytest.mark.parametrize('mode', ['f16x2', 'bf16x3'])
+@pytest.mark.parametrize('B,C1,C2,Co,H,W', WGRAD_CASES)
+def test_wgrad16_weight_and_bias_gradient(B, C1, C2, Co, H, W, mode):
+    """Tuning key 'wgrad16' (wgrad_halo16.hip): dW and the fused bias gradient against the 32x32x16 kernel (same products, another
+    order: fp32 atomics reorder the sums anyway) and against torch fp32."""
+    from hoig_amd import ops, _lib as L
+    g = torch.Generator().manual_seed(17)
+    x1 = torch.randn(B, H, W, C1, generator=g).cuda()
+    x2 = torch.randn(B, H, W, C2, generator=g).cuda() if C2 else None
+    w = ops.pack_weight((torch.randn(Co, C1 + C2, 3, 3, generator=g) * 0.05).cuda())
+    bias = None if C2 else torch.randn(Co, generator=g).cuda()
+    gy = torch.randn(B, H, W, Co, generator=g).cuda()
+    prev = L.set_tuning('wgrad16', 0)
+    ops.set_precision(mode)
+    try:
+        res = []
+        for v in (0, 1):
+            L.set_tuning('wgrad16', v)
+            wd = w.clone().requires_grad_(True)
+            bd = bias.clone().requires_grad_(True) if bias is not None else None
+            if x2 is not None:
+                y = ops.conv2d_cat2(x1, x2, wd)
+            else:
+                y = ops.conv2d(x1, wd, bd, 1, 1)
+            y.backward(gy)
+            torch.cuda.synchronize()
+            res.append((wd.grad.clone(), None if bd is None else bd.grad.clone()))
+    finally:
+        ops.set_precision('f32')
+        L.set_tuning('wgrad16', prev)
+    (dw0, db0), (dw1, db1) = res
+    assert rel_err(dw1, dw0) < 1e-5
+    if db0 is not None:
+        assert rel_err(db1, db0) < 1e-5
+    xr = (torch.cat([x1, x2], 3) if x2 is not None else x1).permute(0, 3, 1, 2)
+    wr = w.detach().clone().requires_grad_(True)
+    br = bias.clone().requires_grad_(True) if bias is not None else None
+    F.conv2d(xr, wr, br, padding=1).backward(gy.permute(0, 3, 1, 2))
+    assert rel_err(dw1, wr.grad) < (8e-3 if mode == 'f16x2' else 3e-4)
+    if br is not None:
+        assert rel_err(db1, br.grad) < 1e-4

@@ -152,3 +152,32 @@ def test_trainer_accepts_rasterised_batches():
     model.optimize_parameters()
     errs = model.get_current_errors()
     assert all(np.isfinite(v) for v in errs.values()), errs
+
+
+def test_trainer_reports_a_bad_face_index_of_the_last_batch():
+    """a batch staged with the deferred range check is reported by the next host-side read (get_current_errors / save /
+    get_current_visuals), not only when another batch follows; an eval-mode batch is checked before it runs."""
+    from hoig_amd import ops
+    from hoig_amd.models import ModelsFactory
+    from common import opt_namespace
+    ops.set_precision('bf16x3')
+    r = synthetic.make_raster(1, 9)
+    opt = opt_namespace(gen_name='generator_spade_attn', local_rank=0, image_size=256)
+    torch.manual_seed(3)
+    model = ModelsFactory.get_by_name('trainer', opt, use_ddp=False)
+    arm = torch.zeros(1, 1, 256, 256)
+    bad = r['ref_fim'].clone()
+    bad[0, 5, 5] = 10 ** 6
+    batch = dict(src_img=r['src_img'], ref_img=r['ref_img'], src_faces=r['src_faces'], src_fim=r['src_fim'],
+                 src_wim=r['src_wim'], ref_fim=bad, ref_wim=r['ref_wim'],
+                 tables=[r['tables'][k] for k in r['obj_ids']], maskA=arm, maskB=arm)
+    model.set_train()
+    model.set_input(batch)                       # no host wait, indices clamped for the kernels
+    model.optimize_parameters()
+    with pytest.raises(IndexError):
+        model.get_current_errors()
+    model.get_current_errors()                   # reported once
+    model.set_eval()
+    with pytest.raises(IndexError):
+        model.set_input(batch)
+    model.set_train()

@@ -1,0 +1,124 @@
+"""Cross-stream ordering of the training step, role by role.
+
+The eager step spreads its chains over eight HIP streams: the generator's three branch streams, two loss streams, the D stream,
+the weight-gradient side stream and the optimiser side stream ('Streams').  Two ordering bugs of earlier rounds
+were found by accident because timing hid them.  Here every role in turn is DELAYED by tens of milliseconds where it forks off and
+where its backward begins (ops.test_delay / ops.delay_backward): a consumer that is not ordered behind that role then reads stale
+or half-written data, and the step leaves the single-stream step's results -- which are what the reference computes
+(models/trainer.py:417-434: one stream, forward -> G step -> D step).
+
+What is compared, from a common seeded state: the loss terms of two steps, and after EACH step the first Adam moment of both
+networks (0.5 * gradient after step 1: exactly what the optimiser READ, so an optimiser that ran ahead of a late weight gradient
+shows up directly) and the parameter update.  test_the_detector_sees_a_missing_join removes Trainer._join_backward_streams and
+demands that the same check FAILS."""
+import pytest
+import torch
+
+from common import product_trainer
+
+pytestmark = pytest.mark.gpu
+ROLES = ['g_bg', 'g_obj', 'g_src', 'loss_adv', 'loss_vgg', 'd', 'wgrad', 'opt']
+DELAY = 60_000_000          # cycles: ~30 ms, several times the 128x128 step
+
+
+@pytest.fixture(autouse=True)
+def _precision():
+    from hoig_amd import ops
+    ops.set_precision('bf16x3:f16x2')       # the benchmarked arithmetic
+    yield
+    ops.set_precision('f32')
+    ops._TEST_DELAYS.clear()
+
+
+def _run(side, batch, delays=None, single_stream=False, graph=False, steps=2):
+    """-> per step: (losses, G's first moment, D's first moment, G's weights), from the seeded state."""
+    from hoig_amd import ops
+    from hoig_amd.models.networks import generator as G
+    fork, wside = G._FORK_STREAMS, ops._WGRAD_SIDE
+    ops._TEST_DELAYS.clear()
+    ops._TEST_DELAYS.update(delays or {})
+    if single_stream:
+        G._FORK_STREAMS, ops._WGRAD_SIDE = False, False
+    try:
+        m = product_trainer('generator_spade_attn', batch, side, hip_graph=graph)
+        w0 = m._G.flat.clone()
+        out = []
+        n = steps + (2 if graph else 0)            # (a captured step replays from its third call on a batch shape)
+        for i in range(n):
+            m.optimize_parameters()
+            torch.cuda.synchronize()
+            out.append((m.get_current_errors(), m._optimizer_G.exp_avg.clone(), m._optimizer_D.exp_avg.clone(),
+                        m._G.flat.clone() - w0))
+        if graph:
+            assert any(g['graphs'] is not None for g in m._graphs.values()), 'the step was never captured'
+        return out
+    finally:
+        G._FORK_STREAMS, ops._WGRAD_SIDE = fork, wside
+        ops._TEST_DELAYS.clear()
+
+
+def _rel(a, b):
+    return float((a - b).norm() / b.norm().clamp_min(1e-30))
+
+
+def _compare(run, ref, tag, steps=1):
+    """Step 1 tightly (same weights, same inputs: only the order of fp32 atomic sums differs); later steps of this seeded GAN are
+    chaotic run to run (tests/test_graph_gpu.py::_copy_state: 1 % in g_adv on step 2), so they are held to a bound that a stale
+    read still misses by far."""
+    for i in range(steps):
+        (e, mg, md, dw), (er, mgr, mdr, dwr) = run[i], ref[i]
+        tol = 1e-3 if i == 0 else 5e-2
+        for k in er:
+            assert abs(e[k] - er[k]) <= tol * max(abs(er[k]), 1e-2), (tag, 'step', i, k, e[k], er[k])
+        lim = 2e-3 if i == 0 else 0.2
+        assert _rel(mg, mgr) < lim, (tag, 'step', i, "G's gradient as Adam read it", _rel(mg, mgr))
+        assert _rel(md, mdr) < lim, (tag, 'step', i, "D's gradient as Adam read it", _rel(md, mdr))
+        assert _rel(dw, dwr) < (0.05 if i == 0 else 0.5), (tag, 'step', i, "G's update", _rel(dw, dwr))
+
+
+@pytest.fixture(scope='module')
+def reference_128():
+    return _run(128, 2, single_stream=True)
+
+
+def test_multi_stream_step_equals_single_stream_step(reference_128):
+    _compare(_run(128, 2), reference_128, 'no delay', steps=2)
+
+
+@pytest.mark.parametrize('role', ROLES)
+def test_delayed_role_eager(role, reference_128):
+    _compare(_run(128, 2, {role: DELAY}), reference_128, role, steps=2)
+
+
+@pytest.mark.parametrize('role', ['g_bg', 'g_src', 'loss_adv', 'wgrad', 'opt'])
+def test_delayed_role_captured_graph(role, reference_128):
+    """The same under the captured hipGraph: the delay kernels are captured with the step and replayed.  Steps 0-1 are the eager
+    warm-up; the first replay (step 2) continues from their state, so it is compared with the eager delayed run's own step 2 --
+    the captured step must compute what the eager step computes (tests/test_graph_gpu.py) also when a role is late."""
+    run = _run(128, 2, {role: DELAY}, graph=True, steps=1)
+    _compare(run, reference_128, role + ' (graph warm-up)', steps=2)
+    eager = _run(128, 2, {role: DELAY}, steps=3)
+    (e, mg, md, dw), (er, mgr, mdr, dwr) = run[2], eager[2]
+    for k in er:
+        assert abs(e[k] - er[k]) <= 0.1 * max(abs(er[k]), 1e-2), (role, k, e[k], er[k])
+    assert _rel(mg, mgr) < 0.3 and _rel(md, mdr) < 0.3, (role, _rel(mg, mgr), _rel(md, mdr))
+
+
+def test_the_detector_sees_a_missing_join(reference_128):
+    """Negative control: without Trainer._join_backward_streams (the bug of rounds 1-2) a delayed branch must FAIL the check."""
+    from hoig_amd.models import trainer as T
+    keep = T.Trainer._join_backward_streams
+    T.Trainer._join_backward_streams = lambda self: None
+    try:
+        run = _run(128, 2, {'g_bg': DELAY})
+    finally:
+        T.Trainer._join_backward_streams = keep
+    with pytest.raises(AssertionError):
+        _compare(run, reference_128, 'g_bg without the join', steps=2)
+
+
+def test_delayed_roles_at_the_bench_size():
+    """Once at 256 x 256, batch 8 (BASELINE.json configs[1]): the two roles whose bugs were found in rounds 2 and 3."""
+    ref = _run(256, 8, single_stream=True, steps=1)
+    for role in ('g_obj', 'opt'):
+        _compare(_run(256, 8, {role: 4 * DELAY}, steps=1), ref, role + ' at 256', steps=1)

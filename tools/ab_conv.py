@@ -18,6 +18,8 @@ SHAPES = {
     's1': [(16, 512, 512, 32, 32, 3), (8, 512, 512, 32, 32, 3), (8, 128, 1024, 32, 32, 3), (16, 128, 1024, 32, 32, 3),
            (8, 256, 256, 64, 64, 3), (8, 128, 256, 128, 128, 3), (16, 128, 256, 128, 128, 3), (8, 128, 128, 128, 128, 3),
            (8, 128, 512, 64, 64, 3), (16, 128, 512, 64, 64, 3), (8, 64, 64, 256, 256, 3), (8, 64, 128, 128, 128, 3)],
+    'wg': [(16, 512, 512, 32, 32, 3), (8, 512, 512, 32, 32, 3), (8, 128, 1024, 32, 32, 3), (16, 128, 1024, 32, 32, 3),
+           (8, 256, 256, 64, 64, 3), (8, 128, 256, 128, 128, 3), (16, 128, 256, 128, 128, 3), (8, 64, 64, 256, 256, 3)],
     'attn5': [(8, 512, 128, 40, 40, 5), (8, 512, 128, 36, 36, 5), (8, 128, 128, 136, 136, 5), (8, 256, 128, 72, 72, 5)],
 }
 

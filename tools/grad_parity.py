@@ -1,6 +1,7 @@
 """Gradient parity of one optimiser step against the CPU oracle at a given size, REPEATED, so that the run-to-run spread is seen
 next to the arithmetic's own error (TEST INFRASTRUCTURE: imports tests/common.py and the oracle).
-    python tools/grad_parity.py side batch repeats mode[@min_tiles] ...     e.g.  256 1 4 f16f6@1 f16f6@192 bf16x3:f16x2"""
+    python tools/grad_parity.py side batch repeats mode[@min_tiles][+subnet=mode,...] ...
+    e.g.  256 1 4 f16f6@1 bf16x3:f16x2 bf16x3:f16x2+vgg=f16x2,d=f16x2      (the '+' part: ops.set_subnet_precision)"""
 import os, sys, io, contextlib, torch
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, 'tests'))
@@ -13,8 +14,10 @@ side, batch, reps = int(sys.argv[1]), int(sys.argv[2]), int(sys.argv[3])
 ofwd, oerr, ograd = oracle_side(side, batch)
 print('%-22s | %-9s | %-9s | %s' % ('mode@f6_min_tiles run', 'fwd max', 'loss max', 'gradient rel-L2 median / p95 / worst (tensor)'))
 for spec in sys.argv[4:]:
-    mode, _, tiles = spec.partition('@')
+    base, _, submap = spec.partition('+')
+    mode, _, tiles = base.partition('@')
     ops.set_precision(mode)
+    ops.set_subnet_precision(submap)
     old = ops.set_f6_min_tiles(int(tiles) if tiles else 192)
     for r in range(reps):
         with contextlib.redirect_stdout(io.StringIO()), contextlib.redirect_stderr(io.StringIO()):
@@ -36,3 +39,4 @@ for spec in sys.argv[4:]:
         del m
         torch.cuda.empty_cache()
     ops.set_f6_min_tiles(old)
+    ops.set_subnet_precision(None)
