@@ -26,7 +26,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)          # the product package only; tests/ + oracle/ are reachable from the cpu-baseline child alone
 
 GFLOP_PER_PAIR_TRAIN_256 = 2555.2      # BASELINE.md §2 / SURVEY.md §8d (3*G + 3*VGG + 9*D), generator_spade_attn
-PMC_FILES = ['r03_pmc_dominant_conv.json', 'r02_pmc_dominant_conv_f6.json', 'r02_pmc_dominant_conv.json', 'r01_pmc_dominant_conv.json']      # newest first (matched by kernel name below)
+PMC_FILES = ['r04_pmc_dominant_conv.json', 'r03_pmc_dominant_conv.json', 'r02_pmc_dominant_conv_f6.json', 'r02_pmc_dominant_conv.json', 'r01_pmc_dominant_conv.json']      # newest first (matched by kernel name below)
 PEAK_F32, PEAK_16 = 157.3, 2500.0          # TFLOP/s dense MFMA (fp32 / fp16-bf16), MI355X_MICROARCH.md
 DTYPE_NAMES = {'f16f6': 'fwd: fp16 hi*hi + the two cross terms of the hi/lo split on block-scaled fp6 MFMA (1.6 bf16-MFMA units per product; layers outside that kernel: three fp16 terms) / bwd: bf16x2 (dy split hi+lo, weights and x single bf16), f32 accumulate',
                'bf16x3:f16x2': 'f16x3 fwd (both operands split hi+lo on fp16, 3 MFMAs per product) / bf16x2 bwd (dy split hi+lo, weights and x single bf16, 2 MFMAs per product), f32 accumulate',
@@ -65,7 +65,10 @@ def dominant_kernel_roofline(batch, side, precision, iters=50):
     # share a pass); the committed summary is attached when it was taken on the same kernel and shape
     traffic, traffic_source = None, None
     fwd_prec = precision.partition(':')[0]
-    want = 'conv_halo3_f6_kernel' if fwd_prec == 'f16f6' else ('conv_halo3_bf16_kernel' if fwd_prec in ('bf16x3', 'f16x3') else None)
+    from hoig_amd import _lib
+    m16 = _lib.lib.hoig_set_tuning(b'mfma16', -1) == 1          # the 8-row tilings run on v_mfma_f32_16x16x32 (conv_halo16.hip)
+    halo = 'conv_halo3_m16_kernel' if m16 else 'conv_halo3_bf16_kernel'
+    want = 'conv_halo3_f6_kernel' if fwd_prec == 'f16f6' else (halo if fwd_prec in ('bf16x3', 'f16x3') else None)
     for fn in PMC_FILES:
         try:
             pmc = json.load(open(os.path.join(ROOT, 'profiles', fn)))
@@ -80,8 +83,9 @@ def dominant_kernel_roofline(batch, side, precision, iters=50):
     achieved = flops / (ms * 1e-3) / 1e12
     fwd = precision.partition(':')[0]
     peak = PEAK_F32 if fwd == 'f32' else PEAK_16
+    nsx = {3: 2, 2: 3, 1: 1}[MFMA_TERMS[fwd]] if fwd not in ('f32', 'f16f6') else 0
     kname = ('igemm_f32_kernel' if fwd == 'f32' else 'conv_halo3_f6_kernel' if fwd == 'f16f6' else
-             'conv_halo3_bf16_kernel<%d,4,2,128,2,true>' % {3: 2, 2: 3, 1: 1}[MFMA_TERMS[fwd]])
+             ('conv_halo3_m16_kernel<%d,4,2,128,true>' % nsx if m16 else 'conv_halo3_bf16_kernel<%d,4,2,128,2,true>' % nsx))
     return dict(bound='mfma', kernel='%s (conv3x3 s1 512->512 @%dx%d, %d images = src+tsf stacked)' % (kname, h, h, batch),
                 achieved=round(achieved, 2), peak=peak, unit='TFLOP/s', mfma_terms_per_product=MFMA_TERMS[fwd],
                 frac=round(achieved / peak, 4), traffic=traffic, traffic_source=traffic_source, avg_launch_ms=round(ms, 4),
@@ -333,6 +337,19 @@ def main():
     is_captured = lambda: bool(model._graphs) and all(g['graphs'] is not None for g in model._graphs.values())
     main_captured = is_captured()
 
+    def host_issue_ms(samples=5):
+        """Host time to issue ONE step on an idle device: the median of `samples` warmed steps, each bracketed by a barrier (one
+        un-warmed sample right after switching the step form read 148.9 ms in round 3's driver run: VERDICT r3)."""
+        ts = []
+        for i in range(samples + 2):
+            barrier()
+            t = time.perf_counter()
+            model.optimize_parameters()
+            ts.append((time.perf_counter() - t) * 1e3)
+        barrier()
+        ts = sorted(ts[2:])
+        return ts[len(ts) // 2]
+
     other_ms, other_host_ms = None, None
     if args.graph_steps > 0:                       # the same step in the other form, same process, same weights
         model._use_graph = not args.graph
@@ -345,16 +362,14 @@ def main():
             model.optimize_parameters()
         barrier()
         other_ms = (time.perf_counter() - t1) / args.graph_steps * 1e3
-        t1 = time.perf_counter()                   # host time of ONE step issued on an idle device (pure issue cost)
-        model.optimize_parameters()
-        other_host_ms = (time.perf_counter() - t1) * 1e3
-        barrier()
+        other_host_ms = host_issue_ms()
         other_captured = is_captured()
         model._use_graph = bool(args.graph)
-    t1 = time.perf_counter()
-    model.optimize_parameters()
-    main_host_ms = (time.perf_counter() - t1) * 1e3
-    barrier()
+        model.set_input(inputs)
+        for _ in range(trainer_mod._GRAPH_WARMUP + 2):      # back in the main form, warmed again
+            model.optimize_parameters()
+        barrier()
+    main_host_ms = host_issue_ms()
 
     if rank == 0:
         ms = dt / args.steps * 1e3

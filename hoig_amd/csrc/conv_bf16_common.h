@@ -182,6 +182,24 @@ __device__ __forceinline__ bool tap_alive(const Geom &g, int hp, int wp, int rs)
 // launch<BM, BN, WM, WN> of conv_igemm_bf16.hip; `cfg` = 0: 128x128 on 4 waves, 1: 128x128 on 8 waves, 2: 64x128, 3: 128x64, 4: 64x64)
 int launch_igemm_m16(Args a, int ns, int cfg, hipStream_t st);
 
+// conv_flat16.hip: valid KS x KS convolutions (and their data gradients) on a flattened pixel axis
+struct FlatArgs {
+    const float *A;            // source tensor [Bn][Hs][Ws][Cg]
+    const unsigned short *Wh, *Wl;
+    const float *bias;
+    float *C;                  // destination [Bn][Hd][Wd][N]
+    const float *addend;       // (nullable) same shape as C: C = conv + addend
+    int Bn, Hc, Wc;            // canvas: the grid the taps walk (the input grid of the convolution)
+    int Hs, Ws, oy, ox;        // the source grid and its offset on the canvas (zero elsewhere)
+    int Hd, Wd;                // canvas positions (y < Hd, x < Wd) are outputs
+    int KS, Cg, N, K, flip, f16;
+    int act;
+    float slope, oscale;
+    int HWc, Q, HP;            // filled in by the launcher: Hc * Wc, Bn * Hc * Wc, halo positions per tile
+    int nblk, nblk_n, cb_per_split;
+};
+int launch_flat_m16(FlatArgs a, int ns, hipStream_t st);
+
 // argument block of the weight-gradient halo kernels (wgrad_halo_bf16_kernel in conv_igemm_bf16.hip, wgrad_halo16.hip)
 struct WHaloArgs {
     const float *DY, *X, *X2;  // X2 (nullable): the input is [X | X2] along channels, X holding the first ci1
@@ -205,5 +223,6 @@ int launch_wgrad_halo_m16(const WHaloArgs &a, int ns, int th, int cm, dim3 grid,
 // conv_halo16.hip: the 3x3 stride-1 halo kernel on v_mfma_f32_16x16x32 (8 rows x 32 pixels x bn channels per workgroup, bn = 128
 // or 64; `a` carries that tiling's geometry); HOIG_EUNSUPPORTED for shapes it has no tiling for
 int launch_halo3_m16(HaloArgs a, int ns, int bn, hipStream_t st);
+int launch_halo_s2_m16(const HaloArgs &a, int ns, bool scatter, hipStream_t st);
 
 }  // namespace hoig_detail

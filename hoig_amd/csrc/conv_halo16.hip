@@ -29,6 +29,44 @@ __device__ __forceinline__ f32x4 mfma_m16(const bf16x8 a, const bf16x8 b, const 
 
 constexpr int round128(int v) { return (v + 127) / 128 * 128; }
 
+// Instance-norm statistics of what a workgroup stored (halo_stats_epilogue of the 32x32 kernels): the 16 lanes of a channel quad
+// hold different pixels (four xor steps), the WM waves with the same wn different rows (LDS, dead by now), then ONE atomic per
+// (workgroup, channel, moment) into the accumulators of the image.
+template <int NTW, int WM, int BN, int NT>
+__device__ __forceinline__ void m16_stats_epilogue(float (&st1)[NTW][4], float (&st2)[NTW][4], unsigned char *lds, float *stats_img, int N,
+                                                   int n0, int wm, int wn, int lane, int tid) {
+    const int l15 = lane & 15, lg = lane >> 4;
+#pragma unroll
+    for (int j = 0; j < NTW; ++j)
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+#pragma unroll
+            for (int o = 1; o < 16; o <<= 1) {
+                st1[j][q] += __shfl_xor(st1[j][q], o);
+                st2[j][q] += __shfl_xor(st2[j][q], o);
+            }
+    __syncthreads();
+    float *red = reinterpret_cast<float *>(lds);      // [WM][2][BN]
+    if (l15 == 0) {
+#pragma unroll
+        for (int j = 0; j < NTW; ++j)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int cl = wn * (NTW * 16) + j * 16 + lg * 4 + q;
+                red[(wm * 2 + 0) * BN + cl] = st1[j][q];
+                red[(wm * 2 + 1) * BN + cl] = st2[j][q];
+            }
+    }
+    __syncthreads();
+    for (int e = tid; e < 2 * BN; e += NT) {
+        const int mom = e / BN, cl = e - mom * BN;
+        float v = 0.f;
+#pragma unroll
+        for (int k = 0; k < WM; ++k) v += red[(k * 2 + mom) * BN + cl];
+        if (n0 + cl < N) atomicAdd(&stats_img[(size_t)mom * N + n0 + cl], v);
+    }
+}
+
 template <int WM, int BN>
 struct M16Layout {
     static constexpr int TH = 2 * WM, HW = 34, HPIX = (TH + 2) * HW;
@@ -280,41 +318,282 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_halo3_m16_kernel(const Halo
             }
         }
     }
-    if (p.stats) {
-        // instance-norm statistics of what was stored (halo_stats_epilogue of the 32x32 kernel): the 16 lanes of a channel
-        // quad hold different pixels (four xor steps), the WM waves with the same wn different rows (LDS, dead by now), then one
-        // atomic per (workgroup, channel, moment)
+    if (p.stats) m16_stats_epilogue<NTW, WM, BN, NT>(st1, st2, smem, p.stats + (size_t)b * 2 * p.N, p.N, n0, wm, wn, lane, tid);
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// Stride-2 3x3 layers (Conv2d s2 p1 and ConvTranspose2d s2 p1 op1, forward and data gradient) on the 16x16 MFMA: the parity-phase
+// decomposition, step table and tile of conv_halo_s2_bf16_kernel (conv_igemm_bf16.hip: 4 x 32 coarse pixels x BN channels, four
+// waves, steps of <= 2 taps over a (4+1) x 33 halo image, two workgroups per CU), with the LDS images and the swapped operand
+// roles of conv_halo3_m16_kernel above (a lane ends up with four consecutive channels of one pixel: 16-B stores, also strided
+// over the fine grid in scatter mode).
+template <int NSX, int BN, bool SCATTER, bool F16>
+__global__ __launch_bounds__(256) void conv_halo_s2_m16_kernel(const HaloArgs p) {
+    constexpr int NS = NSX == 1 ? 1 : 2, NB = NSX == 2 ? 2 : 1;
+    constexpr int TH = 4, TW = 32, NT = 256, WN = 2;
+    constexpr int RB = BN * 4 / NT;
+    constexpr int HH = TH + 1, HW = TW + 1, HPIX = HH * HW;
+    constexpr int PHALF = HPIX * 32, P23 = round128(PHALF) + 64, PLANE_P = round128(P23 + PHALF);
+    constexpr int W23 = BN * 32 + 64, PLANE_W = round128(W23 + BN * 32);
+    constexpr int MT = 4, NTW = BN / (16 * WN);
+    __shared__ __attribute__((aligned(16))) unsigned char smem[NS * PLANE_P + 2 * NB * PLANE_W];
+    unsigned char *Ph = smem, *Pl = smem + PLANE_P;
+    unsigned char *Wbase = smem + NS * PLANE_P;            // two tap tiles of (Wh, Wl)
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int l15 = lane & 15, lg = lane >> 4;
+    const int wm = wave / WN, wn = wave % WN;
+    int tile = hoig_xcd_remap(blockIdx.x, p.nblk);
+    int P = 0, Q = 0;
+    if (SCATTER) {
+        P = (tile >> 1) & 1;
+        Q = tile & 1;
+        tile >>= 2;
+    }
+    int mt_ = tile / p.nblk_n;
+    const int n0 = (tile % p.nblk_n) * BN;
+    const int tx_ = mt_ % p.tiles_x;
+    mt_ /= p.tiles_x;
+    const int ty_ = mt_ % p.tiles_y, b = mt_ / p.tiles_y;
+    const int y0 = ty_ * TH, x0 = tx_ * TW;                // coarse-grid tile origin
+
+    const int brow = tid >> 2, bpos = tid & 3;
+    const unsigned short *wrow_h[RB], *wrow_l[RB];
+    int woff[RB];
 #pragma unroll
-        for (int j = 0; j < NTW; ++j)
+    for (int i = 0; i < RB; ++i) {
+        const int row = brow + (NT / 4) * i;
+        const int n = n0 + row;
+        const size_t o = ((size_t)(n >> 5) * (p.K >> 5)) * 1024 + (n & 31) * 32 + bpos * 8;
+        wrow_h[i] = n < p.N ? p.Wh + o : nullptr;
+        wrow_l[i] = (NB == 2 && n < p.N) ? p.Wl + o : nullptr;
+        const int c = bpos ^ ((row >> 2) & 3);
+        woff[i] = (c >> 1) * W23 + row * 32 + (c & 1) * 16;
+    }
+    int wread[NTW], pread[MT];
 #pragma unroll
-            for (int q = 0; q < 4; ++q)
+    for (int j = 0; j < NTW; ++j) wread[j] = (lg >> 1) * W23 + (wn * (NTW * 16) + j * 16 + l15) * 32 + (lg & 1) * 16;
 #pragma unroll
-                for (int o = 1; o < 16; o <<= 1) {
-                    st1[j][q] += __shfl_xor(st1[j][q], o);
-                    st2[j][q] += __shfl_xor(st2[j][q], o);
+    for (int m = 0; m < MT; ++m)
+        pread[m] = (lg >> 1) * P23 + ((wm * 2 + (m >> 1)) * HW + (m & 1) * 16 + l15) * 32 + (lg & 1) * 16;
+
+    f32x4 acc[NTW][MT];
+#pragma unroll
+    for (int j = 0; j < NTW; ++j)
+#pragma unroll
+        for (int m = 0; m < MT; ++m) acc[j][m] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    // ---- step table (wave-uniform scalar code; see conv_halo_s2_bf16_kernel) ----
+    struct Step {
+        int cb, ntap, tap[2], pp, qq;
+        bool load;
+    };
+    const int spc = SCATTER ? ((P ? 2 : 1) * (Q ? 2 : 1) + 1) / 2 : 5;     // steps per 32-channel block
+    const int ncb = p.Cg >> 5, T = ncb * spc;
+    auto step_info = [&](int step) -> Step {
+        Step s_;
+        s_.cb = step / spc;
+        const int idx = step - s_.cb * spc;
+        s_.pp = s_.qq = 0;
+        if (!SCATTER) {
+            s_.load = idx != 1;
+            switch (idx) {
+                case 0: s_.pp = 1; s_.qq = 1; s_.ntap = 2; s_.tap[0] = 0; s_.tap[1] = 2; break;
+                case 1: s_.pp = 1; s_.qq = 1; s_.ntap = 2; s_.tap[0] = 6; s_.tap[1] = 8; break;
+                case 2: s_.pp = 1; s_.qq = 0; s_.ntap = 2; s_.tap[0] = 1; s_.tap[1] = 7; break;
+                case 3: s_.pp = 0; s_.qq = 1; s_.ntap = 2; s_.tap[0] = 3; s_.tap[1] = 5; break;
+                default: s_.ntap = 1; s_.tap[0] = 4; s_.tap[1] = 4; break;
+            }
+        } else {
+            s_.load = idx == 0;
+            const int r0 = P ? 0 : 1, r1 = 2, s0 = Q ? 0 : 1, s1 = 2;
+            if (P && Q) {
+                s_.ntap = 2;
+                s_.tap[0] = (idx ? r1 : r0) * 3 + s0;
+                s_.tap[1] = (idx ? r1 : r0) * 3 + s1;
+            } else if (P) {
+                s_.ntap = 2; s_.tap[0] = r0 * 3 + s0; s_.tap[1] = r1 * 3 + s0;
+            } else if (Q) {
+                s_.ntap = 2; s_.tap[0] = r0 * 3 + s0; s_.tap[1] = r0 * 3 + s1;
+            } else {
+                s_.ntap = 1; s_.tap[0] = s_.tap[1] = 4;
+            }
+        }
+        return s_;
+    };
+    // halo offset (rows, columns in {0,1}) of tap (r,s):  gather: (r != 0, s != 0)   scatter: (r == 0, s == 0)
+    auto tap_off = [&](int tap) -> int {
+        const int r = tap / 3, s_ = tap - r * 3;
+        const int dr = SCATTER ? (r == 0) : (r != 0), dc = SCATTER ? (s_ == 0) : (s_ != 0);
+        return (dr * HW + dc) * 32;
+    };
+
+    uint4 rbh[2][RB], rbl[2][RB];
+    auto load_b = [&](const Step &s_) {
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {
+            const size_t koff = (size_t)(s_.tap[t] * p.Cg + s_.cb * 32) * 32;
+#pragma unroll
+            for (int i = 0; i < RB; ++i) {
+                rbh[t][i] = wrow_h[i] ? *reinterpret_cast<const uint4 *>(wrow_h[i] + koff) : make_uint4(0, 0, 0, 0);
+                if (NB == 2)
+                    rbl[t][i] = wrow_l[i] ? *reinterpret_cast<const uint4 *>(wrow_l[i] + koff) : make_uint4(0, 0, 0, 0);
+            }
+        }
+    };
+    auto store_b = [&]() {
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {
+            unsigned char *Wh = Wbase + t * NB * PLANE_W, *Wl = Wh + PLANE_W;
+#pragma unroll
+            for (int i = 0; i < RB; ++i) {
+                *reinterpret_cast<uint4 *>(Wh + woff[i]) = rbh[t][i];
+                if (NB == 2) *reinterpret_cast<uint4 *>(Wl + woff[i]) = rbl[t][i];
+            }
+        }
+    };
+    const float *Aimg = p.A + (size_t)b * p.H * p.W * p.Cg;       // p.H x p.W: the gathered tensor (fine grid in gather mode)
+    constexpr int HSLICES = (HPIX * 8 + NT - 1) / NT;
+    float4 hregs[2][HSLICES];                                     // halo images fetched TWO steps ahead, alternating sets
+    auto halo_load = [&](const Step &s_, float4 (&hreg)[HSLICES]) {
+#pragma unroll
+        for (int sl = 0; sl < HSLICES; ++sl) {
+            const int i = tid + NT * sl;
+            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (i < HPIX * 8) {
+                const int pix = i >> 3, c4 = i & 7;
+                const int hy = pix / HW, hx = pix - hy * HW;
+                const int gy = SCATTER ? y0 + hy : 2 * (y0 - 1 + hy) + s_.pp;
+                const int gx = SCATTER ? x0 + hx : 2 * (x0 - 1 + hx) + s_.qq;
+                if (gy >= 0 && gy < p.H && gx >= 0 && gx < p.W)
+                    v = *reinterpret_cast<const float4 *>(Aimg + ((size_t)gy * p.W + gx) * p.Cg + s_.cb * 32 + c4 * 4);
+            }
+            hreg[sl] = v;
+        }
+    };
+    auto halo_store = [&](const float4 (&hreg)[HSLICES]) {
+#pragma unroll
+        for (int sl = 0; sl < HSLICES; ++sl) {
+            const int i = tid + NT * sl;
+            if (i < HPIX * 8) {
+                const int pix = i >> 3, c4 = i & 7;
+                uint2 hi, lo;
+                split4t<F16>(hreg[sl], hi, lo);
+                const int off = (c4 >> 2) * P23 + pix * 32 + (c4 & 3) * 8;
+                *reinterpret_cast<uint2 *>(Ph + off) = hi;
+                if (NS == 2) *reinterpret_cast<uint2 *>(Pl + off) = lo;
+            }
+        }
+    };
+    auto compute = [&](const Step &s_) {
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {
+            if (t >= s_.ntap) break;
+            const int tapoff = tap_off(s_.tap[t]);
+            const unsigned char *Wh = Wbase + t * NB * PLANE_W, *Wl = Wh + PLANE_W;
+            bf16x8 ph[MT], pl[MT];
+#pragma unroll
+            for (int m = 0; m < MT; ++m) {
+                ph[m] = *reinterpret_cast<const bf16x8 *>(Ph + pread[m] + tapoff);
+                if (NS == 2) pl[m] = *reinterpret_cast<const bf16x8 *>(Pl + pread[m] + tapoff);
+            }
+            bf16x8 wh[2], wl[2];
+            wh[0] = *reinterpret_cast<const bf16x8 *>(Wh + wread[0]);
+            if (NB == 2) wl[0] = *reinterpret_cast<const bf16x8 *>(Wl + wread[0]);
+#pragma unroll
+            for (int j = 0; j < NTW; ++j) {
+                if (j + 1 < NTW) {
+                    wh[(j + 1) & 1] = *reinterpret_cast<const bf16x8 *>(Wh + wread[j + 1]);
+                    if (NB == 2) wl[(j + 1) & 1] = *reinterpret_cast<const bf16x8 *>(Wl + wread[j + 1]);
                 }
-        __syncthreads();
-        float *red = reinterpret_cast<float *>(smem);      // [WM][2][BN]
-        if (l15 == 0) {
+                __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-            for (int j = 0; j < NTW; ++j)
+                for (int m = 0; m < MT; ++m) {
+                    if (NS == 2) acc[j][m] = mfma_m16<F16>(wh[j & 1], pl[m], acc[j][m]);
+                    if (NB == 2) acc[j][m] = mfma_m16<F16>(wl[j & 1], ph[m], acc[j][m]);
+                    acc[j][m] = mfma_m16<F16>(wh[j & 1], ph[m], acc[j][m]);
+                }
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        }
+    };
+
+    Step cur = step_info(0);
+    halo_load(cur, hregs[0]);
+    load_b(cur);
+    halo_store(hregs[0]);
+    store_b();
+    Step nxt = cur;
+    if (T > 1) {
+        nxt = step_info(1);
+        if (nxt.load) halo_load(nxt, hregs[1]);
+    }
+    __syncthreads();
+    auto one_step = [&](int step, float4 (&mine)[HSLICES], float4 (&other)[HSLICES]) {
+        const bool more = step + 1 < T;
+        if (more) load_b(nxt);
+        if (step + 2 < T) {
+            const Step n2 = step_info(step + 2);
+            if (n2.load) halo_load(n2, mine);             // stored at the end of step+1
+        }
+        compute(cur);
+        if (more) {
+            __syncthreads();                  // every wave has finished reading the weight tiles (and the halo)
+            if (nxt.load) halo_store(other);  // fetched during step-1
+            store_b();
+            __syncthreads();
+            cur = nxt;
+            if (step + 2 < T) nxt = step_info(step + 2);
+        }
+    };
+#pragma unroll 1
+    for (int step = 0; step < T; step += 2) {
+        one_step(step, hregs[0], hregs[1]);
+        if (step + 1 < T) one_step(step + 1, hregs[1], hregs[0]);
+    }
+
+    const float nslope = p.act == HOIG_ACT_NONE ? 1.f : (p.act == HOIG_ACT_RELU ? 0.f : p.slope);
+    const bool special = p.act == HOIG_ACT_TANH || p.act == HOIG_ACT_SIGMOID;
+    float4 bias_r[NTW];
+#pragma unroll
+    for (int j = 0; j < NTW; ++j) {
+        const int n = n0 + wn * (NTW * 16) + j * 16 + lg * 4;
+        bias_r[j] = (p.bias && n < p.N) ? *reinterpret_cast<const float4 *>(p.bias + n) : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+    float st1[NTW][4], st2[NTW][4];
+#pragma unroll
+    for (int j = 0; j < NTW; ++j)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) st1[j][q] = st2[j][q] = 0.f;
+    // output grid: gather mode = the coarse grid; scatter mode = twice the coarse grid, phase (P,Q)
+    const int Ho = SCATTER ? 2 * p.H : p.tiles_y * TH, Wo = SCATTER ? 2 * p.W : p.tiles_x * TW;
+#pragma unroll
+    for (int m = 0; m < MT; ++m) {
+        const int cy = y0 + wm * 2 + (m >> 1), cx = x0 + (m & 1) * 16 + l15;
+        const int oy = SCATTER ? 2 * cy + P : cy, ox = SCATTER ? 2 * cx + Q : cx;
+        const size_t pix = ((size_t)b * Ho + oy) * Wo + ox;
+#pragma unroll
+        for (int j = 0; j < NTW; ++j) {
+            const int n = n0 + wn * (NTW * 16) + j * 16 + lg * 4;
+            if (n < p.N) {
+                float v[4];
+                const float bq[4] = {bias_r[j].x, bias_r[j].y, bias_r[j].z, bias_r[j].w};
+#pragma unroll
+                for (int q = 0; q < 4; ++q) v[q] = fast_act(acc[j][m][q] * p.oscale + bq[q], nslope, special, p.act, p.slope);
+                if (p.addend) {
+                    const float4 ad = *reinterpret_cast<const float4 *>(p.addend + pix * p.N + n);
+                    v[0] += ad.x; v[1] += ad.y; v[2] += ad.z; v[3] += ad.w;
+                }
 #pragma unroll
                 for (int q = 0; q < 4; ++q) {
-                    const int cl = wn * (NTW * 16) + j * 16 + lg * 4 + q;
-                    red[(wm * 2 + 0) * BN + cl] = st1[j][q];
-                    red[(wm * 2 + 1) * BN + cl] = st2[j][q];
+                    st1[j][q] += v[q];
+                    st2[j][q] += v[q] * v[q];
                 }
-        }
-        __syncthreads();
-        float *stats_img = p.stats + (size_t)b * 2 * p.N;
-        for (int e = tid; e < 2 * BN; e += NT) {
-            const int mom = e / BN, cl = e - mom * BN;
-            float v = 0.f;
-#pragma unroll
-            for (int k = 0; k < WM; ++k) v += red[(k * 2 + mom) * BN + cl];
-            if (n0 + cl < p.N) atomicAdd(&stats_img[(size_t)mom * p.N + n0 + cl], v);
+                *reinterpret_cast<float4 *>(p.C + pix * p.N + n) = make_float4(v[0], v[1], v[2], v[3]);
+            }
         }
     }
+    if (p.stats) m16_stats_epilogue<NTW, 2, BN, NT>(st1, st2, smem, p.stats + (size_t)b * 2 * p.N, p.N, n0, wm, wn, lane, tid);
 }
 
 template <int NS, int BN>
@@ -336,7 +615,27 @@ int launch_one(const HaloArgs &a, hipStream_t st) {
     return HOIG_OK;
 }
 
+template <bool SCATTER>
+int launch_s2(const HaloArgs &a, int ns, hipStream_t st) {
+    const bool n64 = (a.N % 128) != 0;
+    if (n64) {
+        if (a.f16) HOIG_NS_SWITCH(ns, conv_halo_s2_m16_kernel<NSX, 64, SCATTER, true><<<a.nblk, 256, 0, st>>>(a));
+        else HOIG_NS_SWITCH(ns, conv_halo_s2_m16_kernel<NSX, 64, SCATTER, false><<<a.nblk, 256, 0, st>>>(a));
+    } else {
+        if (a.f16) HOIG_NS_SWITCH(ns, conv_halo_s2_m16_kernel<NSX, 128, SCATTER, true><<<a.nblk, 256, 0, st>>>(a));
+        else HOIG_NS_SWITCH(ns, conv_halo_s2_m16_kernel<NSX, 128, SCATTER, false><<<a.nblk, 256, 0, st>>>(a));
+    }
+    HOIG_LAUNCH_CHECK();
+    return HOIG_OK;
+}
+
 }  // namespace
+
+// the stride-2 3x3 layers: `a` arrives with the geometry launch_halo_s2 (conv_igemm_bf16.hip) computes
+int launch_halo_s2_m16(const HaloArgs &a, int ns, bool scatter, hipStream_t st) {
+    if (a.N % 64 || a.Cg % 32) return HOIG_EUNSUPPORTED;
+    return scatter ? launch_s2<true>(a, ns, st) : launch_s2<false>(a, ns, st);
+}
 
 // `a` arrives with the geometry of an 8-row tiling filled in (tiles_x / tiles_y / nblk_n / nblk / nmajor) for channel tiles
 // of `bn` = 128 or 64

@@ -1020,6 +1020,13 @@ int launch_halo3(HaloArgs a, int ns, hipStream_t st) {
         }
         HOIG_NS_SWITCH(ns, return launch_halo3_one<NSX, 2, 2, 64, 0>(a, st));
     }
+    if (m16 && hoig_tuning(HOIG_TUNE_FEW128) != 0 && a.H % 8 == 0 && a.nblk / 2 < 256 && a.nblk >= 192 && a.N % 128 == 0) {
+        // experiment: the 8-image launches of src_model / tsf_model (which run side by side on two streams) on 128-channel
+        // tiles -- 128 workgroups each, half the chip per launch -- instead of 256 workgroups of 64-channel tiles
+        a.tiles_y = a.H / 8;
+        a.nblk = a.Bn * a.tiles_x * a.tiles_y * a.nblk_n;
+        return launch_halo3_m16(a, ns, 128, st);
+    }
     if (a.H % 8 == 0 && a.nblk / 2 < 256 && a.nblk >= 192) {   // too few 8-row tiles at BN = 128: 8 rows x 64 channels
         a.tiles_y = a.H / 8;
         a.nblk_n = a.N / 64;
@@ -1333,6 +1340,9 @@ int launch_halo_s2(HaloArgs a, int ns, hipStream_t st) {
     a.nblk_n = a.N / (n64 ? 64 : 128);
     a.nblk = a.Bn * a.tiles_x * a.tiles_y * a.nblk_n * (SCATTER ? 4 : 1);
     a.nmajor = 0;
+    // on v_mfma_f32_16x16x32 (conv_halo16.hip): +10..24 % (profiles/r04_s2_16_ab.txt) except the scatter launches with 64-channel
+    // tiles (ConvTranspose2d 128 -> 64 forward at full resolution: -5 %), which stay on the 32x32 kernel
+    if (hoig_tuning(HOIG_TUNE_S2_16) != 0 && !(SCATTER && n64)) return launch_halo_s2_m16(a, ns, SCATTER, st);
     if (n64) {
         if (a.f16) HOIG_NS_SWITCH(ns, conv_halo_s2_bf16_kernel<NSX, 64, SCATTER, true><<<a.nblk, 256, 0, st>>>(a));
         else HOIG_NS_SWITCH(ns, conv_halo_s2_bf16_kernel<NSX, 64, SCATTER, false><<<a.nblk, 256, 0, st>>>(a));
@@ -1549,6 +1559,33 @@ int run(const hoig_conv_desc *d, const float *a, const unsigned short *wh, const
         return launch_halo<5>(h, ns, st);
     }
     if (a2 || c2) return HOIG_EUNSUPPORTED;
+    // 3x3 "same" layers with too few tiles for the halo kernel above (N = 128 at 32 x 32: the data gradient of SPADE's 128 -> 1024
+    // convolutions): a valid convolution over the zero-padded canvas on the flattened-axis kernel, split over the channel blocks
+    if (hoig_tuning(HOIG_TUNE_FLAT5) >= 2 && !d->transposed && d->stride == 1 && d->R == 3 && d->S == 3 && d->pad == 1 &&
+        p.N % 128 == 0 && !stats) {
+        FlatArgs f;
+        f.A = a; f.Wh = wh; f.Wl = wl; f.bias = bias; f.C = c; f.addend = addend;
+        f.Bn = d->B; f.Hc = d->Hi + 2; f.Wc = d->Wi + 2; f.KS = 3; f.act = p.act; f.slope = p.slope;
+        f.Cg = g.Cg; f.N = p.N; f.K = p.K; f.flip = dgrad ? 1 : 0; f.f16 = p.f16; f.oscale = p.oscale;
+        f.Hs = d->Hi; f.Ws = d->Wi; f.oy = f.ox = 1; f.Hd = d->Hi; f.Wd = d->Wi;
+        const int rc = launch_flat_m16(f, ns, st);
+        if (rc != HOIG_EUNSUPPORTED) return rc;
+    }
+    // the attention's VALID 5x5 convolutions over narrow maps (and their data gradients) on the flattened-axis halo kernel
+    if (hoig_tuning(HOIG_TUNE_FLAT5) != 0 && !d->transposed && d->stride == 1 && d->R == 5 && d->S == 5 && d->pad == 0 &&
+        d->Ho == d->Hi - 4 && d->Wo == d->Wi - 4 && p.N % 128 == 0 && !stats) {
+        FlatArgs f;
+        f.A = a; f.Wh = wh; f.Wl = wl; f.bias = bias; f.C = c; f.addend = addend;
+        f.Bn = d->B; f.Hc = d->Hi; f.Wc = d->Wi; f.KS = 5; f.act = p.act; f.slope = p.slope;
+        f.Cg = g.Cg; f.N = p.N; f.K = p.K; f.flip = dgrad ? 1 : 0; f.f16 = p.f16; f.oscale = p.oscale;
+        if (!dgrad) {
+            f.Hs = d->Hi; f.Ws = d->Wi; f.oy = f.ox = 0; f.Hd = d->Ho; f.Wd = d->Wo;
+        } else {
+            f.Hs = d->Ho; f.Ws = d->Wo; f.oy = f.ox = 4; f.Hd = d->Hi; f.Wd = d->Wi;
+        }
+        const int rc = launch_flat_m16(f, ns, st);
+        if (rc != HOIG_EUNSUPPORTED) return rc;
+    }
     // stride-2 3x3 pad-1 layers on the parity-phase halo kernel.  gather: Conv2d forward / ConvTranspose2d data gradient;
     // scatter: ConvTranspose2d forward / Conv2d data gradient
     static const bool no_s2 = getenv("HOIG_NO_HALO_S2") != nullptr;
@@ -1575,7 +1612,10 @@ int run(const hoig_conv_desc *d, const float *a, const unsigned short *wh, const
         }
     }
     if (addend || stats) return HOIG_EUNSUPPORTED;
-    const bool m16 = hoig_tuning(HOIG_TUNE_IGEMM16) != 0;      // on v_mfma_f32_16x16x32 (conv_igemm16.hip)
+    // on v_mfma_f32_16x16x32 (conv_igemm16.hip): 1 = forward launches (three fp16 terms: +16 % on the attention's 5x5 convolutions),
+    // 2 = data gradients too (two bf16 terms per k-block leave less to hide the single LDS stage behind: measured 0-25 % slower)
+    const int t16 = hoig_tuning(HOIG_TUNE_IGEMM16);
+    const bool m16 = t16 >= 2 || (t16 == 1 && !dgrad);
     if (p.N <= 64) {
         if (t128 >= 512) return m16 ? launch_igemm_m16(p, ns, 3, st) : launch<128, 64, 2, 2>(p, ns, st);
         return m16 ? launch_igemm_m16(p, ns, 4, st) : launch<64, 64, 2, 2>(p, ns, st);

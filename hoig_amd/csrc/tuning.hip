@@ -12,6 +12,9 @@ Entry g_table[HOIG_TUNE_COUNT] = {
     {"mfma16", 1},
     {"wgrad16", 0},
     {"igemm16", 0},
+    {"s2_16", 0},
+    {"flat5", 0},
+    {"few128", 0},
 };
 }  // namespace
 

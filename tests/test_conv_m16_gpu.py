@@ -179,3 +179,42 @@ def test_wgrad16_weight_and_bias_gradient(B, C1, C2, Co, H, W, mode):
     assert rel_err(dw1, wr.grad) < (8e-3 if mode == 'f16x2' else 3e-4)
     if br is not None:
         assert rel_err(db1, br.grad) < 1e-4
+
+
+@pytest.mark.parametrize('mode', ['bf16x3', 'f16x2'])
+@pytest.mark.parametrize('B,Ci,Co,Hi,Wi,bias', [(8, 512, 128, 40, 40, False),      # the attention's source-side convolution
+                                                (8, 128, 128, 36, 36, True),       # ... its target side (output 32 x 32)
+                                                (2, 128, 256, 21, 44, True),       # two channel tiles, no split over the channel blocks
+                                                (1, 64, 128, 9, 52, False)])       # the widest canvas the kernel takes; one image
+def test_flat5_valid_convolution_and_its_data_gradient(B, Ci, Co, Hi, Wi, bias, mode):
+    """Tuning key 'flat5' (conv_flat16.hip): valid 5x5 convolutions on the flattened pixel axis, forward (split over the channel
+    blocks with the atomic epilogue where the launch has few tiles) and data gradient (N = Ci: needs Ci % 128 == 0, else the generic
+    kernel runs), against torch fp32 and against the generic kernel."""
+    from hoig_amd import ops, _lib as L
+    g = torch.Generator().manual_seed(23)
+    x = torch.randn(B, Hi, Wi, Ci, generator=g).cuda()
+    w = ops.pack_weight((torch.randn(Co, Ci, 5, 5, generator=g) * 0.03).cuda())
+    b = torch.randn(Co, generator=g).cuda() if bias else None
+    gy = torch.randn(B, Hi - 4, Wi - 4, Co, generator=g).cuda()
+    prev = L.set_tuning('flat5', 0)
+    ops.set_precision(mode)
+    try:
+        res = []
+        for v in (0, 1):
+            L.set_tuning('flat5', v)
+            xd = x.clone().requires_grad_(True)
+            y = ops.conv2d(xd, w.clone().requires_grad_(True), b, 1, 0)
+            y.backward(gy)
+            torch.cuda.synchronize()
+            res.append((y.detach(), xd.grad))
+    finally:
+        ops.set_precision('f32')
+        L.set_tuning('flat5', prev)
+    xr = x.permute(0, 3, 1, 2).clone().requires_grad_(True)
+    yr = F.conv2d(xr, w, b)
+    yr.backward(gy.permute(0, 3, 1, 2))
+    bf, bd = (3e-4, 3e-4) if mode == 'bf16x3' else (1e-3, 8e-3)
+    for tag, (y, dx) in zip(('generic', 'flat'), res):
+        ef, ed = rel_err(y, yr.detach().permute(0, 2, 3, 1)), rel_err(dx, xr.grad.permute(0, 2, 3, 1))
+        assert ef < bf and ed < bd, (tag, ef, ed)
+    assert rel_err(res[1][0], res[0][0]) < 1e-5 and rel_err(res[1][1], res[0][1]) < 1e-4

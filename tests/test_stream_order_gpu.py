@@ -9,7 +9,7 @@ or half-written data, and the step leaves the single-stream step's results -- wh
 
 What is compared, from a common seeded state: the loss terms of two steps, and after EACH step the first Adam moment of both
 networks (0.5 * gradient after step 1: exactly what the optimiser READ, so an optimiser that ran ahead of a late weight gradient
-shows up directly) and the parameter update.  test_the_detector_sees_a_missing_join removes Trainer._join_backward_streams and
+shows up directly), tensor by tensor.  test_the_detector_sees_a_missing_join removes Trainer._join_backward_streams and
 demands that the same check FAILS."""
 import pytest
 import torch
@@ -31,7 +31,7 @@ def _precision():
 
 
 def _run(side, batch, delays=None, single_stream=False, graph=False, steps=2):
-    """-> per step: (losses, G's first moment, D's first moment, G's weights), from the seeded state."""
+    """-> per step: (losses, G's first Adam moment, D's, the two networks), from the seeded state."""
     from hoig_amd import ops
     from hoig_amd.models.networks import generator as G
     fork, wside = G._FORK_STREAMS, ops._WGRAD_SIDE
@@ -41,14 +41,12 @@ def _run(side, batch, delays=None, single_stream=False, graph=False, steps=2):
         G._FORK_STREAMS, ops._WGRAD_SIDE = False, False
     try:
         m = product_trainer('generator_spade_attn', batch, side, hip_graph=graph)
-        w0 = m._G.flat.clone()
         out = []
         n = steps + (2 if graph else 0)            # (a captured step replays from its third call on a batch shape)
         for i in range(n):
             m.optimize_parameters()
             torch.cuda.synchronize()
-            out.append((m.get_current_errors(), m._optimizer_G.exp_avg.clone(), m._optimizer_D.exp_avg.clone(),
-                        m._G.flat.clone() - w0))
+            out.append((m.get_current_errors(), m._optimizer_G.exp_avg.clone(), m._optimizer_D.exp_avg.clone(), m._G, m._D))
         if graph:
             assert any(g['graphs'] is not None for g in m._graphs.values()), 'the step was never captured'
         return out
@@ -57,23 +55,28 @@ def _run(side, batch, delays=None, single_stream=False, graph=False, steps=2):
         ops._TEST_DELAYS.clear()
 
 
-def _rel(a, b):
-    return float((a - b).norm() / b.norm().clamp_min(1e-30))
+def _worst(net, a, b):
+    """Largest per-tensor relative L2 difference of two flat buffers of `net` -> (value, tensor name)."""
+    da, db = net.export_dict(a), net.export_dict(b)
+    return max((float((da[k] - db[k]).norm() / db[k].norm().clamp_min(1e-30)), k) for k in db)
 
 
 def _compare(run, ref, tag, steps=1):
-    """Step 1 tightly (same weights, same inputs: only the order of fp32 atomic sums differs); later steps of this seeded GAN are
-    chaotic run to run (tests/test_graph_gpu.py::_copy_state: 1 % in g_adv on step 2), so they are held to a bound that a stale
-    read still misses by far."""
+    """Per TENSOR: a weight gradient that arrived after the optimiser read the buffer leaves that tensor's moment at (part of)
+    its value -- a relative difference near 1 -- while the aggregate norm of a 183-M-parameter network would hide a late 25-k stem.
+    Run-to-run noise: fp32 atomics reorder the instance-norm sums, ReLU masks flip at values near zero, and single gradient
+    tensors then differ by up to 2e-2 between two runs of the SAME code; later steps of this seeded GAN are
+    chaotic (tests/test_graph_gpu.py::_copy_state: 1 % in g_adv on step 2), so they are held to a bound that a stale read still
+    misses by far."""
     for i in range(steps):
-        (e, mg, md, dw), (er, mgr, mdr, dwr) = run[i], ref[i]
+        (e, mg, md, net_g, net_d), (er, mgr, mdr, _, _) = run[i], ref[i]
         tol = 1e-3 if i == 0 else 5e-2
         for k in er:
             assert abs(e[k] - er[k]) <= tol * max(abs(er[k]), 1e-2), (tag, 'step', i, k, e[k], er[k])
-        lim = 2e-3 if i == 0 else 0.2
-        assert _rel(mg, mgr) < lim, (tag, 'step', i, "G's gradient as Adam read it", _rel(mg, mgr))
-        assert _rel(md, mdr) < lim, (tag, 'step', i, "D's gradient as Adam read it", _rel(md, mdr))
-        assert _rel(dw, dwr) < (0.05 if i == 0 else 0.5), (tag, 'step', i, "G's update", _rel(dw, dwr))
+        lim = 0.1 if i == 0 else 0.6
+        wg, wd = _worst(net_g, mg, mgr), _worst(net_d, md, mdr)
+        assert wg[0] < lim, (tag, 'step', i, "G's gradient as Adam read it", wg)
+        assert wd[0] < lim, (tag, 'step', i, "D's gradient as Adam read it", wd)
 
 
 @pytest.fixture(scope='module')
@@ -98,10 +101,15 @@ def test_delayed_role_captured_graph(role, reference_128):
     run = _run(128, 2, {role: DELAY}, graph=True, steps=1)
     _compare(run, reference_128, role + ' (graph warm-up)', steps=2)
     eager = _run(128, 2, {role: DELAY}, steps=3)
-    (e, mg, md, dw), (er, mgr, mdr, dwr) = run[2], eager[2]
+    (e, mg, md, net_g, net_d), (er, mgr, mdr, _, _) = run[2], eager[2]
     for k in er:
         assert abs(e[k] - er[k]) <= 0.1 * max(abs(er[k]), 1e-2), (role, k, e[k], er[k])
-    assert _rel(mg, mgr) < 0.3 and _rel(md, mdr) < 0.3, (role, _rel(mg, mgr), _rel(md, mdr))
+    # (third step of a chaotic GAN: single small tensors -- a 25-element attention bias -- differ by 0.9 between two runs of the
+    # same code; a stale read would put a whole sub-network's tensors there)
+    for net, a, b in ((net_g, mg, mgr), (net_d, md, mdr)):
+        da, db = net.export_dict(a), net.export_dict(b)
+        far = [k for k in db if float((da[k] - db[k]).norm() / db[k].norm().clamp_min(1e-30)) > 0.5]
+        assert len(far) <= 0.03 * len(db), (role, len(far), len(db), far[:8])
 
 
 def test_the_detector_sees_a_missing_join(reference_128):
@@ -113,8 +121,11 @@ def test_the_detector_sees_a_missing_join(reference_128):
         run = _run(128, 2, {'g_bg': DELAY})
     finally:
         T.Trainer._join_backward_streams = keep
+    (_, mg, _, net_g, _), (_, mgr, _, _, _) = run[0], reference_128[0]
+    worst = _worst(net_g, mg, mgr)
+    assert worst[0] > 0.5 and worst[1].startswith('bg_model'), worst       # the optimiser ran ahead of bg_model's weight gradients
     with pytest.raises(AssertionError):
-        _compare(run, reference_128, 'g_bg without the join', steps=2)
+        _compare(run, reference_128, 'g_bg without the join', steps=1)
 
 
 def test_delayed_roles_at_the_bench_size():

@@ -20,6 +20,10 @@ SHAPES = {
            (8, 128, 512, 64, 64, 3), (16, 128, 512, 64, 64, 3), (8, 64, 64, 256, 256, 3), (8, 64, 128, 128, 128, 3)],
     'wg': [(16, 512, 512, 32, 32, 3), (8, 512, 512, 32, 32, 3), (8, 128, 1024, 32, 32, 3), (16, 128, 1024, 32, 32, 3),
            (8, 256, 256, 64, 64, 3), (8, 128, 256, 128, 128, 3), (16, 128, 256, 128, 128, 3), (8, 64, 64, 256, 256, 3)],
+    # (B, Ci, Co, H, W, k, stride, transposed): the stride-2 3x3 layers of the generator (Conv2d s2 p1 / ConvTranspose2d s2 p1 op1)
+    's2': [(16, 64, 128, 256, 256, 3, 2, 0), (16, 128, 256, 128, 128, 3, 2, 0), (16, 256, 512, 64, 64, 3, 2, 0),
+           (16, 512, 256, 32, 32, 3, 2, 1), (16, 256, 128, 64, 64, 3, 2, 1), (16, 128, 64, 128, 128, 3, 2, 1),
+           (8, 64, 128, 256, 256, 3, 2, 0), (8, 128, 64, 128, 128, 3, 2, 1)],
     'attn5': [(8, 512, 128, 40, 40, 5), (8, 512, 128, 36, 36, 5), (8, 128, 128, 136, 136, 5), (8, 256, 128, 72, 72, 5)],
 }
 
@@ -42,23 +46,28 @@ def main():
     st = torch.cuda.current_stream().cuda_stream
     p = lambda t: t.data_ptr()
     print('precision %s, %d rounds x %d launches, random data' % (a.prec, a.rounds, a.iters))
-    for (B, Ci, Co, H, W, k) in SHAPES[a.shapes]:
+    for shp in SHAPES[a.shapes]:
+        B, Ci, Co, H, W, k = shp[:6]
+        stride, tr = (shp[6], bool(shp[7])) if len(shp) > 6 else (1, False)
         pad = 1 if k == 3 else 0
-        Ho, Wo = H + 2 * pad - k + 1, W + 2 * pad - k + 1
+        if tr:
+            Ho, Wo = 2 * H, 2 * W
+        else:
+            Ho, Wo = (H + 2 * pad - k) // stride + 1, (W + 2 * pad - k) // stride + 1
         x = torch.randn(B, H, W, Ci, device='cuda')
-        w = ops.pack_weight((torch.randn(Co, Ci, k, k, device='cuda') * 0.02))
+        w = ops.pack_weight(torch.randn((Ci, Co, k, k) if tr else (Co, Ci, k, k), device='cuda') * 0.02, transposed=tr)
         dy = torch.randn(B, Ho, Wo, Co, device='cuda')
         y, dx, dw = torch.empty_like(dy), torch.empty_like(x), torch.zeros_like(w)
-        d = L.ConvDesc(B, H, W, Ci, Ho, Wo, Co, k, k, 1, pad, 0, 0, 0.0, ops.precision)
+        d = L.ConvDesc(B, H, W, Ci, Ho, Wo, Co, k, k, stride, pad, 1 if tr else 0, 0, 0.0, ops.precision)
         d_dg, d_wg = ops._bwd_descs(d)
-        hi, lo = ops._packed_planes(w, False, False)
-        thi, tlo = ops._packed_planes(w, False, True)
+        hi, lo = ops._packed_planes(w, tr, False)
+        thi, tlo = ops._packed_planes(w, tr, True)
         fns = {
             'fwd': lambda: L.call('hoig_conv2d_fwd_packed', ctypes.byref(d), p(x), p(hi), p(lo), None, p(y), st),
             'dgrad': lambda: L.call('hoig_conv2d_bwd_data_packed', ctypes.byref(d_dg), p(dy), p(thi), p(tlo), p(dx), st),
             'wgrad': lambda: L.call('hoig_conv2d_bwd_weight', ctypes.byref(d_wg), p(x), p(dy), p(dw), None, st),
         }
-        flop = 2.0 * B * Ho * Wo * Ci * Co * k * k
+        flop = 2.0 * B * (H * W if tr else Ho * Wo) * Ci * Co * k * k
         for kind in a.kinds.split(','):
             fn = fns[kind]
             times = [[] for _ in variants]
@@ -75,7 +84,7 @@ def main():
                     torch.cuda.synchronize()
                     if r:                      # round 0 warms up
                         times[vi].append(e0.elapsed_time(e1) / a.iters * 1e3)
-            line = '%-5s %2d %3dx%-3d %4d->%-4d k%d |' % (kind, B, H, W, Ci, Co, k)
+            line = '%-5s %2d %3dx%-3d %4d->%-4d k%d s%d%s |' % (kind, B, H, W, Ci, Co, k, stride, 'T' if tr else ' ')
             for v, t in zip(a.variants, times):
                 med, mn = statistics.median(t), min(t)
                 line += '  [%s] med %7.1f us %6.1f TF  min %7.1f us |' % (v, med, flop / med / 1e6, mn)

@@ -13,20 +13,28 @@ from hoig_amd import _lib as L, ops, synthetic            # noqa: E402
 from hoig_amd.options import opt_namespace                # noqa: E402
 from hoig_amd.models import ModelsFactory                 # noqa: E402
 
-FAMILIES = {
-    'norm_fwd': ['hoig_inorm_fwd_fused', 'hoig_inorm_stats', 'hoig_inorm_apply', 'hoig_inorm_apply_ld'],
-    'norm_bwd': ['hoig_inorm_bwd_fused_add', 'hoig_inorm_bwd_fused', 'hoig_inorm_bwd', 'hoig_inorm_bwd_ld', 'hoig_inorm_bwd_add_ld'],
-    'conv_fwd': ['hoig_conv2d_fwd_packed', 'hoig_conv2d_fwd', 'hoig_conv2d_cat_fwd_packed', 'hoig_conv2d_fwd_heads'],
-    'conv_dgrad': ['hoig_conv2d_bwd_data_packed', 'hoig_conv2d_bwd_data_packed_add', 'hoig_conv2d_bwd_data',
-                   'hoig_conv2d_cat_bwd_data_packed'],
-    'conv_wgrad': ['hoig_conv2d_bwd_weight'],
-    'attention': ['hoig_attn_pixel_fwd', 'hoig_attn_pixel_bwd', 'hoig_attn_src_gather', 'hoig_attn_gs_gather',
-                  'hoig_replicate_pad_fwd', 'hoig_replicate_pad_bwd_add', 'hoig_replicate_pad_bwd'],
-    'optimiser': ['hoig_adam_step_dev', 'hoig_adam_tick', 'hoig_pack_conv_weights_bf16_all'],
-    'pointwise': ['hoig_add', 'hoig_add_act', 'hoig_act_bwd', 'hoig_act_bwd_colsum', 'hoig_colsum_accum', 'hoig_copy_channels',
-                  'hoig_compose_fwd', 'hoig_compose_bwd', 'hoig_maxpool2_fwd', 'hoig_maxpool2_bwd',
-                  'hoig_loss_accumulate', 'hoig_tv_accumulate', 'hoig_sum', 'hoig_sum_scaled'],
-}
+import re          # noqa: E402
+
+# Families are built from the library's own symbol table (hoig_amd._lib._SIGS) by name pattern, so an entry point added later
+# lands in its family by itself (round 3's hand-written lists missed the *_stats, *_f6 and cat wgrad entry points, and
+# its forward / weight-gradient figures were understated by the launches that kept running).
+PATTERNS = [
+    ('norm_fwd', r'hoig_inorm_(fwd_fused|stats|stats_from_sums|apply|apply_ld)$'),
+    ('norm_bwd', r'hoig_inorm_bwd'),
+    ('conv_wgrad', r'hoig_conv2d_(cat_)?bwd_weight$'),
+    ('conv_dgrad', r'hoig_conv2d_(cat_)?bwd_data'),
+    ('conv_fwd', r'hoig_conv2d_(cat_)?fwd'),
+    ('attention', r'hoig_(attn_(pixel|src_gather|gs_gather)|replicate_pad)'),
+    ('optimiser', r'hoig_(adam_step_dev|adam_tick|adam_step|pack_conv_weights)'),
+    ('pointwise', r'hoig_(add|add_act|act_bwd|act_bwd_colsum|colsum_accum|copy_channels|cat2_channels|compose_fwd|compose_bwd|'
+                  r'maxpool2_fwd|maxpool2_bwd|loss_accumulate|loss_fwd_bwd|tv_accumulate|tv_fwd_bwd|sum|sum_scaled)$'),
+]
+FAMILIES = {name: [] for name, _ in PATTERNS}
+for sym in sorted(L._SIGS):
+    for name, pat in PATTERNS:
+        if re.match(pat, sym):
+            FAMILIES[name].append(sym)
+            break
 
 
 def step_ms(m, steps=12, warmup=3):
@@ -46,6 +54,8 @@ m = ModelsFactory.get_by_name('trainer', opt, use_ddp=False)
 m.set_input(synthetic.make_inputs(8, 256, seed=1))
 full = step_ms(m)
 print('full step                                   %.2f ms' % full, flush=True)
+for fam, names in FAMILIES.items():
+    print('# %-10s %s' % (fam, ' '.join(n[5:] for n in names)))
 stub = lambda *a: 0
 # The optimiser stays knocked out in every other run: the weights then never change, so a family whose outputs are garbage (stale
 # finite memory, not NaN) cannot poison them -- a step on NaN data draws less power and runs 4 ms FASTER, which would be booked
