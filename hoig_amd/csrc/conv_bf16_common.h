@@ -196,7 +196,7 @@ struct FlatArgs {
     int act;
     float slope, oscale;
     int HWc, Q, HP;            // filled in by the launcher: Hc * Wc, Bn * Hc * Wc, halo positions per tile
-    int nblk, nblk_n, cb_per_split;
+    int nblk, nblk_n, steps_per_split;
 };
 int launch_flat_m16(FlatArgs a, int ns, hipStream_t st);
 

@@ -53,7 +53,8 @@ __global__ __launch_bounds__(512) void conv_flat_m16_kernel(const FlatArgs p) {
     const int tile = hoig_xcd_remap(blockIdx.x, p.nblk);
     const int n_mt = p.nblk / p.nblk_n;
     const int q0 = (tile % n_mt) * PT, n0 = (tile / n_mt) * BN;      // channel-tile major: an XCD streams few weight tiles
-    const int cb_begin = blockIdx.y * p.cb_per_split, cb_end = min(p.Cg >> 5, cb_begin + p.cb_per_split);
+    // split over K: this workgroup multiplies steps [s_begin, s_end) of the (channel block, tap group) walk
+    const int s_begin = blockIdx.y * p.steps_per_split, s_end = min((p.Cg >> 5) * ((KS * KS + TPS - 1) / TPS), s_begin + p.steps_per_split);
 
     // halo: thread -> (position h, 4-channel group c4); the source offset of a position does not depend on the channel block
     int src_off[HSL];
@@ -96,9 +97,9 @@ __global__ __launch_bounds__(512) void conv_flat_m16_kernel(const FlatArgs p) {
         for (int m = 0; m < MT; ++m) acc[j][m] = f32x4{0.f, 0.f, 0.f, 0.f};
 
     uint4 rbh[TPS], rbl[TPS];
-    const int T = (cb_end - cb_begin) * NGRP;             // step = (channel block, group of TPS taps)
+    const int T = s_end - s_begin;                        // step = (channel block, group of TPS taps)
     auto load_b = [&](int step) {
-        const int cb = cb_begin + step / NGRP, g = step % NGRP;
+        const int cb = (s_begin + step) / NGRP, g = (s_begin + step) % NGRP;
 #pragma unroll
         for (int t = 0; t < TPS; ++t) {
             const int tap = min(g * TPS + t, KK - 1);
@@ -196,7 +197,7 @@ __global__ __launch_bounds__(512) void conv_flat_m16_kernel(const FlatArgs p) {
     };
 
     if (T > 0) {
-        halo_load(cb_begin);
+        halo_load(s_begin / NGRP);
         halo_store();
         load_b(0);
         store_b(0);
@@ -206,12 +207,12 @@ __global__ __launch_bounds__(512) void conv_flat_m16_kernel(const FlatArgs p) {
     int bbuf = 0;
 #pragma unroll 1
     for (int step = 0; step < T; ++step) {
-        const int cbi = step / NGRP, g = step - cbi * NGRP;
+        const int cb = (s_begin + step) / NGRP, g = (s_begin + step) - cb * NGRP;
         const bool more = step + 1 < T;
         const bool boundary = more && g == NGRP - 1;
         if (more) store_b(bbuf ^ 1);                  // weights of step+1 (registers loaded during the previous step)
         if (step + 2 < T) load_b(step + 2);
-        if (boundary) halo_load(cb_begin + cbi + 1);
+        if (boundary) halo_load(cb + 1);
         compute(g, bbuf);
         if (boundary) {
             __syncthreads();                          // every wave is done with the halo
@@ -329,14 +330,15 @@ int launch_flat_m16(FlatArgs a, int ns, hipStream_t st) {
     a.nblk_n = a.N / BN;
     a.nblk = n_mt * a.nblk_n;
     const int ncb = a.Cg >> 5;
+    const int steps = ncb * ((KS * KS + TPS - 1) / TPS);
     int split = 1;
-    if (a.nblk <= 128 && !a.addend && a.act == HOIG_ACT_NONE) {      // few tiles, long K: split the channel blocks, add with atomics
+    if (a.nblk <= 128 && !a.addend && a.act == HOIG_ACT_NONE) {      // few tiles, long K: split the step walk, add with atomics
         split = 256 / a.nblk;                     // ONE round of workgroups on the 256 CUs: 300 of them would take two
-        if (split > ncb / 2) split = ncb / 2;
+        if (split > steps / 8) split = steps / 8;
         if (split < 1) split = 1;
     }
-    a.cb_per_split = (int)hoig_cdiv(ncb, split);
-    split = (int)hoig_cdiv(ncb, a.cb_per_split);
+    a.steps_per_split = (int)hoig_cdiv(steps, split);
+    split = (int)hoig_cdiv(steps, a.steps_per_split);
     dim3 grid(a.nblk, split);
     if (split > 1 && hipMemsetAsync(a.C, 0, (size_t)a.Bn * a.Hd * a.Wd * a.N * sizeof(float), st) != hipSuccess) return HOIG_ELAUNCH;
     return KS == 3 ? launch_ks<3>(a, ns, grid, shm, split > 1, st) : launch_ks<5>(a, ns, grid, shm, split > 1, st);

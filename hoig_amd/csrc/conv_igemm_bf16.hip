@@ -385,8 +385,8 @@ int launch(Args a, int ns, hipStream_t st) {
     a.ksplit = 1;
     a.steps_per_split = 0;
     const int steps = (a.K / BK);
-    static const int sk_target = getenv("HOIG_SPLITK_TARGET") ? atoi(getenv("HOIG_SPLITK_TARGET")) : 1024;   // (sweep 512 / 768 / 1024: 2.07 / 1.90 / 1.91 ms for the attention forward GEMMs)
-    static const int sk_maxblk = getenv("HOIG_SPLITK_MAXBLK") ? atoi(getenv("HOIG_SPLITK_MAXBLK")) : 192;
+    constexpr int sk_target = 1024;      // (sweep 512 / 768 / 1024: 2.07 / 1.90 / 1.91 ms for the attention forward GEMMs)
+    constexpr int sk_maxblk = 192;
     if (a.nblk < sk_maxblk && steps >= 32 && a.act == HOIG_ACT_NONE && !a.g.tile_skip) {
         int want = (int)hoig_cdiv(sk_target, a.nblk);
         if (want > steps / 8) want = steps / 8;
@@ -1531,13 +1531,12 @@ int run(const hoig_conv_desc *d, const float *a, const unsigned short *wh, const
     if (ns == 2 && !wl) return HOIG_EINVAL;
     const long t128 = hoig_cdiv(p.M, 128);
     if (p.N <= 32 || p.N % 32 != 0) return HOIG_EUNSUPPORTED;
-    static const bool no_thin = getenv("HOIG_NO_THIN_DGRAD") != nullptr;
-    if (!no_thin && dgrad && !d->transposed && d->R == 1 && d->S == 1 && d->stride == 1 && d->pad == 0 && g.Cg == 128 &&
+    if (dgrad && !d->transposed && d->R == 1 && d->S == 1 && d->stride == 1 && d->pad == 0 && g.Cg == 128 &&
         p.N >= 1024 && p.N % 64 == 0 && p.M % 128 == 0 && !a2 && !c2 && !addend && !stats)
         return launch_dgrad_thin(a, wh, wl, c, p.M, p.N, ns, st);
     // stride-1 "same" convolutions (and their data gradients): LDS-resident input halo, weights streamed per tap
     if (!d->transposed && d->stride == 1 && d->R == d->S && 2 * d->pad == d->R - 1 && (d->R == 1 || d->R == 3 || d->R == 5) &&
-        d->Wi % 32 == 0 && d->Hi % 4 == 0 && p.N % 64 == 0 && getenv("HOIG_NO_HALO") == nullptr &&
+        d->Wi % 32 == 0 && d->Hi % 4 == 0 && p.N % 64 == 0 &&
         (long)d->B * (d->Hi / 4) * (d->Wi / 32) * ((p.N + 127) / 128) >= 160) {   // fewer tiles: the generic kernel splits K
         HaloArgs h;
         h.A = a; h.Wh = wh; h.Wl = wl; h.bias = bias; h.C = c;
@@ -1588,8 +1587,7 @@ int run(const hoig_conv_desc *d, const float *a, const unsigned short *wh, const
     }
     // stride-2 3x3 pad-1 layers on the parity-phase halo kernel.  gather: Conv2d forward / ConvTranspose2d data gradient;
     // scatter: ConvTranspose2d forward / Conv2d data gradient
-    static const bool no_s2 = getenv("HOIG_NO_HALO_S2") != nullptr;
-    if (!no_s2 && d->stride == 2 && d->R == 3 && d->S == 3 && d->pad == 1 && d->Hi % 2 == 0 && d->Wi % 2 == 0 &&
+    if (d->stride == 2 && d->R == 3 && d->S == 3 && d->pad == 1 && d->Hi % 2 == 0 && d->Wi % 2 == 0 &&
         p.N % 64 == 0) {
         // fine / coarse grids: Conv2d: fine = input (Hi), coarse = output (Ho = Hi/2); ConvTranspose2d: fine = output
         const int fine_h = d->transposed ? d->Ho : d->Hi, fine_w = d->transposed ? d->Wo : d->Wi;
@@ -1936,15 +1934,15 @@ int launch_wgrad_bf16(WArgs a, int ns, hipStream_t st) {
     const int nbm = (int)hoig_cdiv(a.Co, BM), nbn = (int)hoig_cdiv(a.K, 128);
     a.nblk_n = nbn;
     a.nblk_mn = nbm * nbn;
-    static const int target_blocks = getenv("HOIG_WGRAD_BLOCKS") ? atoi(getenv("HOIG_WGRAD_BLOCKS")) : 512;
+    constexpr int target_blocks = 512;
     int splits = (int)hoig_cdiv(target_blocks, a.nblk_mn);
     // every split adds |dW| fp32 atomics (~235 G/s chip-wide, i.e. as slow as the MFMA work of ~2000 pixels) while fewer
     // than ~2 workgroups per CU leave SIMDs idle: measured optimum ~512 workgroups (sweep 512/1024/2048: 32.7/33.1/33.1 ms
     // of weight gradients per step), splits of at least 512 pixels
-    static const int min_px = getenv("HOIG_WGRAD_MIN_PX") ? atoi(getenv("HOIG_WGRAD_MIN_PX")) : 512;
+    constexpr int min_px = 512;
     // tiny K (the SPADE label convs: 12 channels x 9 taps): one column tile, next to no atomics, and a workgroup's pixel loop
     // is pure load latency -- split four times finer
-    static const int small_k_px = getenv("HOIG_WGRAD_SMALLK_PX") ? atoi(getenv("HOIG_WGRAD_SMALLK_PX")) : 128;
+    constexpr int small_k_px = 128;
     const int max_splits = (int)hoig_cdiv(a.M, a.K <= 128 ? (small_k_px < min_px ? small_k_px : min_px) : min_px);
     if (splits > max_splits) splits = max_splits;
     if (splits < 1) splits = 1;
@@ -2261,17 +2259,17 @@ int launch_wgrad_halo(const hoig_conv_desc *d, const float *x, const float *dy, 
     }
     const bool s2 = d->stride == 2;
     a.nblk_ci = a.Ci / 32;
-    static const int cm_env = getenv("HOIG_WGRAD_HALO_CM") ? atoi(getenv("HOIG_WGRAD_HALO_CM")) : 2;
+    constexpr int cm_env = 2;
     const int cm = (d->R == 3 && cm_env == 2 && a.Co % 128 == 0) ? 2 : 1;      // (a.Co: channels of the plain operand)
     a.nblk = (a.Co / (64 * cm)) * a.nblk_ci;
     // 4-row pixel tiles for the stride-1 3x3 layers on 128-channel workgroups, where every workgroup still gets >= 8 of them
-    static const int th_env = getenv("HOIG_WGRAD_HALO_TH") ? atoi(getenv("HOIG_WGRAD_HALO_TH")) : 4;
+    constexpr int th_env = 4;
     const bool th4 = th_env == 4 && cm == 2 && d->R == 3 && !s2 && !d->transposed && ns != 2 && a.H % 4 == 0 &&
                      (int64_t)a.Bn * (a.W / 32) * (a.H / 4) * a.nblk >= 8 * 256;
     a.tiles_x = a.W / 32;
     a.tiles_y = a.H / (th4 ? 4 : 2);
     a.n_mtiles = a.Bn * a.tiles_x * a.tiles_y;
-    static const int target_blocks = getenv("HOIG_WGRAD_HALO_BLOCKS") ? atoi(getenv("HOIG_WGRAD_HALO_BLOCKS")) : 512;
+    constexpr int target_blocks = 512;
     // 5x5: a workgroup owns 25 taps x 64 x 32 outputs, so every pixel split costs 2.8x the atomics of a 3x3 one: 256 (measured)
     int splits = (int)hoig_cdiv((d->R == 5 ? target_blocks / 2 : target_blocks) / cm, a.nblk);
     if (splits > a.n_mtiles) splits = a.n_mtiles;
@@ -2311,15 +2309,13 @@ int launch_wgrad_halo(const hoig_conv_desc *d, const float *x, const float *dy, 
 }  // namespace
 
 bool hoig_conv_bf16_wgrad_fuses_bias(const hoig_conv_desc *d) {
-    static const bool no_halo = getenv("HOIG_NO_WGRAD_HALO") != nullptr;
-    if (no_halo || d->precision == HOIG_PREC_F32 || d->R != d->S) return false;
-    static const bool no_s2 = getenv("HOIG_NO_WGRAD_HALO_S2") != nullptr;
+    if (d->precision == HOIG_PREC_F32 || d->R != d->S) return false;
     if (d->transposed)           // ConvTranspose2d 3x3 stride 2 pad 1 output_padding 1: the same kernel with x and dy swapped
-        return !no_s2 && d->stride == 2 && d->R == 3 && d->pad == 1 && d->Ho == 2 * d->Hi && d->Wo == 2 * d->Wi &&
+        return d->stride == 2 && d->R == 3 && d->pad == 1 && d->Ho == 2 * d->Hi && d->Wo == 2 * d->Wi &&
                d->Wi % 32 == 0 && d->Hi % 2 == 0 && d->Co % 32 == 0 && d->Ci % 64 == 0;
     if (d->Wo % 32 || d->Ho % 2 || d->Ci % 32 || d->Co % 64) return false;
     if (d->stride == 2)          // Conv2d 3x3 stride 2 pad 1 on the column-parity halo (the generator's down-sampling layers)
-        return !no_s2 && d->R == 3 && d->pad == 1 && d->Hi == 2 * d->Ho && d->Wi == 2 * d->Wo;
+        return d->R == 3 && d->pad == 1 && d->Hi == 2 * d->Ho && d->Wi == 2 * d->Wo;
     if (d->stride != 1) return false;
     if (d->R == 3) return d->pad == 1 && d->Hi == d->Ho && d->Wi == d->Wo;
     return d->R == 5 && d->pad == 0 && d->Hi == d->Ho + 4 && d->Wi == d->Wo + 4;      // the attention's valid 5x5

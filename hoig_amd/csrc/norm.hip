@@ -15,7 +15,7 @@ inline int inorm_chunks(int HW) {
     // >= 16 pixel rows per workgroup (a 32x32 map already yields 64 workgroups per image), at most HOIG_NORM_CHUNKS (128) per
     // image: every workgroup closes with one atomic per (channel, moment) into the image's accumulators, the workgroups of a
     // launch finish together, and same-address atomics retire at ~25 ns each -- 512 chunks were a 13-us tail on every launch
-    static const int cap = getenv("HOIG_NORM_CHUNKS") ? atoi(getenv("HOIG_NORM_CHUNKS")) : 128;
+    constexpr int cap = 128;
     int n = (HW + 15) / 16;
     if (n > cap) n = cap;
     if (n < 1) n = 1;
@@ -422,7 +422,7 @@ __global__ __launch_bounds__(TNT) void inorm_tile_bwd_kernel(const float *__rest
 }
 
 bool tile_ok(int B, int HW, int C) {
-    static const bool off = getenv("HOIG_NORM_TILE") != nullptr && atoi(getenv("HOIG_NORM_TILE")) == 0;
+    constexpr bool off = false;
     return !off && B > 0 && HW > 0 && HW <= TEPT * TPL && C > 0 && C % TCG == 0;
 }
 

@@ -11,10 +11,10 @@ struct Entry {
 Entry g_table[HOIG_TUNE_COUNT] = {
     {"mfma16", 1},
     {"wgrad16", 0},
-    {"igemm16", 0},
-    {"s2_16", 0},
-    {"flat5", 0},
-    {"few128", 0},
+    {"igemm16", 1},
+    {"s2_16", 1},
+    {"flat5", 2},
+    {"few128", 1},
 };
 }  // namespace
 

@@ -29,13 +29,10 @@ def as_nchw(t):
     return t.permute(0, 3, 1, 2)
 
 
-# HOIG_STREAMS=0 (alias HOIG_G_STREAMS=0): every chain of the step on the caller's stream -- per-kernel profiles only add up that
+# HOIG_STREAMS=0: every chain of the step on the caller's stream -- per-kernel profiles only add up that
 # way.  Default: the sub-networks that do not read each other run on HIP streams of their own ('Concurrent
 # chains'); inside a captured step those forks are the hipGraph's parallel branches.
-_FORK_STREAMS = os.environ.get('HOIG_STREAMS', os.environ.get('HOIG_G_STREAMS', '1')) == '1'
-
-
-_FUSE_HEADS = os.environ.get('HOIG_FUSE_HEADS', '1') == '1'      # A/B switch: the three x-side heads as separate convolutions
+_FORK_STREAMS = os.environ.get('HOIG_STREAMS', '1') == '1'
 
 
 def forks_streams():
@@ -74,7 +71,7 @@ class Generator(ParamTree):
 
     def _branch_streams(self, device):
         if getattr(self, '_streams', None) is None:
-            self._streams = tuple(ops.new_stream(device) for _ in range(3))
+            self._streams = tuple(ops.new_stream(device, role) for role in ('g_bg', 'g_obj', 'g_src'))
         return self._streams
 
     # ---- building blocks -------------------------------------------------------------------
@@ -368,7 +365,7 @@ class Generator(ParamTree):
         # the other half are computed and dropped: 2 of 5 columns of a convolution that is bound by reading its input), so the
         # backward is ONE data gradient instead of three plus two full-resolution zero-padded slice gradients and their sums.
         # It runs where the map was made (the object branch's stream), ahead of the joins below.
-        fused_y = self.F.get('obj_model.heads_y.weight') if (_FUSE_HEADS and obj_both.is_cuda) else None
+        fused_y = self.F.get('obj_model.heads_y.weight') if obj_both.is_cuda else None
         if fused_y is not None:
             with (torch.cuda.stream(s_obj) if fork else contextlib.nullcontext()):
                 obj_o, my_src, my_tsf = ops.conv_heads(obj_both, fused_y, (3, 1, 1), (ACT_TANH, ACT_NONE, ACT_NONE))
@@ -395,7 +392,7 @@ class Generator(ParamTree):
 
         def regress(x, y, p):                                              # generator.py:311-315
             fused = self.F.get(p + '.heads_x.weight')
-            if fused is not None and _FUSE_HEADS and x.is_cuda:
+            if fused is not None and x.is_cuda:
                 img, mh, mbt = ops.conv_heads(x, fused, (3, 1, 1), (ACT_TANH, ACT_SIGMOID, ACT_NONE))
             else:
                 img = self._conv(x, p + '.img_reg.0', pad=3, act=ACT_TANH)

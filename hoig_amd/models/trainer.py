@@ -7,9 +7,10 @@ get_current_scalars / get_current_visuals / save / load / update_learning_rate``
 tensors in HBM, every operator a hand-written gfx950 kernel (hoig_amd/ops.py), one flat buffer per network, fused
 Adam, RCCL gradient exchange overlapped with the D step (hoig_amd/ddp.py).
 
-Out of scope here: ``HandRecoveryFlow`` (MANO + neural renderer input preparation,
-trainer.py:14-185).  ``set_input`` therefore accepts the tensors that stage produces (the a2 surface) -- a dict
-with the keys of ``hoig_amd.synthetic.make_inputs`` -- and raises for raw dataloader batches.
+``set_input`` takes the raw dataloader batch train_ddp.py:92 passes (imageA/B, maskA/B, manoA/B) when the caller supplies the MANO
+model and the per-object renderer buffers -- assets the reference does not ship (``opt.mano_model``, ``opt.object_assets``;
+hoig_amd/hand_recovery.py runs ``HandRecoveryFlow.forward``, trainer.py:46-145, as three device stages) -- or images + rasteriser
+outputs, or the prepared tensors that stage produces (the a2 surface: a dict with the keys of ``hoig_amd.synthetic.make_inputs``).
 """
 import math
 import os
@@ -32,7 +33,6 @@ from .networks.vgg19 import Vgg19, VGGLoss
 # Off by default: on this ROCm the replay costs the host 4 ms instead of 28 ms per step, but the graph's internal stream mapping
 # overlaps the chains less than the eager streams do -- 80.2 / 81.7 ms per replayed step against 74.8 / 79.5 ms eager, two boxes
 #  -- and the step is GPU-bound either way.
-_LOSS_SLOTS = os.environ.get('HOIG_LOSS_SLOTS', '1') == '1'      # A/B switch: 0 = the objectives composed with torch scalar arithmetic
 _GRAPH = os.environ.get('HOIG_GRAPH', '0') == '1'
 _GRAPH_WARMUP = 2         # eager steps per input signature before the capture (lazily made buffers and planes then exist)
 _GRAPH_MAX_SIGNATURES = 3
@@ -53,6 +53,7 @@ def _mark(tag, stream=None):
 PREPARED_KEYS = ['input_G_bg', 'input_G_src_obj', 'input_G_tsf_obj', 'input_G_src_hand', 'input_G_tsf_hand', 'T',
                  'real_src', 'real_tsf', 'bg_mask', 'hand_mask']
 RASTER_KEYS = ['src_img', 'ref_img', 'src_faces', 'src_fim', 'src_wim', 'ref_fim', 'ref_wim', 'tables']
+RAW_KEYS = ['imageA', 'imageB', 'manoA', 'manoB']          # what train_ddp.py:92 passes (trainer.py:324-331)
 
 
 def _labelcolormap(n):
@@ -89,7 +90,7 @@ class Trainer(BaseModel):
         self._dexycb = 'dex' in str(getattr(opt, 'dataset_mode', 'hov3')).lower()
         self._world = dist.get_world_size() if (use_ddp and dist.is_initialized()) else 1
         # G's gradient exchange + Adam run on a side stream beside the D step; D's run there beside the next forward of G
-        self._side = ops.new_stream(self.device)
+        self._side = ops.new_stream(self.device, 'opt')
         self._loss_streams = None
         self._d_stream = None
         self._use_graph = bool(getattr(opt, 'hip_graph', _GRAPH))
@@ -113,7 +114,7 @@ class Trainer(BaseModel):
 
     # ------------------------------------------------------------------ construction (trainer.py:217-322)
     def _init_create_networks(self, use_ddp=False):
-        self._hdr = None          # HandRecoveryFlow: out of scope (needs MANO assets + neural_renderer)
+        self._hdr = None          # hoig_amd.hand_recovery.HandRecoveryFlow, built on the first raw batch (set_raw_input)
         self._G = self._create_generator()
         self._G.init_weights()
         payload = getattr(self._opt, 'ddp_payload', None)        # None: HOIG_DDP_PAYLOAD / fp32 (hoig_amd/ddp.py)
@@ -183,8 +184,8 @@ class Trainer(BaseModel):
         if self._opt.use_vgg:
             self._crt_tsf = VGGLoss(vgg=vgg_net)
         # the terms of the two objectives live in device slots that the loss kernels add into (ops.LossSlots)
-        self._g_terms = ops.LossSlots(['g_adv', 'g_rec', 'g_tsf', 'g_mask', 'g_mask_smooth'], self.device) if _LOSS_SLOTS else None
-        self._d_terms = ops.LossSlots(['d'], self.device, extra=['d_real', 'd_fake']) if _LOSS_SLOTS else None
+        self._g_terms = ops.LossSlots(['g_adv', 'g_rec', 'g_tsf', 'g_mask', 'g_mask_smooth'], self.device)
+        self._d_terms = ops.LossSlots(['d'], self.device, extra=['d_real', 'd_fake'])
         z = lambda: torch.zeros((), device=self.device)
         self._loss_g_rec, self._loss_g_tsf, self._loss_g_adv = z(), z(), z()
         self._loss_g_smooth, self._loss_g_mask, self._loss_g_mask_smooth = z(), z(), z()
@@ -192,14 +193,33 @@ class Trainer(BaseModel):
 
     # ------------------------------------------------------------------ inputs
     def set_input(self, input):
+        """trainer.py:324-362.  Three forms of `input`: the raw dataloader batch (imageA/B, manoA/B, and maskA/B on the HOv3 copy: needs opt.mano_model and
+        opt.object_assets, see set_raw_input), images + rasteriser outputs (set_rasterised_input), or the prepared tensors
+        (set_prepared_input: the synthetic-benchmark surface)."""
         if all(k in input for k in PREPARED_KEYS):
             return self.set_prepared_input(input)
         if all(k in input for k in RASTER_KEYS):
             return self.set_rasterised_input(input)
-        raise NotImplementedError(
-            'Trainer.set_input: raw dataloader batches need the MANO layer of HandRecoveryFlow (smplx, trainer.py:46-49), '
-            'which is outside the accelerated path; pass the prepared tensors %s or images + rasteriser outputs %s'
-            % (PREPARED_KEYS, RASTER_KEYS))
+        if all(k in input for k in RAW_KEYS):
+            return self.set_raw_input(input)
+        raise KeyError('Trainer.set_input: expected the raw batch %s, images + rasteriser outputs %s, or the prepared tensors %s'
+                       % (RAW_KEYS, RASTER_KEYS, PREPARED_KEYS))
+
+    def set_raw_input(self, inp):
+        """The batch train_ddp.py:92 passes, through HandRecoveryFlow on the device (hoig_amd/hand_recovery.py: MANO layer ->
+        projection -> rasteriser -> tensor stage; trainer.py:324-362).  The MANO model and the per-object renderer buffers are
+        the caller's (opt.mano_model, opt.object_assets): the reference builds them from assets it does not ship."""
+        if self._hdr is None:
+            from ..hand_recovery import HandRecoveryFlow
+            try:
+                self._hdr = HandRecoveryFlow(self._opt, device=self.device)
+            except ValueError as ex:
+                raise NotImplementedError('Trainer.set_input(raw batch): %s' % ex)
+        with torch.no_grad():
+            src_img, tsf_img = inp['imageA'].to(self.device, non_blocking=True), inp['imageB'].to(self.device, non_blocking=True)
+            out = self._hdr(src_img, tsf_img, inp['manoA'], inp['manoB'])
+            from .. import input_prep as IP
+            return self.set_prepared_input(IP.to_prepared(out, src_img.float(), tsf_img.float(), inp.get('maskA'), inp.get('maskB')))
 
     def set_rasterised_input(self, inp):
         """Raw images + the rasteriser's outputs (``render_fim_wim``: face vertices, face index / weight maps) and the
@@ -387,7 +407,7 @@ class Trainer(BaseModel):
         if ev_fwd is not None and generator_forks_streams():
             main = torch.cuda.current_stream()
             if self._d_stream is None:
-                self._d_stream = ops.new_stream(self.device)
+                self._d_stream = ops.new_stream(self.device, 'd')
             self._d_stream.wait_event(ev_fwd)
             ops.cross_stream(fake_tsf_imgs, self._d_stream)
             with torch.cuda.stream(self._d_stream):
@@ -533,9 +553,8 @@ class Trainer(BaseModel):
         # one after the other on the caller's stream.
         fork = fake_tsf.is_cuda and generator_forks_streams()
         T = self._g_terms
-        into = (lambda name: T.term(name)) if T is not None else (lambda name: None)
-        if T is not None:
-            T.begin()                      # (on the caller's stream, before the loss streams fork from it)
+        into = T.term
+        T.begin()                          # (on the caller's stream, before the loss streams fork from it)
         if fork:
             main = torch.cuda.current_stream()
             # operand planes are (re)made lazily by whoever asks first: make D's and VGG's here, on the caller's stream, so that
@@ -543,7 +562,7 @@ class Trainer(BaseModel):
             self._net(self._D).refresh_planes()
             self._crt_tsf.vgg.refresh_planes()
             if self._loss_streams is None:
-                self._loss_streams = (ops.new_stream(self.device), ops.new_stream(self.device))
+                self._loss_streams = (ops.new_stream(self.device, 'loss_adv'), ops.new_stream(self.device, 'loss_vgg'))
             s_adv, s_vgg = self._loss_streams
             s_adv.wait_stream(main)
             with torch.cuda.stream(s_adv):
@@ -563,23 +582,16 @@ class Trainer(BaseModel):
         tsf = self._crt_tsf.forward_nhwc(fake_tsf, n['real_tsf'], o.lambda_tsf, side=s_vgg, into=into('g_tsf'))
         if fork:
             main.wait_stream(s_adv)
-            if T is None:
-                ops.cross_stream(self._loss_g_adv, main)
         crt = ops.bce_loss if o.mask_bce else ops.mse_loss
         masks = [crt(mbg, n['bg_mask'], o.lambda_mask, into=into('g_mask')), crt(mh, n['hand_mask'], o.lambda_mask, into=into('g_mask'))]
         smooth = []
         if o.lambda_mask_smooth != 0:
             smooth = [ops.tv_loss(mbg, o.lambda_mask_smooth, into=into('g_mask_smooth')),
                       ops.tv_loss(mh, o.lambda_mask_smooth, into=into('g_mask_smooth'))]
-        if T is not None:
-            # every term already sits, scaled, in its slot: one launch sums them; the reported values are views of the slots
-            self._loss_g_tsf, self._loss_g_mask = T.value('g_tsf'), T.value('g_mask')
-            self._loss_g_mask_smooth = T.value('g_mask_smooth')
-            return T.total(self._loss_g_adv, self._loss_g_rec, *(tsf + masks + smooth))
-        self._loss_g_tsf, self._loss_g_mask = tsf, masks[0] + masks[1]
-        if smooth:
-            self._loss_g_mask_smooth = smooth[0] + smooth[1]
-        return self._loss_g_adv + self._loss_g_rec + self._loss_g_tsf + self._loss_g_mask + self._loss_g_mask_smooth
+        # every term already sits, scaled, in its slot: one launch sums them; the reported values are views of the slots
+        self._loss_g_tsf, self._loss_g_mask = T.value('g_tsf'), T.value('g_mask')
+        self._loss_g_mask_smooth = T.value('g_mask_smooth')
+        return T.total(self._loss_g_adv, self._loss_g_rec, *(tsf + masks + smooth))
 
     def _optimize_D(self, fake_tsf_imgs):
         """trainer.py:459-474."""
@@ -591,20 +603,13 @@ class Trainer(BaseModel):
         d_both = self._D.forward_nhwc(torch.cat([n['d_real_in'], ops.cat_channels([fake_tsf, n['tsf_cond']])], dim=0))
         d_real, d_fake = d_both[:nb], d_both[nb:]
         T = self._d_terms
-        if T is not None:
-            T.begin()
-            loss_real = ops.lsgan_loss(d_real, 1.0, o.lambda_D_prob, into=T.term('d'))
-            loss_fake = ops.lsgan_loss(d_fake, -1.0, o.lambda_D_prob, into=T.term('d'))
-            with torch.no_grad():
-                self._d_real = ops.mean(d_real, into=T.term('d_real'))
-                self._d_fake = ops.mean(d_fake, into=T.term('d_fake'))
-            return T.total(loss_real, loss_fake)
-        loss_real = ops.lsgan_loss(d_real, 1.0, o.lambda_D_prob)
-        loss_fake = ops.lsgan_loss(d_fake, -1.0, o.lambda_D_prob)
+        T.begin()
+        loss_real = ops.lsgan_loss(d_real, 1.0, o.lambda_D_prob, into=T.term('d'))
+        loss_fake = ops.lsgan_loss(d_fake, -1.0, o.lambda_D_prob, into=T.term('d'))
         with torch.no_grad():
-            self._d_real = ops.mean(d_real)
-            self._d_fake = ops.mean(d_fake)
-        return loss_real + loss_fake
+            self._d_real = ops.mean(d_real, into=T.term('d_real'))
+            self._d_fake = ops.mean(d_fake, into=T.term('d_fake'))
+        return T.total(loss_real, loss_fake)
 
     backward_G = _optimize_G        # north_star vocabulary
     backward_D = _optimize_D

@@ -165,37 +165,28 @@ def _packed_planes(w, transposed, for_dgrad):
 
 _own_streams = []
 _stream_banks = {}
-_QUEUE_OF_ROLE = [int(v) for v in os.environ.get('HOIG_STREAM_MAP', '3,1,3,1,2,2,2,2').split(',')]
+# Hardware-queue class of each stream ROLE of the step.  The runtime gives every new HIP stream the least-used of its (four)
+# hardware queues, so entry k of a bank of streams created back to back sits on queue k mod 4 (class 0 = the queue of the caller's
+# default stream), and WHICH roles share a hardware queue is worth up to 20 % of the step time
+# (profiles/r03_stream_queue_map.txt, one box: the three branch chains on three different queues 77-78 ms, every side role on one
+# queue 79-88 ms, the assignment below 72.9 ms): kernels of different queues interleave at workgroup granularity, and four heavy
+# chains doing that to each other are slower than two pairs.  Streams of ONE class execute in order: a stalled role stalls its
+# class mates (tests/test_stream_order_gpu.py moves a role to a class of its own where it needs one role late).
+_QUEUE_OF_ROLE = {'opt': 3, 'g_bg': 1, 'g_obj': 3, 'g_src': 1, 'loss_adv': 2, 'loss_vgg': 2, 'd': 2, 'wgrad': 2}
 
 
-def new_stream(device=None):
-    """A HIP stream that no other stream object of the process aliases.  torch.cuda.Stream() takes its streams round-robin from
-    a pool of 32 per device: in a process that has created more than that (a test session with a dozen Trainers) two roles of
-    the step end up on ONE HIP stream, and a stream that waits for itself inside a capture crashes hipStreamEndCapture (ROCm
-    7.2: unbounded recursion over the capture's parallel streams).  The library creates the stream, torch wraps it."""
+def new_stream(device=None, role='opt'):
+    """A HIP stream for stream role `role` that no other stream object of the process aliases.  torch.cuda.Stream() takes its
+    streams round-robin from a pool of 32 per device: in a process that has created more than that (a test session with a dozen
+    Trainers) two roles of the step end up on ONE HIP stream, and a stream that waits for itself inside a capture crashes
+    hipStreamEndCapture (ROCm 7.2: unbounded recursion over the capture's parallel streams).  The library creates the streams in
+    banks of 32, back to back; torch wraps the one this role's queue class asks for."""
     dev = torch.device('cuda', torch.cuda.current_device()) if device is None else torch.device(device)
-    if os.environ.get('HOIG_POOL_STREAMS') == '1':          # A/B switch: PyTorch's pooled streams, as in rounds 1-2
-        return torch.cuda.Stream(device=dev)
     bank = _stream_banks.get(dev)
     if bank is None:
-        # A bank of 32 streams created back to back.  The runtime gives every new stream the least-used of its (four) hardware
-        # queues, so bank entry k sits on queue k mod 4 (class 0 = the queue of the caller's default stream), and WHICH roles of
-        # the step share a hardware queue is worth up to 20 % of the step time (profiles/r03_stream_queue_map.txt, one box: the
-        # three branch chains on three different queues 77-78 ms, every side role on one queue 79-88 ms, the assignment below
-        # 72.9 ms = what PyTorch's pooled streams happened to get in rounds 1-2): kernels of different queues interleave at
-        # workgroup granularity, and four heavy chains doing that to each other are slower than two pairs.  _QUEUE_OF_ROLE is the
-        # queue class of the n-th stream a process asks for -- the order is fixed by the code: optimiser side stream (3), bg /
-        # obj / src branch streams (1 / 3 / 1), the two loss streams, the D stream, the weight-gradient stream (2).
-        bank = _stream_banks[dev] = {'free': [[], [], [], []], 'n': 0}
-        with torch.cuda.device(dev):
-            for k in range(32):
-                h = ctypes.c_void_p()
-                call('hoig_stream_create', ctypes.byref(h))
-                bank['free'][k % 4].append(h.value)
-    role = bank['n']
-    bank['n'] += 1
-    q = _QUEUE_OF_ROLE[role % len(_QUEUE_OF_ROLE)]
-    if not bank['free'][q]:                     # (a long session: more streams, same queue classes)
+        bank = _stream_banks[dev] = {'free': [[], [], [], []]}
+    q = _QUEUE_OF_ROLE[role]
+    if not bank['free'][q]:                     # (first use, or a long session: more streams, same queue classes)
         with torch.cuda.device(dev):
             for k in range(32):
                 h = ctypes.c_void_p()
@@ -267,7 +258,7 @@ def _wgrad_side_stream(device):
         return None
     s = _wgrad_streams.get(device)
     if s is None:
-        s = _wgrad_streams[device] = new_stream(device)
+        s = _wgrad_streams[device] = new_stream(device, 'wgrad')
     if _capture_depth:
         _capture_forked.add(s)
     return s
@@ -467,14 +458,11 @@ def conv2d(x, w, b=None, stride=1, pad=0, act=L.ACT_NONE, slope=0.0, prec=None, 
     return _Conv.apply(x, w, b, stride, pad, False, act, slope, None, precision if prec is None else prec, dead_bias)
 
 
-_FORK = os.environ.get('HOIG_CONV_FORK', '1') == '1'      # A/B switch: 0 = autograd sums the gradients of a fanned-out tensor itself
-
-
 def conv2d_fork(x, w, b=None, stride=1, pad=0, act=L.ACT_NONE, slope=0.0, prec=None, dead_bias=False):
     """-> (conv2d(x, ...), x') for a tensor x with a SECOND consumer (the skip of a residual block: generator.py:29-32).  x' is
     x; the second consumer must read x' so that its gradient comes back through this node, which adds it in the epilogue of its
     data-gradient kernel (hoig_conv2d_bwd_data_packed_add) -- one extra read instead of the autograd engine's three-pass sum."""
-    if not _FORK or not x.requires_grad:
+    if not x.requires_grad:
         return conv2d(x, w, b, stride, pad, act, slope, prec, dead_bias), x
     return _Conv.apply(x, w, b, stride, pad, False, act, slope, None, precision if prec is None else prec, dead_bias, True)
 
@@ -534,9 +522,6 @@ class _ConvCat2(Function):
         return dx1, dx2, (dw if ret_w else None), None, None
 
 
-_CAT_CONV = os.environ.get('HOIG_CAT_CONV', '1') == '1'
-
-
 def conv2d_cat2(x1, x2, w, prec=None, norm_next=False):
     """conv2d(cat_channels([x1, x2]), w, None, 1, 1) (3x3, no bias); without the concatenation when the shapes are on the
     16-bit halo path, else through cat_channels.  norm_next: the output goes straight into an instance norm (_conv_fwd_raw)."""
@@ -544,7 +529,7 @@ def conv2d_cat2(x1, x2, w, prec=None, norm_next=False):
     B, H, W_, C1 = x1.shape
     C2 = x2.shape[-1]
     Co = w.shape[0]
-    ok = (_CAT_CONV and prec != L.PREC_F32 and x1.is_cuda and tuple(w.shape[2:]) == (3, 3) and w.shape[1] == C1 + C2 and
+    ok = (prec != L.PREC_F32 and x1.is_cuda and tuple(w.shape[2:]) == (3, 3) and w.shape[1] == C1 + C2 and
           C1 % 64 == 0 and C2 % 64 == 0 and Co % 64 == 0 and W_ % 32 == 0 and H % 4 == 0 and
           B * (H // 4) * (W_ // 32) * ((Co + 127) // 128) >= 160 and B * (H // 4) * (W_ // 32) * ((C1 + C2 + 127) // 128) >= 160 and
           x1.shape[:3] == x2.shape[:3] and x1.is_contiguous() and x2.is_contiguous())
@@ -633,10 +618,8 @@ def conv_transpose2d(x, w, stride=2, pad=1, output_padding=1, prec=None, norm_ne
 
 # ------------------------------------------------------------------------------------------------- instance norm
 _norm_ws = {}
-_NORM_KEEP_Y = os.environ.get('HOIG_NORM_KEEP_Y', '0') == '1'      # A/B switch: read y in the backward as before
 
 
-_CONV_STATS = os.environ.get('HOIG_CONV_STATS', '1') == '1'   # A/B switch: 0 = every instance norm computes its statistics itself
 _stats_pending = {}     # (device, stream) -> (data_ptr, B, HW, C) of the tensor whose sums a convolution left in that workspace
 
 
@@ -663,7 +646,7 @@ def _conv_stats_workspace(y):
     """Accumulators for the statistics of `y` (a convolution output about to be written), or None when its instance norm would
     not read them: maps of <= 1024 pixels take the one-launch norm kernel, which computes its own."""
     B, H, W_, C = y.shape
-    if not _CONV_STATS or H * W_ <= 1024 or C % 4:
+    if H * W_ <= 1024 or C % 4:
         return None
     return _norm_workspace(L.lib.hoig_inorm_workspace_bytes(B, H * W_, C) // 4, y.device)
 
@@ -700,7 +683,7 @@ class _INorm(Function):
             L.check(rc, 'hoig_inorm_fwd_fused')
         ctx.cfg = (mode, act, slope, B, HW, C, residual is not None)
         # (Leaky)ReLU after a plain / affine norm: the backward recomputes the activation mask from x instead of reading y
-        y_free = act in (L.ACT_RELU, L.ACT_LRELU) and mode in (0, 1) and not _NORM_KEEP_Y
+        y_free = act in (L.ACT_RELU, L.ACT_LRELU) and mode in (0, 1)
         ctx.save_for_backward(x, mean, rstd, p0, p1, y if (act != L.ACT_NONE and not y_free) else None)
         return y
 
@@ -796,7 +779,7 @@ class _SpadeFused(Function):
 def spade_norm_fused(x, gb, act=L.ACT_NONE, slope=0.0, eps=1e-5, fork=False):
     """fork=True -> (y, x') for an x with a second consumer, which must read x' (see conv2d_fork): its gradient is then added by
     the norm's backward kernel."""
-    if fork and not (_FORK and x.requires_grad):
+    if fork and not x.requires_grad:
         return _SpadeFused.apply(x, gb, act, slope, eps), x
     return _SpadeFused.apply(x, gb, act, slope, eps, fork)
 
@@ -852,9 +835,6 @@ def _copy_channels(x, y, x_off, y_off, n, accumulate=False):
          _st())
 
 
-_CAT_BWD_VIEWS = os.environ.get('HOIG_CAT_BWD_VIEWS', '1') == '1'
-
-
 class _Cat(Function):
     @staticmethod
     def forward(ctx, *xs):
@@ -879,15 +859,10 @@ class _Cat(Function):
         outs, off = [], 0
         for i, c in enumerate(ctx.cs):
             if ctx.needs_input_grad[i]:
-                if _CAT_BWD_VIEWS:
-                    # a strided VIEW: where autograd sums it with another gradient of the same tensor (an encoder output also
-                    # feeds the next level) the add reads it in place and the slice copy never happens; single consumers
-                    # make it contiguous themselves
-                    outs.append(dy[..., off:off + c])
-                else:
-                    g = torch.empty(dy.shape[:-1] + (c,), dtype=dy.dtype, device=dy.device)
-                    _copy_channels(dy, g, off, 0, c)
-                    outs.append(g)
+                # a strided VIEW: where autograd sums it with another gradient of the same tensor (an encoder output also
+                # feeds the next level) the add reads it in place and the slice copy never happens; single consumers
+                # make it contiguous themselves
+                outs.append(dy[..., off:off + c])
             else:
                 outs.append(None)
             off += c
@@ -1038,32 +1013,10 @@ def _x3(d):
     return c
 
 
-_F6_SCOPE = tuple(p for p in os.environ.get('HOIG_F6_SCOPE', '').split(',') if p)      # experiment: f16f6 only in these sub-networks
-
-
-def _f6_in_scope(w):
-    """With HOIG_F6_SCOPE=<prefix>,<prefix> the fp6 forward is used only for weights of those sub-networks (by parameter-name
-    prefix, e.g. bg_model,obj_model); everything else of an 'f16f6' run stays on three fp16 terms."""
-    if not _F6_SCOPE:
-        return True
-    owner = getattr(w, '_hoig_owner', None)
-    if owner is None or not hasattr(owner, '_offsets'):
-        return False
-    rng = getattr(owner, '_f6_scope_ranges', None)
-    if rng is None:
-        names = list(owner._offsets.items())
-        ends = [o for _, o in names[1:]] + [owner.flat.numel()]
-        rng = owner._f6_scope_ranges = [(o, e) for (n, o), e in zip(names, ends) if n.startswith(_F6_SCOPE)]
-    off = w.storage_offset()
-    return any(a <= off < b for a, b in rng)
-
-
 def _conv_fwd_raw(d, x, w, b, y, transposed=False, norm_next=False):
     """y = conv(x, w) (+bias, activation) on the kernel the precision mode selects.  norm_next: y goes straight into an instance
     norm -- where the layer's kernel can, it also leaves the per-image channel sums of y in the stream's norm workspace
     (hoig_conv2d_fwd_packed_stats) and says so (_stats_offer); the norm then skips its statistics pass."""
-    if d.precision == L.PREC_F16F6 and not _f6_in_scope(w):
-        d = _x3(d)
     if norm_next and d.precision not in (L.PREC_F32, L.PREC_F16F6) and d.Ci % 32 == 0 and d.Co % 32 == 0 and d.Co > 32:
         ws = _conv_stats_workspace(y)
         if ws is not None:
@@ -1267,19 +1220,14 @@ class _LocalAttn(Function):
         return dsrc, dtgt, None, dgs, rets[0], rets[1], rets[2], rets[3], None, None
 
 
-_ATTN_PREC = os.environ.get('HOIG_ATTN_PREC')          # experiment switch: arithmetic of the attention's two 5x5 convolutions
-
-
 def _attn_prec(prec):
-    if prec is None:
-        prec = _PREC[_ATTN_PREC] if (_ATTN_PREC and precision != L.PREC_F32) else precision
-    return prec
+    return precision if prec is None else prec
 
 
 def attn_source_conv(source, ws, prec=None, fork=False):
     """Gs of local_attention(): the part that depends on the source features and the source half of the weight only.
     fork=True -> (Gs, source'): later readers of `source` must read source' (see conv2d_fork)."""
-    if fork and not (_FORK and source.requires_grad):
+    if fork and not source.requires_grad:
         return _AttnSourceConv.apply(source, ws, _attn_prec(prec)), source
     return _AttnSourceConv.apply(source, ws, _attn_prec(prec), fork)
 
@@ -1290,7 +1238,7 @@ def local_attention(source, target, flow, wt, ws, b1, w2, b2, prec=None, gs=None
     prec = _attn_prec(prec)
     if gs is None:
         gs = _AttnSourceConv.apply(source, ws, prec)
-    if fork and not (_FORK and source.requires_grad and target.requires_grad):
+    if fork and not (source.requires_grad and target.requires_grad):
         return _LocalAttn.apply(source, target, flow.contiguous(), gs, wt, b1, w2, b2, prec), source, target
     return _LocalAttn.apply(source, target, flow.contiguous(), gs, wt, b1, w2, b2, prec, fork)
 

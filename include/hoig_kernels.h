@@ -401,7 +401,14 @@ const char *hoig_version(void);
 
 /* Kernel-variant choices that are tuning, not semantics (every value computes the same result up to summation order): one table
  * instead of per-variant environment switches.  key -> value; returns the previous value, or -1 for an unknown key; value < 0 only
- * queries.  Keys: "mfma16" (1, the default: the 8-row 3x3 stride-1 tilings run on v_mfma_f32_16x16x32, conv_halo16.hip; 0: on 32x32x16); "wgrad16" (1: the stride-1 3x3 weight gradients on v_mfma_f32_16x16x32, wgrad_halo16.hip); "igemm16" (the generic implicit GEMM on v_mfma_f32_16x16x32, conv_igemm16.hip: 1 = forward launches, 2 = data gradients too); "s2_16" (1: the stride-2 3x3 layers on it, conv_halo16.hip); "flat5" (conv_flat16.hip, the flattened-axis halo kernel: 1 = the attention's valid 5x5 convolutions and their data gradients, 2 = also the 3x3 "same" layers with too few tiles for the halo kernels); "few128" (experiment: 128-channel tiles for the 3x3 launches with 192-511 four-row tiles).
+ * queries.  Keys and defaults (each adopted on an interleaved A/B committed under profiles/r04_*):
+ *   "mfma16"  1  the 8-row 3x3 stride-1 tilings on v_mfma_f32_16x16x32 (conv_halo16.hip); 0: on 32x32x16
+ *   "s2_16"   1  the stride-2 3x3 layers on it (conv_halo16.hip; scatter launches with 64-channel tiles stay on 32x32x16)
+ *   "igemm16" 1  the generic implicit GEMM on it (conv_igemm16.hip): 1 = forward launches, 2 = data gradients too
+ *   "flat5"   2  the flattened-axis halo kernel (conv_flat16.hip): 1 = the attention's valid 5x5 convolutions and their data
+ *                gradients, 2 = also the 3x3 "same" layers with too few tiles for the halo kernels
+ *   "few128"  1  128-channel tiles for the 3x3 launches with 192-511 four-row tiles (the 8-image launches of two concurrent chains)
+ *   "wgrad16" 0  the stride-1 3x3 weight gradients on 16x16x32 (wgrad_halo16.hip): measured 5-20 % slower than 32x32x16
  * Process-wide, not synchronised: set before launching. */
 int hoig_set_tuning(const char *key, int value);
 

@@ -114,13 +114,20 @@ def test_delayed_role_captured_graph(role, reference_128):
 
 def test_the_detector_sees_a_missing_join(reference_128):
     """Negative control: without Trainer._join_backward_streams (the bug of rounds 1-2) a delayed branch must FAIL the check."""
+    from hoig_amd import ops
     from hoig_amd.models import trainer as T
-    keep = T.Trainer._join_backward_streams
+    keep, queues = T.Trainer._join_backward_streams, dict(ops._QUEUE_OF_ROLE)
     T.Trainer._join_backward_streams = lambda self: None
+    # Streams of one hardware-queue class run in order, so a sleeping bg stream would also hold back src_model's stream (its
+    # class mate), through it the tsf chain on the caller's stream (which waits for the source features' gradients), and the
+    # optimiser would come late by itself.  Give the bg branch a queue class of its own for this run.
+    ops._QUEUE_OF_ROLE.update(g_bg=1, g_src=2, g_obj=2, opt=3)
     try:
         run = _run(128, 2, {'g_bg': DELAY})
     finally:
         T.Trainer._join_backward_streams = keep
+        ops._QUEUE_OF_ROLE.clear()
+        ops._QUEUE_OF_ROLE.update(queues)
     (_, mg, _, net_g, _), (_, mgr, _, _, _) = run[0], reference_128[0]
     worst = _worst(net_g, mg, mgr)
     assert worst[0] > 0.5 and worst[1].startswith('bg_model'), worst       # the optimiser ran ahead of bg_model's weight gradients

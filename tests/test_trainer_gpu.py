@@ -189,8 +189,10 @@ def test_api_surface_and_checkpoint_roundtrip(tmp_path):
     m.set_eval()
     m.optimize_parameters()                                     # no-op outside training (trainer.py:418)
     assert hasattr(m, 'backward_G') and hasattr(m, 'backward_D')
-    with pytest.raises(NotImplementedError):
+    with pytest.raises(KeyError):                               # neither the raw batch, nor rasteriser outputs, nor prepared tensors
         m.set_input({'imageA': torch.zeros(1)})
+    with pytest.raises(NotImplementedError, match='mano_model'):    # a raw batch without the caller's MANO model / object buffers
+        m.set_input({k: torch.zeros(1) for k in ('imageA', 'imageB', 'manoA', 'manoB')})
 
 
 def test_dexycb_resume_replays_the_learning_rate_decay(tmp_path):

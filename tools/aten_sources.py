@@ -9,7 +9,7 @@ from torch.profiler import profile, ProfilerActivity
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 os.environ.setdefault('HOIG_WGRAD_STREAM', '0')
-os.environ.setdefault('HOIG_G_STREAMS', '0')
+os.environ.setdefault('HOIG_STREAMS', '0')
 from hoig_amd import ops, synthetic                       # noqa: E402
 from hoig_amd.options import opt_namespace                # noqa: E402
 from hoig_amd.models import ModelsFactory                 # noqa: E402

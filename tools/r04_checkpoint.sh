@@ -1,8 +1,8 @@
 #!/bin/bash
-# Round-3 evidence run on the MI355X box (through gpurun): tests, bench, rocprofv3 stats and PMC passes -> gpurun_out/<tag>_*
+# Round-4 evidence run on the MI355X box (through gpurun): tests, bench, rocprofv3 stats and PMC passes -> gpurun_out/<tag>_*
 set -u
 O=$GRAFT_REPO_ROOT/gpurun_out
-TAG=${1:-r03}
+TAG=${1:-r04}
 mkdir -p $O
 cd $GRAFT_REPO_ROOT
 python -c "from hoig_amd import _lib; _lib.lib" || { echo "library does not load: stale snapshot?"; exit 9; }
@@ -27,13 +27,18 @@ for c in "fetch FETCH_SIZE" "write WRITE_SIZE" "sq SQ_VALU_MFMA_BUSY_CYCLES GRBM
   cp $(find /tmp/p_pmcf_$n -name "*counter_collection.csv" | head -1) /tmp/pmcf_$n.csv
 done
 cd $GRAFT_REPO_ROOT
-python tools/pmc_summary.py conv_halo3_bf16_kernel $O/${TAG}_pmc_dominant_conv.json fetch=$O/${TAG}_pmc_fetch_dominant_conv.csv write=$O/${TAG}_pmc_write_dominant_conv.csv sq=$O/${TAG}_pmc_sq_dominant_conv.csv > /dev/null
+python tools/pmc_summary.py conv_halo3_m16_kernel $O/${TAG}_pmc_dominant_conv.json fetch=$O/${TAG}_pmc_fetch_dominant_conv.csv write=$O/${TAG}_pmc_write_dominant_conv.csv sq=$O/${TAG}_pmc_sq_dominant_conv.csv > /dev/null
 python tools/pmc_summary.py ALL $O/${TAG}_pmc_genfwd_b32.json fetch=/tmp/pmcf_fetch.csv write=/tmp/pmcf_write.csv sq=/tmp/pmcf_sq.csv > /dev/null
 python tools/timeline.py /tmp/${TAG}_bench_trace.csv 2000 > $O/${TAG}_timeline_eager.txt 2>&1
+# the dominant SHAPE inside the multi-stream step and inside the one-stream step (the template serves several shapes)
+python tools/dominant_in_step.py /tmp/${TAG}_bench_trace.csv conv_halo3_m16_kernel 131072 > $O/${TAG}_dominant_in_step.txt 2>&1
+python tools/dominant_in_step.py $(find /tmp/p_serial -name "*kernel_trace.csv" | head -1) conv_halo3_m16_kernel 131072 >> $O/${TAG}_dominant_in_step.txt 2>&1
 python tools/kstats_top.py $O/${TAG}_serial_kernel_stats.csv 5 70 > $O/${TAG}_serial_top.txt
 HOIG_WGRAD_STREAM=0 HOIG_STREAMS=0 ROWS=150 python tools/conv_table.py bf16x3:f16x2 2>/dev/null | grep -v "created\|amdgpu" > $O/${TAG}_conv_table.txt
 cd /tmp
 HOIG_STREAMS=0 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/p_fwd -- python3 $GRAFT_REPO_ROOT/tools/fwd_only.py > /dev/null 2>&1
 cp $(find /tmp/p_fwd -name "*kernel_stats.csv" | head -1) $O/${TAG}_genfwd_b32_kernel_stats.csv
 cd $GRAFT_REPO_ROOT
+python tools/knockout_step.py 2>/dev/null | grep -v "created\|amdgpu\|WARNING" > $O/${TAG}_knockout_step.txt
+cat $O/${TAG}_dominant_in_step.txt $O/${TAG}_knockout_step.txt
 tail -5 $O/${TAG}_pytest_gpu.log 2>/dev/null; cat $O/${TAG}_bench.json; head -20 $O/${TAG}_pmc_dominant_conv.json; head -12 $O/${TAG}_serial_top.txt
