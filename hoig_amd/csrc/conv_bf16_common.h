@@ -178,6 +178,16 @@ __device__ __forceinline__ bool tap_alive(const Geom &g, int hp, int wp, int rs)
     return (((hp + g.pad - r) & 1) == 0) && (((wp + g.pad - s) & 1) == 0);
 }
 
+// wgrad_flat.hip: weight gradient of valid 5x5 stride-1 convolutions on the flattened pixel axis
+struct WFlatArgs {
+    const float *X, *DY;
+    float *DW, *DB;
+    int Ci, Co, Wc, HWc, Q, Ho, Wo, HPOS;
+    int nblk_ci, nblk, n_mtiles, mt_per_split;
+};
+int launch_wgrad_flat5(const float *x, const float *dy, float *dw, float *dbias, int Bn, int Hi, int Wi, int Ci, int Co, int ns,
+                       hipStream_t st);
+
 // conv_igemm16.hip: the generic implicit GEMM on v_mfma_f32_16x16x32 (same tiles, split-K rule and geometry handling as
 // launch<BM, BN, WM, WN> of conv_igemm_bf16.hip; `cfg` = 0: 128x128 on 4 waves, 1: 128x128 on 8 waves, 2: 64x128, 3: 128x64, 4: 64x64)
 int launch_igemm_m16(Args a, int ns, int cfg, hipStream_t st);

@@ -2271,7 +2271,10 @@ int launch_wgrad_halo(const hoig_conv_desc *d, const float *x, const float *dy, 
     a.n_mtiles = a.Bn * a.tiles_x * a.tiles_y;
     constexpr int target_blocks = 512;
     // 5x5: a workgroup owns 25 taps x 64 x 32 outputs, so every pixel split costs 2.8x the atomics of a 3x3 one: 256 (measured)
-    int splits = (int)hoig_cdiv((d->R == 5 ? target_blocks / 2 : target_blocks) / cm, a.nblk);
+    // experiment ("wgrad_few"): the 8-image 32 x 32 launches (64 four-row tiles) run side by side on two branch streams in G's
+    // backward: 128 workgroups each -- half the pixel splits, half the atomics -- instead of 256
+    const int target = (hoig_tuning(HOIG_TUNE_WGRAD_FEW) != 0 && th4 && a.n_mtiles <= 64) ? target_blocks / 2 : target_blocks;
+    int splits = (int)hoig_cdiv((d->R == 5 ? target / 2 : target) / cm, a.nblk);
     if (splits > a.n_mtiles) splits = a.n_mtiles;
     if (splits < 1) splits = 1;
     a.mt_per_split = (int)hoig_cdiv(a.n_mtiles, splits);
@@ -2351,6 +2354,12 @@ int hoig_conv_bf16_wgrad(const hoig_conv_desc *d, const float *x, const float *d
         a.lh = __builtin_ctz(a.Hp);
     }
     const int ns = ns_of_precision(d->precision);
+    // the attention's valid 5x5 convolutions on the flattened-axis kernel (wgrad_flat.hip)
+    if (hoig_tuning(HOIG_TUNE_WFLAT5) != 0 && !d->transposed && d->stride == 1 && d->R == 5 && d->S == 5 && d->pad == 0 &&
+        d->Ho == d->Hi - 4 && d->Wo == d->Wi - 4) {
+        const int rc = launch_wgrad_flat5(x, dy, dw, dbias, d->B, d->Hi, d->Wi, d->Ci, d->Co, ns, st);
+        if (rc != HOIG_EUNSUPPORTED) return rc;
+    }
     if (hoig_conv_bf16_wgrad_fuses_bias(d)) return launch_wgrad_halo(d, x, dy, dw, dbias, ns, st);
     if (a.Co <= 64) return launch_wgrad_bf16<64>(a, ns, st);
     return launch_wgrad_bf16<128>(a, ns, st);

@@ -218,3 +218,42 @@ def test_flat5_valid_convolution_and_its_data_gradient(B, Ci, Co, Hi, Wi, bias, 
         ef, ed = rel_err(y, yr.detach().permute(0, 2, 3, 1)), rel_err(dx, xr.grad.permute(0, 2, 3, 1))
         assert ef < bf and ed < bd, (tag, ef, ed)
     assert rel_err(res[1][0], res[0][0]) < 1e-5 and rel_err(res[1][1], res[0][1]) < 1e-4
+
+
+@pytest.mark.parametrize('mode', ['f16x2', 'bf16x3'])
+@pytest.mark.parametrize('B,Ci,Co,Hi,Wi,bias', [(8, 512, 128, 40, 40, False),      # the attention's source side: output 36 x 36
+                                                (4, 128, 128, 36, 36, True),       # its target side: output 32 x 32 (the halo kernel's shape)
+                                                (2, 64, 192, 13, 66, True),        # the widest canvas of the kernel; three co tiles
+                                                (1, 32, 64, 9, 11, False)])        # fewer positions than one pixel tile
+def test_wflat5_weight_gradient_of_valid_5x5(B, Ci, Co, Hi, Wi, bias, mode):
+    """Tuning key 'wflat5' (wgrad_flat.hip): dW and the bias gradient of valid 5x5 convolutions on the flattened pixel axis, against
+    the kernels it replaces and against torch fp32."""
+    from hoig_amd import ops, _lib as L
+    g = torch.Generator().manual_seed(29)
+    x = torch.randn(B, Hi, Wi, Ci, generator=g).cuda()
+    w = ops.pack_weight((torch.randn(Co, Ci, 5, 5, generator=g) * 0.03).cuda())
+    b = torch.randn(Co, generator=g).cuda() if bias else None
+    gy = torch.randn(B, Hi - 4, Wi - 4, Co, generator=g).cuda()
+    prev = L.set_tuning('wflat5', 0)
+    ops.set_precision(mode)
+    try:
+        res = []
+        for v in (0, 1):
+            L.set_tuning('wflat5', v)
+            wd = w.clone().requires_grad_(True)
+            bd = b.clone().requires_grad_(True) if bias else None
+            ops.conv2d(x, wd, bd, 1, 0).backward(gy)
+            torch.cuda.synchronize()
+            res.append((wd.grad.clone(), None if bd is None else bd.grad.clone()))
+    finally:
+        ops.set_precision('f32')
+        L.set_tuning('wflat5', prev)
+    wr = w.detach().clone().requires_grad_(True)
+    br = b.clone().requires_grad_(True) if bias else None
+    F.conv2d(x.permute(0, 3, 1, 2), wr, br).backward(gy.permute(0, 3, 1, 2))
+    lim = 8e-3 if mode == 'f16x2' else 3e-4
+    for tag, (dw, db) in zip(('halo / generic', 'flat'), res):
+        assert rel_err(dw, wr.grad) < lim, (tag, rel_err(dw, wr.grad))
+        if db is not None:
+            assert rel_err(db, br.grad) < 1e-4, tag
+    assert rel_err(res[1][0], res[0][0]) < 1e-4
