@@ -2355,8 +2355,10 @@ int hoig_conv_bf16_wgrad(const hoig_conv_desc *d, const float *x, const float *d
     }
     const int ns = ns_of_precision(d->precision);
     // the attention's valid 5x5 convolutions on the flattened-axis kernel (wgrad_flat.hip)
-    if (hoig_tuning(HOIG_TUNE_WFLAT5) != 0 && !d->transposed && d->stride == 1 && d->R == 5 && d->S == 5 && d->pad == 0 &&
-        d->Ho == d->Hi - 4 && d->Wo == d->Wi - 4) {
+    // (1: where the 2 x 32-pixel halo kernel cannot run -- output widths that are not multiples of 32: 193 -> 118 us on the
+    // source-side convolution; 2: also where it can -- measured 10 % slower there, profiles/r04_wflat5_ab.txt)
+    if (!d->transposed && d->stride == 1 && d->R == 5 && d->S == 5 && d->pad == 0 && d->Ho == d->Hi - 4 && d->Wo == d->Wi - 4 &&
+        (hoig_tuning(HOIG_TUNE_WFLAT5) >= 2 || (hoig_tuning(HOIG_TUNE_WFLAT5) == 1 && !hoig_conv_bf16_wgrad_fuses_bias(d)))) {
         const int rc = launch_wgrad_flat5(x, dy, dw, dbias, d->B, d->Hi, d->Wi, d->Ci, d->Co, ns, st);
         if (rc != HOIG_EUNSUPPORTED) return rc;
     }

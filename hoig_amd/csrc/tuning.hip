@@ -15,8 +15,8 @@ Entry g_table[HOIG_TUNE_COUNT] = {
     {"s2_16", 1},
     {"flat5", 2},
     {"few128", 1},
-    {"wflat5", 0},
-    {"wgrad_few", 0},
+    {"wflat5", 1},
+    {"wgrad_few", 1},
 };
 }  // namespace
 

@@ -408,7 +408,9 @@ const char *hoig_version(void);
  *   "flat5"   2  the flattened-axis halo kernel (conv_flat16.hip): 1 = the attention's valid 5x5 convolutions and their data
  *                gradients, 2 = also the 3x3 "same" layers with too few tiles for the halo kernels
  *   "few128"  1  128-channel tiles for the 3x3 launches with 192-511 four-row tiles (the 8-image launches of two concurrent chains)
- *   "wflat5"  0  the weight gradient of the attention's valid 5x5 convolutions on the flattened pixel axis (wgrad_flat.hip)
+ *   "wflat5"  1  the weight gradient of the attention's valid 5x5 convolutions on the flattened pixel axis (wgrad_flat.hip):
+ *                1 = where the output width is not a multiple of 32 (the 2 x 32-pixel halo kernel cannot run), 2 = always
+ *   "wgrad_few" 1  half the pixel splits for the weight gradients of the 8-image 32 x 32 launches (two of them run side by side)
  *   "wgrad16" 0  the stride-1 3x3 weight gradients on 16x16x32 (wgrad_halo16.hip): measured 5-20 % slower than 32x32x16
  * Process-wide, not synchronised: set before launching. */
 int hoig_set_tuning(const char *key, int value);

@@ -238,7 +238,7 @@ def test_wflat5_weight_gradient_of_valid_5x5(B, Ci, Co, Hi, Wi, bias, mode):
     ops.set_precision(mode)
     try:
         res = []
-        for v in (0, 1):
+        for v in (0, 2):                       # 2: the flattened kernel also where the halo kernel could run
             L.set_tuning('wflat5', v)
             wd = w.clone().requires_grad_(True)
             bd = b.clone().requires_grad_(True) if bias else None

@@ -9,8 +9,8 @@ or half-written data, and the step leaves the single-stream step's results -- wh
 
 What is compared, from a common seeded state: the loss terms of two steps, and after EACH step the first Adam moment of both
 networks (0.5 * gradient after step 1: exactly what the optimiser READ, so an optimiser that ran ahead of a late weight gradient
-shows up directly), tensor by tensor.  test_the_detector_sees_a_reader_that_does_not_wait removes the readers' wait for the
-optimiser stream and demands that the same check FAILS."""
+shows up directly), tensor by tensor.  test_the_detector_sees_an_optimiser_that_does_not_wait removes the optimiser
+stream's wait for the backward and demands that the same check FAILS."""
 import pytest
 import torch
 
@@ -30,7 +30,7 @@ def _precision():
     ops._TEST_DELAYS.clear()
 
 
-def _run(side, batch, delays=None, single_stream=False, graph=False, steps=2):
+def _run(side, batch, delays=None, single_stream=False, graph=False, steps=2, mutate=None):
     """-> per step: (losses, G's first Adam moment, D's, the two networks), from the seeded state."""
     from hoig_amd import ops
     from hoig_amd.models.networks import generator as G
@@ -41,6 +41,8 @@ def _run(side, batch, delays=None, single_stream=False, graph=False, steps=2):
         G._FORK_STREAMS, ops._WGRAD_SIDE = False, False
     try:
         m = product_trainer('generator_spade_attn', batch, side, hip_graph=graph)
+        if mutate is not None:
+            mutate(m)
         out = []
         n = steps + (2 if graph else 0)            # (a captured step replays from its third call on a batch shape)
         for i in range(n):
@@ -105,31 +107,35 @@ def test_delayed_role_captured_graph(role, reference_128):
     for k in er:
         assert abs(e[k] - er[k]) <= 0.1 * max(abs(er[k]), 1e-2), (role, k, e[k], er[k])
     # (third step of a chaotic GAN: single small tensors -- a 25-element attention bias -- differ by 0.9 between two runs of the
-    # same code; a stale read would put a whole sub-network's tensors there)
+    # same code, and the attention layers' 36 small tensors are the noisiest of the 425; a stale read would put a whole
+    # sub-network's tensors there)
     for net, a, b in ((net_g, mg, mgr), (net_d, md, mdr)):
         da, db = net.export_dict(a), net.export_dict(b)
         far = [k for k in db if float((da[k] - db[k]).norm() / db[k].norm().clamp_min(1e-30)) > 0.5]
-        assert len(far) <= 0.03 * len(db), (role, len(far), len(db), far[:8])
+        assert len(far) <= 0.1 * len(db), (role, len(far), len(db), far[:8])
 
 
-def test_the_detector_sees_a_reader_that_does_not_wait(reference_128):
-    """Negative control: remove the readers' wait for the optimiser side stream (ParamTree.wait_pending: the bug class of round 2)
-    and delay that stream -- the second step then runs on weights the optimiser has not written yet and the check must FAIL.
+def test_the_detector_sees_an_optimiser_that_does_not_wait(reference_128):
+    """Negative control: take away the optimiser side stream's wait for the caller's stream (Trainer._step).  Adam then starts
+    while the backward is still running, reads gradients that are not all there, and the check must FAIL on the first step --
+    with a whole tensor's moment missing, not at the noise level.
 
-    (The other ordering bug of the earlier rounds, the missing join of the backward's branch streams, cannot serve as the control
-    any more: measured here (profiles/r04_diag_join.txt), the caller's stream is ordered behind the branch streams after
+    (Neither of the two ordering bugs of the earlier rounds can serve as the control any more.  The missing join of the backward's
+    branch streams: measured here (profiles/r04_diag_join.txt), the caller's stream is ordered behind the branch streams after
     `backward()` even with Trainer._join_backward_streams removed -- the flat parameters are autograd leaves, their (no-op)
     AccumulateGrad nodes run on the stream of their branch, and the engine joins the caller's stream with every such leaf stream
-    when the backward ends.  The explicit join stays: it is what a captured step relies on.)"""
-    from hoig_amd import nn
-    keep = nn.ParamTree.wait_pending
-    nn.ParamTree.wait_pending = lambda self, *a, **k: None
-    try:
-        run = _run(128, 2, {'opt': DELAY})
-    finally:
-        nn.ParamTree.wait_pending = keep
+    when the backward ends; the explicit join stays, a captured step relies on it.  A reader that does not wait for the
+    optimiser reads weights that are ONE step old: 2e-4 per element, numerically invisible next to this GAN's run-to-run
+    spread -- timing tests cannot see that class, which is why the per-stream PendingUpdate bookkeeping is unit-tested on its
+    own: tests/test_graph_gpu.py::test_readers_wait_for_a_delayed_optimiser_side_stream.)"""
+    def mutate(m):
+        m._side.wait_stream = lambda stream: None
+    run = _run(128, 2, mutate=mutate, steps=1)
+    (_, mg, _, net_g, _), (_, mgr, _, _, _) = run[0], reference_128[0]
+    worst = _worst(net_g, mg, mgr)
+    assert worst[0] > 0.5, worst
     with pytest.raises(AssertionError):
-        _compare(run, reference_128, 'opt without the readers\' wait', steps=2)
+        _compare(run, reference_128, 'optimiser without its wait', steps=1)
 
 
 def test_delayed_roles_at_the_bench_size():
