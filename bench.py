@@ -274,6 +274,7 @@ def main():
     ap.add_argument('--graph', action='store_true', help='time the step as a replayed hipGraph (default: issued kernel by kernel on its streams, which is faster on this ROCm: DESIGN.md section 3c)')
     ap.add_argument('--graph-steps', type=int, default=20, help='steps of the comparison leg in the OTHER form (captured if the main run is eager, and vice versa); 0 = skip')
     ap.add_argument('--no-gen-fwd', action='store_true')
+    ap.add_argument('--host-samples', type=int, default=5, help='warmed samples of the host issue time per step (median reported); 0 = one plain step (profiling runs)')
     ap.add_argument('--fwd-batch', type=int, default=32, help='batch of the generator-forward latency leg')
     ap.add_argument('--cpu-baseline-worker', type=int, default=0, help=argparse.SUPPRESS)
     ap.add_argument('--cpu-budget', type=int, default=150, help='wall seconds the CPU-baseline child may use')
@@ -337,9 +338,16 @@ def main():
     is_captured = lambda: bool(model._graphs) and all(g['graphs'] is not None for g in model._graphs.values())
     main_captured = is_captured()
 
-    def host_issue_ms(samples=5):
+    def host_issue_ms(samples=args.host_samples):
         """Host time to issue ONE step on an idle device: the median of `samples` warmed steps, each bracketed by a barrier (one
         un-warmed sample right after switching the step form read 148.9 ms in round 3's driver run: VERDICT r3)."""
+        if samples <= 0:
+            barrier()
+            t = time.perf_counter()
+            model.optimize_parameters()
+            dt_ = (time.perf_counter() - t) * 1e3
+            barrier()
+            return dt_
         ts = []
         for i in range(samples + 2):
             barrier()

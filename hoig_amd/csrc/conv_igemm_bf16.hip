@@ -1340,9 +1340,15 @@ int launch_halo_s2(HaloArgs a, int ns, hipStream_t st) {
     a.nblk_n = a.N / (n64 ? 64 : 128);
     a.nblk = a.Bn * a.tiles_x * a.tiles_y * a.nblk_n * (SCATTER ? 4 : 1);
     a.nmajor = 0;
-    // on v_mfma_f32_16x16x32 (conv_halo16.hip): +10..24 % (profiles/r04_s2_16_ab.txt) except the scatter launches with 64-channel
-    // tiles (ConvTranspose2d 128 -> 64 forward at full resolution: -5 %), which stay on the 32x32 kernel
-    if (hoig_tuning(HOIG_TUNE_S2_16) != 0 && !(SCATTER && n64)) return launch_halo_s2_m16(a, ns, SCATTER, st);
+    // scatter mode with all four output phases in one workgroup (conv_halo16.hip): one halo load instead of four
+    if (SCATTER && hoig_tuning(HOIG_TUNE_S2_ALL) != 0) {
+        const int rc = launch_halo_s2_all_m16(a, ns, st);
+        if (rc != HOIG_EUNSUPPORTED) return rc;
+    }
+    // on v_mfma_f32_16x16x32 (conv_halo16.hip): +10..24 % (profiles/r04_s2_16_ab.txt) except the THREE-term scatter launches with
+    // 64-channel tiles (ConvTranspose2d 128 -> 64 forward at full resolution: -5 %; the two-term data gradient of the same
+    // shape: +24 %), which stay on the 32x32 kernel
+    if (hoig_tuning(HOIG_TUNE_S2_16) != 0 && !(SCATTER && n64 && ns == 2)) return launch_halo_s2_m16(a, ns, SCATTER, st);
     if (n64) {
         if (a.f16) HOIG_NS_SWITCH(ns, conv_halo_s2_bf16_kernel<NSX, 64, SCATTER, true><<<a.nblk, 256, 0, st>>>(a));
         else HOIG_NS_SWITCH(ns, conv_halo_s2_bf16_kernel<NSX, 64, SCATTER, false><<<a.nblk, 256, 0, st>>>(a));

@@ -130,10 +130,13 @@ def test_the_detector_sees_an_optimiser_that_does_not_wait(reference_128):
     own: tests/test_graph_gpu.py::test_readers_wait_for_a_delayed_optimiser_side_stream.)"""
     def mutate(m):
         m._side.wait_stream = lambda stream: None
-    run = _run(128, 2, mutate=mutate, steps=1)
+    # (at 128 x 128, batch 2 the step is host-bound: the device has long finished the backward when the host issues Adam, so the
+    # missing wait alone changes nothing -- the bg branch is delayed as in the tests above; its hardware-queue class is not the
+    # optimiser stream's, ops._QUEUE_OF_ROLE)
+    run = _run(128, 2, {'g_bg': DELAY}, mutate=mutate, steps=1)
     (_, mg, _, net_g, _), (_, mgr, _, _, _) = run[0], reference_128[0]
     worst = _worst(net_g, mg, mgr)
-    assert worst[0] > 0.5, worst
+    assert worst[0] > 0.5 and worst[1].startswith('bg_model'), worst
     with pytest.raises(AssertionError):
         _compare(run, reference_128, 'optimiser without its wait', steps=1)
 

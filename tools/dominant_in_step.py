@@ -1,7 +1,11 @@
 """In-step time of one launch SHAPE (not of a kernel template, which serves several layer shapes) from a rocprofv3 kernel trace
 (VERDICT r3 item 5).    python tools/dominant_in_step.py <kernel_trace.csv> <kernel-name substring> <grid size x> [GFLOP per launch]
 The step's dominant launch: 3x3 stride-1 512->512 at 32x32 over 16 stacked images = 256 workgroups of 512 threads
-(Grid_Size_X 131072) of conv_halo3_m16_kernel<2,4,2,128,true>; 77.31 GFLOP algorithmic."""
+(Grid_Size_X 131072) of conv_halo3_m16_kernel<2,4,2,128,true>; 77.31 GFLOP algorithmic.
+CAVEAT (round 4): the grid does not identify that shape uniquely -- the 8-image 128 -> 1024 SPADE convolutions launch the same
+template on the same 256 workgroups -- so the figure this prints averages both; the per-SHAPE in-step time that DESIGN.md quotes
+comes from tools/conv_table.py, which brackets every launch with events on its own stream and keys them by the convolution
+descriptor (profiles/r04_conv_table.txt: one stream; r04_conv_table_streams.txt: the multi-stream step)."""
 import csv
 import sys
 

@@ -12,9 +12,9 @@ fi
 python bench.py > $O/${TAG}_bench.json 2> $O/${TAG}_bench.err
 export TMPDIR=/tmp
 cd /tmp
-HOIG_WGRAD_STREAM=0 HOIG_STREAMS=0 HOIG_BENCH_NO_ROOF=1 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/p_serial -- python3 $GRAFT_REPO_ROOT/bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-gen-fwd --graph-steps 0 > /dev/null 2>&1
+HOIG_WGRAD_STREAM=0 HOIG_STREAMS=0 HOIG_BENCH_NO_ROOF=1 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/p_serial -- python3 $GRAFT_REPO_ROOT/bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-gen-fwd --graph-steps 0 --host-samples 0 > /dev/null 2>&1
 cp $(find /tmp/p_serial -name "*kernel_stats.csv" | head -1) $O/${TAG}_serial_kernel_stats.csv
-rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/p_bench -- python3 $GRAFT_REPO_ROOT/bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-gen-fwd --graph-steps 0 > /dev/null 2>&1
+rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/p_bench -- python3 $GRAFT_REPO_ROOT/bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-gen-fwd --graph-steps 0 --host-samples 0 > /dev/null 2>&1
 cp $(find /tmp/p_bench -name "*kernel_stats.csv" | head -1) $O/${TAG}_bench_kernel_stats.csv
 cp $(find /tmp/p_bench -name "*kernel_trace.csv" | head -1) /tmp/${TAG}_bench_trace.csv
 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/p_dom -- python3 $GRAFT_REPO_ROOT/tools/dominant_conv.py bf16x3 > /dev/null 2>&1
@@ -35,6 +35,8 @@ python tools/dominant_in_step.py /tmp/${TAG}_bench_trace.csv conv_halo3_m16_kern
 python tools/dominant_in_step.py $(find /tmp/p_serial -name "*kernel_trace.csv" | head -1) conv_halo3_m16_kernel 131072 >> $O/${TAG}_dominant_in_step.txt 2>&1
 python tools/kstats_top.py $O/${TAG}_serial_kernel_stats.csv 5 70 > $O/${TAG}_serial_top.txt
 HOIG_WGRAD_STREAM=0 HOIG_STREAMS=0 ROWS=150 python tools/conv_table.py bf16x3:f16x2 2>/dev/null | grep -v "created\|amdgpu" > $O/${TAG}_conv_table.txt
+# the same per-SHAPE table inside the multi-stream step (events on each launch's own stream: durations include what runs beside it)
+ROWS=40 python tools/conv_table.py bf16x3:f16x2 2>/dev/null | grep -v "created\|amdgpu" > $O/${TAG}_conv_table_streams.txt
 cd /tmp
 HOIG_STREAMS=0 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/p_fwd -- python3 $GRAFT_REPO_ROOT/tools/fwd_only.py > /dev/null 2>&1
 cp $(find /tmp/p_fwd -name "*kernel_stats.csv" | head -1) $O/${TAG}_genfwd_b32_kernel_stats.csv
