@@ -234,6 +234,5 @@ int launch_wgrad_halo_m16(const WHaloArgs &a, int ns, int th, int cm, dim3 grid,
 // or 64; `a` carries that tiling's geometry); HOIG_EUNSUPPORTED for shapes it has no tiling for
 int launch_halo3_m16(HaloArgs a, int ns, int bn, hipStream_t st);
 int launch_halo_s2_m16(const HaloArgs &a, int ns, bool scatter, hipStream_t st);
-int launch_halo_s2_all_m16(HaloArgs a, int ns, hipStream_t st);
 
 }  // namespace hoig_detail

@@ -15,7 +15,6 @@
 // that the staging stores (ds_write_b64 of the split halo: 2 pixels x 8 lanes; ds_write_b128 of the weight chunks: 2 rows x 4
 // lanes) fill a whole 128-B bank window per lane group.
 #include "conv_bf16_common.h"
-#include <type_traits>
 
 namespace hoig_detail {
 namespace {
@@ -597,221 +596,6 @@ __global__ __launch_bounds__(256) void conv_halo_s2_m16_kernel(const HaloArgs p)
     if (p.stats) m16_stats_epilogue<NTW, 2, BN, NT>(st1, st2, smem, p.stats + (size_t)b * 2 * p.N, p.N, n0, wm, wn, lane, tid);
 }
 
-// ---------------------------------------------------------------------------------------------------------------------
-// Scatter mode with ALL FOUR output phases in one workgroup (ConvTranspose2d s2 forward, Conv2d s2 data gradient):
-// out[2i - 1 + (r,s)] += in[i] w[r][s].  conv_halo_s2_m16_kernel<.., SCATTER> gives each workgroup ONE output parity phase of a
-// coarse tile, so the same (4+1) x 33 input halo is loaded and split four times and a launch at full resolution is 8192 short
-// workgroups.  Here a workgroup owns the coarse tile's 4 x 32 input pixels x 64 output channels for all four phases -- 8 x 64
-// fine pixels, whole rows of the output: tap (r, s) feeds phase (P, Q) = (r != 1, s != 1) from the halo at offset
-// (r == 0, s == 0), nine taps over ONE halo image per 32-channel block, one tap ROW of weight tiles per step.  Accumulators:
-// 4 phases x (4 pixel tiles x 2 channel tiles) per wave = 128 registers; two workgroups of four waves per CU.
-template <int NSX, bool F16>
-__global__ __launch_bounds__(256) void conv_halo_s2_all_m16_kernel(const HaloArgs p) {
-    constexpr int NS = NSX == 1 ? 1 : 2, NB = NSX == 2 ? 2 : 1;
-    constexpr int TH = 4, TW = 32, NT = 256, WN = 2, BN = 64, KS = 3;
-    constexpr int HH = TH + 1, HW = TW + 1, HPIX = HH * HW;
-    constexpr int PHALF = HPIX * 32, P23 = round128(PHALF) + 64, PLANE_P = round128(P23 + PHALF);
-    constexpr int W23 = BN * 32 + 64, PLANE_W = round128(W23 + BN * 32);
-    constexpr int MT = 4, NTW = BN / (16 * WN);
-    __shared__ __attribute__((aligned(16))) unsigned char smem[NS * PLANE_P + KS * NB * PLANE_W];
-    unsigned char *Ph = smem, *Pl = smem + PLANE_P;
-    unsigned char *Wbase = smem + NS * PLANE_P;            // the three tap tiles of a row, (Wh, Wl) each
-
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int l15 = lane & 15, lg = lane >> 4;
-    const int wm = wave / WN, wn = wave % WN;
-    const int tile = hoig_xcd_remap(blockIdx.x, p.nblk);
-    int mt_ = tile / p.nblk_n;
-    const int n0 = (tile % p.nblk_n) * BN;
-    const int tx_ = mt_ % p.tiles_x;
-    mt_ /= p.tiles_x;
-    const int ty_ = mt_ % p.tiles_y, b = mt_ / p.tiles_y;
-    const int y0 = ty_ * TH, x0 = tx_ * TW;                // coarse-grid tile origin
-
-    const int brow = tid >> 2, bpos = tid & 3;             // 64 weight rows x 4 chunk positions = 256 threads
-    const unsigned short *wrow_h, *wrow_l;
-    int woff;
-    {
-        const int n = n0 + brow;
-        const size_t o = ((size_t)(n >> 5) * (p.K >> 5)) * 1024 + (n & 31) * 32 + bpos * 8;
-        wrow_h = n < p.N ? p.Wh + o : nullptr;
-        wrow_l = (NB == 2 && n < p.N) ? p.Wl + o : nullptr;
-        const int c = bpos ^ ((brow >> 2) & 3);
-        woff = (c >> 1) * W23 + brow * 32 + (c & 1) * 16;
-    }
-    int wread[NTW], pread[MT];
-#pragma unroll
-    for (int j = 0; j < NTW; ++j) wread[j] = (lg >> 1) * W23 + (wn * (NTW * 16) + j * 16 + l15) * 32 + (lg & 1) * 16;
-#pragma unroll
-    for (int m = 0; m < MT; ++m)
-        pread[m] = (lg >> 1) * P23 + ((wm * 2 + (m >> 1)) * HW + (m & 1) * 16 + l15) * 32 + (lg & 1) * 16;
-
-    f32x4 acc[4][NTW][MT];
-#pragma unroll
-    for (int ph = 0; ph < 4; ++ph)
-#pragma unroll
-        for (int j = 0; j < NTW; ++j)
-#pragma unroll
-            for (int m = 0; m < MT; ++m) acc[ph][j][m] = f32x4{0.f, 0.f, 0.f, 0.f};
-
-    uint4 rbh[KS], rbl[KS];
-    const int ncb = p.Cg >> 5;
-    auto load_b = [&](int cb, int r) {
-#pragma unroll
-        for (int t = 0; t < KS; ++t) {
-            const size_t koff = (size_t)((r * KS + t) * p.Cg + cb * 32) * 32;
-            rbh[t] = wrow_h ? *reinterpret_cast<const uint4 *>(wrow_h + koff) : make_uint4(0, 0, 0, 0);
-            if (NB == 2) rbl[t] = wrow_l ? *reinterpret_cast<const uint4 *>(wrow_l + koff) : make_uint4(0, 0, 0, 0);
-        }
-    };
-    auto store_b = [&]() {
-#pragma unroll
-        for (int t = 0; t < KS; ++t) {
-            unsigned char *Wh = Wbase + t * NB * PLANE_W, *Wl = Wh + PLANE_W;
-            *reinterpret_cast<uint4 *>(Wh + woff) = rbh[t];
-            if (NB == 2) *reinterpret_cast<uint4 *>(Wl + woff) = rbl[t];
-        }
-    };
-    const float *Aimg = p.A + (size_t)b * p.H * p.W * p.Cg;       // p.H x p.W: the gathered tensor (the coarse grid)
-    constexpr int HSLICES = (HPIX * 8 + NT - 1) / NT;
-    float4 hreg[HSLICES];
-    auto halo_load = [&](int cb) {
-#pragma unroll
-        for (int sl = 0; sl < HSLICES; ++sl) {
-            const int i = tid + NT * sl;
-            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (i < HPIX * 8) {
-                const int pix = i >> 3, c4 = i & 7;
-                const int hy = pix / HW, hx = pix - hy * HW;
-                const int gy = y0 + hy, gx = x0 + hx;
-                if (gy < p.H && gx < p.W)
-                    v = *reinterpret_cast<const float4 *>(Aimg + ((size_t)gy * p.W + gx) * p.Cg + cb * 32 + c4 * 4);
-            }
-            hreg[sl] = v;
-        }
-    };
-    auto halo_store = [&]() {
-#pragma unroll
-        for (int sl = 0; sl < HSLICES; ++sl) {
-            const int i = tid + NT * sl;
-            if (i < HPIX * 8) {
-                const int pix = i >> 3, c4 = i & 7;
-                uint2 hi, lo;
-                split4t<F16>(hreg[sl], hi, lo);
-                const int off = (c4 >> 2) * P23 + pix * 32 + (c4 & 3) * 8;
-                *reinterpret_cast<uint2 *>(Ph + off) = hi;
-                if (NS == 2) *reinterpret_cast<uint2 *>(Pl + off) = lo;
-            }
-        }
-    };
-    // the three taps of row r (a compile-time constant, so that the phase index of every accumulator is static)
-    auto compute_row = [&](auto rc) {
-        constexpr int r = decltype(rc)::value;
-#pragma unroll
-        for (int t = 0; t < KS; ++t) {
-            constexpr int P = r != 1;
-            const int Q = t != 1;                                  // (static after unrolling)
-            const int tapoff = ((r == 0 ? 1 : 0) * HW + (t == 0 ? 1 : 0)) * 32;
-            const unsigned char *Wh = Wbase + t * NB * PLANE_W, *Wl = Wh + PLANE_W;
-            bf16x8 ph[MT], pl[MT];
-#pragma unroll
-            for (int m = 0; m < MT; ++m) {
-                ph[m] = *reinterpret_cast<const bf16x8 *>(Ph + pread[m] + tapoff);
-                if (NS == 2) pl[m] = *reinterpret_cast<const bf16x8 *>(Pl + pread[m] + tapoff);
-            }
-#pragma unroll
-            for (int j = 0; j < NTW; ++j) {
-                const bf16x8 wh = *reinterpret_cast<const bf16x8 *>(Wh + wread[j]);
-                bf16x8 wl;
-                if (NB == 2) wl = *reinterpret_cast<const bf16x8 *>(Wl + wread[j]);
-#pragma unroll
-                for (int m = 0; m < MT; ++m) {
-                    f32x4 &a = acc[P * 2 + Q][j][m];
-                    if (NS == 2) a = mfma_m16<F16>(wh, pl[m], a);
-                    if (NB == 2) a = mfma_m16<F16>(wl, ph[m], a);
-                    a = mfma_m16<F16>(wh, ph[m], a);
-                }
-            }
-        }
-    };
-
-    halo_load(0);
-    load_b(0, 0);
-    halo_store();
-    store_b();
-    __syncthreads();
-#pragma unroll 1
-    for (int cb = 0; cb < ncb; ++cb) {
-        const bool more = cb + 1 < ncb;
-        // row 0
-        load_b(cb, 1);
-        if (more) halo_load(cb + 1);
-        compute_row(std::integral_constant<int, 0>());
-        __syncthreads();
-        store_b();
-        __syncthreads();
-        // row 1
-        load_b(cb, 2);
-        compute_row(std::integral_constant<int, 1>());
-        __syncthreads();
-        store_b();
-        __syncthreads();
-        // row 2
-        if (more) load_b(cb + 1, 0);
-        compute_row(std::integral_constant<int, 2>());
-        if (more) {
-            __syncthreads();                  // every wave has finished reading the weight tiles and the halo
-            halo_store();
-            store_b();
-            __syncthreads();
-        }
-    }
-
-    const float nslope = p.act == HOIG_ACT_NONE ? 1.f : (p.act == HOIG_ACT_RELU ? 0.f : p.slope);
-    const bool special = p.act == HOIG_ACT_TANH || p.act == HOIG_ACT_SIGMOID;
-    float4 bias_r[NTW];
-#pragma unroll
-    for (int j = 0; j < NTW; ++j) {
-        const int n = n0 + wn * (NTW * 16) + j * 16 + lg * 4;
-        bias_r[j] = (p.bias && n < p.N) ? *reinterpret_cast<const float4 *>(p.bias + n) : make_float4(0.f, 0.f, 0.f, 0.f);
-    }
-    float st1[NTW][4], st2[NTW][4];
-#pragma unroll
-    for (int j = 0; j < NTW; ++j)
-#pragma unroll
-        for (int q = 0; q < 4; ++q) st1[j][q] = st2[j][q] = 0.f;
-    const int Ho = 2 * p.H, Wo = 2 * p.W;
-#pragma unroll
-    for (int m = 0; m < MT; ++m) {
-        const int cy = y0 + wm * 2 + (m >> 1), cx = x0 + (m & 1) * 16 + l15;
-#pragma unroll
-        for (int ph = 0; ph < 4; ++ph) {
-            const size_t pix = ((size_t)b * Ho + 2 * cy + (ph >> 1)) * Wo + 2 * cx + (ph & 1);
-#pragma unroll
-            for (int j = 0; j < NTW; ++j) {
-                const int n = n0 + wn * (NTW * 16) + j * 16 + lg * 4;
-                if (n < p.N) {
-                    float v[4];
-                    const float bq[4] = {bias_r[j].x, bias_r[j].y, bias_r[j].z, bias_r[j].w};
-#pragma unroll
-                    for (int q = 0; q < 4; ++q) v[q] = fast_act(acc[ph][j][m][q] * p.oscale + bq[q], nslope, special, p.act, p.slope);
-                    if (p.addend) {
-                        const float4 ad = *reinterpret_cast<const float4 *>(p.addend + pix * p.N + n);
-                        v[0] += ad.x; v[1] += ad.y; v[2] += ad.z; v[3] += ad.w;
-                    }
-#pragma unroll
-                    for (int q = 0; q < 4; ++q) {
-                        st1[j][q] += v[q];
-                        st2[j][q] += v[q] * v[q];
-                    }
-                    *reinterpret_cast<float4 *>(p.C + pix * p.N + n) = make_float4(v[0], v[1], v[2], v[3]);
-                }
-            }
-        }
-    }
-    if (p.stats) m16_stats_epilogue<NTW, 2, BN, NT>(st1, st2, smem, p.stats + (size_t)b * 2 * p.N, p.N, n0, wm, wn, lane, tid);
-}
-
 template <int NS, int BN>
 int launch_one(const HaloArgs &a, hipStream_t st) {
     constexpr int WM = 4, WN = 2;
@@ -846,17 +630,6 @@ int launch_s2(const HaloArgs &a, int ns, hipStream_t st) {
 }
 
 }  // namespace
-
-// scatter mode, all four phases per workgroup: `a` carries the coarse-grid geometry (H, W, tiles_x, tiles_y, Bn)
-int launch_halo_s2_all_m16(HaloArgs a, int ns, hipStream_t st) {
-    if (a.N % 64 || a.Cg % 32 || a.W % 32 || a.H % 4) return HOIG_EUNSUPPORTED;
-    a.nblk_n = a.N / 64;
-    a.nblk = a.Bn * a.tiles_x * a.tiles_y * a.nblk_n;
-    if (a.f16) HOIG_NS_SWITCH(ns, conv_halo_s2_all_m16_kernel<NSX, true><<<a.nblk, 256, 0, st>>>(a));
-    else HOIG_NS_SWITCH(ns, conv_halo_s2_all_m16_kernel<NSX, false><<<a.nblk, 256, 0, st>>>(a));
-    HOIG_LAUNCH_CHECK();
-    return HOIG_OK;
-}
 
 // the stride-2 3x3 layers: `a` arrives with the geometry launch_halo_s2 (conv_igemm_bf16.hip) computes
 int launch_halo_s2_m16(const HaloArgs &a, int ns, bool scatter, hipStream_t st) {

@@ -1340,11 +1340,6 @@ int launch_halo_s2(HaloArgs a, int ns, hipStream_t st) {
     a.nblk_n = a.N / (n64 ? 64 : 128);
     a.nblk = a.Bn * a.tiles_x * a.tiles_y * a.nblk_n * (SCATTER ? 4 : 1);
     a.nmajor = 0;
-    // scatter mode with all four output phases in one workgroup (conv_halo16.hip): one halo load instead of four
-    if (SCATTER && hoig_tuning(HOIG_TUNE_S2_ALL) != 0) {
-        const int rc = launch_halo_s2_all_m16(a, ns, st);
-        if (rc != HOIG_EUNSUPPORTED) return rc;
-    }
     // on v_mfma_f32_16x16x32 (conv_halo16.hip): +10..24 % (profiles/r04_s2_16_ab.txt) except the THREE-term scatter launches with
     // 64-channel tiles (ConvTranspose2d 128 -> 64 forward at full resolution: -5 %; the two-term data gradient of the same
     // shape: +24 %), which stay on the 32x32 kernel

@@ -17,7 +17,6 @@ Entry g_table[HOIG_TUNE_COUNT] = {
     {"few128", 1},
     {"wflat5", 1},
     {"wgrad_few", 1},
-    {"s2_all", 0},
 };
 }  // namespace
 

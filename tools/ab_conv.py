@@ -43,6 +43,9 @@ def main():
     a = ap.parse_args()
     ops.set_precision(a.prec)
     variants = [parse(v) for v in a.variants]
+    # every key any variant names starts each variant from its default (a key set by one variant must not leak into the next)
+    defaults = {k: L.set_tuning(k, -1) for v in variants for k in v}
+    variants = [dict(defaults, **v) for v in variants]
     st = torch.cuda.current_stream().cuda_stream
     p = lambda t: t.data_ptr()
     print('precision %s, %d rounds x %d launches, random data' % (a.prec, a.rounds, a.iters))
