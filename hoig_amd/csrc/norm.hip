@@ -12,7 +12,7 @@ namespace {
 constexpr int NT = 256;
 
 inline int inorm_chunks(int HW) {
-    // >= 16 pixel rows per workgroup (a 32x32 map already yields 64 workgroups per image), at most HOIG_NORM_CHUNKS (128) per
+    // >= 16 pixel rows per workgroup (a 32x32 map already yields 64 workgroups per image), at most 128 per
     // image: every workgroup closes with one atomic per (channel, moment) into the image's accumulators, the workgroups of a
     // launch finish together, and same-address atomics retire at ~25 ns each -- 512 chunks were a 13-us tail on every launch
     constexpr int cap = 128;

@@ -315,8 +315,8 @@ class Generator(ParamTree):
                     else:
                         next(gen, None)
 
-        # infer_front (generator.py:379-464).  src_model never reads tsf_model's features, so it runs AHEAD on a stream of its own
-        # (HOIG_SRC_STREAM=0: on the main stream); tsf_model waits, level by level, for the src features it warps in.
+        # infer_front (generator.py:379-464).  src_model never reads tsf_model's features, so it runs AHEAD on a stream of its own;
+        # tsf_model waits, level by level, for the src features it warps in.
         import contextlib
         fork_src = fork
         on_src = (lambda: torch.cuda.stream(s_src)) if fork_src else contextlib.nullcontext

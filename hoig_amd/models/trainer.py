@@ -549,8 +549,8 @@ class Trainer(BaseModel):
         fake_src, fake_tsf = to_nhwc(fake_src_imgs), to_nhwc(fake_tsf_imgs)
         mbg, mh = to_nhwc(fake_masks_bg), to_nhwc(fake_masks_hand)
         # The adversarial term (D on the fake) and the perceptual term (VGG on the fake, VGG on the target) do not read each other:
-        # three chains on three streams, like the generator's sub-networks (their backward replays there too); HOIG_LOSS_STREAMS=0:
-        # one after the other on the caller's stream.
+        # three chains on three streams, like the generator's sub-networks (their backward replays there too); HOIG_STREAMS=0: one after
+        # the other on the caller's stream.
         fork = fake_tsf.is_cuda and generator_forks_streams()
         T = self._g_terms
         into = T.term

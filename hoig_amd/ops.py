@@ -241,7 +241,7 @@ def delay_backward(x, role):
 _wgrad_streams = {}
 # weight gradients on a side stream, beside the data-gradient chain: '1' always, '0' never, 'auto' (default) wherever the
 # backward is ONE chain -- the generator's backward already runs as three concurrent chains (its forward forks onto branch
-# streams, HOIG_G_STREAMS), and a fourth stream of one-workgroup-per-CU kernels beside them costs 1 % (measured)
+# streams, HOIG_STREAMS), and a fourth stream of one-workgroup-per-CU kernels beside them costs 1 % (measured)
 _WGRAD_MODE = os.environ.get('HOIG_WGRAD_STREAM', 'auto')
 _WGRAD_SIDE = _WGRAD_MODE != '0'
 _wgrad_side_paused = False
