@@ -586,6 +586,8 @@ int hoig_conv_small_ci_fwd(const hoig_conv_desc *d, const float *x, const float 
 int hoig_conv_dot_fwd(const hoig_conv_desc *d, const float *x, const float *w, const float *bias, float *y, hipStream_t st);
 int hoig_conv_small_fwd_acts(const hoig_conv_desc *d, const float *x, const float *w, const float *bias, float *y,
                              unsigned long long acts, hipStream_t st);
+int hoig_conv_head7_m16(const hoig_conv_desc *d, const float *x, const float *w, const float *bias, float *y, unsigned long long acts,
+                        hipStream_t st);                  // conv_head16.hip
 // conv_thin.hip: stride-1 'same' convolutions with <= 8 (3x3: 16) channels on one side, taps in place of the missing channels
 int hoig_conv_thin_fwd(const hoig_conv_desc *d, const float *x, const float *w, const float *bias, float *y, hipStream_t st);
 int hoig_conv_thin_dgrad(const hoig_conv_desc *d, const float *dy, const float *w, float *dx, int accumulate, hipStream_t st);
@@ -608,7 +610,8 @@ extern "C" int hoig_conv2d_fwd(const hoig_conv_desc *d, const float *x, const fl
     if (rc) return rc;
     if (!x || !w || !y) return HOIG_EINVAL;
     hipStream_t st = (hipStream_t)stream;
-    rc = hoig_conv_small_fwd(d, x, w, bias, y, st);           // 7x7 heads with <= 4 output channels: direct fp32 kernel
+    rc = hoig_conv_head7_m16(d, x, w, bias, y, uniform_acts(d->act), st);      // 7x7 heads, three-term forward: MFMA, taps as columns
+    if (rc == HOIG_EUNSUPPORTED) rc = hoig_conv_small_fwd(d, x, w, bias, y, st);    // ... exact fp32 / other shapes: direct fp32 kernel
     if (rc == HOIG_EUNSUPPORTED && thin_enabled()) rc = hoig_conv_thin_out(d, x, w, bias, y, uniform_acts(d->act), 0, st);   // 3x3, <= 16 outputs
     if (rc == HOIG_EUNSUPPORTED && thin_enabled()) rc = hoig_conv_thin_fwd(d, x, w, bias, y, st);      // thin-input convs on MFMA
     if (rc == HOIG_EUNSUPPORTED) rc = hoig_conv_small_ci_fwd(d, x, w, bias, y, st);    // 7x7 stems with <= 8 input channels
@@ -633,7 +636,8 @@ extern "C" int hoig_conv2d_fwd_heads(const hoig_conv_desc *d, const float *x, co
     int rc = check_desc(d);
     if (rc) return rc;
     if (!x || !w || !y) return HOIG_EINVAL;
-    rc = hoig_conv_small_fwd_acts(d, x, w, bias, y, acts, (hipStream_t)stream);          // 7x7, <= 5 outputs: fp32 VALU (every mode)
+    rc = hoig_conv_head7_m16(d, x, w, bias, y, acts, (hipStream_t)stream);               // 7x7, 3-5 outputs, three-term forward: MFMA
+    if (rc == HOIG_EUNSUPPORTED) rc = hoig_conv_small_fwd_acts(d, x, w, bias, y, acts, (hipStream_t)stream);     // 7x7, <= 5 outputs: fp32 VALU
     if (rc == HOIG_EUNSUPPORTED) rc = hoig_conv_thin_out(d, x, w, bias, y, acts, 0, (hipStream_t)stream);
     return rc;
 }

@@ -17,6 +17,7 @@ Entry g_table[HOIG_TUNE_COUNT] = {
     {"few128", 1},
     {"wflat5", 1},
     {"wgrad_few", 1},
+    {"head16", 1},
 };
 }  // namespace
 

@@ -411,6 +411,8 @@ const char *hoig_version(void);
  *   "wflat5"  1  the weight gradient of the attention's valid 5x5 convolutions on the flattened pixel axis (wgrad_flat.hip):
  *                1 = where the output width is not a multiple of 32 (the 2 x 32-pixel halo kernel cannot run), 2 = always
  *   "wgrad_few" 1  half the pixel splits for the weight gradients of the 8-image 32 x 32 launches (two of them run side by side)
+ *   "head16"  1  the forward of the 7x7 image / mask heads (64 -> 3..5 channels) on 16x16x32 with the horizontal taps as MFMA
+ *                columns (conv_head16.hip), three-term forward arithmetic only; 0: the exact-fp32 VALU kernel (conv_small.hip)
  *   "wgrad16" 0  the stride-1 3x3 weight gradients on 16x16x32 (wgrad_halo16.hip): measured 5-20 % slower than 32x32x16
  * Process-wide, not synchronised: set before launching. */
 int hoig_set_tuning(const char *key, int value);

@@ -257,3 +257,41 @@ def test_wflat5_weight_gradient_of_valid_5x5(B, Ci, Co, Hi, Wi, bias, mode):
         if db is not None:
             assert rel_err(db, br.grad) < 1e-4, tag
     assert rel_err(res[1][0], res[0][0]) < 1e-4
+
+
+@pytest.mark.parametrize('B,Co,H,W', [(2, 5, 64, 64),          # one strip of four tiles, four row chunks
+                                      (1, 5, 40, 256),         # the step's shape: two overlapping strips of nine tiles; a ragged last chunk
+                                      (2, 3, 16, 256),         # bg_model's head (two column tiles)
+                                      (1, 4, 23, 272),         # three strips, the last 16 pixels wide
+                                      (1, 5, 9, 150),          # a ragged width: the last tile of the second strip is part padding
+                                      (1, 3, 7, 16)])          # fewer rows than taps, one tile
+def test_head16_forward_of_the_7x7_heads(B, Co, H, W):
+    """Tuning key 'head16' (conv_head16.hip): the 7x7 heads' forward with the horizontal taps as MFMA columns, against the exact-fp32
+    VALU kernel it replaces and against torch fp32 -- fused heads with one activation per channel (hoig_conv2d_fwd_heads) and a plain
+    convolution with bias and tanh (hoig_conv2d_fwd: bg_model's head)."""
+    from hoig_amd import ops, _lib as L
+    g = torch.Generator().manual_seed(31 + Co)
+    x = (torch.randn(B, H, W, 64, generator=g).abs() * 0.7).cuda()          # (post-ReLU features)
+    w = ops.pack_weight((torch.randn(Co, 64, 7, 7, generator=g) * 0.02).cuda())
+    bias = (torch.randn(Co, generator=g) * 0.1).cuda()
+    splits, acts = ((3, Co - 3), (L.ACT_TANH, L.ACT_SIGMOID)) if Co > 3 else ((3,), (L.ACT_TANH,))
+    prev = L.set_tuning('head16', 0)
+    ops.set_precision('bf16x3')
+    try:
+        res = []
+        for v in (0, 1):
+            L.set_tuning('head16', v)
+            with torch.no_grad():
+                heads = ops.conv_heads(x, w, splits, acts)
+                plain = ops.conv2d(x, w, bias, 1, 3, act=L.ACT_TANH)
+            torch.cuda.synchronize()
+            res.append((torch.cat(heads, dim=-1), plain))
+    finally:
+        ops.set_precision('f32')
+        L.set_tuning('head16', prev)
+    pre = F.conv2d(x.permute(0, 3, 1, 2), w, padding=3).permute(0, 2, 3, 1)
+    want_heads = torch.cat([torch.tanh(pre[..., :3]), torch.sigmoid(pre[..., 3:])], dim=-1)
+    want_plain = torch.tanh(pre + bias)
+    for tag, (heads, plain) in zip(('fp32 VALU', 'mfma'), res):
+        assert rel_err(heads, want_heads) < 1e-5 and rel_err(plain, want_plain) < 1e-5, (tag, rel_err(heads, want_heads), rel_err(plain, want_plain))
+    assert (res[1][0] - res[0][0]).abs().max() < 2e-5 and (res[1][1] - res[0][1]).abs().max() < 2e-5
