@@ -370,6 +370,98 @@ __global__ __launch_bounds__(256) void pack_all_kernel(const float *__restrict__
     }
 }
 
+// Adam and the operand split in ONE pass over the weights (hoig_adam_pack_step): the update of a convolution weight and its
+// four 16-bit planes used to be two launches -- Adam over the flat buffer (28 B per parameter), then pack_all_kernel re-reading
+// every updated weight (4 B) and writing the planes with 2-byte stores -- at the END of a step, where nothing runs beside them.
+// Here a workgroup owns one 32(co) x 32(ci) tile of one weight as in pack_all_kernel; a thread updates FOUR consecutive input
+// channels (float4 of p, g, m, v; the arithmetic of adam_dev_kernel, expression for expression) and writes their forward planes
+// as 8-byte stores; the data-gradient planes go through the same LDS transpose, four output channels per thread.  Workgroups
+// past the tile count do the plain update of the parameters that have no planes (`plain`: 1024-element chunks).
+__global__ __launch_bounds__(256) void adam_pack_kernel(float *__restrict__ flat, const float *__restrict__ grad, float *__restrict__ m_,
+                                                        float *__restrict__ v_, const float *__restrict__ derived, float gscale,
+                                                        const int64_t *__restrict__ segs, int nseg, int64_t ntiles,
+                                                        const int64_t *__restrict__ plain, unsigned short *__restrict__ hi_f,
+                                                        unsigned short *__restrict__ lo_f, unsigned short *__restrict__ hi_d,
+                                                        unsigned short *__restrict__ lo_d) {
+    const float step_size = derived[0], omb1 = derived[1], b2 = derived[2], omb2 = derived[3], eps = derived[4], bc2_sqrt = derived[5];
+    struct Q { float4 p, g, m, v; };
+    auto load4 = [&](int64_t i) -> Q {
+        Q q;
+        q.p = *reinterpret_cast<const float4 *>(flat + i);
+        q.g = *reinterpret_cast<const float4 *>(grad + i);
+        q.m = *reinterpret_cast<const float4 *>(m_ + i);
+        q.v = *reinterpret_cast<const float4 *>(v_ + i);
+        return q;
+    };
+    auto update4 = [&](Q q, int64_t i) -> float4 {
+        float *pe = &q.p.x, *me = &q.m.x, *ve = &q.v.x;
+        const float *ge = &q.g.x;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const float gk = ge[k] * gscale;
+            me[k] = me[k] + (gk - me[k]) * omb1;
+            ve[k] = ve[k] * b2 + omb2 * (gk * gk);
+            const float denom = sqrtf(ve[k]) / bc2_sqrt + eps;
+            pe[k] = pe[k] - step_size * (me[k] / denom);
+        }
+        *reinterpret_cast<float4 *>(flat + i) = q.p;
+        *reinterpret_cast<float4 *>(m_ + i) = q.m;
+        *reinterpret_cast<float4 *>(v_ + i) = q.v;
+        return q.p;
+    };
+    if ((int64_t)blockIdx.x >= ntiles) {
+        const int64_t *c = plain + 2 * ((int64_t)blockIdx.x - ntiles);
+        const int e = 4 * (int)threadIdx.x;
+        if (e < (int)c[1]) update4(load4(c[0] + e), c[0] + e);
+        return;
+    }
+    int lo_s = 0, hi_s = nseg - 1;
+    while (lo_s < hi_s) {                 // last segment whose first tile <= blockIdx.x
+        const int mid = (lo_s + hi_s + 1) >> 1;
+        if (segs[(int64_t)mid * 6 + 5] <= (int64_t)blockIdx.x) lo_s = mid; else hi_s = mid - 1;
+    }
+    const int64_t *sg = segs + (int64_t)lo_s * 6;
+    const int64_t off = sg[0];
+    const int Co = (int)sg[1], RS = (int)sg[2], Ci = (int)sg[3], flags = (int)sg[4];
+    const int t = (int)((int64_t)blockIdx.x - sg[5]);
+    const int tiles_ci = Ci >> 5;
+    const int co0 = (t / tiles_ci) * 32, ci0 = (t % tiles_ci) * 32;
+    const int row = threadIdx.x >> 3, c4 = (threadIdx.x & 7) * 4;
+    __shared__ unsigned int tile[32][33];
+    const int co = co0 + row, ci = ci0 + c4;
+    const int64_t e0 = off + (int64_t)co * RS * Ci + ci;
+    Q nxt = load4(e0);
+    for (int rs = 0; rs < RS; ++rs) {
+        const Q cur = nxt;
+        if (rs + 1 < RS) nxt = load4(e0 + (int64_t)(rs + 1) * Ci);          // the next tap's rows are in flight while this one is split
+        const float4 w4 = update4(cur, e0 + (int64_t)rs * Ci);
+        const float we[4] = {w4.x, w4.y, w4.z, w4.w};
+        unsigned short h[4], l[4];
+        if (flags & 1) {
+#pragma unroll
+            for (int k = 0; k < 4; ++k) split_weight(we[k], true, h[k], l[k]);
+            const size_t o = off + plane_index(co, rs * Ci + ci, RS * Ci);
+            *reinterpret_cast<uint2 *>(hi_f + o) = make_uint2(h[0] | ((unsigned)h[1] << 16), h[2] | ((unsigned)h[3] << 16));
+            *reinterpret_cast<uint2 *>(lo_f + o) = make_uint2(l[0] | ((unsigned)l[1] << 16), l[2] | ((unsigned)l[3] << 16));
+        }
+        if (flags & 2) {
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                split_weight(we[k], false, h[k], l[k]);
+                tile[row][c4 + k] = (unsigned int)h[k] | ((unsigned int)l[k] << 16);
+            }
+            __syncthreads();
+            unsigned int pk[4];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) pk[k] = tile[c4 + k][row];          // (ci = ci0 + row, co = co0 + c4 + k)
+            const size_t o = off + plane_index(ci0 + row, rs * Co + co0 + c4, RS * Co);
+            *reinterpret_cast<uint2 *>(hi_d + o) = make_uint2((pk[0] & 0xffffu) | (pk[1] << 16), (pk[2] & 0xffffu) | (pk[3] << 16));
+            *reinterpret_cast<uint2 *>(lo_d + o) = make_uint2((pk[0] >> 16) | (pk[1] & 0xffff0000u), (pk[2] >> 16) | (pk[3] & 0xffff0000u));
+            __syncthreads();
+        }
+    }
+}
+
 template <int BM, int BN, int WM, int WN, int BK = 32>
 int launch(Args a, int ns, hipStream_t st) {
     constexpr int NT = WM * WN * 64;
@@ -1650,6 +1742,19 @@ extern "C" int hoig_pack_conv_weights_bf16_all(const float *flat, const int64_t 
                                                hoig_stream_t stream) {
     if (!flat || !segs || nseg <= 0 || ntiles <= 0 || !hi_f || !lo_f || !hi_d || !lo_d) return HOIG_EINVAL;
     pack_all_kernel<<<(unsigned)ntiles, 256, 0, (hipStream_t)stream>>>(flat, segs, nseg, hi_f, lo_f, hi_d, lo_d);
+    HOIG_LAUNCH_CHECK();
+    return HOIG_OK;
+}
+
+extern "C" int hoig_adam_pack_step(float *flat, const float *grad, float *exp_avg, float *exp_avg_sq, const float *derived,
+                                   float grad_scale, const int64_t *segs, int nseg, int64_t ntiles, const int64_t *plain,
+                                   int64_t nplain, uint16_t *hi_f, uint16_t *lo_f, uint16_t *hi_d, uint16_t *lo_d,
+                                   hoig_stream_t stream) {
+    if (!flat || !grad || !exp_avg || !exp_avg_sq || !derived || !segs || nseg <= 0 || ntiles <= 0 || nplain < 0 || (nplain && !plain) ||
+        !hi_f || !lo_f || !hi_d || !lo_d)
+        return HOIG_EINVAL;
+    adam_pack_kernel<<<(unsigned)(ntiles + nplain), 256, 0, (hipStream_t)stream>>>(flat, grad, exp_avg, exp_avg_sq, derived, grad_scale, segs,
+                                                                                 nseg, ntiles, plain, hi_f, lo_f, hi_d, lo_d);
     HOIG_LAUNCH_CHECK();
     return HOIG_OK;
 }

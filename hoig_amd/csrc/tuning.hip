@@ -18,6 +18,7 @@ Entry g_table[HOIG_TUNE_COUNT] = {
     {"wflat5", 1},
     {"wgrad_few", 1},
     {"head16", 1},
+    {"adam_pack", 1},
 };
 }  // namespace
 

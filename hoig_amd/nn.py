@@ -203,8 +203,33 @@ class ParamTree(nn.Module):
                 self._plane_bufs = ()
                 return
             self._plane_table = torch.tensor(rows, dtype=torch.int64, device=self.flat.device)
+            self._plain_chunks = self._build_plain_chunks(rows)
             self._plane_bufs = tuple(torch.empty(self.flat.numel(), dtype=torch.int16, device=self.flat.device)
                                      for _ in range(4))
+
+    def _build_plain_chunks(self, rows):
+        """The parts of the flat buffer that no row of the plane table covers, as (first element, count <= 1024) chunks for
+        hoig_adam_pack_step; None if two rows overlap (the fused step is then not used)."""
+        spans = sorted((r[0], r[0] + r[1] * r[2] * r[3]) for r in rows)
+        chunks, at = [], 0
+        for a, b in spans + [(self.flat.numel(), self.flat.numel())]:
+            if a < at:
+                return None
+            while at < a:
+                n = min(1024, a - at)
+                chunks.append([at, n])
+                at += n
+            at = b
+        if any(c[0] % 4 or c[1] % 4 for c in chunks):
+            return None
+        return torch.tensor(chunks if chunks else [[0, 0]], dtype=torch.int64, device=self.flat.device), len(chunks)
+
+    def fused_step_tables(self):
+        """(plane table, tile count, plain chunks, chunk count, the four plane buffers) for hoig_adam_pack_step, or None while the
+        planes do not exist (fp32 mode, before the first forward) or cannot be updated in the optimiser's launch."""
+        if not self._plane_bufs or getattr(self, '_plain_chunks', None) is None:
+            return None
+        return (self._plane_table, self._plane_tiles) + self._plain_chunks + (self._plane_bufs,)
 
     def _refresh_planes(self):
         """Split the current weights into bf16 planes (one launch) if they changed since the last split.  Called lazily by
@@ -448,6 +473,15 @@ class FusedAdam(object):
         self.step_count += 1
         self._on_device = self._on_device[:4] + (float(self.step_count),)
         fl, gr, m, v = self.tree.flat, self.tree.flat_grad, self.exp_avg, self.exp_avg_sq
+        fused = self.tree.fused_step_tables() if ready is None and L.set_tuning('adam_pack', -1) else None
+        if fused is not None:
+            # the update and the operand planes of the updated weights in one launch (include/hoig_kernels.h)
+            table, ntiles, plain, nplain, b = fused
+            L.call('hoig_adam_pack_step', _p(fl), _p(gr), _p(m), _p(v), _p(self._derived), grad_scale, _p(table), table.shape[0],
+                   ntiles, _p(plain), nplain, _p(b[0]), _p(b[1]), _p(b[2]), _p(b[3]), _st())
+            self.tree.version += 1
+            self.tree._plane_version = self.tree.version
+            return
         for a, b in (ready if ready is not None else [(0, fl.numel())]):
             L.call('hoig_adam_step_dev', fl.data_ptr() + 4 * a, gr.data_ptr() + 4 * a, m.data_ptr() + 4 * a,
                    v.data_ptr() + 4 * a, b - a, _p(self._derived), grad_scale, _st())

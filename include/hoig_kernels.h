@@ -347,6 +347,15 @@ int hoig_adam_step(float *param, const float *grad, float *exp_avg, float *exp_a
 int hoig_adam_tick(double *state, float *derived, hoig_stream_t stream);
 int hoig_adam_step_dev(float *param, const float *grad, float *exp_avg, float *exp_avg_sq, int64_t n, const float *derived,
                        float grad_scale, hoig_stream_t stream);
+/* hoig_adam_step_dev over a WHOLE flat buffer and hoig_pack_conv_weights_bf16_all of the updated weights in one launch: the
+ * weights of the table (`segs`, `nseg`, `ntiles`: as for hoig_pack_conv_weights_bf16_all; every table weight has Co % 32 == Ci % 32
+ * == 0 and the rows must not overlap) are updated tile by tile and their planes written from the registers that hold the new values;
+ * `plain` (device memory) holds nplain rows of 2 int64 {first element, count <= 1024, both multiples of 4}: the rest of the buffer,
+ * updated without planes.  Every element of the buffer must be covered exactly once by the table or by `plain`.  Same arithmetic as
+ * hoig_adam_step_dev, element for element. */
+int hoig_adam_pack_step(float *flat, const float *grad, float *exp_avg, float *exp_avg_sq, const float *derived, float grad_scale,
+                        const int64_t *segs, int nseg, int64_t ntiles, const int64_t *plain, int64_t nplain, uint16_t *hi_f,
+                        uint16_t *lo_f, uint16_t *hi_d, uint16_t *lo_d, hoig_stream_t stream);
 
 /* A non-blocking HIP stream owned by the library (the step's side streams: see hoig_amd/ops.py new_stream for why they are not
  * taken from PyTorch's round-robin stream pool). */
@@ -413,6 +422,8 @@ const char *hoig_version(void);
  *   "wgrad_few" 1  half the pixel splits for the weight gradients of the 8-image 32 x 32 launches (two of them run side by side)
  *   "head16"  1  the forward of the 7x7 image / mask heads (64 -> 3..5 channels) on 16x16x32 with the horizontal taps as MFMA
  *                columns (conv_head16.hip), three-term forward arithmetic only; 0: the exact-fp32 VALU kernel (conv_small.hip)
+ *   "adam_pack" 1  (read by the host side, hoig_amd/nn.py) the optimiser step and the split of the updated weights into operand planes
+ *                as one launch (hoig_adam_pack_step); 0: hoig_adam_step_dev, then hoig_pack_conv_weights_bf16_all before the next forward
  *   "wgrad16" 0  the stride-1 3x3 weight gradients on 16x16x32 (wgrad_halo16.hip): measured 5-20 % slower than 32x32x16
  * Process-wide, not synchronised: set before launching. */
 int hoig_set_tuning(const char *key, int value);

@@ -25,7 +25,7 @@ PATTERNS = [
     ('conv_dgrad', r'hoig_conv2d_(cat_)?bwd_data'),
     ('conv_fwd', r'hoig_conv2d_(cat_)?fwd'),
     ('attention', r'hoig_(attn_(pixel|src_gather|gs_gather)|replicate_pad)'),
-    ('optimiser', r'hoig_(adam_step_dev|adam_tick|adam_step|pack_conv_weights)'),
+    ('optimiser', r'hoig_(adam_step_dev|adam_tick|adam_step|adam_pack_step|pack_conv_weights)'),
     ('pointwise', r'hoig_(add|add_act|act_bwd|act_bwd_colsum|colsum_accum|copy_channels|cat2_channels|compose_fwd|compose_bwd|'
                   r'maxpool2_fwd|maxpool2_bwd|loss_accumulate|loss_fwd_bwd|tv_accumulate|tv_fwd_bwd|sum|sum_scaled)$'),
 ]
