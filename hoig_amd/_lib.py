@@ -116,6 +116,8 @@ _SIGS = {
     'hoig_adam_step': [_vp, _vp, _vp, _vp, _i64, _d, _d, _d, _d, _i, _f, _vp],
     'hoig_adam_tick': [_vp, _vp, _vp],
     'hoig_adam_step_dev': [_vp, _vp, _vp, _vp, _i64, _vp, _f, _vp],
+    'hoig_resize_linear_u8': [_vp, _i, _i, _i, _i, _vp, _i, _i, _vp],
+    'hoig_warp_affine_u8': [_vp, _i, _i, _i, _i, _vp, _i, _i, _i, _vp, _vp],
     'hoig_adam_pack_step': [_vp, _vp, _vp, _vp, _vp, _f, _vp, _i, _i64, _vp, _i64, _vp, _vp, _vp, _vp, _vp],
     'hoig_stream_create': [ctypes.POINTER(ctypes.c_void_p)],
     'hoig_stream_destroy': [_vp],

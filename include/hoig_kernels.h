@@ -406,6 +406,19 @@ size_t hoig_rasterize_workspace_bytes(int B, int F);
 int hoig_rasterize_fim_wim(const float *faces, int B, int F, int image_size, float near, float far, int32_t *fim,
                            float *wim, void *workspace, hoig_stream_t stream);
 
+/* ---- data loader, device side: the image work of HOv3Dataset._get_sample (HOIG_HOv3/data/hov3_dataset.py:215-223,
+ *      63-91) and of __getitem__'s transform (:208-212,267) for a batch of decoded 8-bit frames.  Both replace calls into
+ *      opencv-python 4.5.1.48 (requirements.txt:99) and follow its fixed-point algorithms integer for integer (hoig_amd/csrc/data_prep.hip).
+ * hoig_resize_linear_u8: cv2.resize(src, (Wd, Hd)) with the default INTER_LINEAR (:219): uint8 [B][Hs][Ws][C] -> [B][Hd][Wd][C], C <= 4.
+ * hoig_warp_affine_u8: cv2.warpAffine(src, M, (Wd, Hd), flags=cv2.INTER_LINEAR) (:78; BORDER_CONSTANT, value 0) with M the FORWARD
+ *   2x3 transform of each sample as the reference passes it (float32 values widened to double: M [B][6]); mode 0: dst uint8
+ *   [B][Hd][Wd][C]; mode 1 (C == 3): dst float [B][3][Hd][Wd], channel c = ((float(v[2-c]) / 255) - 0.5) / 0.5 -- astype(float32),
+ *   / 255.0, [:, :, ::-1], ToTensor, Normalize(0.5, 0.5) (:79,222,209,267); mode 2: dst float [B][1][Hd][Wd] = float(v[C-1]) / 128
+ *   (:223). ---- */
+int hoig_resize_linear_u8(const uint8_t *src, int B, int Hs, int Ws, int C, uint8_t *dst, int Hd, int Wd, hoig_stream_t stream);
+int hoig_warp_affine_u8(const uint8_t *src, int B, int Hs, int Ws, int C, const double *M, int Hd, int Wd, int mode, void *dst,
+                        hoig_stream_t stream);
+
 const char *hoig_version(void);
 
 /* Kernel-variant choices that are tuning, not semantics (every value computes the same result up to summation order): one table

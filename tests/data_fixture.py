@@ -1,0 +1,89 @@
+"""A synthetic HO3D-v3-shaped directory tree for the loader tests: frames, masks, per-frame annotations, the three
+parameter pickles and OBJ meshes, laid out as HOIG_HOv3/data/hov3_dataset.py:164-257 reads them.  PNG frames (lossless: the tests do
+not depend on a JPEG decoder)."""
+import os
+import pickle
+from types import SimpleNamespace
+
+import numpy as np
+
+OBJNAMES = ['003_cracker_box', '004_sugar_box', '006_mustard_bottle', '010_potted_meat_can', '011_banana', '021_bleach_cleanser',
+            '025_mug', '035_power_drill', '037_scissors']
+
+
+def build(root, seed=0, seqs=(('ABF1', 2), ('MC2', 5)), frames=4, frame_hw=(480, 640), mask_hw=(240, 320), n_obj_verts=None):
+    """-> opt namespace for HOv3Dataset / CustomDatasetDataLoader.  seqs: (sequence name, object id); videos are '<seq>_0'."""
+    from PIL import Image
+    g = np.random.Generator(np.random.Philox(key=[seed, 4]))
+    pics, params, objs = os.path.join(root, 'images'), os.path.join(root, 'params'), os.path.join(root, 'obj')
+    os.makedirs(params, exist_ok=True)
+    bbx, vids = {}, {}
+    for seq, obj_id in seqs:
+        for sub in ('rgb', 'mask', 'meta'):
+            os.makedirs(os.path.join(pics, 'train', seq, sub), exist_ok=True)
+        vid = seq + '_0'
+        bbx[vid] = [float(v) for v in (g.uniform(60, 200), g.uniform(40, 120), g.uniform(180, 330), g.uniform(180, 330))]
+        vids[vid] = []
+        name = OBJNAMES[obj_id]
+        nv = (n_obj_verts or {}).get(obj_id, 50 + 7 * obj_id)
+        os.makedirs(os.path.join(objs, name), exist_ok=True)
+        with open(os.path.join(objs, name, name + '.obj'), 'w') as f:
+            f.write('# synthetic\nmtllib x.mtl\n')
+            for v in g.uniform(-0.08, 0.08, (nv, 3)):
+                f.write('v %.6f %.6f %.6f\n' % tuple(v))
+            f.write('vt 0.5 0.5\nvn 0 0 1\nf 1/1/1 2/1/1 3/1/1\n')
+        for k in range(frames):
+            fid = '%04d' % k
+            # smooth + noisy content so that interpolation is exercised everywhere
+            yy, xx = np.mgrid[0:frame_hw[0], 0:frame_hw[1]]
+            base = (np.stack([xx * 0.37 + yy * 0.11, yy * 0.41, (xx + yy) * 0.23], -1) + 40 * k) % 256
+            img = np.clip(base + g.integers(-20, 20, base.shape), 0, 255).astype(np.uint8)
+            Image.fromarray(img).save(os.path.join(pics, 'train', seq, 'rgb', fid + '.png'))
+            m = (g.uniform(size=mask_hw + (1,)) < 0.3) * np.array([0, 128, 255], np.uint8)        # R channel (cv2's last) = 0 / 255
+            blob = np.zeros(mask_hw + (3,), np.uint8)
+            blob[mask_hw[0] // 4:mask_hw[0] // 2, mask_hw[1] // 3:mask_hw[1] // 2] = (255, 0, 0)
+            Image.fromarray(np.maximum(m.astype(np.uint8), blob)).save(os.path.join(pics, 'train', seq, 'mask', '%05d.png' % k))
+            anno = {'objName': name, 'camMat': np.array([[600., 0, 128], [0, 600., 128], [0, 0, 1]]),
+                    'handPose': g.standard_normal(48) * 0.3, 'handBeta': g.standard_normal(10), 'handTrans': np.array([0.0, 0.0, -0.5]) + g.uniform(-0.05, 0.05, 3),
+                    'objRot': g.uniform(-1.5, 1.5, (3, 1)), 'objTrans': np.array([0.05, 0.0, -0.5]) + g.uniform(-0.02, 0.02, 3)}
+            with open(os.path.join(pics, 'train', seq, 'meta', fid + '.pkl'), 'wb') as f:
+                pickle.dump(anno, f)
+            vids[vid].append(fid + '.png')
+    with open(os.path.join(params, 'HOv3-CR_bbx.pkl'), 'wb') as f:
+        pickle.dump(bbx, f)
+    for n in ('HOv3-CR_train_new.pkl', 'HOv3-CR_test_new.pkl'):
+        with open(os.path.join(params, n), 'wb') as f:
+            pickle.dump(vids, f)
+    return SimpleNamespace(data_dir=root, params_dir='params', images_dir='images', pairs_dir=os.path.join(root, 'pairs.pkl'), obj_dir=objs,
+                           dataset_mode='hov3', batch_size=2, serial_batches=True, n_threads_train=0, n_threads_test=0, num_repeats=1)
+
+
+def write_pairs(opt, pairs):
+    with open(opt.pairs_dir, 'wb') as f:
+        pickle.dump(pairs, f)
+
+
+def oracle_batch(opt, names_a, names_b):
+    """The reference's collated batch for the named samples, by the CPU oracle (oracle/data_oracle.py) from the files on disk."""
+    from PIL import Image
+    from oracle import data_oracle as O
+
+    def view(names):
+        bbx = pickle.load(open(os.path.join(opt.data_dir, opt.params_dir, 'HOv3-CR_bbx.pkl'), 'rb'))
+        out = {k: [] for k in ('image', 'mask', 'cam', 'trans', 'pose', 'shape', 'handtrans', 'vertices_obj', 'objName')}
+        for name in names:
+            vid, fid = name.split('/')
+            seq = vid.split('_')[0]
+            base = os.path.join(opt.data_dir, opt.images_dir, 'train', seq)
+            bgr = lambda p: np.ascontiguousarray(np.asarray(Image.open(p).convert('RGB'))[:, :, ::-1])
+            image, mask, trans = O.sample_tensors(bgr(os.path.join(base, 'rgb', fid)),
+                                                  bgr(os.path.join(base, 'mask', '%05d.png' % int(fid.split('.')[0]))), bbx[vid])
+            anno = pickle.load(open(os.path.join(base, 'meta', fid.split('.')[0] + '.pkl'), 'rb'))
+            v = O.read_obj_vertices(open(os.path.join(opt.obj_dir, anno['objName'], anno['objName'] + '.obj')).read())
+            out['image'].append(image); out['mask'].append(mask); out['trans'].append(trans)
+            out['cam'].append(anno['camMat'].astype(np.float32)); out['pose'].append(anno['handPose'].astype(np.float32))
+            out['shape'].append(anno['handBeta'].astype(np.float32)); out['handtrans'].append(anno['handTrans'].astype(np.float32))
+            out['vertices_obj'].append(O.posed_object_vertices(v, anno['objRot'], anno['objTrans']))
+            out['objName'].append(OBJNAMES.index(anno['objName']))
+        return {k: np.stack(v) for k, v in out.items()}
+    return view(names_a), view(names_b)

@@ -1,0 +1,123 @@
+"""SURVEY 8f row 4, CPU side: the loader's oracle (oracle/data_oracle.py -- parity UNPINNED for the OpenCV primitives: opencv-python
+4.5.1.48 is not installed and the reference holds no vectors for its loader) against known answers that any correct restatement of
+cv2.warpAffine / cv2.resize / cv2.Rodrigues / cv2.getAffineTransform must reproduce, the package's host geometry against the oracle,
+and HOv3Dataset's host half on a synthetic directory tree."""
+import numpy as np
+import pytest
+import torch
+
+import data_fixture as FX
+from oracle import data_oracle as O
+
+
+def _img(h, w, c=3, seed=0):
+    return np.random.Generator(np.random.Philox(key=[seed, h * w])).integers(0, 256, (h, w, c)).astype(np.uint8)
+
+
+def test_warp_identity_and_integer_shift_copy_pixels():
+    a = _img(19, 23)
+    eye = np.array([[1, 0, 0], [0, 1, 0]], np.float32)
+    assert np.array_equal(O.warp_affine_linear_u8(a, eye, (23, 19)), a)
+    sh = O.warp_affine_linear_u8(a, np.array([[1, 0, 3], [0, 1, -2]], np.float32), (23, 19))        # dst(x, y) = src(x - 3, y + 2)
+    want = np.zeros_like(a)
+    want[:17, 3:] = a[2:, :20]
+    assert np.array_equal(sh, want)
+    # a larger canvas: everything outside the source is the constant border 0
+    big = O.warp_affine_linear_u8(a, np.array([[1, 0, 5], [0, 1, 4]], np.float32), (40, 30))
+    assert np.array_equal(big[4:23, 5:28], a) and big[:4].max() == 0 and big[:, :5].max() == 0 and big[23:].max() == 0
+
+
+def test_warp_half_pixel_blends_two_neighbours_with_round_half_up():
+    a = _img(6, 9, 1, seed=3)
+    out = O.warp_affine_linear_u8(a, np.array([[2, 0, 0], [0, 1, 0]], np.float32), (17, 6))           # dst(x) = src(x / 2)
+    assert np.array_equal(out[:, 0:17:2, 0], a[:, :, 0])
+    mid = (a[:, :-1, 0].astype(int) + a[:, 1:, 0] + 1) >> 1                                             # weights 1/2, 1/2: (a + b + 1) >> 1
+    assert np.array_equal(out[:, 1:16:2, 0], mid)
+    # a quarter-pixel shift: src x = dst x - 0.25 -> weights 1/4 on the left neighbour, 3/4 on the pixel itself
+    q = O.warp_affine_linear_u8(a, np.array([[1, 0, 0.25], [0, 1, 0]], np.float32), (9, 6))
+    want = (a[:, :-1, 0].astype(int) * 8 + a[:, 1:, 0].astype(int) * 24 + 16) >> 5
+    assert np.array_equal(q[:, 1:, 0], want)
+    assert np.array_equal(q[:, 0, 0], (a[:, 0, 0].astype(int) * 24 + 16) >> 5)                          # left neighbour = border 0
+
+
+def test_resize_known_answers():
+    a = _img(12, 16)
+    assert np.array_equal(O.resize_linear_u8(a, (16, 12)), a)
+    const = np.full((5, 7, 3), 201, np.uint8)
+    assert np.array_equal(O.resize_linear_u8(const, (14, 10)), np.full((10, 14, 3), 201, np.uint8))
+    # 2x along x only: out[2k] = (s[k-1] + 3 s[k] + 2) >> 2, out[2k+1] = (3 s[k] + s[k+1] + 2) >> 2 (edges replicate)
+    row = _img(1, 9, 1, seed=5)
+    up = O.resize_linear_u8(np.repeat(row, 3, axis=0), (18, 3))[1, :, 0].astype(int)
+    s = row[0, :, 0].astype(int)
+    sp = np.concatenate([s[:1], s, s[-1:]])
+    assert np.array_equal(up[0::2], (sp[:-2] + 3 * s + 2) >> 2) and np.array_equal(up[1::2], (3 * s + sp[2:] + 2) >> 2)
+    # against a float bilinear with the same sampling grid, everywhere within one grey level
+    b = _img(24, 32, 3, seed=7)
+    got = O.resize_linear_u8(b, (64, 48)).astype(float)
+    ys = np.clip((np.arange(48) + 0.5) * 0.5 - 0.5, 0, 23); xs = np.clip((np.arange(64) + 0.5) * 0.5 - 0.5, 0, 31)
+    y0, x0 = np.floor(ys).astype(int), np.floor(xs).astype(int)
+    y1, x1 = np.minimum(y0 + 1, 23), np.minimum(x0 + 1, 31)
+    fy, fx = (ys - y0)[:, None, None], (xs - x0)[None, :, None]
+    bf = b.astype(float)
+    ref = (bf[y0][:, x0] * (1 - fx) + bf[y0][:, x1] * fx) * (1 - fy) + (bf[y1][:, x0] * (1 - fx) + bf[y1][:, x1] * fx) * fy
+    assert np.abs(got - ref).max() <= 1.0
+
+
+def test_rodrigues_and_affine_known_answers():
+    r = O.rodrigues(np.array([0, 0, np.pi / 2]))
+    assert np.allclose(r, [[0, -1, 0], [1, 0, 0], [0, 0, 1]], atol=1e-15)
+    assert np.array_equal(O.rodrigues(np.zeros((3, 1))), np.eye(3))
+    g = np.random.Generator(np.random.Philox(key=[1, 2]))
+    for _ in range(20):
+        v = g.uniform(-2, 2, 3)
+        R = O.rodrigues(v)
+        assert np.allclose(R @ R.T, np.eye(3), atol=1e-14) and abs(np.linalg.det(R) - 1) < 1e-14
+        assert np.allclose(R @ v, v, atol=1e-14)                                   # the axis is fixed
+        assert O.rodrigues(v.astype(np.float32)).dtype == np.float32
+    src = np.float32([[10, 20], [10, 70], [90, 20]]); dst = np.float32([[128, 128], [128, 256], [256, 128]])
+    m = O.get_affine_transform(src, dst)
+    assert np.allclose(m, [[1.6, 0, 112], [0, 2.56, 76.8]], atol=1e-12)
+    for p, q in zip(src, dst):
+        assert np.allclose(m @ [p[0], p[1], 1], q, atol=1e-10)
+    verts = O.read_obj_vertices('# c\nv 1 2 3\nvn 0 0 1\nv -0.5 1e-3 7 0.1\nf 1 2 1\n\nvt 0 0\n')
+    assert verts.dtype == np.float64 and np.array_equal(verts, [[1, 2, 3], [-0.5, 1e-3, 7]])
+
+
+def test_host_geometry_matches_the_oracle():
+    from hoig_amd.data import geometry as G
+    g = np.random.Generator(np.random.Philox(key=[3, 4]))
+    for _ in range(200):
+        bbox = [g.uniform(0, 400), g.uniform(0, 300), g.uniform(50, 400), g.uniform(50, 400)]
+        assert np.array_equal(G.patch_transform(bbox), O.patch_transform(bbox))
+        v = g.uniform(-3, 3, (3, 1))
+        assert np.array_equal(G.rodrigues(v), O.rodrigues(v)) and np.array_equal(G.rodrigues(v.astype(np.float32)), O.rodrigues(v.astype(np.float32)))
+
+
+def test_dataset_host_half_on_a_synthetic_tree(tmp_path):
+    from hoig_amd.data import DatasetFactory
+    from hoig_amd.data.device_stage import collate_raw
+    opt = FX.build(str(tmp_path), seed=2)
+    ds = DatasetFactory.get_by_name('hov3', opt, True)
+    assert ds.name == 'HOv3Dataset' and len(ds) == 2
+    np.random.seed(0)
+    rec = ds[1]
+    a, b = rec['A'], rec['B']
+    assert a['name'].startswith('MC2_0/') and b['name'].startswith('MC2_0/') and a['name'] != b['name']      # two frames of one video
+    assert a['frame'].shape == (480, 640, 3) and a['frame'].dtype == torch.uint8 and a['mask'].shape == (240, 320, 3)
+    assert a['objName'] == 5 and a['pose'].dtype == torch.float32 and a['obj_rot'].dtype == torch.float64
+    FX.write_pairs(opt, [('ABF1_0/0001.png', 'MC2_0/0003.png'), ('MC2_0/0000.png', 'ABF1_0/0002.png'), ('ABF1_0/0000.png', 'ABF1_0/0003.png')])
+    ds = DatasetFactory.get_by_name('hov3', opt, True)
+    assert len(ds) == 3 and ds[0]['A']['name'] == 'ABF1_0/0001.png' and ds[0]['B']['name'] == 'MC2_0/0003.png' and ds[4]['A']['name'] == 'MC2_0/0000.png'
+    raw = collate_raw([ds[0], ds[1]])
+    assert raw['A']['frame'].shape == (2, 480, 640, 3) and raw['B']['objName'] == [5, 2] and raw['A']['bbox'].shape == (2, 4)
+    # the decoded frame is what is on disk, in cv2.imread's channel order
+    from PIL import Image
+    disk = np.asarray(Image.open(str(tmp_path / 'images/train/ABF1/rgb/0001.png')))
+    assert np.array_equal(raw['A']['frame'][0].numpy(), disk[:, :, ::-1])
+    # and the oracle makes a plausible sample of it
+    (va, vb) = FX.oracle_batch(opt, ['ABF1_0/0001.png'], ['MC2_0/0003.png'])
+    assert va['image'].shape == (1, 3, 256, 256) and -1.0 <= va['image'].min() and va['image'].max() <= 1.0
+    assert set(np.unique(va['mask'])) <= set((np.arange(256) / 128.0).astype(np.float32)) and va['mask'].max() > 1.9
+    assert np.count_nonzero(vb['vertices_obj'][0].any(axis=1)) == 50 + 7 * 5
+    with pytest.raises(ValueError):
+        DatasetFactory.get_by_name('nope', opt, True)
