@@ -77,6 +77,9 @@ class DatasetFactory(object):
         if dataset_name == 'hov3':
             from .hov3_dataset import HOv3Dataset
             dataset = HOv3Dataset(opt, is_for_train)
+        elif dataset_name == 'ycb':                                         # the HOIG_DexYCB copy's factory (its data/__init__.py:45-47)
+            from .ycb_dataset import YCBDataset
+            dataset = YCBDataset(opt, is_for_train)
         else:
             raise ValueError("Dataset [%s] not recognized." % dataset_name)
         print('Dataset {} was created'.format(dataset.name))

@@ -7,13 +7,11 @@ Per batch and view: one H2D copy of the frames and one of the masks, ``hoig_resi
 vertices (:246-248) from meshes that were parsed once and live on the device.  Everything is issued on a side stream, one batch ahead
 of the training step (``submit`` / ``finish``)."""
 import ctypes
-import os
 
 import numpy as np
 import torch
 
 from . import geometry as G
-from .hov3_dataset import MAX_OBJ_VERTS, OBJNAMES
 
 PATCH = 256
 MASK_SIZE = (640, 480)              # cv2.resize(mask, (640, 480)): (width, height)
@@ -34,35 +32,36 @@ def collate_raw(items):
 
 
 class MeshCache(object):
-    """object id -> (n, 3) float64 vertices on the device, read from ``<obj_dir>/<name>/<name>.obj`` on first use."""
+    """object id -> (n, 3) float64 vertices on the device, read from the dataset's mesh file of that object on first use."""
 
-    def __init__(self, obj_dir, device):
-        self._dir, self._device, self._verts = obj_dir, device, {}
+    def __init__(self, dataset, device):
+        self._dataset, self._device, self._verts = dataset, device, {}
 
     def get(self, obj_id):
         v = self._verts.get(obj_id)
         if v is None:
-            name = OBJNAMES[obj_id]
-            v = torch.from_numpy(G.read_obj_vertices(os.path.join(self._dir, name, name + '.obj'))).to(self._device)
-            if v.shape[0] > MAX_OBJ_VERTS:
-                raise ValueError('%s: %d vertices, the batch tensor holds %d (hov3_dataset.py:246)' % (name, v.shape[0], MAX_OBJ_VERTS))
+            path = self._dataset.mesh_path(obj_id)
+            v = torch.from_numpy(G.read_obj_vertices(path)).to(self._device)
+            if v.shape[0] > self._dataset.max_obj_verts:
+                raise ValueError('%s: %d vertices, the batch tensor holds %d' % (path, v.shape[0], self._dataset.max_obj_verts))
             self._verts[obj_id] = v
         return v
 
 
 class DeviceStage(object):
-    def __init__(self, dataset=None, device=None, obj_dir=None):
+    def __init__(self, dataset, device=None):
         from .. import _lib as L
         self._L = L
         self.device = torch.device('cuda', torch.cuda.current_device()) if device is None else torch.device(device)
-        self._meshes = MeshCache(obj_dir if obj_dir is not None else getattr(dataset, 'obj_dir', os.path.join('assets', 'obj')), self.device)
+        self._meshes = MeshCache(dataset, self.device)
+        self._max_verts = dataset.max_obj_verts
         self._stream = None
 
     # ---- one view (A or B) of a batch
     def _images(self, col):
         L, dev = self._L, self.device
-        frames, masks = col['frame'], col['mask']
-        if not torch.is_tensor(frames) or not torch.is_tensor(masks):
+        frames, masks = col['frame'], col.get('mask')
+        if not torch.is_tensor(frames) or not (masks is None or torch.is_tensor(masks)):
             raise ValueError('the frames (and the masks) of a batch must have one size')
         B, Hs, Ws, _ = frames.shape
         st = torch.cuda.current_stream().cuda_stream
@@ -70,9 +69,11 @@ class DeviceStage(object):
         trans = np.stack([G.patch_transform(b) for b in col['bbox'].numpy()])                   # (B, 2, 3) float32, host
         m_dev = torch.from_numpy(trans.astype(np.float64).reshape(B, 6)).to(dev, non_blocking=True)
         f_dev = frames.to(dev, non_blocking=True)
-        k_dev = masks.to(dev, non_blocking=True)
         image = torch.empty((B, 3, PATCH, PATCH), dtype=torch.float32, device=dev)
         L.call('hoig_warp_affine_u8', p(f_dev), B, Hs, Ws, 3, p(m_dev), PATCH, PATCH, 1, p(image), st)
+        if masks is None:                                                   # (the DexYCB copy has no arm mask)
+            return image, None, torch.from_numpy(trans)
+        k_dev = masks.to(dev, non_blocking=True)
         big = torch.empty((B, MASK_SIZE[1], MASK_SIZE[0], 3), dtype=torch.uint8, device=dev)
         L.call('hoig_resize_linear_u8', p(k_dev), B, masks.shape[1], masks.shape[2], 3, p(big), MASK_SIZE[1], MASK_SIZE[0], st)
         mask = torch.empty((B, 1, PATCH, PATCH), dtype=torch.float32, device=dev)
@@ -80,14 +81,19 @@ class DeviceStage(object):
         return image, mask, torch.from_numpy(trans)
 
     def _object_vertices(self, col):
-        """:246-248: zeros((7866, 3), float32); [:n] = v @ Rodrigues(objRot).T + objTrans -- float64 on the device, rounded on assignment."""
+        """hov3_dataset.py:246-248: zeros((7866, 3), float32); [:n] = v @ Rodrigues(objRot).T + objTrans; ycb_dataset.py:165-169,292-293:
+        zeros((8000, 3)); [:n] = (pose_obj @ [v | 1].T)[:3].T -- float64 on the device, rounded to float32 on assignment."""
         dev = self.device
         ids = [int(k) for k in col['objName']]
-        rot, f32 = col['obj_rot'].numpy(), col['rot_is_f32']
-        R = np.stack([G.rodrigues(r.astype(np.float32) if f else r).astype(np.float64) for r, f in zip(rot, f32)])
-        R_dev = torch.from_numpy(R).to(dev, non_blocking=True)
-        t_dev = col['obj_trans'].to(dev, non_blocking=True)
-        out = torch.zeros((len(ids), MAX_OBJ_VERTS, 3), dtype=torch.float32, device=dev)
+        if 'obj_pose' in col:
+            P = col['obj_pose'].to(dev, non_blocking=True)
+            R_dev, t_dev = P[:, :3, :3], P[:, :3, 3]
+        else:
+            rot, f32 = col['obj_rot'].numpy(), col['rot_is_f32']
+            R = np.stack([G.rodrigues(r.astype(np.float32) if f else r).astype(np.float64) for r, f in zip(rot, f32)])
+            R_dev = torch.from_numpy(R).to(dev, non_blocking=True)
+            t_dev = col['obj_trans'].to(dev, non_blocking=True)
+        out = torch.zeros((len(ids), self._max_verts, 3), dtype=torch.float32, device=dev)
         for k in sorted(set(ids)):
             rows = [i for i, o in enumerate(ids) if o == k]
             idx = torch.tensor(rows, device=dev)
@@ -100,9 +106,11 @@ class DeviceStage(object):
         image, mask, trans = self._images(col)
         dev = self.device
         mano = {'cam': col['cam'].to(dev, non_blocking=True), 'trans': trans.to(dev, non_blocking=True),
-                'pose': col['pose'].to(dev, non_blocking=True), 'shape': col['shape'].to(dev, non_blocking=True),
-                'handtrans': col['handtrans'].to(dev, non_blocking=True), 'vertices_obj': self._object_vertices(col),
-                'objName': torch.tensor([int(k) for k in col['objName']], dtype=torch.int64)}       # (stays on the host: hand_recovery.py)
+                'pose': col['pose'].to(dev, non_blocking=True), 'shape': col['shape'].to(dev, non_blocking=True)}
+        if 'handtrans' in col:
+            mano['handtrans'] = col['handtrans'].to(dev, non_blocking=True)
+        mano['vertices_obj'] = self._object_vertices(col)
+        mano['objName'] = torch.tensor([int(k) for k in col['objName']], dtype=torch.int64)          # (stays on the host: hand_recovery.py)
         return image, mask, mano, list(col['name'])
 
     # ---- a batch: issue on the side stream, hand over on the caller's
@@ -116,6 +124,8 @@ class DeviceStage(object):
             done.record()
         batch = {'imageA': a[0], 'maskA': a[1], 'manoA': a[2], 'nameA': a[3],
                  'imageB': b[0], 'maskB': b[1], 'manoB': b[2], 'nameB': b[3]}
+        if a[1] is None:                                                    # ycb_dataset.py:278-279: no mask keys
+            del batch['maskA'], batch['maskB']
         return batch, done, raw                                         # (raw: the pinned source stays alive until the copies ran)
 
     def finish(self, pending):

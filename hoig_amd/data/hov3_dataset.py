@@ -41,6 +41,12 @@ def imread_bgr(path):
 
 
 class HOv3Dataset(DatasetBase):
+    max_obj_verts = MAX_OBJ_VERTS
+    objnames = OBJNAMES
+
+    def mesh_path(self, obj_id):
+        return os.path.join(self.obj_dir, OBJNAMES[obj_id], OBJNAMES[obj_id] + '.obj')                  # :239
+
     def __init__(self, opt, is_for_train=True):
         super(HOv3Dataset, self).__init__(opt, is_for_train)
         self._name = 'HOv3Dataset'

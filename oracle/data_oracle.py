@@ -230,3 +230,30 @@ def sample_tensors(image_bgr, mask_bgr, bbox):
     t = np.ascontiguousarray(image_inv.transpose(2, 0, 1))                 # ToTensor on a float ndarray: HWC -> CHW, no scaling
     t = (t - np.float32(0.5)) / np.float32(0.5)                            # Normalize: sub_(mean).div_(std)
     return t.astype(np.float32), mask_inv.astype(np.float32), trans
+
+
+# ---- the HOIG_DexYCB copy (HOIG_DexYCB/data/ycb_dataset.py:132-174,281-305): no mask, corner-form boxes, the object posed by a 3x4 matrix
+YCB_MAX_OBJ_VERTS = 8000
+
+
+def ycb_sample_tensors(image_bgr, bbox_xyxy):
+    """:284-290, :274: -> image (3, 256, 256) float32 in [-1, 1] (RGB), trans (2, 3) float32."""
+    bbox = [bbox_xyxy[0], bbox_xyxy[1], bbox_xyxy[2] - bbox_xyxy[0], bbox_xyxy[3] - bbox_xyxy[1]]
+    trans = patch_transform(bbox)
+    image = warp_affine_linear_u8(image_bgr, trans, (256, 256)).astype(np.float32)
+    image_inv = (image / 255.0)[:, :, ::-1].copy()
+    t = np.ascontiguousarray(image_inv.transpose(2, 0, 1))
+    t = (t - np.float32(0.5)) / np.float32(0.5)
+    return t.astype(np.float32), trans
+
+
+def ycb_object_vertices(v, pose_y, grasp_id):
+    """:153-169, :292-293: the non-zero 3x4 poses of the label file get a fourth row, the grasped one (indexed AMONG THE NON-ZERO ones, as
+    the reference does) multiplies the homogeneous vertices in float64; rounded to float32 into 8000 rows."""
+    pose_obj_list = [np.vstack((pose_y[o], np.array([[0, 0, 0, 1]], dtype=np.float32))) for o in range(len(pose_y))
+                     if not np.all(pose_y[o] == 0.0)]
+    homo = np.concatenate([v, np.ones_like(v)[:, 2:]], axis=1)
+    now = np.matmul(pose_obj_list[grasp_id], homo.T)[:3].transpose(1, 0)
+    out = np.zeros((YCB_MAX_OBJ_VERTS, 3), dtype=np.float32)
+    out[:now.shape[0]] = now
+    return out

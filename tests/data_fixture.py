@@ -87,3 +87,77 @@ def oracle_batch(opt, names_a, names_b):
             out['objName'].append(OBJNAMES.index(anno['objName']))
         return {k: np.stack(v) for k, v in out.items()}
     return view(names_a), view(names_b)
+
+
+YCB_NAMES = ['002_master_chef_can', '003_cracker_box', '004_sugar_box', '005_tomato_soup_can', '006_mustard_bottle',
+             '007_tuna_fish_can', '008_pudding_box', '009_gelatin_box', '010_potted_meat_can', '011_banana',
+             '019_pitcher_base', '021_bleach_cleanser', '024_bowl', '025_mug', '035_power_drill', '036_wood_block',
+             '037_scissors', '040_large_marker', '051_large_clamp', '052_extra_large_clamp', '061_foam_brick']
+
+
+def build_ycb(root, seed=0, vids=(('20200709-subject-01/20200709_141754/836212060125', (3, 11, 16), 1),
+                                  ('20200813-subject-02/20200813_145612/932122062010', (7, 2), 0)), frames=3):
+    """A DexYCB-shaped tree for ycb_dataset.py:230-305.  vids: (video id, ycb class ids (1-based), ycb_grasp_ind).  The first video's label
+    files carry an all-zero pose BEFORE the grasped object's, so that the reference's index-among-non-zero-poses quirk shows."""
+    from PIL import Image
+    g = np.random.Generator(np.random.Philox(key=[seed, 9]))
+    params = os.path.join(root, 'params')
+    os.makedirs(params, exist_ok=True)
+    bbx, info, lists = {}, {}, {}
+    for vi, (vid, ycb_ids, grasp) in enumerate(vids):
+        os.makedirs(os.path.join(root, 'images', vid), exist_ok=True)
+        x0, y0 = g.uniform(80, 200), g.uniform(40, 140)
+        bbx[vid] = [x0, y0, x0 + g.uniform(180, 300), y0 + g.uniform(180, 300)]
+        info[vid] = {'intrinsics': {'fx': 615.0 + vi, 'fy': 614.5, 'ppx': 312.25, 'ppy': 241.5}, 'ycb_grasp_ind': grasp,
+                     'ycb_ids': list(ycb_ids), 'mano_betas': [float(v) for v in g.standard_normal(10)]}
+        lists[vid] = list(range(frames))
+        for cid in ycb_ids:
+            name = YCB_NAMES[cid - 1]
+            os.makedirs(os.path.join(root, 'models', name), exist_ok=True)
+            with open(os.path.join(root, 'models', name, 'textured_pre.obj'), 'w') as f:
+                for v in g.uniform(-0.1, 0.1, (40 + 3 * cid, 3)):
+                    f.write('v %.6f %.6f %.6f\n' % tuple(v))
+                f.write('f 1 2 3\n')
+        for k in range(frames):
+            yy, xx = np.mgrid[0:480, 0:640]
+            img = (np.stack([xx * 0.3 + 20 * k, yy * 0.5, (xx + 2 * yy) * 0.2], -1) % 256).astype(np.uint8)
+            Image.fromarray(img).save(os.path.join(root, 'images', vid, 'color_%06d.jpg' % k), quality=92)
+            pose_y = np.zeros((len(ycb_ids), 3, 4), np.float32)
+            for o in range(len(ycb_ids)):
+                if vi == 0 and o == 0:
+                    continue                                    # an object without a pose in front of the grasped one
+                a = g.uniform(-1, 1, 3)
+                th = np.linalg.norm(a)
+                K = np.array([[0, -a[2], a[1]], [a[2], 0, -a[0]], [-a[1], a[0], 0]]) / th
+                pose_y[o, :, :3] = np.eye(3) + np.sin(th) * K + (1 - np.cos(th)) * K @ K
+                pose_y[o, :, 3] = g.uniform(-0.3, 0.3, 3) + (0, 0, 0.8)
+            pose_m = g.standard_normal((1, 51)).astype(np.float32) * 0.3
+            np.savez(os.path.join(root, 'images', vid, 'labels_%06d.npz' % k), pose_y=pose_y, pose_m=pose_m)
+    for n, obj in (('DexYCB-bbx.pkl', bbx), ('valid_video_info.pkl', info), ('DexYCB_train.pkl', lists), ('DexYCB_test.pkl', lists)):
+        with open(os.path.join(params, n), 'wb') as f:
+            pickle.dump(obj, f)
+    return SimpleNamespace(data_dir=root, params_dir='params', images_dir='images', pairs_dir=os.path.join(root, 'pairs.pkl'),
+                           dataset_mode='ycb', batch_size=2, serial_batches=True, n_threads_train=0, n_threads_test=0, num_repeats=1)
+
+
+def oracle_batch_ycb(opt, names):
+    """The DexYCB copy's collated view for the named samples ('<video id>/<frame>'), by the CPU oracle."""
+    from PIL import Image
+    from oracle import data_oracle as O
+    par = lambda n: pickle.load(open(os.path.join(opt.data_dir, opt.params_dir, n), 'rb'))
+    bbx, info = par('DexYCB-bbx.pkl'), par('valid_video_info.pkl')
+    out = {k: [] for k in ('image', 'cam', 'trans', 'pose', 'shape', 'vertices_obj', 'objName')}
+    for name in names:
+        vid, fid = name.rsplit('/', 1)
+        bgr = np.ascontiguousarray(np.asarray(Image.open(os.path.join(opt.data_dir, opt.images_dir, vid, 'color_%06d.jpg' % int(fid))).convert('RGB'))[:, :, ::-1])
+        image, trans = O.ycb_sample_tensors(bgr, bbx[vid])
+        s = info[vid]
+        label = np.load(os.path.join(opt.data_dir, 'images', vid, 'labels_%06d.npz' % int(fid)))
+        gname = YCB_NAMES[s['ycb_ids'][s['ycb_grasp_ind']] - 1]
+        v = O.read_obj_vertices(open(os.path.join(opt.data_dir, 'models', gname, 'textured_pre.obj')).read())
+        out['image'].append(image); out['trans'].append(trans)
+        out['cam'].append(np.array([s['intrinsics'][k] for k in ('fx', 'fy', 'ppx', 'ppy')], np.float32))
+        out['pose'].append(label['pose_m'][0].astype(np.float32)); out['shape'].append(np.array(s['mano_betas'], np.float32))
+        out['vertices_obj'].append(O.ycb_object_vertices(v, label['pose_y'], s['ycb_grasp_ind']))
+        out['objName'].append(YCB_NAMES.index(gname))
+    return {k: np.stack(v) for k, v in out.items()}

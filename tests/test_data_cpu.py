@@ -121,3 +121,32 @@ def test_dataset_host_half_on_a_synthetic_tree(tmp_path):
     assert np.count_nonzero(vb['vertices_obj'][0].any(axis=1)) == 50 + 7 * 5
     with pytest.raises(ValueError):
         DatasetFactory.get_by_name('nope', opt, True)
+
+
+def test_ycb_dataset_host_half_on_a_synthetic_tree(tmp_path):
+    """The HOIG_DexYCB copy's loader (ycb_dataset.py:230-305): corner-form boxes, label files, the grasped object's pose indexed among
+    the non-zero poses."""
+    from hoig_amd.data import DatasetFactory
+    from hoig_amd.data.device_stage import collate_raw
+    opt = FX.build_ycb(str(tmp_path), seed=3)
+    ds = DatasetFactory.get_by_name('ycb', opt, True)
+    assert ds.name == 'YCBDataset' and len(ds) == 2
+    v0, v1 = '20200709-subject-01/20200709_141754/836212060125', '20200813-subject-02/20200813_145612/932122062010'
+    FX.write_pairs(opt, [(v0 + '/1', v1 + '/2'), (v1 + '/0', v0 + '/2')])
+    ds = DatasetFactory.get_by_name('ycb', opt, True)
+    rec = ds[0]
+    a, b = rec['A'], rec['B']
+    assert a['name'] == v0 + '/1' and b['name'] == v1 + '/2' and 'mask' not in a
+    assert a['frame'].shape == (480, 640, 3) and a['cam'].shape == (4,) and a['pose'].shape == (51,) and a['shape'].shape == (10,)
+    assert a['objName'] == FX.YCB_NAMES.index('019_pitcher_base') and b['objName'] == FX.YCB_NAMES.index('008_pudding_box')
+    import pickle, os
+    bb = pickle.load(open(os.path.join(str(tmp_path), 'params', 'DexYCB-bbx.pkl'), 'rb'))[v0]
+    assert np.allclose(a['bbox'].numpy(), [bb[0], bb[1], bb[2] - bb[0], bb[3] - bb[1]])
+    # video 0: ycb_grasp_ind = 1, but the pose in front of it is all zero -> the reference's list of non-zero poses is indexed with 1,
+    # i.e. it takes the THIRD object's pose (ycb_dataset.py:155-168)
+    label = np.load(os.path.join(str(tmp_path), 'images', v0, 'labels_000001.npz'))
+    assert np.array_equal(a['obj_pose'][:3].numpy(), label['pose_y'][2].astype(np.float64)) and a['obj_pose'][3].tolist() == [0, 0, 0, 1]
+    raw = collate_raw([ds[0], ds[1]])
+    assert raw['A']['frame'].shape == (2, 480, 640, 3) and raw['A']['obj_pose'].shape == (2, 4, 4)
+    want = FX.oracle_batch_ycb(opt, [v0 + '/1'])
+    assert want['image'].shape == (1, 3, 256, 256) and np.count_nonzero(want['vertices_obj'][0].any(axis=1)) == 40 + 3 * 11

@@ -97,6 +97,32 @@ def test_loader_batches_match_the_oracle(tmp_path):
                 assert np.array_equal(v.any(axis=2), want['vertices_obj'].any(axis=2))
 
 
+def test_ycb_loader_batches_match_the_oracle(tmp_path):
+    from hoig_amd.data import CustomDatasetDataLoader
+    opt = FX.build_ycb(str(tmp_path), seed=6)
+    v0, v1 = '20200709-subject-01/20200709_141754/836212060125', '20200813-subject-02/20200813_145612/932122062010'
+    pairs = [(v0 + '/1', v1 + '/2'), (v1 + '/0', v0 + '/2'), (v0 + '/0', v0 + '/1')]
+    FX.write_pairs(opt, pairs)
+    loader = CustomDatasetDataLoader(opt, is_for_train=True)
+    at = 0
+    for b in loader.load_data():
+        n = len(b['nameA'])
+        assert 'maskA' not in b and 'handtrans' not in b['manoA']
+        for side, col in (('A', 0), ('B', 1)):
+            want = FX.oracle_batch_ycb(opt, [p[col] for p in pairs[at:at + n]])
+            assert b['name' + side] == [p[col] for p in pairs[at:at + n]]
+            assert np.array_equal(b['image' + side].cpu().numpy(), want['image'])
+            mano = b['mano' + side]
+            for k in ('cam', 'trans', 'pose', 'shape'):
+                assert np.array_equal(mano[k].cpu().numpy(), want[k]), k
+            assert mano['objName'].tolist() == want['objName'].tolist()
+            v = mano['vertices_obj'].cpu().numpy()
+            assert v.shape == (n, 8000, 3) and np.abs(v - want['vertices_obj']).max() <= 1e-7 and (v != want['vertices_obj']).mean() < 1e-3
+            assert np.array_equal(v.any(axis=2), want['vertices_obj'].any(axis=2))
+        at += n
+    assert at == 3
+
+
 def test_trainer_takes_the_loaders_batch(tmp_path):
     """train_ddp.py:88-92: for batch in loader: model.set_input(batch); model.optimize_parameters() -- with the synthetic MANO model and
     renderer tables of tests/test_hand_recovery_gpu.py standing in for the unshipped assets."""
