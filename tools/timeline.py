@@ -1,13 +1,13 @@
 """Concurrency timeline of ONE training step from a rocprofv3 --kernel-trace CSV: how many kernels are in flight over the step,
 where the chip runs a single kernel (or nothing), and which kernels those are.
     python tools/timeline.py <kernel_trace.csv> [bucket_us=1000]
-The step = the window between the last two launches of D's Adam (adam_dev_kernel / adam_kernel: two per step, G then D)."""
+The step = the window between the last two launches of D's Adam (adam_pack_kernel / adam_dev_kernel / adam_kernel: two per step, G then D)."""
 import csv, sys, collections, re
 rows = list(csv.DictReader(open(sys.argv[1])))
 bucket = int(sys.argv[2]) * 1000 if len(sys.argv) > 2 else 1000000
 ks = sorted(((int(r['Start_Timestamp']), int(r['End_Timestamp']), r['Kernel_Name'], r.get('Queue_Id', ''), int(r.get('Grid_Size', 0) or 0),
               int(r.get('Workgroup_Size', 1) or 1)) for r in rows), key=lambda t: t[0])
-adam = [i for i, k in enumerate(ks) if re.search(r'adam_(dev_)?kernel', k[2])]
+adam = [i for i, k in enumerate(ks) if re.search(r'adam_(dev_|pack_)?kernel', k[2])]
 lo, hi = adam[-3], adam[-1]            # D-adam of step n-1 .. D-adam of step n
 win = ks[lo + 1:hi + 1]
 t0, t1 = win[0][0], max(k[1] for k in win)
