@@ -552,6 +552,8 @@ class _ConvHeads(Function):
         B, H, W_, Ci = x.shape
         Co, _, R, S = w.shape
         assert sum(splits) == Co and len(splits) == len(acts)
+        if Co > 16:
+            raise ValueError('conv_heads: %d output channels, the per-channel activation codes hold 16' % Co)
         d = ConvDesc(B, H, W_, Ci, H, W_, Co, R, S, 1, R // 2, 0, L.ACT_NONE, 0.0, prec)
         codes, ch = 0, 0
         for n, a in zip(splits, acts):
