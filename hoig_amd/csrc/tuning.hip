@@ -19,6 +19,7 @@ Entry g_table[HOIG_TUNE_COUNT] = {
     {"wgrad_few", 1},
     {"head16", 1},
     {"adam_pack", 1},
+    {"d_early", 1},
 };
 }  // namespace
 

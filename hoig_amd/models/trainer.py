@@ -21,7 +21,7 @@ import numpy as np
 import torch
 import torch.distributed as dist
 
-from .. import ops
+from .. import _lib, ops
 from ..ddp import FlatDDP
 from ..nn import FusedAdam
 from .base_model import BaseModel
@@ -360,16 +360,23 @@ class Trainer(BaseModel):
 
     def _eager_step(self, trainable=True, keep_data_for_visuals=False):
         ops.test_step_begins()
-        fake_tsf_imgs, ev_fwd = self._phase_g(keep_data_for_visuals)
+        # The D step reads the fake image and D's weights only.  Issued BEFORE G's backward (tuning key 'd_early') its four
+        # milliseconds of kernels run beside the first, thin part of that backward (the loss chains' data gradients) instead of being
+        # issued -- and largely executed -- after it: the host spends ~20 ms inside loss_G.backward().
+        early = bool(trainable and generator_forks_streams() and _lib.set_tuning('d_early', -1))
+        fake_tsf_imgs, ev_fwd = self._phase_g(keep_data_for_visuals, d_early=early)
         self._step(self._G, self._optimizer_G, overlap=trainable)
         if trainable:
             _mark('d_phase_begin')
-            self._phase_d(fake_tsf_imgs, ev_fwd)
+            if early:
+                torch.cuda.current_stream().wait_stream(self._d_stream)
+            else:
+                self._phase_d(fake_tsf_imgs, ev_fwd)
             _mark('d_phase_end')
             self._wait_g()            # G's update has had the whole D step to finish; later readers need no special care
             self._step(self._D, self._optimizer_D, overlap=True)
 
-    def _phase_g(self, keep_data_for_visuals=False):
+    def _phase_g(self, keep_data_for_visuals=False, d_early=False):
         """Forward, the G loss and its backward (trainer.py:419-427).  Returns the fake target image and the event that marks the
         end of the forward (what the D step waits for)."""
         _, _, fake_src_imgs, fake_tsf_imgs, fake_masks_bg, fake_masks_hand = \
@@ -380,6 +387,11 @@ class Trainer(BaseModel):
         netD.set_requires_grad(False)       # the reference computes D grads here and zeroes them at :432
         loss_G = self._optimize_G(fake_src_imgs, fake_tsf_imgs, fake_masks_bg, fake_masks_hand)
         self._optimizer_G.zero_grad()
+        if d_early:
+            # (G's graph above was recorded with D frozen: its backward still skips D's weight gradients, and D's own gradients
+            # below land in D's buffer, which that backward never touches; D's Adam stays behind G's backward and step)
+            netD.set_requires_grad(True)
+            self._phase_d(fake_tsf_imgs, ev_fwd, join=False)
         ops.pause_wgrad_side(generator_forks_streams())     # G's backward is several concurrent chains already
         loss_G.backward()
         ops.pause_wgrad_side(False)
@@ -399,7 +411,7 @@ class Trainer(BaseModel):
         for st in streams:
             main.wait_stream(st)
 
-    def _phase_d(self, fake_tsf_imgs, ev_fwd=None):
+    def _phase_d(self, fake_tsf_imgs, ev_fwd=None, join=True):
         """The D loss and its backward (trainer.py:429-433).  It reads the fake image and D's weights, nothing of G's backward:
         given the forward's event it runs on a stream of its own that only waits for the generator's forward, i.e. BESIDE G's
         backward chains.  D's Adam still follows G's backward through D: it is queued on the side stream behind G's step, which
@@ -413,7 +425,8 @@ class Trainer(BaseModel):
             with torch.cuda.stream(self._d_stream):
                 ops.test_delay('d')
                 self._d_backward(fake_tsf_imgs)
-            main.wait_stream(self._d_stream)
+            if join:
+                main.wait_stream(self._d_stream)
         else:
             self._d_backward(fake_tsf_imgs)
 

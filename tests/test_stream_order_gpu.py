@@ -131,9 +131,20 @@ def test_the_detector_sees_an_optimiser_that_does_not_wait(reference_128):
     def mutate(m):
         m._side.wait_stream = lambda stream: None
     # (at 128 x 128, batch 2 the step is host-bound: the device has long finished the backward when the host issues Adam, so the
-    # missing wait alone changes nothing -- the bg branch is delayed as in the tests above; its hardware-queue class is not the
-    # optimiser stream's, ops._QUEUE_OF_ROLE)
-    run = _run(128, 2, {'g_bg': DELAY}, mutate=mutate, steps=1)
+    # missing wait alone changes nothing -- the bg branch is delayed as in the tests above, four times as long: the first step of a
+    # trainer spends tens of milliseconds of host time in lazy initialisation.
+    # Whether the unordered Adam then really RUNS early is up to the hardware queues: streams that share one execute in order, the
+    # runtime binds a stream to its queue when the stream is first used, and a stalled branch stalls its queue mates -- measured
+    # (tools/diag_dearly.py, profiles/r04_d_early_ab.txt): with the D step issued after G's backward the mutated Adam reads a
+    # zero gradient for whole tensors of tsf_model; with the D step issued before it (tuning key d_early, the default) the same
+    # mutation is hidden in a cold process and visible in a warm one.  The control pins the order in which it is always visible:
+    # what it shows is that the CHECK sees a stale read, not that every missing wait produces one.)
+    from hoig_amd import _lib as L
+    prev = L.set_tuning('d_early', 0)
+    try:
+        run = _run(128, 2, {'g_bg': 4 * DELAY}, mutate=mutate, steps=1)
+    finally:
+        L.set_tuning('d_early', prev)
     (_, mg, _, net_g, _), (_, mgr, _, _, _) = run[0], reference_128[0]
     worst = _worst(net_g, mg, mgr)
     assert worst[0] > 0.5, worst          # (whole tensors missing: Adam read the buffer before their weight gradients ran)
