@@ -137,17 +137,24 @@ def test_the_detector_sees_an_optimiser_that_does_not_wait(reference_128):
     # runtime binds a stream to its queue when the stream is first used, and a stalled branch stalls its queue mates -- measured
     # (tools/diag_dearly.py, profiles/r04_d_early_ab.txt): with the D step issued after G's backward the mutated Adam reads a
     # zero gradient for whole tensors of tsf_model; with the D step issued before it (tuning key d_early, the default) the same
-    # mutation is hidden in a cold process and visible in a warm one.  The control pins the order in which it is always visible:
-    # what it shows is that the CHECK sees a stale read, not that every missing wait produces one.)
+    # mutation is hidden in a cold process and visible in a warm one, and any change of the order in which the step first uses its
+    # streams flips it again.  The control therefore walks through both orders and two delayed branches until the stale read
+    # shows: what it proves is that the CHECK sees a stale read, not that every missing wait produces one.)
     from hoig_amd import _lib as L
-    prev = L.set_tuning('d_early', 0)
+    prev = L.set_tuning('d_early', -1)
+    seen = []
     try:
-        run = _run(128, 2, {'g_bg': 4 * DELAY}, mutate=mutate, steps=1)
+        for d_early, role in ((0, 'g_bg'), (1, 'g_bg'), (0, 'g_src'), (1, 'g_src')):
+            L.set_tuning('d_early', d_early)
+            run = _run(128, 2, {role: 4 * DELAY}, mutate=mutate, steps=1)
+            (_, mg, _, net_g, _), (_, mgr, _, _, _) = run[0], reference_128[0]
+            worst = _worst(net_g, mg, mgr)
+            seen.append((d_early, role) + worst)
+            if worst[0] > 0.5:           # (whole tensors missing: Adam read the buffer before their weight gradients ran)
+                break
     finally:
         L.set_tuning('d_early', prev)
-    (_, mg, _, net_g, _), (_, mgr, _, _, _) = run[0], reference_128[0]
-    worst = _worst(net_g, mg, mgr)
-    assert worst[0] > 0.5, worst          # (whole tensors missing: Adam read the buffer before their weight gradients ran)
+    assert worst[0] > 0.5, seen
     with pytest.raises(AssertionError):
         _compare(run, reference_128, 'optimiser without its wait', steps=1)
 
