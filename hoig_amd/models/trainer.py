@@ -362,8 +362,9 @@ class Trainer(BaseModel):
         ops.test_step_begins()
         # The D step reads the fake image and D's weights only.  Issued BEFORE G's backward (tuning key 'd_early') its four
         # milliseconds of kernels run beside the first, thin part of that backward (the loss chains' data gradients) instead of being
-        # issued -- and largely executed -- after it: the host spends ~20 ms inside loss_G.backward().
-        early = bool(trainable and generator_forks_streams() and _lib.set_tuning('d_early', -1))
+        # issued -- and largely executed -- after it: the host spends ~20 ms inside loss_G.backward().  Not under a gradient exchange:
+        # there the D step is what G's all-reduce + Adam hide behind, and it stays after G's backward.
+        early = bool(trainable and generator_forks_streams() and not self._sync_active() and _lib.set_tuning('d_early', -1))
         fake_tsf_imgs, ev_fwd = self._phase_g(keep_data_for_visuals, d_early=early)
         self._step(self._G, self._optimizer_G, overlap=trainable)
         if trainable:

@@ -437,8 +437,9 @@ const char *hoig_version(void);
  *                columns (conv_head16.hip), three-term forward arithmetic only; 0: the exact-fp32 VALU kernel (conv_small.hip)
  *   "adam_pack" 1  (read by the host side, hoig_amd/nn.py) the optimiser step and the split of the updated weights into operand planes
  *                as one launch (hoig_adam_pack_step); 0: hoig_adam_step_dev, then hoig_pack_conv_weights_bf16_all before the next forward
- *   "d_early" 1  (read by the host side, hoig_amd/models/trainer.py) the D step is issued on its stream BEFORE G's backward instead of
- *                after it; 0: after (both orders compute the same step: D's weights change only in D's own update, which stays last)
+ *   "d_early" 1  (read by the host side, hoig_amd/models/trainer.py) without a gradient exchange the D step is issued on its stream BEFORE
+ *                G's backward instead of after it; 0: after (both orders compute the same step: D's weights change only in D's own
+ *                update, which stays last).  With an exchange (world > 1) it always follows G's backward: G's all-reduce hides behind it
  *   "wgrad16" 0  the stride-1 3x3 weight gradients on 16x16x32 (wgrad_halo16.hip): measured 5-20 % slower than 32x32x16
  * Process-wide, not synchronised: set before launching. */
 int hoig_set_tuning(const char *key, int value);
