@@ -19,6 +19,7 @@ import torch
 from . import input_prep as IP
 from . import raster
 from .mano import HandModelRecovery, ManoModel
+from .options import is_dexycb
 
 FAR_AWAY = -1.0e6        # padding faces: all three vertices at one point far left of the image -> the rasteriser's empty box
 
@@ -28,7 +29,7 @@ class HandRecoveryFlow(object):
         self._name = 'HandRecoveryFlow'
         self._opt = opt
         self.device = device if device is not None else torch.device('cuda', torch.cuda.current_device())
-        self._dexycb = 'dex' in str(getattr(opt, 'dataset_mode', 'hov3')).lower()
+        self._dexycb = is_dexycb(opt)
         mano = mano if mano is not None else getattr(opt, 'mano_model', None)
         objects = objects if objects is not None else getattr(opt, 'object_assets', None)
         if not isinstance(mano, ManoModel) and not mano or not objects:

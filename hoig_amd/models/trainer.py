@@ -22,6 +22,7 @@ import torch
 import torch.distributed as dist
 
 from .. import _lib, ops
+from ..options import is_dexycb
 from ..ddp import FlatDDP
 from ..nn import FusedAdam
 from .base_model import BaseModel
@@ -87,7 +88,7 @@ class Trainer(BaseModel):
         else:
             self.device = torch.device('cuda', torch.cuda.current_device())
         torch.cuda.set_device(self.device)
-        self._dexycb = 'dex' in str(getattr(opt, 'dataset_mode', 'hov3')).lower()
+        self._dexycb = is_dexycb(opt)
         self._world = dist.get_world_size() if (use_ddp and dist.is_initialized()) else 1
         # G's gradient exchange + Adam run on a side stream beside the D step; D's run there beside the next forward of G
         self._side = ops.new_stream(self.device, 'opt')

@@ -4,6 +4,13 @@ when no reference ``options/`` parser is around.  A real run passes the referenc
 import types
 
 
+def is_dexycb(opt):
+    """The HOIG_DexYCB copy's layouts (13 / 9 / 24 input channels, its MANO and camera conventions, its resume rules) are selected by the
+    copy's own option value -- ``--dataset_mode ycb`` (scripts/train_ycb_ddp.sh:7) -- or by 'dexycb'."""
+    m = str(getattr(opt, 'dataset_mode', 'hov3')).lower()
+    return 'dex' in m or 'ycb' in m
+
+
 def opt_namespace(**over):
     d = dict(gpu_ids='0', is_train=True, checkpoints_dir='/tmp/hoig_ckpt', name='t', map_name='uv_seg', cond_nc=2,
              local_rank=0, gen_name='generator_spade_attn', use_spade=True, repeat_num=6, norm_type='instance',

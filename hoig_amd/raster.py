@@ -33,8 +33,19 @@ def rasterize_fim_wim(faces, image_size=256, near=DEFAULT_NEAR, far=DEFAULT_FAR)
 
 def project(vertices, cam):
     """orthographic_proj_withz_idrot (nmr.py:109-140): OpenGL axis change, camera matrix, perspective divide, 2x3 crop
-    transform, pixel -> [-1,1]; z = the axis-changed depth.  vertices (B,V,3), cam (B,15)."""
+    transform, pixel -> [-1,1]; z = the axis-changed depth.  vertices (B,V,3), cam (B,15).
+    cam (B,10) = [fx, fy, cx, cy | 2x3 crop transform] is the HOIG_DexYCB copy's function of the same name (its utils/nmr.py:146-163
+    with cam2pixel :38-48): no axis change, x / (z + 1e-8) * f + c, the crop transform, pixel -> [-1,1]; z = the vertex's own depth."""
     bs = cam.shape[0]
+    if cam.shape[1] == 10:
+        f, c, trans = cam[:, 0:2], cam[:, 2:4], cam[:, 4:].reshape(bs, 2, 3)
+        # (the reference multiplies (B,V) by f[:, 0] of shape (B,): it only runs with B = 1, one call per sample, trainer.py:66 --
+        # the per-sample scalar is what the batched form below applies)
+        x = vertices[:, :, 0] / (vertices[:, :, 2] + 1e-8) * f[:, 0:1] + c[:, 0:1]
+        y = vertices[:, :, 1] / (vertices[:, :, 2] + 1e-8) * f[:, 1:2] + c[:, 1:2]
+        xy1 = torch.stack([x, y, torch.ones_like(x)], dim=1)
+        xy = torch.einsum('ijk,ikm->ijm', trans, xy1).permute(0, 2, 1)
+        return torch.cat((xy / 255.0 * 2 - 1, vertices[:, :, 2:3]), dim=2)
     cam_mat, trans = cam[:, 0:9].reshape(bs, 3, 3), cam[:, 9:].reshape(bs, 2, 3)
     change = torch.tensor([[1., 0., 0.], [0., -1., 0.], [0., 0., -1.]], dtype=torch.float32, device=vertices.device)
     pts = torch.einsum('ijk,mk->ijm', vertices, change)

@@ -96,7 +96,7 @@ YCB_NAMES = ['002_master_chef_can', '003_cracker_box', '004_sugar_box', '005_tom
 
 
 def build_ycb(root, seed=0, vids=(('20200709-subject-01/20200709_141754/836212060125', (3, 11, 16), 1),
-                                  ('20200813-subject-02/20200813_145612/932122062010', (7, 2), 0)), frames=3):
+                                  ('20200813-subject-02/20200813_145612/932122062010', (7, 2), 0)), frames=3, n_obj_verts=None):
     """A DexYCB-shaped tree for ycb_dataset.py:230-305.  vids: (video id, ycb class ids (1-based), ycb_grasp_ind).  The first video's label
     files carry an all-zero pose BEFORE the grasped object's, so that the reference's index-among-non-zero-poses quirk shows."""
     from PIL import Image
@@ -115,7 +115,7 @@ def build_ycb(root, seed=0, vids=(('20200709-subject-01/20200709_141754/83621206
             name = YCB_NAMES[cid - 1]
             os.makedirs(os.path.join(root, 'models', name), exist_ok=True)
             with open(os.path.join(root, 'models', name, 'textured_pre.obj'), 'w') as f:
-                for v in g.uniform(-0.1, 0.1, (40 + 3 * cid, 3)):
+                for v in g.uniform(-0.1, 0.1, ((n_obj_verts or {}).get(cid - 1, 40 + 3 * cid), 3)):
                     f.write('v %.6f %.6f %.6f\n' % tuple(v))
                 f.write('f 1 2 3\n')
         for k in range(frames):

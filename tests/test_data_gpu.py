@@ -153,3 +153,40 @@ def test_trainer_takes_the_loaders_batch(tmp_path):
         assert torch.equal(model._real_src, batch['imageA']) and torch.equal(model._armask_tsf, batch['maskB'])
     finally:
         ops.set_precision('f32')
+
+
+def test_dexycb_trainer_takes_the_ycb_loaders_batch(tmp_path):
+    """The HOIG_DexYCB copy end to end: --dataset_mode ycb (its scripts/train_ycb_ddp.sh:7) selects its loader, its MANO / camera
+    conventions and its channel layout; the loader's batch goes through Trainer.set_input and a step."""
+    from test_hand_recovery_gpu import _assets
+    from common import opt_namespace
+    from hoig_amd import ops
+    from hoig_amd.data import CustomDatasetDataLoader
+    from hoig_amd.mano import ManoModel
+    from hoig_amd.models import ModelsFactory
+    from oracle import mano_oracle as M
+    obj_ids = [10, 6]                                    # 019_pitcher_base, 008_pudding_box: the grasped objects of the fixture's two videos
+    assets, nv = _assets(obj_ids, 23)
+    opt_d = FX.build_ycb(str(tmp_path), seed=9, n_obj_verts=nv)
+    v0, v1 = '20200709-subject-01/20200709_141754/836212060125', '20200813-subject-02/20200813_145612/932122062010'
+    FX.write_pairs(opt_d, [(v0 + '/0', v0 + '/2'), (v1 + '/1', v1 + '/0')])
+    loader = CustomDatasetDataLoader(opt_d, is_for_train=True)
+    opt = opt_namespace(gen_name='generator_spade_attn', local_rank=0, image_size=256, dataset_mode='ycb')
+    opt.mano_model = ManoModel.from_dict(M.synthetic_model(4))
+    opt.object_assets = assets
+    ops.set_precision('bf16x3')
+    try:
+        torch.manual_seed(5)
+        model = ModelsFactory.get_by_name('trainer', opt, use_ddp=False)
+        assert model._dexycb
+        model.set_train()
+        n = 0
+        for batch in loader.load_data():
+            assert batch['manoA']['cam'].shape == (2, 4) and batch['manoA']['pose'].shape == (2, 51)
+            model.set_input(batch)
+            model.optimize_parameters()
+            n += 1
+        assert n == 1 and all(np.isfinite(v) for v in model.get_current_errors().values())
+        assert model._input_G_src_hand.shape[1] == 12 and torch.equal(model._real_tsf, batch['imageB'])
+    finally:
+        ops.set_precision('f32')

@@ -81,6 +81,15 @@ def test_vertex_stage_on_device_matches_reference_fixture():
     np.testing.assert_allclose(faces.cpu().numpy(), g['faces'], rtol=0, atol=2e-5)
 
 
+def test_vertex_stage_on_device_matches_reference_fixture_dexycb():
+    import os
+    from hoig_amd import raster
+    g = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), 'golden', 'raster_vertex_stage_dexycb.npz'))
+    faces = raster.project_to_faces(torch.from_numpy(g['cam']).cuda(), torch.from_numpy(g['vertices']).cuda(),
+                                    torch.from_numpy(g['faces_idx']).cuda())
+    np.testing.assert_allclose(faces.cpu().numpy(), g['faces'], rtol=0, atol=2e-5)
+
+
 def test_vertices_to_generator_inputs_end_to_end():
     """The whole HandRecoveryFlow.forward chain on the device -- render_fim_wim for the source and the reference pose, then
     the input preparation -- against the oracle chain (C rasteriser + torch restatement) on the same vertices."""

@@ -88,6 +88,17 @@ def test_vertex_stage_matches_reference_fixture():
     np.testing.assert_allclose(faces.numpy(), g['faces'], rtol=0, atol=1e-6)
 
 
+def test_vertex_stage_matches_reference_fixture_dexycb():
+    """The HOIG_DexYCB copy's projection (cam = [fx, fy, cx, cy | crop transform], its utils/nmr.py:38-48,146-163) against the fixture
+    made by that copy's own code, one sample at a time as it runs there (tests/golden/make_golden_raster_vertex.py dexycb)."""
+    import os
+    from hoig_amd import raster
+    g = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), 'golden', 'raster_vertex_stage_dexycb.npz'))
+    faces = raster.project_to_faces(torch.from_numpy(g['cam']), torch.from_numpy(g['vertices']), torch.from_numpy(g['faces_idx']))
+    np.testing.assert_allclose(faces.numpy(), g['faces'], rtol=0, atol=1e-6)
+    assert np.abs(g['faces'][..., :2]).max() < 1.5                 # (the fixture's geometry lands in and around the image)
+
+
 def test_wrapper_conventions_match_reference_python():
     """Build container only: the reference's OWN Python wrapper (neural_renderer/rasterize.py: fill, call sequence, vertical
     flips) run over the oracle's restatement of the two CUDA kernels gives exactly what oracle_rasterize_fim_wim returns."""
