@@ -55,9 +55,11 @@ class CustomDatasetDataLoader(object):
             self._dataloader = torch.utils.data.DataLoader(
                 self._dataset, batch_size=self._opt.batch_size, shuffle=not self._opt.serial_batches,
                 num_workers=int(self._num_threds), drop_last=False, collate_fn=collate_raw, pin_memory=pin)
-        self._stage = DeviceStage(self._dataset, device=self._device)
+        self._stage = None                      # (made by load_data(): the host half alone needs no GPU)
 
     def load_data(self):
+        if self._stage is None:
+            self._stage = DeviceStage(self._dataset, device=self._device)
         return _DeviceBatches(self._dataloader, self._stage)
 
     def load_raw_data(self):

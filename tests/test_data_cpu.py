@@ -150,3 +150,18 @@ def test_ycb_dataset_host_half_on_a_synthetic_tree(tmp_path):
     assert raw['A']['frame'].shape == (2, 480, 640, 3) and raw['A']['obj_pose'].shape == (2, 4, 4)
     want = FX.oracle_batch_ycb(opt, [v0 + '/1'])
     assert want['image'].shape == (1, 3, 256, 256) and np.count_nonzero(want['vertices_obj'][0].any(axis=1)) == 40 + 3 * 11
+
+
+def test_loader_host_half_runs_without_a_gpu(tmp_path):
+    """CustomDatasetDataLoader.load_raw_data(): worker processes decode and collate; nothing touches a device."""
+    from hoig_amd.data import CustomDatasetDataLoader
+    opt = FX.build(str(tmp_path), seed=4)
+    pairs = [('ABF1_0/0001.png', 'MC2_0/0003.png'), ('MC2_0/0000.png', 'ABF1_0/0002.png'), ('ABF1_0/0000.png', 'ABF1_0/0003.png')]
+    FX.write_pairs(opt, pairs)
+    opt.n_threads_train = 2
+    loader = CustomDatasetDataLoader(opt, is_for_train=True)
+    assert len(loader) == 3 and loader.load_sampler() is None
+    raws = list(loader.load_raw_data())
+    assert [r['A']['frame'].shape[0] for r in raws] == [2, 1]
+    assert [n for r in raws for n in r['A']['name']] == [p[0] for p in pairs]
+    assert raws[0]['A']['frame'].dtype == torch.uint8 and raws[0]['B']['mask'].shape == (2, 240, 320, 3)

@@ -23,6 +23,7 @@ with tempfile.TemporaryDirectory() as root:
     FX.write_pairs(opt, [('ABF1_0/%04d.png' % (k % 4), 'MC2_0/%04d.png' % ((k + 1) % 4)) for k in range(B)])
     loader = CustomDatasetDataLoader(opt, is_for_train=True)
     raw = next(iter(loader.load_raw_data()))
+    loader.load_data()
     stage = loader._stage
     for _ in range(3):
         stage(raw)
