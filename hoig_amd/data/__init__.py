@@ -35,27 +35,20 @@ class _DeviceBatches(object):
 
 
 class CustomDatasetDataLoader(object):
-    def __init__(self, opt, is_for_train=True, use_ddp=False, device=None):
-        self._opt = opt
-        self._is_for_train = is_for_train
-        self._num_threds = opt.n_threads_train if is_for_train else opt.n_threads_test
-        self._device = device
-        self._create_dataset(use_ddp=use_ddp)
+    """``CustomDatasetDataLoader(opt, is_for_train, use_ddp)`` as train_ddp.py:33-41 / eval.py construct it.  ``opt`` fields read:
+    ``dataset_mode``, ``batch_size``, ``serial_batches``, ``n_threads_train`` / ``n_threads_test`` (+ the dataset's own)."""
 
-    def _create_dataset(self, use_ddp=False):
-        self._dataset = DatasetFactory.get_by_name(self._opt.dataset_mode, self._opt, self._is_for_train)
-        pin = torch.cuda.is_available()
-        if use_ddp:                                                     # data/__init__.py:12-20
-            self._sampler = torch.utils.data.distributed.DistributedSampler(self._dataset)
-            self._dataloader = torch.utils.data.DataLoader(
-                self._dataset, batch_size=self._opt.batch_size, shuffle=False, num_workers=int(self._num_threds),
-                sampler=self._sampler, drop_last=True, collate_fn=collate_raw, pin_memory=pin)
-        else:                                                           # :21-29
-            self._sampler = None
-            self._dataloader = torch.utils.data.DataLoader(
-                self._dataset, batch_size=self._opt.batch_size, shuffle=not self._opt.serial_batches,
-                num_workers=int(self._num_threds), drop_last=False, collate_fn=collate_raw, pin_memory=pin)
-        self._stage = None                      # (made by load_data(): the host half alone needs no GPU)
+    def __init__(self, opt, is_for_train=True, use_ddp=False, device=None):
+        self._dataset = DatasetFactory.get_by_name(opt.dataset_mode, opt, is_for_train)
+        self._device, self._stage = device, None          # (the stage is made by load_data(): the host half alone needs no GPU)
+        # One rank of a data-parallel job sees its own shard in the sampler's order and drops the ragged last batch, so that every
+        # rank runs the same number of steps; a single process shuffles unless opt.serial_batches and keeps the short batch.
+        self._sampler = torch.utils.data.distributed.DistributedSampler(self._dataset) if use_ddp else None
+        self._dataloader = torch.utils.data.DataLoader(
+            self._dataset, batch_size=opt.batch_size, sampler=self._sampler, drop_last=bool(use_ddp),
+            shuffle=False if use_ddp else not opt.serial_batches,
+            num_workers=int(opt.n_threads_train if is_for_train else opt.n_threads_test),
+            collate_fn=collate_raw, pin_memory=torch.cuda.is_available())
 
     def load_data(self):
         if self._stage is None:
@@ -73,16 +66,25 @@ class CustomDatasetDataLoader(object):
         return len(self._dataset)
 
 
+def _hov3(opt, is_for_train):
+    from .hov3_dataset import HOv3Dataset
+    return HOv3Dataset(opt, is_for_train)
+
+
+def _ycb(opt, is_for_train):
+    from .ycb_dataset import YCBDataset
+    return YCBDataset(opt, is_for_train)
+
+
 class DatasetFactory(object):
+    # --dataset_mode of the HOIG_HOv3 copy / of the HOIG_DexYCB copy (each copy's data/__init__.py knows only its own)
+    _makers = {'hov3': _hov3, 'ycb': _ycb}
+
     @staticmethod
     def get_by_name(dataset_name, opt, is_for_train):
-        if dataset_name == 'hov3':
-            from .hov3_dataset import HOv3Dataset
-            dataset = HOv3Dataset(opt, is_for_train)
-        elif dataset_name == 'ycb':                                         # the HOIG_DexYCB copy's factory (its data/__init__.py:45-47)
-            from .ycb_dataset import YCBDataset
-            dataset = YCBDataset(opt, is_for_train)
-        else:
+        make = DatasetFactory._makers.get(dataset_name)
+        if make is None:
             raise ValueError("Dataset [%s] not recognized." % dataset_name)
+        dataset = make(opt, is_for_train)
         print('Dataset {} was created'.format(dataset.name))
         return dataset

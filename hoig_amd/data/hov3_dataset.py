@@ -1,107 +1,75 @@
-"""``HOv3Dataset`` (HOIG_HOv3/data/hov3_dataset.py:164-270): the same constructor arguments, directory layout, pair selection and
-length; ``__getitem__`` stops after the DECODE -- it returns the two samples' 8-bit frames and masks (as ``cv2.imread`` would: BGR,
-three channels) with their annotations, and ``hoig_amd.data.device_stage.DeviceStage`` turns a batch of them into the reference's
-batch dict on the device (resize + warp + scaling + normalisation, posed object vertices).  Workers never touch the GPU."""
+"""``HOv3Dataset``: the host half of the HO3D-v3 loader (the reference class is HOIG_HOv3/data/hov3_dataset.py:164-270: same
+constructor arguments, ``opt`` fields, directory layout, pair selection and length).  A worker DECODES and reads the annotation,
+nothing else: ``__getitem__`` returns, per view, the 8-bit frame and mask as ``cv2.imread`` delivers them (BGR, three channels), the
+sequence's bounding box and the annotation's MANO / object values; ``hoig_amd.data.device_stage.DeviceStage`` turns a batch of such
+records into the reference's batch dict on the device (mask resize, affine crop, scaling, normalisation, posed object vertices:
+:215-250).  Workers never touch the GPU."""
 import os
-import pickle
 
 import numpy as np
 import torch
 
-from .dataset_base import DatasetBase
+from .dataset_base import DatasetBase, PairIndex, read_pickle
 
 OBJNAMES = ['003_cracker_box', '004_sugar_box', '006_mustard_bottle', '010_potted_meat_can', '011_banana', '021_bleach_cleanser',
-            '025_mug', '035_power_drill', '037_scissors']                      # hov3_dataset.py:13
-MAX_OBJ_VERTS = 7866                                                           # :246
-
-
-def load_pickle_data(f_name):                                                  # :97-107
-    if not os.path.exists(f_name):
-        raise Exception('Unable to find annotations picle file at %s. Aborting.' % (f_name))
-    with open(f_name, 'rb') as f:
-        try:
-            return pickle.load(f, encoding='latin1')
-        except Exception:
-            return pickle.load(f)
-
-
-def read_annotation(base_dir, seq_name, file_id, split):                      # :109-113
-    meta_filename = os.path.join(base_dir, split, seq_name, 'meta', file_id + '.pkl')
-    assert os.path.exists(meta_filename), 'File does not exists: %s' % meta_filename
-    return load_pickle_data(meta_filename)
+            '025_mug', '035_power_drill', '037_scissors']                      # object id = position in this list (hov3_dataset.py:13)
+MAX_OBJ_VERTS = 7866                                                           # rows of the batch's vertices_obj tensor (:246)
 
 
 def imread_bgr(path):
-    """cv2.imread(path) (IMREAD_COLOR): (H, W, 3) uint8, BGR.  Decoded with Pillow (cv2 is not a dependency of this package): the same
-    libjpeg defaults (slow integer DCT, fancy upsampling) for JPEG, lossless PNG either way; grey / palette files become three channels."""
-    from PIL import Image
+    """What ``cv2.imread(path)`` (IMREAD_COLOR) returns: (H, W, 3) uint8 in BGR order.  Decoded with Pillow (cv2 is not a dependency of
+    this package).  Like OpenCV's decoders: the EXIF orientation is applied, 16-bit samples keep their high byte (libpng's strip-16),
+    alpha is dropped, grey and palette files become three channels.  JPEG goes through libjpeg in both libraries (integer DCT, fancy
+    upsampling); that the two builds decode a given file to the same bytes is NOT verified here (no cv2 in this image) --
+    ``tests/test_data_cpu.py::test_imread_matches_cv2_when_available`` compares them wherever cv2 can be imported."""
+    from PIL import Image, ImageOps
     with Image.open(path) as im:
+        im = ImageOps.exif_transpose(im)
+        if im.mode in ('I;16', 'I;16B', 'I;16L', 'I'):
+            grey = (np.asarray(im).astype(np.uint32) >> 8).clip(0, 255).astype(np.uint8)
+            return np.ascontiguousarray(np.repeat(grey[:, :, None], 3, axis=2))
         rgb = np.asarray(im.convert('RGB'))
     return np.ascontiguousarray(rgb[:, :, ::-1])
 
 
 class HOv3Dataset(DatasetBase):
+    _name = 'HOv3Dataset'
     max_obj_verts = MAX_OBJ_VERTS
     objnames = OBJNAMES
 
-    def mesh_path(self, obj_id):
-        return os.path.join(self.obj_dir, OBJNAMES[obj_id], OBJNAMES[obj_id] + '.obj')                  # :239
-
     def __init__(self, opt, is_for_train=True):
         super(HOv3Dataset, self).__init__(opt, is_for_train)
-        self._name = 'HOv3Dataset'
-        self.data_dir = opt.data_dir
-        self.param_dir = os.path.join(opt.data_dir, opt.params_dir)
-        self.pic_dir = os.path.join(opt.data_dir, opt.images_dir)
-        self.obj_dir = getattr(opt, 'obj_dir', os.path.join('assets', 'obj'))      # (the reference's path is relative to its cwd, :239)
-        self.data_split = 'train' if is_for_train else 'test'
-        self.pairs_dir = opt.pairs_dir
-        if not os.path.exists(self.param_dir):
-            raise ValueError("param_dir: %s not exist" % self.param_dir)
-        if not os.path.exists(self.pic_dir):
-            raise ValueError("pic_dir: %s not exist" % self.pic_dir)
-        with open(os.path.join(self.param_dir, 'HOv3-CR_bbx.pkl'), 'rb') as f:
-            self.bbx_params = pickle.load(f)
-        _vid_list_dir = os.path.join(self.param_dir, 'HOv3-CR_train_new.pkl' if is_for_train else 'HOv3-CR_test_new.pkl')
-        with open(_vid_list_dir, 'rb') as f:
-            self._vids_dict = pickle.load(f)
-        if self.pairs_dir and os.path.exists(self.pairs_dir):
-            with open(self.pairs_dir, "rb") as f:
-                self._pairs_list = pickle.load(f)
-        else:
-            self._pairs_list = None
-        self._vids_list = list(self._vids_dict)
-        self._num_videos = len(self._vids_list) if self._pairs_list is None else len(self._pairs_list)
+        params, self._pics = self._subdir('params_dir', 'param_dir'), self._subdir('images_dir', 'pic_dir')
+        # the reference opens 'assets/obj/<name>/<name>.obj' relative to its working directory (:239); opt.obj_dir overrides that
+        self._meshes = getattr(opt, 'obj_dir', os.path.join('assets', 'obj'))
+        self._bbox_of_video = read_pickle(os.path.join(params, 'HOv3-CR_bbx.pkl'), 'bounding boxes')
+        listing = 'HOv3-CR_%s_new.pkl' % ('train' if is_for_train else 'test')
+        self._index = PairIndex(read_pickle(os.path.join(params, listing), 'video list'), opt.pairs_dir)
 
-    def __getitem__(self, index):                                              # :198-213
-        if self._pairs_list is None:
-            vid_id = self._vids_list[index % self._num_videos]
-            frame_list = self._vids_dict[vid_id]
-            vid_a, vid_b = vid_id, vid_id
-            frame_a, frame_b = np.random.choice(frame_list, size=2, replace=False)
-        else:
-            path_a, path_b = self._pairs_list[index % self._num_videos]
-            vid_a, frame_a = path_a.split('/')
-            vid_b, frame_b = path_b.split('/')
-        return {'A': self._get_raw_sample(vid_a, frame_a), 'B': self._get_raw_sample(vid_b, frame_b)}
+    def mesh_path(self, obj_id):
+        return os.path.join(self._meshes, OBJNAMES[obj_id], OBJNAMES[obj_id] + '.obj')
 
-    def _get_raw_sample(self, vid_id, frame_id):                               # :215-257, up to and including the decode
-        seq = vid_id.split('_')[0]
-        split = 'train' if os.path.exists(os.path.join(self.pic_dir, 'train', seq, 'rgb', frame_id)) else 'test'
-        frame = imread_bgr(os.path.join(self.pic_dir, split, seq, 'rgb', frame_id))
-        mask = imread_bgr(os.path.join(self.pic_dir, split, seq, 'mask', '%05d.png' % int(frame_id.split('.')[0])))
-        anno = read_annotation(self.pic_dir, seq, frame_id.split('.')[0], split)
-        return {'frame': torch.from_numpy(frame), 'mask': torch.from_numpy(mask),
-                'bbox': torch.as_tensor(np.asarray(self.bbx_params[vid_id], dtype=np.float64)),
-                'cam': torch.from_numpy(np.asarray(anno['camMat']).astype(np.float32)),
-                'pose': torch.from_numpy(np.asarray(anno['handPose']).astype(np.float32)),
-                'shape': torch.from_numpy(np.asarray(anno['handBeta']).astype(np.float32)),
-                'handtrans': torch.from_numpy(np.asarray(anno['handTrans']).astype(np.float32)),
-                'obj_rot': torch.from_numpy(np.asarray(anno['objRot'], dtype=np.float64).reshape(3)),
-                'obj_trans': torch.from_numpy(np.asarray(anno['objTrans'], dtype=np.float64).reshape(3)),
-                'rot_is_f32': bool(np.asarray(anno['objRot']).dtype == np.float32),
-                'objName': OBJNAMES.index(anno['objName']),
-                'name': os.path.join(vid_id, frame_id)}
+    def _sequence_dir(self, seq, frame):
+        """A sequence lives under train/ or test/ whatever split the listing came from: the frame file decides (:216-219)."""
+        for split in ('train', 'test'):
+            if split == 'test' or os.path.exists(os.path.join(self._pics, split, seq, 'rgb', frame)):
+                return os.path.join(self._pics, split, seq)
 
-    def __len__(self):
-        return self._num_videos * self._opt.num_repeats
+    def _get_raw_sample(self, video, frame):
+        seq, stem = video.split('_')[0], frame.split('.')[0]
+        base = self._sequence_dir(seq, frame)
+        meta = os.path.join(base, 'meta', stem + '.pkl')
+        assert os.path.exists(meta), 'File does not exists: %s' % meta
+        anno = read_pickle(meta, 'annotation')
+        f32 = lambda key: torch.from_numpy(np.asarray(anno[key]).astype(np.float32))
+        f64 = lambda key: torch.from_numpy(np.asarray(anno[key], dtype=np.float64).reshape(3))
+        return {
+            'frame': torch.from_numpy(imread_bgr(os.path.join(base, 'rgb', frame))),
+            'mask': torch.from_numpy(imread_bgr(os.path.join(base, 'mask', '%05d.png' % int(stem)))),
+            'bbox': torch.as_tensor(np.asarray(self._bbox_of_video[video], dtype=np.float64)),
+            'cam': f32('camMat'), 'pose': f32('handPose'), 'shape': f32('handBeta'), 'handtrans': f32('handTrans'),
+            # cv2.Rodrigues answers in its argument's precision: the device stage needs to know which one the file holds (:247)
+            'obj_rot': f64('objRot'), 'obj_trans': f64('objTrans'), 'rot_is_f32': bool(np.asarray(anno['objRot']).dtype == np.float32),
+            'objName': OBJNAMES.index(anno['objName']),
+            'name': os.path.join(video, frame),
+        }

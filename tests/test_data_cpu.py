@@ -165,3 +165,97 @@ def test_loader_host_half_runs_without_a_gpu(tmp_path):
     assert [r['A']['frame'].shape[0] for r in raws] == [2, 1]
     assert [n for r in raws for n in r['A']['name']] == [p[0] for p in pairs]
     assert raws[0]['A']['frame'].dtype == torch.uint8 and raws[0]['B']['mask'].shape == (2, 240, 320, 3)
+
+
+def test_random_pairs_follow_numpys_global_generator(tmp_path):
+    """Without a pairs file sample i is video i mod n and two distinct frames drawn with np.random.choice (hov3_dataset.py:199-203):
+    a seeded run visits the reference's pairs."""
+    from hoig_amd.data import DatasetFactory
+    opt = FX.build(str(tmp_path), seed=6)
+    opt.num_repeats = 3
+    ds = DatasetFactory.get_by_name('hov3', opt, True)
+    assert len(ds) == 2 * 3
+    np.random.seed(11)
+    recs = [ds[i] for i in (0, 1, 5)]
+    got = [(r['A']['name'], r['B']['name']) for r in recs]
+    np.random.seed(11)
+    frames = ['%04d.png' % k for k in range(4)]
+    for (a, b), vid in zip(got, ('ABF1_0', 'MC2_0', 'MC2_0')):
+        fa, fb = np.random.choice(frames, size=2, replace=False)
+        assert (a, b) == ('%s/%s' % (vid, fa), '%s/%s' % (vid, fb)) and fa != fb
+
+
+def test_missing_directories_and_files_are_named(tmp_path):
+    from hoig_amd.data import DatasetFactory
+    opt = FX.build(str(tmp_path), seed=7)
+    opt.params_dir = 'nowhere'
+    with pytest.raises(ValueError, match='param_dir'):
+        DatasetFactory.get_by_name('hov3', opt, True)
+    opt.params_dir, opt.images_dir = 'params', 'nowhere'
+    with pytest.raises(ValueError, match='pic_dir'):
+        DatasetFactory.get_by_name('hov3', opt, True)
+
+
+def test_imread_follows_cv2_conventions(tmp_path):
+    """imread_bgr = cv2.imread(IMREAD_COLOR): BGR order, EXIF orientation applied, 16-bit samples reduced to their high byte, alpha
+    dropped, grey widened to three channels."""
+    from PIL import Image
+    from hoig_amd.data.hov3_dataset import imread_bgr
+    rgb = _img(5, 7, 3, seed=9)
+    Image.fromarray(rgb).save(tmp_path / 'a.png')
+    assert np.array_equal(imread_bgr(str(tmp_path / 'a.png')), rgb[:, :, ::-1])
+    exif = Image.Exif()
+    exif[0x0112] = 6                                         # "rotate 90 degrees clockwise to display"
+    Image.fromarray(rgb).save(tmp_path / 'r.png', exif=exif)
+    assert np.array_equal(imread_bgr(str(tmp_path / 'r.png')), np.rot90(rgb, -1)[:, :, ::-1])
+    g16 = np.random.Generator(np.random.Philox(key=[1, 2])).integers(0, 65536, (4, 6)).astype(np.uint16)
+    Image.fromarray(g16).save(tmp_path / 'g.png')
+    out = imread_bgr(str(tmp_path / 'g.png'))
+    assert out.shape == (4, 6, 3) and np.array_equal(out[:, :, 0], (g16 >> 8).astype(np.uint8)) and np.array_equal(out[:, :, 0], out[:, :, 2])
+    rgba = np.dstack([rgb, np.full((5, 7), 17, np.uint8)])
+    Image.fromarray(rgba).save(tmp_path / 't.png')
+    assert np.array_equal(imread_bgr(str(tmp_path / 't.png')), rgb[:, :, ::-1])
+    Image.fromarray(rgb[:, :, 0]).save(tmp_path / 'l.png')
+    assert np.array_equal(imread_bgr(str(tmp_path / 'l.png')), np.repeat(rgb[:, :, :1], 3, axis=2))
+
+
+def test_imread_matches_cv2_when_available(tmp_path):
+    """The decode itself (libjpeg through Pillow vs through OpenCV) and the OpenCV restatements can only be compared where cv2 exists;
+    this image has none, so the test documents the gap instead of hiding it."""
+    cv2 = pytest.importorskip('cv2')
+    from PIL import Image
+    from hoig_amd.data.hov3_dataset import imread_bgr
+    yy, xx = np.mgrid[0:96, 0:128]
+    img = (np.stack([xx * 1.7 + yy, yy * 2.1, (xx + yy) * 0.9], -1) % 256).astype(np.uint8)
+    Image.fromarray(img).save(tmp_path / 'j.jpg', quality=90)
+    Image.fromarray(img).save(tmp_path / 'p.png')
+    for n in ('j.jpg', 'p.png'):
+        assert np.array_equal(imread_bgr(str(tmp_path / n)), cv2.imread(str(tmp_path / n))), n
+    a = _img(48, 64)
+    m = np.array([[0.9, 0.1, 3.3], [-0.2, 1.1, 2.7]], np.float32)
+    assert np.array_equal(O.warp_affine_linear_u8(a, m, (40, 30)), cv2.warpAffine(a, m, (40, 30)))
+    assert np.array_equal(O.resize_linear_u8(a, (100, 70)), cv2.resize(a, (100, 70)))
+
+
+def test_host_files_are_not_the_references(tmp_path):
+    """the loader's host half keeps the reference's NAMES; its bodies are this package's own.  No file of hoig_amd/data shares
+    more than a quarter of its non-trivial lines with a file of the reference's data packages (build container only)."""
+    import glob
+    import os
+    refs = glob.glob('/root/reference/*/data/*.py')
+    if not refs:
+        pytest.skip('no reference checkout')
+
+    def lines(p):
+        out = []
+        for l in open(p):
+            l = l.strip()
+            if len(l) >= 12 and not l.startswith(('#', 'import ', 'from ')):
+                out.append(l)
+        return out
+    ref_lines = [set(lines(r)) for r in refs]
+    root = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), 'hoig_amd', 'data')
+    for f in glob.glob(os.path.join(root, '*.py')):
+        mine = lines(f)
+        share = max(sum(1 for l in mine if l in r) for r in ref_lines) / max(1, len(mine))
+        assert share <= 0.25, (f, share)
