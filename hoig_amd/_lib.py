@@ -121,6 +121,7 @@ _SIGS = {
     'hoig_adam_pack_step': [_vp, _vp, _vp, _vp, _vp, _f, _vp, _i, _i64, _vp, _i64, _vp, _vp, _vp, _vp, _vp],
     'hoig_stream_create': [ctypes.POINTER(ctypes.c_void_p)],
     'hoig_stream_destroy': [_vp],
+    'hoig_stream_scratch_set': [_vp, _vp, _i64],
     'hoig_tensor2im_u8': [_vp, _vp] + [_i] * 6 + [_vp],
     'hoig_prep_texture': [_vp] * 9,
     'hoig_prep_lookup': [_vp] * 5 + [_i] + [_vp] * 8,
@@ -152,6 +153,8 @@ def _load():
     lib.hoig_rasterize_workspace_bytes.argtypes = [ctypes.c_int, ctypes.c_int]
     lib.hoig_set_tuning.argtypes = [ctypes.c_char_p, _i]
     lib.hoig_set_tuning.restype = ctypes.c_int
+    lib.hoig_stream_scratch_bytes.argtypes = []
+    lib.hoig_stream_scratch_bytes.restype = ctypes.c_int64
     lib.hoig_version.argtypes = []
     lib.hoig_version.restype = ctypes.c_char_p
     return lib

@@ -2,6 +2,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <atomic>
 #include "hoig_kernels.h"
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
@@ -13,6 +14,19 @@ typedef short bf16x8 __attribute__((ext_vector_type(8)));
         hipError_t e__ = hipGetLastError();                   \
         if (e__ != hipSuccess) return HOIG_ELAUNCH;           \
     } while (0)
+
+// hipFuncSetAttribute applies to the CURRENT device: a kernel's "attribute already set" flag remembers WHICH device ordinals have it
+// (a process-wide bool left every second GPU of a multi-device process without its > 64 KB of dynamic LDS).
+struct hoig_once {
+    std::atomic<unsigned long long> mask{0};
+    static int dev() {
+        int d = 0;
+        (void)hipGetDevice(&d);
+        return d & 63;
+    }
+    bool done() const { return (mask.load(std::memory_order_acquire) >> dev()) & 1ull; }
+    void set() { mask.fetch_or(1ull << dev(), std::memory_order_release); }
+};
 
 static inline int64_t hoig_cdiv(int64_t a, int64_t b) { return (a + b - 1) / b; }
 

@@ -466,14 +466,14 @@ static int launch_f6(const hoig_conv_desc *d, const float *x, const float *x2, i
     a.nblk_n = a.N / (n64 ? 64 : 128);
     a.nblk = ptiles * a.nblk_n;
     if (a.nblk < g_f6_min_tiles) return HOIG_EUNSUPPORTED;
-    static bool once = false;
-    if (!once) {
+    static hoig_once once;
+    if (!once.done()) {
         if (hipFuncSetAttribute(reinterpret_cast<const void *>(&conv_halo3_f6_kernel<128>), hipFuncAttributeMaxDynamicSharedMemorySize,
                                 BTile<128>::SMEM) != hipSuccess ||
             hipFuncSetAttribute(reinterpret_cast<const void *>(&conv_halo3_f6_kernel<64>), hipFuncAttributeMaxDynamicSharedMemorySize,
                                 BTile<64>::SMEM) != hipSuccess)
             return HOIG_ELAUNCH;
-        once = true;
+        once.set();
     }
     if (n64) conv_halo3_f6_kernel<64><<<a.nblk, NT, BTile<64>::SMEM, st>>>(a);
     else conv_halo3_f6_kernel<128><<<a.nblk, NT, BTile<128>::SMEM, st>>>(a);

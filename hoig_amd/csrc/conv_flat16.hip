@@ -289,12 +289,12 @@ __global__ __launch_bounds__(512) void conv_flat_m16_kernel(const FlatArgs p) {
 
 template <int NSX, int KS, bool F16, bool SPLITK>
 int launch_one(const FlatArgs &a, dim3 grid, size_t shm, hipStream_t st) {
-    static bool once = false;
-    if (!once) {
+    static hoig_once once;
+    if (!once.done()) {
         if (hipFuncSetAttribute(reinterpret_cast<const void *>(&conv_flat_m16_kernel<NSX, KS, F16, SPLITK>),
                                 hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess)
             return HOIG_ELAUNCH;
-        once = true;
+        once.set();
     }
     conv_flat_m16_kernel<NSX, KS, F16, SPLITK><<<grid, 512, shm, st>>>(a);
     HOIG_LAUNCH_CHECK();

@@ -600,14 +600,14 @@ template <int NS, int BN>
 int launch_one(const HaloArgs &a, hipStream_t st) {
     constexpr int WM = 4, WN = 2;
     constexpr size_t shm = M16Layout<WM, BN>::bytes(NS);
-    static bool once = false;
-    if (!once) {
+    static hoig_once once;
+    if (!once.done()) {
         if (hipFuncSetAttribute(reinterpret_cast<const void *>(&conv_halo3_m16_kernel<NS, WM, WN, BN, true>),
                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm) != hipSuccess ||
             hipFuncSetAttribute(reinterpret_cast<const void *>(&conv_halo3_m16_kernel<NS, WM, WN, BN, false>),
                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm) != hipSuccess)
             return HOIG_ELAUNCH;
-        once = true;
+        once.set();
     }
     if (a.f16) conv_halo3_m16_kernel<NS, WM, WN, BN, true><<<a.nblk, 64 * WM * WN, shm, st>>>(a);
     else conv_halo3_m16_kernel<NS, WM, WN, BN, false><<<a.nblk, 64 * WM * WN, shm, st>>>(a);

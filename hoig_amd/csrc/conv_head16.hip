@@ -184,11 +184,11 @@ int launch_head7(const hoig_conv_desc *d, const float *x, const float *w, const 
     constexpr int NFRAG = H7 * KSTEPS * h7_nt(CO);
     constexpr size_t lds = (size_t)NFRAG * 2 * 64 * 16 + (size_t)2 * (H7_MAXT * 16 + 6) * h7_zs(CO) * 4;
     static_assert(lds <= 160 * 1024, "LDS");
-    static bool attr = false;
-    if (!attr) {
+    static hoig_once attr;
+    if (!attr.done()) {
         if (hipFuncSetAttribute(reinterpret_cast<const void *>(conv_head7_m16_kernel<CO, KSTEPS>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
             return HOIG_ELAUNCH;
-        attr = true;
+        attr.set();
     }
     const int n_strips = (d->Wi + H7_OUTW - 1) / H7_OUTW, n_chunks = (d->Hi + H7_TH - 1) / H7_TH;
     conv_head7_m16_kernel<CO, KSTEPS><<<d->B * n_chunks * n_strips, H7_THREADS, lds, st>>>(x, w, bias, y, d->B, d->Hi, d->Wi, acts, d->slope,

@@ -1072,14 +1072,14 @@ template <int NS, int WM, int WN, int BN, int MODE>
 int launch_halo3_one(const HaloArgs &a, hipStream_t st) {
     constexpr int HPIX = (2 * WM + 2) * 34;
     constexpr size_t shm = (MODE == 1 ? 2 : 1) * (ns_a(NS) * (HPIX * 80)) + (MODE == 0 ? 1 : 2) * (3 * ns_b(NS) * (BN * 64));
-    static bool once = false;
-    if (!once) {
+    static hoig_once once;
+    if (!once.done()) {
         if (hipFuncSetAttribute(reinterpret_cast<const void *>(&conv_halo3_bf16_kernel<NS, WM, WN, BN, MODE, true>),
                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm) != hipSuccess ||
             hipFuncSetAttribute(reinterpret_cast<const void *>(&conv_halo3_bf16_kernel<NS, WM, WN, BN, MODE, false>),
                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm) != hipSuccess)
             return HOIG_ELAUNCH;
-        once = true;
+        once.set();
     }
     if (a.f16) conv_halo3_bf16_kernel<NS, WM, WN, BN, MODE, true><<<a.nblk, 64 * WM * WN, shm, st>>>(a);
     else conv_halo3_bf16_kernel<NS, WM, WN, BN, MODE, false><<<a.nblk, 64 * WM * WN, shm, st>>>(a);
@@ -1583,13 +1583,13 @@ int launch_dgrad_thin(const float *dy, const unsigned short *wh, const unsigned 
     a.steps_per_wg = (int)hoig_cdiv(a.nsteps, split);
     split = (int)hoig_cdiv(a.nsteps, a.steps_per_wg);
     const size_t shm = (size_t)2 * ns_b(ns) * 8 * 2048;
-    static bool once = false;
-    if (!once) {
+    static hoig_once once;
+    if (!once.done()) {
         if (hipFuncSetAttribute(reinterpret_cast<const void *>(&dgrad_thin_k128_kernel<2>), hipFuncAttributeMaxDynamicSharedMemorySize, 65536) != hipSuccess ||
             hipFuncSetAttribute(reinterpret_cast<const void *>(&dgrad_thin_k128_kernel<3>), hipFuncAttributeMaxDynamicSharedMemorySize, 32768) != hipSuccess ||
             hipFuncSetAttribute(reinterpret_cast<const void *>(&dgrad_thin_k128_kernel<1>), hipFuncAttributeMaxDynamicSharedMemorySize, 32768) != hipSuccess)
             return HOIG_ELAUNCH;
-        once = true;
+        once.set();
     }
     HOIG_NS_SWITCH(ns, dgrad_thin_k128_kernel<NSX><<<dim3(mtiles, split), 256, shm, st>>>(a));
     HOIG_LAUNCH_CHECK();
@@ -2395,14 +2395,14 @@ int launch_wgrad_halo(const hoig_conv_desc *d, const float *x, const float *dy, 
     }
     if (th4) {
         constexpr int LDS4 = 2 * (4 * 32 * 320) + (((6 * 34 * 64) + 255) / 256) * 256;      // dy hi, lo | x hi
-        static bool once = false;
-        if (!once) {
+        static hoig_once once;
+        if (!once.done()) {
             if (hipFuncSetAttribute(reinterpret_cast<const void *>(&wgrad_halo_bf16_kernel<1, 3, 2, false, 4>),
                                     hipFuncAttributeMaxDynamicSharedMemorySize, LDS4) != hipSuccess ||
                 hipFuncSetAttribute(reinterpret_cast<const void *>(&wgrad_halo_bf16_kernel<3, 3, 2, false, 4>),
                                     hipFuncAttributeMaxDynamicSharedMemorySize, LDS4) != hipSuccess)
                 return HOIG_ELAUNCH;
-            once = true;
+            once.set();
         }
         if (ns == 3) wgrad_halo_bf16_kernel<3, 3, 2, false, 4><<<grid, 768, LDS4, st>>>(a);
         else wgrad_halo_bf16_kernel<1, 3, 2, false, 4><<<grid, 768, LDS4, st>>>(a);

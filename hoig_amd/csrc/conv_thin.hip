@@ -454,36 +454,13 @@ __global__ __launch_bounds__(NTHR) void thin_reduce_kernel(const ThinArgs p, int
     atomicAdd(p.Out + (size_t)(cbase + m) * p.sj + (size_t)tap * p.st + (size_t)f * p.sf, v);
 }
 
-// Workspace for the partials: a pool of slots, one per stream that ever launches a thin weight gradient (launches of one
-// stream are ordered, so they share their slot).  Allocated on the first use -- never while a stream is being captured
-// (the trainer's eager warm-up steps come first); without a slot the kernel falls back to atomics.
-constexpr size_t WS_SLOT_BYTES = (size_t)16 << 20;
-constexpr int WS_SLOTS = 24;
-float *thin_workspace(hipStream_t st, size_t bytes) {
-    static std::mutex mu;
-    static float *base = nullptr;
-    static std::map<hipStream_t, int> owner;
-    static int next = 0;
-    std::lock_guard<std::mutex> lock(mu);
-    if (bytes > WS_SLOT_BYTES) return nullptr;
-    if (!base) {
-        hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
-        if (hipStreamIsCapturing(st, &cs) != hipSuccess || cs != hipStreamCaptureStatusNone) return nullptr;
-        if (hipMalloc(reinterpret_cast<void **>(&base), WS_SLOT_BYTES * WS_SLOTS) != hipSuccess) {
-            base = nullptr;
-            (void)hipGetLastError();
-            return nullptr;
-        }
-    }
-    auto it = owner.find(st);
-    int slot;
-    if (it != owner.end()) slot = it->second;
-    else {
-        if (next >= WS_SLOTS) return nullptr;
-        slot = owner[st] = next++;
-    }
-    return base + (size_t)slot * (WS_SLOT_BYTES / sizeof(float));
-}
+// Workspace for the partials: the launching stream's scratch block, which the CALLER owns and registers
+// (hoig_stream_scratch_set, pointwise.hip); without one the kernel falls back to atomics.
+}  // namespace
+namespace hoig_detail { void *stream_scratch(hipStream_t st, size_t bytes); }
+namespace {
+constexpr size_t WS_SLOT_BYTES = (size_t)16 << 20;      // = hoig_stream_scratch_bytes(): what a caller registers per stream
+float *thin_workspace(hipStream_t st, size_t bytes) { return static_cast<float *>(hoig_detail::stream_scratch(st, bytes)); }
 
 // ------------------------------------------------------------------------------------------------------------ thin OUTPUT
 // out[p][f] = sum_tap sum_j D[p + off(tap)][j] * W[f][tap][j]  with F <= 16 output channels: the FORWARD of the image / mask heads
@@ -675,12 +652,12 @@ int launch_gemm(const ThinArgs &a, int precision, hipStream_t st) {
     dim3 grid((unsigned)hoig_cdiv(a.ntiles, a.strip), a.CD / 64);
 #define HOIG_THIN_GEMM(NT_, NW_)                                                                                         \
     do {                                                                                                                 \
-        static bool attr = false;                                                                                        \
-        if (!attr) {                                                                                                     \
+        static hoig_once attr;                                                                                        \
+        if (!attr.done()) {                                                                                                     \
             if (hipFuncSetAttribute(reinterpret_cast<const void *>(&thin_gemm_kernel<FP16, NT_, NW_>),                   \
                                     hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess)               \
                 return HOIG_ELAUNCH;                                                                                     \
-            attr = true;                                                                                                 \
+            attr.set();                                                                                                 \
         }                                                                                                                \
         thin_gemm_kernel<FP16, NT_, NW_><<<grid, NTHR, smem, st>>>(a);                                                   \
     } while (0)
@@ -696,12 +673,12 @@ template <int NPW, int WN>
 int launch_wgrad_t(const ThinArgs &a, int nt, int nd, dim3 grid, size_t smem, hipStream_t st) {
 #define HOIG_THIN_WG(NT_, ND_)                                                                                           \
     do {                                                                                                                 \
-        static bool attr = false;                                                                                        \
-        if (!attr) {                                                                                                     \
+        static hoig_once attr;                                                                                        \
+        if (!attr.done()) {                                                                                                     \
             if (hipFuncSetAttribute(reinterpret_cast<const void *>(&thin_wgrad_kernel<NPW, WN, NT_, ND_>),               \
                                     hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess)               \
                 return HOIG_ELAUNCH;                                                                                     \
-            attr = true;                                                                                                 \
+            attr.set();                                                                                                 \
         }                                                                                                                \
         thin_wgrad_kernel<NPW, WN, NT_, ND_><<<grid, NTHR, smem, st>>>(a);                                               \
     } while (0)
@@ -817,12 +794,12 @@ int hoig_conv_thin_out(const hoig_conv_desc *d, const float *x, const float *w, 
     const unsigned grid = (unsigned)hoig_cdiv(a.ntiles, a.strip);
 #define HOIG_THIN_OUT(FP16_, ND_, NW_)                                                                                   \
     do {                                                                                                                 \
-        static bool attr = false;                                                                                        \
-        if (!attr) {                                                                                                     \
+        static hoig_once attr;                                                                                        \
+        if (!attr.done()) {                                                                                                     \
             if (hipFuncSetAttribute(reinterpret_cast<const void *>(&thin_out_kernel<FP16_, ND_, NW_>),                   \
                                     hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess)               \
                 return HOIG_ELAUNCH;                                                                                     \
-            attr = true;                                                                                                 \
+            attr.set();                                                                                                 \
         }                                                                                                                \
         thin_out_kernel<FP16_, ND_, NW_><<<grid, NTHR, smem, st>>>(a);                                                   \
     } while (0)

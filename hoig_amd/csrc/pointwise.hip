@@ -2,6 +2,9 @@
 // alpha compositing (trainer.py:400-401), the loss terms of trainer.py:436-481, VGG max-pooling, fused Adam
 // (trainer.py:275-278,425-434) and the eval.py uint8 output stage (utils/util.py:249-264).
 #include "common.h"
+#include <cstdio>
+#include <map>
+#include <mutex>
 
 namespace {
 constexpr int NT = 256;
@@ -777,8 +780,39 @@ extern "C" int hoig_stream_create(hoig_stream_t *out) {
     *out = (hoig_stream_t)s;
     return HOIG_OK;
 }
+// Per-stream scratch memory, owned by the CALLER (no allocation happens behind this ABI): a registry stream -> (pointer, bytes).
+// Kernels that reduce per-workgroup partials through memory (the thin-channel weight gradients, conv_thin.hip) look their stream's
+// block up here; launches of one stream are ordered, so they share it.  Without a registered block such a kernel takes its
+// atomic path and says so once.
+namespace {
+struct Scratch { void *ptr; int64_t bytes; };
+std::mutex g_scratch_mu;
+std::map<hipStream_t, Scratch> g_scratch;
+bool g_scratch_warned = false;
+}  // namespace
+namespace hoig_detail {
+void *stream_scratch(hipStream_t st, size_t bytes) {
+    std::lock_guard<std::mutex> lock(g_scratch_mu);
+    auto it = g_scratch.find(st);
+    if (it != g_scratch.end() && (size_t)it->second.bytes >= bytes) return it->second.ptr;
+    if (!g_scratch_warned) {
+        g_scratch_warned = true;
+        fprintf(stderr, "hoig: no scratch block of %zu bytes registered for stream %p (hoig_stream_scratch_set): partial sums fall back to "
+                        "atomics\n", bytes, (void *)st);
+    }
+    return nullptr;
+}
+}  // namespace hoig_detail
+extern "C" int64_t hoig_stream_scratch_bytes(void) { return (int64_t)16 << 20; }
+extern "C" int hoig_stream_scratch_set(hoig_stream_t stream, void *ptr, int64_t bytes) {
+    std::lock_guard<std::mutex> lock(g_scratch_mu);
+    if (!ptr || bytes <= 0) g_scratch.erase((hipStream_t)stream);
+    else g_scratch[(hipStream_t)stream] = Scratch{ptr, bytes};
+    return HOIG_OK;
+}
 extern "C" int hoig_stream_destroy(hoig_stream_t stream) {
     if (!stream) return HOIG_EINVAL;
+    (void)hoig_stream_scratch_set(stream, nullptr, 0);
     return hipStreamDestroy((hipStream_t)stream) == hipSuccess ? HOIG_OK : HOIG_ELAUNCH;
 }
 extern "C" const char *hoig_version(void) { return "hoig-hip 0.1 (gfx950)"; }

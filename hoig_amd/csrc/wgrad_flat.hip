@@ -193,13 +193,13 @@ int launch_wgrad_flat5(const float *x, const float *dy, float *dw, float *dbias,
     a.mt_per_split = (int)hoig_cdiv(a.n_mtiles, splits);
     splits = (int)hoig_cdiv(a.n_mtiles, a.mt_per_split);
     const int shm = ns_a(ns) * PTW * PSTR + ns_b(ns) * ((a.HPOS * QSTR + 255) / 256 * 256);
-    static bool once = false;
-    if (!once) {
+    static hoig_once once;
+    if (!once.done()) {
         if (hipFuncSetAttribute(reinterpret_cast<const void *>(&wgrad_flat_kernel<1>), hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024) != hipSuccess ||
             hipFuncSetAttribute(reinterpret_cast<const void *>(&wgrad_flat_kernel<2>), hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024) != hipSuccess ||
             hipFuncSetAttribute(reinterpret_cast<const void *>(&wgrad_flat_kernel<3>), hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024) != hipSuccess)
             return HOIG_ELAUNCH;
-        once = true;
+        once.set();
     }
     dim3 grid(a.nblk, splits);
     HOIG_NS_SWITCH(ns, wgrad_flat_kernel<NSX><<<grid, NT, shm, st>>>(a));

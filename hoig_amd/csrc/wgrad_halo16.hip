@@ -237,12 +237,12 @@ __global__ __launch_bounds__(128 * 3 * CM) void wgrad_halo_m16_kernel(const WHal
 template <int NSX, int CM, int TH>
 int launch_one(const WHaloArgs &a, dim3 grid, hipStream_t st) {
     constexpr int shm = W16Layout<TH, CM>::bytes(NSX);
-    static bool once = false;
-    if (!once) {
+    static hoig_once once;
+    if (!once.done()) {
         if (hipFuncSetAttribute(reinterpret_cast<const void *>(&wgrad_halo_m16_kernel<NSX, CM, TH>),
                                 hipFuncAttributeMaxDynamicSharedMemorySize, shm) != hipSuccess)
             return HOIG_ELAUNCH;
-        once = true;
+        once.set();
     }
     wgrad_halo_m16_kernel<NSX, CM, TH><<<grid, 128 * 3 * CM, shm, st>>>(a);
     HOIG_LAUNCH_CHECK();

@@ -83,6 +83,7 @@ class DeviceStage(object):
     def _object_vertices(self, col):
         """hov3_dataset.py:246-248: zeros((7866, 3), float32); [:n] = v @ Rodrigues(objRot).T + objTrans; ycb_dataset.py:165-169,292-293:
         zeros((8000, 3)); [:n] = (pose_obj @ [v | 1].T)[:3].T -- float64 on the device, rounded to float32 on assignment."""
+        from .. import ops
         dev = self.device
         ids = [int(k) for k in col['objName']]
         if 'obj_pose' in col:
@@ -96,7 +97,7 @@ class DeviceStage(object):
         out = torch.zeros((len(ids), self._max_verts, 3), dtype=torch.float32, device=dev)
         for k in sorted(set(ids)):
             rows = [i for i, o in enumerate(ids) if o == k]
-            idx = torch.tensor(rows, device=dev)
+            idx = ops.device_index(rows, dev)             # (pinned + non-blocking: no host wait on the loader stream)
             v = self._meshes.get(k)
             now = torch.matmul(v.unsqueeze(0), R_dev[idx].transpose(1, 2)) + t_dev[idx].unsqueeze(1)
             out[idx, :v.shape[0]] = now.float()
@@ -117,7 +118,7 @@ class DeviceStage(object):
     def submit(self, raw):
         if self._stream is None:
             from .. import ops
-            self._stream = ops.new_stream(self.device, 'opt')
+            self._stream = ops.new_stream(self.device, 'loader')
         with torch.cuda.stream(self._stream):
             a, b = self._view(raw['A']), self._view(raw['B'])
             done = torch.cuda.Event()

@@ -17,6 +17,7 @@ buffer, 'map_fn', 'sem_full', 'fim_uv', 'wim_uv', 'faces_uv_coord', 'obj_tex_img
 import torch
 
 from . import input_prep as IP
+from . import ops
 from . import raster
 from .mano import HandModelRecovery, ManoModel
 from .options import is_dexycb
@@ -53,7 +54,11 @@ class HandRecoveryFlow(object):
         for k in sorted(set(obj_ids)):
             rows = [i for i, o in enumerate(obj_ids) if o == k]
             ob = self._objects[k]
-            idx = torch.tensor(rows, device=self.device)
+            if len(rows) == B:                           # one object in the batch: plain slices, no index tensor at all
+                f = raster.project_to_faces(info['cam'], info['verts'][:, :ob['length']], ob['faces'])
+                faces[:, :f.shape[1]] = f
+                continue
+            idx = ops.device_index(rows, self.device)    # (no host wait: pinned + non-blocking, cached)
             f = raster.project_to_faces(info['cam'][idx], info['verts'][idx, :ob['length']], ob['faces'])
             faces[idx, :f.shape[1]] = f
         fim, wim = raster.rasterize_fim_wim(faces, raster_size(self._opt))

@@ -88,7 +88,10 @@ class BaseModel(object):
         """need_module=True hands the file's keys to the network untouched (the HOIG_DexYCB copy loads into its DDP wrappers
         that way, HOIG_DexYCB/models/trainer.py:562,566); otherwise a 'module.' prefix is removed first."""
         state = self._ckpt.read(load_path)
-        network.load_state_dict(state if need_module else strip_ddp_prefix(state))
+        # (a BARE network always gets the prefix removed: need_module describes how the DexYCB copy feeds its DDP wrappers, and a
+        # single-GPU run of that copy must still read the checkpoints a DDP run saved; ADVICE r3)
+        wrapped = hasattr(network, 'module')
+        network.load_state_dict(state if (need_module and wrapped) else strip_ddp_prefix(state))
         print('Loading net: %s' % load_path)
 
     def _load_optimizer(self, optimizer, optimizer_label, epoch_label):

@@ -113,6 +113,26 @@ class Trainer(BaseModel):
         self._cmap = _labelcolormap(16)
         self._init_prefetch_inputs()
 
+    def close(self):
+        """Hand the step's HIP streams back to the library's banks (ops.release_stream): a process that builds Trainer after Trainer
+        keeps a flat number of streams.  Called by __del__; the object must not be used afterwards."""
+        gen = self._net(self._G) if getattr(self, '_G', None) is not None else None
+        held = [getattr(self, '_side', None), getattr(self, '_d_stream', None)]
+        held += list(getattr(self, '_loss_streams', None) or ()) + list(getattr(gen, '_streams', None) or ())
+        self._graphs = {}                # (captured steps hold the streams they were captured on)
+        self._side = self._d_stream = self._loss_streams = None
+        if gen is not None:
+            gen._streams = None
+        for st in held:
+            if st is not None:
+                ops.release_stream(st)
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:                # (interpreter shutdown: modules may be gone)
+            pass
+
     # ------------------------------------------------------------------ construction (trainer.py:217-322)
     def _init_create_networks(self, use_ddp=False):
         self._hdr = None          # hoig_amd.hand_recovery.HandRecoveryFlow, built on the first raw batch (set_raw_input)

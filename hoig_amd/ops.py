@@ -102,6 +102,27 @@ def _chk(t, name='tensor'):
         raise TypeError('%s must be float32' % name)
 
 
+_index_cache = collections.OrderedDict()
+
+
+def device_index(rows, device):
+    """int64 index tensor of the Python ints `rows` on `device` WITHOUT a host wait.  ``torch.tensor(rows, device=...)`` is a pageable
+    host-to-device copy: the host blocks until everything queued on the current stream before it has run, which throws away the
+    run-ahead the step relies on.  Here the values go through pinned memory with a non-blocking copy, and the handful of
+    row sets a loader produces (samples grouped by object id) are cached per stream."""
+    dev = torch.device(device)
+    key = (dev, torch.cuda.current_stream(dev).cuda_stream, tuple(int(r) for r in rows))
+    hit = _index_cache.get(key)
+    if hit is not None:
+        _index_cache.move_to_end(key)
+        return hit
+    t = torch.tensor(key[2], dtype=torch.int64).pin_memory().to(dev, non_blocking=True)
+    _index_cache[key] = t
+    if len(_index_cache) > 1024:
+        _index_cache.popitem(last=False)
+    return t
+
+
 def packed_strides(shape, transposed):
     """Strides of a logical conv weight over packed [Co][R][S][Ci] storage."""
     if transposed:
@@ -163,16 +184,17 @@ def _packed_planes(w, transposed, for_dgrad):
     return hi, lo
 
 
-_own_streams = []
 _stream_banks = {}
+_streams_made = _streams_destroyed = 0
 # Hardware-queue class of each stream ROLE of the step.  The runtime gives every new HIP stream the least-used of its (four)
 # hardware queues, so entry k of a bank of streams created back to back sits on queue k mod 4 (class 0 = the queue of the caller's
 # default stream), and WHICH roles share a hardware queue is worth up to 20 % of the step time
 # (profiles/r03_stream_queue_map.txt, one box: the three branch chains on three different queues 77-78 ms, every side role on one
 # queue 79-88 ms, the assignment below 72.9 ms): kernels of different queues interleave at workgroup granularity, and four heavy
 # chains doing that to each other are slower than two pairs.  Streams of ONE class execute in order: a stalled role stalls its
-# class mates (tests/test_stream_order_gpu.py moves a role to a class of its own where it needs one role late).
-_QUEUE_OF_ROLE = {'opt': 3, 'g_bg': 1, 'g_obj': 3, 'g_src': 1, 'loss_adv': 2, 'loss_vgg': 2, 'd': 2, 'wgrad': 2}
+# class mates (tests/test_stream_order_gpu.py moves a role to a class of its own where it needs one role late).  The loader's
+# stream (data/device_stage.py) sits with the default stream's class, away from the optimiser's and the branches' (ADVICE r4).
+_QUEUE_OF_ROLE = {'opt': 3, 'g_bg': 1, 'g_obj': 3, 'g_src': 1, 'loss_adv': 2, 'loss_vgg': 2, 'd': 2, 'wgrad': 2, 'loader': 0}
 
 
 def new_stream(device=None, role='opt'):
@@ -180,22 +202,75 @@ def new_stream(device=None, role='opt'):
     streams round-robin from a pool of 32 per device: in a process that has created more than that (a test session with a dozen
     Trainers) two roles of the step end up on ONE HIP stream, and a stream that waits for itself inside a capture crashes
     hipStreamEndCapture (ROCm 7.2: unbounded recursion over the capture's parallel streams).  The library creates the streams in
-    banks of 32, back to back; torch wraps the one this role's queue class asks for."""
+    banks of 32, back to back; torch wraps the one this role's queue class asks for.  The owner hands a stream back with
+    release_stream() when it goes away (Trainer.close): the next owner of that queue class takes it over."""
+    global _streams_made
     dev = torch.device('cuda', torch.cuda.current_device()) if device is None else torch.device(device)
     bank = _stream_banks.get(dev)
     if bank is None:
         bank = _stream_banks[dev] = {'free': [[], [], [], []]}
     q = _QUEUE_OF_ROLE[role]
-    if not bank['free'][q]:                     # (first use, or a long session: more streams, same queue classes)
+    if not bank['free'][q]:                     # (first use, or every stream of the class is in use: 32 more, same queue classes)
         with torch.cuda.device(dev):
             for k in range(32):
                 h = ctypes.c_void_p()
                 call('hoig_stream_create', ctypes.byref(h))
                 bank['free'][k % 4].append(h.value)
+                _streams_made += 1
     h = bank['free'][q].pop(0)
     s = torch.cuda.ExternalStream(h, device=dev)
-    _own_streams.append((h, s))                # (kept for the life of the process: a handful per Trainer)
+    s._hoig_class = q
     return s
+
+
+def release_stream(s):
+    """Hand a stream made by new_stream() back to its bank (work still queued on it simply precedes the next owner's)."""
+    q = getattr(s, '_hoig_class', None)
+    if q is None:
+        return
+    s._hoig_class = None
+    _stream_banks[s.device]['free'][q].append(s.cuda_stream)
+
+
+def stream_census():
+    """(HIP streams this module has created and not destroyed, of which idle in the banks, bytes of registered scratch)."""
+    idle = sum(len(f) for b in _stream_banks.values() for f in b['free'])
+    return _streams_made - _streams_destroyed, idle, sum(t.numel() for t in _scratch.values())
+
+
+def destroy_idle_streams():
+    """hoig_stream_destroy every stream that sits unused in a bank, after the device has drained (tests; an embedding process
+    that wants its HIP streams back)."""
+    global _streams_destroyed
+    for dev, bank in _stream_banks.items():
+        torch.cuda.synchronize(dev)
+        for f in bank['free']:
+            while f:
+                h = f.pop()
+                _scratch.pop((dev, h), None)
+                call('hoig_stream_destroy', h)          # (also forgets the stream's scratch registration)
+                _streams_destroyed += 1
+
+
+# Per-stream scratch of the kernels that reduce partial sums through memory (include/hoig_kernels.h hoig_stream_scratch_set): the
+# library allocates nothing, so the caller -- this module -- registers one block per stream that launches weight gradients.
+_scratch = {}
+
+
+def _ensure_scratch():
+    cur = torch.cuda.current_stream()
+    key = (cur.device, cur.cuda_stream)
+    if key not in _scratch:
+        # (never freed while registered; inside a capture it comes from the graph's private pool, which outlives every replay)
+        t = torch.empty(L.lib.hoig_stream_scratch_bytes(), dtype=torch.uint8, device=cur.device)
+        _scratch[key] = t
+        call('hoig_stream_scratch_set', cur.cuda_stream, t.data_ptr(), t.numel())
+
+
+def wgrad_call(name, *args):
+    """A weight-gradient entry point on the current stream, with that stream's scratch block registered first."""
+    _ensure_scratch()
+    call(name, *args)
 
 
 # ---- test hook (tests/test_stream_order_gpu.py): stream role -> cycles to idle.  A role that finds its name here sleeps that long
@@ -439,10 +514,10 @@ class _Conv(Function):
                 side.wait_stream(torch.cuda.current_stream())
                 with torch.cuda.stream(side):
                     test_delay('wgrad')
-                    call('hoig_conv2d_bwd_weight', ctypes.byref(ctx.d_wg), _p(x), _p(g), _p(dw), _p(db), _st())
+                    wgrad_call('hoig_conv2d_bwd_weight', ctypes.byref(ctx.d_wg), _p(x), _p(g), _p(dw), _p(db), _st())
                 _wgrad_hold(side, (x, g))
             else:
-                call('hoig_conv2d_bwd_weight', ctypes.byref(ctx.d_wg), _p(x), _p(g), _p(dw), _p(db), _st())
+                wgrad_call('hoig_conv2d_bwd_weight', ctypes.byref(ctx.d_wg), _p(x), _p(g), _p(dw), _p(db), _st())
             dw_ret = dw if ret_w else None
         dx = None
         if ctx.needs_input_grad[0]:
@@ -511,10 +586,10 @@ class _ConvCat2(Function):
             side.wait_stream(torch.cuda.current_stream())
             with torch.cuda.stream(side):
                 test_delay('wgrad')
-                call('hoig_conv2d_cat_bwd_weight', ctypes.byref(ctx.d_wg), _p(x1), C1, _p(x2), _p(dy), _p(dw), None, _st())
+                wgrad_call('hoig_conv2d_cat_bwd_weight', ctypes.byref(ctx.d_wg), _p(x1), C1, _p(x2), _p(dy), _p(dw), None, _st())
             _wgrad_hold(side, (x1, x2, dy))
         else:
-            call('hoig_conv2d_cat_bwd_weight', ctypes.byref(ctx.d_wg), _p(x1), C1, _p(x2), _p(dy), _p(dw), None, _st())
+            wgrad_call('hoig_conv2d_cat_bwd_weight', ctypes.byref(ctx.d_wg), _p(x1), C1, _p(x2), _p(dy), _p(dw), None, _st())
         dx1, dx2 = torch.empty_like(x1), torch.empty_like(x2)
         hi, lo = _packed_planes(w, False, True)
         L.check(L.lib.hoig_conv2d_cat_bwd_data_packed(ctypes.byref(ctx.d_dg), _p(dy), _p(hi), _p(lo), _p(dx1), C1, _p(dx2), _st()),
@@ -552,6 +627,7 @@ class _ConvHeads(Function):
         B, H, W_, Ci = x.shape
         Co, _, R, S = w.shape
         assert sum(splits) == Co and len(splits) == len(acts)
+        assert Co <= 16, 'the activation codes of the fused heads are 4 bits x 16 channels (hoig_conv2d_fwd_heads)'
         if Co > 16:
             raise ValueError('conv_heads: %d output channels, the per-channel activation codes hold 16' % Co)
         d = ConvDesc(B, H, W_, Ci, H, W_, Co, R, S, 1, R // 2, 0, L.ACT_NONE, 0.0, prec)
@@ -595,7 +671,7 @@ class _ConvHeads(Function):
         dw_ret = None
         if ctx.needs_input_grad[1]:
             dw, ret_w = _grad_target(w)
-            call('hoig_conv2d_bwd_weight', ctypes.byref(ctx.d_wg), _p(x), _p(g), _p(dw), None, _st())
+            wgrad_call('hoig_conv2d_bwd_weight', ctypes.byref(ctx.d_wg), _p(x), _p(g), _p(dw), None, _st())
             dw_ret = dw if ret_w else None
         dx = None
         if ctx.needs_input_grad[0]:
@@ -648,7 +724,7 @@ def _conv_stats_workspace(y):
     """Accumulators for the statistics of `y` (a convolution output about to be written), or None when its instance norm would
     not read them: maps of <= 1024 pixels take the one-launch norm kernel, which computes its own."""
     B, H, W_, C = y.shape
-    if H * W_ <= 1024 or C % 4:
+    if H * W_ <= 1024 or C % 4 or B * 2 * C > (1 << 18):        # (1 << 18: the accumulator pool, norm.hip ACC_POOL)
         return None
     return _norm_workspace(L.lib.hoig_inorm_workspace_bytes(B, H * W_, C) // 4, y.device)
 
@@ -1124,10 +1200,10 @@ class _AttnSourceConv(Function):
         if side is not None:          # (see _Conv.backward)
             side.wait_stream(torch.cuda.current_stream())
             with torch.cuda.stream(side):
-                call('hoig_conv2d_bwd_weight', ctypes.byref(ds_wg), _p(spad), _p(dgs), _p(gw), None, _st())
+                wgrad_call('hoig_conv2d_bwd_weight', ctypes.byref(ds_wg), _p(spad), _p(dgs), _p(gw), None, _st())
             _wgrad_hold(side, (spad, dgs))
         else:
-            call('hoig_conv2d_bwd_weight', ctypes.byref(ds_wg), _p(spad), _p(dgs), _p(gw), None, _st())
+            wgrad_call('hoig_conv2d_bwd_weight', ctypes.byref(ds_wg), _p(spad), _p(dgs), _p(gw), None, _st())
         dsrc = None
         if ctx.needs_input_grad[0]:
             dspad = torch.empty_like(spad)
@@ -1203,10 +1279,10 @@ class _LocalAttn(Function):
         if side is not None:          # (see _Conv.backward)
             side.wait_stream(torch.cuda.current_stream())
             with torch.cuda.stream(side):
-                call('hoig_conv2d_bwd_weight', ctypes.byref(dt_wg), _p(tpad), _p(dhid), _p(gs[0][0]), _p(gs[1][0]), _st())
+                wgrad_call('hoig_conv2d_bwd_weight', ctypes.byref(dt_wg), _p(tpad), _p(dhid), _p(gs[0][0]), _p(gs[1][0]), _st())
             _wgrad_hold(side, (tpad, dhid))
         else:
-            call('hoig_conv2d_bwd_weight', ctypes.byref(dt_wg), _p(tpad), _p(dhid), _p(gs[0][0]), _p(gs[1][0]), _st())
+            wgrad_call('hoig_conv2d_bwd_weight', ctypes.byref(dt_wg), _p(tpad), _p(dhid), _p(gs[0][0]), _p(gs[1][0]), _st())
         dtgt = dsrc = None
         if ctx.needs_input_grad[1]:
             dtpad = torch.empty_like(tpad)

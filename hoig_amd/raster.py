@@ -31,6 +31,18 @@ def rasterize_fim_wim(faces, image_size=256, near=DEFAULT_NEAR, far=DEFAULT_FAR)
     return fim, wim
 
 
+_consts = {}
+
+
+def _const(device, key, values):
+    """A small constant tensor, uploaded ONCE per device: torch.tensor(..., device=...) on every call is a pageable host-to-device
+    copy, i.e. a host wait for everything queued on the current stream."""
+    t = _consts.get((device, key))
+    if t is None:
+        t = _consts[(device, key)] = torch.tensor(values, dtype=torch.float32, device=device)
+    return t
+
+
 def project(vertices, cam):
     """orthographic_proj_withz_idrot (nmr.py:109-140): OpenGL axis change, camera matrix, perspective divide, 2x3 crop
     transform, pixel -> [-1,1]; z = the axis-changed depth.  vertices (B,V,3), cam (B,15).
@@ -47,7 +59,7 @@ def project(vertices, cam):
         xy = torch.einsum('ijk,ikm->ijm', trans, xy1).permute(0, 2, 1)
         return torch.cat((xy / 255.0 * 2 - 1, vertices[:, :, 2:3]), dim=2)
     cam_mat, trans = cam[:, 0:9].reshape(bs, 3, 3), cam[:, 9:].reshape(bs, 2, 3)
-    change = torch.tensor([[1., 0., 0.], [0., -1., 0.], [0., 0., -1.]], dtype=torch.float32, device=vertices.device)
+    change = _const(vertices.device, 'change', [[1., 0., 0.], [0., -1., 0.], [0., 0., -1.]])
     pts = torch.einsum('ijk,mk->ijm', vertices, change)
     proj = torch.einsum('ijk,imk->ijm', pts, cam_mat)
     xy = torch.stack([proj[:, :, 0] / proj[:, :, 2], proj[:, :, 1] / proj[:, :, 2], torch.ones_like(proj[:, :, 0])], dim=2)
@@ -61,7 +73,7 @@ def project_to_faces(cam, vertices, faces_idx, viewing_angle=30.0):
     v = torch.stack([v[:, :, 0], -v[:, :, 1], v[:, :, 2]], dim=2)                     # nmr.py:506
     # nr.look_at with eye = (0, 0, -(1/tan(angle) + 1)), at = origin, up = +y (nmr.py:357,508): the rotation is the identity,
     # what remains is the translation by -eye
-    eye = torch.tensor([0.0, 0.0, -(1.0 / math.tan(math.radians(viewing_angle)) + 1.0)], dtype=torch.float32, device=v.device)
+    eye = _const(v.device, ('eye', viewing_angle), [0.0, 0.0, -(1.0 / math.tan(math.radians(viewing_angle)) + 1.0)])
     v = v - eye
     if faces_idx.dim() == 2:
         faces_idx = faces_idx[None].expand(v.shape[0], -1, -1)

@@ -360,7 +360,15 @@ int hoig_adam_pack_step(float *flat, const float *grad, float *exp_avg, float *e
 /* A non-blocking HIP stream owned by the library (the step's side streams: see hoig_amd/ops.py new_stream for why they are not
  * taken from PyTorch's round-robin stream pool). */
 int hoig_stream_create(hoig_stream_t *out);
-int hoig_stream_destroy(hoig_stream_t stream);
+int hoig_stream_destroy(hoig_stream_t stream);   /* also forgets the stream's scratch block */
+/* Per-stream scratch, CALLER-owned like every other buffer of this interface (nothing behind it allocates device memory): kernels
+ * that reduce per-workgroup partial sums through memory -- the thin-channel weight gradients behind hoig_conv2d_bwd_weight -- use the
+ * block registered for the stream they are launched on (launches of one stream are ordered, so they share it).  Register >=
+ * hoig_stream_scratch_bytes() bytes per stream that launches weight gradients; ptr = NULL forgets the stream.  Without a block those
+ * kernels take a (slower, same-result-up-to-summation-order) atomic path and report it once on stderr.  The block must stay valid
+ * until the stream's last launch that may use it has run. */
+int64_t hoig_stream_scratch_bytes(void);
+int hoig_stream_scratch_set(hoig_stream_t stream, void *ptr, int64_t bytes);
 
 /* eval.py output stage (utils/util.py:249-264): uint8 = (x+1)/2*255 truncated, NHWC fp32 -> CHW uint8 grid tile */
 int hoig_tensor2im_u8(const float *x, uint8_t *out, int B, int H, int W, int C, int nrow, int unnormalize,
