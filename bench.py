@@ -26,7 +26,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)          # the product package only; tests/ + oracle/ are reachable from the cpu-baseline child alone
 
 GFLOP_PER_PAIR_TRAIN_256 = 2555.2      # BASELINE.md §2 / SURVEY.md §8d (3*G + 3*VGG + 9*D), generator_spade_attn
-PMC_FILES = ['r04_pmc_dominant_conv.json', 'r03_pmc_dominant_conv.json', 'r02_pmc_dominant_conv_f6.json', 'r02_pmc_dominant_conv.json', 'r01_pmc_dominant_conv.json']      # newest first (matched by kernel name below)
+PMC_FILES = ['r05_pmc_dominant_conv.json', 'r04_pmc_dominant_conv.json', 'r03_pmc_dominant_conv.json', 'r02_pmc_dominant_conv_f6.json', 'r02_pmc_dominant_conv.json', 'r01_pmc_dominant_conv.json']      # newest first (matched by kernel name below)
 PEAK_F32, PEAK_16 = 157.3, 2500.0          # TFLOP/s dense MFMA (fp32 / fp16-bf16), MI355X_MICROARCH.md
 DTYPE_NAMES = {'f16f6': 'fwd: fp16 hi*hi + the two cross terms of the hi/lo split on block-scaled fp6 MFMA (1.6 bf16-MFMA units per product; layers outside that kernel: three fp16 terms) / bwd: bf16x2 (dy split hi+lo, weights and x single bf16), f32 accumulate',
                'bf16x3:f16x2': 'f16x3 fwd (both operands split hi+lo on fp16, 3 MFMAs per product) / bf16x2 bwd (dy split hi+lo, weights and x single bf16, 2 MFMAs per product), f32 accumulate',
@@ -36,19 +36,15 @@ DTYPE_NAMES = {'f16f6': 'fwd: fp16 hi*hi + the two cross terms of the hi/lo spli
 MFMA_TERMS = {'f16f6': 1.6, 'f32': 1, 'bf16x3': 3, 'f16x3': 3, 'f16x2': 2, 'bf16x2': 2, 'bf16': 1, 'f16': 1}      # issued MFMAs per algorithmic one
 
 
-def dominant_kernel_roofline(batch, side, precision, iters=50):
-    """The dominant kernel of the step is the 3x3 stride-1 512->512 convolution at side/8 (72 of ~260 conv calls of a
-    forward, 44% of G's MACs).  Most of its time is spent in the launches of bg_model and obj_model,
-    which process the src and the tsf batch STACKED (2*batch images per launch: profiles/r01_conv_table.txt), so that is
-    the launch shape timed here: the kernel alone, HIP events on the launch stream."""
+def _time_conv_launch(images, h, iters):
+    """Average duration (ms) of ONE 3x3 stride-1 512->512 forward launch over `images` h x h maps: the kernel alone, HIP events on
+    the launch stream, back-to-back launches on random data."""
     from hoig_amd import ops
-    h = side // 8
-    batch = 2 * batch
-    x = torch.randn(batch, h, h, 512, device='cuda')
+    import types
+    x = torch.randn(images, h, h, 512, device='cuda')
     w = ops.pack_weight(torch.randn(512, 512, 3, 3, device='cuda') * 0.02)
     # a weight outside a ParamTree has no version, so ops would re-split it on every call; give it a constant one so that
     # the timed loop launches the convolution kernel only (in the training step the split happens once per optimiser step)
-    import types
     w._hoig_owner = types.SimpleNamespace(version=0, packed_planes=lambda w_, for_dgrad: None)
     for _ in range(10):
         ops.conv2d(x, w, None, 1, 1)
@@ -59,8 +55,27 @@ def dominant_kernel_roofline(batch, side, precision, iters=50):
         ops.conv2d(x, w, None, 1, 1)
     e.record()
     torch.cuda.synchronize()
-    ms = s.elapsed_time(e) / iters
-    flops = 2.0 * batch * h * h * 512 * 512 * 9            # algorithmic: 2*M*N*K, M=B*h*h, N=512, K=9*512
+    return s.elapsed_time(e) / iters
+
+
+def dominant_kernel_roofline(batch, side, precision, iters=50):
+    """The dominant kernel of the step is the 3x3 stride-1 512->512 convolution at side/8 (72 of ~260 conv calls of a
+    forward, 44% of G's MACs).  The step launches it in TWO shapes (profiles/r04_conv_table.txt): 24 times
+    over 2*batch images -- bg_model and obj_model process the src and the tsf batch STACKED -- and 30 times over batch images
+    (src_model and tsf_model, separate weights, side by side on two streams, sized for half the chip each).  Both are timed
+    here, alone; `achieved` is the kernel's average over the launches of a step (flops of the 24 + 30 launches / their time),
+    so that the friendlier shape does not stand for the whole; each shape is listed under `launch_shapes`."""
+    h = side // 8
+    shapes = []
+    for images, calls in ((2 * batch, 24), (batch, 30)):
+        ms = _time_conv_launch(images, h, iters)
+        flops = 2.0 * images * h * h * 512 * 512 * 9        # algorithmic: 2*M*N*K, M=images*h*h, N=512, K=9*512
+        shapes.append(dict(images=images, calls_per_step=calls, avg_launch_ms=round(ms, 4), algorithmic_flop_per_launch=flops,
+                           achieved=round(flops / (ms * 1e-3) / 1e12, 2)))
+    batch2 = 2 * batch
+    ms = shapes[0]['avg_launch_ms']
+    flops_step = sum(sh['calls_per_step'] * sh['algorithmic_flop_per_launch'] for sh in shapes)
+    ms_step = sum(sh['calls_per_step'] * sh['avg_launch_ms'] for sh in shapes)
     # HBM/fabric traffic of this kernel comes from separate rocprofv3 --pmc passes (FETCH_SIZE and WRITE_SIZE cannot
     # share a pass); the committed summary is attached when it was taken on the same kernel and shape
     traffic, traffic_source = None, None
@@ -74,22 +89,26 @@ def dominant_kernel_roofline(batch, side, precision, iters=50):
             pmc = json.load(open(os.path.join(ROOT, 'profiles', fn)))
         except Exception:
             continue
-        if want and pmc.get('kernel_filter', 'conv_halo3_bf16_kernel') == want and batch == 16 and side == 256 and \
+        if want and pmc.get('kernel_filter', 'conv_halo3_bf16_kernel') == want and batch2 == 16 and side == 256 and \
                 'traffic_bytes_per_launch' in pmc:
             traffic = pmc['traffic_bytes_per_launch']
-            traffic_source = ('profiles/%s: separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes over this kernel and shape, '
-                              'committed; NOT measured in this run (counters cannot be read from inside the process)' % fn)
+            traffic_source = ('profiles/%s: separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes over this kernel on its %d-image '
+                              'launch, committed; NOT measured in this run (counters cannot be read from inside the process)' % (fn, batch2))
             break
-    achieved = flops / (ms * 1e-3) / 1e12
+    achieved = flops_step / (ms_step * 1e-3) / 1e12
     fwd = precision.partition(':')[0]
     peak = PEAK_F32 if fwd == 'f32' else PEAK_16
+    for sh in shapes:
+        sh['frac'] = round(sh['achieved'] / peak, 4)
     nsx = {3: 2, 2: 3, 1: 1}[MFMA_TERMS[fwd]] if fwd not in ('f32', 'f16f6') else 0
     kname = ('igemm_f32_kernel' if fwd == 'f32' else 'conv_halo3_f6_kernel' if fwd == 'f16f6' else
              ('conv_halo3_m16_kernel<%d,4,2,128,true>' % nsx if m16 else 'conv_halo3_bf16_kernel<%d,4,2,128,2,true>' % nsx))
-    return dict(bound='mfma', kernel='%s (conv3x3 s1 512->512 @%dx%d, %d images = src+tsf stacked)' % (kname, h, h, batch),
+    return dict(bound='mfma', kernel='%s (conv3x3 s1 512->512 @%dx%d; per step 24 launches over %d images = src+tsf stacked and 30 over %d)'
+                % (kname, h, h, batch2, batch),
                 achieved=round(achieved, 2), peak=peak, unit='TFLOP/s', mfma_terms_per_product=MFMA_TERMS[fwd],
-                frac=round(achieved / peak, 4), traffic=traffic, traffic_source=traffic_source, avg_launch_ms=round(ms, 4),
-                algorithmic_flop_per_launch=flops)
+                frac=round(achieved / peak, 4), traffic=traffic, traffic_source=traffic_source,
+                avg_launch_ms=round(ms_step / sum(sh['calls_per_step'] for sh in shapes), 4),
+                algorithmic_flop_per_launch=flops_step / sum(sh['calls_per_step'] for sh in shapes), launch_shapes=shapes)
 
 
 def gen_forward_latency(opt, batch, side, iters=10):
@@ -248,7 +267,7 @@ def self_launch(args):
     prints the JSON line) and return its exit code."""
     import subprocess
     n_vis = torch.cuda.device_count()
-    if n_vis < args.gpus:
+    if n_vis < args.gpus and not args.dry_run_cpu:
         sys.stderr.write('bench.py: --gpus %d requested but only %d GPU(s) are visible; refusing to run a smaller job under '
                          'that label\n' % (args.gpus, n_vis))
         return 2
@@ -256,6 +275,35 @@ def self_launch(args):
            '--master-addr', '127.0.0.1', '--master-port', str(_free_port()), os.path.abspath(__file__)] + sys.argv[1:]
     env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get('HSA_ENABLE_IPC_MODE_LEGACY', '0'))
     return subprocess.call(cmd, env=env)
+
+
+def dry_run_cpu(args, rank, world):
+    """The N-rank protocol of the real run without a GPU (gloo): W untimed + K timed "steps" (rank r sleeps (r + 1) ms: the slowest
+    rank must set the time), barriers on both sides, MAX over ranks, ONE JSON line on rank 0 -- labelled, with no throughput in it."""
+    if world > 1:
+        os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+        dist.init_process_group(backend='gloo')
+    step = lambda: time.sleep(1e-3 * (rank + 1))
+    barrier = (lambda: dist.barrier()) if world > 1 else (lambda: None)
+    for _ in range(args.warmup):
+        step()
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    barrier()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([dt], dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+    if rank == 0:
+        print(json.dumps({'metric': 'DRY RUN (no GPU work): launcher / barrier / max-over-ranks protocol only', 'value': None,
+                          'unit': None, 'dry_run': True, 'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
+                          'ms_per_step': round(dt / max(1, args.steps) * 1e3, 3), 'scaling': 'weak', 'data': 'none',
+                          'config': {'workload': 'sleep((rank + 1) ms) per step', 'parallelism': 'dp%d' % world}}))
+    if world > 1:
+        dist.destroy_process_group()
 
 
 def main():
@@ -278,6 +326,9 @@ def main():
     ap.add_argument('--fwd-batch', type=int, default=32, help='batch of the generator-forward latency leg')
     ap.add_argument('--cpu-baseline-worker', type=int, default=0, help=argparse.SUPPRESS)
     ap.add_argument('--cpu-budget', type=int, default=150, help='wall seconds the CPU-baseline child may use')
+    ap.add_argument('--dry-run-cpu', action='store_true',
+                    help='no GPU work: run the launcher / rank / barrier / max-over-ranks / rank-0-JSON protocol over gloo with a sleep '
+                         'as the "step" (tests/test_host_cpu.py); the line it prints is labelled a dry run and carries no throughput')
     args = ap.parse_args()
     if args.cpu_baseline_worker:
         return cpu_baseline_worker(args.cpu_baseline_worker, args.cpu_budget)
@@ -289,6 +340,8 @@ def main():
     world = int(os.environ.get('WORLD_SIZE', 1))
     if world != args.gpus:
         sys.exit('bench.py: --gpus %d but the launcher started WORLD_SIZE=%d ranks' % (args.gpus, world))
+    if args.dry_run_cpu:
+        return dry_run_cpu(args, rank, world)
     if torch.cuda.device_count() <= local_rank:
         sys.exit('bench.py: rank %d has no GPU (%d visible)' % (rank, torch.cuda.device_count()))
     ddp = world > 1

@@ -107,6 +107,8 @@ struct HaloArgs {
     int n1;
     const float *addend;       // same shape as C (single-output launches only): C = conv + addend -- the data gradient that lands in
                                // a tensor with a second consumer adds that consumer's gradient itself (ops.conv2d_fork)
+    int a_split;               // 1: A is a PRE-SPLIT tensor, per pixel [hi: Cg bf16][lo: Cg bf16] (hoig_split_planes_bf16): the 3x3
+                               // stride-1 data gradient on conv_halo16.hip copies it to LDS without splitting (no A2 then)
     float *stats;              // (nullable) [Bn][2][N] fp32 accumulators: += per-image, per-channel sum and sum of squares of the
                                // values written to C -- the statistics of the instance norm that reads C next
 #ifdef HOIG_STAMP
@@ -229,6 +231,10 @@ struct WHaloArgs {
 // wgrad_halo16.hip: the stride-1 3x3 weight gradient on v_mfma_f32_16x16x32 (`a` carries the tiling: th = 2 or 4 pixel rows per
 // tile, cm = 1 or 2 groups of 64 dy channels per workgroup); HOIG_EUNSUPPORTED for what it has no variant for
 int launch_wgrad_halo_m16(const WHaloArgs &a, int ns, int th, int cm, dim3 grid, hipStream_t st);
+
+// wgrad_dma.hip: the stride-1 3x3 weight gradient from PRE-SPLIT dy (a.DY points at [pixel][2][Co] bf16: hoig_split_planes_bf16 or a
+// producer's epilogue), staged by LDS-DMA into double-buffered tiles; `a` carries the 4 x 32-pixel tiling; HOIG_EUNSUPPORTED otherwise
+int launch_wgrad_dma(const WHaloArgs &a, int ns, dim3 grid, hipStream_t st);
 
 // conv_halo16.hip: the 3x3 stride-1 halo kernel on v_mfma_f32_16x16x32 (8 rows x 32 pixels x bn channels per workgroup, bn = 128
 // or 64; `a` carries that tiling's geometry); HOIG_EUNSUPPORTED for shapes it has no tiling for

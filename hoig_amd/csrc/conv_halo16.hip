@@ -78,7 +78,11 @@ struct M16Layout {
     static constexpr size_t bytes(int nsx) { return (size_t)ns_a(nsx) * PLANE_P + 2 * 3 * ns_b(nsx) * PLANE_W; }
 };
 
-template <int NSX, int WM, int WN, int BN, bool F16>
+// ASPLIT (data-gradient launches, round 5): the gathered tensor arrives PRE-SPLIT -- per pixel [hi: Cg bf16][lo: Cg bf16], written by
+// the producer of that gradient (hoig_split_planes_bf16; the backward of a norm) -- and the halo goes global -> registers -> LDS in
+// 16-B pieces with no VALU work: the split of a 32-channel block (ten VALU instructions and two ds_write_b64 per 16 B of input,
+// between two barriers, beside nobody's MFMAs) is gone, as is the same split in every other workgroup that reads these pixels.
+template <int NSX, int WM, int WN, int BN, bool F16, bool ASPLIT = false>
 __global__ __launch_bounds__(64 * WM * WN) void conv_halo3_m16_kernel(const HaloArgs p) {
     constexpr int NS = NSX == 1 ? 1 : 2, NB = NSX == 2 ? 2 : 1;      // operand planes: pixels (activations / dy), weights
     using LY = M16Layout<WM, BN>;
@@ -168,6 +172,24 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_halo3_m16_kernel(const Halo
     constexpr int HSLICES = (HPIX * 8 + NT - 1) / NT;
     float4 hreg[HSLICES];
     auto halo_load = [&](int cb) {
+        if constexpr (ASPLIT) {
+            // slice i -> (pixel i >> 3, plane (i >> 2) & 1, 16-B chunk i & 3 of the block's 32 channels)
+            const unsigned short *Aimg = reinterpret_cast<const unsigned short *>(p.A) + (size_t)b * p.H * p.W * 2 * p.Cg + cb * 32;
+#pragma unroll
+            for (int sl = 0; sl < HSLICES; ++sl) {
+                const int i = tid + NT * sl;
+                float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (i < HPIX * 8 && (NS == 2 || !(i & 4))) {
+                    const int pix = i >> 3, plane = (i >> 2) & 1, c8 = i & 3;
+                    const int hy = pix / HW, hx = pix - hy * HW;
+                    const int gy = y0 - p.pad + hy, gx = x0 - p.pad + hx;
+                    if (gy >= 0 && gy < p.H && gx >= 0 && gx < p.W)
+                        v = *reinterpret_cast<const float4 *>(Aimg + ((size_t)gy * p.W + gx) * 2 * p.Cg + plane * p.Cg + c8 * 8);
+                }
+                hreg[sl] = v;
+            }
+            return;
+        }
         const bool second = p.A2 != nullptr && cb * 32 >= p.cg1;
         const int ld = p.A2 ? (second ? p.Cg - p.cg1 : p.cg1) : p.Cg;
         const float *Aimg = (second ? p.A2 : p.A) + (size_t)b * p.H * p.W * ld + (second ? cb * 32 - p.cg1 : cb * 32);
@@ -187,6 +209,17 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_halo3_m16_kernel(const Halo
     };
     auto halo_store = [&]() {
         unsigned char *Ph = Pbase, *Pl = Ph + PLANE_P;
+        if constexpr (ASPLIT) {
+#pragma unroll
+            for (int sl = 0; sl < HSLICES; ++sl) {
+                const int i = tid + NT * sl;
+                if (i < HPIX * 8 && (NS == 2 || !(i & 4))) {
+                    const int pix = i >> 3, plane = (i >> 2) & 1, c8 = i & 3;
+                    *reinterpret_cast<float4 *>(Pbase + plane * PLANE_P + (c8 >> 1) * P23 + pix * 32 + (c8 & 1) * 16) = hreg[sl];
+                }
+            }
+            return;
+        }
 #pragma unroll
         for (int sl = 0; sl < HSLICES; ++sl) {
             const int i = tid + NT * sl;
@@ -608,6 +641,22 @@ int launch_one(const HaloArgs &a, hipStream_t st) {
                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm) != hipSuccess)
             return HOIG_ELAUNCH;
         once.set();
+    }
+    if (a.a_split) {                                       // pre-split gathered tensor: bf16 data-gradient launches without x split
+        if constexpr (NS == 2) return HOIG_EUNSUPPORTED;
+        else {
+            if (a.f16 || a.A2) return HOIG_EUNSUPPORTED;
+            static hoig_once once_s;
+            if (!once_s.done()) {
+                if (hipFuncSetAttribute(reinterpret_cast<const void *>(&conv_halo3_m16_kernel<NS, WM, WN, BN, false, true>),
+                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm) != hipSuccess)
+                    return HOIG_ELAUNCH;
+                once_s.set();
+            }
+            conv_halo3_m16_kernel<NS, WM, WN, BN, false, true><<<a.nblk, 64 * WM * WN, shm, st>>>(a);
+            HOIG_LAUNCH_CHECK();
+            return HOIG_OK;
+        }
     }
     if (a.f16) conv_halo3_m16_kernel<NS, WM, WN, BN, true><<<a.nblk, 64 * WM * WN, shm, st>>>(a);
     else conv_halo3_m16_kernel<NS, WM, WN, BN, false><<<a.nblk, 64 * WM * WN, shm, st>>>(a);

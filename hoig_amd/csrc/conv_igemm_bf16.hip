@@ -1110,6 +1110,7 @@ int launch_halo3(HaloArgs a, int ns, hipStream_t st) {
             a.nblk = a.Bn * a.tiles_x * a.tiles_y * a.nblk_n;
             return launch_halo3_m16(a, ns, 64, st);
         }
+        if (a.a_split) return HOIG_EUNSUPPORTED;               // (pre-split input: conv_halo16.hip only)
         HOIG_NS_SWITCH(ns, return launch_halo3_one<NSX, 2, 2, 64, 0>(a, st));
     }
     if (m16 && hoig_tuning(HOIG_TUNE_FEW128) != 0 && a.H % 8 == 0 && a.nblk / 2 < 256 && a.nblk >= 192 && a.N % 128 == 0) {
@@ -1124,6 +1125,7 @@ int launch_halo3(HaloArgs a, int ns, hipStream_t st) {
         a.nblk_n = a.N / 64;
         a.nblk = a.Bn * a.tiles_x * a.tiles_y * a.nblk_n;
         if (m16) return launch_halo3_m16(a, ns, 64, st);
+        if (a.a_split) return HOIG_EUNSUPPORTED;
         HOIG_NS_SWITCH(ns, return launch_halo3_one<NSX, 4, 2, 64, 2>(a, st));
     }
     // 8 x 32 pixel tiles (8 waves, weight tile shared by 256 pixels) when that still gives every CU a workgroup
@@ -1131,8 +1133,10 @@ int launch_halo3(HaloArgs a, int ns, hipStream_t st) {
         a.tiles_y = a.H / 8;
         a.nblk = a.Bn * a.tiles_x * a.tiles_y * a.nblk_n;
         if (m16) return launch_halo3_m16(a, ns, 128, st);
+        if (a.a_split) return HOIG_EUNSUPPORTED;
         HOIG_NS_SWITCH(ns, return launch_halo3_one<NSX, 4, 2, 128, 2>(a, st));
     }
+    if (a.a_split) return HOIG_EUNSUPPORTED;
     const bool wide = a.nblk < 384;
     HOIG_NS_SWITCH(ns, return wide ? launch_halo3_one<NSX, 2, 4, 128, 1>(a, st) : launch_halo3_one<NSX, 2, 2, 128, 0>(a, st));
     return HOIG_EINVAL;
@@ -1598,7 +1602,7 @@ int launch_dgrad_thin(const float *dy, const unsigned short *wh, const unsigned 
 
 int run(const hoig_conv_desc *d, const float *a, const unsigned short *wh, const unsigned short *wl, const float *bias,
         float *c, bool dgrad, hipStream_t st, const float *a2 = nullptr, int cg1 = 0, float *c2 = nullptr, int n1 = 0,
-        const float *addend = nullptr, float *stats = nullptr) {
+        const float *addend = nullptr, float *stats = nullptr, bool a_split = false) {
     Args p;
     p.A = a; p.Wh = wh; p.Wl = wl; p.bias = bias; p.C = c;
     p.f16 = dgrad ? 0 : 1;                       // forward: fp16-split operands over the 2^8-scaled forward planes
@@ -1636,6 +1640,8 @@ int run(const hoig_conv_desc *d, const float *a, const unsigned short *wh, const
         h.A2 = a2; h.cg1 = cg1; h.C2 = c2; h.n1 = n1;
         h.addend = addend;
         h.stats = stats;
+        h.a_split = a_split ? 1 : 0;
+        if (a_split && (d->R != 3 || a2 || !dgrad)) return HOIG_EUNSUPPORTED;
         if ((addend || stats) && c2) return HOIG_EUNSUPPORTED;
         if (stats && d->R != 3) return HOIG_EUNSUPPORTED;          // (only the 3x3 kernel has the statistics epilogue)
         if ((a2 || c2) && d->R != 3) return HOIG_EUNSUPPORTED;
@@ -1650,7 +1656,7 @@ int run(const hoig_conv_desc *d, const float *a, const unsigned short *wh, const
         if (d->R == 3) return launch_halo3(h, ns, st);
         return launch_halo<5>(h, ns, st);
     }
-    if (a2 || c2) return HOIG_EUNSUPPORTED;
+    if (a2 || c2 || a_split) return HOIG_EUNSUPPORTED;
     // 3x3 "same" layers with too few tiles for the halo kernel above (N = 128 at 32 x 32: the data gradient of SPADE's 128 -> 1024
     // convolutions): a valid convolution over the zero-padded canvas on the flattened-axis kernel, split over the channel blocks
     if (hoig_tuning(HOIG_TUNE_FLAT5) >= 2 && !d->transposed && d->stride == 1 && d->R == 3 && d->S == 3 && d->pad == 1 &&
@@ -1690,7 +1696,7 @@ int run(const hoig_conv_desc *d, const float *a, const unsigned short *wh, const
             h.A = a; h.Wh = wh; h.Wl = wl; h.bias = bias; h.C = c;
             h.Bn = d->B; h.Cg = g.Cg; h.N = p.N; h.K = p.K;
             h.pad = 1; h.flip = 0;
-            h.A2 = nullptr; h.cg1 = 0; h.C2 = nullptr; h.n1 = 0; h.addend = addend; h.stats = stats;
+            h.A2 = nullptr; h.cg1 = 0; h.C2 = nullptr; h.n1 = 0; h.addend = addend; h.stats = stats; h.a_split = 0;
             h.act = p.act; h.slope = p.slope;
             h.f16 = p.f16; h.oscale = p.oscale;
             const bool gather = !g.gatherT;      // the operand is read at 2*o - 1 + tap (fine grid) -> gather mode
@@ -1795,6 +1801,16 @@ extern "C" int hoig_conv2d_bwd_data_packed_add(const hoig_conv_desc *d, const fl
     if (!d || !dy || !wt_hi || !dx || !addend) return HOIG_EINVAL;
     if (!is_16bit_precision(d->precision)) return HOIG_EINVAL;
     return run(d, dy, wt_hi, wt_lo, nullptr, dx, true, (hipStream_t)stream, nullptr, 0, nullptr, 0, addend);
+}
+
+// data gradient (+ addend, nullable) from PRE-SPLIT dy (include/hoig_kernels.h): the 3x3 stride-1 "same" layers on conv_halo16.hip
+extern "C" int hoig_conv2d_bwd_data_packed_split(const hoig_conv_desc *d, const uint16_t *dy_split, const uint16_t *wt_hi,
+                                                 const uint16_t *wt_lo, const float *addend, float *dx, hoig_stream_t stream) {
+    if (!d || !dy_split || !wt_hi || !dx) return HOIG_EINVAL;
+    if (!is_16bit_precision(d->precision)) return HOIG_EINVAL;
+    if (d->precision == HOIG_PREC_BF16X3 || d->transposed || d->stride != 1 || d->R != 3 || d->S != 3) return HOIG_EUNSUPPORTED;
+    return run(d, reinterpret_cast<const float *>(dy_split), wt_hi, wt_lo, nullptr, dx, true, (hipStream_t)stream, nullptr, 0, nullptr, 0,
+               addend, nullptr, true);
 }
 
 // conv(cat[x1, x2]) and its data gradient [dx1 | dx2] without materialising the concatenation (3x3 stride-1 "same" only)
@@ -2351,7 +2367,7 @@ __global__ __launch_bounds__(128 * KS * CM) void wgrad_halo_bf16_kernel(const WH
 }
 
 int launch_wgrad_halo(const hoig_conv_desc *d, const float *x, const float *dy, float *dw, float *dbias, int ns,
-                      hipStream_t st, const float *x2 = nullptr, int ci1 = 0) {
+                      hipStream_t st, const float *x2 = nullptr, int ci1 = 0, bool dy_split = false) {
     WHaloArgs a;
     a.DY = dy; a.X = x; a.DW = dw; a.DB = dbias; a.X2 = x2; a.ci1 = ci1;
     a.Bn = d->B; a.H = d->Ho; a.W = d->Wo; a.Co = d->Co; a.Ci = d->Ci;
@@ -2371,7 +2387,8 @@ int launch_wgrad_halo(const hoig_conv_desc *d, const float *x, const float *dy, 
     // 4-row pixel tiles for the stride-1 3x3 layers on 128-channel workgroups, where every workgroup still gets >= 8 of them
     constexpr int th_env = 4;
     const bool th4 = th_env == 4 && cm == 2 && d->R == 3 && !s2 && !d->transposed && ns != 2 && a.H % 4 == 0 &&
-                     (int64_t)a.Bn * (a.W / 32) * (a.H / 4) * a.nblk >= 8 * 256;
+                     ((int64_t)a.Bn * (a.W / 32) * (a.H / 4) * a.nblk >= 8 * 256 || dy_split);
+    if (dy_split && (!th4 || dbias)) return HOIG_EUNSUPPORTED;      // (pre-split dy: the LDS-DMA kernel only, wgrad_dma.hip)
     a.tiles_x = a.W / 32;
     a.tiles_y = a.H / (th4 ? 4 : 2);
     a.n_mtiles = a.Bn * a.tiles_x * a.tiles_y;
@@ -2389,6 +2406,7 @@ int launch_wgrad_halo(const hoig_conv_desc *d, const float *x, const float *dy, 
 #ifdef HOIG_STAMP
     a.dbg = g_stamp_buf;
 #endif
+    if (dy_split) return launch_wgrad_dma(a, ns, grid, st);
     if (hoig_tuning(HOIG_TUNE_WGRAD16) != 0 && d->R == 3 && !s2 && !d->transposed) {      // on v_mfma_f32_16x16x32 (wgrad_halo16.hip)
         const int rc = launch_wgrad_halo_m16(a, ns, th4 ? 4 : 2, cm, grid, st);
         if (rc != HOIG_EUNSUPPORTED) return rc;
@@ -2471,6 +2489,17 @@ int hoig_conv_bf16_wgrad(const hoig_conv_desc *d, const float *x, const float *d
     if (hoig_conv_bf16_wgrad_fuses_bias(d)) return launch_wgrad_halo(d, x, dy, dw, dbias, ns, st);
     if (a.Co <= 64) return launch_wgrad_bf16<64>(a, ns, st);
     return launch_wgrad_bf16<128>(a, ns, st);
+}
+
+// weight gradient from PRE-SPLIT dy (include/hoig_kernels.h): the stride-1 "same" 3x3 layers the LDS-DMA kernel covers
+extern "C" int hoig_conv2d_bwd_weight_split(const hoig_conv_desc *d, const float *x, const uint16_t *dy_split, float *dw,
+                                            hoig_stream_t stream) {
+    if (!d || !x || !dy_split || !dw) return HOIG_EINVAL;
+    if (!is_16bit_precision(d->precision) || d->precision == HOIG_PREC_BF16X3 || d->transposed || d->stride != 1 || d->R != 3 ||
+        d->S != 3 || !hoig_conv_bf16_wgrad_fuses_bias(d) || (d->Co & 127))
+        return HOIG_EUNSUPPORTED;
+    return launch_wgrad_halo(d, x, reinterpret_cast<const float *>(dy_split), dw, nullptr, ns_of_precision(d->precision),
+                             (hipStream_t)stream, nullptr, 0, true);
 }
 
 // weight gradient of conv(cat[x1, x2]) (3x3 stride-1 "same", bf16 halo kernel only)

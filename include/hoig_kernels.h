@@ -73,6 +73,21 @@ int hoig_conv2d_bwd_data(const hoig_conv_desc *d, const float *dy, const float *
 int hoig_conv2d_bwd_weight(const hoig_conv_desc *d, const float *x, const float *dy, float *dw, float *dbias,
                            hoig_stream_t stream);
 
+/* PRE-SPLIT gradients (round 5).  The two-term backward arithmetic (HOIG_PREC_F16X2) multiplies bf16(dy) and bf16(dy - bf16(dy)) with
+ * one bf16 plane of the other operand; the kernels above make that split of every dy tile in every workgroup that loads it.  A "split
+ * tensor" holds it once: for an fp32 NHWC tensor [.., C] the same 4 bytes per element laid out per pixel as [hi: C x bf16][lo: C x bf16].
+ * hoig_split_planes_bf16 converts (C % 4 == 0); producers of gradients (hoig_inorm_tile_bwd_split ...) write it directly.  The
+ * consumers below compute exactly what their fp32-dy counterparts compute (same two MFMA terms, same accumulation order).
+ * hoig_conv2d_bwd_weight_split: stride-1 "same" 3x3 layers with Wo % 32 == 0, Ho % 4 == 0, Co % 128 == 0, Ci % 32 == 0 in
+ * HOIG_PREC_F16X2 / HOIG_PREC_BF16 (the lo plane is not read then), no bias gradient; HOIG_EUNSUPPORTED otherwise. */
+int hoig_split_planes_bf16(const float *x, uint16_t *out, int64_t npix, int C, hoig_stream_t stream);
+int hoig_conv2d_bwd_weight_split(const hoig_conv_desc *d, const float *x, const uint16_t *dy_split, float *dw, hoig_stream_t stream);
+/* dx = data gradient (+ addend when non-null: hoig_conv2d_bwd_data_packed_add) of a stride-1 "same" 3x3 Conv2d from pre-split dy, on the
+ * 8-row tilings of the v_mfma_f32_16x16x32 kernel (Hi % 8 == 0, Wi % 32 == 0 and enough tiles: HOIG_EUNSUPPORTED otherwise -- the
+ * caller then converts nothing and uses the fp32 entry points). */
+int hoig_conv2d_bwd_data_packed_split(const hoig_conv_desc *d, const uint16_t *dy_split, const uint16_t *wt_hi, const uint16_t *wt_lo,
+                                      const float *addend /*nullable*/, float *dx, hoig_stream_t stream);
+
 /* Forward of a stride-1 'same' convolution with <= 16 output channels over Ci % 64 == 0 inputs and ONE activation PER OUTPUT
  * CHANNEL (acts: the HOIG_ACT_* code of channel f in bits [4f, 4f+4)): the generator's image / mask heads (generator.py:219-235,
  * 311-315: tanh image, sigmoid masks) evaluated as one convolution over the decoder's last feature map.  7x7 with <= 5

@@ -211,3 +211,28 @@ def test_bench_refuses_mislabelled_multi_gpu_runs():
     r = subprocess.run([sys.executable, os.path.join(root, 'bench.py'), '--gpus', '2', '--steps', '1', '--warmup', '0'],
                        env=env, capture_output=True, text=True, timeout=300)
     assert r.returncode != 0 and 'WORLD_SIZE=4' in r.stderr + r.stdout
+
+
+def test_bench_launcher_child_forwards_rank0_json_and_the_exit_code():
+    """`python bench.py --gpus 2` started plainly launches torch.distributed.run as a CHILD and forwards what rank 0 prints and the
+    child's exit code (VERDICT r4 item 8).  Exercised without a GPU through --dry-run-cpu: two ranks over gloo run the real run's
+    protocol (warm-up, barrier, K timed steps, barrier, MAX over ranks, one JSON line on rank 0) with a sleep as the step; rank 1
+    sleeps 2 ms per step, rank 0 one -- the line must carry the SLOWER rank's time."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ('WORLD_SIZE', 'RANK', 'LOCAL_RANK', 'MASTER_ADDR', 'MASTER_PORT')}
+    r = subprocess.run([sys.executable, os.path.join(root, 'bench.py'), '--gpus', '2', '--steps', '20', '--warmup', '2', '--dry-run-cpu'],
+                       env=env, capture_output=True, text=True, timeout=300, cwd='/tmp')
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith('{')]
+    assert len(lines) == 1, r.stdout                                     # ONE line, from rank 0 only
+    out = json.loads(lines[0])
+    assert out['dry_run'] is True and out['value'] is None and out['n_gpus'] == 2 and out['steps'] == 20 and out['warmup'] == 2
+    assert out['config']['parallelism'] == 'dp2' and out['ms_per_step'] >= 2.0, out       # max over ranks, not rank 0's own 1 ms
+    # a rank that fails takes the job down and the parent reports it: WORLD_SIZE / --gpus mismatch inside the child
+    r = subprocess.run([sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', '2', '--master-addr', '127.0.0.1',
+                        '--master-port', '29671', os.path.join(root, 'bench.py'), '--gpus', '3', '--dry-run-cpu'],
+                       env=env, capture_output=True, text=True, timeout=300, cwd='/tmp')
+    assert r.returncode != 0 and 'WORLD_SIZE=2' in r.stderr + r.stdout

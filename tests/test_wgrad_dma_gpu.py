@@ -1,0 +1,104 @@
+"""The weight gradient from PRE-SPLIT dy (hoig_amd/csrc/wgrad_dma.hip): `hoig_split_planes_bf16` makes exactly the
+two bf16 values the register kernel's in-kernel split makes, and `hoig_conv2d_bwd_weight_split` -- dy tiles copied global -> LDS by
+LDS-DMA into double-buffered, XOR-swizzled images -- sums the same products as `hoig_conv2d_bwd_weight`: compared with that kernel (same
+arithmetic: agreement to the order of the fp32 atomics) and with a float64 reference of the convolution's weight gradient."""
+import ctypes
+
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def _p(t):
+    return ctypes.c_void_p(t.data_ptr())
+
+
+def _split_reference(x):
+    hi = x.to(torch.bfloat16)
+    lo = (x - hi.float()).to(torch.bfloat16)
+    return torch.stack([hi, lo], dim=-2)                    # [..., 2, C]
+
+
+def test_split_planes_are_the_kernels_own_split():
+    from hoig_amd import _lib as L
+    g = torch.Generator(device='cuda').manual_seed(1)
+    for shape in ((3, 5, 7, 64), (1, 32, 32, 512), (2, 1, 3, 4)):
+        x = torch.randn(shape, device='cuda', generator=g) * torch.logspace(-6, 3, shape[-1], device='cuda')
+        out = torch.empty(shape[:-1] + (2, shape[-1]), dtype=torch.bfloat16, device='cuda')
+        L.call('hoig_split_planes_bf16', _p(x), _p(out), x.numel() // shape[-1], shape[-1], torch.cuda.current_stream().cuda_stream)
+        want = _split_reference(x)
+        assert torch.equal(out.view(torch.int16), want.view(torch.int16)), shape
+        # hi + lo reproduces x to 2^-16 relative
+        assert ((out[..., 0, :].float() + out[..., 1, :].float() - x).abs() <= x.abs() * 2.0 ** -15).all()
+
+
+@pytest.mark.parametrize('shape', [(2, 32, 32, 64, 128), (3, 32, 64, 96, 256), (16, 32, 32, 512, 512), (1, 8, 32, 32, 128),
+                                   (2, 36, 96, 32, 128)])
+@pytest.mark.parametrize('prec', ['f16x2', 'bf16'])
+def test_weight_gradient_from_split_dy(shape, prec):
+    from hoig_amd import _lib as L, ops
+    B, H, W, Ci, Co = shape
+    if prec == 'bf16' and Ci * Co > 128 * 128:
+        pytest.skip('one large case per arithmetic is enough')
+    g = torch.Generator(device='cuda').manual_seed(B * 1000 + Ci)
+    x = torch.randn(B, H, W, Ci, device='cuda', generator=g)
+    dy = torch.randn(B, H, W, Co, device='cuda', generator=g) * 0.1
+    dys = torch.empty(B, H, W, 2, Co, dtype=torch.bfloat16, device='cuda')
+    st = torch.cuda.current_stream().cuda_stream
+    L.call('hoig_split_planes_bf16', _p(dy), _p(dys), B * H * W, Co, st)
+    d = L.ConvDesc(B, H, W, Ci, H, W, Co, 3, 3, 1, 1, 0, L.ACT_NONE, 0.0, ops._PREC[prec])
+    dw_ref = torch.zeros(Co, 3, 3, Ci, device='cuda')
+    ops.wgrad_call('hoig_conv2d_bwd_weight', ctypes.byref(d), _p(x), _p(dy), _p(dw_ref), None, st)
+    dw = torch.zeros(Co, 3, 3, Ci, device='cuda')
+    for _ in range(2):                                       # twice: the kernel ACCUMULATES into dw
+        L.call('hoig_conv2d_bwd_weight_split', ctypes.byref(d), _p(x), _p(dys), _p(dw), st)
+    torch.cuda.synchronize()
+    scale = dw_ref.abs().max().item()
+    assert (dw - 2 * dw_ref).abs().max().item() <= 2e-5 * scale, (dw - 2 * dw_ref).abs().max().item() / scale
+    if B * H * W * Ci * Co <= 3 * 32 * 64 * 96 * 256:
+        want = torch.nn.grad.conv2d_weight(x.cpu().double().permute(0, 3, 1, 2), (Co, Ci, 3, 3), dy.cpu().double().permute(0, 3, 1, 2),
+                                           padding=1).permute(0, 2, 3, 1).float().cuda()
+        rel = ((dw * 0.5 - want).norm() / want.norm()).item()
+        assert rel < (3e-3 if prec == 'f16x2' else 6e-3), rel
+
+
+def test_split_entry_point_refuses_what_it_has_no_kernel_for():
+    from hoig_amd import _lib as L
+    x = torch.zeros(1, 32, 32, 32, device='cuda')
+    dys = torch.zeros(1, 32, 32, 2, 64, dtype=torch.bfloat16, device='cuda')
+    dw = torch.zeros(64, 3, 3, 32, device='cuda')
+    st = torch.cuda.current_stream().cuda_stream
+    for d in (L.ConvDesc(1, 32, 32, 32, 32, 32, 64, 3, 3, 1, 1, 0, L.ACT_NONE, 0.0, L.PREC_F16X2),           # Co % 128
+              L.ConvDesc(1, 32, 32, 32, 32, 32, 128, 3, 3, 1, 1, 0, L.ACT_NONE, 0.0, L.PREC_F32),            # exact arithmetic
+              L.ConvDesc(1, 32, 32, 32, 32, 32, 128, 3, 3, 1, 1, 0, L.ACT_NONE, 0.0, L.PREC_BF16X3),         # x split as well
+              L.ConvDesc(1, 30, 32, 32, 30, 32, 128, 3, 3, 1, 1, 0, L.ACT_NONE, 0.0, L.PREC_F16X2)):         # rows % 4
+        rc = L.lib.hoig_conv2d_bwd_weight_split(ctypes.byref(d), _p(x), _p(dys), _p(dw), st)
+        assert rc == L.EUNSUPPORTED, rc
+
+
+@pytest.mark.parametrize('shape', [(16, 32, 32, 512, 512), (8, 32, 32, 512, 512), (2, 64, 64, 256, 256), (2, 256, 256, 64, 64)])
+@pytest.mark.parametrize('with_addend', [False, True])
+def test_data_gradient_from_split_dy(shape, with_addend):
+    """hoig_conv2d_bwd_data_packed_split against hoig_conv2d_bwd_data_packed(_add) on the same values: the kernel is the same but for
+    how the halo reaches LDS, so the results are IDENTICAL (one workgroup per output tile, no atomics)."""
+    from hoig_amd import _lib as L, ops
+    B, H, W, Ci, Co = shape
+    g = torch.Generator(device='cuda').manual_seed(7 + B)
+    dy = torch.randn(B, H, W, Co, device='cuda', generator=g) * 0.1
+    w = ops.pack_weight(torch.randn(Co, Ci, 3, 3, device='cuda', generator=g) * 0.02)
+    add = torch.randn(B, H, W, Ci, device='cuda', generator=g) if with_addend else None
+    st = torch.cuda.current_stream().cuda_stream
+    dys = torch.empty(B, H, W, 2, Co, dtype=torch.bfloat16, device='cuda')
+    L.call('hoig_split_planes_bf16', _p(dy), _p(dys), B * H * W, Co, st)
+    thi, tlo = ops._packed_planes(w, False, True)
+    d = L.ConvDesc(B, H, W, Ci, H, W, Co, 3, 3, 1, 1, 0, L.ACT_NONE, 0.0, L.PREC_F16X2)
+    dx_ref, dx = torch.empty(B, H, W, Ci, device='cuda'), torch.empty(B, H, W, Ci, device='cuda')
+    if with_addend:
+        L.call('hoig_conv2d_bwd_data_packed_add', ctypes.byref(d), _p(dy), _p(thi), _p(tlo), _p(add), _p(dx_ref), st)
+    else:
+        L.call('hoig_conv2d_bwd_data_packed', ctypes.byref(d), _p(dy), _p(thi), _p(tlo), _p(dx_ref), st)
+    rc = L.lib.hoig_conv2d_bwd_data_packed_split(ctypes.byref(d), _p(dys), _p(thi), _p(tlo), _p(add) if with_addend else None, _p(dx), st)
+    assert rc == 0, rc
+    torch.cuda.synchronize()
+    assert torch.equal(dx, dx_ref), (dx - dx_ref).abs().max().item()

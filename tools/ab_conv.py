@@ -68,8 +68,15 @@ def main():
         fns = {
             'fwd': lambda: L.call('hoig_conv2d_fwd_packed', ctypes.byref(d), p(x), p(hi), p(lo), None, p(y), st),
             'dgrad': lambda: L.call('hoig_conv2d_bwd_data_packed', ctypes.byref(d_dg), p(dy), p(thi), p(tlo), p(dx), st),
-            'wgrad': lambda: L.call('hoig_conv2d_bwd_weight', ctypes.byref(d_wg), p(x), p(dy), p(dw), None, st),
+            'wgrad': lambda: ops.wgrad_call('hoig_conv2d_bwd_weight', ctypes.byref(d_wg), p(x), p(dy), p(dw), None, st),
         }
+        if 'wgrad_split' in a.kinds or 'split' in a.kinds or 'dgrad_split' in a.kinds:      # pre-split dy (round 5)
+            dys = torch.empty(B, Ho, Wo, 2, Co, dtype=torch.bfloat16, device='cuda')
+            fns['split'] = lambda: L.call('hoig_split_planes_bf16', p(dy), p(dys), B * Ho * Wo, Co, st)
+            fns['split']()
+            fns['wgrad_split'] = lambda: L.call('hoig_conv2d_bwd_weight_split', ctypes.byref(d_wg), p(x), p(dys), p(dw), st)
+            if hasattr(L.lib, 'hoig_conv2d_bwd_data_packed_split'):
+                fns['dgrad_split'] = lambda: L.call('hoig_conv2d_bwd_data_packed_split', ctypes.byref(d_dg), p(dys), p(thi), p(tlo), None, p(dx), st)
         flop = 2.0 * B * (H * W if tr else Ho * Wo) * Ci * Co * k * k
         for kind in a.kinds.split(','):
             fn = fns[kind]
