@@ -78,6 +78,9 @@ _SIGS = {
     'hoig_inorm_fwd_fused': [_vp, _i, _vp, _vp, _i, _i, _f, _vp, _f, _vp, _vp, _vp, _i, _i, _i, _vp],
     'hoig_inorm_bwd_fused': [_vp, _vp, _vp, _i, _vp, _vp, _i, _vp, _vp, _i, _f, _vp, _vp, _vp, _i, _i, _i, _vp],
     'hoig_inorm_bwd_add_ld': [_vp, _vp, _vp, _i, _vp, _vp, _i, _vp, _vp, _i, _f, _vp, _vp, _vp, _vp, _i, _i, _i, _vp, _vp],
+    'hoig_inorm_bwd_add_ld_split': [_vp, _vp, _vp, _i, _vp, _vp, _i, _vp, _vp, _i, _f, _vp, _vp, _vp, _vp, _i, _i, _i, _vp, _vp],
+    'hoig_inorm_bwd_fused_add_split': [_vp, _vp, _vp, _i, _vp, _vp, _i, _vp, _vp, _i, _f, _vp, _vp, _vp, _vp, _i, _i, _i, _vp],
+    'hoig_unsplit_planes_bf16': [_vp, _vp, _i64, _i, _vp],
     'hoig_inorm_bwd_fused_add': [_vp, _vp, _vp, _i, _vp, _vp, _i, _vp, _vp, _i, _f, _vp, _vp, _vp, _vp, _i, _i, _i, _vp],
     'hoig_inorm_bwd': [_vp, _vp, _vp, _i, _vp, _vp, _vp, _vp, _i, _f, _vp, _vp, _vp, _i, _i, _i, _vp, _vp],
     'hoig_replicate_pad_fwd': [_vp, _vp, _i, _i, _i, _i, _i, _vp],
@@ -158,6 +161,8 @@ def _load():
     lib.hoig_set_tuning.restype = ctypes.c_int
     lib.hoig_stream_scratch_bytes.argtypes = []
     lib.hoig_stream_scratch_bytes.restype = ctypes.c_int64
+    lib.hoig_conv2d_bwd_weight_scratch_bytes.argtypes = [ctypes.POINTER(ConvDesc)]
+    lib.hoig_conv2d_bwd_weight_scratch_bytes.restype = ctypes.c_int64
     lib.hoig_version.argtypes = []
     lib.hoig_version.restype = ctypes.c_char_p
     return lib

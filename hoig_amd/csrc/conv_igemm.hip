@@ -691,6 +691,13 @@ static int launch_wgrad(WgradArgs a, hipStream_t st) {
 int hoig_conv_bf16_wgrad(const hoig_conv_desc *d, const float *x, const float *dy, float *dw, float *dbias, hipStream_t st);
 bool hoig_conv_bf16_wgrad_fuses_bias(const hoig_conv_desc *d);
 
+bool hoig_conv_thin_wgrad_applies(const hoig_conv_desc *d);       // conv_thin.hip
+// bytes of per-stream scratch (hoig_stream_scratch_set) hoig_conv2d_bwd_weight wants for this layer: 0 for all but the thin-channel ones
+extern "C" int64_t hoig_conv2d_bwd_weight_scratch_bytes(const hoig_conv_desc *d) {
+    if (!d || check_desc(d)) return 0;
+    return (thin_enabled() && hoig_conv_thin_wgrad_applies(d)) ? hoig_stream_scratch_bytes() : 0;
+}
+
 extern "C" int hoig_conv2d_bwd_weight(const hoig_conv_desc *d, const float *x, const float *dy, float *dw, float *dbias,
                                       hoig_stream_t stream) {
     int rc = check_desc(d);

@@ -720,6 +720,12 @@ int hoig_conv_thin_dgrad(const hoig_conv_desc *d, const float *dy, const float *
     return launch_gemm<false>(a, d->precision, st);
 }
 
+// does hoig_conv_thin_wgrad take this layer (and so want the launching stream's scratch block)?
+bool hoig_conv_thin_wgrad_applies(const hoig_conv_desc *d) {
+    if (d->precision == HOIG_PREC_F32 || !thin_geometry(d)) return false;
+    return (d->Ci <= (d->R <= 3 ? 12 : 8) && (d->Co % 64) == 0) || (d->Co <= 8 && (d->Ci % 64) == 0);
+}
+
 // weight gradient of a thin-input (Ci <= 8, Co % 64 == 0) or thin-output (Co <= 8, Ci % 64 == 0) convolution
 int hoig_conv_thin_wgrad(const hoig_conv_desc *d, const float *x, const float *dy, float *dw, hipStream_t st) {
     if (d->precision == HOIG_PREC_F32 || !thin_geometry(d)) return HOIG_EUNSUPPORTED;

@@ -4,7 +4,7 @@
 // stats  : per (b,c) shifted sums over H*W split across workgroups, one atomic per (workgroup, channel) -> finalise
 // apply  : y = act((x-mean)*rstd*scale+shift) (+ residual)       scale/shift = 1/0 | weight/bias[c] | 1+gamma/beta
 // bwd    : dx = rstd*(g' - mean(g') - xhat*mean(g'*xhat)),  g' = dy*act'(y)*scale ; affine / SPADE parameter grads
-#include "common.h"
+#include "conv_bf16_common.h"
 #include <cstdlib>
 
 namespace {
@@ -141,6 +141,17 @@ __global__ void inorm_bwd_finalize_kernel(float *__restrict__ partial, int C, in
     }
 }
 
+// dx as a SPLIT tensor (include/hoig_kernels.h 'PRE-SPLIT gradients'): pixel `pix` holds [hi: C bf16][lo: C bf16] in the 4C bytes an
+// fp32 row would take; this lane's four channels go out as two 8-B stores.  The values are exactly those the convolution kernels'
+// own split makes of the fp32 value (split4).
+__device__ __forceinline__ void store_split(float *dx, int64_t pix, int C, int c, const float4 o) {
+    uint2 hi, lo;
+    hoig_detail::split4(o, hi, lo);
+    unsigned short *row = reinterpret_cast<unsigned short *>(dx) + pix * (2 * (int64_t)C) + c;
+    *reinterpret_cast<uint2 *>(row) = hi;
+    *reinterpret_cast<uint2 *>(row + C) = lo;
+}
+
 __global__ __launch_bounds__(NT) void inorm_apply_kernel(const float *__restrict__ x, const float *__restrict__ mean,
                                                          const float *__restrict__ rstd, int mode,
                                                          const float *__restrict__ p0, const float *__restrict__ p1,
@@ -184,7 +195,7 @@ __global__ __launch_bounds__(NT) void inorm_bwd_apply_kernel(const float *__rest
                                                              const float *__restrict__ sums, float *__restrict__ dx,
                                                              float *__restrict__ dp0, float *__restrict__ dp1, int HW,
                                                              int C, int64_t n4, int ldp, const float *__restrict__ p1,
-                                                             const float *__restrict__ addend) {
+                                                             const float *__restrict__ addend, int split) {
     const int CV = C >> 2;
     const float inv = 1.f / (float)HW;
     for (int64_t i = (int64_t)blockIdx.x * NT + threadIdx.x; i < n4; i += (int64_t)gridDim.x * NT) {
@@ -239,7 +250,8 @@ __global__ __launch_bounds__(NT) void inorm_bwd_apply_kernel(const float *__rest
             const float4 a = reinterpret_cast<const float4 *>(addend)[i];
             o.x += a.x; o.y += a.y; o.z += a.z; o.w += a.w;
         }
-        reinterpret_cast<float4 *>(dx)[i] = o;
+        if (split) store_split(dx, pix, C, c, o);
+        else reinterpret_cast<float4 *>(dx)[i] = o;
     }
 }
 
@@ -341,7 +353,7 @@ __global__ __launch_bounds__(TNT) void inorm_tile_bwd_kernel(const float *__rest
                                                              int ldp, const float *__restrict__ y, const float *__restrict__ dy,
                                                              int act, float slope, float *__restrict__ dx,
                                                              float *__restrict__ dp0, float *__restrict__ dp1, int HW, int C,
-                                                             const float *__restrict__ addend) {
+                                                             const float *__restrict__ addend, int split) {
     __shared__ float red[TPL * TCG];
     const int b = blockIdx.y, c0 = blockIdx.x * TCG;
     const int cq = threadIdx.x % (TCG / 4), pl = threadIdx.x / (TCG / 4), c = c0 + cq * 4;
@@ -417,7 +429,8 @@ __global__ __launch_bounds__(TNT) void inorm_tile_bwd_kernel(const float *__rest
             const float4 a = *reinterpret_cast<const float4 *>(addend + base + (size_t)r * C);
             o.x += a.x; o.y += a.y; o.z += a.z; o.w += a.w;
         }
-        *reinterpret_cast<float4 *>(dx + base + (size_t)r * C) = o;
+        if (split) store_split(dx, (int64_t)b * HW + r, C, c, o);
+        else *reinterpret_cast<float4 *>(dx + base + (size_t)r * C) = o;
     }
 }
 
@@ -514,10 +527,27 @@ extern "C" int hoig_inorm_bwd(const float *x, const float *mean, const float *rs
                               float *dp1, int B, int HW, int C, void *workspace, hoig_stream_t stream) {
     return hoig_inorm_bwd_ld(x, mean, rstd, mode, p0, p1, C, y, dy, act, slope, dx, dp0, dp1, B, HW, C, workspace, stream);
 }
+static int inorm_bwd_any(const float *x, const float *mean, const float *rstd, int mode, const float *p0, const float *p1, int ld_p,
+                         const float *y, const float *dy, int act, float slope, const float *addend, float *dx, float *dp0, float *dp1,
+                         int B, int HW, int C, void *workspace, hoig_stream_t stream, int split);
 extern "C" int hoig_inorm_bwd_add_ld(const float *x, const float *mean, const float *rstd, int mode, const float *p0,
                                      const float *p1, int ld_p, const float *y, const float *dy, int act, float slope,
                                      const float *addend, float *dx, float *dp0, float *dp1, int B, int HW, int C,
                                      void *workspace, hoig_stream_t stream) {
+    return inorm_bwd_any(x, mean, rstd, mode, p0, p1, ld_p, y, dy, act, slope, addend, dx, dp0, dp1, B, HW, C, workspace, stream, 0);
+}
+// the same with dx written as a SPLIT tensor (uint16 planes in the fp32 tensor's bytes): the gradient of a convolution output whose
+// backward reads pre-split dy (hoig_conv2d_bwd_weight_split / hoig_conv2d_bwd_data_packed_split)
+extern "C" int hoig_inorm_bwd_add_ld_split(const float *x, const float *mean, const float *rstd, int mode, const float *p0,
+                                           const float *p1, int ld_p, const float *y, const float *dy, int act, float slope,
+                                           const float *addend, uint16_t *dx_split, float *dp0, float *dp1, int B, int HW, int C,
+                                           void *workspace, hoig_stream_t stream) {
+    return inorm_bwd_any(x, mean, rstd, mode, p0, p1, ld_p, y, dy, act, slope, addend, reinterpret_cast<float *>(dx_split), dp0, dp1, B,
+                         HW, C, workspace, stream, 1);
+}
+static int inorm_bwd_any(const float *x, const float *mean, const float *rstd, int mode, const float *p0, const float *p1, int ld_p,
+                         const float *y, const float *dy, int act, float slope, const float *addend, float *dx, float *dp0, float *dp1,
+                         int B, int HW, int C, void *workspace, hoig_stream_t stream, int split) {
     if (mode == 2 && (ld_p < C || (ld_p & 3))) return HOIG_EINVAL;
     if (!x || !mean || !rstd || !dy || !dx || !workspace || mode < 0 || mode > 2) return HOIG_EINVAL;
     // y may be NULL for (Leaky)ReLU after a plain or affine instance norm: the sign of y is recomputed from x (for the
@@ -540,7 +570,7 @@ extern "C" int hoig_inorm_bwd_add_ld(const float *x, const float *mean, const fl
     HOIG_LAUNCH_CHECK();
     const int64_t n4 = (int64_t)B * HW * C / 4;
     inorm_bwd_apply_kernel<<<hoig_stream_grid(n4, NT), NT, 0, st>>>(x, mean, rstd, mode, p0, y, dy, act, slope, sums, dx,
-                                                                   dp0, dp1, HW, C, n4, ld_p, p1, addend);
+                                                                   dp0, dp1, HW, C, n4, ld_p, p1, addend, split);
     HOIG_LAUNCH_CHECK();
     return HOIG_OK;
 }
@@ -568,10 +598,25 @@ extern "C" int hoig_inorm_bwd_fused(const float *x, const float *mean, const flo
                                     float *dp0, float *dp1, int B, int HW, int C, hoig_stream_t stream) {
     return hoig_inorm_bwd_fused_add(x, mean, rstd, mode, p0, p1, ld_p, y, dy, act, slope, nullptr, dx, dp0, dp1, B, HW, C, stream);
 }
+static int inorm_bwd_fused_any(const float *x, const float *mean, const float *rstd, int mode, const float *p0, const float *p1,
+                               int ld_p, const float *y, const float *dy, int act, float slope, const float *addend, float *dx,
+                               float *dp0, float *dp1, int B, int HW, int C, hoig_stream_t stream, int split);
 extern "C" int hoig_inorm_bwd_fused_add(const float *x, const float *mean, const float *rstd, int mode, const float *p0,
                                         const float *p1, int ld_p, const float *y, const float *dy, int act, float slope,
                                         const float *addend, float *dx, float *dp0, float *dp1, int B, int HW, int C,
                                         hoig_stream_t stream) {
+    return inorm_bwd_fused_any(x, mean, rstd, mode, p0, p1, ld_p, y, dy, act, slope, addend, dx, dp0, dp1, B, HW, C, stream, 0);
+}
+extern "C" int hoig_inorm_bwd_fused_add_split(const float *x, const float *mean, const float *rstd, int mode, const float *p0,
+                                              const float *p1, int ld_p, const float *y, const float *dy, int act, float slope,
+                                              const float *addend, uint16_t *dx_split, float *dp0, float *dp1, int B, int HW, int C,
+                                              hoig_stream_t stream) {
+    return inorm_bwd_fused_any(x, mean, rstd, mode, p0, p1, ld_p, y, dy, act, slope, addend, reinterpret_cast<float *>(dx_split), dp0,
+                               dp1, B, HW, C, stream, 1);
+}
+static int inorm_bwd_fused_any(const float *x, const float *mean, const float *rstd, int mode, const float *p0, const float *p1,
+                               int ld_p, const float *y, const float *dy, int act, float slope, const float *addend, float *dx,
+                               float *dp0, float *dp1, int B, int HW, int C, hoig_stream_t stream, int split) {
     if (!x || !mean || !rstd || !dy || !dx || mode < 0 || mode > 2) return HOIG_EINVAL;
     if (mode == 2 && (ld_p < C || (ld_p & 3) || !dp0 || !dp1)) return HOIG_EINVAL;
     if (act != HOIG_ACT_NONE && !y &&
@@ -580,7 +625,7 @@ extern "C" int hoig_inorm_bwd_fused_add(const float *x, const float *mean, const
     if (mode != 0 && !p0) return HOIG_EINVAL;
     if (!tile_ok(B, HW, C)) return HOIG_EUNSUPPORTED;
     inorm_tile_bwd_kernel<<<dim3(C / TCG, B), TNT, 0, (hipStream_t)stream>>>(x, mean, rstd, mode, p0, p1, ld_p, y, dy, act, slope,
-                                                                             dx, dp0, dp1, HW, C, addend);
+                                                                             dx, dp0, dp1, HW, C, addend, split);
     HOIG_LAUNCH_CHECK();
     return HOIG_OK;
 }

@@ -20,6 +20,7 @@ Entry g_table[HOIG_TUNE_COUNT] = {
     {"head16", 1},
     {"adam_pack", 1},
     {"d_early", 1},
+    {"split_grads", 1},
 };
 }  // namespace
 

@@ -212,6 +212,23 @@ __global__ __launch_bounds__(256) void split_planes_kernel(const float *__restri
     }
 }
 
+// split [npix][2][C] bf16 -> fp32 [npix][C] = hi + lo (what every 16-bit consumer of the split tensor multiplies with)
+__global__ __launch_bounds__(256) void unsplit_planes_kernel(const unsigned short *__restrict__ in, float *__restrict__ out, int64_t n4,
+                                                             int C4) {
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (int64_t)gridDim.x * 256) {
+        const int64_t px = i / C4;
+        const int c4 = (int)(i - px * C4);
+        const uint2 *s = reinterpret_cast<const uint2 *>(in) + px * (2 * C4) + c4;
+        const uint2 hi = s[0], lo = s[C4];
+        float4 v;
+        v.x = __uint_as_float(hi.x << 16) + __uint_as_float(lo.x << 16);
+        v.y = __uint_as_float(hi.x & 0xFFFF0000u) + __uint_as_float(lo.x & 0xFFFF0000u);
+        v.z = __uint_as_float(hi.y << 16) + __uint_as_float(lo.y << 16);
+        v.w = __uint_as_float(hi.y & 0xFFFF0000u) + __uint_as_float(lo.y & 0xFFFF0000u);
+        reinterpret_cast<float4 *>(out)[i] = v;
+    }
+}
+
 }  // namespace
 
 int launch_wgrad_dma(const WHaloArgs &a, int ns, dim3 grid, hipStream_t st) {
@@ -239,6 +256,15 @@ extern "C" int hoig_split_planes_bf16(const float *x, uint16_t *out, int64_t npi
     if (npix == 0) return HOIG_OK;
     const int64_t n4 = npix * (C / 4);
     hoig_detail::split_planes_kernel<<<hoig_stream_grid(n4, 256), 256, 0, (hipStream_t)stream>>>(x, out, n4, C / 4);
+    HOIG_LAUNCH_CHECK();
+    return HOIG_OK;
+}
+
+extern "C" int hoig_unsplit_planes_bf16(const uint16_t *in, float *out, int64_t npix, int C, hoig_stream_t stream) {
+    if (!in || !out || npix < 0 || C <= 0 || (C & 3)) return HOIG_EINVAL;
+    if (npix == 0) return HOIG_OK;
+    const int64_t n4 = npix * (C / 4);
+    hoig_detail::unsplit_planes_kernel<<<hoig_stream_grid(n4, 256), 256, 0, (hipStream_t)stream>>>(in, out, n4, C / 4);
     HOIG_LAUNCH_CHECK();
     return HOIG_OK;
 }

@@ -416,6 +416,7 @@ class Trainer(BaseModel):
             self._phase_d(fake_tsf_imgs, ev_fwd, join=False)
         ops.pause_wgrad_side(generator_forks_streams())     # G's backward is several concurrent chains already
         loss_G.backward()
+        ops.check_split_grads_consumed()
         ops.pause_wgrad_side(False)
         self._join_backward_streams()
         netD.set_requires_grad(True)
@@ -456,6 +457,7 @@ class Trainer(BaseModel):
         loss_D = self._optimize_D(fake_tsf_imgs)          # (waits for D's previous update on THIS stream: _wait_d)
         self._optimizer_D.zero_grad()
         loss_D.backward()
+        ops.check_split_grads_consumed()
 
     def _step(self, net, optimizer, overlap):
         """gradient exchange (RCCL, under DDP) + fused Adam + the operand planes of the new weights.  With `overlap` they run on

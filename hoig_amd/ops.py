@@ -8,6 +8,7 @@ their weight gradients accumulated in place by the kernels; for ordinary
 tensors the gradient is returned through autograd.
 """
 import collections
+import contextlib
 import ctypes
 import os
 
@@ -229,7 +230,7 @@ def release_stream(s):
     if q is None:
         return
     s._hoig_class = None
-    _stream_banks[s.device]['free'][q].append(s.cuda_stream)
+    _stream_banks[s.device]['free'][q].insert(0, s.cuda_stream)     # (first out again: the same few handles, and their scratch, stay in use)
 
 
 def stream_census():
@@ -257,20 +258,21 @@ def destroy_idle_streams():
 _scratch = {}
 
 
-def _ensure_scratch():
+def _ensure_scratch(nbytes):
     cur = torch.cuda.current_stream()
     key = (cur.device, cur.cuda_stream)
-    if key not in _scratch:
+    if nbytes > 0 and key not in _scratch:
         # (never freed while registered; inside a capture it comes from the graph's private pool, which outlives every replay)
         t = torch.empty(L.lib.hoig_stream_scratch_bytes(), dtype=torch.uint8, device=cur.device)
         _scratch[key] = t
         call('hoig_stream_scratch_set', cur.cuda_stream, t.data_ptr(), t.numel())
 
 
-def wgrad_call(name, *args):
-    """A weight-gradient entry point on the current stream, with that stream's scratch block registered first."""
-    _ensure_scratch()
-    call(name, *args)
+def wgrad_call(name, d, *args):
+    """Weight-gradient entry point `name` for layer `d` (a ConvDesc) on the current stream; if the layer's kernel reduces partial sums
+    through memory (the thin-channel layers), that stream's scratch block is registered first."""
+    _ensure_scratch(L.lib.hoig_conv2d_bwd_weight_scratch_bytes(ctypes.byref(d)))
+    call(name, ctypes.byref(d), *args)
 
 
 # ---- test hook (tests/test_stream_order_gpu.py): stream role -> cycles to idle.  A role that finds its name here sleeps that long
@@ -450,6 +452,60 @@ def join_wgrad_streams():
     _wgrad_pending.clear()          # later work on this stream is ordered after the side stream's reads
 
 
+# --- pre-split gradients (round 5; include/hoig_kernels.h 'PRE-SPLIT gradients').  The two-term backward arithmetic multiplies
+# bf16(dy) and bf16(dy - bf16(dy)); the convolution kernels used to make that split of every dy tile in every workgroup that loads it.
+# Where a convolution's output goes straight into an instance norm, the norm's backward kernel now WRITES its dx as those two planes
+# (per pixel [hi: C bf16][lo: C bf16], in the bytes of the fp32 tensor autograd passes along) and the convolution's weight- and
+# data-gradient kernels copy them to LDS (LDS-DMA / 16-B pieces) without touching the VALU.  The hand-off is explicit: the convolution
+# tags its OUTPUT tensor at forward time (`_hoig_split_grad`: "my backward reads split dy"), the norm that consumes that very tensor
+# object remembers the tag, its backward registers the gradient it wrote here, and the convolution's backward looks its incoming
+# gradient up.  A tagged tensor that reaches anything but such a norm simply gets an fp32 gradient (no tag, no registration).
+_split_grads = {}          # data_ptr -> the gradient tensor that holds planes (alive until its consumer has been issued)
+
+
+def _split_backward_ok(d, w, live_bias, transposed):
+    """May the backward of convolution `d` read pre-split dy?  (the layers hoig_conv2d_bwd_weight_split covers; the data gradient
+    falls back to an un-split copy where its kernel has no pre-split form)"""
+    if not L.lib.hoig_set_tuning(b'split_grads', -1) or transposed or live_bias or d.act != L.ACT_NONE:
+        return False
+    if not getattr(w, '_hoig_flat', False) or (d.R, d.S, d.stride, d.pad) != (3, 3, 1, 1) or (d.Ho, d.Wo) != (d.Hi, d.Wi):
+        return False
+    if d.Co % 128 or d.Ci % 32 or d.Wo % 32 or d.Ho % 8:
+        return False
+    dg, wg = _bwd_descs(d)
+    return dg.precision in (L.PREC_F16X2, L.PREC_BF16) and wg.precision in (L.PREC_F16X2, L.PREC_BF16)
+
+
+def _tag_split(y):
+    y._hoig_split_grad = True
+    return y
+
+
+def _take_split(dy):
+    """-> True if `dy` is a gradient some producer wrote as split planes (and forget it)."""
+    return _split_grads.pop(dy.data_ptr(), None) is not None
+
+
+def _offer_split(dx):
+    _split_grads[dx.data_ptr()] = dx
+
+
+def check_split_grads_consumed():
+    """Every gradient written as planes must have been read by the convolution it was written for: anything left over reached a
+    consumer that took it for fp32 (Trainer calls this after each backward)."""
+    if _split_grads:
+        n = len(_split_grads)
+        _split_grads.clear()
+        raise RuntimeError('%d pre-split gradient tensor(s) were not consumed by a convolution backward' % n)
+
+
+def _unsplit(dys):
+    """split planes -> fp32 (hi + lo) in a new tensor: for a consumer without a pre-split form"""
+    out = torch.empty_like(dys)
+    call('hoig_unsplit_planes_bf16', _p(dys), _p(out), dys.numel() // dys.shape[-1], dys.shape[-1], _st())
+    return out
+
+
 class _Conv(Function):
     @staticmethod
     def forward(ctx, x, w, b, stride, pad, transposed, act, slope, out_hw, prec, dead_bias=False, fork=False):
@@ -476,6 +532,7 @@ class _Conv(Function):
         ctx.has_bias = b is not None and not dead_bias
         ctx.save_for_backward(x, w, b, y if act != L.ACT_NONE else None)
         ctx.fork = fork
+        ctx.split_ok = dead_bias and _split_backward_ok(d, w, ctx.has_bias, transposed)      # (dead_bias: the output's one reader is a norm)
         if fork:
             # (y, x): the caller hands this second output to x's OTHER consumer, so that autograd sees x consumed once -- by
             # this node, whose backward receives both gradients and lets the data-gradient kernel add the other one in its
@@ -491,6 +548,8 @@ class _Conv(Function):
         if dy is None:                      # (fork: only the pass-through output was used)
             return (dxr,) + (None,) * 11
         dy = dy.contiguous()
+        if _take_split(dy):
+            return _Conv._backward_split(ctx, dy, dxr, x, w)
         dw_ret = db_ret = None
         db, ret_b = None, False
         if ctx.needs_input_grad[1] and ctx.has_bias and ctx.needs_input_grad[2]:
@@ -514,10 +573,10 @@ class _Conv(Function):
                 side.wait_stream(torch.cuda.current_stream())
                 with torch.cuda.stream(side):
                     test_delay('wgrad')
-                    wgrad_call('hoig_conv2d_bwd_weight', ctypes.byref(ctx.d_wg), _p(x), _p(g), _p(dw), _p(db), _st())
+                    wgrad_call('hoig_conv2d_bwd_weight', ctx.d_wg, _p(x), _p(g), _p(dw), _p(db), _st())
                 _wgrad_hold(side, (x, g))
             else:
-                wgrad_call('hoig_conv2d_bwd_weight', ctypes.byref(ctx.d_wg), _p(x), _p(g), _p(dw), _p(db), _st())
+                wgrad_call('hoig_conv2d_bwd_weight', ctx.d_wg, _p(x), _p(g), _p(dw), _p(db), _st())
             dw_ret = dw if ret_w else None
         dx = None
         if ctx.needs_input_grad[0]:
@@ -526,11 +585,47 @@ class _Conv(Function):
         return dx, dw_ret, db_ret, None, None, None, None, None, None, None, None, None
 
 
+    @staticmethod
+    def _backward_split(ctx, dys, dxr, x, w):
+        """dy arrived as bf16 hi | lo planes (written by the backward of the norm that reads this convolution's output)."""
+        d_dg, d_wg = ctx.d_dg, ctx.d_wg
+        unsplit = None
+        if ctx.needs_input_grad[1]:
+            dw, ret_w = _grad_target(w)
+            side = _wgrad_side_stream(x.device) if not ret_w else None
+            if side is not None:
+                side.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(side) if side is not None else contextlib.nullcontext():
+                if side is not None:
+                    test_delay('wgrad')
+                rc = L.lib.hoig_conv2d_bwd_weight_split(ctypes.byref(d_wg), _p(x), _p(dys), _p(dw), _st())
+                if rc == L.EUNSUPPORTED:
+                    unsplit = _unsplit(dys)
+                    wgrad_call('hoig_conv2d_bwd_weight', d_wg, _p(x), _p(unsplit), _p(dw), None, _st())
+                else:
+                    L.check(rc, 'hoig_conv2d_bwd_weight_split')
+            if side is not None:
+                _wgrad_hold(side, (x, dys) if unsplit is None else (x, dys, unsplit))
+                unsplit = None                      # (made on the side stream: the data gradient makes its own if it needs one)
+        dx = None
+        if ctx.needs_input_grad[0]:
+            dx = torch.empty_like(x)
+            add = dxr.contiguous() if dxr is not None else None
+            hi, lo = _packed_planes(w, False, True)
+            rc = L.lib.hoig_conv2d_bwd_data_packed_split(ctypes.byref(d_dg), _p(dys), _p(hi), _p(lo), _p(add), _p(dx), _st())
+            if rc == L.EUNSUPPORTED:
+                _conv_dgrad_raw(d_dg, unsplit if unsplit is not None else _unsplit(dys), w, dx, False, addend=add)
+            else:
+                L.check(rc, 'hoig_conv2d_bwd_data_packed_split')
+        return (dx, (dw if (ctx.needs_input_grad[1] and ret_w) else None)) + (None,) * 10
+
+
 def conv2d(x, w, b=None, stride=1, pad=0, act=L.ACT_NONE, slope=0.0, prec=None, dead_bias=False):
     """dead_bias=True: the output feeds an instance normalisation directly, whose mean subtraction makes the bias
     gradient exactly zero in exact arithmetic (the reference computes ~1e-10 rounding noise there); the column sum of dy
     is skipped and the bias gradient left at zero."""
-    return _Conv.apply(x, w, b, stride, pad, False, act, slope, None, precision if prec is None else prec, dead_bias)
+    y = _Conv.apply(x, w, b, stride, pad, False, act, slope, None, precision if prec is None else prec, dead_bias)
+    return _tag_split(y) if getattr(y.grad_fn, 'split_ok', False) else y
 
 
 def conv2d_fork(x, w, b=None, stride=1, pad=0, act=L.ACT_NONE, slope=0.0, prec=None, dead_bias=False):
@@ -539,7 +634,8 @@ def conv2d_fork(x, w, b=None, stride=1, pad=0, act=L.ACT_NONE, slope=0.0, prec=N
     data-gradient kernel (hoig_conv2d_bwd_data_packed_add) -- one extra read instead of the autograd engine's three-pass sum."""
     if not x.requires_grad:
         return conv2d(x, w, b, stride, pad, act, slope, prec, dead_bias), x
-    return _Conv.apply(x, w, b, stride, pad, False, act, slope, None, precision if prec is None else prec, dead_bias, True)
+    y, xr = _Conv.apply(x, w, b, stride, pad, False, act, slope, None, precision if prec is None else prec, dead_bias, True)
+    return (_tag_split(y) if getattr(y.grad_fn, 'split_ok', False) else y), xr
 
 
 class _ConvCat2(Function):
@@ -586,10 +682,10 @@ class _ConvCat2(Function):
             side.wait_stream(torch.cuda.current_stream())
             with torch.cuda.stream(side):
                 test_delay('wgrad')
-                wgrad_call('hoig_conv2d_cat_bwd_weight', ctypes.byref(ctx.d_wg), _p(x1), C1, _p(x2), _p(dy), _p(dw), None, _st())
+                wgrad_call('hoig_conv2d_cat_bwd_weight', ctx.d_wg, _p(x1), C1, _p(x2), _p(dy), _p(dw), None, _st())
             _wgrad_hold(side, (x1, x2, dy))
         else:
-            wgrad_call('hoig_conv2d_cat_bwd_weight', ctypes.byref(ctx.d_wg), _p(x1), C1, _p(x2), _p(dy), _p(dw), None, _st())
+            wgrad_call('hoig_conv2d_cat_bwd_weight', ctx.d_wg, _p(x1), C1, _p(x2), _p(dy), _p(dw), None, _st())
         dx1, dx2 = torch.empty_like(x1), torch.empty_like(x2)
         hi, lo = _packed_planes(w, False, True)
         L.check(L.lib.hoig_conv2d_cat_bwd_data_packed(ctypes.byref(ctx.d_dg), _p(dy), _p(hi), _p(lo), _p(dx1), C1, _p(dx2), _st()),
@@ -671,7 +767,7 @@ class _ConvHeads(Function):
         dw_ret = None
         if ctx.needs_input_grad[1]:
             dw, ret_w = _grad_target(w)
-            wgrad_call('hoig_conv2d_bwd_weight', ctypes.byref(ctx.d_wg), _p(x), _p(g), _p(dw), None, _st())
+            wgrad_call('hoig_conv2d_bwd_weight', ctx.d_wg, _p(x), _p(g), _p(dw), None, _st())
             dw_ret = dw if ret_w else None
         dx = None
         if ctx.needs_input_grad[0]:
@@ -760,6 +856,7 @@ class _INorm(Function):
         else:
             L.check(rc, 'hoig_inorm_fwd_fused')
         ctx.cfg = (mode, act, slope, B, HW, C, residual is not None)
+        ctx.split_dx = getattr(x, '_hoig_split_grad', False)          # x is the output of a convolution whose backward reads split dy
         # (Leaky)ReLU after a plain / affine norm: the backward recomputes the activation mask from x instead of reading y
         y_free = act in (L.ACT_RELU, L.ACT_LRELU) and mode in (0, 1)
         ctx.save_for_backward(x, mean, rstd, p0, p1, y if (act != L.ACT_NONE and not y_free) else None)
@@ -779,14 +876,18 @@ class _INorm(Function):
         elif mode == 2:
             dp0, dp1 = torch.empty_like(x), torch.empty_like(x)
             r0, r1 = dp0, dp1
-        rc = L.lib.hoig_inorm_bwd_fused(_p(x), _p(mean), _p(rstd), mode, _p(p0), _p(p1) if mode == 1 else None, C, _p(y), _p(dy),
-                                        act, slope, _p(dx), _p(dp0), _p(dp1), B, HW, C, _st())
+        sfx = '_split' if ctx.split_dx else ''
+        p1m = _p(p1) if mode == 1 else None
+        rc = getattr(L.lib, 'hoig_inorm_bwd_fused_add' + sfx)(_p(x), _p(mean), _p(rstd), mode, _p(p0), p1m, C, _p(y), _p(dy), act, slope,
+                                                              None, _p(dx), _p(dp0), _p(dp1), B, HW, C, _st())
         if rc == L.EUNSUPPORTED:
             ws = _norm_workspace(L.lib.hoig_inorm_workspace_bytes(B, HW, C) // 4, x.device)
-            call('hoig_inorm_bwd', _p(x), _p(mean), _p(rstd), mode, _p(p0), _p(p1) if mode == 1 else None, _p(y), _p(dy), act,
-                 slope, _p(dx), _p(dp0), _p(dp1), B, HW, C, _p(ws), _st())
+            call('hoig_inorm_bwd_add_ld' + sfx, _p(x), _p(mean), _p(rstd), mode, _p(p0), p1m, C, _p(y), _p(dy), act, slope, None, _p(dx),
+                 _p(dp0), _p(dp1), B, HW, C, _p(ws), _st())
         else:
-            L.check(rc, 'hoig_inorm_bwd_fused')
+            L.check(rc, 'hoig_inorm_bwd_fused_add' + sfx)
+        if ctx.split_dx:
+            _offer_split(dx)
         return dx, r0, r1, None, None, None, (dy if has_res else None), None
 
 
@@ -827,6 +928,7 @@ class _SpadeFused(Function):
         else:
             L.check(rc, 'hoig_inorm_fwd_fused')
         ctx.cfg = (act, slope, B, HW, C)
+        ctx.split_dx = getattr(x, '_hoig_split_grad', False)          # (see _INorm.forward)
         ctx.save_for_backward(x, mean, rstd, gb, y if act != L.ACT_NONE else None)
         if fork:                              # (y, x): see _Conv.forward
             ctx.set_materialize_grads(False)
@@ -843,14 +945,17 @@ class _SpadeFused(Function):
         add = dxr.contiguous() if dxr is not None else None
         dx = torch.empty_like(x)
         dgb = torch.empty_like(gb)
-        rc = L.lib.hoig_inorm_bwd_fused_add(_p(x), _p(mean), _p(rstd), 2, _p(gb), None, 2 * C, _p(y), _p(dy), act, slope, _p(add),
-                                            _p(dx), _p(dgb), dgb.data_ptr() + 4 * C, B, HW, C, _st())
+        sfx = '_split' if ctx.split_dx else ''
+        rc = getattr(L.lib, 'hoig_inorm_bwd_fused_add' + sfx)(_p(x), _p(mean), _p(rstd), 2, _p(gb), None, 2 * C, _p(y), _p(dy), act, slope,
+                                                              _p(add), _p(dx), _p(dgb), dgb.data_ptr() + 4 * C, B, HW, C, _st())
         if rc == L.EUNSUPPORTED:
             ws = _norm_workspace(L.lib.hoig_inorm_workspace_bytes(B, HW, C) // 4, x.device)
-            call('hoig_inorm_bwd_add_ld', _p(x), _p(mean), _p(rstd), 2, _p(gb), None, 2 * C, _p(y), _p(dy), act, slope, _p(add),
+            call('hoig_inorm_bwd_add_ld' + sfx, _p(x), _p(mean), _p(rstd), 2, _p(gb), None, 2 * C, _p(y), _p(dy), act, slope, _p(add),
                  _p(dx), _p(dgb), dgb.data_ptr() + 4 * C, B, HW, C, _p(ws), _st())
         else:
-            L.check(rc, 'hoig_inorm_bwd_fused_add')
+            L.check(rc, 'hoig_inorm_bwd_fused_add' + sfx)
+        if ctx.split_dx:
+            _offer_split(dx)
         return dx, dgb, None, None, None, None
 
 
@@ -1200,10 +1305,10 @@ class _AttnSourceConv(Function):
         if side is not None:          # (see _Conv.backward)
             side.wait_stream(torch.cuda.current_stream())
             with torch.cuda.stream(side):
-                wgrad_call('hoig_conv2d_bwd_weight', ctypes.byref(ds_wg), _p(spad), _p(dgs), _p(gw), None, _st())
+                wgrad_call('hoig_conv2d_bwd_weight', ds_wg, _p(spad), _p(dgs), _p(gw), None, _st())
             _wgrad_hold(side, (spad, dgs))
         else:
-            wgrad_call('hoig_conv2d_bwd_weight', ctypes.byref(ds_wg), _p(spad), _p(dgs), _p(gw), None, _st())
+            wgrad_call('hoig_conv2d_bwd_weight', ds_wg, _p(spad), _p(dgs), _p(gw), None, _st())
         dsrc = None
         if ctx.needs_input_grad[0]:
             dspad = torch.empty_like(spad)
@@ -1279,10 +1384,10 @@ class _LocalAttn(Function):
         if side is not None:          # (see _Conv.backward)
             side.wait_stream(torch.cuda.current_stream())
             with torch.cuda.stream(side):
-                wgrad_call('hoig_conv2d_bwd_weight', ctypes.byref(dt_wg), _p(tpad), _p(dhid), _p(gs[0][0]), _p(gs[1][0]), _st())
+                wgrad_call('hoig_conv2d_bwd_weight', dt_wg, _p(tpad), _p(dhid), _p(gs[0][0]), _p(gs[1][0]), _st())
             _wgrad_hold(side, (tpad, dhid))
         else:
-            wgrad_call('hoig_conv2d_bwd_weight', ctypes.byref(dt_wg), _p(tpad), _p(dhid), _p(gs[0][0]), _p(gs[1][0]), _st())
+            wgrad_call('hoig_conv2d_bwd_weight', dt_wg, _p(tpad), _p(dhid), _p(gs[0][0]), _p(gs[1][0]), _st())
         dtgt = dsrc = None
         if ctx.needs_input_grad[1]:
             dtpad = torch.empty_like(tpad)

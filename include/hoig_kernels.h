@@ -81,6 +81,16 @@ int hoig_conv2d_bwd_weight(const hoig_conv_desc *d, const float *x, const float 
  * hoig_conv2d_bwd_weight_split: stride-1 "same" 3x3 layers with Wo % 32 == 0, Ho % 4 == 0, Co % 128 == 0, Ci % 32 == 0 in
  * HOIG_PREC_F16X2 / HOIG_PREC_BF16 (the lo plane is not read then), no bias gradient; HOIG_EUNSUPPORTED otherwise. */
 int hoig_split_planes_bf16(const float *x, uint16_t *out, int64_t npix, int C, hoig_stream_t stream);
+/* split -> fp32 (hi + lo; out may alias nothing): for a consumer that has no pre-split form */
+int hoig_unsplit_planes_bf16(const uint16_t *in, float *out, int64_t npix, int C, hoig_stream_t stream);
+/* hoig_inorm_bwd_add_ld / hoig_inorm_bwd_fused_add with dx written as a split tensor (same arguments otherwise; addend stays fp32) */
+int hoig_inorm_bwd_add_ld_split(const float *x, const float *mean, const float *rstd, int mode, const float *p0, const float *p1,
+                                int ld_p, const float *y, const float *dy, int act, float slope, const float *addend /*nullable*/,
+                                uint16_t *dx_split, float *dp0, float *dp1, int B, int HW, int C, void *workspace,
+                                hoig_stream_t stream);
+int hoig_inorm_bwd_fused_add_split(const float *x, const float *mean, const float *rstd, int mode, const float *p0, const float *p1,
+                                   int ld_p, const float *y, const float *dy, int act, float slope, const float *addend /*nullable*/,
+                                   uint16_t *dx_split, float *dp0, float *dp1, int B, int HW, int C, hoig_stream_t stream);
 int hoig_conv2d_bwd_weight_split(const hoig_conv_desc *d, const float *x, const uint16_t *dy_split, float *dw, hoig_stream_t stream);
 /* dx = data gradient (+ addend when non-null: hoig_conv2d_bwd_data_packed_add) of a stride-1 "same" 3x3 Conv2d from pre-split dy, on the
  * 8-row tilings of the v_mfma_f32_16x16x32 kernel (Hi % 8 == 0, Wi % 32 == 0 and enough tiles: HOIG_EUNSUPPORTED otherwise -- the
@@ -383,6 +393,9 @@ int hoig_stream_destroy(hoig_stream_t stream);   /* also forgets the stream's sc
  * kernels take a (slower, same-result-up-to-summation-order) atomic path and report it once on stderr.  The block must stay valid
  * until the stream's last launch that may use it has run. */
 int64_t hoig_stream_scratch_bytes(void);
+/* what hoig_conv2d_bwd_weight would use of it for layer d: hoig_stream_scratch_bytes() for the thin-channel layers, 0 for all others
+ * (a caller may register scratch only on the streams that launch such layers) */
+int64_t hoig_conv2d_bwd_weight_scratch_bytes(const hoig_conv_desc *d);
 int hoig_stream_scratch_set(hoig_stream_t stream, void *ptr, int64_t bytes);
 
 /* eval.py output stage (utils/util.py:249-264): uint8 = (x+1)/2*255 truncated, NHWC fp32 -> CHW uint8 grid tile */
@@ -464,6 +477,9 @@ const char *hoig_version(void);
  *                G's backward instead of after it; 0: after (both orders compute the same step: D's weights change only in D's own
  *                update, which stays last).  With an exchange (world > 1) it always follows G's backward: G's all-reduce hides behind it
  *   "wgrad16" 0  the stride-1 3x3 weight gradients on 16x16x32 (wgrad_halo16.hip): measured 5-20 % slower than 32x32x16
+ *   "split_grads" 1  (read by the host side, hoig_amd/ops.py) the backward of a norm that follows an eligible 3x3 convolution writes its
+ *                dx as bf16 hi | lo planes and that convolution's weight / data gradient read them without splitting ('PRE-SPLIT
+ *                gradients' above); 0: fp32 gradients everywhere, split in every consuming workgroup
  * Process-wide, not synchronised: set before launching. */
 int hoig_set_tuning(const char *key, int value);
 

@@ -71,7 +71,7 @@ def test_thin_weight_gradient_uses_the_registered_scratch_and_survives_without()
         for registered in (True, False):
             dw = torch.zeros(Co, 7, 7, Ci, device='cuda')
             if registered:
-                ops.wgrad_call('hoig_conv2d_bwd_weight', ctypes.byref(d), x.data_ptr(), dy.data_ptr(), dw.data_ptr(), None, s.cuda_stream)
+                ops.wgrad_call('hoig_conv2d_bwd_weight', d, x.data_ptr(), dy.data_ptr(), dw.data_ptr(), None, s.cuda_stream)
             else:
                 L.call('hoig_stream_scratch_set', s.cuda_stream, None, 0)
                 L.call('hoig_conv2d_bwd_weight', ctypes.byref(d), x.data_ptr(), dy.data_ptr(), dw.data_ptr(), None, s.cuda_stream)

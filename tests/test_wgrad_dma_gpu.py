@@ -49,7 +49,7 @@ def test_weight_gradient_from_split_dy(shape, prec):
     L.call('hoig_split_planes_bf16', _p(dy), _p(dys), B * H * W, Co, st)
     d = L.ConvDesc(B, H, W, Ci, H, W, Co, 3, 3, 1, 1, 0, L.ACT_NONE, 0.0, ops._PREC[prec])
     dw_ref = torch.zeros(Co, 3, 3, Ci, device='cuda')
-    ops.wgrad_call('hoig_conv2d_bwd_weight', ctypes.byref(d), _p(x), _p(dy), _p(dw_ref), None, st)
+    ops.wgrad_call('hoig_conv2d_bwd_weight', d, _p(x), _p(dy), _p(dw_ref), None, st)
     dw = torch.zeros(Co, 3, 3, Ci, device='cuda')
     for _ in range(2):                                       # twice: the kernel ACCUMULATES into dw
         L.call('hoig_conv2d_bwd_weight_split', ctypes.byref(d), _p(x), _p(dys), _p(dw), st)
@@ -102,3 +102,56 @@ def test_data_gradient_from_split_dy(shape, with_addend):
     assert rc == 0, rc
     torch.cuda.synchronize()
     assert torch.equal(dx, dx_ref), (dx - dx_ref).abs().max().item()
+
+
+@pytest.mark.parametrize('kind', ['in_relu', 'in_affine_residual', 'spade', 'fork'])
+@pytest.mark.parametrize('hw', [(32, 32), (64, 64)])
+def test_norm_backward_hands_the_convolution_split_planes(kind, hw):
+    """conv3x3 -> instance norm (plain / affine + residual / SPADE) with the tuning key `split_grads` on and off: the norm's backward
+    writes its dx as bf16 hi | lo planes (one-launch kernel at 32 x 32, three-kernel path at 64 x 64), the convolution's backward reads
+    them.  Same arithmetic both ways: dx identical, dW to the order of the atomics; every registered gradient is consumed."""
+    from hoig_amd import _lib as L, nn as hnn, ops
+    H, W = hw
+    B, Ci, Co = 4, 64, 128
+    ops.set_precision('bf16x3:f16x2')
+    try:
+        g = torch.Generator(device='cuda').manual_seed(11)
+        tree = hnn.ParamTree({'c.weight': (Co, Ci, 3, 3), 'n.weight': (Co,), 'n.bias': (Co,)}, torch.device('cuda'), {}, {})
+        with torch.no_grad():
+            tree.flat.copy_(torch.randn(tree.flat.shape, device='cuda', generator=g) * 0.05)
+        tree.version += 1
+        x0 = torch.randn(B, H, W, Ci, device='cuda', generator=g)
+        res = torch.randn(B, H, W, Co, device='cuda', generator=g)
+        gb = torch.randn(B, H, W, 2 * Co, device='cuda', generator=g) * 0.3
+        gout = torch.randn(B, H, W, Co, device='cuda', generator=g)
+        outs = {}
+        for split in (1, 0):
+            L.set_tuning('split_grads', split)
+            tree.flat_grad.zero_()
+            x = x0.clone().requires_grad_(True)
+            skip = None
+            if kind == 'fork':
+                y, xr = ops.conv2d_fork(x, tree.P['c.weight'], None, 1, 1, dead_bias=True)
+                skip = xr * 2.0                                         # the second reader of x
+            else:
+                y = ops.conv2d(x, tree.P['c.weight'], None, 1, 1, dead_bias=True)
+            assert getattr(y, '_hoig_split_grad', False) == bool(split)
+            if kind == 'in_affine_residual':
+                z = ops.instance_norm(y, tree.P['n.weight'], tree.P['n.bias'], residual=res)
+            elif kind == 'spade':
+                z = ops.spade_norm_fused(y, gb, act=L.ACT_RELU)
+            else:
+                z = ops.instance_norm(y, act=L.ACT_RELU)
+            loss = (z * gout).sum() + (skip.sum() if skip is not None else 0.0)
+            loss.backward()
+            ops.join_wgrad_streams()
+            ops.check_split_grads_consumed()
+            torch.cuda.synchronize()
+            outs[split] = (x.grad.clone(), tree.flat_grad.clone())
+        dx1, dw1 = outs[1]
+        dx0, dw0 = outs[0]
+        assert torch.equal(dx1, dx0), (dx1 - dx0).abs().max().item()
+        assert (dw1 - dw0).abs().max().item() <= 2e-5 * dw0.abs().max().item()
+    finally:
+        L.set_tuning('split_grads', 1)
+        ops.set_precision('f32')

@@ -68,7 +68,7 @@ def main():
         fns = {
             'fwd': lambda: L.call('hoig_conv2d_fwd_packed', ctypes.byref(d), p(x), p(hi), p(lo), None, p(y), st),
             'dgrad': lambda: L.call('hoig_conv2d_bwd_data_packed', ctypes.byref(d_dg), p(dy), p(thi), p(tlo), p(dx), st),
-            'wgrad': lambda: ops.wgrad_call('hoig_conv2d_bwd_weight', ctypes.byref(d_wg), p(x), p(dy), p(dw), None, st),
+            'wgrad': lambda: ops.wgrad_call('hoig_conv2d_bwd_weight', d_wg, p(x), p(dy), p(dw), None, st),
         }
         if 'wgrad_split' in a.kinds or 'split' in a.kinds or 'dgrad_split' in a.kinds:      # pre-split dy (round 5)
             dys = torch.empty(B, Ho, Wo, 2, Co, dtype=torch.bfloat16, device='cuda')
