@@ -22,6 +22,7 @@
 // plane -- but is double-buffered too, converted and stored at the END of a tile, beside nobody's MFMAs.
 #include "conv_bf16_common.h"
 #include "tuning.h"
+#include <type_traits>
 
 namespace hoig_detail {
 namespace {
@@ -58,56 +59,65 @@ __global__ __launch_bounds__(D_NT) void wgrad_dma_kernel(const WHaloArgs p) {
     // closes a tile, below).  M0 = the wave-uniform LDS byte address of the piece (cdna_hip_programming.md 5.7).
     const size_t lane_src = (size_t)(lane >> 4) * pstr + (size_t)(((lane & 15) ^ (4 * (lane >> 4))) * 8);
     const unsigned lds0 = __builtin_amdgcn_readfirstlane((unsigned)(size_t)(__attribute__((address_space(3))) unsigned char *)smem);
-    auto dma_dy = [&](int mt, int bsel) {
+    // piece i of this wave (plane-major: j = wave + 12 i over the NS * 32 pieces of a tile) of the tile at `base`, into buffer bsel
+    constexpr int NPIECE = (NS * 32 + 11) / 12;
+    auto tile_base = [&](int mt) -> const unsigned short * {
         const int tx = mt % p.tiles_x, t2 = mt / p.tiles_x;
         const int ty = t2 % p.tiles_y, b = t2 / p.tiles_y;
-        const unsigned short *base = DYS + (((size_t)b * p.H + ty * TH) * p.W + tx * TW) * pstr + c0 + lane_src;
-        const unsigned dst = lds0 + bsel * PBUF;
-#pragma unroll
-        for (int i = 0; i < (NS * 32 + 11) / 12; ++i) {
-            const int j = wave + 12 * i;                    // (wave-uniform: the branch is scalar)
-            if (j < NS * 32) {
-                const int plane = j >> 5, jj = j & 31;      // tile row jj >> 3, pixels 4 * (jj & 7) ..
-                const unsigned short *src = base + (size_t)plane * p.Co + ((size_t)(jj >> 3) * p.W + 4 * (jj & 7)) * pstr;
-                const unsigned to = __builtin_amdgcn_readfirstlane(dst + plane * D_PLANE + jj * 1024);
-                unsigned keep;
-                asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
-                             : "=&s"(keep) : "v"(src), "s"(to) : "memory");
-            }
+        return DYS + (((size_t)b * p.H + ty * TH) * p.W + tx * TW) * pstr + c0 + lane_src;
+    };
+    auto dma_piece = [&](const unsigned short *base, int bsel, int i) {
+        const int j = wave + 12 * i;                        // (wave-uniform: the branch is scalar)
+        if (j < NS * 32) {
+            const int plane = j >> 5, jj = j & 31;          // tile row jj >> 3, pixels 4 * (jj & 7) ..
+            const unsigned short *src = base + (size_t)plane * p.Co + ((size_t)(jj >> 3) * p.W + 4 * (jj & 7)) * pstr;
+            const unsigned to = __builtin_amdgcn_readfirstlane(lds0 + bsel * PBUF + plane * D_PLANE + jj * 1024);
+            unsigned keep;
+            asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+                         : "=&s"(keep) : "v"(src), "s"(to) : "memory");
         }
     };
 
     // ---- x halo: registers -> one bf16 plane
     constexpr int QSL = (HPIX * 8 + NT - 1) / NT;           // float4s per thread (3)
     float4 rq[QSL];
-    auto load_x = [&](int mt) {
+    // The loads are UNCONDITIONAL (out-of-image positions read a clamped address and are zeroed when the tile is stored): a load under
+    // the bounds branch merges with the zero of the other path, and hipcc resolved that merge with register copies -- and an
+    // `s_waitcnt vmcnt(0)` -- right behind the load.
+    auto halo_pos = [&](int mt, int i, int &gy, int &gx, int &b) -> bool {
         const int tx = mt % p.tiles_x, t2 = mt / p.tiles_x;
-        const int ty = t2 % p.tiles_y, b = t2 / p.tiles_y;
-        const int y0 = ty * TH, x0 = tx * TW;
+        const int ty = t2 % p.tiles_y;
+        b = t2 / p.tiles_y;
+        const int idx = tid + NT * i, hp = idx >> 3;
+        const int hy = hp / HWID, hx = hp - hy * HWID;
+        gy = ty * TH - p.pad + hy;
+        gx = tx * TW - p.pad + hx;
+        return idx < HPIX * 8 && gy >= 0 && gy < p.Hin && gx >= 0 && gx < p.Win;
+    };
+    auto load_x = [&](int mt) {
         const bool second = p.X2 != nullptr && ci0 >= p.ci1;
         const int ldx = p.X2 ? (second ? p.Ci - p.ci1 : p.ci1) : p.Ci;
-        const float *xb = (second ? p.X2 : p.X) + (size_t)b * p.Hin * p.Win * ldx + (second ? ci0 - p.ci1 : ci0);
+        const float *xc = (second ? p.X2 : p.X) + (second ? ci0 - p.ci1 : ci0) + (tid & 7) * 4;
 #pragma unroll
         for (int i = 0; i < QSL; ++i) {
-            const int idx = tid + NT * i;
-            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (idx < HPIX * 8) {
-                const int hp = idx >> 3, c4 = idx & 7;
-                const int hy = hp / HWID, hx = hp - hy * HWID;
-                const int gy = y0 - p.pad + hy, gx = x0 - p.pad + hx;
-                if (gy >= 0 && gy < p.Hin && gx >= 0 && gx < p.Win)
-                    v = *reinterpret_cast<const float4 *>(xb + ((size_t)gy * p.Win + gx) * ldx + c4 * 4);
-            }
-            rq[i] = v;
+            int gy, gx, b;
+            halo_pos(mt, i, gy, gx, b);
+            gy = min(max(gy, 0), p.Hin - 1);
+            gx = min(max(gx, 0), p.Win - 1);
+            rq[i] = *reinterpret_cast<const float4 *>(xc + (((size_t)b * p.Hin + gy) * p.Win + gx) * ldx);
         }
     };
-    auto store_x = [&](int bsel) {
+    auto store_x = [&](int bsel, int mt) {
         unsigned char *Q = Qbase + bsel * D_QBUF;
 #pragma unroll
         for (int i = 0; i < QSL; ++i) {
             const int idx = tid + NT * i;
+            int gy, gx, b;
+            const bool in = halo_pos(mt, i, gy, gx, b);
+            // (pins the conversion HERE: hipcc otherwise moves it up behind the load and waits for the data there)
+            asm volatile("" : "+v"(rq[i].x), "+v"(rq[i].y), "+v"(rq[i].z), "+v"(rq[i].w));
             if (idx < HPIX * 8)
-                *reinterpret_cast<uint2 *>(Q + idx * 8) = make_uint2(cvt2(rq[i].x, rq[i].y), cvt2(rq[i].z, rq[i].w));
+                *reinterpret_cast<uint2 *>(Q + idx * 8) = in ? make_uint2(cvt2(rq[i].x, rq[i].y), cvt2(rq[i].z, rq[i].w)) : make_uint2(0u, 0u);
         }
     };
 
@@ -136,19 +146,33 @@ __global__ __launch_bounds__(D_NT) void wgrad_dma_kernel(const WHaloArgs p) {
         for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
 
     if (mt_begin < mt_end) {
-        dma_dy(mt_begin, 0);
+        const unsigned short *b0 = tile_base(mt_begin);
+#pragma unroll
+        for (int i = 0; i < NPIECE; ++i) dma_piece(b0, 0, i);
         load_x(mt_begin);
-        store_x(0);
+        store_x(0, mt_begin);
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
-    for (int mt = mt_begin; mt < mt_end; ++mt) {
+    // One tile; `nxt` (is there a next tile to stage?) is a compile-time constant of each call: written as a run-time test inside one
+    // loop body, hipcc's wait-count pass sees a path "x loads issued, store_x skipped" and guards every later write to those registers
+    // with s_waitcnt vmcnt(0) -- behind a DMA just issued, i.e. a full memory round trip in three k-steps of every tile.
+    auto tile_body = [&](const int mt, auto nxt_c) {
+        constexpr bool nxt = decltype(nxt_c)::value;
         const int cur = (mt - mt_begin) & 1;
-        const bool nxt = mt + 1 < mt_end;
-        if (nxt) {                                          // lands behind this tile's MFMAs, in the other buffers
-            dma_dy(mt + 1, cur ^ 1);
-            load_x(mt + 1);
+        // the next tile's DMA pieces are issued ONE PER K-STEP below, not in a burst here: twelve waves pushing 64 KB of requests into the
+        // CU's one load path at once stall each other at issue (round 2's stamps of the register kernel: a third of a tile's cycles),
+        // and a wave that waits at issue feeds no MFMAs; with no registers tied to a DMA in flight nothing forces the burst
+        const unsigned short *nb = nullptr;
+        if constexpr (nxt) {
+            nb = tile_base(mt + 1);
+            load_x(mt + 1);                                 // (the quarter of the bytes that goes through registers: up front)
         }
+        auto stage = [&](int kk) {                          // k-step kk carries DMA piece kk of the next tile
+            if constexpr (nxt) {
+                if (kk < NPIECE) dma_piece(nb, cur ^ 1, kk);
+            }
+        };
         const unsigned char *Ph = Pbase + cur * PBUF + trP, *Pl = Ph + D_PLANE;
         const unsigned char *Qh = Qbase + cur * D_QBUF + trQ;
         struct KFrag { bf16x8 ah, al, bh[KS]; };
@@ -173,18 +197,24 @@ __global__ __launch_bounds__(D_NT) void wgrad_dma_kernel(const WHaloArgs p) {
 #pragma unroll
         for (int kk = 0; kk < TH * 2; kk += 2) {
             read_k(f1, kk + 1);
+            stage(kk);
             __builtin_amdgcn_sched_barrier(0);
             mma_k(f0);
             __builtin_amdgcn_sched_barrier(0);
             if (kk + 2 < TH * 2) read_k(f0, kk + 2);
+            stage(kk + 1);
             __builtin_amdgcn_sched_barrier(0);
             mma_k(f1);
             __builtin_amdgcn_sched_barrier(0);
         }
-        if (nxt) store_x(cur ^ 1);                          // (its buffer was last read in the previous tile, a barrier ago)
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");    // this wave's DMA pieces of tile mt + 1 have landed ...
-        __syncthreads();                                    // ... and so have everyone's; everyone is done reading tile mt
-    }
+        if constexpr (nxt) {
+            store_x(cur ^ 1, mt + 1);                       // (its buffer was last read in the previous tile, a barrier ago)
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");    // this wave's DMA pieces of tile mt + 1 have landed ...
+            __syncthreads();                                // ... and so have everyone's; everyone is done reading tile mt
+        }
+    };
+    for (int mt = mt_begin; mt + 1 < mt_end; ++mt) tile_body(mt, std::true_type{});
+    if (mt_begin < mt_end) tile_body(mt_end - 1, std::false_type{});
 
     const int l31 = lane & 31, lh = lane >> 5;
     const int K = KS * KS * p.Ci;

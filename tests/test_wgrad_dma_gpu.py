@@ -99,6 +99,8 @@ def test_data_gradient_from_split_dy(shape, with_addend):
     else:
         L.call('hoig_conv2d_bwd_data_packed', ctypes.byref(d), _p(dy), _p(thi), _p(tlo), _p(dx_ref), st)
     rc = L.lib.hoig_conv2d_bwd_data_packed_split(ctypes.byref(d), _p(dys), _p(thi), _p(tlo), _p(add) if with_addend else None, _p(dx), st)
+    if rc == L.EUNSUPPORTED:
+        pytest.skip('no pre-split form of the data gradient for this shape (the caller un-splits): %r' % (shape,))
     assert rc == 0, rc
     torch.cuda.synchronize()
     assert torch.equal(dx, dx_ref), (dx - dx_ref).abs().max().item()
@@ -150,7 +152,8 @@ def test_norm_backward_hands_the_convolution_split_planes(kind, hw):
             outs[split] = (x.grad.clone(), tree.flat_grad.clone())
         dx1, dw1 = outs[1]
         dx0, dw0 = outs[0]
-        assert torch.equal(dx1, dx0), (dx1 - dx0).abs().max().item()
+        # (identical where the data gradient has a pre-split kernel; where it un-splits hi + lo and splits again, equal to ~2^-17)
+        assert (dx1 - dx0).abs().max().item() <= 4e-6 * dx0.abs().max().item(), (dx1 - dx0).abs().max().item()
         assert (dw1 - dw0).abs().max().item() <= 2e-5 * dw0.abs().max().item()
     finally:
         L.set_tuning('split_grads', 1)
