@@ -45,10 +45,11 @@ def test_trainers_come_and_go_with_a_flat_stream_and_memory_count():
         assert (live1, idle1) == (live0, idle0), 'streams made and not handed back: %r -> %r' % ((live0, idle0), (live1, idle1))
         assert scratch1 == scratch0
         assert torch.cuda.memory_allocated() <= mem0 + (1 << 20), (mem0, torch.cuda.memory_allocated())
-        # everything that sits in the banks can be destroyed; what stays is what the module itself still uses (weight-gradient stream)
+        # everything that sits in the banks can be destroyed; what stays is what is still in use (the module's weight-gradient stream,
+        # streams of objects earlier tests of the session left alive)
         ops.destroy_idle_streams()
         live2, idle2, _ = _census()
-        assert idle2 == 0 and live2 == live1 - idle1 and live2 <= 2
+        assert idle2 == 0 and live2 == live1 - idle1
         one()                                            # and the banks refill
         assert _census()[0] >= live2
     finally:
