@@ -70,6 +70,9 @@ _SIGS = {
     'hoig_split_planes_bf16': [_vp, _vp, _i64, _i, _vp],
     'hoig_conv2d_bwd_weight_split': [ctypes.POINTER(ConvDesc), _vp, _vp, _vp, _vp],
     'hoig_conv2d_bwd_data_packed_split': [ctypes.POINTER(ConvDesc), _vp, _vp, _vp, _vp, _vp, _vp],
+    'hoig_conv2d_fwd_packed_pair': [ctypes.POINTER(ConvDesc)] + [_vp] * 11,
+    'hoig_conv2d_bwd_data_packed_split_pair': [ctypes.POINTER(ConvDesc)] + [_vp] * 11,
+    'hoig_conv2d_bwd_weight_split_pair': [ctypes.POINTER(ConvDesc)] + [_vp] * 7,
     'hoig_conv2d_cat_bwd_weight': [ctypes.POINTER(ConvDesc), _vp, _i, _vp, _vp, _vp, _vp, _vp],
     'hoig_inorm_stats': [_vp, _i, _i, _i, _f, _vp, _vp, _vp, _vp],
     'hoig_inorm_apply': [_vp, _vp, _vp, _i, _vp, _vp, _i, _f, _vp, _vp, _i, _i, _i, _vp],

@@ -107,6 +107,13 @@ struct HaloArgs {
     int n1;
     const float *addend;       // same shape as C (single-output launches only): C = conv + addend -- the data gradient that lands in
                                // a tensor with a second consumer adds that consumer's gradient itself (ops.conv2d_fork)
+    // grouped launch (3x3 stride-1 kernel of conv_halo16.hip only): Bn counts the images of BOTH problems; images b >= b_split read and
+    // write the *_g2 tensors (indexed from their own image 0).  0: one problem.
+    int b_split;
+    const float *A_g2;
+    const unsigned short *Wh_g2, *Wl_g2;
+    const float *bias_g2, *addend_g2;
+    float *C_g2;
     int a_split;               // 1: A is a PRE-SPLIT tensor, per pixel [hi: Cg bf16][lo: Cg bf16] (hoig_split_planes_bf16): the 3x3
                                // stride-1 data gradient on conv_halo16.hip copies it to LDS without splitting (no A2 then)
     float *stats;              // (nullable) [Bn][2][N] fp32 accumulators: += per-image, per-channel sum and sum of squares of the
@@ -223,6 +230,11 @@ struct WHaloArgs {
                                // (ConvTranspose2d stride 2: the plain operand is x, the gathered one dy -- roles swapped)
     int tiles_x, tiles_y, n_mtiles, mt_per_split;
     int nblk_ci, nblk;
+    // grouped launch (wgrad_dma.hip only): Bn counts the images of BOTH problems; a workgroup whose pixel tiles lie in images >= b_split
+    // reads DY_g2 / X_g2 (indexed from their own image 0) and adds into DW_g2; a workgroup's tile range never straddles the two
+    int b_split;
+    const float *DY_g2, *X_g2;
+    float *DW_g2;
 #ifdef HOIG_STAMP
     unsigned long long *dbg;
 #endif

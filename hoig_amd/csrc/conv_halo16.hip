@@ -109,6 +109,15 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_halo3_m16_kernel(const Halo
     mt_ /= p.tiles_x;
     const int ty_ = mt_ % p.tiles_y, b = mt_ / p.tiles_y;
     const int y0 = ty_ * TH, x0 = tx_ * 32;
+    // grouped launch (p.b_split > 0): images b >= b_split are a SECOND problem of the same shape -- own input, weights, bias, addend,
+    // output -- whose tiles ride in this grid (src_model's and tsf_model's layer as one launch that fills the chip, instead of two
+    // half-chip launches on two streams); everything below addresses "its" tensors through these
+    const bool g2 = p.b_split > 0 && b >= p.b_split;
+    const int bi = g2 ? b - p.b_split : b;
+    const float *const gA = g2 ? p.A_g2 : p.A;
+    const unsigned short *const gWh = g2 ? p.Wh_g2 : p.Wh, *const gWl = g2 ? p.Wl_g2 : p.Wl;
+    const float *const gbias = g2 ? p.bias_g2 : p.bias, *const gadd = g2 ? p.addend_g2 : p.addend;
+    float *const gC = g2 ? p.C_g2 : p.C;
 
     // weight staging: thread -> (row, position in the 64-B row of the blocked plane); the plane's position holds logical chunk
     // pos ^ ((row >> 2) & 3) (plane_index)
@@ -121,8 +130,8 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_halo3_m16_kernel(const Halo
         const int n = n0 + row;
         const bool ok = n < p.N && (!B_PART || row < BN);
         const size_t o = ((size_t)(n >> 5) * (p.K >> 5)) * 1024 + (n & 31) * 32 + bpos * 8;
-        wrow_h[i] = ok ? p.Wh + o : nullptr;
-        wrow_l[i] = (NB == 2 && ok) ? p.Wl + o : nullptr;
+        wrow_h[i] = ok ? gWh + o : nullptr;
+        wrow_l[i] = (NB == 2 && ok) ? gWl + o : nullptr;
         const int c = bpos ^ ((row >> 2) & 3);
         woff[i] = (c >> 1) * W23 + row * 32 + (c & 1) * 16;
     }
@@ -174,7 +183,7 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_halo3_m16_kernel(const Halo
     auto halo_load = [&](int cb) {
         if constexpr (ASPLIT) {
             // slice i -> (pixel i >> 3, plane (i >> 2) & 1, 16-B chunk i & 3 of the block's 32 channels)
-            const unsigned short *Aimg = reinterpret_cast<const unsigned short *>(p.A) + (size_t)b * p.H * p.W * 2 * p.Cg + cb * 32;
+            const unsigned short *Aimg = reinterpret_cast<const unsigned short *>(gA) + (size_t)bi * p.H * p.W * 2 * p.Cg + cb * 32;
 #pragma unroll
             for (int sl = 0; sl < HSLICES; ++sl) {
                 const int i = tid + NT * sl;
@@ -192,7 +201,7 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_halo3_m16_kernel(const Halo
         }
         const bool second = p.A2 != nullptr && cb * 32 >= p.cg1;
         const int ld = p.A2 ? (second ? p.Cg - p.cg1 : p.cg1) : p.Cg;
-        const float *Aimg = (second ? p.A2 : p.A) + (size_t)b * p.H * p.W * ld + (second ? cb * 32 - p.cg1 : cb * 32);
+        const float *Aimg = (second ? p.A2 : gA) + (size_t)bi * p.H * p.W * ld + (second ? cb * 32 - p.cg1 : cb * 32);
 #pragma unroll
         for (int sl = 0; sl < HSLICES; ++sl) {
             const int i = tid + NT * sl;
@@ -316,7 +325,7 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_halo3_m16_kernel(const Halo
 #pragma unroll
     for (int j = 0; j < NTW; ++j) {
         const int n = n0 + wn * (NTW * 16) + j * 16 + lg * 4;
-        bias_r[j] = (p.bias && n < p.N) ? *reinterpret_cast<const float4 *>(p.bias + n) : make_float4(0.f, 0.f, 0.f, 0.f);
+        bias_r[j] = (gbias && n < p.N) ? *reinterpret_cast<const float4 *>(gbias + n) : make_float4(0.f, 0.f, 0.f, 0.f);
     }
     float st1[NTW][4], st2[NTW][4];
 #pragma unroll
@@ -326,7 +335,7 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_halo3_m16_kernel(const Halo
 #pragma unroll
     for (int m = 0; m < MT; ++m) {
         const int oy = y0 + wm * 2 + (m >> 1), ox = x0 + (m & 1) * 16 + l15;
-        const size_t pix = ((size_t)b * p.H + oy) * p.W + ox;
+        const size_t pix = ((size_t)bi * p.H + oy) * p.W + ox;
 #pragma unroll
         for (int j = 0; j < NTW; ++j) {
             const int n = n0 + wn * (NTW * 16) + j * 16 + lg * 4;
@@ -335,8 +344,8 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_halo3_m16_kernel(const Halo
                 const float bq[4] = {bias_r[j].x, bias_r[j].y, bias_r[j].z, bias_r[j].w};
 #pragma unroll
                 for (int q = 0; q < 4; ++q) v[q] = fast_act(acc[j][m][q] * p.oscale + bq[q], nslope, special, p.act, p.slope);
-                if (p.addend) {
-                    const float4 ad = *reinterpret_cast<const float4 *>(p.addend + pix * p.N + n);
+                if (gadd) {
+                    const float4 ad = *reinterpret_cast<const float4 *>(gadd + pix * p.N + n);
                     v[0] += ad.x; v[1] += ad.y; v[2] += ad.z; v[3] += ad.w;
                 }
 #pragma unroll
@@ -345,8 +354,8 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_halo3_m16_kernel(const Halo
                     st2[j][q] += v[q] * v[q];
                 }
                 const float4 o = make_float4(v[0], v[1], v[2], v[3]);
-                if (!p.C2) *reinterpret_cast<float4 *>(p.C + pix * p.N + n) = o;
-                else if (n < p.n1) *reinterpret_cast<float4 *>(p.C + pix * p.n1 + n) = o;      // (a 64-column group goes one way)
+                if (!p.C2) *reinterpret_cast<float4 *>(gC + pix * p.N + n) = o;
+                else if (n < p.n1) *reinterpret_cast<float4 *>(gC + pix * p.n1 + n) = o;      // (a 64-column group goes one way)
                 else *reinterpret_cast<float4 *>(p.C2 + pix * (p.N - p.n1) + (n - p.n1)) = o;
             }
         }
@@ -690,6 +699,7 @@ int launch_halo_s2_m16(const HaloArgs &a, int ns, bool scatter, hipStream_t st) 
 // of `bn` = 128 or 64
 int launch_halo3_m16(HaloArgs a, int ns, int bn, hipStream_t st) {
     if (a.H % 8 || a.W % 32 || a.Cg % 32 || a.N % 4) return HOIG_EUNSUPPORTED;
+    if (a.b_split > 0 && (a.A2 || a.C2 || a.stats || a.b_split >= a.Bn)) return HOIG_EUNSUPPORTED;
     if (bn == 128) HOIG_NS_SWITCH(ns, return launch_one<NSX, 128>(a, st));
     if (bn == 64) HOIG_NS_SWITCH(ns, return launch_one<NSX, 64>(a, st));
     return HOIG_EUNSUPPORTED;

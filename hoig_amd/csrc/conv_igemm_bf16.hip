@@ -1110,7 +1110,7 @@ int launch_halo3(HaloArgs a, int ns, hipStream_t st) {
             a.nblk = a.Bn * a.tiles_x * a.tiles_y * a.nblk_n;
             return launch_halo3_m16(a, ns, 64, st);
         }
-        if (a.a_split) return HOIG_EUNSUPPORTED;               // (pre-split input: conv_halo16.hip only)
+        if (a.a_split || a.b_split) return HOIG_EUNSUPPORTED;  // (pre-split input, grouped launch: conv_halo16.hip only)
         HOIG_NS_SWITCH(ns, return launch_halo3_one<NSX, 2, 2, 64, 0>(a, st));
     }
     if (m16 && hoig_tuning(HOIG_TUNE_FEW128) != 0 && a.H % 8 == 0 && a.nblk / 2 < 256 && a.nblk >= 192 && a.N % 128 == 0) {
@@ -1125,7 +1125,7 @@ int launch_halo3(HaloArgs a, int ns, hipStream_t st) {
         a.nblk_n = a.N / 64;
         a.nblk = a.Bn * a.tiles_x * a.tiles_y * a.nblk_n;
         if (m16) return launch_halo3_m16(a, ns, 64, st);
-        if (a.a_split) return HOIG_EUNSUPPORTED;
+        if (a.a_split || a.b_split) return HOIG_EUNSUPPORTED;
         HOIG_NS_SWITCH(ns, return launch_halo3_one<NSX, 4, 2, 64, 2>(a, st));
     }
     // 8 x 32 pixel tiles (8 waves, weight tile shared by 256 pixels) when that still gives every CU a workgroup
@@ -1133,10 +1133,10 @@ int launch_halo3(HaloArgs a, int ns, hipStream_t st) {
         a.tiles_y = a.H / 8;
         a.nblk = a.Bn * a.tiles_x * a.tiles_y * a.nblk_n;
         if (m16) return launch_halo3_m16(a, ns, 128, st);
-        if (a.a_split) return HOIG_EUNSUPPORTED;
+        if (a.a_split || a.b_split) return HOIG_EUNSUPPORTED;
         HOIG_NS_SWITCH(ns, return launch_halo3_one<NSX, 4, 2, 128, 2>(a, st));
     }
-    if (a.a_split) return HOIG_EUNSUPPORTED;
+    if (a.a_split || a.b_split) return HOIG_EUNSUPPORTED;
     const bool wide = a.nblk < 384;
     HOIG_NS_SWITCH(ns, return wide ? launch_halo3_one<NSX, 2, 4, 128, 1>(a, st) : launch_halo3_one<NSX, 2, 2, 128, 0>(a, st));
     return HOIG_EINVAL;
@@ -1600,9 +1600,17 @@ int launch_dgrad_thin(const float *dy, const unsigned short *wh, const unsigned 
     return HOIG_OK;
 }
 
+// the second problem of a grouped launch (hoig_conv2d_*_pair): same descriptor, its own tensors
+struct PairSet {
+    const float *a;
+    const unsigned short *wh, *wl;
+    const float *bias, *addend;
+    float *c;
+};
+
 int run(const hoig_conv_desc *d, const float *a, const unsigned short *wh, const unsigned short *wl, const float *bias,
         float *c, bool dgrad, hipStream_t st, const float *a2 = nullptr, int cg1 = 0, float *c2 = nullptr, int n1 = 0,
-        const float *addend = nullptr, float *stats = nullptr, bool a_split = false) {
+        const float *addend = nullptr, float *stats = nullptr, bool a_split = false, const PairSet *g2 = nullptr) {
     Args p;
     p.A = a; p.Wh = wh; p.Wl = wl; p.bias = bias; p.C = c;
     p.f16 = dgrad ? 0 : 1;                       // forward: fp16-split operands over the 2^8-scaled forward planes
@@ -1634,8 +1642,10 @@ int run(const hoig_conv_desc *d, const float *a, const unsigned short *wh, const
     // stride-1 "same" convolutions (and their data gradients): LDS-resident input halo, weights streamed per tap
     if (!d->transposed && d->stride == 1 && d->R == d->S && 2 * d->pad == d->R - 1 && (d->R == 1 || d->R == 3 || d->R == 5) &&
         d->Wi % 32 == 0 && d->Hi % 4 == 0 && p.N % 64 == 0 &&
-        (long)d->B * (d->Hi / 4) * (d->Wi / 32) * ((p.N + 127) / 128) >= 160) {   // fewer tiles: the generic kernel splits K
+        (long)(g2 ? 2 : 1) * d->B * (d->Hi / 4) * (d->Wi / 32) * ((p.N + 127) / 128) >= 160) {   // fewer tiles: the generic kernel splits K
         HaloArgs h;
+        h.b_split = 0;
+        h.A_g2 = nullptr; h.Wh_g2 = h.Wl_g2 = nullptr; h.bias_g2 = h.addend_g2 = nullptr; h.C_g2 = nullptr;
         h.A = a; h.Wh = wh; h.Wl = wl; h.bias = bias; h.C = c;
         h.A2 = a2; h.cg1 = cg1; h.C2 = c2; h.n1 = n1;
         h.addend = addend;
@@ -1648,6 +1658,11 @@ int run(const hoig_conv_desc *d, const float *a, const unsigned short *wh, const
         if (a2 && (cg1 % 32 || cg1 <= 0 || cg1 >= g.Cg)) return HOIG_EINVAL;
         if (c2 && (n1 % 64 || n1 <= 0 || n1 >= p.N)) return HOIG_EINVAL;
         h.Bn = d->B; h.H = d->Hi; h.W = d->Wi; h.Cg = g.Cg; h.N = p.N; h.K = p.K;
+        if (g2) {                            // grouped launch: both problems' images in one grid (3x3 kernel of conv_halo16.hip only)
+            if (d->R != 3 || a2 || c2 || stats) return HOIG_EUNSUPPORTED;
+            h.Bn = 2 * d->B; h.b_split = d->B;
+            h.A_g2 = g2->a; h.Wh_g2 = g2->wh; h.Wl_g2 = g2->wl; h.bias_g2 = g2->bias; h.addend_g2 = g2->addend; h.C_g2 = g2->c;
+        }
         h.pad = d->pad;                      // dgrad: KS-1-pad == pad for "same" convolutions
         h.flip = dgrad ? 1 : 0;
         h.act = p.act; h.slope = p.slope;
@@ -1656,7 +1671,7 @@ int run(const hoig_conv_desc *d, const float *a, const unsigned short *wh, const
         if (d->R == 3) return launch_halo3(h, ns, st);
         return launch_halo<5>(h, ns, st);
     }
-    if (a2 || c2 || a_split) return HOIG_EUNSUPPORTED;
+    if (a2 || c2 || a_split || g2) return HOIG_EUNSUPPORTED;
     // 3x3 "same" layers with too few tiles for the halo kernel above (N = 128 at 32 x 32: the data gradient of SPADE's 128 -> 1024
     // convolutions): a valid convolution over the zero-padded canvas on the flattened-axis kernel, split over the channel blocks
     if (hoig_tuning(HOIG_TUNE_FLAT5) >= 2 && !d->transposed && d->stride == 1 && d->R == 3 && d->S == 3 && d->pad == 1 &&
@@ -1697,6 +1712,7 @@ int run(const hoig_conv_desc *d, const float *a, const unsigned short *wh, const
             h.Bn = d->B; h.Cg = g.Cg; h.N = p.N; h.K = p.K;
             h.pad = 1; h.flip = 0;
             h.A2 = nullptr; h.cg1 = 0; h.C2 = nullptr; h.n1 = 0; h.addend = addend; h.stats = stats; h.a_split = 0;
+            h.b_split = 0;
             h.act = p.act; h.slope = p.slope;
             h.f16 = p.f16; h.oscale = p.oscale;
             const bool gather = !g.gatherT;      // the operand is read at 2*o - 1 + tap (fine grid) -> gather mode
@@ -1811,6 +1827,29 @@ extern "C" int hoig_conv2d_bwd_data_packed_split(const hoig_conv_desc *d, const 
     if (d->precision == HOIG_PREC_BF16X3 || d->transposed || d->stride != 1 || d->R != 3 || d->S != 3) return HOIG_EUNSUPPORTED;
     return run(d, reinterpret_cast<const float *>(dy_split), wt_hi, wt_lo, nullptr, dx, true, (hipStream_t)stream, nullptr, 0, nullptr, 0,
                addend, nullptr, true);
+}
+
+// GROUPED launches (include/hoig_kernels.h): two convolutions of ONE descriptor -- different tensors, different weights -- as one grid
+extern "C" int hoig_conv2d_fwd_packed_pair(const hoig_conv_desc *d, const float *xa, const float *xb, const uint16_t *wa_hi,
+                                           const uint16_t *wa_lo, const uint16_t *wb_hi, const uint16_t *wb_lo, const float *bias_a,
+                                           const float *bias_b, float *ya, float *yb, hoig_stream_t stream) {
+    if (!d || !xa || !xb || !wa_hi || !wb_hi || !ya || !yb) return HOIG_EINVAL;
+    if (!is_16bit_precision(d->precision)) return HOIG_EINVAL;
+    if (d->transposed || d->stride != 1 || d->R != 3 || d->S != 3) return HOIG_EUNSUPPORTED;
+    const PairSet g2{xb, wb_hi, wb_lo, bias_b, nullptr, yb};
+    return run(d, xa, wa_hi, wa_lo, bias_a, ya, false, (hipStream_t)stream, nullptr, 0, nullptr, 0, nullptr, nullptr, false, &g2);
+}
+extern "C" int hoig_conv2d_bwd_data_packed_split_pair(const hoig_conv_desc *d, const uint16_t *dys_a, const uint16_t *dys_b,
+                                                      const uint16_t *wta_hi, const uint16_t *wta_lo, const uint16_t *wtb_hi,
+                                                      const uint16_t *wtb_lo, const float *addend_a, const float *addend_b, float *dxa,
+                                                      float *dxb, hoig_stream_t stream) {
+    if (!d || !dys_a || !dys_b || !wta_hi || !wtb_hi || !dxa || !dxb) return HOIG_EINVAL;
+    if (!is_16bit_precision(d->precision)) return HOIG_EINVAL;
+    if (d->precision == HOIG_PREC_BF16X3 || d->transposed || d->stride != 1 || d->R != 3 || d->S != 3) return HOIG_EUNSUPPORTED;
+    if ((addend_a == nullptr) != (addend_b == nullptr)) return HOIG_EINVAL;
+    const PairSet g2{reinterpret_cast<const float *>(dys_b), wtb_hi, wtb_lo, nullptr, addend_b, dxb};
+    return run(d, reinterpret_cast<const float *>(dys_a), wta_hi, wta_lo, nullptr, dxa, true, (hipStream_t)stream, nullptr, 0, nullptr, 0,
+               addend_a, nullptr, true, &g2);
 }
 
 // conv(cat[x1, x2]) and its data gradient [dx1 | dx2] without materialising the concatenation (3x3 stride-1 "same" only)
@@ -2366,11 +2405,21 @@ __global__ __launch_bounds__(128 * KS * CM) void wgrad_halo_bf16_kernel(const WH
 #endif
 }
 
+struct WPairSet {
+    const float *x, *dy;
+    float *dw;
+};
 int launch_wgrad_halo(const hoig_conv_desc *d, const float *x, const float *dy, float *dw, float *dbias, int ns,
-                      hipStream_t st, const float *x2 = nullptr, int ci1 = 0, bool dy_split = false) {
+                      hipStream_t st, const float *x2 = nullptr, int ci1 = 0, bool dy_split = false, const WPairSet *g2 = nullptr) {
     WHaloArgs a;
     a.DY = dy; a.X = x; a.DW = dw; a.DB = dbias; a.X2 = x2; a.ci1 = ci1;
     a.Bn = d->B; a.H = d->Ho; a.W = d->Wo; a.Co = d->Co; a.Ci = d->Ci;
+    a.b_split = 0; a.DY_g2 = a.X_g2 = nullptr; a.DW_g2 = nullptr;
+    if (g2) {                  // grouped launch: both problems' pixel tiles in one grid (LDS-DMA kernel only: dy_split)
+        if (!dy_split || d->transposed || x2) return HOIG_EUNSUPPORTED;
+        a.Bn = 2 * d->B; a.b_split = d->B;
+        a.DY_g2 = g2->dy; a.X_g2 = g2->x; a.DW_g2 = g2->dw;
+    }
     a.Hin = d->Hi; a.Win = d->Wi; a.pad = d->pad;
     a.tout = 0;
     if (d->transposed) {       // dW[ci][co][r][s] = sum_i x[i] dy[2i - 1 + (r,s)]: x is the plain operand, dy the gathered one
@@ -2400,6 +2449,7 @@ int launch_wgrad_halo(const hoig_conv_desc *d, const float *x, const float *dy, 
     int splits = (int)hoig_cdiv((d->R == 5 ? target / 2 : target) / cm, a.nblk);
     if (splits > a.n_mtiles) splits = a.n_mtiles;
     if (splits < 1) splits = 1;
+    if (g2) splits = 2 * (int)hoig_cdiv(splits, 2);                       // (the same number of tile ranges in either problem)
     a.mt_per_split = (int)hoig_cdiv(a.n_mtiles, splits);
     splits = (int)hoig_cdiv(a.n_mtiles, a.mt_per_split);
     dim3 grid(a.nblk, splits);
@@ -2500,6 +2550,17 @@ extern "C" int hoig_conv2d_bwd_weight_split(const hoig_conv_desc *d, const float
         return HOIG_EUNSUPPORTED;
     return launch_wgrad_halo(d, x, reinterpret_cast<const float *>(dy_split), dw, nullptr, ns_of_precision(d->precision),
                              (hipStream_t)stream, nullptr, 0, true);
+}
+
+extern "C" int hoig_conv2d_bwd_weight_split_pair(const hoig_conv_desc *d, const float *xa, const float *xb, const uint16_t *dys_a,
+                                                 const uint16_t *dys_b, float *dwa, float *dwb, hoig_stream_t stream) {
+    if (!d || !xa || !xb || !dys_a || !dys_b || !dwa || !dwb) return HOIG_EINVAL;
+    if (!is_16bit_precision(d->precision) || d->precision == HOIG_PREC_BF16X3 || d->transposed || d->stride != 1 || d->R != 3 ||
+        d->S != 3 || !hoig_conv_bf16_wgrad_fuses_bias(d) || (d->Co & 127))
+        return HOIG_EUNSUPPORTED;
+    const WPairSet g2{xb, reinterpret_cast<const float *>(dys_b), dwb};
+    return launch_wgrad_halo(d, xa, reinterpret_cast<const float *>(dys_a), dwa, nullptr, ns_of_precision(d->precision),
+                             (hipStream_t)stream, nullptr, 0, true, &g2);
 }
 
 // weight gradient of conv(cat[x1, x2]) (3x3 stride-1 "same", bf16 halo kernel only)

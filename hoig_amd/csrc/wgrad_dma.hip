@@ -50,8 +50,14 @@ __global__ __launch_bounds__(D_NT) void wgrad_dma_kernel(const WHaloArgs p) {
     const int c0 = (tile / p.nblk_ci) * BM, ci0 = (tile % p.nblk_ci) * BC;
     const int mt_begin = blockIdx.y * p.mt_per_split;
     const int mt_end = min(p.n_mtiles, mt_begin + p.mt_per_split);
-    const unsigned short *const DYS = reinterpret_cast<const unsigned short *>(p.DY);      // split: [pixel][2][Co] bf16
     const size_t pstr = (size_t)2 * p.Co;                   // pixel stride of the split tensor, in bf16 units
+    // grouped launch: this workgroup's tiles all lie in one of the two problems (the launcher aligns the tile ranges); its tensors are
+    // addressed from image b_split
+    const bool g2 = p.b_split > 0 && mt_begin >= p.b_split * p.tiles_x * p.tiles_y;
+    const int b_off = g2 ? p.b_split : 0;
+    const unsigned short *const DYS = reinterpret_cast<const unsigned short *>(g2 ? p.DY_g2 : p.DY) -
+                                      (size_t)b_off * p.H * p.W * pstr;                    // split: [pixel][2][Co] bf16
+    float *const DWg = g2 ? p.DW_g2 : p.DW;
 
     // ---- dy: LDS-DMA.  Piece j of a plane = pixels 4j .. 4j+3 (1 KB); lane l: pixel 4j + (l >> 4), LDS chunk l & 15 <- source chunk
     // (l & 15) ^ (4 * (l >> 4)).  The lane's share of the address is the same for every piece.
@@ -96,8 +102,8 @@ __global__ __launch_bounds__(D_NT) void wgrad_dma_kernel(const WHaloArgs p) {
     }
     const bool second = p.X2 != nullptr && ci0 >= p.ci1;
     const int ldx = p.X2 ? (second ? p.Ci - p.ci1 : p.ci1) : p.Ci;
-    const float *const xc = (second ? p.X2 : p.X) + (second ? ci0 - p.ci1 : ci0) + (tid & 7) * 4;
     const size_t ximg = (size_t)p.Hin * p.Win * ldx;
+    const float *const xc = (second ? p.X2 : (g2 ? p.X_g2 : p.X)) - (size_t)b_off * ximg + (second ? ci0 - p.ci1 : ci0) + (tid & 7) * 4;
     struct Tile { int b, ty, tx; };
     auto tile_of = [&](int mt) -> Tile {
         const int tx = mt % p.tiles_x, t2 = mt / p.tiles_x;
@@ -242,7 +248,7 @@ __global__ __launch_bounds__(D_NT) void wgrad_dma_kernel(const WHaloArgs p) {
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
         const int co = c0 + cb * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
-        float *row = p.DW + (size_t)co * K + (tr * KS) * p.Ci + ci0 + l31;
+        float *row = DWg + (size_t)co * K + (tr * KS) * p.Ci + ci0 + l31;
 #pragma unroll
         for (int t = 0; t < KS; ++t) atomicAdd(row + t * p.Ci, acc[t][r]);
     }
@@ -285,6 +291,7 @@ __global__ __launch_bounds__(256) void unsplit_planes_kernel(const unsigned shor
 int launch_wgrad_dma(const WHaloArgs &a, int ns, dim3 grid, hipStream_t st) {
     if (a.tout || a.DB || ns == 2 || a.W % 32 || a.H % 4 || a.Ci % 32 || a.Co % 128 || a.pad != 1 || a.Hin != a.H || a.Win != a.W)
         return HOIG_EUNSUPPORTED;
+    if (a.b_split > 0 && (a.X2 || a.b_split >= a.Bn || (a.b_split * a.tiles_x * a.tiles_y) % a.mt_per_split)) return HOIG_EUNSUPPORTED;
     static hoig_once once;
     if (!once.done()) {
         if (hipFuncSetAttribute(reinterpret_cast<const void *>(&wgrad_dma_kernel<2>), hipFuncAttributeMaxDynamicSharedMemorySize,

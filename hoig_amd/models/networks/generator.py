@@ -129,6 +129,56 @@ class Generator(ParamTree):
         dx = self._conv(self._spade(dx, seg, name + '.norm_1', ACT_RELU), name + '.conv_1')
         return ops.add(x, dx)
 
+    # ---- src_model's and tsf_model's residual blocks in lock-step (ops.conv2d_pair): the two sub-networks have one architecture and
+    # separate weights (generator.py:379-464), 8 images each at the bench's batch -- two half-chip launches per layer on two streams.
+    # Their 3x3 512 -> 512 convolutions run as GROUPED launches on the caller's stream instead (one grid over both problems: forward,
+    # data gradient, weight gradient); everything between them -- norms, SPADE's small convolutions -- stays on the two streams.
+    # `sy` = (on_src, to_main, to_src): the src stream's context and the two hand-overs (no-ops when everything is on one stream).
+    def _resblock_pair(self, sx, tx, ns, nt, sy):
+        on_src, to_main, to_src = sy
+        P = self.P
+        hs, ht, sx, tx = ops.conv2d_pair(to_main(sx), tx, P[ns + '.main.0.weight'], P[nt + '.main.0.weight'], dead_bias=True, fork=True)
+        to_src(hs); to_src(sx)
+        with on_src():
+            hs = self._in(hs, ns + '.main.1', act=ACT_RELU)
+        ht = self._in(ht, nt + '.main.1', act=ACT_RELU)
+        hs, ht = ops.conv2d_pair(to_main(hs), ht, P[ns + '.main.3.weight'], P[nt + '.main.3.weight'], dead_bias=True)
+        to_src(hs)
+        with on_src():
+            sx = self._in(hs, ns + '.main.4', residual=sx)
+        return sx, self._in(ht, nt + '.main.4', residual=tx)
+
+    def _spade_resblock_pair(self, sx, tx, segs, segt, ns, nt, sy):
+        on_src, to_main, to_src = sy
+        P = self.P
+        with on_src():
+            hs, sx = self._spade(sx, segs, ns + '.norm_0', ACT_RELU, fork=True)
+        ht, tx = self._spade(tx, segt, nt + '.norm_0', ACT_RELU, fork=True)
+        ds, dt = ops.conv2d_pair(to_main(hs), ht, P[ns + '.conv_0.weight'], P[nt + '.conv_0.weight'], P.get(ns + '.conv_0.bias'),
+                                 P.get(nt + '.conv_0.bias'), dead_bias=True)
+        to_src(ds)
+        with on_src():
+            hs = self._spade(ds, segs, ns + '.norm_1', ACT_RELU)
+        ht = self._spade(dt, segt, nt + '.norm_1', ACT_RELU)
+        ds, dt = ops.conv2d_pair(to_main(hs), ht, P[ns + '.conv_1.weight'], P[nt + '.conv_1.weight'], P.get(ns + '.conv_1.bias'),
+                                 P.get(nt + '.conv_1.bias'))
+        to_src(ds)
+        with on_src():
+            sx = ops.add(sx, ds)
+        return sx, ops.add(tx, dt)
+
+    def _resnet_pair(self, sx, tx, segs, segt, i, sy):
+        """-> (src_model's, tsf_model's residual block i), or None where the grouped kernels do not cover the layer."""
+        c = self.cfg
+        ns, nt = 'src_model.resnets.%d' % i, 'tsf_model.resnets.%d' % i
+        spade = c.spade_layers[1] if i < c.repeat_num // 2 else c.spade_layers[2]
+        wkey = '.conv_0.weight' if spade else '.main.0.weight'
+        if not ops.pair_ok(sx, tx, self.P[ns + wkey], self.P[nt + wkey]):
+            return None
+        if spade:
+            return self._spade_resblock_pair(sx, tx, segs, segt, ns, nt, sy)
+        return self._resblock_pair(sx, tx, ns, nt, sy)
+
     def _spade_block(self, x, seg, name, down, fork=False):                # generator.py:74-90
         if fork:
             h, x = self._conv_fork(x, name + '.conv', stride=2)
@@ -342,11 +392,23 @@ class Generator(ParamTree):
             s_enc.append(sx)
             t_enc.append(tx)
             advance()
+        def to_src(t_):                                      # the src stream may read a tensor made on the main stream
+            if fork_src:
+                s_src.wait_stream(main)
+                ops.cross_stream(t_, s_src)
+            return t_
+
         for i in range(c.repeat_num):
-            with on_src():
-                sx = self._resnet(sx, src_hand_c, 'src_model', i)
-                gs, sx = self._attn_source(sx, i + c.n_down + 1)
-            tx = self._resnet(tx, tsf_hand_c, 'tsf_model', i)
+            pair = self._resnet_pair(sx, tx, src_hand_c, tsf_hand_c, i, (on_src, src_ready, to_src))
+            if pair is not None:
+                sx, tx = pair
+                with on_src():
+                    gs, sx = self._attn_source(sx, i + c.n_down + 1)
+            else:
+                with on_src():
+                    sx = self._resnet(sx, src_hand_c, 'src_model', i)
+                    gs, sx = self._attn_source(sx, i + c.n_down + 1)
+                tx = self._resnet(tx, tsf_hand_c, 'tsf_model', i)
             warped, sx, tx = self._transform(src_ready(sx), T, i + c.n_down + 1, y=tx, gs=None if gs is None else src_ready(gs))
             tx = ops.add(tx, warped)
             advance()

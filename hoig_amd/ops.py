@@ -638,6 +638,127 @@ def conv2d_fork(x, w, b=None, stride=1, pad=0, act=L.ACT_NONE, slope=0.0, prec=N
     return (_tag_split(y) if getattr(y.grad_fn, 'split_ok', False) else y), xr
 
 
+def pair_ok(xa, xb, wa, wb, prec=None):
+    """May conv3x3(xa, wa) and conv3x3(xb, wb) run as grouped launches (ops.conv2d_pair)?  The layers every one of the three grouped
+    kernels covers: same shapes, flat weights, stride-1 "same" 3x3, Wi % 32 == 0, Hi % 8 == 0, Ci % 32 == 0, Co % 128 == 0, a 16-bit
+    forward and a two- or one-term backward (pre-split dy)."""
+    prec = precision if prec is None else prec
+    if not L.lib.hoig_set_tuning(b'pair', -1) or prec in (L.PREC_F32, L.PREC_F16F6) or not xa.is_cuda:
+        return False
+    if xa.shape != xb.shape or wa.shape != wb.shape or tuple(wa.shape[2:]) != (3, 3) or wa.shape[1] != xa.shape[-1]:
+        return False
+    if not (getattr(wa, '_hoig_flat', False) and getattr(wb, '_hoig_flat', False)):
+        return False
+    B, H, W_, Ci = xa.shape
+    Co = wa.shape[0]
+    if W_ % 32 or H % 8 or Ci % 32 or Co % 128 or 2 * B * (H // 8) * (W_ // 32) * (Co // 128) < 96:
+        return False
+    return precision_dgrad in (L.PREC_F16X2, L.PREC_BF16) and precision_wgrad in (L.PREC_F16X2, L.PREC_BF16) and prec == precision
+
+
+class _ConvPair(Function):
+    """(conv3x3(xa, wa) + ba, conv3x3(xb, wb) + bb) -- src_model's and tsf_model's layer (generator.py:379-464: one architecture, two
+    parameter sets, 8 images each at the bench's batch) -- as GROUPED launches: forward, data gradient and weight gradient each run as
+    one grid over both problems (hoig_conv2d_*_pair), which fills the chip where the two single launches each covered half of it.
+    The backward reads pre-split dy: a gradient that arrives as planes (from a norm's backward: _take_split) is used as it is, an fp32
+    one is split once (hoig_split_planes_bf16), after its bias gradient has been taken.  fork: as _Conv (xa, xb have second readers)."""
+
+    @staticmethod
+    def forward(ctx, xa, xb, wa, wb, ba, bb, prec, dead_bias, fork):
+        for t in (xa, xb, wa, wb, ba, bb):
+            _chk(t)
+        assert xa.is_contiguous() and xb.is_contiguous()
+        B, H, W_, Ci = xa.shape
+        Co = wa.shape[0]
+        d = ConvDesc(B, H, W_, Ci, H, W_, Co, 3, 3, 1, 1, 0, L.ACT_NONE, 0.0, prec)
+        ya, yb = torch.empty((B, H, W_, Co), dtype=xa.dtype, device=xa.device), torch.empty((B, H, W_, Co), dtype=xa.dtype, device=xa.device)
+        live = ba is not None and not dead_bias
+        (ha, la), (hb, lb) = _packed_planes(wa, False, False), _packed_planes(wb, False, False)
+        rc = L.lib.hoig_conv2d_fwd_packed_pair(ctypes.byref(d), _p(xa), _p(xb), _p(ha), _p(la), _p(hb), _p(lb), _p(ba) if live else None,
+                                               _p(bb) if live else None, _p(ya), _p(yb), _st())
+        if rc == L.EUNSUPPORTED:              # (no grouped tiling for this shape: one after the other)
+            _conv_fwd_raw(d, xa, wa, ba if live else None, ya)
+            _conv_fwd_raw(d, xb, wb, bb if live else None, yb)
+        else:
+            L.check(rc, 'hoig_conv2d_fwd_packed_pair')
+        ctx.d_dg, ctx.d_wg = _bwd_descs(d)
+        ctx.live_bias = live
+        ctx.save_for_backward(xa, xb, wa, wb, ba if live else None, bb if live else None)
+        ctx.split_ok = dead_bias and _split_backward_ok(d, wa, live, False)
+        ctx.fork = fork
+        if fork:
+            ctx.set_materialize_grads(False)
+            return ya, yb, xa, xb
+        return ya, yb
+
+    @staticmethod
+    def backward(ctx, dya, dyb, dxra=None, dxrb=None):
+        xa, xb, wa, wb, ba, bb = ctx.saved_tensors
+        if dya is None or dyb is None:
+            raise RuntimeError('conv2d_pair: both outputs must be used (a grouped launch has no half)')
+        d_dg, d_wg = ctx.d_dg, ctx.d_wg
+        B, H, W_, Co = dya.shape
+        npix = B * H * W_
+        dys, db_ret = [], [None, None]
+        for i, (dy, b) in enumerate(((dya, ba), (dyb, bb))):
+            dy = dy.contiguous()
+            if _take_split(dy):
+                dys.append(dy)
+                continue
+            if ctx.live_bias and ctx.needs_input_grad[4 + i]:
+                db, ret_b = _grad_target(b)
+                call('hoig_colsum_accum', _p(dy), _p(db), npix, Co, _st())
+                db_ret[i] = db if ret_b else None
+            sp = torch.empty_like(dy)
+            call('hoig_split_planes_bf16', _p(dy), _p(sp), npix, Co, _st())
+            dys.append(sp)
+        dwa, ret_a = _grad_target(wa)
+        dwb, ret_b = _grad_target(wb)
+        side = _wgrad_side_stream(xa.device) if not (ret_a or ret_b) else None
+        if side is not None:
+            side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side) if side is not None else contextlib.nullcontext():
+            if side is not None:
+                test_delay('wgrad')
+            rc = L.lib.hoig_conv2d_bwd_weight_split_pair(ctypes.byref(d_wg), _p(xa), _p(xb), _p(dys[0]), _p(dys[1]), _p(dwa), _p(dwb), _st())
+            if rc == L.EUNSUPPORTED:
+                for x, sp, dw in ((xa, dys[0], dwa), (xb, dys[1], dwb)):
+                    call('hoig_conv2d_bwd_weight_split', ctypes.byref(d_wg), _p(x), _p(sp), _p(dw), _st())
+            else:
+                L.check(rc, 'hoig_conv2d_bwd_weight_split_pair')
+        if side is not None:
+            _wgrad_hold(side, (xa, xb, dys[0], dys[1]))
+        dxa = dxb = None
+        if ctx.needs_input_grad[0] or ctx.needs_input_grad[1]:
+            dxa, dxb = torch.empty_like(xa), torch.empty_like(xb)
+            adds = [None if t is None else t.contiguous() for t in (dxra, dxrb)]
+            if (adds[0] is None) != (adds[1] is None):
+                adds = [t if t is not None else torch.zeros_like(xa) for t in adds]
+            (ha, la), (hb, lb) = _packed_planes(wa, False, True), _packed_planes(wb, False, True)
+            rc = L.lib.hoig_conv2d_bwd_data_packed_split_pair(ctypes.byref(d_dg), _p(dys[0]), _p(dys[1]), _p(ha), _p(la), _p(hb), _p(lb),
+                                                              _p(adds[0]), _p(adds[1]), _p(dxa), _p(dxb), _st())
+            if rc == L.EUNSUPPORTED:
+                for sp, hi, lo, add, dx, w in ((dys[0], ha, la, adds[0], dxa, wa), (dys[1], hb, lb, adds[1], dxb, wb)):
+                    rc1 = L.lib.hoig_conv2d_bwd_data_packed_split(ctypes.byref(d_dg), _p(sp), _p(hi), _p(lo), _p(add), _p(dx), _st())
+                    if rc1 == L.EUNSUPPORTED:
+                        _conv_dgrad_raw(d_dg, _unsplit(sp), w, dx, False, addend=add)
+                    else:
+                        L.check(rc1, 'hoig_conv2d_bwd_data_packed_split')
+            else:
+                L.check(rc, 'hoig_conv2d_bwd_data_packed_split_pair')
+        return dxa, dxb, (dwa if ret_a else None), (dwb if ret_b else None), db_ret[0], db_ret[1], None, None, None
+
+
+def conv2d_pair(xa, xb, wa, wb, ba=None, bb=None, prec=None, dead_bias=False, fork=False):
+    """-> (ya, yb) [+ (xa', xb') with fork=True: see conv2d_fork]: the two 3x3 convolutions as grouped launches.  Callers check
+    pair_ok() first; anything else goes through conv2d / conv2d_fork twice."""
+    out = _ConvPair.apply(xa, xb, wa, wb, ba, bb, precision if prec is None else prec, dead_bias, fork)
+    if getattr(out[0].grad_fn, 'split_ok', False):
+        _tag_split(out[0])
+        _tag_split(out[1])
+    return out
+
+
 class _ConvCat2(Function):
     """conv3x3(cat[x1, x2]) for the decoder's skip convolutions (generator.py:305-306) WITHOUT the concatenated tensor: the
     halo kernels read their input halo from x1 or x2 by channel block (forward, weight gradient) and write the data

@@ -98,6 +98,22 @@ int hoig_conv2d_bwd_weight_split(const hoig_conv_desc *d, const float *x, const 
 int hoig_conv2d_bwd_data_packed_split(const hoig_conv_desc *d, const uint16_t *dy_split, const uint16_t *wt_hi, const uint16_t *wt_lo,
                                       const float *addend /*nullable*/, float *dx, hoig_stream_t stream);
 
+/* GROUPED launches (round 5): two convolutions of ONE descriptor d (d->B images each) over different tensors with different weights --
+ * src_model's and tsf_model's layer (generator.py:379-464: same architecture, separate parameters) -- as ONE grid: the tiles of the
+ * second problem ride behind the first's, so the launch fills the chip where the two half-size launches each covered half of it.
+ * Results are those of the two single launches.  Stride-1 "same" 3x3 layers on the 8-row tilings of conv_halo16.hip / on
+ * wgrad_dma.hip; HOIG_EUNSUPPORTED otherwise (the caller launches the two problems one after the other).  The backward forms read
+ * pre-split dy ('PRE-SPLIT gradients' above); addend_a / addend_b: both or neither. */
+int hoig_conv2d_fwd_packed_pair(const hoig_conv_desc *d, const float *xa, const float *xb, const uint16_t *wa_hi, const uint16_t *wa_lo,
+                                const uint16_t *wb_hi, const uint16_t *wb_lo, const float *bias_a /*nullable*/,
+                                const float *bias_b /*nullable*/, float *ya, float *yb, hoig_stream_t stream);
+int hoig_conv2d_bwd_data_packed_split_pair(const hoig_conv_desc *d, const uint16_t *dys_a, const uint16_t *dys_b, const uint16_t *wta_hi,
+                                           const uint16_t *wta_lo, const uint16_t *wtb_hi, const uint16_t *wtb_lo,
+                                           const float *addend_a /*nullable*/, const float *addend_b /*nullable*/, float *dxa, float *dxb,
+                                           hoig_stream_t stream);
+int hoig_conv2d_bwd_weight_split_pair(const hoig_conv_desc *d, const float *xa, const float *xb, const uint16_t *dys_a,
+                                      const uint16_t *dys_b, float *dwa, float *dwb, hoig_stream_t stream);
+
 /* Forward of a stride-1 'same' convolution with <= 16 output channels over Ci % 64 == 0 inputs and ONE activation PER OUTPUT
  * CHANNEL (acts: the HOIG_ACT_* code of channel f in bits [4f, 4f+4)): the generator's image / mask heads (generator.py:219-235,
  * 311-315: tanh image, sigmoid masks) evaluated as one convolution over the decoder's last feature map.  7x7 with <= 5
@@ -477,6 +493,9 @@ const char *hoig_version(void);
  *                G's backward instead of after it; 0: after (both orders compute the same step: D's weights change only in D's own
  *                update, which stays last).  With an exchange (world > 1) it always follows G's backward: G's all-reduce hides behind it
  *   "wgrad16" 0  the stride-1 3x3 weight gradients on 16x16x32 (wgrad_halo16.hip): measured 5-20 % slower than 32x32x16
+ *   "pair"    1  (read by the host side, hoig_amd/models/networks/generator.py) the 3x3 512 -> 512 convolutions of src_model's and
+ *                tsf_model's residual blocks as grouped launches (hoig_conv2d_*_pair); 0: one launch per sub-network, on two streams
+ *   "wgrad_ko" 0  diagnostic instantiations of wgrad_dma_kernel (tools/ab_conv.py; results are WRONG with any bit set)
  *   "split_grads" 1  (read by the host side, hoig_amd/ops.py) the backward of a norm that follows an eligible 3x3 convolution writes its
  *                dx as bf16 hi | lo planes and that convolution's weight / data gradient read them without splitting ('PRE-SPLIT
  *                gradients' above); 0: fp32 gradients everywhere, split in every consuming workgroup

@@ -163,3 +163,92 @@ def test_norm_backward_hands_the_convolution_split_planes(kind, hw):
     finally:
         L.set_tuning('split_grads', 1)
         ops.set_precision('f32')
+
+
+@pytest.mark.parametrize('shape', [(8, 32, 32, 512, 512), (2, 64, 64, 128, 256), (4, 32, 32, 128, 1024)])
+def test_grouped_launch_equals_the_two_single_launches(shape):
+    """hoig_conv2d_*_pair: two convolutions of one descriptor (different tensors, different weights) as ONE grid -- src_model's and
+    tsf_model's layer.  Forward and data gradient are those of the single launches bit for bit (one workgroup per output tile either
+    way); the weight gradients agree to the order of the atomics."""
+    from hoig_amd import _lib as L, ops
+    B, H, W, Ci, Co = shape
+    g = torch.Generator(device='cuda').manual_seed(5 + B)
+    st = torch.cuda.current_stream().cuda_stream
+    xs = [torch.randn(B, H, W, Ci, device='cuda', generator=g) for _ in range(2)]
+    dys = [torch.randn(B, H, W, Co, device='cuda', generator=g) * 0.1 for _ in range(2)]
+    ws = [ops.pack_weight(torch.randn(Co, Ci, 3, 3, device='cuda', generator=g) * 0.02) for _ in range(2)]
+    bias = [torch.randn(Co, device='cuda', generator=g) for _ in range(2)]
+    adds = [torch.randn(B, H, W, Ci, device='cuda', generator=g) for _ in range(2)]
+    fwd_planes = [ops._packed_planes(w, False, False) for w in ws]
+    bwd_planes = [ops._packed_planes(w, False, True) for w in ws]
+    d = L.ConvDesc(B, H, W, Ci, H, W, Co, 3, 3, 1, 1, 0, L.ACT_NONE, 0.0, L.PREC_BF16X3)
+    d2 = L.ConvDesc(B, H, W, Ci, H, W, Co, 3, 3, 1, 1, 0, L.ACT_NONE, 0.0, L.PREC_F16X2)
+    # forward
+    y_ref = [torch.empty(B, H, W, Co, device='cuda') for _ in range(2)]
+    for i in range(2):
+        L.call('hoig_conv2d_fwd_packed', ctypes.byref(d), _p(xs[i]), _p(fwd_planes[i][0]), _p(fwd_planes[i][1]), _p(bias[i]), _p(y_ref[i]), st)
+    y = [torch.empty_like(t) for t in y_ref]
+    rc = L.lib.hoig_conv2d_fwd_packed_pair(ctypes.byref(d), _p(xs[0]), _p(xs[1]), _p(fwd_planes[0][0]), _p(fwd_planes[0][1]),
+                                           _p(fwd_planes[1][0]), _p(fwd_planes[1][1]), _p(bias[0]), _p(bias[1]), _p(y[0]), _p(y[1]), st)
+    if rc == L.EUNSUPPORTED:
+        pytest.skip('no grouped tiling for %r' % (shape,))
+    assert rc == 0
+    torch.cuda.synchronize()
+    assert torch.equal(y[0], y_ref[0]) and torch.equal(y[1], y_ref[1])
+    # backward from split dy
+    sp = [torch.empty(B, H, W, 2, Co, dtype=torch.bfloat16, device='cuda') for _ in range(2)]
+    for i in range(2):
+        L.call('hoig_split_planes_bf16', _p(dys[i]), _p(sp[i]), B * H * W, Co, st)
+    for with_add in (False, True):
+        dx_ref = [torch.empty(B, H, W, Ci, device='cuda') for _ in range(2)]
+        for i in range(2):
+            if with_add:
+                L.call('hoig_conv2d_bwd_data_packed_add', ctypes.byref(d2), _p(dys[i]), _p(bwd_planes[i][0]), _p(bwd_planes[i][1]), _p(adds[i]),
+                       _p(dx_ref[i]), st)
+            else:
+                L.call('hoig_conv2d_bwd_data_packed', ctypes.byref(d2), _p(dys[i]), _p(bwd_planes[i][0]), _p(bwd_planes[i][1]), _p(dx_ref[i]), st)
+        dx = [torch.empty_like(t) for t in dx_ref]
+        L.call('hoig_conv2d_bwd_data_packed_split_pair', ctypes.byref(d2), _p(sp[0]), _p(sp[1]), _p(bwd_planes[0][0]), _p(bwd_planes[0][1]),
+               _p(bwd_planes[1][0]), _p(bwd_planes[1][1]), _p(adds[0]) if with_add else None, _p(adds[1]) if with_add else None,
+               _p(dx[0]), _p(dx[1]), st)
+        torch.cuda.synchronize()
+        assert torch.equal(dx[0], dx_ref[0]) and torch.equal(dx[1], dx_ref[1]), with_add
+    dw_ref = [torch.zeros(Co, 3, 3, Ci, device='cuda') for _ in range(2)]
+    for i in range(2):
+        L.call('hoig_conv2d_bwd_weight_split', ctypes.byref(d2), _p(xs[i]), _p(sp[i]), _p(dw_ref[i]), st)
+    dw = [torch.zeros_like(t) for t in dw_ref]
+    L.call('hoig_conv2d_bwd_weight_split_pair', ctypes.byref(d2), _p(xs[0]), _p(xs[1]), _p(sp[0]), _p(sp[1]), _p(dw[0]), _p(dw[1]), st)
+    torch.cuda.synchronize()
+    for i in range(2):
+        assert (dw[i] - dw_ref[i]).abs().max().item() <= 2e-5 * dw_ref[i].abs().max().item(), i
+
+
+def test_step_with_grouped_launches_matches_the_step_without():
+    """Trainer at 256 x 256, batch 4, with src_model's / tsf_model's residual-block convolutions as grouped launches (tuning key `pair`)
+    and as one launch per sub-network: the forward is identical (the same tiles, issued in one grid), the seven loss terms agree, the
+    generator's gradient agrees to the order of the fp32 atomics / mask flips."""
+    from common import product_trainer
+    from hoig_amd import _lib as L, ops
+    ops.set_precision('bf16x3:f16x2')
+    res = {}
+    try:
+        for pair in (1, 0):
+            L.set_tuning('pair', pair)
+            m = product_trainer('generator_spade_attn', 4, 256)
+            with torch.no_grad():
+                outs = [o.float().clone() for o in m.forward()]
+            m.optimize_parameters()
+            torch.cuda.synchronize()
+            res[pair] = (outs, dict(m.get_current_errors()), m._net(m._G).flat_grad.clone())
+            m.close()
+            del m
+            torch.cuda.empty_cache()
+    finally:
+        L.set_tuning('pair', 1)
+        ops.set_precision('f32')
+    for a, b in zip(res[1][0], res[0][0]):
+        assert torch.equal(a, b)
+    for k, v in res[0][1].items():
+        assert abs(res[1][1][k] - v) <= 1e-5 * max(abs(v), 1e-2), (k, res[1][1][k], v)
+    g1, g0 = res[1][2], res[0][2]
+    assert ((g1 - g0).norm() / g0.norm()).item() < 2e-2

@@ -70,15 +70,31 @@ def main():
             'dgrad': lambda: L.call('hoig_conv2d_bwd_data_packed', ctypes.byref(d_dg), p(dy), p(thi), p(tlo), p(dx), st),
             'wgrad': lambda: ops.wgrad_call('hoig_conv2d_bwd_weight', d_wg, p(x), p(dy), p(dw), None, st),
         }
-        if 'wgrad_split' in a.kinds or 'split' in a.kinds or 'dgrad_split' in a.kinds:      # pre-split dy (round 5)
+        if 'wgrad_split' in a.kinds or 'split' in a.kinds or 'dgrad_split' in a.kinds or 'pair' in a.kinds:      # pre-split dy (round 5)
             dys = torch.empty(B, Ho, Wo, 2, Co, dtype=torch.bfloat16, device='cuda')
             fns['split'] = lambda: L.call('hoig_split_planes_bf16', p(dy), p(dys), B * Ho * Wo, Co, st)
             fns['split']()
             fns['wgrad_split'] = lambda: L.call('hoig_conv2d_bwd_weight_split', ctypes.byref(d_wg), p(x), p(dys), p(dw), st)
+            if 'pair' in a.kinds:           # grouped launches: this problem twice (two tensors, two weights) as one grid vs one after the other
+                x2, dy2, dys2 = torch.randn_like(x), torch.randn_like(dy), torch.empty_like(dys)
+                w2 = ops.pack_weight(torch.randn_like(w) * 0.02)
+                L.call('hoig_split_planes_bf16', p(dy2), p(dys2), B * Ho * Wo, Co, st)
+                hi2, lo2 = ops._packed_planes(w2, tr, False)
+                thi2, tlo2 = ops._packed_planes(w2, tr, True)
+                y2, dx2, dw2 = torch.empty_like(y), torch.empty_like(dx), torch.zeros_like(dw)
+                fns['fwd_2x'] = lambda: (fns['fwd'](), L.call('hoig_conv2d_fwd_packed', ctypes.byref(d), p(x2), p(hi2), p(lo2), None, p(y2), st))
+                fns['fwd_pair'] = lambda: L.call('hoig_conv2d_fwd_packed_pair', ctypes.byref(d), p(x), p(x2), p(hi), p(lo), p(hi2), p(lo2), None, None, p(y), p(y2), st)
+                fns['dgrad_2x'] = lambda: (L.call('hoig_conv2d_bwd_data_packed_split', ctypes.byref(d_dg), p(dys), p(thi), p(tlo), None, p(dx), st),
+                                           L.call('hoig_conv2d_bwd_data_packed_split', ctypes.byref(d_dg), p(dys2), p(thi2), p(tlo2), None, p(dx2), st))
+                fns['dgrad_pair'] = lambda: L.call('hoig_conv2d_bwd_data_packed_split_pair', ctypes.byref(d_dg), p(dys), p(dys2), p(thi), p(tlo), p(thi2), p(tlo2), None, None, p(dx), p(dx2), st)
+                fns['wgrad_2x'] = lambda: (L.call('hoig_conv2d_bwd_weight_split', ctypes.byref(d_wg), p(x), p(dys), p(dw), st),
+                                           L.call('hoig_conv2d_bwd_weight_split', ctypes.byref(d_wg), p(x2), p(dys2), p(dw2), st))
+                fns['wgrad_pair'] = lambda: L.call('hoig_conv2d_bwd_weight_split_pair', ctypes.byref(d_wg), p(x), p(x2), p(dys), p(dys2), p(dw), p(dw2), st)
             if hasattr(L.lib, 'hoig_conv2d_bwd_data_packed_split'):
                 fns['dgrad_split'] = lambda: L.call('hoig_conv2d_bwd_data_packed_split', ctypes.byref(d_dg), p(dys), p(thi), p(tlo), None, p(dx), st)
         flop = 2.0 * B * (H * W if tr else Ho * Wo) * Ci * Co * k * k
-        for kind in a.kinds.split(','):
+        kinds = [k for k in a.kinds.split(',') if k != 'pair'] + (['fwd_2x', 'fwd_pair', 'dgrad_2x', 'dgrad_pair', 'wgrad_2x', 'wgrad_pair'] if 'pair' in a.kinds else [])
+        for kind in kinds:
             fn = fns[kind]
             times = [[] for _ in variants]
             for r in range(a.rounds + 1):
