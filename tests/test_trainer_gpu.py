@@ -48,7 +48,7 @@ GOLDEN = [('generator_spade_attn', 'hov3_spade_attn_64.npz'), ('generator_spade'
           ('generator_spade_attn', 'dexycb_spade_attn_64.npz')]
 
 
-@pytest.mark.parametrize('precision', ['f32', 'bf16x3', 'bf16x3:f16x2', 'f16f6'])
+@pytest.mark.parametrize('precision', ['f32', 'bf16x3', 'bf16x3:f16x2', pytest.param('f16f6', marks=pytest.mark.gpu_slow)])
 @pytest.mark.parametrize('gen_name,fname', GOLDEN)
 def test_trainer_matches_reference_golden(gen_name, fname, precision):
     """Both shipped arithmetic modes (exact-fp32 MFMA and split-bf16 MFMA) must meet the same 1e-3 bound, on every generator
@@ -96,7 +96,7 @@ def test_trainer_matches_reference_golden(gen_name, fname, precision):
             assert abs(got - want) <= 1e-3 * want, name
 
 
-@pytest.mark.parametrize('precision', ['f32', 'bf16x3', 'bf16x3:f16x2', 'f16f6'])
+@pytest.mark.parametrize('precision', ['f32', 'bf16x3', 'bf16x3:f16x2', pytest.param('f16f6', marks=pytest.mark.gpu_slow)])
 def test_trainer_vs_oracle_128(precision):
     """128x128, batch 1 (D's instance norms see >= 7x7 maps): forward, all 7 loss terms and every gradient tensor of G
     and D against the CPU oracle."""
