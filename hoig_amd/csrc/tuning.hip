@@ -22,7 +22,7 @@ Entry g_table[HOIG_TUNE_COUNT] = {
     {"d_early", 1},
     {"split_grads", 1},
     {"wgrad_ko", 0},
-    {"pair", 1},
+    {"pair", 2},
 };
 }  // namespace
 

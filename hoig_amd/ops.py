@@ -643,7 +643,8 @@ def pair_ok(xa, xb, wa, wb, prec=None):
     kernels covers: same shapes, flat weights, stride-1 "same" 3x3, Wi % 32 == 0, Hi % 8 == 0, Ci % 32 == 0, Co % 128 == 0, a 16-bit
     forward and a two- or one-term backward (pre-split dy)."""
     prec = precision if prec is None else prec
-    if not L.lib.hoig_set_tuning(b'pair', -1) or prec in (L.PREC_F32, L.PREC_F16F6) or not xa.is_cuda:
+    mode = L.lib.hoig_set_tuning(b'pair', -1)           # 0: never, 1: always, 2: in captured steps only (include/hoig_kernels.h)
+    if not mode or (mode == 2 and not capturing()) or prec in (L.PREC_F32, L.PREC_F16F6) or not xa.is_cuda:
         return False
     if xa.shape != xb.shape or wa.shape != wb.shape or tuple(wa.shape[2:]) != (3, 3) or wa.shape[1] != xa.shape[-1]:
         return False

@@ -493,8 +493,10 @@ const char *hoig_version(void);
  *                G's backward instead of after it; 0: after (both orders compute the same step: D's weights change only in D's own
  *                update, which stays last).  With an exchange (world > 1) it always follows G's backward: G's all-reduce hides behind it
  *   "wgrad16" 0  the stride-1 3x3 weight gradients on 16x16x32 (wgrad_halo16.hip): measured 5-20 % slower than 32x32x16
- *   "pair"    1  (read by the host side, hoig_amd/models/networks/generator.py) the 3x3 512 -> 512 convolutions of src_model's and
- *                tsf_model's residual blocks as grouped launches (hoig_conv2d_*_pair); 0: one launch per sub-network, on two streams
+ *   "pair"    2  (read by the host side, hoig_amd/models/networks/generator.py) the 3x3 512 -> 512 convolutions of src_model's and
+ *                tsf_model's residual blocks as grouped launches (hoig_conv2d_*_pair): 1 = always, 2 = in CAPTURED steps only, 0 = never
+ *                (one launch per sub-network, on two streams).  Measured (profiles/r05_pair_ab.txt): the eager step loses 0.6 ms to the
+ *                lock-step of the two chains (the norms between the convolutions no longer overlap), the replayed graph gains 0.7 ms
  *   "wgrad_ko" 0  diagnostic instantiations of wgrad_dma_kernel (tools/ab_conv.py; results are WRONG with any bit set)
  *   "split_grads" 1  (read by the host side, hoig_amd/ops.py) the backward of a norm that follows an eligible 3x3 convolution writes its
  *                dx as bf16 hi | lo planes and that convolution's weight / data gradient read them without splitting ('PRE-SPLIT

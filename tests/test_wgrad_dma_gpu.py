@@ -208,9 +208,12 @@ def test_grouped_launch_equals_the_two_single_launches(shape):
             else:
                 L.call('hoig_conv2d_bwd_data_packed', ctypes.byref(d2), _p(dys[i]), _p(bwd_planes[i][0]), _p(bwd_planes[i][1]), _p(dx_ref[i]), st)
         dx = [torch.empty_like(t) for t in dx_ref]
-        L.call('hoig_conv2d_bwd_data_packed_split_pair', ctypes.byref(d2), _p(sp[0]), _p(sp[1]), _p(bwd_planes[0][0]), _p(bwd_planes[0][1]),
-               _p(bwd_planes[1][0]), _p(bwd_planes[1][1]), _p(adds[0]) if with_add else None, _p(adds[1]) if with_add else None,
-               _p(dx[0]), _p(dx[1]), st)
+        rc = L.lib.hoig_conv2d_bwd_data_packed_split_pair(ctypes.byref(d2), _p(sp[0]), _p(sp[1]), _p(bwd_planes[0][0]), _p(bwd_planes[0][1]),
+                                                          _p(bwd_planes[1][0]), _p(bwd_planes[1][1]), _p(adds[0]) if with_add else None,
+                                                          _p(adds[1]) if with_add else None, _p(dx[0]), _p(dx[1]), st)
+        if rc == L.EUNSUPPORTED:                 # (too few tiles of Ci channels for a grouped tiling: the caller falls back per problem)
+            break
+        assert rc == 0
         torch.cuda.synchronize()
         assert torch.equal(dx[0], dx_ref[0]) and torch.equal(dx[1], dx_ref[1]), with_add
     dw_ref = [torch.zeros(Co, 3, 3, Ci, device='cuda') for _ in range(2)]
@@ -244,10 +247,10 @@ def test_step_with_grouped_launches_matches_the_step_without():
             del m
             torch.cuda.empty_cache()
     finally:
-        L.set_tuning('pair', 1)
+        L.set_tuning('pair', 2)
         ops.set_precision('f32')
-    for a, b in zip(res[1][0], res[0][0]):
-        assert torch.equal(a, b)
+    for a, b in zip(res[1][0], res[0][0]):          # (not bitwise: the large maps' norm statistics come from fp32 atomics in both runs)
+        assert (a - b).abs().max().item() <= 1e-4 * max(b.abs().max().item(), 1e-3)
     for k, v in res[0][1].items():
         assert abs(res[1][1][k] - v) <= 1e-5 * max(abs(v), 1e-2), (k, res[1][1][k], v)
     g1, g0 = res[1][2], res[0][2]
