@@ -23,6 +23,7 @@ Entry g_table[HOIG_TUNE_COUNT] = {
     {"split_grads", 1},
     {"wgrad_ko", 0},
     {"pair", 2},
+    {"pad_in", 1},
 };
 }  // namespace
 

@@ -29,7 +29,8 @@ class PatchDiscriminator(ParamTree):
     def forward_nhwc(self, x):
         P = self.P
         prec = ops.subnet_precision('d')
-        x = ops.conv2d(x, P['model.0.weight'], P['model.0.bias'], 2, 1, ACT_LRELU, 0.2, prec=prec)
+        # (19 [DexYCB: 24] input channels: zero-padded to 32 so that the layer runs on the 16-bit kernels, ops.conv2d_padded_in)
+        x = ops.conv2d_padded_in(x, P['model.0.weight'], P['model.0.bias'], 2, 1, ACT_LRELU, 0.2, prec=prec)
         idx = 2
         for _ in range(1, self.n_layers):
             x = ops.conv2d(x, P['model.%d.weight' % idx], P['model.%d.bias' % idx], 2, 1, dead_bias=True, prec=prec)

@@ -497,6 +497,8 @@ const char *hoig_version(void);
  *                tsf_model's residual blocks as grouped launches (hoig_conv2d_*_pair): 1 = always, 2 = in CAPTURED steps only, 0 = never
  *                (one launch per sub-network, on two streams).  Measured (profiles/r05_pair_ab.txt): the eager step loses 0.6 ms to the
  *                lock-step of the two chains (the norms between the convolutions no longer overlap), the replayed graph gains 0.7 ms
+ *   "pad_in"  1  (read by the host side, hoig_amd/ops.py conv2d_padded_in) the discriminator's first layer (19 / 24 input channels) with
+ *                input and weight zero-padded to 32 channels on the 16-bit kernels; 0: the exact-fp32 kernel it took before
  *   "wgrad_ko" 0  diagnostic instantiations of wgrad_dma_kernel (tools/ab_conv.py; results are WRONG with any bit set)
  *   "split_grads" 1  (read by the host side, hoig_amd/ops.py) the backward of a norm that follows an eligible 3x3 convolution writes its
  *                dx as bf16 hi | lo planes and that convolution's weight / data gradient read them without splitting ('PRE-SPLIT

@@ -44,8 +44,8 @@ def test_config5_eval_forward_b32_hipgraph_replay():
     last-bit difference of an activation can move an fp6 rounding of a cross term, so two runs differ by up to that arithmetic's
     own error against fp32 -- measured 3e-5 ... 2e-4 through the 45 conv + norm layers at 32 images, bound 5e-4; the parity
     statement is the oracle comparison below at TOL), must re-read its static
-    input buffers (new inputs -> new outputs without re-capture), and its first two samples must match the ORACLE's forward
-    of those two samples."""
+    input buffers (new inputs -> new outputs without re-capture), and its first sample must match the ORACLE's forward
+    of that sample."""
     from hoig_amd import synthetic
     B, S = 32, 256
     m = product_trainer('generator_spade_attn', B, S)
@@ -65,13 +65,11 @@ def test_config5_eval_forward_b32_hipgraph_replay():
     for e, a, b in zip(eager, r1, r2):
         assert torch.isfinite(a).all()
         assert rel_err(a, e) < 5e-4 and rel_err(b, a) < 5e-4
-    ot = oracle_trainer('generator_spade_attn', 2, S)          # same per-sample seeds: samples 0,1 of the batch of 32
-    with torch.no_grad():
-        want = ot.forward()
+    want = oracle_256_b1()[0]                                   # same per-sample seeds: sample 0 of the batch of 32
     for name, got, w in zip(['src_bg', 'tsf_bg', 'src_img', 'tsf_img'], r1[:4], want[:4]):
-        assert rel_err(got[:2], w) < TOL, name
-    assert rel_err(torch.cat([r1[4][:2], r1[4][B:B + 2]]), want[4]) < TOL        # masks: src then tsf along the batch
-    assert rel_err(torch.cat([r1[5][:2], r1[5][B:B + 2]]), want[5]) < TOL
+        assert rel_err(got[:1], w) < TOL, name
+    assert rel_err(torch.cat([r1[4][:1], r1[4][B:B + 1]]), want[4]) < TOL        # masks: src then tsf along the batch
+    assert rel_err(torch.cat([r1[5][:1], r1[5][B:B + 1]]), want[5]) < TOL
     # the graph reads the staged input buffers: overwrite them in place with another batch and replay
     other = synthetic.make_inputs(B, S, seed=SEEDS['inputs'] + 1)
     with torch.no_grad():
@@ -122,24 +120,37 @@ def _step_is_mean_of_halves(B, S, dataset):
     return full
 
 
+_ORACLE_256 = {}
+
+
+def oracle_256_b1():
+    """(forward outputs, loss terms, gradients) of the ORACLE's step at 256 x 256 on sample 0 of the seeded batch: ~20 s of CPU, shared by
+    the tests of this module."""
+    if not _ORACLE_256:
+        sys_path_tools()
+        from precision_frontier import oracle_side
+        _ORACLE_256['v'] = oracle_side(256, 1)
+    return _ORACLE_256['v']
+
+
 def test_config2_256_forward_and_step():
-    """configs[1]: 256x256 HO3Dv3-shaped, batch 8, full G+D step.  Batch 2 against the oracle (forward outputs and the seven
-    loss terms of one step); batch 8: finite, and its losses are the mean of its halves' losses."""
-    S = 256
-    ot = oracle_trainer('generator_spade_attn', 2, S)
-    m = product_trainer('generator_spade_attn', 2, S)
+    """configs[1]: 256x256 HO3Dv3-shaped, batch 8, full G+D step.  The batch-8 forward against the oracle on its first sample (samples
+    are seeded one by one: sample 0 of any batch is the oracle's batch of one; the oracle's losses and gradients at this size are
+    compared in test_config2_gradients_256_against_oracle); batch 8: finite, and its losses are the mean of its halves' losses."""
+    S, B = 256, 8
+    want = oracle_256_b1()[0]
+    from hoig_amd import ops
+    ops.set_precision('bf16x3:f16x2')
+    m = product_trainer('generator_spade_attn', B, S)
     with torch.no_grad():
-        want, got = ot.forward(), m.forward()
-    for a, b in zip(got, want):
-        assert rel_err(a, b) < TOL
-    ot.optimize_parameters()
-    m.optimize_parameters()
-    eo, ep = ot.get_current_errors(), m.get_current_errors()
-    for k in eo:
-        assert abs(eo[k] - ep[k]) <= _loss_tol(eo[k]), (k, eo[k], ep[k])
-    del m, ot
+        got = m.forward()
+    for name, g, w in zip(['src_bg', 'tsf_bg', 'src_img', 'tsf_img'], got[:4], want[:4]):
+        assert rel_err(g[:1], w) < TOL, name
+    assert rel_err(torch.cat([got[4][:1], got[4][B:B + 1]]), want[4]) < TOL      # masks: src then tsf along the batch
+    assert rel_err(torch.cat([got[5][:1], got[5][B:B + 1]]), want[5]) < TOL
+    del m
     torch.cuda.empty_cache()
-    _step_is_mean_of_halves(8, S, 'hov3')
+    _step_is_mean_of_halves(B, S, 'hov3')
 
 
 def test_bench_line_contract():
@@ -181,9 +192,7 @@ def test_config2_gradients_256_against_oracle():
     (1e-3) here and reported for its gradients: median 1.5e-2, p95 2.0e-2..2.4e-2, worst 2.7e-2..4.3e-2 -- beyond 3e-2, which is
     why it is not the default."""
     from hoig_amd import ops
-    sys_path_tools()
-    from precision_frontier import oracle_side
-    ofwd, oerr, ograd = oracle_side(256, 1)
+    ofwd, oerr, ograd = oracle_256_b1()
     from conftest import want_gpu_slow
     modes = (('bf16x3:f16x2', (1e-2, 2e-2, 3e-2)),) + ((('f16f6', None),) if want_gpu_slow() else ())     # (the opt-in arithmetic's leg: opt-in)
     for mode, limits in modes:

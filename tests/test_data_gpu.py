@@ -69,6 +69,7 @@ def test_loader_batches_match_the_oracle(tmp_path):
     opt = FX.build(str(tmp_path), seed=5)
     pairs = [('ABF1_0/0001.png', 'MC2_0/0003.png'), ('MC2_0/0000.png', 'ABF1_0/0002.png'), ('ABF1_0/0000.png', 'ABF1_0/0003.png')]
     FX.write_pairs(opt, pairs)
+    oracle = {}                                          # (the numpy oracle takes seconds per sample: once per batch, not per worker count)
     for workers in (0, 2):
         opt.n_threads_train = workers
         loader = CustomDatasetDataLoader(opt, is_for_train=True)
@@ -80,7 +81,9 @@ def test_loader_batches_match_the_oracle(tmp_path):
         at = 0
         for b in batches:
             n = len(b['nameA'])
-            va, vb = FX.oracle_batch(opt, [p[0] for p in pairs[at:at + n]], [p[1] for p in pairs[at:at + n]])
+            if at not in oracle:
+                oracle[at] = FX.oracle_batch(opt, [p[0] for p in pairs[at:at + n]], [p[1] for p in pairs[at:at + n]])
+            va, vb = oracle[at]
             at += n
             for side, want in (('A', va), ('B', vb)):
                 assert b['image' + side].is_cuda and b['image' + side].dtype == torch.float32

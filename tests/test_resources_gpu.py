@@ -39,7 +39,7 @@ def test_trainers_come_and_go_with_a_flat_stream_and_memory_count():
         live0, idle0, scratch0 = _census()
         mem0 = torch.cuda.memory_allocated()
         assert scratch0 > 0, 'a training step launches thin-channel weight gradients: their stream registers a scratch block'
-        for _ in range(8):
+        for _ in range(4):
             one()
         live1, idle1, scratch1 = _census()
         assert (live1, idle1) == (live0, idle0), 'streams made and not handed back: %r -> %r' % ((live0, idle0), (live1, idle1))

@@ -96,7 +96,8 @@ def test_trainer_matches_reference_golden(gen_name, fname, precision):
             assert abs(got - want) <= 1e-3 * want, name
 
 
-@pytest.mark.parametrize('precision', ['f32', 'bf16x3', 'bf16x3:f16x2', pytest.param('f16f6', marks=pytest.mark.gpu_slow)])
+@pytest.mark.parametrize('precision', [pytest.param('f32', marks=pytest.mark.gpu_slow), pytest.param('bf16x3', marks=pytest.mark.gpu_slow),
+                                       'bf16x3:f16x2', pytest.param('f16f6', marks=pytest.mark.gpu_slow)])
 def test_trainer_vs_oracle_128(precision):
     """128x128, batch 1 (D's instance norms see >= 7x7 maps): forward, all 7 loss terms and every gradient tensor of G
     and D against the CPU oracle."""
