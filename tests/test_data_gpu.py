@@ -69,7 +69,10 @@ def test_loader_batches_match_the_oracle(tmp_path):
     opt = FX.build(str(tmp_path), seed=5)
     pairs = [('ABF1_0/0001.png', 'MC2_0/0003.png'), ('MC2_0/0000.png', 'ABF1_0/0002.png'), ('ABF1_0/0000.png', 'ABF1_0/0003.png')]
     FX.write_pairs(opt, pairs)
-    oracle = {}                                          # (the numpy oracle takes seconds per sample: once per batch, not per worker count)
+    oracle = {}
+    # worker processes are FORKED: after the large-batch tests of a session the caching allocator holds tens of GB of mapped device
+    # memory, and forking that address space took ~20 s per worker (50 s of this test in the full suite, 3 s alone)
+    torch.cuda.empty_cache()
     for workers in (0, 2):
         opt.n_threads_train = workers
         loader = CustomDatasetDataLoader(opt, is_for_train=True)
