@@ -15,6 +15,7 @@
 // that the staging stores (ds_write_b64 of the split halo: 2 pixels x 8 lanes; ds_write_b128 of the weight chunks: 2 rows x 4
 // lanes) fill a whole 128-B bank window per lane group.
 #include "conv_bf16_common.h"
+#include "tuning.h"
 
 namespace hoig_detail {
 namespace {
@@ -82,7 +83,14 @@ struct M16Layout {
 // the producer of that gradient (hoig_split_planes_bf16; the backward of a norm) -- and the halo goes global -> registers -> LDS in
 // 16-B pieces with no VALU work: the split of a 32-channel block (ten VALU instructions and two ds_write_b64 per 16 B of input,
 // between two barriers, beside nobody's MFMAs) is gone, as is the same split in every other workgroup that reads these pixels.
-template <int NSX, int WM, int WN, int BN, bool F16, bool ASPLIT = false>
+// WDMA (round 5; tuning key `wdma16`): the weight tiles of a step go global -> LDS by LDS-DMA (global_load_lds_dwordx4 from inline asm:
+// through the builtin hipcc guards the step's first ds_read with `s_waitcnt vmcnt(0)` and the copy lands BEFORE the MFMAs instead of
+// behind them -- which is what round 2's "9 % slower" measurement of the builtin form ran into).  A 32-row block of a blocked plane is
+// 2 KB contiguous in HBM; a piece = (block, half image h) = 1 KB of LDS: lane l copies row l >> 1's chunk 2h + (l & 1), which the plane
+// keeps at position chunk ^ ((row >> 2) & 3).  The step's 3 x NB x BN/32 x 2 pieces are spread over the waves and, per wave, over the
+// step's MFMA groups; they are issued for step + 1 into the other weight buffer and waited for (vmcnt(0)) before the step's closing
+// barrier.  No staging registers (24 VGPRs), no ds_write, no load two steps ahead.
+template <int NSX, int WM, int WN, int BN, bool F16, bool ASPLIT = false, bool WDMA = false>
 __global__ __launch_bounds__(64 * WM * WN) void conv_halo3_m16_kernel(const HaloArgs p) {
     constexpr int NS = NSX == 1 ? 1 : 2, NB = NSX == 2 ? 2 : 1;      // operand planes: pixels (activations / dy), weights
     using LY = M16Layout<WM, BN>;
@@ -178,6 +186,29 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_halo3_m16_kernel(const Halo
             }
         }
     };
+    // ---- WDMA: piece q of a step = (tap t, plane pl, 32-row block blk, half image h); wave w issues pieces w, w + 8, ..
+    constexpr int NPIECE_STEP = KS * NB * (BN / 32) * 2, NPW = (NPIECE_STEP + WM * WN - 1) / (WM * WN);
+    const int wave_u = __builtin_amdgcn_readfirstlane(wave);
+    const unsigned lds_w0 = __builtin_amdgcn_readfirstlane((unsigned)(size_t)(__attribute__((address_space(3))) unsigned char *)Wbase);
+    const int drow = lane >> 1;
+    const unsigned dlane0 = drow * 32 + (((0 + (lane & 1)) ^ ((drow >> 2) & 3)) << 3);       // element offset inside a block, h = 0
+    const unsigned dlane1 = drow * 32 + (((2 + (lane & 1)) ^ ((drow >> 2) & 3)) << 3);       // h = 1
+    auto dma_piece = [&](int step, int buf, int i) {
+        const int q = wave_u + (WM * WN) * i;
+        if (q >= NPIECE_STEP) return;
+        const int h = q & 1, blk = (q >> 1) % (BN / 32), tp = (q >> 1) / (BN / 32);          // tp = t * NB + plane
+        const int t = tp / NB, pl = tp - t * NB;
+        const int cb = step / KS, r = step - cb * KS;
+        const int tap = r * KS + t;
+        const int wtap = p.flip ? (KS * KS - 1 - tap) : tap;
+        const size_t koff = (size_t)(wtap * p.Cg + cb * 32) * 32;
+        const unsigned short *plane = pl ? gWl : gWh;
+        const unsigned short *src = plane + ((size_t)((n0 >> 5) + blk) * (p.K >> 5)) * 1024 + koff + (h ? dlane1 : dlane0);
+        const unsigned to = __builtin_amdgcn_readfirstlane(lds_w0 + buf * BBUF + tp * PLANE_W + h * W23 + blk * 1024);
+        unsigned keep;
+        asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+                     : "=&s"(keep) : "v"(src), "s"(to) : "memory");
+    };
     constexpr int HSLICES = (HPIX * 8 + NT - 1) / NT;
     float4 hreg[HSLICES];
     auto halo_load = [&](int cb) {
@@ -252,7 +283,7 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_halo3_m16_kernel(const Halo
     struct WF {
         bf16x8 h, l;
     };
-    auto compute = [&](int r, int bbuf) {
+    auto compute = [&](int r, int bbuf, int dma_step) {      // dma_step >= 0 (WDMA): the step whose weight pieces ride between the groups
         const unsigned char *Ph = Pbase, *Pl = Ph + PLANE_P;
         const unsigned char *Wst = Wbase + bbuf * BBUF;
         auto read_p = [&](PF &f, int t, int m) {
@@ -281,6 +312,9 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_halo3_m16_kernel(const Halo
                 for (int q = 0; q < PPG; ++q)
                     if (j * PPG + q < MT) read_p(pf[(t + 1) & 1], t + 1, j * PPG + q);
             }
+            if constexpr (WDMA) {
+                if (dma_step >= 0 && g < NPW) dma_piece(dma_step, bbuf ^ 1, g);
+            }
             __builtin_amdgcn_sched_barrier(0);      // reads of the next group stay AHEAD of this group's MFMAs
             const PF &pc = pf[t & 1];
             const WF &wc = wf[g & 1];
@@ -296,9 +330,15 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_halo3_m16_kernel(const Halo
 
     halo_load(0);
     halo_store();
-    load_b(0);
-    store_b(0);
-    if (T > 1) load_b(1);
+    if constexpr (WDMA) {
+#pragma unroll
+        for (int i = 0; i < NPW; ++i) dma_piece(0, 0, i);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    } else {
+        load_b(0);
+        store_b(0);
+        if (T > 1) load_b(1);
+    }
     __syncthreads();
     int bbuf = 0;
 #pragma unroll 1
@@ -306,14 +346,17 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_halo3_m16_kernel(const Halo
         const int cb = step / KS, r = step - cb * KS;
         const bool more = step + 1 < T;
         const bool boundary = more && r == KS - 1;
-        if (more) store_b(bbuf ^ 1);                  // weights of step+1 (registers loaded during the previous step)
-        if (step + 2 < T) load_b(step + 2);
+        if constexpr (!WDMA) {
+            if (more) store_b(bbuf ^ 1);              // weights of step+1 (registers loaded during the previous step)
+            if (step + 2 < T) load_b(step + 2);
+        }
         if (boundary) halo_load(cb + 1);
-        compute(r, bbuf);
+        compute(r, bbuf, (WDMA && more) ? step + 1 : -1);
         if (boundary) {
             __syncthreads();                          // every wave is done with the halo
             halo_store();
         }
+        if constexpr (WDMA) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // this wave's pieces of step + 1 have landed
         __syncthreads();
         bbuf ^= 1;
     }
@@ -666,6 +709,21 @@ int launch_one(const HaloArgs &a, hipStream_t st) {
             HOIG_LAUNCH_CHECK();
             return HOIG_OK;
         }
+    }
+    if (hoig_tuning(HOIG_TUNE_WDMA16) != 0 && a.N % BN == 0) {       // weight tiles by LDS-DMA (whole channel tiles only)
+        static hoig_once once_d;
+        if (!once_d.done()) {
+            if (hipFuncSetAttribute(reinterpret_cast<const void *>(&conv_halo3_m16_kernel<NS, WM, WN, BN, true, false, true>),
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm) != hipSuccess ||
+                hipFuncSetAttribute(reinterpret_cast<const void *>(&conv_halo3_m16_kernel<NS, WM, WN, BN, false, false, true>),
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm) != hipSuccess)
+                return HOIG_ELAUNCH;
+            once_d.set();
+        }
+        if (a.f16) conv_halo3_m16_kernel<NS, WM, WN, BN, true, false, true><<<a.nblk, 64 * WM * WN, shm, st>>>(a);
+        else conv_halo3_m16_kernel<NS, WM, WN, BN, false, false, true><<<a.nblk, 64 * WM * WN, shm, st>>>(a);
+        HOIG_LAUNCH_CHECK();
+        return HOIG_OK;
     }
     if (a.f16) conv_halo3_m16_kernel<NS, WM, WN, BN, true><<<a.nblk, 64 * WM * WN, shm, st>>>(a);
     else conv_halo3_m16_kernel<NS, WM, WN, BN, false><<<a.nblk, 64 * WM * WN, shm, st>>>(a);
