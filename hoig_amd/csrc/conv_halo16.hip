@@ -705,7 +705,17 @@ int launch_one(const HaloArgs &a, hipStream_t st) {
                     return HOIG_ELAUNCH;
                 once_s.set();
             }
-            conv_halo3_m16_kernel<NS, WM, WN, BN, false, true><<<a.nblk, 64 * WM * WN, shm, st>>>(a);
+            if (hoig_tuning(HOIG_TUNE_WDMA16) != 0 && a.N % BN == 0) {
+                static hoig_once once_sd;
+                if (!once_sd.done()) {
+                    if (hipFuncSetAttribute(reinterpret_cast<const void *>(&conv_halo3_m16_kernel<NS, WM, WN, BN, false, true, true>),
+                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm) != hipSuccess)
+                        return HOIG_ELAUNCH;
+                    once_sd.set();
+                }
+                conv_halo3_m16_kernel<NS, WM, WN, BN, false, true, true><<<a.nblk, 64 * WM * WN, shm, st>>>(a);
+            } else
+                conv_halo3_m16_kernel<NS, WM, WN, BN, false, true><<<a.nblk, 64 * WM * WN, shm, st>>>(a);
             HOIG_LAUNCH_CHECK();
             return HOIG_OK;
         }

@@ -59,6 +59,20 @@ def call(name, *a):
 
 ops._conv_fwd_raw, ops._conv_dgrad_raw, ops.call = fwd, dgrad, call
 
+
+def wrap_lib(name, kind):
+    """the pre-split entry points are called through L.lib directly (ops._Conv._backward_split): time them too"""
+    orig = getattr(L.lib, name)
+
+    def f(dref, *a):
+        return timed(kind, dref._obj, lambda: orig(dref, *a))
+    setattr(L.lib, name, f)
+
+
+from hoig_amd import _lib as L          # noqa: E402
+wrap_lib('hoig_conv2d_bwd_weight_split', 'wgrad')
+wrap_lib('hoig_conv2d_bwd_data_packed_split', 'dgrad')
+
 opt = opt_namespace(gen_name='generator_spade_attn', local_rank=0, image_size=side, hip_graph=False)
 torch.manual_seed(8)
 model = ModelsFactory.get_by_name('trainer', opt, use_ddp=False)

@@ -21,7 +21,7 @@ import re          # noqa: E402
 PATTERNS = [
     ('norm_fwd', r'hoig_inorm_(fwd_fused|stats|stats_from_sums|apply|apply_ld)$'),
     ('norm_bwd', r'hoig_inorm_bwd'),
-    ('conv_wgrad', r'hoig_conv2d_(cat_)?bwd_weight$'),
+    ('conv_wgrad', r'hoig_conv2d_(cat_)?bwd_weight(_split)?(_pair)?$'),
     ('conv_dgrad', r'hoig_conv2d_(cat_)?bwd_data'),
     ('conv_fwd', r'hoig_conv2d_(cat_)?fwd'),
     ('attention', r'hoig_(attn_(pixel|src_gather|gs_gather)|replicate_pad)'),
