@@ -18,6 +18,7 @@
 // Few tiles and a long K (N = 128: 50 tiles at batch 8): the channel blocks are split over blockIdx.y and the partial results
 // added with fp32 atomics (pixels on the result's rows, v_permlane16_swap -> two 128-B runs per atomic instruction: conv_igemm16.hip).
 #include "conv_bf16_common.h"
+#include "tuning.h"
 
 namespace hoig_detail {
 namespace {
@@ -35,7 +36,8 @@ constexpr int round128(int v) { return (v + 127) / 128 * 128; }
 constexpr int PT = 256, BN = 128, TPS = 3, HSL = 8;      // positions / channels per workgroup, taps per step, halo slices per thread
 constexpr int W23 = BN * 32 + 64, PLANE_W = round128(W23 + BN * 32);
 
-template <int NSX, int KS, bool F16, bool SPLITK>
+// WDMA: the weight tiles of a step by LDS-DMA, as in conv_halo3_m16_kernel (conv_halo16.hip: same plane layout, same LDS images)
+template <int NSX, int KS, bool F16, bool SPLITK, bool WDMA = false>
 __global__ __launch_bounds__(512) void conv_flat_m16_kernel(const FlatArgs p) {
     constexpr int NS = NSX == 1 ? 1 : 2, NB = NSX == 2 ? 2 : 1;
     constexpr int NT = 512, WN = 2, MT = 4, NTW = 4, KK = KS * KS;
@@ -117,6 +119,28 @@ __global__ __launch_bounds__(512) void conv_flat_m16_kernel(const FlatArgs p) {
             if (NB == 2) *reinterpret_cast<uint4 *>(Wl + woff) = rbl[t];
         }
     };
+    // ---- WDMA: piece q of a step = (tap t of the group, plane, 32-row block, half image); wave w issues pieces w, w + 8, ..
+    constexpr int NPIECE_STEP = TPS * NB * (BN / 32) * 2, NPW = (NPIECE_STEP + 7) / 8;
+    const int wave_u = __builtin_amdgcn_readfirstlane(wave);
+    const unsigned lds_w0 = __builtin_amdgcn_readfirstlane((unsigned)(size_t)(__attribute__((address_space(3))) unsigned char *)Wbase);
+    const int drow = lane >> 1;
+    const unsigned dlane0 = drow * 32 + (((0 + (lane & 1)) ^ ((drow >> 2) & 3)) << 3);
+    const unsigned dlane1 = drow * 32 + (((2 + (lane & 1)) ^ ((drow >> 2) & 3)) << 3);
+    auto dma_piece = [&](int step, int buf, int i) {
+        const int q = wave_u + 8 * i;
+        if (q >= NPIECE_STEP) return;
+        const int h = q & 1, blk = (q >> 1) % (BN / 32), tp = (q >> 1) / (BN / 32);
+        const int t = tp / NB, pl = tp - t * NB;
+        const int cb = (s_begin + step) / NGRP, g = (s_begin + step) % NGRP;
+        const int tap = min(g * TPS + t, KK - 1);
+        const int wtap = p.flip ? (KK - 1 - tap) : tap;
+        const size_t koff = (size_t)(wtap * p.Cg + cb * 32) * 32;
+        const unsigned short *src = (pl ? p.Wl : p.Wh) + ((size_t)((n0 >> 5) + blk) * (p.K >> 5)) * 1024 + koff + (h ? dlane1 : dlane0);
+        const unsigned to = __builtin_amdgcn_readfirstlane(lds_w0 + buf * BBUF + tp * PLANE_W + h * W23 + blk * 1024);
+        unsigned keep;
+        asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+                     : "=&s"(keep) : "v"(src), "s"(to) : "memory");
+    };
     float4 hreg[HSL];
     auto halo_load = [&](int cb) {
 #pragma unroll
@@ -145,7 +169,7 @@ __global__ __launch_bounds__(512) void conv_flat_m16_kernel(const FlatArgs p) {
     };
     // a group = (tap, channel tile): its weight fragments against the tap's eight pixel fragments (read once per tap); the
     // fragments of the next group, and a quarter of the next tap's pixel fragments, are read before this group's MFMAs issue
-    auto compute = [&](int g, int bbuf) {
+    auto compute = [&](int g, int bbuf, int dma_step) {
         const unsigned char *Wst = Wbase + bbuf * BBUF;
         const int ntap = min(TPS, KK - g * TPS);
         int tapoff[TPS];
@@ -176,6 +200,9 @@ __global__ __launch_bounds__(512) void conv_flat_m16_kernel(const FlatArgs p) {
                 const int gi = t * NTW + j;
                 if (gi + 1 < TPS * NTW) read_w(wf[(gi + 1) & 1], (gi + 1) / NTW, (gi + 1) % NTW);
                 if (t + 1 < TPS) read_p(pf[(t + 1) & 1], t + 1, j);
+                if constexpr (WDMA) {
+                    if (dma_step >= 0 && gi < NPW) dma_piece(dma_step, bbuf ^ 1, gi);
+                }
                 __builtin_amdgcn_sched_barrier(0);
                 const PF &pc = pf[t & 1];
                 const WF &wc = wf[gi & 1];
@@ -194,15 +221,28 @@ __global__ __launch_bounds__(512) void conv_flat_m16_kernel(const FlatArgs p) {
                 __builtin_amdgcn_sched_barrier(0);
             }
         }
+        if constexpr (WDMA) {                                  // (a channel block's last group has KK % TPS taps: fewer slots than pieces)
+            if (dma_step >= 0) {
+#pragma unroll
+                for (int i = 0; i < NPW; ++i)
+                    if (i >= ntap * NTW) dma_piece(dma_step, bbuf ^ 1, i);
+            }
+        }
     };
 
     if (T > 0) {
         halo_load(s_begin / NGRP);
         halo_store();
-        load_b(0);
-        store_b(0);
-        if (T > 1) load_b(1);
+        if constexpr (WDMA) {
+#pragma unroll
+            for (int i = 0; i < NPW; ++i) dma_piece(0, 0, i);
+        } else {
+            load_b(0);
+            store_b(0);
+            if (T > 1) load_b(1);
+        }
     }
+    if constexpr (WDMA) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
     int bbuf = 0;
 #pragma unroll 1
@@ -210,14 +250,17 @@ __global__ __launch_bounds__(512) void conv_flat_m16_kernel(const FlatArgs p) {
         const int cb = (s_begin + step) / NGRP, g = (s_begin + step) - cb * NGRP;
         const bool more = step + 1 < T;
         const bool boundary = more && g == NGRP - 1;
-        if (more) store_b(bbuf ^ 1);                  // weights of step+1 (registers loaded during the previous step)
-        if (step + 2 < T) load_b(step + 2);
+        if constexpr (!WDMA) {
+            if (more) store_b(bbuf ^ 1);              // weights of step+1 (registers loaded during the previous step)
+            if (step + 2 < T) load_b(step + 2);
+        }
         if (boundary) halo_load(cb + 1);
-        compute(g, bbuf);
+        compute(g, bbuf, (WDMA && more) ? step + 1 : -1);
         if (boundary) {
             __syncthreads();                          // every wave is done with the halo
             halo_store();
         }
+        if constexpr (WDMA) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
         bbuf ^= 1;
     }
@@ -289,6 +332,18 @@ __global__ __launch_bounds__(512) void conv_flat_m16_kernel(const FlatArgs p) {
 
 template <int NSX, int KS, bool F16, bool SPLITK>
 int launch_one(const FlatArgs &a, dim3 grid, size_t shm, hipStream_t st) {
+    if (hoig_tuning(HOIG_TUNE_WDMA16) >= 2) {              // (2: the flattened-axis kernel too)
+        static hoig_once once_d;
+        if (!once_d.done()) {
+            if (hipFuncSetAttribute(reinterpret_cast<const void *>(&conv_flat_m16_kernel<NSX, KS, F16, SPLITK, true>),
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess)
+                return HOIG_ELAUNCH;
+            once_d.set();
+        }
+        conv_flat_m16_kernel<NSX, KS, F16, SPLITK, true><<<grid, 512, shm, st>>>(a);
+        HOIG_LAUNCH_CHECK();
+        return HOIG_OK;
+    }
     static hoig_once once;
     if (!once.done()) {
         if (hipFuncSetAttribute(reinterpret_cast<const void *>(&conv_flat_m16_kernel<NSX, KS, F16, SPLITK>),

@@ -24,7 +24,7 @@ Entry g_table[HOIG_TUNE_COUNT] = {
     {"wgrad_ko", 0},
     {"pair", 2},
     {"pad_in", 1},
-    {"wdma16", 1},
+    {"wdma16", 2},
 };
 }  // namespace
 

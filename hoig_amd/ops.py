@@ -194,8 +194,9 @@ _streams_made = _streams_destroyed = 0
 # queue 79-88 ms, the assignment below 72.9 ms): kernels of different queues interleave at workgroup granularity, and four heavy
 # chains doing that to each other are slower than two pairs.  Streams of ONE class execute in order: a stalled role stalls its
 # class mates (tests/test_stream_order_gpu.py moves a role to a class of its own where it needs one role late).  The loader's
-# stream (data/device_stage.py) sits with the default stream's class, away from the optimiser's and the branches' (ADVICE r4).
-_QUEUE_OF_ROLE = {'opt': 3, 'g_bg': 1, 'g_obj': 3, 'g_src': 1, 'loss_adv': 2, 'loss_vgg': 2, 'd': 2, 'wgrad': 2, 'loader': 0}
+# stream (data/device_stage.py) has a role of its own (it shared 'opt'): class 2, whose members -- the loss chains, the D
+# step, the weight gradients -- are idle during the generator's forward, which is when batch i + 1 is staged.
+_QUEUE_OF_ROLE = {'opt': 3, 'g_bg': 1, 'g_obj': 3, 'g_src': 1, 'loss_adv': 2, 'loss_vgg': 2, 'd': 2, 'wgrad': 2, 'loader': 2}
 
 
 def new_stream(device=None, role='opt'):

@@ -499,9 +499,10 @@ const char *hoig_version(void);
  *                lock-step of the two chains (the norms between the convolutions no longer overlap), the replayed graph gains 0.7 ms
  *   "pad_in"  1  (read by the host side, hoig_amd/ops.py conv2d_padded_in) the discriminator's first layer (19 / 24 input channels) with
  *                input and weight zero-padded to 32 channels on the 16-bit kernels; 0: the exact-fp32 kernel it took before
- *   "wdma16"  1  the weight tiles of the 16x16x32 3x3 stride-1 kernel by LDS-DMA (conv_halo16.hip WDMA: inline-asm global_load_lds, one step
- *                ahead, pieces spread over the MFMA groups): +3..7 % on every layer of that kernel, step 63.85 -> 63.03 ms
- *                (profiles/r05_wdma16_ab.txt); 0: through registers, two steps ahead
+ *   "wdma16"  2  the weight tiles of the 16x16x32 3x3 stride-1 kernel (1) and of the flattened-axis kernel (2) by LDS-DMA (conv_halo16.hip /
+ *                conv_flat16.hip WDMA: inline-asm global_load_lds, one step ahead, pieces spread over the MFMA groups): +3..7 % on every
+ *                layer of the first, +2..5 % on the attention's 5x5 layers, step 63.85 -> 63.03 -> 62.8 ms (profiles/r05_wdma16_ab.txt);
+ *                0: through registers, two steps ahead
  *   "wgrad_ko" 0  diagnostic instantiations of wgrad_dma_kernel (tools/ab_conv.py; results are WRONG with any bit set)
  *   "split_grads" 1  (read by the host side, hoig_amd/ops.py) the backward of a norm that follows an eligible 3x3 convolution writes its
  *                dx as bf16 hi | lo planes and that convolution's weight / data gradient read them without splitting ('PRE-SPLIT
