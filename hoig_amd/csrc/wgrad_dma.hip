@@ -229,12 +229,17 @@ __global__ __launch_bounds__(D_NT) void wgrad_dma_kernel(const WHaloArgs p) {
             __builtin_amdgcn_sched_barrier(0);
             if (kk + 2 < TH * 2) read_k(f0, kk + 2);
             stage(kk + 1);
+            // the next tile's x halo is converted and stored BESIDE the last k-steps' MFMAs of the other waves, not between the last MFMA and
+            // the barrier (its buffer was last read in the previous tile, a barrier ago; its loads were issued at the top of this tile and
+            // the last DMA piece a k-step ago, so the wait in front of the conversion finds everything landed)
+            if constexpr (nxt && !(KO & 1) && !(KO & 8)) {
+                if (kk == TH * 2 - 2) store_x(cur ^ 1);
+            }
             __builtin_amdgcn_sched_barrier(0);
             mma_k(f1);
             __builtin_amdgcn_sched_barrier(0);
         }
         if constexpr (nxt) {
-            if constexpr (!(KO & 1) && !(KO & 8)) store_x(cur ^ 1);      // (its buffer was last read in the previous tile, a barrier ago)
             if constexpr (!(KO & 4)) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");    // this wave's DMA pieces of tile mt + 1 have landed ...
             __syncthreads();                                // ... and so have everyone's; everyone is done reading tile mt
         }
