@@ -48,6 +48,28 @@ with tempfile.TemporaryDirectory() as root:
         model.optimize_parameters()
     torch.cuda.synchronize()
     ms_a = (time.perf_counter() - t0) / steps * 1e3
+    def timed(fn, n=steps):
+        for _ in range(4):
+            fn()
+        torch.cuda.synchronize()
+        t = time.perf_counter()
+        for _ in range(n):
+            fn()
+        torch.cuda.synchronize()
+        return (time.perf_counter() - t) / n * 1e3
+    prepared = synthetic.make_inputs(B, 256, seed=8)
+
+    def with_prepared():
+        model.set_input(prepared)
+        model.optimize_parameters()
+    ms_p = timed(with_prepared)
+    prepared_dev = {k: (v.cuda() if torch.is_tensor(v) else v) for k, v in prepared.items()}
+
+    def with_prepared_dev():
+        model.set_input(prepared_dev)
+        model.optimize_parameters()
+    ms_pd = timed(with_prepared_dev)
+    ms_pd_alone = timed(lambda: model.set_input(prepared_dev))
     # (b) train_ddp.py:88-92: for batch in loader: set_input(batch); optimize_parameters()
     torch.cuda.empty_cache()
     loader = CustomDatasetDataLoader(opt_d, is_for_train=True)
@@ -61,5 +83,48 @@ with tempfile.TemporaryDirectory() as root:
         n += 1
     torch.cuda.synchronize()
     ms_b = (time.perf_counter() - t0) / (n - 4) * 1e3
+    fixed = batch                                            # the loop's last batch: the raw path without the loader
+
+    def loader_leg(use_batch):
+        k, t = 0, None
+        for b in CustomDatasetDataLoader(opt_d, is_for_train=True).load_data():
+            if k == 4:
+                torch.cuda.synchronize()
+                t = time.perf_counter()
+            if use_batch:
+                model.set_input(b)
+            model.optimize_parameters()
+            k += 1
+        torch.cuda.synchronize()
+        return (time.perf_counter() - t) / (k - 4) * 1e3
+    ms_idle_loader = loader_leg(False)                       # the loader runs, its batches are dropped: the loader's own interference
+
+    def with_raw():
+        model.set_input(fixed)
+        model.optimize_parameters()
+    ms_r = timed(with_raw)
+    # where the raw path's extra time goes: host time of the two calls (no synchronisation inside the loop: the host runs ahead of the
+    # device by whatever slack the step leaves) and the stage alone on an idle device
+    host_in = host_st = 0.0
+    torch.cuda.synchronize()
+    for _ in range(steps):
+        t = time.perf_counter()
+        model.set_input(fixed)
+        t1 = time.perf_counter()
+        model.optimize_parameters()
+        host_in, host_st = host_in + (t1 - t), host_st + (time.perf_counter() - t1)
+    torch.cuda.synchronize()
+    host_in, host_st = host_in / steps * 1e3, host_st / steps * 1e3
+
+    def stage_only():
+        model.set_input(fixed)
+    ms_stage = timed(stage_only)
     print('step on prepared synthetic inputs (staged once)          : %.2f ms' % ms_a)
+    print('set_input(prepared tensors) + step, every step           : %.2f ms  (%+.2f ms)' % (ms_p, ms_p - ms_a))
+    print('set_input(prepared tensors ON THE DEVICE) + step            : %.2f ms  (%+.2f ms; the call alone on an idle device %.2f ms)'
+          % (ms_pd, ms_pd - ms_a, ms_pd_alone))
+    print('set_input(one raw device batch, no loader) + step        : %.2f ms  (%+.2f ms)' % (ms_r, ms_r - ms_a))
+    print('  host time of the two calls in that loop                  : set_input %.2f ms, optimize_parameters %.2f ms' % (host_in, host_st))
+    print('  raw set_input alone, back to back on an idle device    : %.2f ms' % ms_stage)
+    print('loader running, batches dropped (step on the staged inputs): %.2f ms  (%+.2f ms)' % (ms_idle_loader, ms_idle_loader - ms_a))
     print('loader (%d workers) + raw set_input + step, %2d timed steps : %.2f ms  (%+.2f ms)' % (workers, n - 4, ms_b, ms_b - ms_a))
