@@ -483,12 +483,13 @@ def _tag_split(y):
 
 
 def _take_split(dy):
-    """-> True if `dy` is a gradient some producer wrote as split planes (and forget it)."""
-    return _split_grads.pop(dy.data_ptr(), None) is not None
+    """-> None, or (tensor, bias_done) if `dy` is a gradient some producer wrote as split planes (and forget it); bias_done: that
+    producer also accumulated the column sums of dy into the consumer's bias gradient."""
+    return _split_grads.pop(dy.data_ptr(), None)
 
 
-def _offer_split(dx):
-    _split_grads[dx.data_ptr()] = dx
+def _offer_split(dx, bias_done=False):
+    _split_grads[dx.data_ptr()] = (dx, bias_done)
 
 
 def check_split_grads_consumed():
@@ -534,6 +535,14 @@ class _Conv(Function):
         ctx.save_for_backward(x, w, b, y if act != L.ACT_NONE else None)
         ctx.fork = fork
         ctx.split_ok = dead_bias and _split_backward_ok(d, w, ctx.has_bias, transposed)      # (dead_bias: the output's one reader is a norm)
+        # an eligible layer whose dy arrives as fp32 (no norm behind it: SPADE's conv_1, its gamma/beta convolution): one pass splits dy
+        # (8 B per element) for the two kernels that would otherwise each split every tile they load (tuning key split_grads = 2)
+        ctx.split_pass = (not ctx.split_ok and act == L.ACT_NONE and L.lib.hoig_set_tuning(b'split_grads', -1) == 2 and
+                          _split_backward_ok(d, w, False, transposed))
+        # ... or, with a LIVE bias whose gradient accumulates in a flat buffer, by a producer that also sums dy's columns into that
+        # buffer (split_grads = 3; today: _SpadeFused for its [gamma | beta] convolution)
+        ctx.split_ok_bias = (not dead_bias and ctx.has_bias and act == L.ACT_NONE and getattr(b, '_hoig_flat', False) and
+                             L.lib.hoig_set_tuning(b'split_grads', -1) >= 3 and _split_backward_ok(d, w, False, transposed))
         if fork:
             # (y, x): the caller hands this second output to x's OTHER consumer, so that autograd sees x consumed once -- by
             # this node, whose backward receives both gradients and lets the data-gradient kernel add the other one in its
@@ -549,8 +558,21 @@ class _Conv(Function):
         if dy is None:                      # (fork: only the pass-through output was used)
             return (dxr,) + (None,) * 11
         dy = dy.contiguous()
-        if _take_split(dy):
+        took = _take_split(dy)
+        if took is not None:
+            if ctx.has_bias and not took[1]:
+                raise RuntimeError('pre-split dy for a convolution with a live bias, and nobody summed its columns')
             return _Conv._backward_split(ctx, dy, dxr, x, w)
+        if ctx.split_pass:
+            npix, db_ret = dy.numel() // d.Co, None
+            if ctx.has_bias and ctx.needs_input_grad[2]:
+                db, ret_b = _grad_target(b)
+                call('hoig_colsum_accum', _p(dy), _p(db), npix, d.Co, _st())
+                db_ret = db if ret_b else None
+            dys = torch.empty_like(dy)
+            call('hoig_split_planes_bf16', _p(dy), _p(dys), npix, d.Co, _st())
+            res = _Conv._backward_split(ctx, dys, dxr, x, w)
+            return res[:2] + (db_ret,) + res[3:]
         dw_ret = db_ret = None
         db, ret_b = None, False
         if ctx.needs_input_grad[1] and ctx.has_bias and ctx.needs_input_grad[2]:
@@ -626,6 +648,8 @@ def conv2d(x, w, b=None, stride=1, pad=0, act=L.ACT_NONE, slope=0.0, prec=None, 
     gradient exactly zero in exact arithmetic (the reference computes ~1e-10 rounding noise there); the column sum of dy
     is skipped and the bias gradient left at zero."""
     y = _Conv.apply(x, w, b, stride, pad, False, act, slope, None, precision if prec is None else prec, dead_bias)
+    if getattr(y.grad_fn, 'split_ok_bias', False):
+        y._hoig_split_grad_bias = b             # (read by _SpadeFused only: "write my dy split AND sum its columns into this bias")
     return _tag_split(y) if getattr(y.grad_fn, 'split_ok', False) else y
 
 
@@ -1052,6 +1076,9 @@ class _SpadeFused(Function):
             L.check(rc, 'hoig_inorm_fwd_fused')
         ctx.cfg = (act, slope, B, HW, C)
         ctx.split_dx = getattr(x, '_hoig_split_grad', False)          # (see _INorm.forward)
+        # the convolution that made gb reads its dy pre-split: this backward writes [dgamma | dbeta] as planes and sums their columns
+        # into that convolution's bias gradient (single-launch form only: the maps of at most 1024 pixels)
+        ctx.gb_bias = getattr(gb, '_hoig_split_grad_bias', None) if rc != L.EUNSUPPORTED else None
         ctx.save_for_backward(x, mean, rstd, gb, y if act != L.ACT_NONE else None)
         if fork:                              # (y, x): see _Conv.forward
             ctx.set_materialize_grads(False)
@@ -1069,6 +1096,16 @@ class _SpadeFused(Function):
         dx = torch.empty_like(x)
         dgb = torch.empty_like(gb)
         sfx = '_split' if ctx.split_dx else ''
+        if ctx.gb_bias is not None:
+            db, _ = _grad_target(ctx.gb_bias)
+            L.check(L.lib.hoig_inorm_bwd_fused_add_planes(_p(x), _p(mean), _p(rstd), 2, _p(gb), None, 2 * C, _p(y), _p(dy), act, slope,
+                                                          _p(add), _p(dx), _p(dgb), dgb.data_ptr() + 4 * C, _p(db),
+                                                          (1 if ctx.split_dx else 0) | 2, B, HW, C, _st()),
+                    'hoig_inorm_bwd_fused_add_planes')
+            _offer_split(dgb, bias_done=True)
+            if ctx.split_dx:
+                _offer_split(dx)
+            return dx, dgb, None, None, None, None
         rc = getattr(L.lib, 'hoig_inorm_bwd_fused_add' + sfx)(_p(x), _p(mean), _p(rstd), 2, _p(gb), None, 2 * C, _p(y), _p(dy), act, slope,
                                                               _p(add), _p(dx), _p(dgb), dgb.data_ptr() + 4 * C, B, HW, C, _st())
         if rc == L.EUNSUPPORTED:

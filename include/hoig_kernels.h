@@ -91,6 +91,16 @@ int hoig_inorm_bwd_add_ld_split(const float *x, const float *mean, const float *
 int hoig_inorm_bwd_fused_add_split(const float *x, const float *mean, const float *rstd, int mode, const float *p0, const float *p1,
                                    int ld_p, const float *y, const float *dy, int act, float slope, const float *addend /*nullable*/,
                                    uint16_t *dx_split, float *dp0, float *dp1, int B, int HW, int C, hoig_stream_t stream);
+/* The general single-launch form.  planes bit 0: dx as a split tensor; bit 1 (mode 2 only; dp1 == dp0 + C, ld_p == 2C): the per-pixel
+ * parameter gradients [dgamma | dbeta] as ONE split tensor of width 2C -- the dy of the convolution that made [gamma | beta]
+ * (spade.py:33-34 evaluated as one 3x3 convolution with 2C outputs), whose weight / data gradient then read it pre-split.
+ * dp_colsum (nullable, mode 2 only): [2C] fp32 accumulators, += the column sums of [dgamma | dbeta] over all B*HW pixels = that
+ * convolution's bias gradient, summed from the fp32 values where they are made (no pass over the tensor).  HOIG_EINVAL on a plane
+ * request the layout cannot hold, HOIG_EUNSUPPORTED where hoig_inorm_bwd_fused_add is. */
+int hoig_inorm_bwd_fused_add_planes(const float *x, const float *mean, const float *rstd, int mode, const float *p0, const float *p1,
+                                    int ld_p, const float *y, const float *dy, int act, float slope, const float *addend /*nullable*/,
+                                    void *dx, void *dp0, void *dp1, float *dp_colsum /*nullable*/, int planes, int B, int HW, int C,
+                                    hoig_stream_t stream);
 int hoig_conv2d_bwd_weight_split(const hoig_conv_desc *d, const float *x, const uint16_t *dy_split, float *dw, hoig_stream_t stream);
 /* dx = data gradient (+ addend when non-null: hoig_conv2d_bwd_data_packed_add) of a stride-1 "same" 3x3 Conv2d from pre-split dy, on the
  * 8-row tilings of the v_mfma_f32_16x16x32 kernel (Hi % 8 == 0, Wi % 32 == 0 and enough tiles: HOIG_EUNSUPPORTED otherwise -- the
@@ -506,7 +516,13 @@ const char *hoig_version(void);
  *   "wgrad_ko" 0  diagnostic instantiations of wgrad_dma_kernel (tools/ab_conv.py; results are WRONG with any bit set)
  *   "split_grads" 1  (read by the host side, hoig_amd/ops.py) the backward of a norm that follows an eligible 3x3 convolution writes its
  *                dx as bf16 hi | lo planes and that convolution's weight / data gradient read them without splitting ('PRE-SPLIT
- *                gradients' above); 0: fp32 gradients everywhere, split in every consuming workgroup
+ *                gradients' above); 0: fp32 gradients everywhere, split in every consuming workgroup; 2: as 1, and an eligible convolution
+ *                whose dy arrives as fp32 (SPADE's conv_1, its [gamma | beta] convolution) splits it in a pass of its own first
+ *                (measured: step +0.25 ms, profiles/r05_split_pass_ab.txt -- not adopted); 3: as 1, and SPADE's backward writes
+ *                [dgamma | dbeta] as planes and sums the bias gradient (hoig_inorm_bwd_fused_add_planes) for the [gamma | beta]
+ *                convolution (measured: weight gradient 76 -> 65 us, but that layer's data gradient -- 1024 -> 128 channels, the
+ *                flattened-axis kernel -- has no pre-split form and un-splits first: step +0.25 ms, profiles/r05_split_gb_ab.txt,
+ *                r05_split_shapes.txt -- not adopted)
  * Process-wide, not synchronised: set before launching. */
 int hoig_set_tuning(const char *key, int value);
 

@@ -165,6 +165,95 @@ def test_norm_backward_hands_the_convolution_split_planes(kind, hw):
         ops.set_precision('f32')
 
 
+@pytest.mark.parametrize('planes', [1, 2, 3])
+def test_spade_backward_writes_gamma_beta_gradients_as_planes(planes):
+    """hoig_inorm_bwd_fused_add_planes against hoig_inorm_bwd_fused_add: the same dx and [dgamma | dbeta], as fp32 or as the bf16 hi | lo
+    planes the convolution kernels' own split makes of those fp32 values (bit for bit), and the column sums of [dgamma | dbeta]
+    accumulated into the [2C] buffer of the convolution's bias gradient."""
+    from hoig_amd import _lib as L
+    B, H, W, C = 3, 32, 32, 64
+    HW = H * W
+    g = torch.Generator(device='cuda').manual_seed(5)
+    x = torch.randn(B, H, W, C, device='cuda', generator=g)
+    gb = torch.randn(B, H, W, 2 * C, device='cuda', generator=g) * 0.3
+    dy = torch.randn(B, H, W, C, device='cuda', generator=g)
+    add = torch.randn(B, H, W, C, device='cuda', generator=g)
+    st = torch.cuda.current_stream().cuda_stream
+    y, mean, rstd = torch.empty_like(x), torch.empty(B, C, device='cuda'), torch.empty(B, C, device='cuda')
+    L.call('hoig_inorm_fwd_fused', _p(x), 2, _p(gb), gb.data_ptr() + 4 * C, 2 * C, L.ACT_RELU, 0.0, None, 1e-5, _p(y), _p(mean), _p(rstd),
+           B, HW, C, st)
+    dx0, dgb0 = torch.empty_like(x), torch.empty_like(gb)
+    L.call('hoig_inorm_bwd_fused_add', _p(x), _p(mean), _p(rstd), 2, _p(gb), None, 2 * C, _p(y), _p(dy), L.ACT_RELU, 0.0, _p(add), _p(dx0),
+           _p(dgb0), dgb0.data_ptr() + 4 * C, B, HW, C, st)
+    dx1, dgb1 = torch.empty_like(x), torch.empty_like(gb)
+    col = torch.full((2 * C,), 0.5, device='cuda')                     # (accumulated INTO: starts non-zero)
+    L.call('hoig_inorm_bwd_fused_add_planes', _p(x), _p(mean), _p(rstd), 2, _p(gb), None, 2 * C, _p(y), _p(dy), L.ACT_RELU, 0.0, _p(add),
+           _p(dx1), _p(dgb1), dgb1.data_ptr() + 4 * C, _p(col), planes, B, HW, C, st)
+    torch.cuda.synchronize()
+
+    def as_planes(t):
+        return _split_reference(t).view(torch.int16)
+
+    if planes & 1:
+        assert torch.equal(dx1.view(torch.bfloat16).view(B, H, W, 2, C).view(torch.int16), as_planes(dx0))
+    else:
+        assert torch.equal(dx1, dx0)
+    if planes & 2:
+        assert torch.equal(dgb1.view(torch.bfloat16).view(B, H, W, 2, 2 * C).view(torch.int16), as_planes(dgb0))
+    else:
+        assert torch.equal(dgb1, dgb0)
+    want = 0.5 + dgb0.double().sum(dim=(0, 1, 2))
+    assert (col.double() - want).abs().max().item() <= 1e-5 * want.abs().max().item()
+    # a plane request the layout cannot hold
+    rc = L.lib.hoig_inorm_bwd_fused_add_planes(_p(x), _p(mean), _p(rstd), 2, _p(gb), None, 2 * C, _p(y), _p(dy), L.ACT_RELU, 0.0, None,
+                                               _p(dx1), _p(dgb1), dgb1.data_ptr() + 8 * C, None, 2, B, HW, C, st)
+    assert rc == L.EINVAL
+    rc = L.lib.hoig_inorm_bwd_fused_add_planes(_p(x), _p(mean), _p(rstd), 0, None, None, C, None, _p(dy), L.ACT_NONE, 0.0, None,
+                                               _p(dx1), None, None, _p(col), 0, B, HW, C, st)
+    assert rc == L.EINVAL
+
+
+def test_spade_gamma_beta_convolution_reads_planes_from_the_norm_backward():
+    """mlp_shared activation -> the [gamma | beta] 3x3 convolution (live bias) -> SPADE modulation, with `split_grads` = 3 and 1: the
+    SPADE backward writes [dgamma | dbeta] as planes and sums their columns into the convolution's bias gradient; the convolution's
+    weight and data gradients read the planes.  Same arithmetic both ways."""
+    from hoig_amd import _lib as L, nn as hnn, ops
+    B, H, W, Cl, C = 4, 32, 32, 128, 256
+    ops.set_precision('bf16x3:f16x2')
+    try:
+        g = torch.Generator(device='cuda').manual_seed(13)
+        tree = hnn.ParamTree({'gb.weight': (2 * C, Cl, 3, 3), 'gb.bias': (2 * C,)}, torch.device('cuda'), {}, {})
+        with torch.no_grad():
+            tree.flat.copy_(torch.randn(tree.flat.shape, device='cuda', generator=g) * 0.03)
+        tree.version += 1
+        a0 = torch.randn(B, H, W, Cl, device='cuda', generator=g).relu()
+        x0 = torch.randn(B, H, W, C, device='cuda', generator=g)
+        gout = torch.randn(B, H, W, C, device='cuda', generator=g)
+        outs = {}
+        for split in (3, 1):
+            L.set_tuning('split_grads', split)
+            tree.flat_grad.zero_()
+            a = a0.clone().requires_grad_(True)
+            x = x0.clone().requires_grad_(True)
+            gb = ops.conv2d(a, tree.P['gb.weight'], tree.P['gb.bias'], 1, 1)
+            assert (getattr(gb, '_hoig_split_grad_bias', None) is not None) == (split == 3)
+            z = ops.spade_norm_fused(x, gb, act=L.ACT_RELU)
+            (z * gout).sum().backward()
+            ops.join_wgrad_streams()
+            ops.check_split_grads_consumed()
+            torch.cuda.synchronize()
+            outs[split] = (a.grad.clone(), x.grad.clone(), tree.flat_grad.clone(), tree.P['gb.bias'].grad.clone())
+        da3, dx3, dp3, db3 = outs[3]
+        da1, dx1, dp1, db1 = outs[1]
+        assert torch.equal(dx3, dx1)
+        assert (da3 - da1).abs().max().item() <= 4e-6 * da1.abs().max().item()
+        assert ((dp3 - dp1).norm() / dp1.norm()).item() < 2e-5
+        assert db1.abs().max().item() > 0 and (db3 - db1).abs().max().item() <= 1e-5 * db1.abs().max().item()
+    finally:
+        L.set_tuning('split_grads', 1)
+        ops.set_precision('f32')
+
+
 @pytest.mark.parametrize('shape', [(8, 32, 32, 512, 512), (2, 64, 64, 128, 256), (4, 32, 32, 128, 1024)])
 def test_grouped_launch_equals_the_two_single_launches(shape):
     """hoig_conv2d_*_pair: two convolutions of one descriptor (different tensors, different weights) as ONE grid -- src_model's and
