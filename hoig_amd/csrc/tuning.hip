@@ -25,6 +25,7 @@ Entry g_table[HOIG_TUNE_COUNT] = {
     {"pair", 2},
     {"pad_in", 1},
     {"wdma16", 2},
+    {"s2_pipe", 1},
 };
 }  // namespace
 

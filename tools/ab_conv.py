@@ -24,6 +24,8 @@ SHAPES = {
     's2': [(16, 64, 128, 256, 256, 3, 2, 0), (16, 128, 256, 128, 128, 3, 2, 0), (16, 256, 512, 64, 64, 3, 2, 0),
            (16, 512, 256, 32, 32, 3, 2, 1), (16, 256, 128, 64, 64, 3, 2, 1), (16, 128, 64, 128, 128, 3, 2, 1),
            (8, 64, 128, 256, 256, 3, 2, 0), (8, 128, 64, 128, 128, 3, 2, 1)],
+    's2small': [(2, 64, 128, 256, 256, 3, 2, 0), (4, 64, 128, 256, 256, 3, 2, 0), (2, 128, 256, 128, 128, 3, 2, 0), (4, 128, 256, 128, 128, 3, 2, 0),
+                (4, 256, 512, 64, 64, 3, 2, 0), (8, 256, 512, 64, 64, 3, 2, 0)],
     'attn5': [(8, 512, 128, 40, 40, 5), (8, 512, 128, 36, 36, 5), (8, 128, 128, 136, 136, 5), (8, 256, 128, 72, 72, 5)],
 }
 
