@@ -246,7 +246,7 @@ int launch_wgrad_halo_m16(const WHaloArgs &a, int ns, int th, int cm, dim3 grid,
 
 // wgrad_dma.hip: the stride-1 3x3 weight gradient from PRE-SPLIT dy (a.DY points at [pixel][2][Co] bf16: hoig_split_planes_bf16 or a
 // producer's epilogue), staged by LDS-DMA into double-buffered tiles; `a` carries the 4 x 32-pixel tiling; HOIG_EUNSUPPORTED otherwise
-int launch_halo_s2_m16p(const HaloArgs &a, int ns, bool scatter, hipStream_t st);      // conv_s2_16.hip
+int launch_halo_s2_m16p(const HaloArgs &a, int ns, bool scatter, bool rows8, hipStream_t st);      // conv_s2_16.hip
 int launch_wgrad_dma(const WHaloArgs &a, int ns, dim3 grid, hipStream_t st);
 
 // conv_halo16.hip: the 3x3 stride-1 halo kernel on v_mfma_f32_16x16x32 (8 rows x 32 pixels x bn channels per workgroup, bn = 128

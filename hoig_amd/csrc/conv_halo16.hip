@@ -697,11 +697,19 @@ int launch_one(const HaloArgs &a, hipStream_t st) {
 template <bool SCATTER>
 int launch_s2(const HaloArgs &a, int ns, hipStream_t st) {
     const bool n64 = (a.N % 128) != 0;
-    // conv_s2_16.hip, the statically walked form: a workgroup alone on its CU runs 26-33 % faster (its loads fly behind its MFMAs); two
-    // workgroups per CU fill each other's stalls in the form below just as well and the CU's load path is the limit either way
-    // (profiles/r05_s2_pipe_ab.txt) -- so: grids of at most one workgroup per CU (key s2_pipe = 1), 2 = always, 0 = never
+    // conv_s2_16.hip, the statically walked form (loads in flight behind the MFMAs, weight tiles by LDS-DMA), where it measured
+    // faster (key s2_pipe = 1; profiles/r05_s2_dma_ab.txt):
+    //  * 8 x 32 tiles, eight waves, one workgroup per CU, wherever that still gives every CU a workgroup and N is a multiple of 128:
+    //    a weight tile serves 256 pixels -- a third fewer bytes through the CU's load path per MFMA, the path that bounds these
+    //    layers: 12-24 % faster on every such launch of the step;
+    //  * grids of at most one workgroup per CU: 4 x 32 tiles, 15-30 % faster;
+    //  * in between and for 64-channel tiles: the kernel below (two workgroups per CU fill each other's stalls there; the static walk
+    //    on 4 x 32 tiles is 0-40 % SLOWER with two workgroups on a CU).
+    // 2 / 3: the 4-row / 8-row form wherever it can run (tests, A/B); 0: never.
     const int pipe = hoig_tuning(HOIG_TUNE_S2_PIPE);
-    if (pipe == 2 || (pipe == 1 && a.nblk <= 256)) return launch_halo_s2_m16p(a, ns, SCATTER, st);
+    const bool rows8_ok = a.nblk >= 512 && !(a.tiles_y & 1) && a.N % 128 == 0;
+    if (rows8_ok && (pipe == 1 || pipe == 3)) return launch_halo_s2_m16p(a, ns, SCATTER, true, st);
+    if (pipe == 2 || (pipe != 0 && a.nblk <= 256)) return launch_halo_s2_m16p(a, ns, SCATTER, false, st);
     if (n64) {
         if (a.f16) HOIG_NS_SWITCH(ns, conv_halo_s2_m16_kernel<NSX, 64, SCATTER, true><<<a.nblk, 256, 0, st>>>(a));
         else HOIG_NS_SWITCH(ns, conv_halo_s2_m16_kernel<NSX, 64, SCATTER, false><<<a.nblk, 256, 0, st>>>(a));

@@ -15,18 +15,25 @@ namespace {
 // of the halo prefetch are named, not indexed, and halo loads are unconditional (an out-of-image position reads its image's first
 // pixel and is zeroed when the set is stored) -- the recipe of wgrad_dma.hip.  Arithmetic, LDS images, step order and epilogue are
 // those of the kernel above: results are bit-identical.
-template <int NSX, int BN, bool SCATTER, bool F16>
-__global__ __launch_bounds__(256) void conv_halo_s2_m16p_kernel(const HaloArgs p) {
+//
+// WM = 4 (round 5): the same walk over an 8 x 32 tile with eight waves -- a weight tile then serves 256 pixels instead of 128 and the halo
+// overhead falls from 1.29 to 1.16, i.e. a third fewer bytes through the CU's load path per MFMA (that path, not the MFMA pipe, bounds
+// these layers: 53 KB per 96-MFMA step and workgroup at WM = 2).  One workgroup per CU (72 KB of LDS, 2 waves per SIMD), which is
+// exactly where the static walk pays.
+template <int NSX, int BN, bool SCATTER, bool F16, int WM>
+__global__ __launch_bounds__(128 * WM) void conv_halo_s2_m16p_kernel(const HaloArgs p) {
     constexpr int NS = NSX == 1 ? 1 : 2, NB = NSX == 2 ? 2 : 1;
-    constexpr int TH = 4, TW = 32, NT = 256, WN = 2;
+    constexpr int TH = 2 * WM, TW = 32, WN = 2, NT = 64 * WM * WN;
     constexpr int RB = BN * 4 / NT;
+    static_assert(RB >= 1, "more threads than 16-B weight chunks per tap");
     constexpr int HH = TH + 1, HW = TW + 1, HPIX = HH * HW;
     constexpr int PHALF = HPIX * 32, P23 = round128(PHALF) + 64, PLANE_P = round128(P23 + PHALF);
     constexpr int W23 = BN * 32 + 64, PLANE_W = round128(W23 + BN * 32);
     constexpr int MT = 4, NTW = BN / (16 * WN);
-    __shared__ __attribute__((aligned(16))) unsigned char smem[NS * PLANE_P + 2 * NB * PLANE_W];
+    extern __shared__ __attribute__((aligned(1024))) unsigned char smem[];    // NS * PLANE_P + 2 * BBUF (s2p_lds)
     unsigned char *Ph = smem, *Pl = smem + PLANE_P;
-    unsigned char *Wbase = smem + NS * PLANE_P;            // two tap tiles of (Wh, Wl)
+    constexpr int BBUF = 2 * NB * PLANE_W;                 // two tap tiles of (Wh, Wl); DOUBLE-buffered
+    unsigned char *Wbase = smem + NS * PLANE_P;
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int l15 = lane & 15, lg = lane >> 4;
@@ -45,19 +52,6 @@ __global__ __launch_bounds__(256) void conv_halo_s2_m16p_kernel(const HaloArgs p
     const int ty_ = mt_ % p.tiles_y, b = mt_ / p.tiles_y;
     const int y0 = ty_ * TH, x0 = tx_ * TW;                // coarse-grid tile origin
 
-    const int brow = tid >> 2, bpos = tid & 3;
-    const unsigned short *wrow_h[RB], *wrow_l[RB];
-    int woff[RB];
-#pragma unroll
-    for (int i = 0; i < RB; ++i) {
-        const int row = brow + (NT / 4) * i;
-        const int n = min(n0 + row, p.N - 1);              // (N % 64 == 0 and BN | N here: never clamps; keeps the load unconditional)
-        const size_t o = ((size_t)(n >> 5) * (p.K >> 5)) * 1024 + (n & 31) * 32 + bpos * 8;
-        wrow_h[i] = p.Wh + o;
-        wrow_l[i] = NB == 2 ? p.Wl + o : nullptr;
-        const int c = bpos ^ ((row >> 2) & 3);
-        woff[i] = (c >> 1) * W23 + row * 32 + (c & 1) * 16;
-    }
     int wread[NTW], pread[MT];
 #pragma unroll
     for (int j = 0; j < NTW; ++j) wread[j] = (lg >> 1) * W23 + (wn * (NTW * 16) + j * 16 + l15) * 32 + (lg & 1) * 16;
@@ -79,41 +73,39 @@ __global__ __launch_bounds__(256) void conv_halo_s2_m16p_kernel(const HaloArgs p
         return (dr * HW + dc) * 32;
     };
 
-    // ---- weights: two tap tiles, registers -> LDS (single-buffered in LDS: stored between the two barriers that end a step)
-    typedef unsigned u32x4 __attribute__((ext_vector_type(4)));    // (a native vector: uint4 copies are memcpys that SROA left in memory here)
-    u32x4 rbh[2][RB], rbl[2][RB];
+    // ---- weights: the two tap tiles of the NEXT step go global -> LDS by LDS-DMA into the other weight buffer (the recipe of
+    // conv_halo3_m16_kernel's WDMA: inline asm, M0 = the piece's LDS address, no staging registers, no ds_write; a 32-row block of a
+    // blocked plane is 2 KB contiguous; piece q = (tap t, plane, block, half image h) = 1 KB of LDS: lane l copies row l >> 1's chunk
+    // 2h + (l & 1), which the plane keeps at position chunk ^ ((row >> 2) & 3)).  Issued at the TOP of a step, before that step's halo
+    // loads: the `s_waitcnt vmcnt(<halo loads of this step>)` that ends the step then finds the pieces landed and leaves the halo
+    // loads in flight.
+    constexpr int NWAVE = WM * WN, NPIECE = 2 * NB * (BN / 32) * 2, NPW = (NPIECE + NWAVE - 1) / NWAVE;
+    const int wave_u = __builtin_amdgcn_readfirstlane(wave);
+    const unsigned lds_w0 = __builtin_amdgcn_readfirstlane((unsigned)(size_t)(__attribute__((address_space(3))) unsigned char *)Wbase);
+    const int drow = lane >> 1;
+    const unsigned dlane0 = drow * 32 + (((0 + (lane & 1)) ^ ((drow >> 2) & 3)) << 3);       // element offset inside a block, h = 0
+    const unsigned dlane1 = drow * 32 + (((2 + (lane & 1)) ^ ((drow >> 2) & 3)) << 3);       // h = 1
+    int wb = 1;                                            // the weight buffer the CURRENT step reads (wave-uniform)
     auto load_b = [&](int tap0, int tap1, int cb) __attribute__((always_inline)) {
 #pragma unroll
-        for (int t = 0; t < 2; ++t) {
-            const size_t koff = (size_t)((t ? tap1 : tap0) * p.Cg + cb * 32) * 32;
-#pragma unroll
-            for (int i = 0; i < RB; ++i) {
-                rbh[t][i] = *reinterpret_cast<const u32x4 *>(wrow_h[i] + koff);
-                if (NB == 2) rbl[t][i] = *reinterpret_cast<const u32x4 *>(wrow_l[i] + koff);
-            }
-        }
-    };
-    auto store_b = [&]() __attribute__((always_inline)) {
-#pragma unroll
-        for (int t = 0; t < 2; ++t) {
-            unsigned char *Wh = Wbase + t * NB * PLANE_W, *Wl = Wh + PLANE_W;
-#pragma unroll
-            for (int i = 0; i < RB; ++i) {
-                *reinterpret_cast<u32x4 *>(Wh + woff[i]) = rbh[t][i];
-                if (NB == 2) *reinterpret_cast<u32x4 *>(Wl + woff[i]) = rbl[t][i];
+        for (int i = 0; i < NPW; ++i) {
+            const int q = wave_u + NWAVE * i;
+            if (q < NPIECE) {
+                const int h = q & 1, blk = (q >> 1) % (BN / 32), tp = (q >> 1) / (BN / 32);  // tp = t * NB + plane
+                const int t = tp / NB, pl = tp - t * NB;
+                const size_t koff = (size_t)((t ? tap1 : tap0) * p.Cg + cb * 32) * 32;
+                const unsigned short *src = (pl ? p.Wl : p.Wh) + ((size_t)((n0 >> 5) + blk) * (p.K >> 5)) * 1024 + koff +
+                                            (h ? dlane1 : dlane0);
+                const unsigned to = __builtin_amdgcn_readfirstlane(lds_w0 + (wb ^ 1) * BBUF + tp * PLANE_W + h * W23 + blk * 1024);
+                unsigned keep;
+                asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+                             : "=&s"(keep) : "v"(src), "s"(to) : "memory");
             }
         }
     };
 
-    // ---- halo images: a thread's slices are the same halo positions in every image (computed once); loads are unconditional
+    // ---- halo images: loads are unconditional (an out-of-image position reads its image's first pixel and is zeroed at the store)
     constexpr int HSLICES = (HPIX * 8 + NT - 1) / NT;
-    int hy_[HSLICES], hx_[HSLICES];
-#pragma unroll
-    for (int sl = 0; sl < HSLICES; ++sl) {
-        const int i = tid + NT * sl, pix = i >> 3;
-        hy_[sl] = i < HPIX * 8 ? pix / HW : (1 << 24);    // (a slice past the halo fails every bounds test)
-        hx_[sl] = pix - (pix / HW) * HW;
-    }
     const float *const Ac = p.A + (size_t)b * p.H * p.W * p.Cg + (tid & 7) * 4;       // p.H x p.W: the gathered tensor
     struct HaloSet {
         float4 r[HSLICES];
@@ -121,12 +113,19 @@ __global__ __launch_bounds__(256) void conv_halo_s2_m16p_kernel(const HaloArgs p
     };
     HaloSet hs0, hs1;
     auto halo_load = [&](HaloSet &h, int cb, int pp, int qq) __attribute__((always_inline)) {
+        // (opaque: with the phase a compile-time constant of each call site hipcc keeps every site's slice offsets in registers across
+        // the whole block -- forty of them -- and spills; computed at the load they are ten VALU instructions per slice)
+        asm volatile("" : "+s"(pp), "+s"(qq));
         h.in = 0;
 #pragma unroll
         for (int sl = 0; sl < HSLICES; ++sl) {
-            const int gy = SCATTER ? y0 + hy_[sl] : 2 * (y0 - 1 + hy_[sl]) + pp;
-            const int gx = SCATTER ? x0 + hx_[sl] : 2 * (x0 - 1 + hx_[sl]) + qq;
-            const bool in = (unsigned)gy < (unsigned)p.H && (unsigned)gx < (unsigned)p.W;
+            // (positions recomputed per image: ten registers matter more here than ten VALU instructions; a slice past the halo fails
+            // the bounds test)
+            const int i = tid + NT * sl, pix = i >> 3;
+            const int hy = pix / HW, hx = pix - hy * HW;
+            const int gy = SCATTER ? y0 + hy : 2 * (y0 - 1 + hy) + pp;
+            const int gx = SCATTER ? x0 + hx : 2 * (x0 - 1 + hx) + qq;
+            const bool in = i < HPIX * 8 && (unsigned)gy < (unsigned)p.H && (unsigned)gx < (unsigned)p.W;
             h.in |= in ? (1u << sl) : 0u;
             h.r[sl] = *reinterpret_cast<const float4 *>(Ac + (in ? (size_t)(gy * p.W + gx) * p.Cg : (size_t)0) + cb * 32);
         }
@@ -152,7 +151,7 @@ __global__ __launch_bounds__(256) void conv_halo_s2_m16p_kernel(const HaloArgs p
         for (int t = 0; t < 2; ++t) {
             if (t >= ntap) break;
             const int tapoff = tap_off(t ? tap1 : tap0);
-            const unsigned char *Wh = Wbase + t * NB * PLANE_W, *Wl = Wh + PLANE_W;
+            const unsigned char *Wh = Wbase + wb * BBUF + t * NB * PLANE_W, *Wl = Wh + PLANE_W;
             bf16x8 ph[MT], pl[MT];
 #pragma unroll
             for (int m = 0; m < MT; ++m) {
@@ -179,12 +178,24 @@ __global__ __launch_bounds__(256) void conv_halo_s2_m16p_kernel(const HaloArgs p
             }
         }
     };
-    // the end of a step: everyone is done reading the weight tiles (and the halo image); the next step's go in; everyone sees them
-    auto turn = [&](HaloSet *h) __attribute__((always_inline)) {
+    // the end of a step.  PEND = the halo loads this step issued behind its DMA pieces: they stay in flight, the pieces have landed;
+    // everyone is done reading the step's weight buffer (the next DMA overwrites it) and the halo image; the next image goes in
+    typedef std::integral_constant<int, HSLICES> Halo;
+    typedef std::integral_constant<int, 0> None;
+    auto turn = [&](HaloSet *h, auto pend_c) __attribute__((always_inline)) {
+        asm volatile("s_waitcnt vmcnt(%0)" ::"n"(decltype(pend_c)::value) : "memory");
         __syncthreads();
-        if (h) halo_store(*h);
-        store_b();
-        __syncthreads();
+        if (h) {
+            halo_store(*h);
+            __syncthreads();
+        }
+        wb ^= 1;
+    };
+    // the first step's operands: DMA into buffer 0, image from hs_first
+    auto prologue = [&](HaloSet &h) __attribute__((always_inline)) {
+        halo_store(h);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        wb = 0;
     };
 
     if constexpr (!SCATTER) {
@@ -192,32 +203,31 @@ __global__ __launch_bounds__(256) void conv_halo_s2_m16p_kernel(const HaloArgs p
         // image is fetched two steps before the step that reads it and stored at the end of the step in between:
         //   step 0 fetches (1,0) -> hs0      step 1 fetches (0,1) -> hs1, stores hs0      step 2 fetches (0,0) -> hs0, stores hs1
         //   step 3 fetches the next block's (1,1) -> hs1, stores hs0                      step 4 stores hs1
-        halo_load(hs1, 0, 1, 1);
         load_b(0, 2, 0);
-        halo_store(hs1);
-        store_b();
+        halo_load(hs1, 0, 1, 1);
+        prologue(hs1);
         __syncthreads();
         auto block = [&](const int cb, auto last_c) __attribute__((always_inline)) {
             constexpr bool last = decltype(last_c)::value;
             load_b(6, 8, cb);
             halo_load(hs0, cb, 1, 0);
             compute(0, 2, 2);
-            turn(nullptr);
+            turn(nullptr, Halo{});
             load_b(1, 7, cb);
             halo_load(hs1, cb, 0, 1);
             compute(6, 8, 2);
-            turn(&hs0);
+            turn(&hs0, Halo{});
             load_b(3, 5, cb);
             halo_load(hs0, cb, 0, 0);
             compute(1, 7, 2);
-            turn(&hs1);
+            turn(&hs1, Halo{});
             load_b(4, 4, cb);
             if constexpr (!last) halo_load(hs1, cb + 1, 1, 1);
             compute(3, 5, 2);
-            turn(&hs0);
+            turn(&hs0, std::conditional_t<last, None, Halo>{});
             if constexpr (!last) load_b(0, 2, cb + 1);
             compute(4, 4, 1);
-            if constexpr (!last) turn(&hs1);
+            if constexpr (!last) turn(&hs1, None{});
         };
 #pragma unroll 1
         for (int cb = 0; cb + 1 < ncb; ++cb) block(cb, std::false_type{});
@@ -225,24 +235,23 @@ __global__ __launch_bounds__(256) void conv_halo_s2_m16p_kernel(const HaloArgs p
     } else {
         // scatter: ONE halo image per 32-channel block; output phase (P, Q) reads taps r in {P ? 0 : 1, 2 if P}, s likewise
         const int r0 = P ? 0 : 1, s0 = Q ? 0 : 1;
-        halo_load(hs0, 0, 0, 0);
         if (P && Q) {
             // four taps, two steps per block: {(r0,s0),(r0,2)} then {(2,s0),(2,2)}; the next block's image is fetched in the first step
             // and stored at the end of the second
             const int ta0 = r0 * 3 + s0, ta1 = r0 * 3 + 2, tb0 = 6 + s0, tb1 = 8;
             load_b(ta0, ta1, 0);
-            halo_store(hs0);
-            store_b();
+            halo_load(hs0, 0, 0, 0);
+            prologue(hs0);
             __syncthreads();
             auto block = [&](const int cb, auto last_c) __attribute__((always_inline)) {
                 constexpr bool last = decltype(last_c)::value;
                 load_b(tb0, tb1, cb);
                 if constexpr (!last) halo_load(hs0, cb + 1, 0, 0);
                 compute(ta0, ta1, 2);
-                turn(nullptr);
+                turn(nullptr, std::conditional_t<last, None, Halo>{});
                 if constexpr (!last) load_b(ta0, ta1, cb + 1);
                 compute(tb0, tb1, 2);
-                if constexpr (!last) turn(&hs0);
+                if constexpr (!last) turn(&hs0, None{});
             };
 #pragma unroll 1
             for (int cb = 0; cb + 1 < ncb; ++cb) block(cb, std::false_type{});
@@ -253,8 +262,8 @@ __global__ __launch_bounds__(256) void conv_halo_s2_m16p_kernel(const HaloArgs p
             const int ntap = (P || Q) ? 2 : 1;
             const int t0 = r0 * 3 + s0, t1 = P ? 6 + s0 : (Q ? r0 * 3 + 2 : t0);
             load_b(t0, t1, 0);
-            halo_store(hs0);
-            store_b();
+            halo_load(hs0, 0, 0, 0);
+            prologue(hs0);
             halo_load(hs1, ncb > 1 ? 1 : 0, 0, 0);         // (one block only: a harmless re-read)
             __syncthreads();
             // has1: block cb + 1 exists (its weights are fetched, its image stored); has2: block cb + 2 exists (its image is fetched)
@@ -263,7 +272,7 @@ __global__ __launch_bounds__(256) void conv_halo_s2_m16p_kernel(const HaloArgs p
                 if constexpr (has1) load_b(t0, t1, cb + 1);
                 if constexpr (has2) halo_load(mine, cb + 2, 0, 0);
                 compute(t0, t1, ntap);
-                if constexpr (has1) turn(&other);
+                if constexpr (has1) turn(&other, std::conditional_t<has2, Halo, None>{});
             };
             int cb = 0;
 #pragma unroll 1
@@ -326,26 +335,56 @@ __global__ __launch_bounds__(256) void conv_halo_s2_m16p_kernel(const HaloArgs p
             }
         }
     }
-    if (p.stats) m16_stats_epilogue<NTW, 2, BN, NT>(st1, st2, smem, p.stats + (size_t)b * 2 * p.N, p.N, n0, wm, wn, lane, tid);
+    if (p.stats) m16_stats_epilogue<NTW, WM, BN, NT>(st1, st2, smem, p.stats + (size_t)b * 2 * p.N, p.N, n0, wm, wn, lane, tid);
 }
 
-template <bool SCATTER>
-int launch_s2p(const HaloArgs &a, int ns, hipStream_t st) {
-    if ((a.N % 128) != 0) {
-        if (a.f16) HOIG_NS_SWITCH(ns, conv_halo_s2_m16p_kernel<NSX, 64, SCATTER, true><<<a.nblk, 256, 0, st>>>(a));
-        else HOIG_NS_SWITCH(ns, conv_halo_s2_m16p_kernel<NSX, 64, SCATTER, false><<<a.nblk, 256, 0, st>>>(a));
-    } else {
-        if (a.f16) HOIG_NS_SWITCH(ns, conv_halo_s2_m16p_kernel<NSX, 128, SCATTER, true><<<a.nblk, 256, 0, st>>>(a));
-        else HOIG_NS_SWITCH(ns, conv_halo_s2_m16p_kernel<NSX, 128, SCATTER, false><<<a.nblk, 256, 0, st>>>(a));
+template <int BN, int WM>
+constexpr int s2p_lds(int nsx) {
+    constexpr int HPIX = (2 * WM + 1) * 33, PHALF = HPIX * 32, P23 = round128(PHALF) + 64, PLANE_P = round128(P23 + PHALF);
+    constexpr int W23 = BN * 32 + 64, PLANE_W = round128(W23 + BN * 32);
+    return (nsx == 1 ? 1 : 2) * PLANE_P + 2 * (2 * (nsx == 2 ? 2 : 1) * PLANE_W);
+}
+
+template <int NSX, int BN, bool SCATTER, bool F16, int WM>
+int launch_s2p_one(const HaloArgs &a, hipStream_t st) {
+    constexpr int shm = s2p_lds<BN, WM>(NSX);
+    static hoig_once once;
+    if (!once.done()) {
+        if (hipFuncSetAttribute(reinterpret_cast<const void *>(&conv_halo_s2_m16p_kernel<NSX, BN, SCATTER, F16, WM>),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, shm) != hipSuccess)
+            return HOIG_ELAUNCH;
+        once.set();
     }
+    conv_halo_s2_m16p_kernel<NSX, BN, SCATTER, F16, WM><<<a.nblk, 128 * WM, shm, st>>>(a);
     HOIG_LAUNCH_CHECK();
     return HOIG_OK;
 }
 
+template <bool SCATTER, int WM>
+int launch_s2p(const HaloArgs &a, int ns, hipStream_t st) {
+    if ((a.N % 128) != 0) {
+        if constexpr (WM == 2) {
+            if (a.f16) HOIG_NS_SWITCH(ns, return launch_s2p_one<NSX, 64, SCATTER, true, 2>(a, st));
+            HOIG_NS_SWITCH(ns, return launch_s2p_one<NSX, 64, SCATTER, false, 2>(a, st));
+        }
+        return HOIG_EUNSUPPORTED;
+    }
+    if (a.f16) HOIG_NS_SWITCH(ns, return launch_s2p_one<NSX, 128, SCATTER, true, WM>(a, st));
+    HOIG_NS_SWITCH(ns, return launch_s2p_one<NSX, 128, SCATTER, false, WM>(a, st));
+    return HOIG_EINVAL;
+}
+
 }  // namespace
 
-int launch_halo_s2_m16p(const HaloArgs &a, int ns, bool scatter, hipStream_t st) {
-    return scatter ? launch_s2p<true>(a, ns, st) : launch_s2p<false>(a, ns, st);
+// `a` arrives with the 4-row geometry launch_halo_s2 (conv_igemm_bf16.hip) computes; rows8: re-tile to 8 x 32 (the caller has checked
+// that the coarse height is a multiple of 8 and N of 128)
+int launch_halo_s2_m16p(const HaloArgs &a_, int ns, bool scatter, bool rows8, hipStream_t st) {
+    if (!rows8) return scatter ? launch_s2p<true, 2>(a_, ns, st) : launch_s2p<false, 2>(a_, ns, st);
+    HaloArgs a = a_;
+    if ((a.tiles_y & 1) || (a.N % 128)) return HOIG_EUNSUPPORTED;
+    a.tiles_y /= 2;
+    a.nblk /= 2;
+    return scatter ? launch_s2p<true, 4>(a, ns, st) : launch_s2p<false, 4>(a, ns, st);
 }
 
 }  // namespace hoig_detail

@@ -514,9 +514,9 @@ const char *hoig_version(void);
  *                layer of the first, +2..5 % on the attention's 5x5 layers, step 63.85 -> 63.03 -> 62.8 ms (profiles/r05_wdma16_ab.txt);
  *                0: through registers, two steps ahead
  *   "s2_pipe"  1  the stride-2 3x3 kernel on the 16x16 MFMA in its statically walked form (conv_s2_16.hip: loads in flight behind the
- *                MFMAs) for grids of at most one workgroup per CU (26-33 % faster there: 112 -> 74 us on 8 x 64x64 256 -> 512); 2: for
- *                every grid (two workgroups per CU: 0-15 % SLOWER -- they fill each other's stalls in the old form and the CU's load
- *                path, 53 KB per step, is the limit either way); 0: never.  profiles/r05_s2_pipe_ab.txt
+ *                MFMAs, weight tiles by LDS-DMA) where it measured faster: 8 x 32 tiles with eight waves wherever that leaves every CU
+ *                a workgroup and N % 128 == 0 (12-24 %: 132 -> 100 us on 16 x 64x64 256 -> 512), 4 x 32 tiles for grids of at most one
+ *                workgroup per CU (15-30 %); 2 / 3: the 4-row / 8-row form wherever it can run; 0: never.  profiles/r05_s2_dma_ab.txt
  *   "wgrad_ko" 0  diagnostic instantiations of wgrad_dma_kernel (tools/ab_conv.py; results are WRONG with any bit set)
  *   "split_grads" 1  (read by the host side, hoig_amd/ops.py) the backward of a norm that follows an eligible 3x3 convolution writes its
  *                dx as bf16 hi | lo planes and that convolution's weight / data gradient read them without splitting ('PRE-SPLIT

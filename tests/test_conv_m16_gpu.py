@@ -321,7 +321,7 @@ def test_stride2_statically_walked_kernel_is_bit_identical(B, Ci, Co, H, transpo
         x0 = torch.randn(B, H, H, Ci, device='cuda', generator=g)
         w0 = torch.randn((Ci, Co, 3, 3) if transposed else (Co, Ci, 3, 3), device='cuda', generator=g) * 0.05
         outs = []
-        for v in (0, 2):
+        for v in (0, 2, 3):
             L.set_tuning('s2_pipe', v)
             x = x0.clone().requires_grad_(True)
             w = ops.pack_weight(w0, transposed=transposed).requires_grad_(True)
@@ -334,10 +334,10 @@ def test_stride2_statically_walked_kernel_is_bit_identical(B, Ci, Co, H, transpo
             ops.join_wgrad_streams()
             torch.cuda.synchronize()
             outs.append((y.detach().clone(), x.grad.clone(), gy))
-        (y0, dx0, gy), (y1, dx1, _) = outs
+        (y0, dx0, gy), (y1, dx1, _), (y3, dx3, _) = outs
         # (a side whose output channel count is no multiple of 64 runs on another kernel under either key value -- one that sums with
         # atomics where tiles are few: compared to rounding there)
-        for a0, a1, n in ((y0, y1, Co), (dx0, dx1, Ci)):
+        for a0, a1, n in ((y0, y1, Co), (dx0, dx1, Ci), (y0, y3, Co), (dx0, dx3, Ci)):      # (y3 / dx3: the 8 x 32 tile form)
             if n % 64 == 0:
                 assert torch.equal(a0, a1), (a0 - a1).abs().max().item()
             else:
