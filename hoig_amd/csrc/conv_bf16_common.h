@@ -109,6 +109,12 @@ struct HaloArgs {
                                // a tensor with a second consumer adds that consumer's gradient itself (ops.conv2d_fork)
     // grouped launch (3x3 stride-1 kernel of conv_halo16.hip only): Bn counts the images of BOTH problems; images b >= b_split read and
     // write the *_g2 tensors (indexed from their own image 0).  0: one problem.
+    // forward of an INFERENCE chain conv -> instance norm (+ affine) -> ReLU -> THIS convolution (3x3 stride-1 kernel of conv_halo16.hip
+    // only): the gathered tensor is the RAW output of the first convolution; the halo loader applies x * in_scale[b][c] + in_shift[b][c]
+    // (the norm folded to one FMA per element, per image and channel of the Cg gathered channels) and ReLU on channels >= in_relu_c0
+    // to every pixel inside the image (the zero padding stays zero).  nullptr: off.
+    const float *in_scale = nullptr, *in_shift = nullptr;
+    int in_relu_c0 = 0;
     int b_split;
     const float *A_g2;
     const unsigned short *Wh_g2, *Wl_g2;

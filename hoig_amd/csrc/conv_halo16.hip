@@ -43,7 +43,10 @@ struct M16Layout {
 // keeps at position chunk ^ ((row >> 2) & 3).  The step's 3 x NB x BN/32 x 2 pieces are spread over the waves and, per wave, over the
 // step's MFMA groups; they are issued for step + 1 into the other weight buffer and waited for (vmcnt(0)) before the step's closing
 // barrier.  No staging registers (24 VGPRs), no ds_write, no load two steps ahead.
-template <int NSX, int WM, int WN, int BN, bool F16, bool ASPLIT = false, bool WDMA = false>
+// NORMIN (round 5; inference only): HaloArgs::in_scale / in_shift / in_relu_c0 -- the instance norm (+ affine) and ReLU that sit between
+// the producing convolution and this one are applied HERE, to the raw tensor, when the halo image is converted (one FMA and one max per
+// element, beside the split that is there anyway): the norm's apply pass -- a read and a write of the tensor -- does not run.
+template <int NSX, int WM, int WN, int BN, bool F16, bool ASPLIT = false, bool WDMA = false, bool NORMIN = false>
 __global__ __launch_bounds__(64 * WM * WN) void conv_halo3_m16_kernel(const HaloArgs p) {
     constexpr int NS = NSX == 1 ? 1 : 2, NB = NSX == 2 ? 2 : 1;      // operand planes: pixels (activations / dy), weights
     using LY = M16Layout<WM, BN>;
@@ -164,6 +167,9 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_halo3_m16_kernel(const Halo
     };
     constexpr int HSLICES = (HPIX * 8 + NT - 1) / NT;
     float4 hreg[HSLICES];
+    float4 nsc = make_float4(1.f, 1.f, 1.f, 1.f), nsh = make_float4(0.f, 0.f, 0.f, 0.f);      // NORMIN: scale / shift of the image in hreg[]
+    bool nrelu = false;
+    unsigned hin = 0;                                      // NORMIN: bit sl = slice sl lies inside the image
     auto halo_load = [&](int cb) {
         if constexpr (ASPLIT) {
             // slice i -> (pixel i >> 3, plane (i >> 2) & 1, 16-B chunk i & 3 of the block's 32 channels)
@@ -186,6 +192,13 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_halo3_m16_kernel(const Halo
         const bool second = p.A2 != nullptr && cb * 32 >= p.cg1;
         const int ld = p.A2 ? (second ? p.Cg - p.cg1 : p.cg1) : p.Cg;
         const float *Aimg = (second ? p.A2 : gA) + (size_t)bi * p.H * p.W * ld + (second ? cb * 32 - p.cg1 : cb * 32);
+        if constexpr (NORMIN) {            // this thread's four channels of the block (slice i -> channel quad i & 7 = tid & 7: NT % 8 == 0)
+            const size_t co = (size_t)bi * p.Cg + cb * 32 + (tid & 7) * 4;
+            nsc = *reinterpret_cast<const float4 *>(p.in_scale + co);
+            nsh = *reinterpret_cast<const float4 *>(p.in_shift + co);
+            nrelu = cb * 32 + (tid & 7) * 4 >= p.in_relu_c0;
+            hin = 0;
+        }
 #pragma unroll
         for (int sl = 0; sl < HSLICES; ++sl) {
             const int i = tid + NT * sl;
@@ -194,8 +207,10 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_halo3_m16_kernel(const Halo
                 const int pix = i >> 3, c4 = i & 7;
                 const int hy = pix / HW, hx = pix - hy * HW;
                 const int gy = y0 - p.pad + hy, gx = x0 - p.pad + hx;
-                if (gy >= 0 && gy < p.H && gx >= 0 && gx < p.W)
+                if (gy >= 0 && gy < p.H && gx >= 0 && gx < p.W) {
                     v = *reinterpret_cast<const float4 *>(Aimg + ((size_t)gy * p.W + gx) * ld + c4 * 4);
+                    if constexpr (NORMIN) hin |= 1u << sl;
+                }
             }
             hreg[sl] = v;
         }
@@ -219,7 +234,15 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_halo3_m16_kernel(const Halo
             if (i < HPIX * 8) {
                 const int pix = i >> 3, c4 = i & 7;
                 uint2 hi, lo;
-                split4t<F16>(hreg[sl], hi, lo);
+                float4 v = hreg[sl];
+                if constexpr (NORMIN) {
+                    if ((hin >> sl) & 1u) {             // (the zero padding stays zero: the norm applies to the tensor, not to its frame)
+                        v.x = fmaf(v.x, nsc.x, nsh.x); v.y = fmaf(v.y, nsc.y, nsh.y);
+                        v.z = fmaf(v.z, nsc.z, nsh.z); v.w = fmaf(v.w, nsc.w, nsh.w);
+                        if (nrelu) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
+                    }
+                }
+                split4t<F16>(v, hi, lo);
                 const int off = (c4 >> 2) * P23 + pix * 32 + (c4 & 3) * 8;
                 *reinterpret_cast<uint2 *>(Ph + off) = hi;
                 if (NS == 2) *reinterpret_cast<uint2 *>(Pl + off) = lo;
@@ -648,6 +671,7 @@ int launch_one(const HaloArgs &a, hipStream_t st) {
         once.set();
     }
     if (a.a_split) {                                       // pre-split gathered tensor: bf16 data-gradient launches without x split
+        if (a.in_scale) return HOIG_EUNSUPPORTED;
         if constexpr (NS == 2) return HOIG_EUNSUPPORTED;
         else {
             if (a.f16 || a.A2) return HOIG_EUNSUPPORTED;
@@ -672,6 +696,19 @@ int launch_one(const HaloArgs &a, hipStream_t st) {
             HOIG_LAUNCH_CHECK();
             return HOIG_OK;
         }
+    }
+    if (a.in_scale) {                                      // inference chain: norm + ReLU of the gathered tensor applied in the loader
+        if (!a.f16 || a.N % BN || !a.in_shift || a.b_split > 0) return HOIG_EUNSUPPORTED;
+        static hoig_once once_n;
+        if (!once_n.done()) {
+            if (hipFuncSetAttribute(reinterpret_cast<const void *>(&conv_halo3_m16_kernel<NS, WM, WN, BN, true, false, true, true>),
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm) != hipSuccess)
+                return HOIG_ELAUNCH;
+            once_n.set();
+        }
+        conv_halo3_m16_kernel<NS, WM, WN, BN, true, false, true, true><<<a.nblk, 64 * WM * WN, shm, st>>>(a);
+        HOIG_LAUNCH_CHECK();
+        return HOIG_OK;
     }
     if (hoig_tuning(HOIG_TUNE_WDMA16) != 0 && a.N % BN == 0) {       // weight tiles by LDS-DMA (whole channel tiles only)
         static hoig_once once_d;

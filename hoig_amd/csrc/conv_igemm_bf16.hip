@@ -1110,7 +1110,7 @@ int launch_halo3(HaloArgs a, int ns, hipStream_t st) {
             a.nblk = a.Bn * a.tiles_x * a.tiles_y * a.nblk_n;
             return launch_halo3_m16(a, ns, 64, st);
         }
-        if (a.a_split || a.b_split) return HOIG_EUNSUPPORTED;  // (pre-split input, grouped launch: conv_halo16.hip only)
+        if (a.a_split || a.b_split || a.in_scale) return HOIG_EUNSUPPORTED;  // (pre-split input, grouped launch: conv_halo16.hip only)
         HOIG_NS_SWITCH(ns, return launch_halo3_one<NSX, 2, 2, 64, 0>(a, st));
     }
     if (m16 && hoig_tuning(HOIG_TUNE_FEW128) != 0 && a.H % 8 == 0 && a.nblk / 2 < 256 && a.nblk >= 192 && a.N % 128 == 0) {
@@ -1125,7 +1125,7 @@ int launch_halo3(HaloArgs a, int ns, hipStream_t st) {
         a.nblk_n = a.N / 64;
         a.nblk = a.Bn * a.tiles_x * a.tiles_y * a.nblk_n;
         if (m16) return launch_halo3_m16(a, ns, 64, st);
-        if (a.a_split || a.b_split) return HOIG_EUNSUPPORTED;
+        if (a.a_split || a.b_split || a.in_scale) return HOIG_EUNSUPPORTED;
         HOIG_NS_SWITCH(ns, return launch_halo3_one<NSX, 4, 2, 64, 2>(a, st));
     }
     // 8 x 32 pixel tiles (8 waves, weight tile shared by 256 pixels) when that still gives every CU a workgroup
@@ -1133,10 +1133,10 @@ int launch_halo3(HaloArgs a, int ns, hipStream_t st) {
         a.tiles_y = a.H / 8;
         a.nblk = a.Bn * a.tiles_x * a.tiles_y * a.nblk_n;
         if (m16) return launch_halo3_m16(a, ns, 128, st);
-        if (a.a_split || a.b_split) return HOIG_EUNSUPPORTED;
+        if (a.a_split || a.b_split || a.in_scale) return HOIG_EUNSUPPORTED;
         HOIG_NS_SWITCH(ns, return launch_halo3_one<NSX, 4, 2, 128, 2>(a, st));
     }
-    if (a.a_split || a.b_split) return HOIG_EUNSUPPORTED;
+    if (a.a_split || a.b_split || a.in_scale) return HOIG_EUNSUPPORTED;
     const bool wide = a.nblk < 384;
     HOIG_NS_SWITCH(ns, return wide ? launch_halo3_one<NSX, 2, 4, 128, 1>(a, st) : launch_halo3_one<NSX, 2, 2, 128, 0>(a, st));
     return HOIG_EINVAL;
@@ -1601,6 +1601,11 @@ int launch_dgrad_thin(const float *dy, const unsigned short *wh, const unsigned 
 }
 
 // the second problem of a grouped launch (hoig_conv2d_*_pair): same descriptor, its own tensors
+// the norm a forward launch applies to its gathered tensor (HaloArgs::in_scale ...)
+struct InNorm {
+    const float *scale, *shift;
+    int relu_c0;
+};
 struct PairSet {
     const float *a;
     const unsigned short *wh, *wl;
@@ -1610,7 +1615,11 @@ struct PairSet {
 
 int run(const hoig_conv_desc *d, const float *a, const unsigned short *wh, const unsigned short *wl, const float *bias,
         float *c, bool dgrad, hipStream_t st, const float *a2 = nullptr, int cg1 = 0, float *c2 = nullptr, int n1 = 0,
-        const float *addend = nullptr, float *stats = nullptr, bool a_split = false, const PairSet *g2 = nullptr) {
+        const float *addend = nullptr, float *stats = nullptr, bool a_split = false, const PairSet *g2 = nullptr,
+        const InNorm *in = nullptr) {
+    if (in && (dgrad || d->R != 3 || d->S != 3 || d->stride != 1 || d->pad != 1 || d->transposed || a_split || g2 ||
+               hoig_tuning(HOIG_TUNE_MFMA16) == 0))
+        return HOIG_EUNSUPPORTED;
     Args p;
     p.A = a; p.Wh = wh; p.Wl = wl; p.bias = bias; p.C = c;
     p.f16 = dgrad ? 0 : 1;                       // forward: fp16-split operands over the 2^8-scaled forward planes
@@ -1651,6 +1660,7 @@ int run(const hoig_conv_desc *d, const float *a, const unsigned short *wh, const
         h.addend = addend;
         h.stats = stats;
         h.a_split = a_split ? 1 : 0;
+        h.in_scale = in ? in->scale : nullptr; h.in_shift = in ? in->shift : nullptr; h.in_relu_c0 = in ? in->relu_c0 : 0;
         if (a_split && (d->R != 3 || a2 || !dgrad)) return HOIG_EUNSUPPORTED;
         if ((addend || stats) && c2) return HOIG_EUNSUPPORTED;
         if (stats && d->R != 3) return HOIG_EUNSUPPORTED;          // (only the 3x3 kernel has the statistics epilogue)
@@ -1671,7 +1681,7 @@ int run(const hoig_conv_desc *d, const float *a, const unsigned short *wh, const
         if (d->R == 3) return launch_halo3(h, ns, st);
         return launch_halo<5>(h, ns, st);
     }
-    if (a2 || c2 || a_split || g2) return HOIG_EUNSUPPORTED;
+    if (a2 || c2 || a_split || g2 || in) return HOIG_EUNSUPPORTED;
     // 3x3 "same" layers with too few tiles for the halo kernel above (N = 128 at 32 x 32: the data gradient of SPADE's 128 -> 1024
     // convolutions): a valid convolution over the zero-padded canvas on the flattened-axis kernel, split over the channel blocks
     if (hoig_tuning(HOIG_TUNE_FLAT5) >= 2 && !d->transposed && d->stride == 1 && d->R == 3 && d->S == 3 && d->pad == 1 &&
@@ -1809,6 +1819,17 @@ extern "C" int hoig_conv2d_cat_fwd_packed_stats(const hoig_conv_desc *d, const f
     if (!d || !x1 || !x2 || !w_hi || !y || !stats) return HOIG_EINVAL;
     if (!is_16bit_precision(d->precision)) return HOIG_EINVAL;
     return run(d, x1, w_hi, w_lo, bias, y, false, (hipStream_t)stream, x2, C1, nullptr, 0, nullptr, stats);
+}
+
+// forward of conv -> instance norm (+ affine) -> ReLU -> THIS 3x3 stride-1 convolution in INFERENCE: x (and x2) are RAW, the loader
+// applies x * in_scale + in_shift per (image, gathered channel) and ReLU on channels >= in_relu_c0 (include/hoig_kernels.h)
+extern "C" int hoig_conv2d_fwd_packed_normin(const hoig_conv_desc *d, const float *x, int C1, const float *x2, const uint16_t *w_hi,
+                                             const uint16_t *w_lo, const float *bias, const float *in_scale, const float *in_shift,
+                                             int in_relu_c0, float *y, float *stats, hoig_stream_t stream) {
+    if (!d || !x || !w_hi || !y || !in_scale || !in_shift || in_relu_c0 < 0) return HOIG_EINVAL;
+    if (!is_16bit_precision(d->precision)) return HOIG_EINVAL;
+    const InNorm in{in_scale, in_shift, in_relu_c0};
+    return run(d, x, w_hi, w_lo, bias, y, false, (hipStream_t)stream, x2, x2 ? C1 : 0, nullptr, 0, nullptr, stats, false, nullptr, &in);
 }
 
 // dx = data gradient + addend (HOIG_EUNSUPPORTED where the layer's kernel has no such epilogue: the caller adds separately)

@@ -347,6 +347,9 @@ __global__ __launch_bounds__(TNT) void inorm_tile_fwd_kernel(const float *__rest
     }
 }
 
+// GB (round 5, off the default path): the [dgamma | dbeta] stores as split planes and their column sums -- a template flag, not a run-time
+// one: the eight registers of the two extra sums cost every launch of the plain form 11 us (31 -> 42 us) when they were unconditional
+template <bool GB>
 __global__ __launch_bounds__(TNT) void inorm_tile_bwd_kernel(const float *__restrict__ x, const float *__restrict__ mean,
                                                              const float *__restrict__ rstd, int mode,
                                                              const float *__restrict__ p0, const float *__restrict__ p1,
@@ -396,15 +399,17 @@ __global__ __launch_bounds__(TNT) void inorm_tile_bwd_kernel(const float *__rest
         if (mode == 2) {                    // dgamma = g*xhat, dbeta = g (per pixel); then g' = g * (1 + gamma)
             const size_t po = ((size_t)b * HW + r) * ldp + c;
             const float4 dga = make_float4(gg.x * hh.x, gg.y * hh.y, gg.z * hh.z, gg.w * hh.w);
-            if (split & 2) {                // [gamma | beta] of width ldp = 2C as ONE split tensor (dp1 == dp0 + C: checked by the launcher)
+            if (GB && (split & 2)) {        // [gamma | beta] of width ldp = 2C as ONE split tensor (dp1 == dp0 + C: checked by the launcher)
                 store_split(dp0, (int64_t)b * HW + r, ldp, c, dga);
                 store_split(dp0, (int64_t)b * HW + r, ldp, C + c, gg);
             } else {
                 *reinterpret_cast<float4 *>(dp0 + po) = dga;
                 *reinterpret_cast<float4 *>(dp1 + po) = gg;
             }
-            cs1.x += gg.x; cs1.y += gg.y; cs1.z += gg.z; cs1.w += gg.w;
-            cs2.x += dga.x; cs2.y += dga.y; cs2.z += dga.z; cs2.w += dga.w;
+            if constexpr (GB) {
+                cs1.x += gg.x; cs1.y += gg.y; cs1.z += gg.z; cs1.w += gg.w;
+                cs2.x += dga.x; cs2.y += dga.y; cs2.z += dga.z; cs2.w += dga.w;
+            }
             const float4 ga = *reinterpret_cast<const float4 *>(p0 + po);
             gg.x *= 1.f + ga.x; gg.y *= 1.f + ga.y; gg.z *= 1.f + ga.z; gg.w *= 1.f + ga.w;
         }
@@ -415,7 +420,7 @@ __global__ __launch_bounds__(TNT) void inorm_tile_bwd_kernel(const float *__rest
     }
     s1 = tile_reduce(s1, red, cq, pl);
     s2 = tile_reduce(s2, red, cq, pl);
-    if (mode == 2 && dp_colsum) {           // the bias gradient of the convolution that made [gamma | beta]: its dy is written here
+    if (GB && mode == 2 && dp_colsum) {     // the bias gradient of the convolution that made [gamma | beta]: its dy is written here
         cs1 = tile_reduce(cs1, red, cq, pl);
         cs2 = tile_reduce(cs2, red, cq, pl);
         if (pl == 0) {
@@ -540,6 +545,27 @@ extern "C" int hoig_inorm_bwd_ld(const float *x, const float *mean, const float 
     return hoig_inorm_bwd_add_ld(x, mean, rstd, mode, p0, p1, ld_p, y, dy, act, slope, nullptr, dx, dp0, dp1, B, HW, C, workspace,
                                  stream);
 }
+// The norm as ONE FMA per element (for a consumer that applies it while it loads: hoig_conv2d_fwd_packed_normin):
+// scale[b][c] = rstd * gamma, shift[b][c] = beta - mean * scale, written with row stride ld_out (the consumer's gathered channel count)
+__global__ void inorm_fold_kernel(const float *__restrict__ mean, const float *__restrict__ rstd, const float *__restrict__ gamma,
+                                  const float *__restrict__ beta, int C, int total, float *__restrict__ scale, float *__restrict__ shift,
+                                  int ld_out) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= total) return;
+    const int b = i / C, c = i - b * C;
+    const float sc = rstd[i] * (gamma ? gamma[c] : 1.f);
+    scale[(size_t)b * ld_out + c] = sc;
+    shift[(size_t)b * ld_out + c] = (beta ? beta[c] : 0.f) - mean[i] * sc;
+}
+extern "C" int hoig_inorm_fold(const float *mean, const float *rstd, const float *gamma, const float *beta, int B, int C, float *scale,
+                               float *shift, int ld_out, hoig_stream_t stream) {
+    if (!mean || !rstd || !scale || !shift || B <= 0 || C <= 0 || ld_out < C) return HOIG_EINVAL;
+    const int total = B * C;
+    inorm_fold_kernel<<<(total + 255) / 256, 256, 0, (hipStream_t)stream>>>(mean, rstd, gamma, beta, C, total, scale, shift, ld_out);
+    HOIG_LAUNCH_CHECK();
+    return HOIG_OK;
+}
+
 extern "C" int hoig_inorm_bwd(const float *x, const float *mean, const float *rstd, int mode, const float *p0,
                               const float *p1, const float *y, const float *dy, int act, float slope, float *dx, float *dp0,
                               float *dp1, int B, int HW, int C, void *workspace, hoig_stream_t stream) {
@@ -658,8 +684,12 @@ static int inorm_bwd_fused_any(const float *x, const float *mean, const float *r
         return HOIG_EINVAL;
     if (mode != 0 && !p0) return HOIG_EINVAL;
     if (!tile_ok(B, HW, C)) return HOIG_EUNSUPPORTED;
-    inorm_tile_bwd_kernel<<<dim3(C / TCG, B), TNT, 0, (hipStream_t)stream>>>(x, mean, rstd, mode, p0, p1, ld_p, y, dy, act, slope,
-                                                                             dx, dp0, dp1, HW, C, addend, split, dp_colsum);
+    if ((split & 2) || dp_colsum)
+        inorm_tile_bwd_kernel<true><<<dim3(C / TCG, B), TNT, 0, (hipStream_t)stream>>>(x, mean, rstd, mode, p0, p1, ld_p, y, dy, act,
+                                                                                       slope, dx, dp0, dp1, HW, C, addend, split, dp_colsum);
+    else
+        inorm_tile_bwd_kernel<false><<<dim3(C / TCG, B), TNT, 0, (hipStream_t)stream>>>(x, mean, rstd, mode, p0, p1, ld_p, y, dy, act,
+                                                                                        slope, dx, dp0, dp1, HW, C, addend, split, nullptr);
     HOIG_LAUNCH_CHECK();
     return HOIG_OK;
 }

@@ -26,6 +26,7 @@ Entry g_table[HOIG_TUNE_COUNT] = {
     {"pad_in", 1},
     {"wdma16", 2},
     {"s2_pipe", 1},
+    {"norm_in", 1},
 };
 }  // namespace
 

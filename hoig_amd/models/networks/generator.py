@@ -118,6 +118,14 @@ class Generator(ParamTree):
         return self._in(h, name + '.1', act=ACT_RELU)
 
     def _resblock(self, x, name):                                          # generator.py:9-32
+        if not torch.is_grad_enabled():
+            # inference: the first norm + ReLU are applied by the second convolution's loader (ops.conv2d_after_norm)
+            h = self._conv(x, name + '.main.0', to_norm=True)
+            y = ops.conv2d_after_norm(h, self.P[name + '.main.1.weight'], self.P[name + '.main.1.bias'], self.P[name + '.main.3.weight'],
+                                      self.P.get(name + '.main.3.bias'), norm_next=True)
+            if y is None:
+                y = self._conv(self._in(h, name + '.main.1', act=ACT_RELU), name + '.main.3', to_norm=True)
+            return self._in(y, name + '.main.4', residual=x)
         # (x has two readers, the first conv and the skip: conv2d_fork routes the skip's gradient through the conv's backward)
         h, x = self._conv_fork(x, name + '.main.0')
         h = self._in(h, name + '.main.1', act=ACT_RELU)
@@ -228,12 +236,21 @@ class Generator(ParamTree):
 
     def _decode_level(self, x, enc, seg, p, i):                            # generator.py:298-309
         nd = self.cfg.n_down
+        name = p + '.skippers.%d' % i
         if self.cfg.spade_layers[3]:
             x = self._spade_block(x, seg, p + '.decoders.%d' % i, False)
+        elif not torch.is_grad_enabled() and self.P.get(name + '.0.bias') is None:
+            # inference: the up-sampled operand stays raw; its norm + ReLU are applied by the skip convolution's loader
+            dn = p + '.decoders.%d' % i
+            xr = self._convT(x, dn + '.0')
+            y = ops.conv2d_after_norm(xr, self.P[dn + '.1.weight'], self.P[dn + '.1.bias'], self.P[name + '.0.weight'], None,
+                                      first=enc[nd - 1 - i], norm_next=True)
+            if y is not None:
+                return self._in(y, name + '.1', act=ACT_RELU)
+            x = self._in(xr, dn + '.1', act=ACT_RELU)
         else:
             x = self._conv_in_relu(x, p + '.decoders.%d' % i, transposed=True)
         # cat[skip, up] -> conv3x3 -> IN -> ReLU: the convolution reads the two tensors directly (ops.conv2d_cat2)
-        name = p + '.skippers.%d' % i
         if self.P.get(name + '.0.bias') is None:
             return self._in(ops.conv2d_cat2(enc[nd - 1 - i], x, self.P[name + '.0.weight'], norm_next=True), name + '.1', act=ACT_RELU)
         return self._conv_in_relu(ops.cat_channels([enc[nd - 1 - i], x]), name)

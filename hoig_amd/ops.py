@@ -856,6 +856,54 @@ def conv2d_cat2(x1, x2, w, prec=None, norm_next=False):
     return _ConvCat2.apply(x1, x2, w, prec, norm_next)
 
 
+def conv2d_after_norm(xraw, gamma, beta, w, b=None, first=None, norm_next=False, eps=1e-5):
+    """INFERENCE only (no autograd): conv3x3_s1_p1(cat[first, relu(IN(xraw) * gamma + beta)], w) + b WITHOUT the norm's pass over the
+    tensor -- the second convolution's halo loader applies the norm, folded to one FMA per element, and the ReLU while it converts the
+    raw tensor for the MFMAs (hoig_conv2d_fwd_packed_normin; the reference chains generator.py:16-22 and :298-309).  The statistics
+    are the ones the producing convolution left in the stream's accumulators where it could (_conv_fwd_raw), else one read of xraw.
+    `first` (optional) = an already-activated tensor that precedes xraw along the channels (the decoder's skip operand).
+    -> y, or None where the layer is not on that kernel (the caller then normalises in a pass of its own, as in training)."""
+    assert not torch.is_grad_enabled(), 'conv2d_after_norm has no backward'
+    _chk(xraw, 'x'); _chk(w, 'w')
+    B, H, W_, C = xraw.shape
+    HW = H * W_
+    C1 = first.shape[-1] if first is not None else 0
+    Co = w.shape[0]
+    if (precision in (L.PREC_F32, L.PREC_F16F6) or tuple(w.shape[2:]) != (3, 3) or w.shape[1] != C1 + C or C % 32 or C1 % 32 or Co % 64
+            or W_ % 32 or H % 8 or not xraw.is_contiguous() or (first is not None and (not first.is_contiguous() or first.shape[:3] != xraw.shape[:3]))
+            or not L.lib.hoig_set_tuning(b'norm_in', -1)):
+        _stats_drop(xraw)
+        return None
+    dev = xraw.device
+    mean = torch.empty(B * C, dtype=torch.float32, device=dev)
+    rstd = torch.empty_like(mean)
+    ws, have = _norm_workspace(L.lib.hoig_inorm_workspace_bytes(B, HW, C) // 4, dev, take=(xraw.data_ptr(), B, HW, C))
+    if have:
+        call('hoig_inorm_stats_from_sums', B, HW, C, eps, _p(mean), _p(rstd), _p(ws), _st())
+    else:
+        call('hoig_inorm_stats', _p(xraw), B, HW, C, eps, _p(mean), _p(rstd), _p(ws), _st())
+    Cg = C1 + C
+    fold = torch.empty(2, B, Cg, dtype=torch.float32, device=dev)
+    if C1:
+        fold[0, :, :C1] = 1.0
+        fold[1, :, :C1] = 0.0
+    call('hoig_inorm_fold', _p(mean), _p(rstd), _p(gamma), _p(beta), B, C, fold.data_ptr() + 4 * C1, fold.data_ptr() + 4 * (B * Cg + C1), Cg,
+         _st())
+    y = torch.empty((B, H, W_, Co), dtype=xraw.dtype, device=dev)
+    d = ConvDesc(B, H, W_, Cg, H, W_, Co, 3, 3, 1, 1, 0, L.ACT_NONE, 0.0, precision)
+    hi, lo = _packed_planes(w, False, False)
+    sws = _conv_stats_workspace(y) if norm_next else None
+    a, a2 = (first, xraw) if first is not None else (xraw, None)
+    rc = L.lib.hoig_conv2d_fwd_packed_normin(ctypes.byref(d), _p(a), C1, _p(a2), _p(hi), _p(lo), _p(b), fold.data_ptr(),
+                                             fold.data_ptr() + 4 * B * Cg, C1, _p(y), _p(sws), _st())
+    if rc == L.EUNSUPPORTED:
+        return None
+    L.check(rc, 'hoig_conv2d_fwd_packed_normin')
+    if sws is not None:
+        _stats_offer(y)
+    return y
+
+
 class _ConvHeads(Function):
     """The generator's image / mask heads over ONE feature map as one 7x7 convolution with a per-channel activation
     (generator.py:311-315: img_reg -> tanh, attetion_reg_hand -> sigmoid, and the x half of attetion_reg_bg, whose sigmoid
@@ -970,6 +1018,14 @@ def _conv_stats_workspace(y):
     if H * W_ <= 1024 or C % 4 or B * 2 * C > (1 << 18):        # (1 << 18: the accumulator pool, norm.hip ACC_POOL)
         return None
     return _norm_workspace(L.lib.hoig_inorm_workspace_bytes(B, H * W_, C) // 4, y.device)
+
+
+def _stats_drop(x):
+    """Nobody will take the sums the producer of `x` left in the accumulators: clear them now (_norm_workspace does when asked)."""
+    key = (x.device, torch.cuda.current_stream(x.device).cuda_stream)
+    pend = _stats_pending.get(key)
+    if pend is not None and pend[0] == x.data_ptr():
+        _norm_workspace(1, x.device)
 
 
 def _stats_offer(y):

@@ -101,6 +101,20 @@ int hoig_inorm_bwd_fused_add_planes(const float *x, const float *mean, const flo
                                     int ld_p, const float *y, const float *dy, int act, float slope, const float *addend /*nullable*/,
                                     void *dx, void *dp0, void *dp1, float *dp_colsum /*nullable*/, int planes, int B, int HW, int C,
                                     hoig_stream_t stream);
+/* ---- INFERENCE: the norm between two convolutions applied by the second one's loader (VERDICT r1-r4 "consumer half of the norm
+ *      fusion"; the reference chains generator.py:16-22 (ResidualBlock: conv - IN - ReLU - conv) and :298-309 (decoder level: ConvTranspose
+ *      - IN - ReLU - cat - conv)).  hoig_inorm_fold turns the statistics of the RAW tensor (hoig_inorm_stats / _stats_from_sums) and the
+ *      affine parameters (nullable) into one FMA per element: scale[b][c] = rstd * gamma, shift[b][c] = beta - mean * scale, rows of
+ *      ld_out floats.  hoig_conv2d_fwd_packed_normin is hoig_conv2d_fwd_packed / hoig_conv2d_cat_fwd_packed(_stats) (x2 nullable: the
+ *      gathered tensor is [x | x2] with C1 channels in x) for stride-1 "same" 3x3 layers on the 8-row tilings of the 16x16x32 kernel:
+ *      every in-image element of the gathered tensor becomes x * in_scale[b][c] + in_shift[b][c] (c over all Ci gathered channels), then
+ *      max(., 0) for c >= in_relu_c0, before it is split for the MFMAs; the zero padding stays zero.  No backward: forward-only launches
+ *      (torch.no_grad()).  HOIG_EUNSUPPORTED where that kernel cannot run the layer (the caller then normalises in a pass of its own). */
+int hoig_inorm_fold(const float *mean, const float *rstd, const float *gamma /*nullable*/, const float *beta /*nullable*/, int B, int C,
+                    float *scale, float *shift, int ld_out, hoig_stream_t stream);
+int hoig_conv2d_fwd_packed_normin(const hoig_conv_desc *d, const float *x, int C1, const float *x2 /*nullable*/, const uint16_t *w_hi,
+                                  const uint16_t *w_lo, const float *bias /*nullable*/, const float *in_scale, const float *in_shift,
+                                  int in_relu_c0, float *y, float *stats /*nullable*/, hoig_stream_t stream);
 int hoig_conv2d_bwd_weight_split(const hoig_conv_desc *d, const float *x, const uint16_t *dy_split, float *dw, hoig_stream_t stream);
 /* dx = data gradient (+ addend when non-null: hoig_conv2d_bwd_data_packed_add) of a stride-1 "same" 3x3 Conv2d from pre-split dy, on the
  * 8-row tilings of the v_mfma_f32_16x16x32 kernel (Hi % 8 == 0, Wi % 32 == 0 and enough tiles: HOIG_EUNSUPPORTED otherwise -- the
@@ -517,6 +531,10 @@ const char *hoig_version(void);
  *                MFMAs, weight tiles by LDS-DMA) where it measured faster: 8 x 32 tiles with eight waves wherever that leaves every CU
  *                a workgroup and N % 128 == 0 (12-24 %: 132 -> 100 us on 16 x 64x64 256 -> 512), 4 x 32 tiles for grids of at most one
  *                workgroup per CU (15-30 %); 2 / 3: the 4-row / 8-row form wherever it can run; 0: never.  profiles/r05_s2_dma_ab.txt
+ *   "norm_in"  1  (read by the host side, hoig_amd/ops.py conv2d_after_norm) INFERENCE forwards apply the norm + ReLU of a single-reader
+ *                conv - IN - ReLU - conv3x3 chain in the second convolution's loader (hoig_conv2d_fwd_packed_normin); 0: every norm is a
+ *                pass of its own.  Batch-32 generator forward 2.511 -> 2.494 ms per image (the flagship's SPADE norms modulate per
+ *                pixel and stay passes)
  *   "wgrad_ko" 0  diagnostic instantiations of wgrad_dma_kernel (tools/ab_conv.py; results are WRONG with any bit set)
  *   "split_grads" 1  (read by the host side, hoig_amd/ops.py) the backward of a norm that follows an eligible 3x3 convolution writes its
  *                dx as bf16 hi | lo planes and that convolution's weight / data gradient read them without splitting ('PRE-SPLIT

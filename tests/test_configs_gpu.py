@@ -232,3 +232,25 @@ def sys_path_tools():
     p = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), 'tools')
     if p not in sys.path:
         sys.path.insert(0, p)
+
+
+def test_eval_forward_with_and_without_the_loader_norm():
+    """eval.py's forward (no_grad) with the single-reader IN -> ReLU -> conv3x3 chains fused into the consumer's loader (tuning key
+    `norm_in`, default on; ops.conv2d_after_norm) against the same forward with every norm as a pass of its own: every output within
+    1e-4 (a re-association of fp32 operations inside the 3-term arithmetic), and the fused forward launches fewer norm kernels."""
+    from hoig_amd import _lib as L
+    m = product_trainer('generator_spade_attn', 4, 256)
+    m.set_eval()
+    outs = {}
+    prev = L.set_tuning('norm_in', -1)
+    try:
+        for v in (0, 1):
+            L.set_tuning('norm_in', v)
+            with torch.no_grad():
+                outs[v] = [o.clone() for o in m.forward()]
+            torch.cuda.synchronize()
+    finally:
+        L.set_tuning('norm_in', prev)
+    for a, b in zip(outs[1], outs[0]):
+        assert torch.isfinite(a).all()
+        assert rel_err(a, b) < 1e-4

@@ -354,3 +354,59 @@ def test_stride2_statically_walked_kernel_is_bit_identical(B, Ci, Co, H, transpo
     finally:
         L.set_tuning('s2_pipe', prev)
         ops.set_precision('f32')
+
+
+@pytest.mark.parametrize('case', ['resblock_32', 'resblock_64', 'decoder_cat'])
+def test_inference_norm_applied_by_the_consumers_loader(case):
+    """ops.conv2d_after_norm (hoig_conv2d_fwd_packed_normin): conv3x3(relu(IN(x) * gamma + beta)) with the norm folded into the halo
+    loader, against the same chain with the norm as a pass of its own -- same arithmetic up to the association of the fold (one FMA
+    instead of subtract / multiply / FMA): 2e-5 of the output's scale; the zero frame of the padding must stay zero (the border pixels
+    are where a norm applied to the frame would show).  'decoder_cat': the skip operand precedes x along the channels and is read as
+    it is (generator.py:298-309)."""
+    from hoig_amd import _lib as L, ops
+    ops.set_precision('bf16x3:f16x2')
+    try:
+        g = torch.Generator(device='cuda').manual_seed(21)
+        if case == 'decoder_cat':
+            B, H, W, C1, C, Co = 8, 64, 64, 128, 128, 128
+        elif case == 'resblock_64':
+            B, H, W, C1, C, Co = 4, 64, 64, 0, 256, 256
+        else:
+            B, H, W, C1, C, Co = 16, 32, 32, 0, 128, 256
+        x = torch.randn(B, H, W, C, device='cuda', generator=g) * 2.0 + 0.7           # (a mean and a spread for the norm to remove)
+        first = torch.randn(B, H, W, C1, device='cuda', generator=g).relu() if C1 else None
+        gamma = torch.rand(C, device='cuda', generator=g) + 0.5
+        beta = torch.randn(C, device='cuda', generator=g) * 0.3
+        w = ops.pack_weight(torch.randn(Co, C1 + C, 3, 3, device='cuda', generator=g) * 0.05)
+        bias = torch.randn(Co, device='cuda', generator=g) if case != 'decoder_cat' else None
+        with torch.no_grad():
+            y = ops.conv2d_after_norm(x, gamma, beta, w, bias, first=first, norm_next=False)
+            assert y is not None, 'the layer should be on the 8-row tilings of the 16x16x32 kernel'
+            xn = ops.instance_norm(x, gamma, beta, act=L.ACT_RELU)
+            if first is not None:
+                want = ops.conv2d_cat2(first, xn, w)
+            else:
+                want = ops.conv2d(xn, w, bias, 1, 1)
+        torch.cuda.synchronize()
+        scale = want.abs().max().item()
+        assert (y - want).abs().max().item() <= 2e-5 * scale, (y - want).abs().max().item() / scale
+        border = torch.ones(H, W, dtype=torch.bool, device='cuda')
+        border[1:-1, 1:-1] = False
+        assert (y[:, border] - want[:, border]).abs().max().item() <= 2e-5 * scale
+        # and against torch, in fp64
+        xr = torch.nn.functional.instance_norm(x.permute(0, 3, 1, 2).double(), weight=gamma.double(), bias=beta.double(), eps=1e-5).relu()
+        if first is not None:
+            xr = torch.cat([first.permute(0, 3, 1, 2).double(), xr], 1)
+        wd = w.double()                                                                # (packed = logical values, other strides)
+        ref = F.conv2d(xr, wd, bias.double() if bias is not None else None, padding=1).permute(0, 2, 3, 1)
+        assert rel_err(y.double(), ref) < 3e-4
+        # statistics already left by a producing convolution are taken from the accumulators, not recomputed: same result
+        with torch.no_grad():
+            src = torch.randn(B, H, W, 64, device='cuda', generator=g)
+            w0 = ops.pack_weight(torch.randn(C, 64, 3, 3, device='cuda', generator=g) * 0.1)
+            raw = ops.conv2d(src, w0, None, 1, 1, dead_bias=True)                     # (offers its sums on maps of > 1024 pixels)
+            y1 = ops.conv2d_after_norm(raw, gamma, beta, w, bias, first=first)
+            y2 = ops.conv2d_after_norm(raw.clone(), gamma, beta, w, bias, first=first)   # (a copy: nobody offered sums for it)
+        assert (y1 - y2).abs().max().item() <= 2e-5 * y2.abs().max().item()
+    finally:
+        ops.set_precision('f32')
