@@ -30,11 +30,13 @@ def _precision():
     ops._TEST_DELAYS.clear()
 
 
-def _run(side, batch, delays=None, single_stream=False, graph=False, steps=2, mutate=None):
-    """-> per step: (losses, G's first Adam moment, D's, the two networks), from the seeded state."""
+def _run(side, batch, delays=None, single_stream=False, graph=False, steps=2, mutate=None, queues=None):
+    """-> per step: (losses, G's first Adam moment, D's, the two networks), from the seeded state.  queues: {role: hardware-queue class}
+    overrides for the streams this run's Trainer creates."""
     from hoig_amd import ops
     from hoig_amd.models.networks import generator as G
-    fork, wside = G._FORK_STREAMS, ops._WGRAD_SIDE
+    fork, wside, qmap = G._FORK_STREAMS, ops._WGRAD_SIDE, dict(ops._QUEUE_OF_ROLE)
+    ops._QUEUE_OF_ROLE.update(queues or {})
     ops._TEST_DELAYS.clear()
     ops._TEST_DELAYS.update(delays or {})
     if single_stream:
@@ -54,6 +56,8 @@ def _run(side, batch, delays=None, single_stream=False, graph=False, steps=2, mu
         return out
     finally:
         G._FORK_STREAMS, ops._WGRAD_SIDE = fork, wside
+        ops._QUEUE_OF_ROLE.clear()
+        ops._QUEUE_OF_ROLE.update(qmap)
         ops._TEST_DELAYS.clear()
 
 
@@ -116,47 +120,31 @@ def test_delayed_role_captured_graph(role, reference_128):
 
 
 def test_the_detector_sees_an_optimiser_that_does_not_wait(reference_128):
-    """Negative control: take away the optimiser side stream's wait for the caller's stream (Trainer._step).  Adam then starts
-    while the backward is still running, reads gradients that are not all there, and the check must FAIL on the first step --
-    with a whole tensor's moment missing, not at the noise level.
+    """Negative control, deterministic: take away the optimiser side stream's wait for the caller's stream
+    (Trainer._step), hold the WEIGHT-GRADIENT side stream back by four step times where its first launch of the backward goes out, and
+    give the optimiser's stream a hardware-queue class of its own (class 0, which no role of the step uses: streams of one class
+    execute in order, so a class mate stalled behind the delay would hold Adam back and hide the missing wait -- that was the
+    queue luck the earlier form of this control depended on).  Adam then runs while every weight gradient is still waiting, reads a
+    zeroed buffer, and the check must FAIL on the first step with whole tensors' moments missing -- asserted on one named tensor, the
+    first residual block of tsf_model, not on "some tensor somewhere".
 
-    (Neither of the two ordering bugs of the earlier rounds can serve as the control any more.  The missing join of the backward's
-    branch streams: measured here (profiles/r04_diag_join.txt), the caller's stream is ordered behind the branch streams after
-    `backward()` even with Trainer._join_backward_streams removed -- the flat parameters are autograd leaves, their (no-op)
-    AccumulateGrad nodes run on the stream of their branch, and the engine joins the caller's stream with every such leaf stream
-    when the backward ends; the explicit join stays, a captured step relies on it.  A reader that does not wait for the
-    optimiser reads weights that are ONE step old: 2e-4 per element, numerically invisible next to this GAN's run-to-run
-    spread -- timing tests cannot see that class, which is why the per-stream PendingUpdate bookkeeping is unit-tested on its
-    own: tests/test_graph_gpu.py::test_readers_wait_for_a_delayed_optimiser_side_stream.)"""
+    (Neither of the two ordering bugs of the earlier rounds can serve as the control any more: the caller's stream is ordered behind
+    the branch streams after `backward()` even without Trainer._join_backward_streams (profiles/r04_diag_join.txt), and a reader that
+    does not wait for the optimiser reads weights that are ONE step old -- numerically invisible; that class is covered by
+    tests/test_graph_gpu.py::test_readers_wait_for_a_delayed_optimiser_side_stream.)"""
     def mutate(m):
         m._side.wait_stream = lambda stream: None
-    # (at 128 x 128, batch 2 the step is host-bound: the device has long finished the backward when the host issues Adam, so the
-    # missing wait alone changes nothing -- the bg branch is delayed as in the tests above, four times as long: the first step of a
-    # trainer spends tens of milliseconds of host time in lazy initialisation.
-    # Whether the unordered Adam then really RUNS early is up to the hardware queues: streams that share one execute in order, the
-    # runtime binds a stream to its queue when the stream is first used, and a stalled branch stalls its queue mates -- measured
-    # (tools/diag_dearly.py, profiles/r04_d_early_ab.txt): with the D step issued after G's backward the mutated Adam reads a
-    # zero gradient for whole tensors of tsf_model; with the D step issued before it (tuning key d_early, the default) the same
-    # mutation is hidden in a cold process and visible in a warm one, and any change of the order in which the step first uses its
-    # streams flips it again.  The control therefore walks through both orders and two delayed branches until the stale read
-    # shows: what it proves is that the CHECK sees a stale read, not that every missing wait produces one.)
-    from hoig_amd import _lib as L
-    prev = L.set_tuning('d_early', -1)
-    seen = []
-    try:
-        for d_early, role in ((0, 'g_bg'), (1, 'g_bg'), (0, 'g_src'), (1, 'g_src')):
-            L.set_tuning('d_early', d_early)
-            run = _run(128, 2, {role: 4 * DELAY}, mutate=mutate, steps=1)
-            (_, mg, _, net_g, _), (_, mgr, _, _, _) = run[0], reference_128[0]
-            worst = _worst(net_g, mg, mgr)
-            seen.append((d_early, role) + worst)
-            if worst[0] > 0.5:           # (whole tensors missing: Adam read the buffer before their weight gradients ran)
-                break
-    finally:
-        L.set_tuning('d_early', prev)
-    assert worst[0] > 0.5, seen
+    run = _run(128, 2, {'wgrad': 4 * DELAY}, mutate=mutate, steps=1, queues={'opt': 0})
+    (_, mg, _, net_g, _), (_, mgr, _, _, _) = run[0], reference_128[0]
+    got, want = net_g.export_dict(mg), net_g.export_dict(mgr)
+    name = next(k for k in want if k.startswith('tsf_model.') and k.endswith('.weight') and want[k].dim() == 4)
+    rel = float((got[name] - want[name]).norm() / want[name].norm())
+    assert rel > 0.5, (name, rel)              # (its weight gradient had not run when Adam read the buffer)
+    assert _worst(net_g, mg, mgr)[0] > 0.5
     with pytest.raises(AssertionError):
         _compare(run, reference_128, 'optimiser without its wait', steps=1)
+    # and the same delay and queue placement WITH the wait: the step is right (the wait is what orders Adam, not the queues)
+    _compare(_run(128, 2, {'wgrad': 4 * DELAY}, steps=1, queues={'opt': 0}), reference_128, 'wgrad late, optimiser on its own queue', steps=1)
 
 
 def test_delayed_roles_at_the_bench_size():
