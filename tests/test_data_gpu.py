@@ -72,6 +72,8 @@ def test_loader_batches_match_the_oracle(tmp_path):
     oracle = {}
     # worker processes are FORKED: after the large-batch tests of a session the caching allocator holds tens of GB of mapped device
     # memory, and forking that address space took ~20 s per worker (50 s of this test in the full suite, 3 s alone)
+    import gc
+    gc.collect()                 # (Trainers of earlier tests sit in reference cycles until the collector runs; their tensors pin the cache)
     torch.cuda.empty_cache()
     for workers in (0, 2):
         opt.n_threads_train = workers
