@@ -12,7 +12,7 @@ def pytest_configure(config):
     global _config
     _config = config
     config.addinivalue_line('markers', 'gpu: needs a real MI355X (run with -m gpu on the GPU box)')
-    config.addinivalue_line('markers', 'gpu_slow: GPU tests of the OPT-IN f16f6 forward arithmetic (duplicates of default-arithmetic tests): '
+    config.addinivalue_line('markers', 'gpu_slow: GPU tests of the OPT-IN f16f6 forward arithmetic and other duplicates of default tests: '
                                        'skipped under plain `-m gpu`, run with `-m "gpu or gpu_slow"` or HOIG_GPU_SLOW=1')
 
 
@@ -28,7 +28,7 @@ def want_gpu_slow(config=None):
 def pytest_collection_modifyitems(config, items):
     import torch
     if not want_gpu_slow(config):          # (keeps the driver's `-m gpu` run inside its time limit: VERDICT r4 item 9)
-        opt_in = pytest.mark.skip(reason='opt-in arithmetic (f16f6): run with -m "gpu or gpu_slow" or HOIG_GPU_SLOW=1')
+        opt_in = pytest.mark.skip(reason='opt-in duplicate (f16f6 arithmetic, extra roles): run with -m "gpu or gpu_slow" or HOIG_GPU_SLOW=1')
         for item in items:
             if 'gpu_slow' in item.keywords:
                 item.add_marker(opt_in)

@@ -48,7 +48,8 @@ def test_config5_eval_forward_b32_hipgraph_replay():
     of that sample."""
     from hoig_amd import synthetic
     B, S = 32, 256
-    m = product_trainer('generator_spade_attn', B, S)
+    first = synthetic.make_inputs(B, S, seed=SEEDS['inputs'])
+    m = product_trainer('generator_spade_attn', B, S, inputs=first)
     m.set_eval()
     with torch.no_grad():
         eager = [o.clone() for o in m.forward()]
@@ -71,7 +72,11 @@ def test_config5_eval_forward_b32_hipgraph_replay():
     assert rel_err(torch.cat([r1[4][:1], r1[4][B:B + 1]]), want[4]) < TOL        # masks: src then tsf along the batch
     assert rel_err(torch.cat([r1[5][:1], r1[5][B:B + 1]]), want[5]) < TOL
     # the graph reads the staged input buffers: overwrite them in place with another batch and replay
-    other = synthetic.make_inputs(B, S, seed=SEEDS['inputs'] + 1)
+    # (another batch: the samples of this one rotated by one place along the batch -- every static buffer changes; generating 32 new
+    # synthetic samples on the host took 10 s of this test)
+    full = first['real_src'].shape[0]
+    other = {k: (torch.cat([torch.roll(v[:full], 1, 0), torch.roll(v[full:], 1, 0)], 0) if torch.is_tensor(v) and v.shape[0] == 2 * full
+                 else (torch.roll(v, 1, 0) if torch.is_tensor(v) else v)) for k, v in first.items()}
     with torch.no_grad():
         staged = dict(m._n)
         m.set_input(other)                       # allocates new buffers ...
