@@ -75,7 +75,7 @@ def test_loader_batches_match_the_oracle(tmp_path):
     import gc
     gc.collect()                 # (Trainers of earlier tests sit in reference cycles until the collector runs; their tensors pin the cache)
     torch.cuda.empty_cache()
-    for workers in (0, 2):
+    for workers in (0, 1):                      # (one forked worker: every fork of this process costs ~20 s late in a session)
         opt.n_threads_train = workers
         loader = CustomDatasetDataLoader(opt, is_for_train=True)
         assert len(loader) == 3
