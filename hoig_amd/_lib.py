@@ -85,7 +85,6 @@ _SIGS = {
     'hoig_inorm_bwd_fused_add_split': [_vp, _vp, _vp, _i, _vp, _vp, _i, _vp, _vp, _i, _f, _vp, _vp, _vp, _vp, _i, _i, _i, _vp],
     'hoig_inorm_fold': [_vp, _vp, _vp, _vp, _i, _i, _vp, _vp, _i, _vp],
     'hoig_conv2d_fwd_packed_normin': [_vp, _vp, _i, _vp, _vp, _vp, _vp, _vp, _vp, _i, _vp, _vp, _vp],
-    'hoig_inorm_bwd_fused_add_planes': [_vp, _vp, _vp, _i, _vp, _vp, _i, _vp, _vp, _i, _f, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp],
     'hoig_unsplit_planes_bf16': [_vp, _vp, _i64, _i, _vp],
     'hoig_inorm_bwd_fused_add': [_vp, _vp, _vp, _i, _vp, _vp, _i, _vp, _vp, _i, _f, _vp, _vp, _vp, _vp, _i, _i, _i, _vp],
     'hoig_inorm_bwd': [_vp, _vp, _vp, _i, _vp, _vp, _vp, _vp, _i, _f, _vp, _vp, _vp, _i, _i, _i, _vp, _vp],

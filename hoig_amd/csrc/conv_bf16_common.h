@@ -225,7 +225,7 @@ struct FlatArgs {
 };
 int launch_flat_m16(FlatArgs a, int ns, hipStream_t st);
 
-// argument block of the weight-gradient halo kernels (wgrad_halo_bf16_kernel in conv_igemm_bf16.hip, wgrad_halo16.hip)
+// argument block of the weight-gradient halo kernels (wgrad_halo_bf16_kernel in conv_igemm_bf16.hip, wgrad_dma.hip)
 struct WHaloArgs {
     const float *DY, *X, *X2;  // X2 (nullable): the input is [X | X2] along channels, X holding the first ci1
     int ci1;
@@ -245,10 +245,6 @@ struct WHaloArgs {
     unsigned long long *dbg;
 #endif
 };
-
-// wgrad_halo16.hip: the stride-1 3x3 weight gradient on v_mfma_f32_16x16x32 (`a` carries the tiling: th = 2 or 4 pixel rows per
-// tile, cm = 1 or 2 groups of 64 dy channels per workgroup); HOIG_EUNSUPPORTED for what it has no variant for
-int launch_wgrad_halo_m16(const WHaloArgs &a, int ns, int th, int cm, dim3 grid, hipStream_t st);
 
 // wgrad_dma.hip: the stride-1 3x3 weight gradient from PRE-SPLIT dy (a.DY points at [pixel][2][Co] bf16: hoig_split_planes_bf16 or a
 // producer's epilogue), staged by LDS-DMA into double-buffered tiles; `a` carries the 4 x 32-pixel tiling; HOIG_EUNSUPPORTED otherwise

@@ -1113,9 +1113,10 @@ int launch_halo3(HaloArgs a, int ns, hipStream_t st) {
         if (a.a_split || a.b_split || a.in_scale) return HOIG_EUNSUPPORTED;  // (pre-split input, grouped launch: conv_halo16.hip only)
         HOIG_NS_SWITCH(ns, return launch_halo3_one<NSX, 2, 2, 64, 0>(a, st));
     }
-    if (m16 && hoig_tuning(HOIG_TUNE_FEW128) != 0 && a.H % 8 == 0 && a.nblk / 2 < 256 && a.nblk >= 192 && a.N % 128 == 0) {
-        // experiment: the 8-image launches of src_model / tsf_model (which run side by side on two streams) on 128-channel
-        // tiles -- 128 workgroups each, half the chip per launch -- instead of 256 workgroups of 64-channel tiles
+    if (m16 && a.H % 8 == 0 && a.nblk / 2 < 256 && a.nblk >= 192 && a.N % 128 == 0) {
+        // the 8-image launches of src_model / tsf_model (which run side by side on two streams) on 128-channel tiles -- 128
+        // workgroups each, half the chip per launch -- instead of 256 workgroups of 64-channel tiles (round 4: step -0.65 ms,
+        // profiles/r04_few128_ab.txt)
         a.tiles_y = a.H / 8;
         a.nblk = a.Bn * a.tiles_x * a.tiles_y * a.nblk_n;
         return launch_halo3_m16(a, ns, 128, st);
@@ -2464,9 +2465,9 @@ int launch_wgrad_halo(const hoig_conv_desc *d, const float *x, const float *dy, 
     a.n_mtiles = a.Bn * a.tiles_x * a.tiles_y;
     constexpr int target_blocks = 512;
     // 5x5: a workgroup owns 25 taps x 64 x 32 outputs, so every pixel split costs 2.8x the atomics of a 3x3 one: 256 (measured)
-    // experiment ("wgrad_few"): the 8-image 32 x 32 launches (64 four-row tiles) run side by side on two branch streams in G's
-    // backward: 128 workgroups each -- half the pixel splits, half the atomics -- instead of 256
-    const int target = (hoig_tuning(HOIG_TUNE_WGRAD_FEW) != 0 && th4 && a.n_mtiles <= 64) ? target_blocks / 2 : target_blocks;
+    // the 8-image 32 x 32 launches (64 four-row tiles) run side by side on two branch streams in G's backward: 128 workgroups each --
+    // half the pixel splits, half the atomics -- instead of 256 (round 4: step -0.35 ms, profiles/r04_wflat5_ab.txt)
+    const int target = (th4 && a.n_mtiles <= 64) ? target_blocks / 2 : target_blocks;
     int splits = (int)hoig_cdiv((d->R == 5 ? target / 2 : target) / cm, a.nblk);
     if (splits > a.n_mtiles) splits = a.n_mtiles;
     if (splits < 1) splits = 1;
@@ -2478,10 +2479,6 @@ int launch_wgrad_halo(const hoig_conv_desc *d, const float *x, const float *dy, 
     a.dbg = g_stamp_buf;
 #endif
     if (dy_split) return launch_wgrad_dma(a, ns, grid, st);
-    if (hoig_tuning(HOIG_TUNE_WGRAD16) != 0 && d->R == 3 && !s2 && !d->transposed) {      // on v_mfma_f32_16x16x32 (wgrad_halo16.hip)
-        const int rc = launch_wgrad_halo_m16(a, ns, th4 ? 4 : 2, cm, grid, st);
-        if (rc != HOIG_EUNSUPPORTED) return rc;
-    }
     if (th4) {
         constexpr int LDS4 = 2 * (4 * 32 * 320) + (((6 * 34 * 64) + 255) / 256) * 256;      // dy hi, lo | x hi
         static hoig_once once;

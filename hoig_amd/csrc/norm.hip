@@ -347,24 +347,19 @@ __global__ __launch_bounds__(TNT) void inorm_tile_fwd_kernel(const float *__rest
     }
 }
 
-// GB (round 5, off the default path): the [dgamma | dbeta] stores as split planes and their column sums -- a template flag, not a run-time
-// one: the eight registers of the two extra sums cost every launch of the plain form 11 us (31 -> 42 us) when they were unconditional
-template <bool GB>
 __global__ __launch_bounds__(TNT) void inorm_tile_bwd_kernel(const float *__restrict__ x, const float *__restrict__ mean,
                                                              const float *__restrict__ rstd, int mode,
                                                              const float *__restrict__ p0, const float *__restrict__ p1,
                                                              int ldp, const float *__restrict__ y, const float *__restrict__ dy,
                                                              int act, float slope, float *__restrict__ dx,
                                                              float *__restrict__ dp0, float *__restrict__ dp1, int HW, int C,
-                                                             const float *__restrict__ addend, int split,
-                                                             float *__restrict__ dp_colsum) {
+                                                             const float *__restrict__ addend, int split) {
     __shared__ float red[TPL * TCG];
     const int b = blockIdx.y, c0 = blockIdx.x * TCG;
     const int cq = threadIdx.x % (TCG / 4), pl = threadIdx.x / (TCG / 4), c = c0 + cq * 4;
     const size_t base = (size_t)b * HW * C + c;
     const float4 mu = *reinterpret_cast<const float4 *>(mean + (size_t)b * C + c);
     const float4 rs = *reinterpret_cast<const float4 *>(rstd + (size_t)b * C + c);
-    float4 cs1 = make_float4(0.f, 0.f, 0.f, 0.f), cs2 = cs1;          // column sums of dbeta / dgamma (mode 2 with dp_colsum)
     float4 aw = make_float4(1, 1, 1, 1), ab = make_float4(0, 0, 0, 0);
     if (mode == 1) {
         aw = *reinterpret_cast<const float4 *>(p0 + c);
@@ -399,17 +394,8 @@ __global__ __launch_bounds__(TNT) void inorm_tile_bwd_kernel(const float *__rest
         if (mode == 2) {                    // dgamma = g*xhat, dbeta = g (per pixel); then g' = g * (1 + gamma)
             const size_t po = ((size_t)b * HW + r) * ldp + c;
             const float4 dga = make_float4(gg.x * hh.x, gg.y * hh.y, gg.z * hh.z, gg.w * hh.w);
-            if (GB && (split & 2)) {        // [gamma | beta] of width ldp = 2C as ONE split tensor (dp1 == dp0 + C: checked by the launcher)
-                store_split(dp0, (int64_t)b * HW + r, ldp, c, dga);
-                store_split(dp0, (int64_t)b * HW + r, ldp, C + c, gg);
-            } else {
-                *reinterpret_cast<float4 *>(dp0 + po) = dga;
-                *reinterpret_cast<float4 *>(dp1 + po) = gg;
-            }
-            if constexpr (GB) {
-                cs1.x += gg.x; cs1.y += gg.y; cs1.z += gg.z; cs1.w += gg.w;
-                cs2.x += dga.x; cs2.y += dga.y; cs2.z += dga.z; cs2.w += dga.w;
-            }
+            *reinterpret_cast<float4 *>(dp0 + po) = dga;
+            *reinterpret_cast<float4 *>(dp1 + po) = gg;
             const float4 ga = *reinterpret_cast<const float4 *>(p0 + po);
             gg.x *= 1.f + ga.x; gg.y *= 1.f + ga.y; gg.z *= 1.f + ga.z; gg.w *= 1.f + ga.w;
         }
@@ -420,14 +406,6 @@ __global__ __launch_bounds__(TNT) void inorm_tile_bwd_kernel(const float *__rest
     }
     s1 = tile_reduce(s1, red, cq, pl);
     s2 = tile_reduce(s2, red, cq, pl);
-    if (GB && mode == 2 && dp_colsum) {     // the bias gradient of the convolution that made [gamma | beta]: its dy is written here
-        cs1 = tile_reduce(cs1, red, cq, pl);
-        cs2 = tile_reduce(cs2, red, cq, pl);
-        if (pl == 0) {
-            atomicAdd(dp_colsum + c, cs2.x); atomicAdd(dp_colsum + c + 1, cs2.y); atomicAdd(dp_colsum + c + 2, cs2.z); atomicAdd(dp_colsum + c + 3, cs2.w);
-            atomicAdd(dp_colsum + C + c, cs1.x); atomicAdd(dp_colsum + C + c + 1, cs1.y); atomicAdd(dp_colsum + C + c + 2, cs1.z); atomicAdd(dp_colsum + C + c + 3, cs1.w);
-        }
-    }
     if (mode == 1 && pl == 0) {             // affine parameter gradients: dbias += sum g, dweight += sum g*xhat (g before * weight)
         if (dp1) { atomicAdd(dp1 + c, s1.x); atomicAdd(dp1 + c + 1, s1.y); atomicAdd(dp1 + c + 2, s1.z); atomicAdd(dp1 + c + 3, s1.w); }
         if (dp0) { atomicAdd(dp0 + c, s2.x); atomicAdd(dp0 + c + 1, s2.y); atomicAdd(dp0 + c + 2, s2.z); atomicAdd(dp0 + c + 3, s2.w); }
@@ -644,8 +622,7 @@ extern "C" int hoig_inorm_bwd_fused(const float *x, const float *mean, const flo
 }
 static int inorm_bwd_fused_any(const float *x, const float *mean, const float *rstd, int mode, const float *p0, const float *p1,
                                int ld_p, const float *y, const float *dy, int act, float slope, const float *addend, float *dx,
-                               float *dp0, float *dp1, int B, int HW, int C, hoig_stream_t stream, int split,
-                               float *dp_colsum = nullptr);
+                               float *dp0, float *dp1, int B, int HW, int C, hoig_stream_t stream, int split);
 extern "C" int hoig_inorm_bwd_fused_add(const float *x, const float *mean, const float *rstd, int mode, const float *p0,
                                         const float *p1, int ld_p, const float *y, const float *dy, int act, float slope,
                                         const float *addend, float *dx, float *dp0, float *dp1, int B, int HW, int C,
@@ -659,24 +636,9 @@ extern "C" int hoig_inorm_bwd_fused_add_split(const float *x, const float *mean,
     return inorm_bwd_fused_any(x, mean, rstd, mode, p0, p1, ld_p, y, dy, act, slope, addend, reinterpret_cast<float *>(dx_split), dp0,
                                dp1, B, HW, C, stream, 1);
 }
-// the general form: `planes` bit 0 = dx as bf16 hi | lo planes, bit 1 = the per-pixel parameter gradients [dp0 | dp1] (mode 2, the two
-// halves of ONE [.., 2C] tensor: dp1 == dp0 + C, ld_p == 2C) as planes of that tensor -- the dy of the convolution that made
-// [gamma | beta] (spade.py:33-34 run as one convolution), whose weight / data gradient then read it pre-split; dp_colsum (optional,
-// mode 2): [2C] accumulators that receive the column sums of [dp0 | dp1] over all pixels, i.e. that convolution's bias gradient
-// (+=: the fp32 sums of the fp32 values, taken where they are made instead of by a pass over the tensor)
-extern "C" int hoig_inorm_bwd_fused_add_planes(const float *x, const float *mean, const float *rstd, int mode, const float *p0,
-                                               const float *p1, int ld_p, const float *y, const float *dy, int act, float slope,
-                                               const float *addend, void *dx, void *dp0, void *dp1, float *dp_colsum, int planes,
-                                               int B, int HW, int C, hoig_stream_t stream) {
-    if (planes < 0 || planes > 3) return HOIG_EINVAL;
-    if ((planes & 2) && (mode != 2 || ld_p != 2 * C || static_cast<float *>(dp1) != static_cast<float *>(dp0) + C)) return HOIG_EINVAL;
-    if (dp_colsum && mode != 2) return HOIG_EINVAL;
-    return inorm_bwd_fused_any(x, mean, rstd, mode, p0, p1, ld_p, y, dy, act, slope, addend, static_cast<float *>(dx),
-                               static_cast<float *>(dp0), static_cast<float *>(dp1), B, HW, C, stream, planes, dp_colsum);
-}
 static int inorm_bwd_fused_any(const float *x, const float *mean, const float *rstd, int mode, const float *p0, const float *p1,
                                int ld_p, const float *y, const float *dy, int act, float slope, const float *addend, float *dx,
-                               float *dp0, float *dp1, int B, int HW, int C, hoig_stream_t stream, int split, float *dp_colsum) {
+                               float *dp0, float *dp1, int B, int HW, int C, hoig_stream_t stream, int split) {
     if (!x || !mean || !rstd || !dy || !dx || mode < 0 || mode > 2) return HOIG_EINVAL;
     if (mode == 2 && (ld_p < C || (ld_p & 3) || !dp0 || !dp1)) return HOIG_EINVAL;
     if (act != HOIG_ACT_NONE && !y &&
@@ -684,12 +646,8 @@ static int inorm_bwd_fused_any(const float *x, const float *mean, const float *r
         return HOIG_EINVAL;
     if (mode != 0 && !p0) return HOIG_EINVAL;
     if (!tile_ok(B, HW, C)) return HOIG_EUNSUPPORTED;
-    if ((split & 2) || dp_colsum)
-        inorm_tile_bwd_kernel<true><<<dim3(C / TCG, B), TNT, 0, (hipStream_t)stream>>>(x, mean, rstd, mode, p0, p1, ld_p, y, dy, act,
-                                                                                       slope, dx, dp0, dp1, HW, C, addend, split, dp_colsum);
-    else
-        inorm_tile_bwd_kernel<false><<<dim3(C / TCG, B), TNT, 0, (hipStream_t)stream>>>(x, mean, rstd, mode, p0, p1, ld_p, y, dy, act,
-                                                                                        slope, dx, dp0, dp1, HW, C, addend, split, nullptr);
+    inorm_tile_bwd_kernel<<<dim3(C / TCG, B), TNT, 0, (hipStream_t)stream>>>(x, mean, rstd, mode, p0, p1, ld_p, y, dy, act, slope, dx,
+                                                                             dp0, dp1, HW, C, addend, split);
     HOIG_LAUNCH_CHECK();
     return HOIG_OK;
 }

@@ -10,20 +10,14 @@ struct Entry {
 };
 Entry g_table[HOIG_TUNE_COUNT] = {
     {"mfma16", 1},
-    {"wgrad16", 0},
     {"igemm16", 1},
     {"s2_16", 1},
     {"flat5", 2},
-    {"few128", 1},
     {"wflat5", 1},
-    {"wgrad_few", 1},
     {"head16", 1},
-    {"adam_pack", 1},
     {"d_early", 1},
     {"split_grads", 1},
-    {"wgrad_ko", 0},
     {"pair", 2},
-    {"pad_in", 1},
     {"wdma16", 2},
     {"s2_pipe", 1},
     {"norm_in", 1},

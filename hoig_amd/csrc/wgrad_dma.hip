@@ -34,9 +34,7 @@ constexpr int D_PLANE = D_NPX * 256;                                          //
 constexpr int D_QBUF = ((D_HPIX * D_QSTR + 255) / 256) * 256;                 // 13 056 B
 constexpr int wgrad_dma_lds(int ns) { return 2 * ns * D_PLANE + 2 * D_QBUF; } // 157 184 B with two dy planes
 
-// KO (diagnostic instantiations behind the tuning key `wgrad_ko`, tools/ab_conv.py): bit 0 = no staging at all (no DMA, no x loads: the
-// k-loop runs on whatever the first tile left in LDS), bit 1 = no atomic epilogue, bit 2 = one barrier per tile but no vmcnt wait; 8 = no x path (DMA kept); 16 = no DMA (x path kept)
-template <int NS, int KO = 0>      // dy planes: 2 (hi + lo: HOIG_PREC_F16X2) or 1 (hi only: HOIG_PREC_BF16)
+template <int NS>      // dy planes: 2 (hi + lo: HOIG_PREC_F16X2) or 1 (hi only: HOIG_PREC_BF16)
 __global__ __launch_bounds__(D_NT) void wgrad_dma_kernel(const WHaloArgs p) {
     constexpr int TH = D_TH, TW = D_TW, BM = D_BM, BC = D_BC, NT = D_NT, KS = D_KS, HWID = D_HWID, HPIX = D_HPIX, QSTR = D_QSTR;
     constexpr int PBUF = NS * D_PLANE;
@@ -189,13 +187,13 @@ __global__ __launch_bounds__(D_NT) void wgrad_dma_kernel(const WHaloArgs p) {
         // CU's one load path at once stall each other at issue (round 2's stamps of the register kernel: a third of a tile's cycles),
         // and a wave that waits at issue feeds no MFMAs; with no registers tied to a DMA in flight nothing forces the burst
         const unsigned short *nb = nullptr;
-        if constexpr (nxt && !(KO & 1)) {
+        if constexpr (nxt) {
             tnext = tile_next(tnext);
             nb = tile_base(tnext.b, tnext.ty, tnext.tx);
-            if constexpr (!(KO & 8)) load_x(tnext);         // (the quarter of the bytes that goes through registers: up front)
+            load_x(tnext);                                  // (the quarter of the bytes that goes through registers: up front)
         }
         auto stage = [&](int kk) {                          // k-step kk carries DMA piece kk of the next tile
-            if constexpr (nxt && !(KO & 1) && !(KO & 16)) {
+            if constexpr (nxt) {
                 if (kk < NPIECE) dma_piece(nb, cur ^ 1, kk);
             }
         };
@@ -232,7 +230,7 @@ __global__ __launch_bounds__(D_NT) void wgrad_dma_kernel(const WHaloArgs p) {
             // the next tile's x halo is converted and stored BESIDE the last k-steps' MFMAs of the other waves, not between the last MFMA and
             // the barrier (its buffer was last read in the previous tile, a barrier ago; its loads were issued at the top of this tile and
             // the last DMA piece a k-step ago, so the wait in front of the conversion finds everything landed)
-            if constexpr (nxt && !(KO & 1) && !(KO & 8)) {
+            if constexpr (nxt) {
                 if (kk == TH * 2 - 2) store_x(cur ^ 1);
             }
             __builtin_amdgcn_sched_barrier(0);
@@ -240,7 +238,7 @@ __global__ __launch_bounds__(D_NT) void wgrad_dma_kernel(const WHaloArgs p) {
             __builtin_amdgcn_sched_barrier(0);
         }
         if constexpr (nxt) {
-            if constexpr (!(KO & 4)) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");    // this wave's DMA pieces of tile mt + 1 have landed ...
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");    // this wave's DMA pieces of tile mt + 1 have landed ...
             __syncthreads();                                // ... and so have everyone's; everyone is done reading tile mt
         }
     };
@@ -249,7 +247,6 @@ __global__ __launch_bounds__(D_NT) void wgrad_dma_kernel(const WHaloArgs p) {
 
     const int l31 = lane & 31, lh = lane >> 5;
     const int K = KS * KS * p.Ci;
-    if ((KO & 2) && acc[0][0] != 12345.f) return;
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
         const int co = c0 + cb * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
@@ -305,21 +302,6 @@ int launch_wgrad_dma(const WHaloArgs &a, int ns, dim3 grid, hipStream_t st) {
                                 wgrad_dma_lds(1)) != hipSuccess)
             return HOIG_ELAUNCH;
         once.set();
-    }
-    const int ko = hoig_tuning(HOIG_TUNE_WGRAD_KO);
-    if (ns == 3 && ko) {
-        static hoig_once once_ko;
-#define HOIG_KO_CASE(K_)                                                                                                        \
-    if (ko == K_) {                                                                                                             \
-        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&wgrad_dma_kernel<2, K_>), hipFuncAttributeMaxDynamicSharedMemorySize, \
-                                  wgrad_dma_lds(2));                                                                            \
-        wgrad_dma_kernel<2, K_><<<grid, D_NT, wgrad_dma_lds(2), st>>>(a);                                                       \
-    }
-        HOIG_KO_CASE(1) HOIG_KO_CASE(2) HOIG_KO_CASE(3) HOIG_KO_CASE(4) HOIG_KO_CASE(8) HOIG_KO_CASE(16)
-#undef HOIG_KO_CASE
-        (void)once_ko;
-        HOIG_LAUNCH_CHECK();
-        return HOIG_OK;
     }
     if (ns == 3) wgrad_dma_kernel<2><<<grid, D_NT, wgrad_dma_lds(2), st>>>(a);
     else wgrad_dma_kernel<1><<<grid, D_NT, wgrad_dma_lds(1), st>>>(a);

@@ -434,6 +434,7 @@ class FusedAdam(object):
         self.exp_avg = torch.zeros_like(tree.flat)
         self.exp_avg_sq = torch.zeros_like(tree.flat)
         self.step_count = 0
+        self.fuse_planes = True         # the update writes the operand planes of the new weights too (hoig_adam_pack_step); False: two launches
         self._state = torch.zeros(5, dtype=torch.float64, device=tree.flat.device)
         self._derived = torch.zeros(8, dtype=torch.float32, device=tree.flat.device)
         self._on_device = None          # the host values self._state was last written from
@@ -473,7 +474,7 @@ class FusedAdam(object):
         self.step_count += 1
         self._on_device = self._on_device[:4] + (float(self.step_count),)
         fl, gr, m, v = self.tree.flat, self.tree.flat_grad, self.exp_avg, self.exp_avg_sq
-        fused = self.tree.fused_step_tables() if ready is None and L.set_tuning('adam_pack', -1) else None
+        fused = self.tree.fused_step_tables() if (ready is None and self.fuse_planes) else None
         if fused is not None:
             # the update and the operand planes of the updated weights in one launch (include/hoig_kernels.h)
             table, ntiles, plain, nplain, b = fused

@@ -455,13 +455,24 @@ def join_wgrad_streams():
 
 # --- pre-split gradients (round 5; include/hoig_kernels.h 'PRE-SPLIT gradients').  The two-term backward arithmetic multiplies
 # bf16(dy) and bf16(dy - bf16(dy)); the convolution kernels used to make that split of every dy tile in every workgroup that loads it.
-# Where a convolution's output goes straight into an instance norm, the norm's backward kernel now WRITES its dx as those two planes
+# Where a convolution's output goes straight into an instance norm, the norm's backward kernel WRITES its dx as those two planes
 # (per pixel [hi: C bf16][lo: C bf16], in the bytes of the fp32 tensor autograd passes along) and the convolution's weight- and
-# data-gradient kernels copy them to LDS (LDS-DMA / 16-B pieces) without touching the VALU.  The hand-off is explicit: the convolution
-# tags its OUTPUT tensor at forward time (`_hoig_split_grad`: "my backward reads split dy"), the norm that consumes that very tensor
-# object remembers the tag, its backward registers the gradient it wrote here, and the convolution's backward looks its incoming
-# gradient up.  A tagged tensor that reaches anything but such a norm simply gets an fp32 gradient (no tag, no registration).
-_split_grads = {}          # data_ptr -> the gradient tensor that holds planes (alive until its consumer has been issued)
+# data-gradient kernels copy them to LDS (LDS-DMA / 16-B pieces) without touching the VALU.
+# The hand-off is a TOKEN both ends hold (round 6, ADVICE r5: the round-5 form looked gradients up by data_ptr in a module-level table):
+#   * the convolution makes one token per eligible output, keeps it on its backward node and hangs it on the output tensor;
+#   * every norm that reads that tensor object counts itself on the token (`readers`) and keeps the token; its backward writes planes
+#     only if it was the ONLY such reader, and then puts the tensor it wrote on the token (`offered`);
+#   * the convolution's backward takes `offered` and accepts planes only if the gradient it was handed IS that tensor.  Anything else
+#     -- autograd summed the planes with another consumer's fp32 gradient, a hook cloned them -- has already mixed plane bits with
+#     fp32 values: that is an error, raised here, never a silently wrong gradient.  No offer: the gradient is fp32, as before.
+class _SplitToken(object):
+    __slots__ = ('readers', 'offered', '__weakref__')
+
+    def __init__(self):
+        self.readers, self.offered = 0, None
+
+
+_split_live = set()        # tokens whose offer has not been taken yet (emptied by the consumers; check_split_grads_consumed)
 
 
 def _split_backward_ok(d, w, live_bias, transposed):
@@ -477,27 +488,58 @@ def _split_backward_ok(d, w, live_bias, transposed):
     return dg.precision in (L.PREC_F16X2, L.PREC_BF16) and wg.precision in (L.PREC_F16X2, L.PREC_BF16)
 
 
-def _tag_split(y):
-    y._hoig_split_grad = True
+def _tag_split(y, slot=0):
+    """Hang a fresh token on convolution output `y` and on its backward node (slot: which output of a grouped launch)."""
+    tok = _SplitToken()
+    toks = getattr(y.grad_fn, 'split_toks', None)
+    if toks is None:
+        toks = y.grad_fn.split_toks = {}
+    toks[slot] = tok
+    y._hoig_split_grad = tok
     return y
 
 
-def _take_split(dy):
-    """-> None, or (tensor, bias_done) if `dy` is a gradient some producer wrote as split planes (and forget it); bias_done: that
-    producer also accumulated the column sums of dy into the consumer's bias gradient."""
-    return _split_grads.pop(dy.data_ptr(), None)
+def _claim_split(x):
+    """A norm's forward: -> the token of `x` (counted as one more reader), or None if x is not a tagged convolution output."""
+    tok = getattr(x, '_hoig_split_grad', None)
+    if tok is not None:
+        tok.readers += 1
+    return tok
 
 
-def _offer_split(dx, bias_done=False):
-    _split_grads[dx.data_ptr()] = (dx, bias_done)
+def _writes_split(tok):
+    """A norm's backward: does it write its dx as planes?  Only as the tagged tensor's single norm reader."""
+    return tok is not None and tok.readers == 1
+
+
+def _offer_split(tok, dx):
+    tok.offered = dx
+    _split_live.add(tok)
+
+
+def _take_split(ctx, dy, slot=0):
+    """A convolution's backward: True if `dy` holds split planes.  Raises if planes were written for this convolution and `dy` is
+    not the tensor they were written into."""
+    tok = getattr(ctx, 'split_toks', {}).get(slot)
+    if tok is None or tok.offered is None:
+        return False
+    off, tok.offered = tok.offered, None
+    _split_live.discard(tok)
+    if dy is not off and (dy.data_ptr() != off.data_ptr() or dy.shape != off.shape):
+        raise RuntimeError('a norm wrote this convolution\'s incoming gradient as bf16 hi | lo planes, but the gradient that arrived is '
+                           'another tensor: the tagged output had a second consumer (autograd summed plane bits with an fp32 gradient) '
+                           'or a hook replaced it.  Give the second consumer its own copy, or set the tuning key split_grads=0.')
+    return True
 
 
 def check_split_grads_consumed():
-    """Every gradient written as planes must have been read by the convolution it was written for: anything left over reached a
-    consumer that took it for fp32 (Trainer calls this after each backward)."""
-    if _split_grads:
-        n = len(_split_grads)
-        _split_grads.clear()
+    """Every gradient written as planes must have been read by the convolution it was written for: an offer left over means the
+    convolution's backward never ran while something else may have read the planes as fp32 (Trainer calls this after each backward)."""
+    if _split_live:
+        n = len(_split_live)
+        for tok in list(_split_live):
+            tok.offered = None
+        _split_live.clear()
         raise RuntimeError('%d pre-split gradient tensor(s) were not consumed by a convolution backward' % n)
 
 
@@ -535,14 +577,6 @@ class _Conv(Function):
         ctx.save_for_backward(x, w, b, y if act != L.ACT_NONE else None)
         ctx.fork = fork
         ctx.split_ok = dead_bias and _split_backward_ok(d, w, ctx.has_bias, transposed)      # (dead_bias: the output's one reader is a norm)
-        # an eligible layer whose dy arrives as fp32 (no norm behind it: SPADE's conv_1, its gamma/beta convolution): one pass splits dy
-        # (8 B per element) for the two kernels that would otherwise each split every tile they load (tuning key split_grads = 2)
-        ctx.split_pass = (not ctx.split_ok and act == L.ACT_NONE and L.lib.hoig_set_tuning(b'split_grads', -1) == 2 and
-                          _split_backward_ok(d, w, False, transposed))
-        # ... or, with a LIVE bias whose gradient accumulates in a flat buffer, by a producer that also sums dy's columns into that
-        # buffer (split_grads = 3; today: _SpadeFused for its [gamma | beta] convolution)
-        ctx.split_ok_bias = (not dead_bias and ctx.has_bias and act == L.ACT_NONE and getattr(b, '_hoig_flat', False) and
-                             L.lib.hoig_set_tuning(b'split_grads', -1) >= 3 and _split_backward_ok(d, w, False, transposed))
         if fork:
             # (y, x): the caller hands this second output to x's OTHER consumer, so that autograd sees x consumed once -- by
             # this node, whose backward receives both gradients and lets the data-gradient kernel add the other one in its
@@ -558,21 +592,8 @@ class _Conv(Function):
         if dy is None:                      # (fork: only the pass-through output was used)
             return (dxr,) + (None,) * 11
         dy = dy.contiguous()
-        took = _take_split(dy)
-        if took is not None:
-            if ctx.has_bias and not took[1]:
-                raise RuntimeError('pre-split dy for a convolution with a live bias, and nobody summed its columns')
+        if _take_split(ctx, dy):
             return _Conv._backward_split(ctx, dy, dxr, x, w)
-        if ctx.split_pass:
-            npix, db_ret = dy.numel() // d.Co, None
-            if ctx.has_bias and ctx.needs_input_grad[2]:
-                db, ret_b = _grad_target(b)
-                call('hoig_colsum_accum', _p(dy), _p(db), npix, d.Co, _st())
-                db_ret = db if ret_b else None
-            dys = torch.empty_like(dy)
-            call('hoig_split_planes_bf16', _p(dy), _p(dys), npix, d.Co, _st())
-            res = _Conv._backward_split(ctx, dys, dxr, x, w)
-            return res[:2] + (db_ret,) + res[3:]
         dw_ret = db_ret = None
         db, ret_b = None, False
         if ctx.needs_input_grad[1] and ctx.has_bias and ctx.needs_input_grad[2]:
@@ -648,8 +669,6 @@ def conv2d(x, w, b=None, stride=1, pad=0, act=L.ACT_NONE, slope=0.0, prec=None, 
     gradient exactly zero in exact arithmetic (the reference computes ~1e-10 rounding noise there); the column sum of dy
     is skipped and the bias gradient left at zero."""
     y = _Conv.apply(x, w, b, stride, pad, False, act, slope, None, precision if prec is None else prec, dead_bias)
-    if getattr(y.grad_fn, 'split_ok_bias', False):
-        y._hoig_split_grad_bias = b             # (read by _SpadeFused only: "write my dy split AND sum its columns into this bias")
     return _tag_split(y) if getattr(y.grad_fn, 'split_ok', False) else y
 
 
@@ -728,7 +747,7 @@ class _ConvPair(Function):
         dys, db_ret = [], [None, None]
         for i, (dy, b) in enumerate(((dya, ba), (dyb, bb))):
             dy = dy.contiguous()
-            if _take_split(dy):
+            if _take_split(ctx, dy, i):
                 dys.append(dy)
                 continue
             if ctx.live_bias and ctx.needs_input_grad[4 + i]:
@@ -780,8 +799,8 @@ def conv2d_pair(xa, xb, wa, wb, ba=None, bb=None, prec=None, dead_bias=False, fo
     pair_ok() first; anything else goes through conv2d / conv2d_fork twice."""
     out = _ConvPair.apply(xa, xb, wa, wb, ba, bb, precision if prec is None else prec, dead_bias, fork)
     if getattr(out[0].grad_fn, 'split_ok', False):
-        _tag_split(out[0])
-        _tag_split(out[1])
+        _tag_split(out[0], 0)
+        _tag_split(out[1], 1)
     return out
 
 
@@ -1059,7 +1078,7 @@ class _INorm(Function):
         else:
             L.check(rc, 'hoig_inorm_fwd_fused')
         ctx.cfg = (mode, act, slope, B, HW, C, residual is not None)
-        ctx.split_dx = getattr(x, '_hoig_split_grad', False)          # x is the output of a convolution whose backward reads split dy
+        ctx.split_tok = _claim_split(x)          # x is the output of a convolution whose backward reads split dy
         # (Leaky)ReLU after a plain / affine norm: the backward recomputes the activation mask from x instead of reading y
         y_free = act in (L.ACT_RELU, L.ACT_LRELU) and mode in (0, 1)
         ctx.save_for_backward(x, mean, rstd, p0, p1, y if (act != L.ACT_NONE and not y_free) else None)
@@ -1079,7 +1098,8 @@ class _INorm(Function):
         elif mode == 2:
             dp0, dp1 = torch.empty_like(x), torch.empty_like(x)
             r0, r1 = dp0, dp1
-        sfx = '_split' if ctx.split_dx else ''
+        split_dx = _writes_split(ctx.split_tok)
+        sfx = '_split' if split_dx else ''
         p1m = _p(p1) if mode == 1 else None
         rc = getattr(L.lib, 'hoig_inorm_bwd_fused_add' + sfx)(_p(x), _p(mean), _p(rstd), mode, _p(p0), p1m, C, _p(y), _p(dy), act, slope,
                                                               None, _p(dx), _p(dp0), _p(dp1), B, HW, C, _st())
@@ -1089,8 +1109,8 @@ class _INorm(Function):
                  _p(dp0), _p(dp1), B, HW, C, _p(ws), _st())
         else:
             L.check(rc, 'hoig_inorm_bwd_fused_add' + sfx)
-        if ctx.split_dx:
-            _offer_split(dx)
+        if split_dx:
+            _offer_split(ctx.split_tok, dx)
         return dx, r0, r1, None, None, None, (dy if has_res else None), None
 
 
@@ -1131,10 +1151,7 @@ class _SpadeFused(Function):
         else:
             L.check(rc, 'hoig_inorm_fwd_fused')
         ctx.cfg = (act, slope, B, HW, C)
-        ctx.split_dx = getattr(x, '_hoig_split_grad', False)          # (see _INorm.forward)
-        # the convolution that made gb reads its dy pre-split: this backward writes [dgamma | dbeta] as planes and sums their columns
-        # into that convolution's bias gradient (single-launch form only: the maps of at most 1024 pixels)
-        ctx.gb_bias = getattr(gb, '_hoig_split_grad_bias', None) if rc != L.EUNSUPPORTED else None
+        ctx.split_tok = _claim_split(x)          # (see _INorm.forward)
         ctx.save_for_backward(x, mean, rstd, gb, y if act != L.ACT_NONE else None)
         if fork:                              # (y, x): see _Conv.forward
             ctx.set_materialize_grads(False)
@@ -1151,17 +1168,8 @@ class _SpadeFused(Function):
         add = dxr.contiguous() if dxr is not None else None
         dx = torch.empty_like(x)
         dgb = torch.empty_like(gb)
-        sfx = '_split' if ctx.split_dx else ''
-        if ctx.gb_bias is not None:
-            db, _ = _grad_target(ctx.gb_bias)
-            L.check(L.lib.hoig_inorm_bwd_fused_add_planes(_p(x), _p(mean), _p(rstd), 2, _p(gb), None, 2 * C, _p(y), _p(dy), act, slope,
-                                                          _p(add), _p(dx), _p(dgb), dgb.data_ptr() + 4 * C, _p(db),
-                                                          (1 if ctx.split_dx else 0) | 2, B, HW, C, _st()),
-                    'hoig_inorm_bwd_fused_add_planes')
-            _offer_split(dgb, bias_done=True)
-            if ctx.split_dx:
-                _offer_split(dx)
-            return dx, dgb, None, None, None, None
+        split_dx = _writes_split(ctx.split_tok)
+        sfx = '_split' if split_dx else ''
         rc = getattr(L.lib, 'hoig_inorm_bwd_fused_add' + sfx)(_p(x), _p(mean), _p(rstd), 2, _p(gb), None, 2 * C, _p(y), _p(dy), act, slope,
                                                               _p(add), _p(dx), _p(dgb), dgb.data_ptr() + 4 * C, B, HW, C, _st())
         if rc == L.EUNSUPPORTED:
@@ -1170,8 +1178,8 @@ class _SpadeFused(Function):
                  _p(dx), _p(dgb), dgb.data_ptr() + 4 * C, B, HW, C, _p(ws), _st())
         else:
             L.check(rc, 'hoig_inorm_bwd_fused_add' + sfx)
-        if ctx.split_dx:
-            _offer_split(dx)
+        if split_dx:
+            _offer_split(ctx.split_tok, dx)
         return dx, dgb, None, None, None, None
 
 
@@ -1312,9 +1320,9 @@ class _PadConvIn(Function):
 def conv2d_padded_in(x, w, b, stride, pad, act=L.ACT_NONE, slope=0.0, prec=None, to=32):
     """conv2d for a layer whose input channel count is no multiple of 32, on the 16-bit kernels: input and weight are zero-padded to `to`
     channels (one fill + one copy of the input; 68 % more multiply-adds on a kernel that runs 4-6x faster than the exact-fp32 one the
-    layer took before).  In exact-fp32 arithmetic, or with the tuning key `pad_in` off, the plain convolution."""
+    layer took before).  In exact-fp32 arithmetic the plain convolution."""
     p = precision if prec is None else prec
-    if p == L.PREC_F32 or x.shape[-1] % 32 == 0 or not L.lib.hoig_set_tuning(b'pad_in', -1) or not x.is_cuda:
+    if p == L.PREC_F32 or x.shape[-1] % 32 == 0 or not x.is_cuda:
         return conv2d(x, w, b, stride, pad, act, slope, prec=prec)
     return conv2d(_PadChannels.apply(x, to), _PadConvIn.apply(w, to), b, stride, pad, act, slope, prec=prec)
 

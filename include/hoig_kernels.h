@@ -91,16 +91,6 @@ int hoig_inorm_bwd_add_ld_split(const float *x, const float *mean, const float *
 int hoig_inorm_bwd_fused_add_split(const float *x, const float *mean, const float *rstd, int mode, const float *p0, const float *p1,
                                    int ld_p, const float *y, const float *dy, int act, float slope, const float *addend /*nullable*/,
                                    uint16_t *dx_split, float *dp0, float *dp1, int B, int HW, int C, hoig_stream_t stream);
-/* The general single-launch form.  planes bit 0: dx as a split tensor; bit 1 (mode 2 only; dp1 == dp0 + C, ld_p == 2C): the per-pixel
- * parameter gradients [dgamma | dbeta] as ONE split tensor of width 2C -- the dy of the convolution that made [gamma | beta]
- * (spade.py:33-34 evaluated as one 3x3 convolution with 2C outputs), whose weight / data gradient then read it pre-split.
- * dp_colsum (nullable, mode 2 only): [2C] fp32 accumulators, += the column sums of [dgamma | dbeta] over all B*HW pixels = that
- * convolution's bias gradient, summed from the fp32 values where they are made (no pass over the tensor).  HOIG_EINVAL on a plane
- * request the layout cannot hold, HOIG_EUNSUPPORTED where hoig_inorm_bwd_fused_add is. */
-int hoig_inorm_bwd_fused_add_planes(const float *x, const float *mean, const float *rstd, int mode, const float *p0, const float *p1,
-                                    int ld_p, const float *y, const float *dy, int act, float slope, const float *addend /*nullable*/,
-                                    void *dx, void *dp0, void *dp1, float *dp_colsum /*nullable*/, int planes, int B, int HW, int C,
-                                    hoig_stream_t stream);
 /* ---- INFERENCE: the norm between two convolutions applied by the second one's loader (VERDICT r1-r4 "consumer half of the norm
  *      fusion"; the reference chains generator.py:16-22 (ResidualBlock: conv - IN - ReLU - conv) and :298-309 (decoder level: ConvTranspose
  *      - IN - ReLU - cat - conv)).  hoig_inorm_fold turns the statistics of the RAW tensor (hoig_inorm_stats / _stats_from_sums) and the
@@ -505,24 +495,17 @@ const char *hoig_version(void);
  *   "igemm16" 1  the generic implicit GEMM on it (conv_igemm16.hip): 1 = forward launches, 2 = data gradients too
  *   "flat5"   2  the flattened-axis halo kernel (conv_flat16.hip): 1 = the attention's valid 5x5 convolutions and their data
  *                gradients, 2 = also the 3x3 "same" layers with too few tiles for the halo kernels
- *   "few128"  1  128-channel tiles for the 3x3 launches with 192-511 four-row tiles (the 8-image launches of two concurrent chains)
  *   "wflat5"  1  the weight gradient of the attention's valid 5x5 convolutions on the flattened pixel axis (wgrad_flat.hip):
  *                1 = where the output width is not a multiple of 32 (the 2 x 32-pixel halo kernel cannot run), 2 = always
- *   "wgrad_few" 1  half the pixel splits for the weight gradients of the 8-image 32 x 32 launches (two of them run side by side)
  *   "head16"  1  the forward of the 7x7 image / mask heads (64 -> 3..5 channels) on 16x16x32 with the horizontal taps as MFMA
  *                columns (conv_head16.hip), three-term forward arithmetic only; 0: the exact-fp32 VALU kernel (conv_small.hip)
- *   "adam_pack" 1  (read by the host side, hoig_amd/nn.py) the optimiser step and the split of the updated weights into operand planes
- *                as one launch (hoig_adam_pack_step); 0: hoig_adam_step_dev, then hoig_pack_conv_weights_bf16_all before the next forward
  *   "d_early" 1  (read by the host side, hoig_amd/models/trainer.py) without a gradient exchange the D step is issued on its stream BEFORE
  *                G's backward instead of after it; 0: after (both orders compute the same step: D's weights change only in D's own
  *                update, which stays last).  With an exchange (world > 1) it always follows G's backward: G's all-reduce hides behind it
- *   "wgrad16" 0  the stride-1 3x3 weight gradients on 16x16x32 (wgrad_halo16.hip): measured 5-20 % slower than 32x32x16
  *   "pair"    2  (read by the host side, hoig_amd/models/networks/generator.py) the 3x3 512 -> 512 convolutions of src_model's and
  *                tsf_model's residual blocks as grouped launches (hoig_conv2d_*_pair): 1 = always, 2 = in CAPTURED steps only, 0 = never
  *                (one launch per sub-network, on two streams).  Measured (profiles/r05_pair_ab.txt): the eager step loses 0.6 ms to the
  *                lock-step of the two chains (the norms between the convolutions no longer overlap), the replayed graph gains 0.7 ms
- *   "pad_in"  1  (read by the host side, hoig_amd/ops.py conv2d_padded_in) the discriminator's first layer (19 / 24 input channels) with
- *                input and weight zero-padded to 32 channels on the 16-bit kernels; 0: the exact-fp32 kernel it took before
  *   "wdma16"  2  the weight tiles of the 16x16x32 3x3 stride-1 kernel (1) and of the flattened-axis kernel (2) by LDS-DMA (conv_halo16.hip /
  *                conv_flat16.hip WDMA: inline-asm global_load_lds, one step ahead, pieces spread over the MFMA groups): +3..7 % on every
  *                layer of the first, +2..5 % on the attention's 5x5 layers, step 63.85 -> 63.03 -> 62.8 ms (profiles/r05_wdma16_ab.txt);
@@ -535,16 +518,13 @@ const char *hoig_version(void);
  *                conv - IN - ReLU - conv3x3 chain in the second convolution's loader (hoig_conv2d_fwd_packed_normin); 0: every norm is a
  *                pass of its own.  Batch-32 generator forward 2.511 -> 2.494 ms per image (the flagship's SPADE norms modulate per
  *                pixel and stay passes)
- *   "wgrad_ko" 0  diagnostic instantiations of wgrad_dma_kernel (tools/ab_conv.py; results are WRONG with any bit set)
  *   "split_grads" 1  (read by the host side, hoig_amd/ops.py) the backward of a norm that follows an eligible 3x3 convolution writes its
  *                dx as bf16 hi | lo planes and that convolution's weight / data gradient read them without splitting ('PRE-SPLIT
- *                gradients' above); 0: fp32 gradients everywhere, split in every consuming workgroup; 2: as 1, and an eligible convolution
- *                whose dy arrives as fp32 (SPADE's conv_1, its [gamma | beta] convolution) splits it in a pass of its own first
- *                (measured: step +0.25 ms, profiles/r05_split_pass_ab.txt -- not adopted); 3: as 1, and SPADE's backward writes
- *                [dgamma | dbeta] as planes and sums the bias gradient (hoig_inorm_bwd_fused_add_planes) for the [gamma | beta]
- *                convolution (measured: weight gradient 76 -> 65 us, but that layer's data gradient -- 1024 -> 128 channels, the
- *                flattened-axis kernel -- has no pre-split form and un-splits first: step +0.25 ms, profiles/r05_split_gb_ab.txt,
- *                r05_split_shapes.txt -- not adopted)
+ *                gradients' above); 0: fp32 gradients everywhere, split in every consuming workgroup
+ * Round 6 removed the keys whose losing side had lost two rounds running, and with them that side's code: "wgrad16" (the 3x3 weight
+ * gradient on 16x16x32: 5-20 % slower, wgrad_halo16.hip deleted), "wgrad_ko" (knock-out instantiations of the LDS-DMA weight gradient:
+ * a diagnostic), "few128" / "wgrad_few" (launch sizing for the 8-image launches: always on), "adam_pack" / "pad_in" (always on),
+ * "split_grads" 2 / 3 (a split pass of its own, SPADE's [dgamma | dbeta] as planes: both +0.25 ms per step, profiles/r05_split_*_ab.txt).
  * Process-wide, not synchronised: set before launching. */
 int hoig_set_tuning(const char *key, int value);
 

@@ -128,59 +128,6 @@ def test_m16_statistics_epilogue(tuning, B, Ci, Co, H, W):
         assert float(ws[:1 << 18].abs().max()) == 0.0
 
 
-WGRAD_CASES = [
-    # B, C1, C2, Co, H, W                  variant of wgrad_halo_m16_kernel the launcher picks (two-term arithmetic)
-    (8, 512, 0, 512, 32, 32),       # 4-row tiles, 128 dy channels per workgroup: the step's dominant weight gradient
-    (8, 256, 256, 256, 32, 32),     # ... over a two-tensor input (the decoder's skip convolution)
-    (8, 512, 0, 512, 18, 32),       # H % 4 != 0: 2-row tiles
-    (4, 64, 0, 64, 64, 64),         # 64 dy channels per workgroup
-    (2, 96, 0, 192, 16, 64),        # three ci tiles, Co % 128 != 0
-]
-
-
-@pytest.mark.parametrize('mode', ['f16x2', 'bf16x3'])
-@pytest.mark.parametrize('B,C1,C2,Co,H,W', WGRAD_CASES)
-def test_wgrad16_weight_and_bias_gradient(B, C1, C2, Co, H, W, mode):
-    """Tuning key 'wgrad16' (wgrad_halo16.hip): dW and the fused bias gradient against the 32x32x16 kernel (same products, another
-    order: fp32 atomics reorder the sums anyway) and against torch fp32."""
-    from hoig_amd import ops, _lib as L
-    g = torch.Generator().manual_seed(17)
-    x1 = torch.randn(B, H, W, C1, generator=g).cuda()
-    x2 = torch.randn(B, H, W, C2, generator=g).cuda() if C2 else None
-    w = ops.pack_weight((torch.randn(Co, C1 + C2, 3, 3, generator=g) * 0.05).cuda())
-    bias = None if C2 else torch.randn(Co, generator=g).cuda()
-    gy = torch.randn(B, H, W, Co, generator=g).cuda()
-    prev = L.set_tuning('wgrad16', 0)
-    ops.set_precision(mode)
-    try:
-        res = []
-        for v in (0, 1):
-            L.set_tuning('wgrad16', v)
-            wd = w.clone().requires_grad_(True)
-            bd = bias.clone().requires_grad_(True) if bias is not None else None
-            if x2 is not None:
-                y = ops.conv2d_cat2(x1, x2, wd)
-            else:
-                y = ops.conv2d(x1, wd, bd, 1, 1)
-            y.backward(gy)
-            torch.cuda.synchronize()
-            res.append((wd.grad.clone(), None if bd is None else bd.grad.clone()))
-    finally:
-        ops.set_precision('f32')
-        L.set_tuning('wgrad16', prev)
-    (dw0, db0), (dw1, db1) = res
-    assert rel_err(dw1, dw0) < 1e-5
-    if db0 is not None:
-        assert rel_err(db1, db0) < 1e-5
-    xr = (torch.cat([x1, x2], 3) if x2 is not None else x1).permute(0, 3, 1, 2)
-    wr = w.detach().clone().requires_grad_(True)
-    br = bias.clone().requires_grad_(True) if bias is not None else None
-    F.conv2d(xr, wr, br, padding=1).backward(gy.permute(0, 3, 1, 2))
-    assert rel_err(dw1, wr.grad) < (8e-3 if mode == 'f16x2' else 3e-4)
-    if br is not None:
-        assert rel_err(db1, br.grad) < 1e-4
-
-
 @pytest.mark.parametrize('mode', ['bf16x3', 'f16x2'])
 @pytest.mark.parametrize('B,Ci,Co,Hi,Wi,bias', [(8, 512, 128, 40, 40, False),      # the attention's source-side convolution
                                                 (8, 128, 128, 36, 36, True),       # ... its target side (output 32 x 32)

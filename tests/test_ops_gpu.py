@@ -389,7 +389,7 @@ def test_fused_adam_matches_torch():
 
 
 def test_fused_adam_with_planes_matches_the_two_launches():
-    """hoig_adam_pack_step (tuning key 'adam_pack'): the optimiser step that also writes the operand planes of the updated conv weights,
+    """hoig_adam_pack_step (FusedAdam.fuse_planes): the optimiser step that also writes the operand planes of the updated conv weights,
     against hoig_adam_step_dev followed by hoig_pack_conv_weights_bf16_all: parameters, both moments and all four planes bit for bit,
     over a buffer with packed weights (forward-only, dgrad-only and both kinds of planes), unpacked weights and biases in between."""
     from hoig_amd import _lib as L
@@ -399,17 +399,16 @@ def test_fused_adam_with_planes_matches_the_two_launches():
     g = torch.Generator().manual_seed(17)
     ref = {k: torch.randn(v, generator=g) * 0.05 for k, v in shapes.items()}
     grads = [[torch.randn(v, generator=g) for v in shapes.values()] for _ in range(3)]
-    prev = L.set_tuning('adam_pack', 0)
     res = []
-    try:
+    if True:
         for fused in (0, 1):
-            L.set_tuning('adam_pack', fused)
             tree = ParamTree(shapes, torch.device('cuda'))
             tree.load_state_dict(ref)
             tree._ensure_plane_bufs()
             tree._refresh_planes()
             assert tree.fused_step_tables() is not None
             opt = FusedAdam(tree, lr=2e-4, betas=(0.5, 0.999))
+            opt.fuse_planes = bool(fused)
             for gs in grads:
                 with torch.no_grad():
                     for p_, gr in zip(tree.P.values(), gs):
@@ -421,8 +420,6 @@ def test_fused_adam_with_planes_matches_the_two_launches():
             torch.cuda.synchronize()
             flags = dict(tree._plane_flags)
             res.append((tree.flat.clone(), opt.exp_avg.clone(), opt.exp_avg_sq.clone(), [b.clone() for b in tree._plane_bufs], flags, tree))
-    finally:
-        L.set_tuning('adam_pack', prev)
     (f0, m0, v0, b0, flags, tree), (f1, m1, v1, b1, _, _) = res
     assert torch.equal(f0, f1) and torch.equal(m0, m1) and torch.equal(v0, v1)
     assert sorted(flags.values()) == [1, 2, 3, 3]                            # c: forward planes only; b: data-gradient planes only

@@ -137,7 +137,7 @@ def test_norm_backward_hands_the_convolution_split_planes(kind, hw):
                 skip = xr * 2.0                                         # the second reader of x
             else:
                 y = ops.conv2d(x, tree.P['c.weight'], None, 1, 1, dead_bias=True)
-            assert getattr(y, '_hoig_split_grad', False) == bool(split)
+            assert (getattr(y, '_hoig_split_grad', None) is not None) == bool(split)
             if kind == 'in_affine_residual':
                 z = ops.instance_norm(y, tree.P['n.weight'], tree.P['n.bias'], residual=res)
             elif kind == 'spade':
@@ -165,92 +165,83 @@ def test_norm_backward_hands_the_convolution_split_planes(kind, hw):
         ops.set_precision('f32')
 
 
-@pytest.mark.parametrize('planes', [1, 2, 3])
-def test_spade_backward_writes_gamma_beta_gradients_as_planes(planes):
-    """hoig_inorm_bwd_fused_add_planes against hoig_inorm_bwd_fused_add: the same dx and [dgamma | dbeta], as fp32 or as the bf16 hi | lo
-    planes the convolution kernels' own split makes of those fp32 values (bit for bit), and the column sums of [dgamma | dbeta]
-    accumulated into the [2C] buffer of the convolution's bias gradient."""
-    from hoig_amd import _lib as L
-    B, H, W, C = 3, 32, 32, 64
-    HW = H * W
-    g = torch.Generator(device='cuda').manual_seed(5)
-    x = torch.randn(B, H, W, C, device='cuda', generator=g)
-    gb = torch.randn(B, H, W, 2 * C, device='cuda', generator=g) * 0.3
-    dy = torch.randn(B, H, W, C, device='cuda', generator=g)
-    add = torch.randn(B, H, W, C, device='cuda', generator=g)
-    st = torch.cuda.current_stream().cuda_stream
-    y, mean, rstd = torch.empty_like(x), torch.empty(B, C, device='cuda'), torch.empty(B, C, device='cuda')
-    L.call('hoig_inorm_fwd_fused', _p(x), 2, _p(gb), gb.data_ptr() + 4 * C, 2 * C, L.ACT_RELU, 0.0, None, 1e-5, _p(y), _p(mean), _p(rstd),
-           B, HW, C, st)
-    dx0, dgb0 = torch.empty_like(x), torch.empty_like(gb)
-    L.call('hoig_inorm_bwd_fused_add', _p(x), _p(mean), _p(rstd), 2, _p(gb), None, 2 * C, _p(y), _p(dy), L.ACT_RELU, 0.0, _p(add), _p(dx0),
-           _p(dgb0), dgb0.data_ptr() + 4 * C, B, HW, C, st)
-    dx1, dgb1 = torch.empty_like(x), torch.empty_like(gb)
-    col = torch.full((2 * C,), 0.5, device='cuda')                     # (accumulated INTO: starts non-zero)
-    L.call('hoig_inorm_bwd_fused_add_planes', _p(x), _p(mean), _p(rstd), 2, _p(gb), None, 2 * C, _p(y), _p(dy), L.ACT_RELU, 0.0, _p(add),
-           _p(dx1), _p(dgb1), dgb1.data_ptr() + 4 * C, _p(col), planes, B, HW, C, st)
-    torch.cuda.synchronize()
-
-    def as_planes(t):
-        return _split_reference(t).view(torch.int16)
-
-    if planes & 1:
-        assert torch.equal(dx1.view(torch.bfloat16).view(B, H, W, 2, C).view(torch.int16), as_planes(dx0))
-    else:
-        assert torch.equal(dx1, dx0)
-    if planes & 2:
-        assert torch.equal(dgb1.view(torch.bfloat16).view(B, H, W, 2, 2 * C).view(torch.int16), as_planes(dgb0))
-    else:
-        assert torch.equal(dgb1, dgb0)
-    want = 0.5 + dgb0.double().sum(dim=(0, 1, 2))
-    assert (col.double() - want).abs().max().item() <= 1e-5 * want.abs().max().item()
-    # a plane request the layout cannot hold
-    rc = L.lib.hoig_inorm_bwd_fused_add_planes(_p(x), _p(mean), _p(rstd), 2, _p(gb), None, 2 * C, _p(y), _p(dy), L.ACT_RELU, 0.0, None,
-                                               _p(dx1), _p(dgb1), dgb1.data_ptr() + 8 * C, None, 2, B, HW, C, st)
-    assert rc == L.EINVAL
-    rc = L.lib.hoig_inorm_bwd_fused_add_planes(_p(x), _p(mean), _p(rstd), 0, None, None, C, None, _p(dy), L.ACT_NONE, 0.0, None,
-                                               _p(dx1), None, None, _p(col), 0, B, HW, C, st)
-    assert rc == L.EINVAL
+def _tagged_conv(seed=21, B=2, H=32, W=32, Ci=64, Co=128):
+    from hoig_amd import nn as hnn, ops
+    g = torch.Generator(device='cuda').manual_seed(seed)
+    tree = hnn.ParamTree({'c.weight': (Co, Ci, 3, 3)}, torch.device('cuda'), {}, {})
+    with torch.no_grad():
+        tree.flat.copy_(torch.randn(tree.flat.shape, device='cuda', generator=g) * 0.05)
+    tree.version += 1
+    x = torch.randn(B, H, W, Ci, device='cuda', generator=g).requires_grad_(True)
+    y = ops.conv2d(x, tree.P['c.weight'], None, 1, 1, dead_bias=True)
+    assert getattr(y, '_hoig_split_grad', None) is not None              # eligible: the convolution hung a token on its output
+    return tree, x, y, g
 
 
-def test_spade_gamma_beta_convolution_reads_planes_from_the_norm_backward():
-    """mlp_shared activation -> the [gamma | beta] 3x3 convolution (live bias) -> SPADE modulation, with `split_grads` = 3 and 1: the
-    SPADE backward writes [dgamma | dbeta] as planes and sums their columns into the convolution's bias gradient; the convolution's
-    weight and data gradients read the planes.  Same arithmetic both ways."""
-    from hoig_amd import _lib as L, nn as hnn, ops
-    B, H, W, Cl, C = 4, 32, 32, 128, 256
+def test_a_tagged_output_with_a_second_consumer_raises_instead_of_mixing_planes_with_fp32():
+    """conv -> norm hands planes over through the bytes of an fp32 tensor.  If the convolution's output has a SECOND consumer
+    that is not a norm, autograd sums that consumer's fp32 gradient with the plane bits; the convolution's backward must notice that what
+    arrived is not the tensor the norm wrote, and raise -- never produce a gradient from the mixture."""
+    from hoig_amd import _lib as L, ops
     ops.set_precision('bf16x3:f16x2')
     try:
-        g = torch.Generator(device='cuda').manual_seed(13)
-        tree = hnn.ParamTree({'gb.weight': (2 * C, Cl, 3, 3), 'gb.bias': (2 * C,)}, torch.device('cuda'), {}, {})
-        with torch.no_grad():
-            tree.flat.copy_(torch.randn(tree.flat.shape, device='cuda', generator=g) * 0.03)
-        tree.version += 1
-        a0 = torch.randn(B, H, W, Cl, device='cuda', generator=g).relu()
-        x0 = torch.randn(B, H, W, C, device='cuda', generator=g)
-        gout = torch.randn(B, H, W, C, device='cuda', generator=g)
-        outs = {}
-        for split in (3, 1):
+        tree, x, y, g = _tagged_conv()
+        z = ops.instance_norm(y, act=L.ACT_RELU)
+        loss = z.sum() + (y * 0.5).sum()                                 # the second reader: a plain torch op
+        with pytest.raises(RuntimeError, match='second consumer'):
+            loss.backward()
+        ops.join_wgrad_streams()
+        torch.cuda.synchronize()
+        ops.check_split_grads_consumed()                                 # (the failed hand-off left nothing behind)
+    finally:
+        ops.set_precision('f32')
+
+
+def test_two_norms_on_one_tagged_output_fall_back_to_fp32_gradients():
+    """Two norms reading one tagged convolution output both count themselves on its token: neither writes planes, the engine sums two
+    fp32 gradients and the convolution's backward reads fp32 -- the result of the un-tagged path."""
+    from hoig_amd import _lib as L, ops
+    ops.set_precision('bf16x3:f16x2')
+    try:
+        outs = []
+        for split in (1, 0):
             L.set_tuning('split_grads', split)
-            tree.flat_grad.zero_()
-            a = a0.clone().requires_grad_(True)
-            x = x0.clone().requires_grad_(True)
-            gb = ops.conv2d(a, tree.P['gb.weight'], tree.P['gb.bias'], 1, 1)
-            assert (getattr(gb, '_hoig_split_grad_bias', None) is not None) == (split == 3)
-            z = ops.spade_norm_fused(x, gb, act=L.ACT_RELU)
+            g = torch.Generator(device='cuda').manual_seed(21)
+            from hoig_amd import nn as hnn
+            tree = hnn.ParamTree({'c.weight': (128, 64, 3, 3)}, torch.device('cuda'), {}, {})
+            with torch.no_grad():
+                tree.flat.copy_(torch.randn(tree.flat.shape, device='cuda', generator=g) * 0.05)
+            tree.version += 1
+            x = torch.randn(2, 32, 32, 64, device='cuda', generator=g).requires_grad_(True)
+            gout = torch.randn(2, 32, 32, 128, device='cuda', generator=g)
+            y = ops.conv2d(x, tree.P['c.weight'], None, 1, 1, dead_bias=True)
+            z = ops.instance_norm(y, act=L.ACT_RELU) + 2.0 * ops.instance_norm(y)
             (z * gout).sum().backward()
             ops.join_wgrad_streams()
             ops.check_split_grads_consumed()
             torch.cuda.synchronize()
-            outs[split] = (a.grad.clone(), x.grad.clone(), tree.flat_grad.clone(), tree.P['gb.bias'].grad.clone())
-        da3, dx3, dp3, db3 = outs[3]
-        da1, dx1, dp1, db1 = outs[1]
-        assert torch.equal(dx3, dx1)
-        assert (da3 - da1).abs().max().item() <= 4e-6 * da1.abs().max().item()
-        assert ((dp3 - dp1).norm() / dp1.norm()).item() < 2e-5
-        assert db1.abs().max().item() > 0 and (db3 - db1).abs().max().item() <= 1e-5 * db1.abs().max().item()
+            outs.append((x.grad.clone(), tree.flat_grad.clone()))
+        # (this small layer's data gradient runs on the flattened-axis kernel, whose atomic epilogue reorders fp32 sums)
+        assert (outs[0][0] - outs[1][0]).abs().max().item() <= 4e-6 * outs[1][0].abs().max().item()
+        assert ((outs[0][1] - outs[1][1]).norm() / outs[1][1].norm()).item() < 2e-5      # (fp32 atomics order)
     finally:
         L.set_tuning('split_grads', 1)
+        ops.set_precision('f32')
+
+
+def test_an_unconsumed_offer_is_reported_and_released():
+    """A norm wrote planes for a convolution whose backward then never ran (the graph was cut): check_split_grads_consumed reports it
+    and drops the tensor it pinned."""
+    from hoig_amd import _lib as L, ops
+    ops.set_precision('bf16x3:f16x2')
+    try:
+        tree, x, y, g = _tagged_conv()
+        z = ops.instance_norm(y, act=L.ACT_RELU)
+        torch.autograd.grad(z.sum(), y)                                  # stops at y: the convolution's backward does not run
+        with pytest.raises(RuntimeError, match='not consumed'):
+            ops.check_split_grads_consumed()
+        ops.check_split_grads_consumed()                                 # cleared
+    finally:
         ops.set_precision('f32')
 
 

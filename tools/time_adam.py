@@ -1,4 +1,4 @@
-"""Optimiser step + operand-plane refresh of the generator's flat buffer, timed alone: tuning key 'adam_pack' 0 (two launches) / 1."""
+"""Optimiser step + operand-plane refresh of the generator's flat buffer, timed alone: FusedAdam.fuse_planes False (two launches) / True."""
 import os
 import sys
 
@@ -18,7 +18,7 @@ tree = opt.tree
 print('parameters %.1f M, plane tiles %d, plain chunks %d' % (tree.flat.numel() / 1e6, tree._plane_tiles, tree._plain_chunks[1]))
 for r in range(3):
     for v in (0, 1):
-        L.set_tuning('adam_pack', v)
+        opt.fuse_planes = bool(v)
         opt.step(); tree._refresh_planes()
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
@@ -27,4 +27,4 @@ for r in range(3):
             tree._refresh_planes()
         e1.record()
         torch.cuda.synchronize()
-        print('adam_pack=%d  %.1f us per step + refresh' % (v, e0.elapsed_time(e1) * 100), flush=True)
+        print('fuse_planes=%d  %.1f us per step + refresh' % (v, e0.elapsed_time(e1) * 100), flush=True)
