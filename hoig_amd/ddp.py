@@ -12,6 +12,15 @@ at construction, gradients averaged over ranks once per optimiser step -- but de
     stream (the D step needs neither G's gradients nor G's new weights: trainer.py:460 detaches the fake image).
 The averaging factor 1/world is folded into the Adam kernel (grad_scale), not a separate pass.
 Works on CPU tensors with the gloo backend too (tests/test_ddp_gloo.py, world_size 2).
+
+Two exchange modes (`opt.ddp_mode`, env HOIG_DDP_MODE; VERDICT r5 item 6 -- NEITHER has been measured on more than one GPU):
+  * 'after' (default): every slice is queued when the backward has ended, on the side stream, and hides behind the D step;
+  * 'bucket': a slice is queued DURING the backward, as soon as it has received its last contribution -- what the reference's DDP
+    reducer hooks do with 25-MB buckets (trainer.py:426,433) -- on a communication stream that waits for exactly the streams that
+    wrote into it.  Which contribution is a slice's last is LEARNED: the first backward of a step signature counts the gradient
+    writes per slice (ops.set_grad_observer) and exchanges the old way; later backwards count down.  A write that arrives for a
+    slice already on the wire means the pattern changed under the same signature: that is raised, never summed twice.
+Same slices, same SUM, same order of Adam updates: the two modes are bit-identical (tests/test_ddp_gloo.py, tests/test_ddp_gpu.py).
 """
 import os
 
@@ -29,10 +38,11 @@ def _is_dist():
 # on top of the two-term backward's own 6e-3 -- an option for link-bound configurations, not the default (fp32, exact sum order
 # aside).
 _PAYLOAD = os.environ.get('HOIG_DDP_PAYLOAD', 'f32')
+_MODE = os.environ.get('HOIG_DDP_MODE', 'after')
 
 
 class GradSync(object):
-    def __init__(self, flat_param, flat_grad, bucket_bytes=64 << 20, group=None, force=None, payload=None):
+    def __init__(self, flat_param, flat_grad, bucket_bytes=64 << 20, group=None, force=None, payload=None, mode=None):
         """`force` (default: env HOIG_DDP_FORCE=1): run the collectives even in a world of one rank, so that the whole
         exchange path -- RCCL all-reduce per slice, stream ordering, sliced Adam -- executes on a single-GPU box
         (tests/test_ddp_rccl_gpu.py); a one-rank SUM leaves the gradients unchanged."""
@@ -50,25 +60,126 @@ class GradSync(object):
         if self.payload not in ('f32', 'bf16'):
             raise ValueError('gradient payload %r (f32 | bf16)' % self.payload)
         self._wire = None           # bf16 staging buffer of the whole gradient (allocated on first use)
+        self.mode = (mode or _MODE).lower()
+        if self.mode not in ('after', 'bucket'):
+            raise ValueError('ddp_mode %r (after | bucket)' % self.mode)
+        # 'bucket' state: learned write counts per step signature, the running backward's countdown and early launches
+        self._learned = {}
+        self._run = None
+        self._comm = None           # communication stream of the early launches (CUDA tensors only)
+        self.early_launches = 0     # (statistics: slices that went on the wire before the backward had ended, last backward)
 
-    def _submit(self):
-        """Queue the SUM all-reduce of every slice; returns one completion callback per slice."""
+    def _submit_one(self, i):
+        """Queue the SUM all-reduce of slice i behind the current stream; returns its completion callback."""
+        a, b = self.slices[i]
         if self.payload == 'f32':
-            handles = [dist.all_reduce(self.flat_grad[a:b], op=dist.ReduceOp.SUM, group=self.group, async_op=True)
-                       for a, b in self.slices]
-            return [h.wait for h in handles]
+            return dist.all_reduce(self.flat_grad[a:b], op=dist.ReduceOp.SUM, group=self.group, async_op=True).wait
         if self._wire is None:
             self._wire = torch.empty(self.flat_grad.numel(), dtype=torch.bfloat16, device=self.flat_grad.device)
-        waits = []
-        for a, b in self.slices:
-            self._wire[a:b].copy_(self.flat_grad[a:b])
-            h = dist.all_reduce(self._wire[a:b], op=dist.ReduceOp.SUM, group=self.group, async_op=True)
+        self._wire[a:b].copy_(self.flat_grad[a:b])
+        h = dist.all_reduce(self._wire[a:b], op=dist.ReduceOp.SUM, group=self.group, async_op=True)
 
-            def done(h=h, a=a, b=b):
-                h.wait()
-                self.flat_grad[a:b].copy_(self._wire[a:b])
-            waits.append(done)
-        return waits
+        def done():
+            h.wait()
+            self.flat_grad[a:b].copy_(self._wire[a:b])
+        return done
+
+    def _submit(self):
+        """Queue the SUM all-reduce of every slice not yet on the wire; returns one completion callback per slice, in slice order."""
+        early, self._early = getattr(self, '_early', None) or {}, None
+        return [early[i] if i in early else self._submit_one(i) for i in range(len(self.slices))]
+
+    # ---- 'bucket' mode: slices go on the wire while the backward is still running
+    def _slices_of(self, p):
+        g = p.grad
+        off = (g.data_ptr() - self.flat_grad.data_ptr()) // self.flat_grad.element_size()
+        if off < 0 or off >= self.flat_grad.numel():
+            return ()                                   # a parameter of another network
+        per = self.slices[0][1] - self.slices[0][0]
+        return range(off // per, (off + p.numel() - 1) // per + 1)
+
+    def begin_backward(self, key):
+        """Call right before the backward whose gradients this object exchanges; `key`: anything that identifies the shape of that
+        backward (a change of key starts a new learning pass).  No-op unless the mode is 'bucket' and the exchange is active."""
+        if self.mode != 'bucket' or not self.active:
+            return
+        from . import ops
+        if ops.capturing():
+            return                                      # (a captured step exchanges between its two graphs: Trainer._graph_step)
+        learned = self._learned.get(key)
+        self._run = dict(key=key, counts=[0] * len(self.slices), left=None if learned is None else list(learned), prev=None,
+                         launched={}, prev_observer=None, writers=[set() for _ in self.slices])
+        self.early_launches = 0
+        self._run['prev_observer'] = ops.set_grad_observer(self._on_grad)
+
+    def _on_grad(self, p):
+        run = self._run
+        touched = self._slices_of(p)
+        if not touched:
+            if run['prev_observer'] is not None:
+                run['prev_observer'](p)
+            return
+        self._retire_previous()            # the kernels of the previous write have been issued by now
+        if run['left'] is not None:
+            for i in touched:
+                if i in run['launched']:
+                    raise RuntimeError('ddp_mode=bucket: slice %d of the gradient buffer received a contribution after it had gone on '
+                                       'the wire -- the backward changed under an unchanged step signature' % i)
+        stream = torch.cuda.current_stream(self.flat_grad.device) if self.flat_grad.is_cuda else None
+        run['prev'] = (touched, stream)
+
+    def _retire_previous(self):
+        run = self._run
+        if run['prev'] is None:
+            return
+        touched, stream = run['prev']
+        run['prev'] = None
+        for i in touched:
+            run['counts'][i] += 1
+            if stream is not None:
+                run['writers'][i].add(stream)
+            if run['left'] is not None:
+                run['left'][i] -= 1
+                if run['left'][i] == 0:
+                    self._launch_early(i)
+
+    def _launch_early(self, i):
+        """Slice i is final: every kernel that writes into it has been issued -- on the streams of the chains whose layers share the
+        slice, or on a weight-gradient side stream."""
+        writers = self._run['writers'][i]
+        if not self.flat_grad.is_cuda:                  # CPU tensors (gloo): nothing to order
+            self._run['launched'][i] = self._submit_one(i)
+        else:
+            from . import ops
+            if self._comm is None:
+                self._comm = ops.new_stream(self.flat_grad.device, 'opt')
+            # wait_stream = "everything issued on that stream so far", which contains the slice's writes (and, harmlessly, whatever
+            # the chain has queued since)
+            for s in list(writers) + ops.wgrad_side_streams():
+                self._comm.wait_stream(s)
+            with torch.cuda.stream(self._comm):
+                self._run['launched'][i] = self._submit_one(i)
+        self.early_launches += 1
+
+    def end_backward(self):
+        """Call when the backward has returned (and its streams have been joined): retires the last write, stores what was learned,
+        and hands the early launches to the next _submit()."""
+        run, self._run = self._run, None
+        if run is None:
+            return
+        from . import ops
+        self._run = run
+        try:
+            self._retire_previous()
+        finally:
+            self._run = None
+            ops.set_grad_observer(run['prev_observer'])
+        if run['left'] is None:
+            self._learned[run['key']] = run['counts']
+        elif any(run['left']):
+            # fewer writes than learned (a branch of the network did not run): forget, exchange the rest the old way, learn again
+            self._learned.pop(run['key'], None)
+        self._early = run['launched']
 
     def broadcast_params(self, src=0):
         """DDP-constructor behaviour: make rank 0's (unseeded, CPU-RNG) initialisation the one everybody uses
@@ -104,9 +215,9 @@ class FlatDDP(object):
     and saves with the ``module.`` key prefix the reference's DDP checkpoints carry (trainer.py:555-556,
     base_model.py:108-116)."""
 
-    def __init__(self, module, bucket_bytes=64 << 20, payload=None):
+    def __init__(self, module, bucket_bytes=64 << 20, payload=None, mode=None):
         self.module = module
-        self.sync = GradSync(module.flat, module.flat_grad, bucket_bytes, payload=payload)
+        self.sync = GradSync(module.flat, module.flat_grad, bucket_bytes, payload=payload, mode=mode)
         self.sync.broadcast_params(0)
 
     def forward(self, *a, **k):

@@ -139,8 +139,9 @@ class Trainer(BaseModel):
         self._G = self._create_generator()
         self._G.init_weights()
         payload = getattr(self._opt, 'ddp_payload', None)        # None: HOIG_DDP_PAYLOAD / fp32 (hoig_amd/ddp.py)
-        if use_ddp:
-            self._G = FlatDDP(self._G, payload=payload)
+        mode = getattr(self._opt, 'ddp_mode', None)              # None: HOIG_DDP_MODE / 'after'; 'bucket': slices go on the wire during
+        if use_ddp:                                              # G's backward (D's 28 MB are one slice: nothing to bucket)
+            self._G = FlatDDP(self._G, payload=payload, mode=mode)
         self._D = self._create_discriminator()
         self._D.init_weights()
         if use_ddp:
@@ -415,7 +416,14 @@ class Trainer(BaseModel):
             netD.set_requires_grad(True)
             self._phase_d(fake_tsf_imgs, ev_fwd, join=False)
         ops.pause_wgrad_side(generator_forks_streams())     # G's backward is several concurrent chains already
-        loss_G.backward()
+        bucketed = self._sync_active()
+        if bucketed:               # (ddp_mode 'bucket': counts / counts down the gradient writes per slice; a no-op in mode 'after')
+            self._G.sync.begin_backward((self._sig, ops.precision, ops.precision_dgrad, ops.precision_wgrad))
+        try:
+            loss_G.backward()
+        finally:
+            if bucketed:
+                self._G.sync.end_backward()
         ops.check_split_grads_consumed()
         ops.pause_wgrad_side(False)
         self._join_backward_streams()

@@ -140,11 +140,25 @@ def pack_weight(w, transposed=False):
     return out
 
 
+_grad_observer = None
+
+
+def set_grad_observer(fn):
+    """`fn(p)` is called whenever a backward is about to accumulate into the flat-buffer gradient of parameter `p` (the kernels that do
+    so are launched right after, on the current stream or on the weight-gradient side stream).  hoig_amd/ddp.py's bucketed exchange
+    uses it to learn when a slice of the gradient buffer has received its last contribution.  Returns the previous observer."""
+    global _grad_observer
+    prev, _grad_observer = _grad_observer, fn
+    return prev
+
+
 def _grad_target(p):
     """(buffer to accumulate into, returned-through-autograd?)"""
     if getattr(p, '_hoig_flat', False):
         if p.grad is None:
             raise RuntimeError('flat parameter without a gradient view')
+        if _grad_observer is not None:
+            _grad_observer(p)
         return p.grad, False
     if p.dim() == 4:
         g = torch.empty_strided(tuple(p.shape), p.stride(), dtype=p.dtype, device=p.device).zero_()
@@ -438,6 +452,11 @@ def _wgrad_hold(side, tensors):
     _wgrad_pending.append((ev, tensors))
     while _wgrad_pending and _wgrad_pending[0][0].query():
         _wgrad_pending.popleft()
+
+
+def wgrad_side_streams():
+    """The weight-gradient side streams in use (hoig_amd/ddp.py records events on them)."""
+    return list(_wgrad_streams.values())
 
 
 def join_wgrad_streams():

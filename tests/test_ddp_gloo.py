@@ -98,3 +98,78 @@ def test_flat_ddp_broadcast_and_allreduce_world2():
     assert np.array_equal(g0, want) and np.array_equal(g1, want)
     assert s0 == 0.5 and s1 == 0.5                      # the mean is applied by the optimiser (grad_scale)
     assert all(k.startswith('module.') for k in k0)
+
+
+def _worker_bucket(rank, world, port, q):
+    """Three "backwards" over a flat buffer of several slices, the gradient writes announced through ops' observer hook exactly as the
+    kernels' wrappers announce them (ops._grad_target): mode 'bucket' must learn on the first, launch slices early on the later
+    ones, and leave the same sums as mode 'after'."""
+    os.environ['MASTER_ADDR'] = '127.0.0.1'
+    os.environ['MASTER_PORT'] = str(port)
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    from hoig_amd import ops
+    from hoig_amd.ddp import GradSync
+    from hoig_amd.nn import ParamTree
+    from hoig_amd.models.networks.schema import discriminator_schema
+    out = {}
+    for mode in ('after', 'bucket'):
+        tree = ParamTree(discriminator_schema(19, 8, 2).shapes, torch.device('cpu'))
+        sync = GradSync(tree.flat, tree.flat_grad, bucket_bytes=4096, mode=mode)
+        assert len(sync.slices) > 3
+        params = list(tree.P.values())[::-1]                  # a backward meets the last layers first
+        sums, early = [], []
+        for step in range(3):
+            g = torch.Generator().manual_seed(1000 * step + rank)
+            tree.flat_grad.zero_()
+            sync.begin_backward('sig')
+            for p in params:
+                grad, through_autograd = ops._grad_target(p)          # (announces the write when an observer is installed)
+                assert not through_autograd
+                grad.add_(torch.randn(p.shape, generator=g))          # "the kernel"
+            sync.end_backward()
+            early.append(sync.early_launches)
+            got = [ab for ab in sync.iter_all_reduce()]
+            assert got == sync.slices
+            sums.append(tree.flat_grad.clone())
+        # a write that arrives after its slice went on the wire must be refused, not summed twice
+        late = None
+        if mode == 'bucket':
+            sync.begin_backward('sig')
+            try:
+                for p in params + params[:1]:
+                    ops._grad_target(p)
+            except RuntimeError as ex:
+                late = str(ex)
+            sync.end_backward()
+            for _ in sync.iter_all_reduce():                  # (every rank drains the same collectives)
+                pass
+        out[mode] = ([s.numpy().copy() for s in sums], early, late)
+        assert ops._grad_observer is None
+    q.put((rank, out))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_bucket_mode_matches_after_mode_world2():
+    """opt.ddp_mode = 'bucket' (VERDICT r5 item 6): slices are exchanged while the backward is still running -- after a learning pass --
+    and the result is bit-identical to the default mode's; a changed write pattern is an error."""
+    world, port = 2, _free_port()
+    ctx = mp.get_context('spawn')
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_worker_bucket, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = dict(q.get(timeout=180) for _ in range(world))
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    import numpy as np
+    for rank in range(world):
+        after, bucket = res[rank]['after'], res[rank]['bucket']
+        for a, b in zip(after[0], bucket[0]):
+            assert np.array_equal(a, b)
+        assert after[1] == [0, 0, 0]
+        assert bucket[1][0] == 0 and bucket[1][1] > 3 and bucket[1][2] == bucket[1][1]      # learned, then early launches
+        assert bucket[2] is not None and 'after it had gone on the wire' in bucket[2]
+    for a, b in zip(res[0]['bucket'][0], res[1]['bucket'][0]):
+        assert np.array_equal(a, b)                           # both ranks hold the same sums

@@ -100,7 +100,7 @@ def test_rccl_exchange_with_captured_step_and_bf16_payload():
         assert np.isfinite(m16[k]).all() and np.linalg.norm(m16[k]) > 0
 
 
-def _run(use_ddp, port, q):
+def _run(use_ddp, port, q, mode=None, steps=None):
     import torch.distributed as dist
     from common import product_trainer
     from hoig_amd import ops
@@ -123,15 +123,18 @@ def _run(use_ddp, port, q):
             return real_bc(t, *a, **k)
         dist.all_reduce, dist.broadcast = counted_ar, counted_bc
     ops.set_precision('bf16x3')
-    m = product_trainer('generator_spade_attn', BATCH, SIDE, use_ddp=use_ddp)
+    m = product_trainer('generator_spade_attn', BATCH, SIDE, use_ddp=use_ddp, **(dict(ddp_mode=mode) if mode else {}))
     if use_ddp:
         assert dist.get_backend() == 'nccl' and m._G.sync.active and m._D.sync.active and len(m._G.sync.slices) > 4
+        assert m._G.sync.mode == (mode or 'after')
     errs = []
     g = m._net(m._G)
     mom = None
-    for s in range(STEPS):
+    for s in range(steps or STEPS):
         m.optimize_parameters()
         errs.append(dict(m.get_current_errors()))
+        if use_ddp:
+            calls.setdefault('early', []).append(m._G.sync.early_launches)
         if s == 0:            # Adam's first moment after ONE step = (1 - beta1) * (exchanged) gradient of the seeded weights
             torch.cuda.synchronize()
             mom = {k: v.clone() for k, v in g.export_dict(m._optimizer_G.exp_avg).items() if k in PROBE}
@@ -144,10 +147,10 @@ def _run(use_ddp, port, q):
         dist.destroy_process_group()
 
 
-def _spawn(use_ddp):
+def _spawn(use_ddp, mode=None, steps=None):
     ctx = mp.get_context('spawn')
     q = ctx.Queue()
-    p = ctx.Process(target=_run, args=(use_ddp, _free_port(), q))
+    p = ctx.Process(target=_run, args=(use_ddp, _free_port(), q, mode, steps))
     p.start()
     res = q.get(timeout=900)
     p.join(timeout=120)
@@ -179,3 +182,21 @@ def test_rccl_exchange_path_equals_plain_step_and_oracle():
         # 2 steps from the plain run's
         assert np.abs(w_ddp[k] - w_one[k]).max() <= 2.2 * STEPS * 2e-4, k
     assert abs(dsum_ddp - dsum_one) <= 1e-3 * dsum_one
+
+
+def test_rccl_bucket_mode_launches_slices_during_the_backward():
+    """opt.ddp_mode = 'bucket' on RCCL (world 1, exchange forced): the first step learns the gradient writes per slice and exchanges
+    after the backward; from the second step on slices go on the wire while G's backward is still being issued -- every slice but
+    the ones the first layers' weight gradients close -- and the steps' losses stay those of the plain run."""
+    e_b, _, w_b, _, calls = _spawn(True, 'bucket', 3)
+    e_one, _, _, _, _ = _spawn(False, None, 3)
+    n_g = (183501729 * 4 + (64 << 20) - 1) // (64 << 20)
+    print('early launches per step: %s of %d slices' % (calls['early'], n_g))
+    assert calls['early'][0] == 0 and calls['early'][1] >= n_g // 2 and calls['early'][2] == calls['early'][1]
+    assert calls['all_reduce'] >= 3 * (n_g + 1)                      # every slice still travels exactly once per step
+    assert calls['all_reduce'] <= 3 * (n_g + 1) + 2
+    for s in range(3):
+        for k, want in e_one[s].items():
+            assert abs(e_b[s][k] - want) <= (1e-3 if s < 2 else 5e-3) * max(abs(want), 1e-2), (s, k, e_b[s][k], want)
+    for k in PROBE:
+        assert np.isfinite(w_b[k]).all()

@@ -20,8 +20,8 @@ torch.cuda.set_device(0)
 dist.init_process_group('nccl', rank=0, world_size=1, device_id=torch.device('cuda', 0))
 
 
-def run(tag, use_ddp, graph, payload=None):
-    opt = opt_namespace(hip_graph=graph, ddp_payload=payload)
+def run(tag, use_ddp, graph, payload=None, mode=None):
+    opt = opt_namespace(hip_graph=graph, ddp_payload=payload, ddp_mode=mode)
     torch.manual_seed(8)
     with contextlib.redirect_stdout(io.StringIO()), contextlib.redirect_stderr(io.StringIO()):
         m = ModelsFactory.get_by_name('trainer', opt, use_ddp=use_ddp)
@@ -38,8 +38,10 @@ def run(tag, use_ddp, graph, payload=None):
         host += time.perf_counter() - h0
     torch.cuda.synchronize()
     dt = (time.perf_counter() - t0) / steps
-    print('%-44s %7.2f ms/step   host issue %6.2f ms/step   cores available %d' % (tag, dt * 1e3, host / steps * 1e3,
-                                                                                 len(os.sched_getaffinity(0))), flush=True)
+    early = (', %d of %d slices on the wire before the backward ended' % (m._G.sync.early_launches, len(m._G.sync.slices))
+             if use_ddp and mode == 'bucket' else '')
+    print('%-50s %7.2f ms/step   host issue %6.2f ms/step   cores available %d%s' % (tag, dt * 1e3, host / steps * 1e3,
+                                                                                   len(os.sched_getaffinity(0)), early), flush=True)
     del m
     torch.cuda.empty_cache()
 
@@ -48,5 +50,9 @@ run('plain, captured step (one graph)', False, True)
 run('plain, eager', False, False)
 run('RCCL world 1 forced, captured (2 graphs), fp32', True, True, 'f32')
 run('RCCL world 1 forced, captured (2 graphs), bf16', True, True, 'bf16')
-run('RCCL world 1 forced, eager, fp32', True, False, 'f32')
+run('RCCL world 1 forced, eager, fp32, mode after', True, False, 'f32', 'after')
+run('RCCL world 1 forced, eager, fp32, mode bucket', True, False, 'f32', 'bucket')
+run('plain, eager (again)', False, False)
+run('RCCL world 1 forced, eager, fp32, mode after', True, False, 'f32', 'after')
+run('RCCL world 1 forced, eager, fp32, mode bucket', True, False, 'f32', 'bucket')
 dist.destroy_process_group()

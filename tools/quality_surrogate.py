@@ -137,6 +137,7 @@ def main():
     ap.add_argument('--threads', type=int, nargs=2, default=None, help='intra-op threads of the two oracle runs')
     ap.add_argument('--json', default=None)
     ap.add_argument('--save-hip', default=None, help='run the HIP side only and save its images (a GPU box needs no oracle run for that)')
+    ap.add_argument('--oracle-cache', default=None, help='file that keeps the two oracle runs (made if absent)')
     ap.add_argument('--load-hip', default=None, help='take the HIP side from a file written by --save-hip (the oracle runs need no GPU)')
     a = ap.parse_args()
     log = lambda s: print(s, flush=True)
@@ -155,8 +156,16 @@ def main():
         hip['precision'] = os.environ.get('HOIG_PRECISION', 'bf16x3:f16x2')
         torch.save(hip, a.save_hip)
         return
-    ora = oracle_run(a.n, a.side, a.batch, a.steps, ta, log=log)
-    orb = oracle_run(a.n, a.side, a.batch, a.steps, tb, log=log)
+    if a.oracle_cache and os.path.exists(a.oracle_cache):
+        c = torch.load(a.oracle_cache)
+        assert c['args'] == [a.n, a.steps, a.side, a.batch, ta, tb], 'the cached oracle runs used other arguments: %r' % (c['args'],)
+        ora, orb = c['a'], c['b']
+        log('oracle runs (%d / %d threads) loaded from %s' % (ta, tb, a.oracle_cache))
+    else:
+        ora = oracle_run(a.n, a.side, a.batch, a.steps, ta, log=log)
+        orb = oracle_run(a.n, a.side, a.batch, a.steps, tb, log=log)
+        if a.oracle_cache:
+            torch.save(dict(a=ora, b=orb, args=[a.n, a.steps, a.side, a.batch, ta, tb]), a.oracle_cache)
     sd_vgg = seeded_state(GEN)[3]
     rows = report(hip, ora, orb, sd_vgg, log)
     if a.json:
