@@ -160,6 +160,12 @@ def gen_forward_latency(opt, batch, side, iters=10):
         except Exception as ex:          # report, do not hide
             out['hipgraph_error'] = repr(ex)[:200]
     out['batch'] = batch
+    from hoig_amd import ops as _ops
+    with torch.no_grad():
+        with _ops.inference_forward_precision(getattr(opt, 'eval_precision', 'f16f6')) as switched:
+            out['arithmetic'] = ('f16f6: 3x3 stride-1 layers on fp16 hi*hi + two block-scaled fp6 cross terms (1.6 MFMA units per product), the '
+                                 'other layers on three fp16 terms; opt.eval_precision (no backward follows an eval.py forward)' if switched
+                                 else 'the training forward\'s (%s)' % [k for k, v in _ops._PREC.items() if v == _ops.precision][0])
     out['gflop_per_img'] = 787.2 * (side / 256.0) ** 2
     best = out.get('hipgraph_ms_per_img', out['eager_ms_per_img'])
     out['tflops'] = round(out['gflop_per_img'] / best, 2)

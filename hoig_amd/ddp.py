@@ -68,6 +68,10 @@ class GradSync(object):
         self._run = None
         self._comm = None           # communication stream of the early launches (CUDA tensors only)
         self.early_launches = 0     # (statistics: slices that went on the wire before the backward had ended, last backward)
+        # test hook (HOIG_DDP_CHECK=1, one rank): the sum of every early slice when it went on the wire; verify_early_slices() compares
+        # it with the slice after the backward -- a write that landed after the launch shows as a difference
+        self._check = {} if os.environ.get('HOIG_DDP_CHECK', '0') == '1' else None
+        self.check_failures = 0
 
     def _submit_one(self, i):
         """Queue the SUM all-reduce of slice i behind the current stream; returns its completion callback."""
@@ -107,41 +111,52 @@ class GradSync(object):
         if ops.capturing():
             return                                      # (a captured step exchanges between its two graphs: Trainer._graph_step)
         learned = self._learned.get(key)
-        self._run = dict(key=key, counts=[0] * len(self.slices), left=None if learned is None else list(learned), prev=None,
+        self._run = dict(key=key, counts=[0] * len(self.slices), left=None if learned is None else list(learned), pending=[],
                          launched={}, prev_observer=None, writers=[set() for _ in self.slices])
         self.early_launches = 0
         self._run['prev_observer'] = ops.set_grad_observer(self._on_grad)
 
     def _on_grad(self, p):
+        """ops' observer: p = a parameter whose flat gradient the running backward function is about to write; None = a new backward
+        function begins, so the kernels of every write announced so far have been issued (ops._grad_epoch)."""
         run = self._run
+        if p is None:
+            self._retire_pending()
+            if run['prev_observer'] is not None:
+                run['prev_observer'](None)
+            return
         touched = self._slices_of(p)
         if not touched:
             if run['prev_observer'] is not None:
                 run['prev_observer'](p)
             return
-        self._retire_previous()            # the kernels of the previous write have been issued by now
         if run['left'] is not None:
             for i in touched:
                 if i in run['launched']:
                     raise RuntimeError('ddp_mode=bucket: slice %d of the gradient buffer received a contribution after it had gone on '
                                        'the wire -- the backward changed under an unchanged step signature' % i)
         stream = torch.cuda.current_stream(self.flat_grad.device) if self.flat_grad.is_cuda else None
-        run['prev'] = (touched, stream)
+        run['pending'].append((touched, stream))
 
-    def _retire_previous(self):
+    def _retire_pending(self):
         run = self._run
-        if run['prev'] is None:
-            return
-        touched, stream = run['prev']
-        run['prev'] = None
-        for i in touched:
-            run['counts'][i] += 1
-            if stream is not None:
-                run['writers'][i].add(stream)
-            if run['left'] is not None:
-                run['left'][i] -= 1
-                if run['left'][i] == 0:
-                    self._launch_early(i)
+        pending, run['pending'] = run['pending'], []
+        seen = []
+        for touched, stream in pending:
+            for i in touched:
+                run['counts'][i] += 1
+                if stream is not None:
+                    run['writers'][i].add(stream)
+                if run['left'] is not None:
+                    run['left'][i] -= 1
+                    if i not in seen:
+                        seen.append(i)
+        for i in seen:                                  # (after the whole batch: a backward announces its writes, then launches them)
+            if run['left'][i] == 0:
+                self._launch_early(i)
+            elif run['left'][i] < 0:
+                raise RuntimeError('ddp_mode=bucket: slice %d of the gradient buffer received more contributions than the learning '
+                                   'pass counted -- the backward changed under an unchanged step signature' % i)
 
     def _launch_early(self, i):
         """Slice i is final: every kernel that writes into it has been issued -- on the streams of the chains whose layers share the
@@ -158,6 +173,9 @@ class GradSync(object):
             for s in list(writers) + ops.wgrad_side_streams():
                 self._comm.wait_stream(s)
             with torch.cuda.stream(self._comm):
+                if self._check is not None:             # (test hook: what the slice held when it went on the wire)
+                    a, b = self.slices[i]
+                    self._check[i] = self.flat_grad[a:b].double().sum()
                 self._run['launched'][i] = self._submit_one(i)
         self.early_launches += 1
 
@@ -170,7 +188,7 @@ class GradSync(object):
         from . import ops
         self._run = run
         try:
-            self._retire_previous()
+            self._retire_pending()
         finally:
             self._run = None
             ops.set_grad_observer(run['prev_observer'])
@@ -180,6 +198,19 @@ class GradSync(object):
             # fewer writes than learned (a branch of the network did not run): forget, exchange the rest the old way, learn again
             self._learned.pop(run['key'], None)
         self._early = run['launched']
+
+    def verify_early_slices(self):
+        """HOIG_DDP_CHECK=1, world of one rank (the SUM is the identity): every slice that went on the wire early must still hold what
+        it held then.  Host-synchronising; called by the tests after the step's exchange has been waited for."""
+        if self._check is None:
+            return 0
+        bad = 0
+        for i, want in self._check.items():
+            a, b = self.slices[i]
+            bad += int(self.flat_grad[a:b].double().sum().item() != want.item())
+        self._check.clear()
+        self.check_failures += bad
+        return bad
 
     def broadcast_params(self, src=0):
         """DDP-constructor behaviour: make rank 0's (unseeded, CPU-RNG) initialisation the one everybody uses

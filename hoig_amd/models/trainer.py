@@ -348,6 +348,15 @@ class Trainer(BaseModel):
         self._net(self._D).wait_pending()
 
     def forward(self, keep_data_for_visuals=False, return_estimates=False):
+        if not self._is_train and not torch.is_grad_enabled():
+            # generator-only inference (eval.py:59-65; BASELINE.json configs[4]): no backward follows, so the forward may run on the
+            # arithmetic that is bounded by north_star's output tolerance alone (opt.eval_precision, default 'f16f6'; 'same': the
+            # training forward's)
+            with ops.inference_forward_precision(getattr(self._opt, 'eval_precision', 'f16f6')):
+                return self._forward(keep_data_for_visuals)
+        return self._forward(keep_data_for_visuals)
+
+    def _forward(self, keep_data_for_visuals=False):
         self._wait_g()
         n = self._n
         outs = self._G.forward_nhwc(n['input_G_bg'], n['src_obj_rgb'], n['tsf_obj_rgb'], n['src_hand_rgb'],

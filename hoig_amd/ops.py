@@ -43,6 +43,24 @@ def set_precision(name):
 
 set_precision(os.environ.get('HOIG_PRECISION', 'f32'))
 
+
+@contextlib.contextmanager
+def inference_forward_precision(name='f16f6'):
+    """Forward-only launches (eval mode under torch.no_grad(): eval.py:59-65) on a cheaper forward arithmetic than the training
+    forward's.  north_star bounds the OUTPUTS (1e-3); `f16f6` -- fp16 hi*hi plus the two cross terms on block-scaled fp6 MFMAs, 1.6
+    MFMA units per product instead of 3 -- stays inside that bound by 5x at 256 x 256 (tests/test_configs_gpu.py) and was kept out of
+    the TRAINING default only for what its forward error does to the gradients; a forward without a backward
+    has none.  Applies only where the module-level forward is the three-term default: an explicit choice ('f32', 'f16x2', ...) stays."""
+    global precision
+    if name in (None, '', 'same') or precision != L.PREC_BF16X3 or torch.is_grad_enabled():
+        yield False
+        return
+    prev, precision = precision, _PREC[name]
+    try:
+        yield True
+    finally:
+        precision = prev
+
 # Forward arithmetic per sub-network (VERDICT r3 item 7): 'vgg' and 'd' do not sit inside the 45-layer generator chain whose error
 # growth forces three forward terms.  name -> HOIG_PREC_* of that sub-network's convolution FORWARDS (their backward then follows
 # the forward's arithmetic: _bwd_descs); names without an entry use the module-level `precision`.
@@ -145,11 +163,20 @@ _grad_observer = None
 
 def set_grad_observer(fn):
     """`fn(p)` is called whenever a backward is about to accumulate into the flat-buffer gradient of parameter `p` (the kernels that do
-    so are launched right after, on the current stream or on the weight-gradient side stream).  hoig_amd/ddp.py's bucketed exchange
-    uses it to learn when a slice of the gradient buffer has received its last contribution.  Returns the previous observer."""
+    so are launched before that backward returns, on the current stream or on the weight-gradient side stream), and `fn(None)` when the
+    next such backward begins (_grad_epoch).  hoig_amd/ddp.py's bucketed exchange uses it to learn when a slice of the gradient buffer
+    has received its last contribution.  Returns the previous observer."""
     global _grad_observer
     prev, _grad_observer = _grad_observer, fn
     return prev
+
+
+def _grad_epoch():
+    """FIRST statement of every backward that accumulates into flat-buffer gradients: tells the observer that a new backward
+    begins, i.e. that the kernels of every gradient write announced so far have been issued (a backward may announce several writes
+    before it launches the first of them: bias + weight, the four parameters of the attention)."""
+    if _grad_observer is not None:
+        _grad_observer(None)
 
 
 def _grad_target(p):
@@ -606,6 +633,7 @@ class _Conv(Function):
 
     @staticmethod
     def backward(ctx, dy, dxr=None):
+        _grad_epoch()
         x, w, b, y = ctx.saved_tensors
         d = ctx.d
         if dy is None:                      # (fork: only the pass-through output was used)
@@ -757,6 +785,7 @@ class _ConvPair(Function):
 
     @staticmethod
     def backward(ctx, dya, dyb, dxra=None, dxrb=None):
+        _grad_epoch()
         xa, xb, wa, wb, ba, bb = ctx.saved_tensors
         if dya is None or dyb is None:
             raise RuntimeError('conv2d_pair: both outputs must be used (a grouped launch has no half)')
@@ -858,6 +887,7 @@ class _ConvCat2(Function):
 
     @staticmethod
     def backward(ctx, dy):
+        _grad_epoch()
         x1, x2, w = ctx.saved_tensors
         C1 = x1.shape[-1]
         dy = dy.contiguous()
@@ -980,6 +1010,7 @@ class _ConvHeads(Function):
 
     @staticmethod
     def backward(ctx, *douts):
+        _grad_epoch()
         x, w = ctx.saved_tensors[:2]
         ys = ctx.saved_tensors[2:]
         splits, acts = ctx.cfg
@@ -1105,6 +1136,7 @@ class _INorm(Function):
 
     @staticmethod
     def backward(ctx, dy):
+        _grad_epoch()
         x, mean, rstd, p0, p1, y = ctx.saved_tensors
         mode, act, slope, B, HW, C, has_res = ctx.cfg
         dy = dy.contiguous()
@@ -1584,6 +1616,7 @@ class _AttnSourceConv(Function):
 
     @staticmethod
     def backward(ctx, dgs, dsrc_r=None):
+        _grad_epoch()
         ws, spad = ctx.saved_tensors
         ds_dg, ds_wg = ctx.descs
         B, H, W, C = ctx.shape
@@ -1654,6 +1687,7 @@ class _LocalAttn(Function):
 
     @staticmethod
     def backward(ctx, dout, dsrc_r=None, dtgt_r=None):
+        _grad_epoch()
         source, flow, wt, b1, w2, b2, tpad, hidden, attn, kf = ctx.saved_tensors
         dt_dg, dt_wg = ctx.descs
         B, H, W, C = ctx.shape

@@ -51,9 +51,12 @@ def test_config5_eval_forward_b32_hipgraph_replay():
     first = synthetic.make_inputs(B, S, seed=SEEDS['inputs'])
     m = product_trainer('generator_spade_attn', B, S, inputs=first)
     m.set_eval()
+    from hoig_amd import ops, _lib as L
     with torch.no_grad():
+        with ops.inference_forward_precision(getattr(m._opt, 'eval_precision', 'f16f6')) as switched:
+            assert switched and ops.precision == L.PREC_F16F6      # round 6: eval.py's forward runs on fp16 + fp6 cross terms by default
+        assert ops.precision == L.PREC_BF16X3
         eager = [o.clone() for o in m.forward()]
-        from hoig_amd import ops
         graph = torch.cuda.CUDAGraph()
         with ops.graph_capture(graph):
             outs = m.forward()
@@ -244,7 +247,7 @@ def test_eval_forward_with_and_without_the_loader_norm():
     `norm_in`, default on; ops.conv2d_after_norm) against the same forward with every norm as a pass of its own: every output within
     1e-4 (a re-association of fp32 operations inside the 3-term arithmetic), and the fused forward launches fewer norm kernels."""
     from hoig_amd import _lib as L
-    m = product_trainer('generator_spade_attn', 4, 256)
+    m = product_trainer('generator_spade_attn', 4, 256, eval_precision='same')      # (the loader norm sits in the three-term kernel)
     m.set_eval()
     outs = {}
     prev = L.set_tuning('norm_in', -1)

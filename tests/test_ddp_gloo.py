@@ -122,10 +122,15 @@ def _worker_bucket(rank, world, port, q):
             g = torch.Generator().manual_seed(1000 * step + rank)
             tree.flat_grad.zero_()
             sync.begin_backward('sig')
-            for p in params:
-                grad, through_autograd = ops._grad_target(p)          # (announces the write when an observer is installed)
-                assert not through_autograd
-                grad.add_(torch.randn(p.shape, generator=g))          # "the kernel"
+            for k in range(0, len(params), 2):
+                ops._grad_epoch()                                     # a new backward function begins ...
+                targets = []
+                for p in params[k:k + 2]:                             # ... announces its writes (weight + bias) FIRST ...
+                    grad, through_autograd = ops._grad_target(p)
+                    assert not through_autograd
+                    targets.append((p, grad))
+                for p, grad in targets:                               # ... and launches "the kernels" afterwards
+                    grad.add_(torch.randn(p.shape, generator=g))
             sync.end_backward()
             early.append(sync.early_launches)
             got = [ab for ab in sync.iter_all_reduce()]
@@ -137,6 +142,7 @@ def _worker_bucket(rank, world, port, q):
             sync.begin_backward('sig')
             try:
                 for p in params + params[:1]:
+                    ops._grad_epoch()
                     ops._grad_target(p)
             except RuntimeError as ex:
                 late = str(ex)

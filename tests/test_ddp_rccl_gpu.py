@@ -106,7 +106,7 @@ def _run(use_ddp, port, q, mode=None, steps=None):
     from hoig_amd import ops
     calls = dict(all_reduce=0, broadcast=0, bytes=0)
     if use_ddp:
-        os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), HOIG_DDP_FORCE='1',
+        os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), HOIG_DDP_FORCE='1', HOIG_DDP_CHECK='1' if mode == 'bucket' else '0',
                           HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get('HSA_ENABLE_IPC_MODE_LEGACY', '0'))
         torch.cuda.set_device(0)
         dist.init_process_group('nccl', rank=0, world_size=1, device_id=torch.device('cuda', 0))
@@ -135,6 +135,10 @@ def _run(use_ddp, port, q, mode=None, steps=None):
         errs.append(dict(m.get_current_errors()))
         if use_ddp:
             calls.setdefault('early', []).append(m._G.sync.early_launches)
+            if mode == 'bucket':
+                # (the step's exchange and Adam are queued; the gradient buffer is not written again before the next zero_grad)
+                torch.cuda.synchronize()
+                calls['late_writes'] = calls.get('late_writes', 0) + m._G.sync.verify_early_slices()
         if s == 0:            # Adam's first moment after ONE step = (1 - beta1) * (exchanged) gradient of the seeded weights
             torch.cuda.synchronize()
             mom = {k: v.clone() for k, v in g.export_dict(m._optimizer_G.exp_avg).items() if k in PROBE}
@@ -186,10 +190,14 @@ def test_rccl_exchange_path_equals_plain_step_and_oracle():
 
 def test_rccl_bucket_mode_launches_slices_during_the_backward():
     """opt.ddp_mode = 'bucket' on RCCL (world 1, exchange forced): the first step learns the gradient writes per slice and exchanges
-    after the backward; from the second step on slices go on the wire while G's backward is still being issued -- every slice but
-    the ones the first layers' weight gradients close -- and the steps' losses stay those of the plain run."""
+    after the backward; from the second step on slices go on the wire while G's backward is still being issued.  The race this mode
+    could have -- a weight gradient landing in a slice after it went on the wire -- is checked directly (HOIG_DDP_CHECK: with one rank
+    the SUM is the identity, so every early slice must still hold after the step what it held at its launch); the losses follow the
+    plain run's (steps 1 and 2 to 1e-3; the third step's to 5 %: by then two runs of ANY form have drifted apart, Adam's first updates
+    being +-lr whatever the gradient's size -- tools/quality_surrogate.py measures that drift)."""
     e_b, _, w_b, _, calls = _spawn(True, 'bucket', 3)
     e_one, _, _, _, _ = _spawn(False, None, 3)
+    assert calls.get('late_writes', -1) == 0, calls
     n_g = (183501729 * 4 + (64 << 20) - 1) // (64 << 20)
     print('early launches per step: %s of %d slices' % (calls['early'], n_g))
     assert calls['early'][0] == 0 and calls['early'][1] >= n_g // 2 and calls['early'][2] == calls['early'][1]
@@ -197,6 +205,6 @@ def test_rccl_bucket_mode_launches_slices_during_the_backward():
     assert calls['all_reduce'] <= 3 * (n_g + 1) + 2
     for s in range(3):
         for k, want in e_one[s].items():
-            assert abs(e_b[s][k] - want) <= (1e-3 if s < 2 else 5e-3) * max(abs(want), 1e-2), (s, k, e_b[s][k], want)
+            assert abs(e_b[s][k] - want) <= (1e-3 if s < 2 else 5e-2) * max(abs(want), 1e-2), (s, k, e_b[s][k], want)
     for k in PROBE:
         assert np.isfinite(w_b[k]).all()
