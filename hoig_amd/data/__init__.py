@@ -40,6 +40,7 @@ class CustomDatasetDataLoader(object):
 
     def __init__(self, opt, is_for_train=True, use_ddp=False, device=None):
         self._dataset = DatasetFactory.get_by_name(opt.dataset_mode, opt, is_for_train)
+        self._opt = opt
         self._device, self._stage = device, None          # (the stage is made by load_data(): the host half alone needs no GPU)
         # One rank of a data-parallel job sees its own shard in the sampler's order and drops the ragged last batch, so that every
         # rank runs the same number of steps; a single process shuffles unless opt.serial_batches and keeps the short batch.
@@ -52,8 +53,27 @@ class CustomDatasetDataLoader(object):
 
     def load_data(self):
         if self._stage is None:
-            self._stage = DeviceStage(self._dataset, device=self._device)
+            self._stage = DeviceStage(self._dataset, device=self._device, prepare=self._raw_stage())
         return _DeviceBatches(self._dataloader, self._stage)
+
+    def _raw_stage(self):
+        """The raw-batch stage of Trainer.set_input (HandRecoveryFlow.forward, models/trainer.py:46-145, and the assignment of its
+        outputs, :346-362) as the loader's last device step, one batch ahead -- when the options carry what it needs (opt.mano_model,
+        opt.object_assets: train_ddp.py passes ONE opt to the loader and to the model) and opt.loader_prepares is not False.  The
+        batch keeps its raw entries; Trainer.set_input takes the prepared ones."""
+        opt = self._opt
+        if not getattr(opt, 'loader_prepares', True) or getattr(opt, 'mano_model', None) is None or not getattr(opt, 'object_assets', None):
+            return None
+        from .. import input_prep as IP
+        from ..hand_recovery import HandRecoveryFlow
+        flow = HandRecoveryFlow(opt, device=self._device)
+
+        def prepare(b):
+            import torch
+            with torch.no_grad():
+                out = flow(b['imageA'], b['imageB'], b['manoA'], b['manoB'])
+                return IP.to_prepared(out, b['imageA'].float(), b['imageB'].float(), b.get('maskA'), b.get('maskB'))
+        return prepare
 
     def load_raw_data(self):
         """The host half alone: raw batches (decoded 8-bit frames + annotations) as the workers deliver them."""

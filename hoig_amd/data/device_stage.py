@@ -49,9 +49,15 @@ class MeshCache(object):
 
 
 class DeviceStage(object):
-    def __init__(self, dataset, device=None):
+    def __init__(self, dataset, device=None, prepare=None):
+        """prepare (optional): batch dict -> dict of further entries, run on the loader stream right behind the batch's pixel work --
+        i.e. ONE BATCH AHEAD of the step that consumes it.  ``CustomDatasetDataLoader`` passes the raw-batch stage of
+        ``Trainer.set_input`` here (hand_recovery.HandRecoveryFlow + input_prep.to_prepared) when the options carry the MANO model and
+        the object assets: its chain of ~100 small dependent launches then runs beside the previous step instead of in front of the
+        next one, and ``set_input`` finds the prepared tensors in the batch (round 6)."""
         from .. import _lib as L
         self._L = L
+        self._prepare = prepare
         self.device = torch.device('cuda', torch.cuda.current_device()) if device is None else torch.device(device)
         self._meshes = MeshCache(dataset, self.device)
         self._max_verts = dataset.max_obj_verts
@@ -121,12 +127,14 @@ class DeviceStage(object):
             self._stream = ops.new_stream(self.device, 'loader')
         with torch.cuda.stream(self._stream):
             a, b = self._view(raw['A']), self._view(raw['B'])
+            batch = {'imageA': a[0], 'maskA': a[1], 'manoA': a[2], 'nameA': a[3],
+                     'imageB': b[0], 'maskB': b[1], 'manoB': b[2], 'nameB': b[3]}
+            if a[1] is None:                                                # ycb_dataset.py:278-279: no mask keys
+                del batch['maskA'], batch['maskB']
+            if self._prepare is not None:
+                batch.update(self._prepare(batch))
             done = torch.cuda.Event()
             done.record()
-        batch = {'imageA': a[0], 'maskA': a[1], 'manoA': a[2], 'nameA': a[3],
-                 'imageB': b[0], 'maskB': b[1], 'manoB': b[2], 'nameB': b[3]}
-        if a[1] is None:                                                    # ycb_dataset.py:278-279: no mask keys
-            del batch['maskA'], batch['maskB']
         return batch, done, raw                                         # (raw: the pinned source stays alive until the copies ran)
 
     def finish(self, pending):

@@ -163,6 +163,54 @@ def test_trainer_takes_the_loaders_batch(tmp_path):
         ops.set_precision('f32')
 
 
+def test_loader_runs_the_raw_stage_one_batch_ahead_with_the_same_result(tmp_path):
+    """Round 6: when the loader's opt carries the MANO model and the object assets (train_ddp.py passes one opt to both), the loader
+    runs the raw-batch stage itself -- on its stream, behind the batch's pixel work, one batch ahead of the step -- and the batch
+    carries the prepared tensors; Trainer.set_input then stages EXACTLY what it stages from the raw entries of the same batch."""
+    from test_hand_recovery_gpu import _assets
+    from common import opt_namespace
+    from hoig_amd import ops
+    from hoig_amd.data import CustomDatasetDataLoader
+    from hoig_amd.mano import ManoModel
+    from hoig_amd.models import ModelsFactory
+    from hoig_amd.models.trainer import PREPARED_KEYS, RAW_KEYS
+    from oracle import mano_oracle as M
+    assets, nv = _assets([2, 5], 21)
+    opt_d = FX.build(str(tmp_path), seed=8, n_obj_verts=nv)
+    FX.write_pairs(opt_d, [('ABF1_0/0001.png', 'ABF1_0/0003.png'), ('MC2_0/0000.png', 'MC2_0/0002.png'),
+                           ('MC2_0/0001.png', 'MC2_0/0003.png'), ('ABF1_0/0000.png', 'ABF1_0/0002.png')])
+    opt_d.serial_batches = True
+    opt = opt_namespace(gen_name='generator_spade_attn', local_rank=0, image_size=256)
+    opt.mano_model = opt_d.mano_model = ManoModel.from_dict(M.synthetic_model(4))
+    opt.object_assets = opt_d.object_assets = assets
+    opt_d.image_size = 256
+    ops.set_precision('bf16x3')
+    try:
+        torch.manual_seed(3)
+        model = ModelsFactory.get_by_name('trainer', opt, use_ddp=False)
+        model.set_train()
+        staged = {}
+        for ahead in (True, False):
+            opt_d.loader_prepares = ahead
+            got = []
+            for batch in CustomDatasetDataLoader(opt_d, is_for_train=True).load_data():
+                assert all(k in batch for k in RAW_KEYS)
+                assert all(k in batch for k in PREPARED_KEYS) == ahead
+                model.set_input(batch)
+                got.append({k: v.clone() for k, v in model._n.items()})
+                model.optimize_parameters()                      # (the loader's next batch is prepared beside this step)
+            torch.cuda.synchronize()
+            staged[ahead] = got
+        assert len(staged[True]) == len(staged[False]) == 2
+        for a, b in zip(staged[True], staged[False]):
+            assert a.keys() == b.keys()
+            for k in a:
+                assert torch.equal(a[k], b[k]), k
+        assert all(np.isfinite(v) for v in model.get_current_errors().values())
+    finally:
+        ops.set_precision('f32')
+
+
 def test_dexycb_trainer_takes_the_ycb_loaders_batch(tmp_path):
     """The HOIG_DexYCB copy end to end: --dataset_mode ycb (its scripts/train_ycb_ddp.sh:7) selects its loader, its MANO / camera
     conventions and its channel layout; the loader's batch goes through Trainer.set_input and a step."""

@@ -72,6 +72,7 @@ with tempfile.TemporaryDirectory() as root:
     ms_pd_alone = timed(lambda: model.set_input(prepared_dev))
     # (b) train_ddp.py:88-92: for batch in loader: set_input(batch); optimize_parameters()
     torch.cuda.empty_cache()
+    opt_d.loader_prepares = False                           # first: the round-5 form (the raw stage inside Trainer.set_input)
     loader = CustomDatasetDataLoader(opt_d, is_for_train=True)
     n, t0 = 0, None
     for batch in loader.load_data():
@@ -98,6 +99,13 @@ with tempfile.TemporaryDirectory() as root:
         torch.cuda.synchronize()
         return (time.perf_counter() - t) / (k - 4) * 1e3
     ms_idle_loader = loader_leg(False)                       # the loader runs, its batches are dropped: the loader's own interference
+    ms_b2 = loader_leg(True)                                 # (the timed loop above once more: run-to-run spread)
+    # round 6: the raw stage as the loader's last device step, one batch ahead (the loader's opt carries the MANO model and the assets,
+    # as train_ddp.py's single opt does)
+    opt_d.loader_prepares = True
+    opt_d.mano_model, opt_d.object_assets, opt_d.image_size = opt.mano_model, opt.object_assets, 256
+    ms_ahead = [loader_leg(True), loader_leg(True)]
+    opt_d.loader_prepares = False
 
     def with_raw():
         model.set_input(fixed)
@@ -127,4 +135,6 @@ with tempfile.TemporaryDirectory() as root:
     print('  host time of the two calls in that loop                  : set_input %.2f ms, optimize_parameters %.2f ms' % (host_in, host_st))
     print('  raw set_input alone, back to back on an idle device    : %.2f ms' % ms_stage)
     print('loader running, batches dropped (step on the staged inputs): %.2f ms  (%+.2f ms)' % (ms_idle_loader, ms_idle_loader - ms_a))
-    print('loader (%d workers) + raw set_input + step, %2d timed steps : %.2f ms  (%+.2f ms)' % (workers, n - 4, ms_b, ms_b - ms_a))
+    print('loader (%d workers) + raw set_input + step, %2d timed steps : %.2f ms  (%+.2f ms); again %.2f ms' % (workers, n - 4, ms_b, ms_b - ms_a, ms_b2))
+    print('loader runs the raw stage ONE BATCH AHEAD + set_input(prepared entries of the batch) + step : %.2f / %.2f ms  (%+.2f ms)'
+          % (ms_ahead[0], ms_ahead[1], min(ms_ahead) - ms_a))

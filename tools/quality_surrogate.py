@@ -42,7 +42,8 @@ def train_batch(k, side, batch):
 
 
 def oracle_run(n, side, batch, steps, threads, eb=16, log=None):
-    """-> {'init': images, 'trained': images, 'real': images}: fake_tsf of N eval samples before and after `steps` optimiser steps."""
+    """-> {'init': images, 'k<K>': images for every K in `steps`, 'real': images}: fake_tsf of N eval samples before and after K
+    optimiser steps."""
     torch.set_num_threads(threads)
     cfg, sdG, sdD, sdV = seeded_state(GEN)
     ot = O.OracleTrainer(cfg, sdG, sdD, sdV)
@@ -59,12 +60,14 @@ def oracle_run(n, side, batch, steps, threads, eb=16, log=None):
 
     t0 = time.time()
     out['init'], out['real'] = evaluate()
-    for k in range(steps):
+    marks = sorted(set(steps))
+    for k in range(marks[-1]):
         ot.set_prepared_input(train_batch(k, side, batch))
         ot.optimize_parameters()
-    out['trained'], _ = evaluate()
+        if k + 1 in marks:
+            out['k%d' % (k + 1)], _ = evaluate()
     if log:
-        log('oracle, %d threads: %d eval samples twice + %d steps in %.0f s' % (threads, n, steps, time.time() - t0))
+        log('oracle, %d threads: %d eval samples x %d + %d steps in %.0f s' % (threads, n, len(marks) + 1, marks[-1], time.time() - t0))
     return out
 
 
@@ -87,10 +90,12 @@ def hip_run(n, side, batch, steps, eb=16, log=None):
 
     t0 = time.time()
     out['init'] = evaluate()
-    for k in range(steps):
+    marks = sorted(set(steps))
+    for k in range(marks[-1]):
         m.set_input(train_batch(k, side, batch))
         m.optimize_parameters()
-    out['trained'] = evaluate()
+        if k + 1 in marks:
+            out['k%d' % (k + 1)] = evaluate()
     torch.cuda.synchronize()
     if log:
         log('HIP path (%s): the same in %.0f s' % (os.environ.get('HOIG_PRECISION', 'bf16x3:f16x2'), time.time() - t0))
@@ -107,14 +112,15 @@ def compare(a, b, sd_vgg, dims=Q.FEATURE_DIMS):
 def report(hip, ora, orb, sd_vgg, log, dims=Q.FEATURE_DIMS):
     rows = {}
     fb = lambda x, y: Q.frechet_between(x, y, dims=dims)
-    for stage in ('init', 'trained'):
+    stages = ['init'] + sorted((k for k in ora if k.startswith('k')), key=lambda k: int(k[1:]))
+    for stage in stages:
         rows[stage] = dict(hip_vs_oracle=compare(hip[stage], ora[stage], sd_vgg, dims), oracle_vs_oracle=compare(orb[stage], ora[stage], sd_vgg, dims),
                            to_real=dict(hip=fb(hip[stage], ora['real']), oracle=fb(ora[stage], ora['real']),
                                         oracle_other_threads=fb(orb[stage], ora['real'])))
     # scale of the feature space, for reading the absolute numbers: the trace of the oracle's feature covariance
     _, sig = Q.activation_statistics(Q.random_features(ora['init'], dims=dims))
     rows['feature_trace'] = float(np.trace(sig))
-    for stage in ('init', 'trained'):
+    for stage in stages:
         r = rows[stage]
         log('%-8s Frechet  HIP vs oracle %.3e | oracle vs oracle (other thread count) %.3e   [trace of the feature covariance %.3e]'
             % (stage, r['hip_vs_oracle']['frechet'], r['oracle_vs_oracle']['frechet'], rows['feature_trace']))
@@ -131,20 +137,26 @@ def report(hip, ora, orb, sd_vgg, log, dims=Q.FEATURE_DIMS):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--n', type=int, default=256)
-    ap.add_argument('--steps', type=int, default=50)
+    ap.add_argument('--steps', type=int, nargs='+', default=[5, 20, 50], help='optimiser steps after which the N samples are evaluated')
     ap.add_argument('--side', type=int, default=64)
     ap.add_argument('--batch', type=int, default=4)
     ap.add_argument('--threads', type=int, nargs=2, default=None, help='intra-op threads of the two oracle runs')
     ap.add_argument('--json', default=None)
     ap.add_argument('--save-hip', default=None, help='run the HIP side only and save its images (a GPU box needs no oracle run for that)')
+    ap.add_argument('--oracle-only', action='store_true', help='make the two oracle runs and write them to --oracle-cache (no GPU needed)')
     ap.add_argument('--oracle-cache', default=None, help='file that keeps the two oracle runs (made if absent)')
     ap.add_argument('--load-hip', default=None, help='take the HIP side from a file written by --save-hip (the oracle runs need no GPU)')
     a = ap.parse_args()
     log = lambda s: print(s, flush=True)
     cores = len(os.sched_getaffinity(0))
     ta, tb = a.threads or (cores, max(1, cores // 2 - 1))
-    log('# tools/quality_surrogate.py: N = %d eval samples, K = %d optimiser steps, %dx%d, batch %d, %s; oracle on %d / %d threads'
+    log('# tools/quality_surrogate.py: N = %d eval samples, evaluated at K = %s optimiser steps, %dx%d, batch %d, %s; oracle on %d / %d threads'
         % (a.n, a.steps, a.side, a.side, a.batch, GEN, ta, tb))
+    if a.oracle_only:
+        ora = oracle_run(a.n, a.side, a.batch, a.steps, ta, log=log)
+        orb = oracle_run(a.n, a.side, a.batch, a.steps, tb, log=log)
+        torch.save(dict(a=ora, b=orb, args=[a.n, a.steps, a.side, a.batch, ta, tb]), a.oracle_cache)
+        return
     if a.load_hip:
         hip = torch.load(a.load_hip)
         assert hip['args'] == [a.n, a.steps, a.side, a.batch], 'the saved HIP run used other arguments: %r' % (hip['args'],)
