@@ -81,8 +81,8 @@ def dominant_kernel_roofline(batch, side, precision, iters=50):
     traffic, traffic_source = None, None
     fwd_prec = precision.partition(':')[0]
     from hoig_amd import _lib
-    m16 = _lib.lib.hoig_set_tuning(b'mfma16', -1) == 1          # the 8-row tilings run on v_mfma_f32_16x16x32 (conv_halo16.hip)
-    halo = 'conv_halo3_m16_kernel' if m16 else 'conv_halo3_bf16_kernel'
+    m16 = True                                                   # the 8-row tilings run on v_mfma_f32_16x16x32 (conv_halo16.hip)
+    halo = 'conv_halo3_m16_kernel'
     want = 'conv_halo3_f6_kernel' if fwd_prec == 'f16f6' else (halo if fwd_prec in ('bf16x3', 'f16x3') else None)
     for fn in PMC_FILES:
         try:

@@ -124,9 +124,6 @@ struct HaloArgs {
                                // stride-1 data gradient on conv_halo16.hip copies it to LDS without splitting (no A2 then)
     float *stats;              // (nullable) [Bn][2][N] fp32 accumulators: += per-image, per-channel sum and sum of squares of the
                                // values written to C -- the statistics of the instance norm that reads C next
-#ifdef HOIG_STAMP
-    unsigned long long *dbg;   // diagnostic build only (tools/stamp_halo.py): per-wave cycle sums of the step phases
-#endif
 };
 
 // geometry and argument block of the generic implicit-GEMM kernels (igemm_bf16_kernel in conv_igemm_bf16.hip, conv_igemm16.hip)
@@ -241,14 +238,13 @@ struct WHaloArgs {
     int b_split;
     const float *DY_g2, *X_g2;
     float *DW_g2;
-#ifdef HOIG_STAMP
-    unsigned long long *dbg;
-#endif
 };
 
 // wgrad_dma.hip: the stride-1 3x3 weight gradient from PRE-SPLIT dy (a.DY points at [pixel][2][Co] bf16: hoig_split_planes_bf16 or a
 // producer's epilogue), staged by LDS-DMA into double-buffered tiles; `a` carries the 4 x 32-pixel tiling; HOIG_EUNSUPPORTED otherwise
 int launch_halo_s2_m16p(const HaloArgs &a, int ns, bool scatter, bool rows8, hipStream_t st);      // conv_s2_16.hip
+// dgrad_k128.hip: dX[M][N] = dY[M][128] W[N][128]^T for the attention MLP's first layer (N = 25 C up to 12 800; M % 128 == 0, N % 64 == 0)
+int launch_dgrad_thin(const float *dy, const unsigned short *wh, const unsigned short *wl, float *dx, int M, int N, int ns, hipStream_t st);
 int launch_wgrad_dma(const WHaloArgs &a, int ns, dim3 grid, hipStream_t st);
 
 // conv_halo16.hip: the 3x3 stride-1 halo kernel on v_mfma_f32_16x16x32 (8 rows x 32 pixels x bn channels per workgroup, bn = 128

@@ -9,7 +9,6 @@ struct Entry {
     int value;
 };
 Entry g_table[HOIG_TUNE_COUNT] = {
-    {"mfma16", 1},
     {"igemm16", 1},
     {"s2_16", 1},
     {"flat5", 2},

@@ -270,12 +270,16 @@ class Trainer(BaseModel):
         from .. import input_prep as IP
         IP.flush_range_checks(wait=True)
 
-    def set_prepared_input(self, inp):
-        """Stage the a2 attributes (what trainer.py:346-362 assigns).  NCHW tensors (T: B,S,S,2), CPU or device."""
+    def stage_input(self, inp):
+        """The device work of staging the a2 attributes (what trainer.py:346-362 assigns): NCHW tensors (T: B,S,S,2), CPU or device ->
+        the dict of NHWC tensors the step reads, on the CURRENT stream, without touching the model's state (`set_prepared_input`
+        adopts it at once).  Round 6 also ran it one batch ahead on the loader's stream: 67.38 -> 67.32 ms on the loader-fed step,
+        i.e. nothing -- these launches cost GPU time beside a full chip, not latency -- so the loader does not
+        (profiles/r06_loader_step.txt)."""
         dev = self.device
         with torch.no_grad():
             t = {k: v.to(dev, non_blocking=True).float() for k, v in inp.items() if torch.is_tensor(v)}
-            n = self._n = {}
+            n = {}
             for k in ['input_G_bg', 'input_G_src_obj', 'input_G_tsf_obj', 'input_G_src_hand', 'input_G_tsf_hand',
                       'real_src', 'real_tsf', 'bg_mask', 'hand_mask', 'armask_src', 'armask_tsf']:
                 if k in t:
@@ -299,6 +303,14 @@ class Trainer(BaseModel):
                 n['input_G_bg'], n['src_obj_rgb'], n['tsf_obj_rgb'], n['src_hand_cond'], n['tsf_hand_cond'], n['src_obj_cond'],
                 n['tsf_obj_cond'], n.get('armask_src'), n.get('armask_tsf'))
             n['d_real_in'] = ops.cat_channels([n['real_tsf'], n['tsf_cond']])
+        return n
+
+    def set_prepared_input(self, inp):
+        """Stage the a2 attributes (what trainer.py:346-362 assigns).  NCHW tensors (T: B,S,S,2), CPU or device."""
+        return self._adopt_staged(self.stage_input(inp))
+
+    def _adopt_staged(self, n):
+        with torch.no_grad():
             n = self._n = self._stage_static(n)
             # reference-named NCHW views
             self._input_G_bg = as_nchw(n['input_G_bg'])

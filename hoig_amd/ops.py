@@ -1054,430 +1054,6 @@ def conv_transpose2d(x, w, stride=2, pad=1, output_padding=1, prec=None, norm_ne
     return _Conv.apply(x, w, None, stride, pad, True, L.ACT_NONE, 0.0, out_hw, precision if prec is None else prec, norm_next)
 
 
-# ------------------------------------------------------------------------------------------------- instance norm
-_norm_ws = {}
-
-
-_stats_pending = {}     # (device, stream) -> (data_ptr, B, HW, C) of the tensor whose sums a convolution left in that workspace
-
-
-def _norm_workspace(nfloats, device, take=None):
-    """One zero-initialised instance-norm workspace per (device, stream): the kernels leave their accumulators zeroed
-    (include/hoig_kernels.h), so it is never memset again.  A convolution whose output goes straight into an instance norm may
-    have left that tensor's sums in the accumulators (_conv_fwd_raw): `take` = (data_ptr, B, HW, C) of the tensor the caller is
-    about to normalise -> (workspace, True) if they are its sums.  Sums nobody asked for (the norm took another path) are cleared
-    before anyone else uses the accumulators."""
-    key = (device, torch.cuda.current_stream(device).cuda_stream)
-    ws = _norm_ws.get(key)
-    pend = _stats_pending.pop(key, None)
-    if pend is not None and pend == take:
-        return ws, True
-    if ws is None or ws.numel() < nfloats:
-        ws = torch.zeros(max(nfloats, 1 << 20), dtype=torch.float32, device=device)
-        _norm_ws[key] = ws
-    elif pend is not None:
-        ws[:pend[1] * 2 * pend[3]].zero_()
-    return (ws, False) if take is not None else ws
-
-
-def _conv_stats_workspace(y):
-    """Accumulators for the statistics of `y` (a convolution output about to be written), or None when its instance norm would
-    not read them: maps of <= 1024 pixels take the one-launch norm kernel, which computes its own."""
-    B, H, W_, C = y.shape
-    if H * W_ <= 1024 or C % 4 or B * 2 * C > (1 << 18):        # (1 << 18: the accumulator pool, norm.hip ACC_POOL)
-        return None
-    return _norm_workspace(L.lib.hoig_inorm_workspace_bytes(B, H * W_, C) // 4, y.device)
-
-
-def _stats_drop(x):
-    """Nobody will take the sums the producer of `x` left in the accumulators: clear them now (_norm_workspace does when asked)."""
-    key = (x.device, torch.cuda.current_stream(x.device).cuda_stream)
-    pend = _stats_pending.get(key)
-    if pend is not None and pend[0] == x.data_ptr():
-        _norm_workspace(1, x.device)
-
-
-def _stats_offer(y):
-    B, H, W_, C = y.shape
-    _stats_pending[(y.device, torch.cuda.current_stream(y.device).cuda_stream)] = (y.data_ptr(), B, H * W_, C)
-
-
-class _INorm(Function):
-    @staticmethod
-    def forward(ctx, x, p0, p1, mode, act, slope, residual, eps):
-        _chk(x, 'x')
-        assert x.is_contiguous()
-        B, H, W, C = x.shape
-        HW = H * W
-        if act != L.ACT_NONE and residual is not None:
-            raise ValueError('activation + residual in one instance-norm epilogue is not defined')
-        mean = torch.empty(B * C, dtype=torch.float32, device=x.device)
-        rstd = torch.empty_like(mean)
-        y = torch.empty_like(x)
-        # maps of <= 1024 pixels: statistics + apply in one launch from one read of x
-        rc = L.EUNSUPPORTED if HW > 1024 else L.lib.hoig_inorm_fwd_fused(_p(x), mode, _p(p0), _p(p1), C, act, slope, _p(residual),
-                                                                         eps, _p(y), _p(mean), _p(rstd), B, HW, C, _st())
-        if rc == L.EUNSUPPORTED:
-            ws, have = _norm_workspace(L.lib.hoig_inorm_workspace_bytes(B, HW, C) // 4, x.device, take=(x.data_ptr(), B, HW, C))
-            if have:              # the convolution that made x left its sums in the accumulators: no pass over x for them
-                call('hoig_inorm_stats_from_sums', B, HW, C, eps, _p(mean), _p(rstd), _p(ws), _st())
-            else:
-                call('hoig_inorm_stats', _p(x), B, HW, C, eps, _p(mean), _p(rstd), _p(ws), _st())
-            call('hoig_inorm_apply', _p(x), _p(mean), _p(rstd), mode, _p(p0), _p(p1), act, slope, _p(residual), _p(y),
-                 B, HW, C, _st())
-        else:
-            L.check(rc, 'hoig_inorm_fwd_fused')
-        ctx.cfg = (mode, act, slope, B, HW, C, residual is not None)
-        ctx.split_tok = _claim_split(x)          # x is the output of a convolution whose backward reads split dy
-        # (Leaky)ReLU after a plain / affine norm: the backward recomputes the activation mask from x instead of reading y
-        y_free = act in (L.ACT_RELU, L.ACT_LRELU) and mode in (0, 1)
-        ctx.save_for_backward(x, mean, rstd, p0, p1, y if (act != L.ACT_NONE and not y_free) else None)
-        return y
-
-    @staticmethod
-    def backward(ctx, dy):
-        _grad_epoch()
-        x, mean, rstd, p0, p1, y = ctx.saved_tensors
-        mode, act, slope, B, HW, C, has_res = ctx.cfg
-        dy = dy.contiguous()
-        dx = torch.empty_like(x)
-        dp0 = dp1 = r0 = r1 = None
-        if mode == 1:
-            dp0, ret0 = _grad_target(p0)
-            dp1, ret1 = _grad_target(p1)
-            r0, r1 = (dp0 if ret0 else None), (dp1 if ret1 else None)
-        elif mode == 2:
-            dp0, dp1 = torch.empty_like(x), torch.empty_like(x)
-            r0, r1 = dp0, dp1
-        split_dx = _writes_split(ctx.split_tok)
-        sfx = '_split' if split_dx else ''
-        p1m = _p(p1) if mode == 1 else None
-        rc = getattr(L.lib, 'hoig_inorm_bwd_fused_add' + sfx)(_p(x), _p(mean), _p(rstd), mode, _p(p0), p1m, C, _p(y), _p(dy), act, slope,
-                                                              None, _p(dx), _p(dp0), _p(dp1), B, HW, C, _st())
-        if rc == L.EUNSUPPORTED:
-            ws = _norm_workspace(L.lib.hoig_inorm_workspace_bytes(B, HW, C) // 4, x.device)
-            call('hoig_inorm_bwd_add_ld' + sfx, _p(x), _p(mean), _p(rstd), mode, _p(p0), p1m, C, _p(y), _p(dy), act, slope, None, _p(dx),
-                 _p(dp0), _p(dp1), B, HW, C, _p(ws), _st())
-        else:
-            L.check(rc, 'hoig_inorm_bwd_fused_add' + sfx)
-        if split_dx:
-            _offer_split(ctx.split_tok, dx)
-        return dx, r0, r1, None, None, None, (dy if has_res else None), None
-
-
-def instance_norm(x, weight=None, bias=None, act=L.ACT_NONE, slope=0.0, residual=None, eps=1e-5):
-    mode = 1 if weight is not None else 0
-    return _INorm.apply(x, weight, bias, mode, act, slope, residual, eps)
-
-
-def spade_norm(x, gamma, beta, act=L.ACT_NONE, slope=0.0, eps=1e-5):
-    """IN(x) * (1 + gamma) + beta (spade.py:36), optionally followed by an activation."""
-    return _INorm.apply(x, gamma, beta, 2, act, slope, None, eps)
-
-
-class _SpadeFused(Function):
-    """IN(x) * (1 + gamma) + beta with gamma | beta side by side in ONE tensor gb [B,H,W,2C] (the output of the fused
-    gamma|beta convolution); the backward writes dgamma | dbeta straight into the matching [.,2C] gradient."""
-
-    @staticmethod
-    def forward(ctx, x, gb, act, slope, eps, fork=False):
-        _chk(x); _chk(gb)
-        assert x.is_contiguous() and gb.is_contiguous()
-        B, H, W, C = x.shape
-        assert gb.shape[-1] == 2 * C
-        HW = H * W
-        mean = torch.empty(B * C, dtype=torch.float32, device=x.device)
-        rstd = torch.empty_like(mean)
-        y = torch.empty_like(x)
-        rc = L.EUNSUPPORTED if HW > 1024 else L.lib.hoig_inorm_fwd_fused(_p(x), 2, _p(gb), gb.data_ptr() + 4 * C, 2 * C, act, slope,
-                                                                         None, eps, _p(y), _p(mean), _p(rstd), B, HW, C, _st())
-        if rc == L.EUNSUPPORTED:
-            ws, have = _norm_workspace(L.lib.hoig_inorm_workspace_bytes(B, HW, C) // 4, x.device, take=(x.data_ptr(), B, HW, C))
-            if have:
-                call('hoig_inorm_stats_from_sums', B, HW, C, eps, _p(mean), _p(rstd), _p(ws), _st())
-            else:
-                call('hoig_inorm_stats', _p(x), B, HW, C, eps, _p(mean), _p(rstd), _p(ws), _st())
-            call('hoig_inorm_apply_ld', _p(x), _p(mean), _p(rstd), 2, _p(gb), gb.data_ptr() + 4 * C, 2 * C, act, slope, None,
-                 _p(y), B, HW, C, _st())
-        else:
-            L.check(rc, 'hoig_inorm_fwd_fused')
-        ctx.cfg = (act, slope, B, HW, C)
-        ctx.split_tok = _claim_split(x)          # (see _INorm.forward)
-        ctx.save_for_backward(x, mean, rstd, gb, y if act != L.ACT_NONE else None)
-        if fork:                              # (y, x): see _Conv.forward
-            ctx.set_materialize_grads(False)
-            return y, x
-        return y
-
-    @staticmethod
-    def backward(ctx, dy, dxr=None):
-        x, mean, rstd, gb, y = ctx.saved_tensors
-        act, slope, B, HW, C = ctx.cfg
-        if dy is None:
-            return dxr, None, None, None, None, None
-        dy = dy.contiguous()
-        add = dxr.contiguous() if dxr is not None else None
-        dx = torch.empty_like(x)
-        dgb = torch.empty_like(gb)
-        split_dx = _writes_split(ctx.split_tok)
-        sfx = '_split' if split_dx else ''
-        rc = getattr(L.lib, 'hoig_inorm_bwd_fused_add' + sfx)(_p(x), _p(mean), _p(rstd), 2, _p(gb), None, 2 * C, _p(y), _p(dy), act, slope,
-                                                              _p(add), _p(dx), _p(dgb), dgb.data_ptr() + 4 * C, B, HW, C, _st())
-        if rc == L.EUNSUPPORTED:
-            ws = _norm_workspace(L.lib.hoig_inorm_workspace_bytes(B, HW, C) // 4, x.device)
-            call('hoig_inorm_bwd_add_ld' + sfx, _p(x), _p(mean), _p(rstd), 2, _p(gb), None, 2 * C, _p(y), _p(dy), act, slope, _p(add),
-                 _p(dx), _p(dgb), dgb.data_ptr() + 4 * C, B, HW, C, _p(ws), _st())
-        else:
-            L.check(rc, 'hoig_inorm_bwd_fused_add' + sfx)
-        if split_dx:
-            _offer_split(ctx.split_tok, dx)
-        return dx, dgb, None, None, None, None
-
-
-def spade_norm_fused(x, gb, act=L.ACT_NONE, slope=0.0, eps=1e-5, fork=False):
-    """fork=True -> (y, x') for an x with a second consumer, which must read x' (see conv2d_fork): its gradient is then added by
-    the norm's backward kernel."""
-    if fork and not x.requires_grad:
-        return _SpadeFused.apply(x, gb, act, slope, eps), x
-    return _SpadeFused.apply(x, gb, act, slope, eps, fork)
-
-
-# ------------------------------------------------------------------------------------------------- small ops
-class _Add(Function):
-    @staticmethod
-    def forward(ctx, a, b):
-        _chk(a); _chk(b)
-        assert a.shape == b.shape and a.is_contiguous() and b.is_contiguous()
-        y = torch.empty_like(a)
-        call('hoig_add', _p(a), _p(b), _p(y), a.numel(), _st())
-        return y
-
-    @staticmethod
-    def backward(ctx, dy):
-        return dy, dy
-
-
-def add(a, b):
-    return _Add.apply(a, b)
-
-
-class _AddAct(Function):
-    """act(a + b) -- the epilogue of a convolution evaluated as the sum of two convolutions over the halves of its input."""
-
-    @staticmethod
-    def forward(ctx, a, b, act, slope):
-        _chk(a); _chk(b)
-        assert a.shape == b.shape and a.is_contiguous() and b.is_contiguous()
-        y = torch.empty_like(a)
-        call('hoig_add_act', _p(a), _p(b), _p(y), act, slope, a.numel(), _st())
-        ctx.cfg = (act, slope)
-        ctx.save_for_backward(y)
-        return y
-
-    @staticmethod
-    def backward(ctx, dy):
-        y, = ctx.saved_tensors
-        act, slope = ctx.cfg
-        g = torch.empty_like(y)
-        call('hoig_act_bwd', _p(y), _p(dy.contiguous()), _p(g), act, slope, y.numel(), _st())
-        return g, g, None, None
-
-
-def add_act(a, b, act, slope=0.0):
-    return _AddAct.apply(a, b, act, slope)
-
-
-def _copy_channels(x, y, x_off, y_off, n, accumulate=False):
-    npix = x.numel() // x.shape[-1]
-    call('hoig_copy_channels', _p(x), _p(y), npix, x.shape[-1], x_off, y.shape[-1], y_off, n, 1 if accumulate else 0,
-         _st())
-
-
-class _Cat(Function):
-    @staticmethod
-    def forward(ctx, *xs):
-        for t in xs:
-            _chk(t)
-            assert t.is_contiguous()
-        cs = [t.shape[-1] for t in xs]
-        y = torch.empty(xs[0].shape[:-1] + (sum(cs),), dtype=xs[0].dtype, device=xs[0].device)
-        if len(xs) == 2:
-            call('hoig_cat2_channels', _p(xs[0]), cs[0], _p(xs[1]), cs[1], _p(y), y.numel() // y.shape[-1], _st())
-        else:
-            off = 0
-            for t, c in zip(xs, cs):
-                _copy_channels(t, y, 0, off, c)
-                off += c
-        ctx.cs = cs
-        return y
-
-    @staticmethod
-    def backward(ctx, dy):
-        dy = dy.contiguous()
-        outs, off = [], 0
-        for i, c in enumerate(ctx.cs):
-            if ctx.needs_input_grad[i]:
-                # a strided VIEW: where autograd sums it with another gradient of the same tensor (an encoder output also
-                # feeds the next level) the add reads it in place and the slice copy never happens; single consumers
-                # make it contiguous themselves
-                outs.append(dy[..., off:off + c])
-            else:
-                outs.append(None)
-            off += c
-        return tuple(outs)
-
-
-def cat_channels(xs):
-    return _Cat.apply(*xs)
-
-
-class _PadChannels(Function):
-    """x [.., C] -> [.., C'] with zeros behind (C' > C): puts a 19- / 24-channel tensor (the discriminator's input, discriminator.py:29)
-    on the 16-bit convolution kernels, which want multiples of 32 channels."""
-
-    @staticmethod
-    def forward(ctx, x, c_to):
-        _chk(x)
-        assert x.is_contiguous() and c_to > x.shape[-1]
-        y = torch.zeros(x.shape[:-1] + (c_to,), dtype=x.dtype, device=x.device)
-        _copy_channels(x, y, 0, 0, x.shape[-1])
-        ctx.c = x.shape[-1]
-        return y
-
-    @staticmethod
-    def backward(ctx, dy):
-        return dy[..., :ctx.c], None          # (a strided view: see _Cat.backward)
-
-
-class _PadConvIn(Function):
-    """conv weight (Co, Ci, R, S) over packed storage -> (Co, Ci', R, S), zero input channels behind; the gradient of the real channels
-    goes back to the parameter (autograd adds it into its flat gradient view)."""
-
-    @staticmethod
-    def forward(ctx, w, c_to):
-        co, ci, r, s_ = w.shape
-        assert tuple(w.stride()) == packed_strides(w.shape, False) and c_to > ci
-        out = torch.empty_strided((co, c_to, r, s_), packed_strides((co, c_to, r, s_), False), dtype=w.dtype, device=w.device)
-        out.zero_()
-        out[:, :ci].copy_(w)
-        ctx.ci = ci
-        return out
-
-    @staticmethod
-    def backward(ctx, dw):
-        return dw[:, :ctx.ci], None
-
-
-def conv2d_padded_in(x, w, b, stride, pad, act=L.ACT_NONE, slope=0.0, prec=None, to=32):
-    """conv2d for a layer whose input channel count is no multiple of 32, on the 16-bit kernels: input and weight are zero-padded to `to`
-    channels (one fill + one copy of the input; 68 % more multiply-adds on a kernel that runs 4-6x faster than the exact-fp32 one the
-    layer took before).  In exact-fp32 arithmetic the plain convolution."""
-    p = precision if prec is None else prec
-    if p == L.PREC_F32 or x.shape[-1] % 32 == 0 or not x.is_cuda:
-        return conv2d(x, w, b, stride, pad, act, slope, prec=prec)
-    return conv2d(_PadChannels.apply(x, to), _PadConvIn.apply(w, to), b, stride, pad, act, slope, prec=prec)
-
-
-def slice_channels(x, a, b):
-    """x[..., a:b] as a new contiguous NHWC tensor (inputs only; no gradient)."""
-    y = torch.empty(x.shape[:-1] + (b - a,), dtype=x.dtype, device=x.device)
-    _copy_channels(x, y, a, 0, b - a)
-    return y
-
-
-def nchw_to_nhwc(x):
-    _chk(x)
-    x = x.contiguous()
-    B, C, H, W = x.shape
-    y = torch.empty((B, H, W, C), dtype=x.dtype, device=x.device)
-    call('hoig_nchw_to_nhwc', _p(x), _p(y), B, C, H, W, _st())
-    return y
-
-
-def nhwc_to_nchw(x):
-    _chk(x)
-    x = x.contiguous()
-    B, H, W, C = x.shape
-    y = torch.empty((B, C, H, W), dtype=x.dtype, device=x.device)
-    call('hoig_nhwc_to_nchw', _p(x), _p(y), B, C, H, W, _st())
-    return y
-
-
-class _MaxPool(Function):
-    @staticmethod
-    def forward(ctx, x):
-        _chk(x)
-        B, H, W, C = x.shape
-        y = torch.empty((B, H // 2, W // 2, C), dtype=x.dtype, device=x.device)
-        call('hoig_maxpool2_fwd', _p(x), _p(y), B, H, W, C, _st())
-        ctx.save_for_backward(x)
-        return y
-
-    @staticmethod
-    def backward(ctx, dy):
-        x, = ctx.saved_tensors
-        B, H, W, C = x.shape
-        dx = torch.empty_like(x)
-        call('hoig_maxpool2_bwd', _p(x), None, _p(dy.contiguous()), _p(dx), B, H, W, C, _st())
-        return dx
-
-
-def maxpool2(x):
-    return _MaxPool.apply(x)
-
-
-# ------------------------------------------------------------------------------------------------- sampling
-def resize_bilinear_ac(x, ho, wo):
-    B, Hi, Wi, C = x.shape
-    y = torch.empty((B, ho, wo, C), dtype=x.dtype, device=x.device)
-    call('hoig_resize_bilinear_ac', _p(x.contiguous()), _p(y), B, Hi, Wi, C, ho, wo, _st())
-    return y
-
-
-def resize_nearest(x, ho, wo):
-    B, Hi, Wi, C = x.shape
-    if (Hi, Wi) == (ho, wo):
-        return x
-    y = torch.empty((B, ho, wo, C), dtype=x.dtype, device=x.device)
-    call('hoig_resize_nearest', _p(x.contiguous()), _p(y), B, Hi, Wi, C, ho, wo, _st())
-    return y
-
-
-def attn_flow(tscale):
-    B, h = tscale.shape[0], tscale.shape[1]
-    flow = torch.empty((B, 2, h, h), dtype=tscale.dtype, device=tscale.device)
-    call('hoig_attn_flow', _p(tscale.contiguous()), _p(flow), B, h, _st())
-    return flow
-
-
-class _GridSample(Function):
-    @staticmethod
-    def forward(ctx, x, grid):
-        _chk(x); _chk(grid)
-        B, H, W, C = x.shape
-        Ho, Wo = grid.shape[1], grid.shape[2]
-        y = torch.empty((B, Ho, Wo, C), dtype=x.dtype, device=x.device)
-        call('hoig_grid_sample_fwd', _p(x), _p(grid), _p(y), B, H, W, C, Ho, Wo, _st())
-        ctx.save_for_backward(grid)
-        ctx.shape = (B, H, W, C, Ho, Wo)
-        return y
-
-    @staticmethod
-    def backward(ctx, dy):
-        grid, = ctx.saved_tensors
-        B, H, W, C, Ho, Wo = ctx.shape
-        dx = torch.zeros((B, H, W, C), dtype=dy.dtype, device=dy.device)
-        call('hoig_grid_sample_bwd', _p(grid), _p(dy.contiguous()), _p(dx), B, H, W, C, Ho, Wo, _st())
-        return dx, None
-
-
-def grid_sample(x, grid):
-    return _GridSample.apply(x, grid.contiguous())
-
-
-_f6_cache = {}
-
-
 def set_f6_min_tiles(n):
     """Launches of the f16f6 forward with fewer workgroups than `n` run as three fp16 terms (default 192: they would not fill
     the chip).  Returns the previous value.  Parity tests and tools pass 1 to exercise the fp6 kernel at small sizes."""
@@ -1570,412 +1146,16 @@ def _conv_dgrad_raw(d, g, w, dx, transposed=False, addend=None):
         call('hoig_add', _p(out), _p(addend), _p(dx), dx.numel(), _st())
 
 
-_attn_index = {}
-
-
-def attn_index_clear():
-    """Forget the pixel indices of the previous forward (called when a new forward starts: flows change per batch)."""
-    _attn_index.clear()
-
-
-def _attn_pixel_index(flow, B, H, W):
-    """The bucket index of a flow field (hoig_attn_build_index), built once per flow tensor: every attention layer of a
-    resolution shares its flow (generator.py:480-491), and the backward of each needs the same index."""
-    key = (flow.data_ptr(), B, H, W, torch.cuda.current_stream().cuda_stream)
-    hit = _attn_index.get(key)
-    if hit is None:
-        idx = torch.empty(L.lib.hoig_attn_index_ints(B, H, W), dtype=torch.int32, device=flow.device)
-        call('hoig_attn_build_index', _p(flow), _p(idx), B, H, W, _st())
-        hit = _attn_index[key] = (idx, flow)           # (the flow is held so that its address is not reused meanwhile)
-    return hit[0]
-
-
-class _AttnSourceConv(Function):
-    """The source half of ExtractorAttn's first layer: Gs = conv5x5(replicate_pad(source, 4), ws) on the grid [-2, H+1]^2 (see
-    _LocalAttn).  A Function of its own because it depends on the SOURCE features only: the generator evaluates it on the
-    stream of src_model, ahead of the tsf chain that consumes it."""
-
-    @staticmethod
-    def forward(ctx, source, ws, prec, fork=False):
-        _chk(source)
-        _chk(ws)
-        B, H, W, C = source.shape
-        assert tuple(ws.shape) == (128, C, 5, 5) and tuple(ws.stride()) == packed_strides(ws.shape, False)
-        spad = torch.empty((B, H + 8, W + 8, C), dtype=source.dtype, device=source.device)
-        call('hoig_replicate_pad_fwd', _p(source), _p(spad), B, H, W, C, 4, _st())
-        d_s = ConvDesc(B, H + 8, W + 8, C, H + 4, W + 4, 128, 5, 5, 1, 0, 0, L.ACT_NONE, 0.0, prec)
-        gs = torch.empty((B, H + 4, W + 4, 128), dtype=source.dtype, device=source.device)
-        _conv_fwd_raw(d_s, spad, ws, None, gs)
-        ctx.save_for_backward(ws, spad)
-        ctx.descs = _bwd_descs(d_s)
-        ctx.shape = (B, H, W, C)
-        if fork:                              # (gs, source): see _Conv.forward
-            ctx.set_materialize_grads(False)
-            return gs, source
-        return gs
-
-    @staticmethod
-    def backward(ctx, dgs, dsrc_r=None):
-        _grad_epoch()
-        ws, spad = ctx.saved_tensors
-        ds_dg, ds_wg = ctx.descs
-        B, H, W, C = ctx.shape
-        if dgs is None:
-            return dsrc_r, None, None, None
-        dgs = dgs.contiguous()
-        gw, ret_w = _grad_target(ws)
-        side = _wgrad_side_stream(dgs.device) if not ret_w else None
-        if side is not None:          # (see _Conv.backward)
-            side.wait_stream(torch.cuda.current_stream())
-            with torch.cuda.stream(side):
-                wgrad_call('hoig_conv2d_bwd_weight', ds_wg, _p(spad), _p(dgs), _p(gw), None, _st())
-            _wgrad_hold(side, (spad, dgs))
-        else:
-            wgrad_call('hoig_conv2d_bwd_weight', ds_wg, _p(spad), _p(dgs), _p(gw), None, _st())
-        dsrc = None
-        if ctx.needs_input_grad[0]:
-            dspad = torch.empty_like(spad)
-            _conv_dgrad_raw(ds_dg, dgs, ws, dspad)
-            dsrc = torch.empty((B, H, W, C), dtype=dgs.dtype, device=dgs.device)
-            call('hoig_replicate_pad_bwd_add', _p(dspad), _p(dsrc_r.contiguous() if dsrc_r is not None else None), _p(dsrc),
-                 B, H, W, C, 4, _st())                                                           # (writes every element)
-        return dsrc, (gw if ret_w else None), None, None
-
-
-class _LocalAttn(Function):
-    """ExtractorAttn.forward (extract_attn.py:23-29) without any 25x-sized tensor (hoig_amd/csrc/attn.hip):
-    Gt = conv5x5(replicate_pad(target, 2), wt) + b1 ; Gs = conv5x5(replicate_pad(source, 4), ws) on the grid [-2, H+1]^2
-    (_AttnSourceConv, passed in) ; hidden = Gt + bilinear(Gs at pixel + flow) ; LeakyReLU ; conv1x1 128->25 ; softmax ;
-    (1/25) sum_q a_q S_q read from the source's 6x6 footprint.  `wt`, `ws` (128,C,5,5) are the two halves of the reference's
-    (128,2C,5,5) weight (hoig_amd.nn.split_attn_weight)."""
-
-    @staticmethod
-    def forward(ctx, source, target, flow, gs, wt, b1, w2, b2, prec, fork=False):
-        for t in (source, target, flow, gs, wt, b1, w2, b2):
-            _chk(t)
-        B, H, W, C = source.shape
-        assert tuple(wt.shape) == (128, C, 5, 5) and tuple(wt.stride()) == packed_strides(wt.shape, False)
-        assert tuple(gs.shape) == (B, H + 4, W + 4, 128)
-        M = B * H * W
-        # the backward's gather kernels (hoig_attn_src_gather / hoig_attn_build_index) cover less than the forward does: say so
-        # here, before a forward that could not be differentiated (the reference's layers have C = 256 / 512, M <= 131072)
-        if source.requires_grad and (C % 64 or M >= (1 << 20) or W + 8 >= 2048):
-            raise NotImplementedError('local_attention: the backward needs C %% 64 == 0, fewer than 2^20 pixels per batch and '
-                                      'W < 2040 (got C=%d, B*H*W=%d, W=%d)' % (C, M, W))
-        dev, dt = source.device, source.dtype
-        tpad = torch.empty((B, H + 4, W + 4, C), dtype=dt, device=dev)
-        call('hoig_replicate_pad_fwd', _p(target), _p(tpad), B, H, W, C, 2, _st())
-        d_t = ConvDesc(B, H + 4, W + 4, C, H, W, 128, 5, 5, 1, 0, 0, L.ACT_NONE, 0.0, prec)
-        gt = torch.empty((M, 128), dtype=dt, device=dev)
-        _conv_fwd_raw(d_t, tpad, wt, b1, gt)
-        hidden = torch.empty_like(gt)
-        attn = torch.empty((M, 25), dtype=dt, device=dev)
-        out = torch.empty_like(source)
-        kf = torch.empty((M, 36), dtype=dt, device=dev) if source.requires_grad else None
-        call('hoig_attn_pixel_fwd', _p(gt), _p(gs), _p(flow), _p(w2), _p(b2), _p(source), _p(hidden), _p(attn), _p(out),
-             _p(kf), B, H, W, C, _st())
-        ctx.save_for_backward(source, flow, wt, b1, w2, b2, tpad, hidden, attn, kf)
-        ctx.descs = _bwd_descs(d_t)
-        ctx.shape = (B, H, W, C)
-        if fork:
-            # (out, source, target): both feature maps have further readers (the next layer of their chain; the sum
-            # `target + out`), which read these pass-through outputs so that their gradients come back through this node and
-            # are added by its own kernels (see _Conv.forward)
-            ctx.set_materialize_grads(False)
-            return out, source, target
-        return out
-
-    @staticmethod
-    def backward(ctx, dout, dsrc_r=None, dtgt_r=None):
-        _grad_epoch()
-        source, flow, wt, b1, w2, b2, tpad, hidden, attn, kf = ctx.saved_tensors
-        dt_dg, dt_wg = ctx.descs
-        B, H, W, C = ctx.shape
-        if dout is None:
-            return (dsrc_r, dtgt_r) + (None,) * 8
-        dout = dout.contiguous()
-        gs = [_grad_target(p) for p in (wt, b1, w2, b2)]
-        dhid = torch.empty_like(hidden)                       # = dGt
-        e_ws = torch.empty((B * H * W, 36), dtype=dout.dtype, device=dout.device)
-        call('hoig_attn_pixel_bwd', _p(hidden), _p(attn), _p(w2), _p(source), _p(flow), _p(dout), _p(dhid), _p(gs[2][0]),
-             _p(gs[3][0]), _p(e_ws), B, H, W, C, _st())
-        index = _attn_pixel_index(flow, B, H, W)
-        dgs = None
-        if ctx.needs_input_grad[3]:
-            dgs = torch.empty((B, H + 4, W + 4, 128), dtype=dout.dtype, device=dout.device)
-            call('hoig_attn_gs_gather', _p(index), _p(flow), _p(dhid), _p(dgs), B, H, W, _st())
-        side = _wgrad_side_stream(dout.device) if not any(r for _, r in gs) else None
-        if side is not None:          # (see _Conv.backward)
-            side.wait_stream(torch.cuda.current_stream())
-            with torch.cuda.stream(side):
-                wgrad_call('hoig_conv2d_bwd_weight', dt_wg, _p(tpad), _p(dhid), _p(gs[0][0]), _p(gs[1][0]), _st())
-            _wgrad_hold(side, (tpad, dhid))
-        else:
-            wgrad_call('hoig_conv2d_bwd_weight', dt_wg, _p(tpad), _p(dhid), _p(gs[0][0]), _p(gs[1][0]), _st())
-        dtgt = dsrc = None
-        if ctx.needs_input_grad[1]:
-            dtpad = torch.empty_like(tpad)
-            _conv_dgrad_raw(dt_dg, dhid, wt, dtpad)
-            dtgt = torch.empty((B, H, W, C), dtype=dout.dtype, device=dout.device)
-            call('hoig_replicate_pad_bwd_add', _p(dtpad), _p(dtgt_r.contiguous() if dtgt_r is not None else None), _p(dtgt),
-                 B, H, W, C, 2, _st())
-        if ctx.needs_input_grad[0]:                           # the weighted average's part (Gs's part comes from _AttnSourceConv)
-            dsrc = torch.empty((B, H, W, C), dtype=dout.dtype, device=dout.device)
-            call('hoig_attn_src_gather', _p(index), _p(kf), _p(dout), _p(dsrc_r.contiguous() if dsrc_r is not None else None),
-                 _p(dsrc), B, H, W, C, _st())
-        rets = [g if r else None for g, r in gs]
-        return dsrc, dtgt, None, dgs, rets[0], rets[1], rets[2], rets[3], None, None
-
-
-def _attn_prec(prec):
-    return precision if prec is None else prec
-
-
-def attn_source_conv(source, ws, prec=None, fork=False):
-    """Gs of local_attention(): the part that depends on the source features and the source half of the weight only.
-    fork=True -> (Gs, source'): later readers of `source` must read source' (see conv2d_fork)."""
-    if fork and not source.requires_grad:
-        return _AttnSourceConv.apply(source, ws, _attn_prec(prec)), source
-    return _AttnSourceConv.apply(source, ws, _attn_prec(prec), fork)
-
-
-def local_attention(source, target, flow, wt, ws, b1, w2, b2, prec=None, gs=None, fork=False):
-    """`gs`: attn_source_conv(source, ws) if the caller has evaluated it already (on another stream).
-    fork=True -> (out, source', target'): later readers of the two feature maps must read those (see conv2d_fork)."""
-    prec = _attn_prec(prec)
-    if gs is None:
-        gs = _AttnSourceConv.apply(source, ws, prec)
-    if fork and not (source.requires_grad and target.requires_grad):
-        return _LocalAttn.apply(source, target, flow.contiguous(), gs, wt, b1, w2, b2, prec), source, target
-    return _LocalAttn.apply(source, target, flow.contiguous(), gs, wt, b1, w2, b2, prec, fork)
-
-
-# stand-alone equivalents of the reference's two extension modules (NCHW, caller-visible semantics of
-# block_extractor.py:5-54 / local_attn_reshape.py:5-46)
-class _BlockExtractor(Function):
-    @staticmethod
-    def forward(ctx, source, flow, k):
-        _chk(source); _chk(flow)
-        assert source.is_contiguous() and flow.is_contiguous() and flow.shape[1] == 2
-        B, C, Hs, Ws = source.shape
-        Hf, Wf = flow.shape[2], flow.shape[3]
-        out = source.new_zeros((B, C, k * Hf, k * Wf))
-        call('hoig_block_extractor_forward', _p(source), _p(flow), _p(out), B, C, Hs, Ws, Hf, Wf, k, _st())
-        ctx.save_for_backward(source, flow)
-        ctx.k = k
-        return out
-
-    @staticmethod
-    def backward(ctx, g):
-        source, flow = ctx.saved_tensors
-        B, C, Hs, Ws = source.shape
-        Hf, Wf = flow.shape[2], flow.shape[3]
-        gs, gf = torch.zeros_like(source), torch.zeros_like(flow)
-        call('hoig_block_extractor_backward', _p(source), _p(flow), _p(g.contiguous()), _p(gs), _p(gf), B, C, Hs, Ws,
-             Hf, Wf, ctx.k, _st())
-        return gs, gf, None
-
-
-def block_extractor(source, flow, kernel_size):
-    return _BlockExtractor.apply(source.contiguous(), flow.contiguous(), kernel_size)
-
-
-class _LocalAttnReshape(Function):
-    @staticmethod
-    def forward(ctx, x, k):
-        _chk(x)
-        B, C, Hs, Ws = x.shape
-        assert C == k * k
-        out = x.new_zeros((B, 1, k * Hs, k * Ws))
-        call('hoig_local_attn_reshape_forward', _p(x), _p(out), B, Hs, Ws, k, _st())
-        ctx.cfg = (B, Hs, Ws, k)
-        return out
-
-    @staticmethod
-    def backward(ctx, g):
-        B, Hs, Ws, k = ctx.cfg
-        gi = g.new_zeros((B, k * k, Hs, Ws))
-        call('hoig_local_attn_reshape_backward', _p(g.contiguous()), _p(gi), B, Hs, Ws, k, _st())
-        return gi, None
-
-
-def local_attn_reshape(x, kernel_size):
-    return _LocalAttnReshape.apply(x.contiguous(), kernel_size)
-
-
-# ------------------------------------------------------------------------------------------------- compose / losses
-class _Compose(Function):
-    @staticmethod
-    def forward(ctx, bg, obj, hand, mbg, mh):
-        for t in (bg, obj, hand, mbg, mh):
-            _chk(t)
-        C = bg.shape[-1]
-        npix = bg.numel() // C
-        img = torch.empty_like(bg)
-        call('hoig_compose_fwd', _p(bg), _p(obj), _p(hand), _p(mbg), _p(mh), _p(img), npix, C, _st())
-        ctx.save_for_backward(bg, obj, hand, mbg, mh)
-        return img
-
-    @staticmethod
-    def backward(ctx, dimg):
-        bg, obj, hand, mbg, mh = ctx.saved_tensors
-        C = bg.shape[-1]
-        npix = bg.numel() // C
-        dbg, dobj, dhand = torch.empty_like(bg), torch.empty_like(obj), torch.empty_like(hand)
-        dmbg, dmh = torch.empty_like(mbg), torch.empty_like(mh)
-        call('hoig_compose_bwd', _p(bg), _p(obj), _p(hand), _p(mbg), _p(mh), _p(dimg.contiguous()), _p(dbg), _p(dobj),
-             _p(dhand), _p(dmbg), _p(dmh), npix, C, _st())
-        return dbg, dobj, dhand, dmbg, dmh
-
-
-def compose(bg, obj, hand, mbg, mh):
-    """mbg*bg + (1-mbg)*(obj*mh + hand*(1-mh))  (trainer.py:400-401)."""
-    return _Compose.apply(bg, obj, hand, mbg, mh)
-
-
-class LossSlots(object):
-    """The scalar terms of ONE objective (trainer.py:448-457: loss_G = g_adv + g_rec + g_tsf + g_mask + g_mask_smooth) as fp32
-    slots of one small device buffer.  The loss kernels add their scaled value straight into a slot (`into=slots.term(name)`;
-    several calls may share a slot: the five VGG levels of g_tsf), `total()` sums the slots in one launch, and differentiating the
-    total hands every term the constant 1 -- the host composes the objective without the per-term scalar multiplies, adds, fills
-    and gradient scalings torch would launch (42 of them per step).  `extra` names report-only slots (means) outside the total.
-    Usage per step: begin() -> the loss calls -> total(*handles).backward(); value(name) reads a slot (0-dim view, no launch)."""
-
-    def __init__(self, names, device, extra=()):
-        self.names = list(names)
-        self.extra = list(extra)
-        self.buf = torch.zeros(len(self.names) + 1 + len(self.extra), dtype=torch.float32, device=device)
-        self.one = torch.ones((), dtype=torch.float32, device=device)
-
-    def begin(self):
-        self.buf.zero_()
-
-    def _index(self, name):
-        return self.names.index(name) if name in self.names else len(self.names) + 1 + self.extra.index(name)
-
-    def term(self, name):
-        return (self, self._index(name))
-
-    def value(self, name):
-        return self.buf[self._index(name)]
-
-    def total(self, *handles):
-        return _LossRoot.apply(self, *handles)
-
-
-class _LossRoot(Function):
-    """Sum of a LossSlots' objective slots.  Its backward hands each term the constant 1 whatever gradient arrives: the terms
-    (`into=` losses) store their gradient pre-scaled and ignore it anyway -- the total is meant to be differentiated as it is."""
-
-    @staticmethod
-    def forward(ctx, slots, *handles):
-        k = len(slots.names)
-        call('hoig_sum', _p(slots.buf), slots.buf.data_ptr() + 4 * k, k, _st())
-        ctx.one, ctx.n = slots.one, len(handles)
-        return slots.buf[k]
-
-    @staticmethod
-    def backward(ctx, g):
-        return (None,) + (ctx.one,) * ctx.n
-
-
-class _MeanLoss(Function):
-    """scale * mean(loss(pred, target)); the kernel produces the sum and the pre-scaled gradient in one pass.
-    `into` = LossSlots.term(name): the value is a term of that objective (see LossSlots)."""
-
-    @staticmethod
-    def forward(ctx, pred, target, kind, tconst, scale, into=None):
-        _chk(pred); _chk(target)
-        pred = pred.contiguous()
-        n = pred.numel()
-        need = pred.requires_grad
-        dpred = torch.empty_like(pred) if need else None
-        ctx.save_for_backward(dpred)
-        ctx.term = into is not None
-        if into is not None:
-            slots, k = into
-            call('hoig_loss_accumulate', kind, _p(pred), _p(target), tconst, scale / n, slots.buf.data_ptr() + 4 * k, _p(dpred), n,
-                 _st())
-            return slots.buf[k]
-        out = torch.zeros(1, dtype=torch.float32, device=pred.device)
-        call('hoig_loss_fwd_bwd', kind, _p(pred), _p(target), tconst, scale / n, _p(out), _p(dpred), n, _st())
-        return out[0] * (scale / n)
-
-    @staticmethod
-    def backward(ctx, g):
-        dpred, = ctx.saved_tensors
-        if ctx.term:
-            return dpred, None, None, None, None, None
-        return (dpred * g if dpred is not None else None), None, None, None, None, None
-
-
-def l1_loss(pred, target, scale=1.0, into=None):
-    return _MeanLoss.apply(pred, target.contiguous(), L.LOSS_L1, 0.0, scale, into)
-
-
-def mse_loss(pred, target, scale=1.0, into=None):
-    return _MeanLoss.apply(pred, target.contiguous(), L.LOSS_MSE, 0.0, scale, into)
-
-
-def bce_loss(pred, target, scale=1.0, into=None):
-    return _MeanLoss.apply(pred, target.contiguous(), L.LOSS_BCE, 0.0, scale, into)
-
-
-def lsgan_loss(pred, target_value, scale=1.0, into=None):
-    """mean((x - y)^2) * scale with a constant target (trainer.py:476-477)."""
-    return _MeanLoss.apply(pred, None, L.LOSS_MSE, float(target_value), scale, into)
-
-
-class _TV(Function):
-    """Trainer._compute_loss_smooth (trainer.py:479-481) on a single-channel NHWC map."""
-
-    @staticmethod
-    def forward(ctx, m, scale, into=None):
-        _chk(m)
-        m = m.contiguous()
-        B, H, W, C = m.shape
-        assert C == 1
-        nx, ny = B * H * (W - 1), B * (H - 1) * W
-        need = m.requires_grad
-        dm = torch.empty_like(m) if need else None
-        ctx.save_for_backward(dm)
-        ctx.term = into is not None
-        if into is not None:                  # a term of an objective: see LossSlots
-            slots, k = into
-            call('hoig_tv_accumulate', _p(m), scale / nx, scale / ny, slots.buf.data_ptr() + 4 * k, _p(dm), B, H, W, _st())
-            return slots.buf[k]
-        out = torch.zeros(2, dtype=torch.float32, device=m.device)
-        call('hoig_tv_fwd_bwd', _p(m), scale / nx, scale / ny, _p(out), _p(dm), B, H, W, _st())
-        return out[0] * (scale / nx) + out[1] * (scale / ny)
-
-    @staticmethod
-    def backward(ctx, g):
-        dm, = ctx.saved_tensors
-        if ctx.term:
-            return dm, None, None
-        return (dm * g if dm is not None else None), None, None
-
-
-def tv_loss(m, scale=1.0, into=None):
-    return _TV.apply(m, scale, into)
-
-
-def mean(x, into=None):
-    """into = LossSlots.term(name) of a report-only slot: the mean is added there (no result tensor)."""
-    if into is not None:
-        slots, k = into
-        call('hoig_sum_scaled', _p(x.contiguous()), 1.0 / x.numel(), slots.buf.data_ptr() + 4 * k, x.numel(), _st())
-        return slots.buf[k]
-    out = torch.zeros(1, dtype=torch.float32, device=x.device)
-    call('hoig_sum', _p(x.contiguous()), _p(out), x.numel(), _st())
-    return out[0] / x.numel()
-
-
-def tensor2im_u8(x_nhwc, nrow, unnormalize=True):
-    """utils/util.py:249-264 for a batch grid: uint8 CHW of make_grid(nrow, padding=0)."""
-    B, H, W, C = x_nhwc.shape
-    ncol = min(nrow, B)
-    nrw = (B + ncol - 1) // ncol
-    out = torch.empty((C, nrw * H, ncol * W), dtype=torch.uint8, device=x_nhwc.device)
-    call('hoig_tensor2im_u8', _p(x_nhwc.contiguous()), _p(out), B, H, W, C, nrow, 1 if unnormalize else 0, _st())
-    return out
+# ------------------------------------------------------------------------------------------------- the other operator families
+# (round 6: split by family; their names -- private ones too, the tests reach for some -- stay reachable as ops.<name>)
+def _reexport():
+    import importlib
+    g = globals()
+    for mod in ('ops_norm', 'ops_small', 'ops_attn', 'ops_loss'):
+        m = importlib.import_module('.' + mod, __package__)
+        for k, v in vars(m).items():
+            if not k.startswith('__') and k not in ('_o', 'L', 'call', 'ConvDesc', 'Function', 'torch', 'ctypes', 'contextlib'):
+                g[k] = v
+
+
+_reexport()

@@ -490,8 +490,7 @@ const char *hoig_version(void);
 /* Kernel-variant choices that are tuning, not semantics (every value computes the same result up to summation order): one table
  * instead of per-variant environment switches.  key -> value; returns the previous value, or -1 for an unknown key; value < 0 only
  * queries.  Keys and defaults (each adopted on an interleaved A/B committed under profiles/r04_*):
- *   "mfma16"  1  the 8-row 3x3 stride-1 tilings on v_mfma_f32_16x16x32 (conv_halo16.hip); 0: on 32x32x16
- *   "s2_16"   1  the stride-2 3x3 layers on it (conv_halo16.hip; scatter launches with 64-channel tiles stay on 32x32x16)
+ *   "s2_16"   1  the stride-2 3x3 layers on v_mfma_f32_16x16x32 (conv_halo16.hip; scatter launches with 64-channel tiles stay on 32x32x16)
  *   "igemm16" 1  the generic implicit GEMM on it (conv_igemm16.hip): 1 = forward launches, 2 = data gradients too
  *   "flat5"   2  the flattened-axis halo kernel (conv_flat16.hip): 1 = the attention's valid 5x5 convolutions and their data
  *                gradients, 2 = also the 3x3 "same" layers with too few tiles for the halo kernels
@@ -522,7 +521,8 @@ const char *hoig_version(void);
  *                dx as bf16 hi | lo planes and that convolution's weight / data gradient read them without splitting ('PRE-SPLIT
  *                gradients' above); 0: fp32 gradients everywhere, split in every consuming workgroup
  * Round 6 removed the keys whose losing side had lost two rounds running, and with them that side's code: "wgrad16" (the 3x3 weight
- * gradient on 16x16x32: 5-20 % slower, wgrad_halo16.hip deleted), "wgrad_ko" (knock-out instantiations of the LDS-DMA weight gradient:
+ * gradient on 16x16x32: 5-20 % slower, wgrad_halo16.hip deleted), "mfma16" (the 8-row 3x3 stride-1 tilings on 16x16x32: always; their
+ * 32x32x16 instantiations are gone), "wgrad_ko" (knock-out instantiations of the LDS-DMA weight gradient:
  * a diagnostic), "few128" / "wgrad_few" (launch sizing for the 8-image launches: always on), "adam_pack" / "pad_in" (always on),
  * "split_grads" 2 / 3 (a split pass of its own, SPADE's [dgamma | dbeta] as planes: both +0.25 ms per step, profiles/r05_split_*_ab.txt).
  * Process-wide, not synchronised: set before launching. */

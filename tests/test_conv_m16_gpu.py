@@ -1,7 +1,7 @@
-"""The 3x3 stride-1 halo kernel on v_mfma_f32_16x16x32 (hoig_amd/csrc/conv_halo16.hip, tuning key 'mfma16') against the 32x32x16
-kernels it replaces (same split arithmetic, another summation order) and against torch's fp32 convolution: forward, data gradient,
-bias / activation / addend / statistics epilogues, the two-tensor input and the two-tensor output of the decoder's skip convolution.
-Shapes are chosen so that the launcher picks the 8-row tilings (128- and 64-channel tiles) the key switches."""
+"""The 3x3 stride-1 halo kernel on v_mfma_f32_16x16x32 (hoig_amd/csrc/conv_halo16.hip) against torch's fp32 convolution: forward, data
+gradient, bias / activation / addend / statistics epilogues, the two-tensor input and the two-tensor output of the decoder's skip
+convolution.  Shapes are chosen so that the launcher picks the 8-row tilings (128- and 64-channel tiles).  (Until round 6 these tests
+also compared with the 32x32x16 instantiations the kernel replaced in round 4; those are deleted.)"""
 import pytest
 import torch
 import torch.nn.functional as F
@@ -14,18 +14,7 @@ pytestmark = pytest.mark.gpu
 @pytest.fixture
 def tuning():
     from hoig_amd import _lib as L
-    prev = L.set_tuning('mfma16', 0)
     yield L
-    L.set_tuning('mfma16', prev)
-
-
-def _both(L, fn):
-    out = []
-    for v in (0, 1):
-        L.set_tuning('mfma16', v)
-        out.append(fn())
-    torch.cuda.synchronize()
-    return out
 
 
 CASES = [
@@ -62,7 +51,8 @@ def test_m16_forward_and_data_gradient(tuning, B, Ci, Co, H, W, mode):
             with torch.no_grad():
                 ya = ops.conv2d(x1.detach(), wd, bias, 1, 1, act=L.ACT_LRELU, slope=0.2)
             return y.detach(), xd.grad, ya
-        (y0, dx0, ya0), (y1, dx1, ya1) = _both(L, run)
+        y1, dx1, ya1 = run()
+        torch.cuda.synchronize()
     finally:
         ops.set_precision('f32')
     # an independent reference: torch fp32 on the device
@@ -72,11 +62,8 @@ def test_m16_forward_and_data_gradient(tuning, B, Ci, Co, H, W, mode):
     dxr = 2 * (xr.grad.permute(0, 2, 3, 1) + addend)
     yr = yr.detach().permute(0, 2, 3, 1)
     bf, bd = (3e-4, 3e-4) if mode == 'bf16x3' else (1e-3, 8e-3)
-    for tag, y, dx, ya in (('32x32x16', y0, dx0, ya0), ('16x16x32', y1, dx1, ya1)):
-        ef, ed, ea = rel_err(y, yr), rel_err(dx, dxr), rel_err(ya, F.leaky_relu(yr, 0.2))
-        assert ef < bf and ed < bd and ea < bf, (tag, ef, ed, ea)
-    # and the two kernels against each other: the same products in another order
-    assert rel_err(y1, y0) < 2e-6 and rel_err(ya1, ya0) < 2e-6 and rel_err(dx1, dx0) < (2e-6 if mode == 'bf16x3' else 1e-4)
+    ef, ed, ea = rel_err(y1, yr), rel_err(dx1, dxr), rel_err(ya1, F.leaky_relu(yr, 0.2))
+    assert ef < bf and ed < bd and ea < bf, (ef, ed, ea)
 
 
 @pytest.mark.parametrize('B,C1,C2,Co,H,W', [(4, 256, 256, 256, 32, 128), (8, 64, 128, 256, 64, 64)])
@@ -95,10 +82,14 @@ def test_m16_two_tensor_input_and_output(tuning, B, C1, C2, Co, H, W):
         y = ops.conv2d_cat2(a1, a2, w.clone().requires_grad_(True), prec=L.PREC_BF16X3)
         y.backward(gy)
         return y.detach(), a1.grad, a2.grad
-    (y0, d10, d20), (y1, d11, d21) = _both(L, run)
-    assert rel_err(y1, y0) < 2e-6 and rel_err(d11, d10) < 2e-6 and rel_err(d21, d20) < 2e-6
-    yr = F.conv2d(torch.cat([x1, x2], 3).permute(0, 3, 1, 2), w.permute(0, 1, 2, 3).contiguous(), padding=1)
-    assert rel_err(y1, yr.permute(0, 2, 3, 1)) < 3e-4
+    y1, d11, d21 = run()
+    torch.cuda.synchronize()
+    xr = torch.cat([x1, x2], 3).permute(0, 3, 1, 2).clone().requires_grad_(True)
+    yr = F.conv2d(xr, w.permute(0, 1, 2, 3).contiguous(), padding=1)
+    yr.backward(gy.permute(0, 3, 1, 2))
+    dr = xr.grad.permute(0, 2, 3, 1)
+    assert rel_err(y1, yr.detach().permute(0, 2, 3, 1)) < 3e-4
+    assert rel_err(d11, dr[..., :C1]) < 3e-4 and rel_err(d21, dr[..., C1:]) < 3e-4
 
 
 @pytest.mark.parametrize('B,Ci,Co,H,W', [(8, 64, 128, 64, 64), (8, 64, 256, 64, 64)])
@@ -118,10 +109,12 @@ def test_m16_statistics_epilogue(tuning, B, Ci, Co, H, W):
             y = ops.instance_norm(h)
             assert not ops._stats_pending
             return h, y
-        (h0, y0), (h1, y1) = _both(L, run)
+        h1, y1 = run()
+        torch.cuda.synchronize()
     finally:
         ops.set_precision('f32')
-    assert rel_err(h1, h0) < 2e-6 and rel_err(y1, y0) < 1e-5
+    hr = F.conv2d(x.permute(0, 3, 1, 2), w, padding=1).permute(0, 2, 3, 1)
+    assert rel_err(h1, hr) < 3e-4
     yr = F.instance_norm(h1.permute(0, 3, 1, 2), eps=1e-5).permute(0, 2, 3, 1)
     assert rel_err(y1, yr) < 1e-4
     for ws in ops._norm_ws.values():

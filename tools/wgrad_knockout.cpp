@@ -1,5 +1,5 @@
 // Times the weight gradient of the step's dominant layer (16 x 32x32 x 512 -> 512, 3x3: wgrad_halo_bf16_kernel<NSX, 3, 2>) with parts
-// of the kernel compiled out (HOIG_WG_KO bits, hoig_amd/csrc/conv_igemm_bf16.hip); second argument 0 = all-zero operands (the same
+// of the kernel compiled out (HOIG_WG_KO bits, hoig_amd/csrc/wgrad_igemm_bf16.hip); second argument 0 = all-zero operands (the same
 // instruction stream without data toggling).  Built per variant by tools/wgrad_knockout.sh.
 #include <hip/hip_runtime.h>
 #include <cstdint>
