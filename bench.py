@@ -26,7 +26,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)          # the product package only; tests/ + oracle/ are reachable from the cpu-baseline child alone
 
 GFLOP_PER_PAIR_TRAIN_256 = 2555.2      # BASELINE.md §2 / SURVEY.md §8d (3*G + 3*VGG + 9*D), generator_spade_attn
-PMC_FILES = ['r05_pmc_dominant_conv.json', 'r04_pmc_dominant_conv.json', 'r03_pmc_dominant_conv.json', 'r02_pmc_dominant_conv_f6.json', 'r02_pmc_dominant_conv.json', 'r01_pmc_dominant_conv.json']      # newest first (matched by kernel name below)
+PMC_FILES = ['r06_pmc_dominant_conv.json', 'r05_pmc_dominant_conv.json', 'r04_pmc_dominant_conv.json', 'r03_pmc_dominant_conv.json', 'r02_pmc_dominant_conv_f6.json', 'r02_pmc_dominant_conv.json', 'r01_pmc_dominant_conv.json']      # newest first (matched by kernel name below)
 PEAK_F32, PEAK_16 = 157.3, 2500.0          # TFLOP/s dense MFMA (fp32 / fp16-bf16), MI355X_MICROARCH.md
 DTYPE_NAMES = {'f16f6': 'fwd: fp16 hi*hi + the two cross terms of the hi/lo split on block-scaled fp6 MFMA (1.6 bf16-MFMA units per product; layers outside that kernel: three fp16 terms) / bwd: bf16x2 (dy split hi+lo, weights and x single bf16), f32 accumulate',
                'bf16x3:f16x2': 'f16x3 fwd (both operands split hi+lo on fp16, 3 MFMAs per product) / bf16x2 bwd (dy split hi+lo, weights and x single bf16, 2 MFMAs per product), f32 accumulate',
@@ -103,7 +103,8 @@ def dominant_kernel_roofline(batch, side, precision, iters=50):
     nsx = {3: 2, 2: 3, 1: 1}[MFMA_TERMS[fwd]] if fwd not in ('f32', 'f16f6') else 0
     kname = ('igemm_f32_kernel' if fwd == 'f32' else 'conv_halo3_f6_kernel' if fwd == 'f16f6' else
              ('conv_halo3_m16_kernel<%d,4,2,128,true>' % nsx if m16 else 'conv_halo3_bf16_kernel<%d,4,2,128,2,true>' % nsx))
-    return dict(bound='mfma', kernel='%s (conv3x3 s1 512->512 @%dx%d; per step 24 launches over %d images = src+tsf stacked and 30 over %d)'
+    return dict(bound='mfma', launch_mix='the EAGER step\'s: a captured step runs the 30 eight-image launches as 15 grouped launches over 16 images (tuning key pair = 2)',
+                kernel='%s (conv3x3 s1 512->512 @%dx%d; per step 24 launches over %d images = src+tsf stacked and 30 over %d)'
                 % (kname, h, h, batch2, batch),
                 achieved=round(achieved, 2), peak=peak, unit='TFLOP/s', mfma_terms_per_product=MFMA_TERMS[fwd],
                 frac=round(achieved / peak, 4), traffic=traffic, traffic_source=traffic_source,

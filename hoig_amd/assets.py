@@ -101,7 +101,8 @@ def _texture_image(path, device):
     out = torch.empty((1, ATLAS, ATLAS, 3), dtype=torch.uint8, device=device)
     L.call('hoig_resize_linear_u8', rgb.data_ptr(), 1, int(rgb.shape[0]), int(rgb.shape[1]), 3, out.data_ptr(), ATLAS, ATLAS,
            torch.cuda.current_stream().cuda_stream)
-    return out[0].float() / 255.0 * 2.0 - 1
+    # (the three float operations on the HOST, as the reference's torch-CPU expression does them: a device division is not IEEE-exact)
+    return (out[0].cpu().float() / 255.0 * 2.0 - 1).to(device)
 
 
 def host_tables(hand_obj_path, objects, sem_hand, viewing_angle=30.0):

@@ -787,13 +787,19 @@ extern "C" int hoig_stream_create(hoig_stream_t *out) {
 namespace {
 struct Scratch { void *ptr; int64_t bytes; };
 std::mutex g_scratch_mu;
-std::map<hipStream_t, Scratch> g_scratch;
+// keyed by (device ordinal, stream): the null stream has the same handle on every device of a multi-device process
+std::map<std::pair<int, hipStream_t>, Scratch> g_scratch;
+std::pair<int, hipStream_t> scratch_key(hipStream_t st) {
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    return std::make_pair(dev, st);
+}
 bool g_scratch_warned = false;
 }  // namespace
 namespace hoig_detail {
 void *stream_scratch(hipStream_t st, size_t bytes) {
     std::lock_guard<std::mutex> lock(g_scratch_mu);
-    auto it = g_scratch.find(st);
+    auto it = g_scratch.find(scratch_key(st));
     if (it != g_scratch.end() && (size_t)it->second.bytes >= bytes) return it->second.ptr;
     if (!g_scratch_warned) {
         g_scratch_warned = true;
@@ -806,8 +812,8 @@ void *stream_scratch(hipStream_t st, size_t bytes) {
 extern "C" int64_t hoig_stream_scratch_bytes(void) { return (int64_t)16 << 20; }
 extern "C" int hoig_stream_scratch_set(hoig_stream_t stream, void *ptr, int64_t bytes) {
     std::lock_guard<std::mutex> lock(g_scratch_mu);
-    if (!ptr || bytes <= 0) g_scratch.erase((hipStream_t)stream);
-    else g_scratch[(hipStream_t)stream] = Scratch{ptr, bytes};
+    if (!ptr || bytes <= 0) g_scratch.erase(scratch_key((hipStream_t)stream));
+    else g_scratch[scratch_key((hipStream_t)stream)] = Scratch{ptr, bytes};
     return HOIG_OK;
 }
 extern "C" int hoig_stream_destroy(hoig_stream_t stream) {

@@ -805,22 +805,37 @@ class _ConvPair(Function):
             sp = torch.empty_like(dy)
             call('hoig_split_planes_bf16', _p(dy), _p(sp), npix, Co, _st())
             dys.append(sp)
-        dwa, ret_a = _grad_target(wa)
-        dwb, ret_b = _grad_target(wb)
-        side = _wgrad_side_stream(xa.device) if not (ret_a or ret_b) else None
-        if side is not None:
-            side.wait_stream(torch.cuda.current_stream())
-        with torch.cuda.stream(side) if side is not None else contextlib.nullcontext():
+        # weight gradients: only for the weights that need one (frozen weights: ADVICE r5); a shape the LDS-DMA kernel refuses degrades to
+        # the un-split kernel per problem, as _Conv._backward_split does
+        need = (bool(ctx.needs_input_grad[2]), bool(ctx.needs_input_grad[3]))
+        dwa, ret_a = _grad_target(wa) if need[0] else (None, False)
+        dwb, ret_b = _grad_target(wb) if need[1] else (None, False)
+        if need[0] or need[1]:
+            side = _wgrad_side_stream(xa.device) if not (ret_a or ret_b) else None
             if side is not None:
-                test_delay('wgrad')
-            rc = L.lib.hoig_conv2d_bwd_weight_split_pair(ctypes.byref(d_wg), _p(xa), _p(xb), _p(dys[0]), _p(dys[1]), _p(dwa), _p(dwb), _st())
-            if rc == L.EUNSUPPORTED:
-                for x, sp, dw in ((xa, dys[0], dwa), (xb, dys[1], dwb)):
-                    call('hoig_conv2d_bwd_weight_split', ctypes.byref(d_wg), _p(x), _p(sp), _p(dw), _st())
-            else:
-                L.check(rc, 'hoig_conv2d_bwd_weight_split_pair')
-        if side is not None:
-            _wgrad_hold(side, (xa, xb, dys[0], dys[1]))
+                side.wait_stream(torch.cuda.current_stream())
+            held = [xa, xb, dys[0], dys[1]]
+            with torch.cuda.stream(side) if side is not None else contextlib.nullcontext():
+                if side is not None:
+                    test_delay('wgrad')
+                rc = L.EUNSUPPORTED
+                if need[0] and need[1]:
+                    rc = L.lib.hoig_conv2d_bwd_weight_split_pair(ctypes.byref(d_wg), _p(xa), _p(xb), _p(dys[0]), _p(dys[1]), _p(dwa), _p(dwb), _st())
+                if rc == L.EUNSUPPORTED:
+                    for x, sp, dw, nd in ((xa, dys[0], dwa, need[0]), (xb, dys[1], dwb, need[1])):
+                        if not nd:
+                            continue
+                        rc1 = L.lib.hoig_conv2d_bwd_weight_split(ctypes.byref(d_wg), _p(x), _p(sp), _p(dw), _st())
+                        if rc1 == L.EUNSUPPORTED:
+                            plain = _unsplit(sp)
+                            held.append(plain)
+                            wgrad_call('hoig_conv2d_bwd_weight', d_wg, _p(x), _p(plain), _p(dw), None, _st())
+                        else:
+                            L.check(rc1, 'hoig_conv2d_bwd_weight_split')
+                else:
+                    L.check(rc, 'hoig_conv2d_bwd_weight_split_pair')
+            if side is not None:
+                _wgrad_hold(side, tuple(held))
         dxa = dxb = None
         if ctx.needs_input_grad[0] or ctx.needs_input_grad[1]:
             dxa, dxb = torch.empty_like(xa), torch.empty_like(xb)
@@ -839,7 +854,7 @@ class _ConvPair(Function):
                         L.check(rc1, 'hoig_conv2d_bwd_data_packed_split')
             else:
                 L.check(rc, 'hoig_conv2d_bwd_data_packed_split_pair')
-        return dxa, dxb, (dwa if ret_a else None), (dwb if ret_b else None), db_ret[0], db_ret[1], None, None, None
+        return dxa, dxb, (dwa if (need[0] and ret_a) else None), (dwb if (need[1] and ret_b) else None), db_ret[0], db_ret[1], None, None, None
 
 
 def conv2d_pair(xa, xb, wa, wb, ba=None, bb=None, prec=None, dead_bias=False, fork=False):

@@ -335,3 +335,40 @@ def test_step_with_grouped_launches_matches_the_step_without():
         assert abs(res[1][1][k] - v) <= 1e-5 * max(abs(v), 1e-2), (k, res[1][1][k], v)
     g1, g0 = res[1][2], res[0][2]
     assert ((g1 - g0).norm() / g0.norm()).item() < 2e-2
+
+
+def test_grouped_backward_skips_the_weight_gradient_of_a_frozen_weight():
+    """ops.conv2d_pair with one of the two weights frozen (the grouped backward used to compute -- and need a gradient
+    buffer for -- both): the live weight's gradient and both data gradients equal the all-live run's, the frozen one's buffer stays
+    untouched."""
+    from hoig_amd import _lib as L, nn as hnn, ops
+    ops.set_precision('bf16x3:f16x2')
+    prev = L.set_tuning('pair', 1)
+    try:
+        g = torch.Generator(device='cuda').manual_seed(23)
+        tree = hnn.ParamTree({'a.weight': (128, 64, 3, 3), 'b.weight': (128, 64, 3, 3)}, torch.device('cuda'), {}, {})
+        with torch.no_grad():
+            tree.flat.copy_(torch.randn(tree.flat.shape, device='cuda', generator=g) * 0.05)
+        tree.version += 1
+        xa0, xb0 = (torch.randn(8, 32, 32, 64, device='cuda', generator=g) for _ in range(2))
+        ga, gb = (torch.randn(8, 32, 32, 128, device='cuda', generator=g) for _ in range(2))
+        wa, wb = tree.P['a.weight'], tree.P['b.weight']
+        assert ops.pair_ok(xa0, xb0, wa, wb)
+        res = []
+        for frozen in (False, True):
+            tree.flat_grad.zero_()
+            wb.requires_grad_(not frozen)
+            xa, xb = xa0.clone().requires_grad_(True), xb0.clone().requires_grad_(True)
+            ya, yb = ops.conv2d_pair(xa, xb, wa, wb)
+            ((ya * ga).sum() + (yb * gb).sum()).backward()
+            ops.join_wgrad_streams()
+            torch.cuda.synchronize()
+            res.append((xa.grad.clone(), xb.grad.clone(), wa.grad.clone(), wb.grad.clone()))
+        wb.requires_grad_(True)
+        (dxa0, dxb0, dwa0, dwb0), (dxa1, dxb1, dwa1, dwb1) = res
+        assert torch.equal(dxa0, dxa1) and torch.equal(dxb0, dxb1)
+        assert ((dwa0 - dwa1).norm() / dwa0.norm()).item() < 2e-5 and dwb0.abs().max().item() > 0
+        assert dwb1.abs().max().item() == 0.0
+    finally:
+        L.set_tuning('pair', prev)
+        ops.set_precision('f32')
