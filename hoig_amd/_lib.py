@@ -138,6 +138,9 @@ _SIGS = {
     'hoig_prep_lookup': [_vp] * 5 + [_i] + [_vp] * 8,
     'hoig_prep_assemble': [_i] + [_vp] * 17 + [_i] + [_vp] * 6,
     'hoig_rasterize_fim_wim': [_vp, _i, _i, _i, _f, _f, _vp, _vp, _vp, _vp],
+    'hoig_project_faces': [_vp, _i, _vp, _i, _vp, _vp, _i, _i, _f, _f, _vp, _vp],
+    'hoig_prep_texture_batched': [_i, _vp, _vp, _i64, _vp, _vp, _vp, _vp, _vp, _vp, _vp],
+    'hoig_prep_lookup_batched': [_i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _vp, _vp, _vp, _vp, _vp, _vp],
     'hoig_mano_lbs': [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _vp, _vp, _vp, _vp, _vp, _i, _vp, _i, _vp],
 }
 

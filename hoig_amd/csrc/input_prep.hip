@@ -147,6 +147,121 @@ __global__ void prep_lookup_kernel(const int *__restrict__ fim, const float *__r
     }
 }
 
+
+// ---- batched forms (round 6): one launch for the whole batch instead of one per sample.  The per-sample object tables differ (every
+// sample has its own object), so their device addresses travel BY VALUE in the argument block (B <= HOIG_PREP_MAX_BATCH); blockIdx.y is
+// the sample.  Same arithmetic as the per-sample kernels above, which stay (they are the C ABI of one sample).
+constexpr int MAXB = HOIG_PREP_MAX_BATCH;
+struct TexBatch {
+    const float *src_img, *src_faces;          // [B,3,S,S], [B,Fstride/9,3,3]
+    const int *src_fim;                        // [B,S,S]
+    const int *fim_uv[MAXB];
+    const float *wim_uv[MAXB], *obj_tex[MAXB];
+    unsigned char *occ;                        // [B, S*TW]
+    float *tex;                                // [B,3,S,TW]
+    long long face_stride;                     // floats between two samples' face tensors
+};
+__global__ void prep_occlusion_batched_kernel(const TexBatch a) {
+    const int b = blockIdx.y;
+    const int i = blockIdx.x * NT + threadIdx.x;
+    if (i >= S * TW) return;
+    const float *faces = a.src_faces + (size_t)b * a.face_stride;
+    const int *src_fim = a.src_fim + (size_t)b * S * S;
+    const int f = a.fim_uv[b][i];
+    unsigned char o = 0;
+    if (f != -1) {
+        const float2 t = bary<3>(faces, f, a.wim_uv[b] + (size_t)i * 3);
+        const float px = __fmul_rn(__fadd_rn(t.x, 1.f) / 2.f, 255.f), py = __fmul_rn(__fadd_rn(t.y, 1.f) / 2.f, 255.f);
+        const int cx = min(max((int)px, 0), 255), cy = min(max((int)py, 0), 255);
+        bool vis = false;
+#pragma unroll
+        for (int dy = -1; dy <= 1; ++dy)
+#pragma unroll
+            for (int dx = -1; dx <= 1; ++dx) {
+                const int qx = min(max(cx + dx, 0), 255), qy = min(max(cy + dy, 0), 255);
+                vis |= src_fim[qy * 256 + qx] == f;
+            }
+        o = vis ? 0 : 1;
+    }
+    a.occ[(size_t)b * S * TW + i] = o;
+}
+__global__ void prep_texture_batched_kernel(const TexBatch a) {
+    const int b = blockIdx.y;
+    const int i = blockIdx.x * NT + threadIdx.x;
+    if (i >= S * TW) return;
+    const int y = i / TW, x = i - y * TW;
+    float *tex = a.tex + (size_t)b * 3 * S * TW;
+    if (x >= 384) {
+#pragma unroll
+        for (int c = 0; c < 3; ++c) tex[(size_t)c * S * TW + i] = a.obj_tex[b][((size_t)y * 256 + (x - 384)) * 3 + c];
+        return;
+    }
+    const unsigned char *occ = a.occ + (size_t)b * S * TW;
+    bool o2 = false;                                       // dilate(erode(occ))
+    for (int dy = -1; dy <= 1; ++dy)
+        for (int dx = -1; dx <= 1; ++dx) {
+            const int qy = y + dy, qx = x + dx;
+            if (qy < 0 || qy >= S || qx < 0 || qx >= TW) continue;
+            bool e = true;
+            for (int ey = -1; ey <= 1; ++ey)
+                for (int ex = -1; ex <= 1; ++ex) {
+                    const int ry = qy + ey, rx = qx + ex;
+                    if (ry < 0 || ry >= S || rx < 0 || rx >= TW) continue;
+                    e &= occ[ry * TW + rx] != 0;
+                }
+            o2 |= e;
+        }
+    float v[3] = {1.f, 1.f, 1.f};
+    if (!o2) {
+        const int f = a.fim_uv[b][i];
+        float2 t = make_float2(-2.f, -2.f);
+        if (f != -1) t = bary<3>(a.src_faces + (size_t)b * a.face_stride, f, a.wim_uv[b] + (size_t)i * 3);
+        sample3(a.src_img + (size_t)b * 3 * S * S, S, S, t.x, t.y, false, v);
+    }
+#pragma unroll
+    for (int c = 0; c < 3; ++c) tex[(size_t)c * S * TW + i] = v[c];
+}
+
+struct LookupBatch {
+    const int *fim;                            // [B,S,S]
+    const float *wim;                          // [B,S,S,3]
+    const float *map_fn[MAXB], *sem[MAXB], *uv_coord[MAXB];
+    int n_faces[MAXB];
+    const float *tex, *src_faces;              // [B,3,S,TW], [B,.,3,3]
+    long long face_stride;
+    float *cond, *seg, *hand_region, *rend, *T;    // [B,3,S,S], [B,S,S], [B,S,S], [B,3,S,S], [B,S,S,2] (nullable)
+};
+__global__ void prep_lookup_batched_kernel(const LookupBatch a) {
+    const int b = blockIdx.y;
+    const int i = blockIdx.x * NT + threadIdx.x;
+    if (i >= S * S) return;
+    const size_t P = (size_t)S * S;
+    const int f = a.fim[b * P + i];
+    const int row = f < 0 ? a.n_faces[b] : f;
+    const float *map_fn = a.map_fn[b];
+    float *cond = a.cond + b * 3 * P;
+    cond[i] = map_fn[row * 3];
+    cond[P + i] = map_fn[row * 3 + 1];
+    cond[2 * P + i] = map_fn[row * 3 + 2];
+    a.seg[b * P + i] = a.sem[b][row];
+    a.hand_region[b * P + i] = (f != -1 && f < NHAND) ? 0.f : 1.f;
+    const float *w = a.wim + (b * P + i) * 3;
+    float2 tt = make_float2(-2.f, -2.f);
+    if (f != -1) tt = bary<2>(a.uv_coord[b], f, w);
+    float v[3];
+    sample3(a.tex + (size_t)b * 3 * S * TW, S, TW, tt.x, tt.y, true, v);
+    float *rend = a.rend + b * 3 * P;
+    rend[i] = v[0];
+    rend[P + i] = v[1];
+    rend[2 * P + i] = v[2];
+    if (a.T) {
+        float2 t = make_float2(-2.f, -2.f);
+        if (f != -1) t = bary<3>(a.src_faces + (size_t)b * a.face_stride, f, w);
+        a.T[(b * P + i) * 2] = t.x;
+        a.T[(b * P + i) * 2 + 1] = t.y;
+    }
+}
+
 // util.morph(mode='erode'): sum over the ks x ks window with the outside counted as 1, == ks * ks
 __device__ inline float erode(const float *__restrict__ m, int y, int x, int r) {
     float s = 0.f;
@@ -244,6 +359,44 @@ extern "C" int hoig_prep_lookup(const int32_t *fim, const float *wim, const floa
         return HOIG_EINVAL;
     prep_lookup_kernel<<<(S * S + NT - 1) / NT, NT, 0, ST>>>(fim, wim, map_fn, sem_full, faces_uv_coord, n_faces, tex, src_faces,
                                                              cond, seg, hand_region, rend, T);
+    HOIG_LAUNCH_CHECK();
+    return HOIG_OK;
+}
+
+extern "C" int hoig_prep_texture_batched(int B, const float *src_img, const float *src_faces, int64_t face_stride, const int32_t *src_fim,
+                                         const int32_t *const *fim_uv, const float *const *wim_uv, const float *const *obj_tex_img,
+                                         unsigned char *occ_ws, float *tex, hoig_stream_t stream) {
+    if (B <= 0 || B > HOIG_PREP_MAX_BATCH) return HOIG_EUNSUPPORTED;
+    if (!src_img || !src_faces || !src_fim || !fim_uv || !wim_uv || !obj_tex_img || !occ_ws || !tex || face_stride <= 0) return HOIG_EINVAL;
+    TexBatch a;
+    a.src_img = src_img; a.src_faces = src_faces; a.src_fim = src_fim; a.occ = occ_ws; a.tex = tex; a.face_stride = face_stride;
+    for (int b = 0; b < B; ++b) {
+        if (!fim_uv[b] || !wim_uv[b] || !obj_tex_img[b]) return HOIG_EINVAL;
+        a.fim_uv[b] = fim_uv[b]; a.wim_uv[b] = wim_uv[b]; a.obj_tex[b] = obj_tex_img[b];
+    }
+    const dim3 grid((S * TW + NT - 1) / NT, B);
+    prep_occlusion_batched_kernel<<<grid, NT, 0, ST>>>(a);
+    prep_texture_batched_kernel<<<grid, NT, 0, ST>>>(a);
+    HOIG_LAUNCH_CHECK();
+    return HOIG_OK;
+}
+
+extern "C" int hoig_prep_lookup_batched(int B, const int32_t *fim, const float *wim, const float *const *map_fn, const float *const *sem_full,
+                                        const float *const *faces_uv_coord, const int *n_faces, const float *tex, const float *src_faces,
+                                        int64_t face_stride, float *cond, float *seg, float *hand_region, float *rend, float *T,
+                                        hoig_stream_t stream) {
+    if (B <= 0 || B > HOIG_PREP_MAX_BATCH) return HOIG_EUNSUPPORTED;
+    if (!fim || !wim || !map_fn || !sem_full || !faces_uv_coord || !n_faces || !tex || !cond || !seg || !hand_region || !rend ||
+        (T && (!src_faces || face_stride <= 0)))
+        return HOIG_EINVAL;
+    LookupBatch a;
+    a.fim = fim; a.wim = wim; a.tex = tex; a.src_faces = src_faces; a.face_stride = face_stride;
+    a.cond = cond; a.seg = seg; a.hand_region = hand_region; a.rend = rend; a.T = T;
+    for (int b = 0; b < B; ++b) {
+        if (!map_fn[b] || !sem_full[b] || !faces_uv_coord[b] || n_faces[b] <= 0) return HOIG_EINVAL;
+        a.map_fn[b] = map_fn[b]; a.sem[b] = sem_full[b]; a.uv_coord[b] = faces_uv_coord[b]; a.n_faces[b] = n_faces[b];
+    }
+    prep_lookup_batched_kernel<<<dim3((S * S + NT - 1) / NT, B), NT, 0, ST>>>(a);
     HOIG_LAUNCH_CHECK();
     return HOIG_OK;
 }

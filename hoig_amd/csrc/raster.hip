@@ -148,6 +148,54 @@ __global__ __launch_bounds__(NT) void raster_tile_kernel(const float *__restrict
         wim[o * 3 + 2] = best >= 0 ? wmin[2] : 0.f;
     }
 }
+
+// ---- the vertex stage of render_fim_wim for a whole batch in ONE launch (round 6): projection (nmr.py:109-140 / the DexYCB copy's
+// :146-163), y flip (:506), nr.look_at with the renderer's eye (a shift of z: the rotation is the identity) and nr.vertices_to_faces,
+// for samples whose objects -- hence face lists -- differ: the lists' device addresses travel by value in the argument block.
+// hoig_amd.raster.project_to_faces is the same arithmetic as ~20 batched torch ops per object group (it stays: the reference-shaped
+// function, and the test fixture's subject); this file is compiled without FMA contraction, so sums are (a + b) + c as written.
+struct ProjArgs {
+    const float *cam, *verts;                  // [B][cam_dim], [B][V][3]
+    const long long *faces[HOIG_PREP_MAX_BATCH];   // [F_b][3] int64
+    int nf[HOIG_PREP_MAX_BATCH];
+    int B, V, cam_dim, Fmax;
+    float eye_z, pad;
+    float *out;                                // [B][Fmax][3][3]
+};
+__global__ void project_faces_kernel(const ProjArgs a) {
+    const int b = blockIdx.y;
+    const int i = blockIdx.x * NT + threadIdx.x;           // (face, corner)
+    if (i >= a.Fmax * 3) return;
+    const int f = i / 3;
+    float *o = a.out + ((size_t)b * a.Fmax * 3 + i) * 3;
+    if (f >= a.nf[b]) {                                    // padding face: all three vertices at one far-away point
+        o[0] = a.pad; o[1] = a.pad; o[2] = a.pad;
+        return;
+    }
+    const long long vid = a.faces[b][i];
+    const float *v = a.verts + ((size_t)b * a.V + (size_t)vid) * 3;
+    const float *c = a.cam + (size_t)b * a.cam_dim;
+    float x, y, z;
+    const float *tr;
+    if (a.cam_dim == 15) {                                 // HOv3: OpenGL axis change, 3x3 camera matrix, perspective divide
+        const float p0 = v[0], p1 = -v[1], p2 = -v[2];
+        const float q0 = (p0 * c[0] + p1 * c[1]) + p2 * c[2];
+        const float q1 = (p0 * c[3] + p1 * c[4]) + p2 * c[5];
+        const float q2 = (p0 * c[6] + p1 * c[7]) + p2 * c[8];
+        x = q0 / q2; y = q1 / q2; z = p2;
+        tr = c + 9;
+    } else {                                               // DexYCB: [fx, fy, cx, cy | 2x3 crop transform]
+        x = v[0] / (v[2] + 1e-8f) * c[0] + c[2];
+        y = v[1] / (v[2] + 1e-8f) * c[1] + c[3];
+        z = v[2];
+        tr = c + 4;
+    }
+    const float u = (tr[0] * x + tr[1] * y) + tr[2];       // the 2x3 crop transform on (x, y, 1)
+    const float w = (tr[3] * x + tr[4] * y) + tr[5];
+    o[0] = u / 255.0f * 2.f - 1.f;
+    o[1] = -(w / 255.0f * 2.f - 1.f);                      // nmr.py:506
+    o[2] = z - a.eye_z;                                    // look_at: vertices - eye
+}
 }  // namespace
 
 extern "C" size_t hoig_rasterize_workspace_bytes(int B, int F) {
@@ -163,6 +211,23 @@ extern "C" int hoig_rasterize_fim_wim(const float *faces, int B, int F, int imag
     raster_setup_kernel<<<(B * F + NT - 1) / NT, NT, 0, st>>>(faces, B * F, image_size, rec, box);
     const int tiles = (image_size + TILE - 1) / TILE;
     raster_tile_kernel<<<dim3(tiles * tiles, B), NT, 0, st>>>(rec, box, F, image_size, near, far, fim, wim);
+    HOIG_LAUNCH_CHECK();
+    return HOIG_OK;
+}
+
+extern "C" int hoig_project_faces(const float *cam, int cam_dim, const float *verts, int V, const int64_t *const *face_lists,
+                                  const int *n_faces, int B, int Fmax, float eye_z, float pad_value, float *faces_out,
+                                  hoig_stream_t stream) {
+    if (B <= 0 || B > HOIG_PREP_MAX_BATCH) return HOIG_EUNSUPPORTED;
+    if (!cam || !verts || !face_lists || !n_faces || !faces_out || V <= 0 || Fmax <= 0 || (cam_dim != 15 && cam_dim != 10)) return HOIG_EINVAL;
+    ProjArgs a;
+    a.cam = cam; a.verts = verts; a.B = B; a.V = V; a.cam_dim = cam_dim; a.Fmax = Fmax; a.eye_z = eye_z; a.pad = pad_value; a.out = faces_out;
+    for (int b = 0; b < B; ++b) {
+        if (!face_lists[b] || n_faces[b] < 0 || n_faces[b] > Fmax) return HOIG_EINVAL;
+        a.faces[b] = reinterpret_cast<const long long *>(face_lists[b]);
+        a.nf[b] = n_faces[b];
+    }
+    project_faces_kernel<<<dim3((Fmax * 3 + NT - 1) / NT, B), NT, 0, (hipStream_t)stream>>>(a);
     HOIG_LAUNCH_CHECK();
     return HOIG_OK;
 }

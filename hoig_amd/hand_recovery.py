@@ -47,20 +47,24 @@ class HandRecoveryFlow(object):
             self._objects[int(k)] = dict(faces=faces, tables=tables, length=int(faces.max()) + 1)      # trainer.py:65
 
     def _render(self, info, obj_ids, fmax):
-        """render_fim_wim (nmr.py:496-513) for every sample of one view: samples that share an object are projected together, the
-        whole batch is rasterised by one launch pair."""
+        """render_fim_wim (nmr.py:496-513) for every sample of one view: ONE launch projects every sample's vertices through its own
+        object's face list (round 6: hoig_project_faces; ~20 batched torch ops per object group before), one launch pair rasterises
+        the whole batch."""
         B = len(obj_ids)
-        faces = torch.full((B, fmax, 3, 3), FAR_AWAY, dtype=torch.float32, device=self.device)
-        for k in sorted(set(obj_ids)):
-            rows = [i for i, o in enumerate(obj_ids) if o == k]
-            ob = self._objects[k]
-            if len(rows) == B:                           # one object in the batch: plain slices, no index tensor at all
-                f = raster.project_to_faces(info['cam'], info['verts'][:, :ob['length']], ob['faces'])
-                faces[:, :f.shape[1]] = f
-                continue
-            idx = ops.device_index(rows, self.device)    # (no host wait: pinned + non-blocking, cached)
-            f = raster.project_to_faces(info['cam'][idx], info['verts'][idx, :ob['length']], ob['faces'])
-            faces[idx, :f.shape[1]] = f
+        if B <= IP.MAX_BATCH:
+            need = max(self._objects[k]['length'] for k in obj_ids)
+            if info['verts'].shape[1] < need:
+                raise ValueError('the batch holds %d vertices per sample; its objects\' face lists address %d' % (info['verts'].shape[1], need))
+            faces = raster.project_faces_batched(info['cam'], info['verts'], [self._objects[k]['faces'] for k in obj_ids], fmax,
+                                                 pad_value=FAR_AWAY)
+        else:
+            faces = torch.full((B, fmax, 3, 3), FAR_AWAY, dtype=torch.float32, device=self.device)
+            for k in sorted(set(obj_ids)):
+                rows = [i for i, o in enumerate(obj_ids) if o == k]
+                ob = self._objects[k]
+                idx = ops.device_index(rows, self.device)    # (no host wait: pinned + non-blocking, cached)
+                f = raster.project_to_faces(info['cam'][idx], info['verts'][idx, :ob['length']], ob['faces'])
+                faces[idx, :f.shape[1]] = f
         fim, wim = raster.rasterize_fim_wim(faces, raster_size(self._opt))
         return faces, fim, wim
 

@@ -6,7 +6,7 @@ meshes, not part of this build) has produced, per sample and view, the projected
 the barycentric weight map.  Everything downstream -- encode_fim / encode_sem (nmr.py:567-595), cal_bc_transform
 (nmr.py:874-968), get_texture_backward_warp (nmr.py:973-1058), sample_from_texture_dense (nmr.py:1068-1100), the two
 ``F.grid_sample`` calls and the 3x3 / 15x15 ``util.morph`` erosions with the channel bookkeeping of trainer.py:103-145 -- runs
-as three HIP kernels per sample plus one per batch (hoig_amd/csrc/input_prep.hip); the reference runs ~60 small torch ops per
+as five HIP launches per batch (round 6; three kernels per sample plus one per batch before: hoig_amd/csrc/input_prep.hip); the reference runs ~60 small torch ops per
 sample in a Python loop.  HOv3 and DexYCB channel layouts; 256 x 256 only, as the reference hard-wires it.
 
 ``prepare_inputs`` returns the reference's 12-tuple (NCHW).  ``to_prepared`` turns it into the dict ``Trainer.set_input``
@@ -17,6 +17,7 @@ import torch
 from . import _lib as L
 
 S, TEX_W = 256, 640
+MAX_BATCH = 32                      # HOIG_PREP_MAX_BATCH (include/hoig_kernels.h): the batched entry points' limit
 _TABLE_KEYS = ('map_fn', 'sem_full', 'fim_uv', 'wim_uv', 'faces_uv_coord', 'obj_tex_img')
 
 
@@ -116,22 +117,41 @@ def prepare_inputs(src_img, ref_img, src_faces, src_fim, src_wim, ref_fim, ref_w
     dev = src_img.device
     new = lambda *shape: torch.empty(shape, dtype=torch.float32, device=dev)
     st = torch.cuda.current_stream().cuda_stream
-    occ = torch.empty(S * TEX_W, dtype=torch.uint8, device=dev)
-    tex = new(3, S, TEX_W)
     cond_s, cond_r, rend_s, rend_r = new(B, 3, S, S), new(B, 3, S, S), new(B, 3, S, S), new(B, 3, S, S)
     seg_s, seg_r, hr_s, hr_r = new(B, S, S), new(B, S, S), new(B, S, S), new(B, S, S)
     T_raw = new(B, S, S, 2)
-    for i in range(B):
-        tb = tables[i]
+    for i, tb in enumerate(tables):
         if src_faces.shape[1] < tb.n_faces:
             raise ValueError('src_faces has fewer rows than sample %d has faces' % i)
-        L.call('hoig_prep_texture', src_img[i].data_ptr(), src_faces[i].data_ptr(), src_fim[i].data_ptr(), tb.fim_uv.data_ptr(),
-               tb.wim_uv.data_ptr(), tb.obj_tex_img.data_ptr(), occ.data_ptr(), tex.data_ptr(), st)
+    if B <= MAX_BATCH:
+        # one call per stage for the whole batch (round 6): the per-sample tables travel as host arrays of device pointers
+        import ctypes
+        vp = lambda ts: ctypes.cast((ctypes.c_void_p * B)(*[t.data_ptr() for t in ts]), ctypes.c_void_p)
+        nf = ctypes.cast((ctypes.c_int * B)(*[tb.n_faces for tb in tables]), ctypes.c_void_p)
+        occ = torch.empty(B, S * TEX_W, dtype=torch.uint8, device=dev)
+        tex = new(B, 3, S, TEX_W)
+        fstride = int(src_faces.stride(0))
+        L.call('hoig_prep_texture_batched', B, src_img.data_ptr(), src_faces.data_ptr(), fstride, src_fim.data_ptr(),
+               vp([tb.fim_uv for tb in tables]), vp([tb.wim_uv for tb in tables]), vp([tb.obj_tex_img for tb in tables]),
+               occ.data_ptr(), tex.data_ptr(), st)
+        maps = (vp([tb.map_fn for tb in tables]), vp([tb.sem_full for tb in tables]), vp([tb.faces_uv_coord for tb in tables]))
         for fim, wim, cond, seg, hr, rend, T in ((src_fim, src_wim, cond_s, seg_s, hr_s, rend_s, None),
                                                  (ref_fim, ref_wim, cond_r, seg_r, hr_r, rend_r, T_raw)):
-            L.call('hoig_prep_lookup', fim[i].data_ptr(), wim[i].data_ptr(), tb.map_fn.data_ptr(), tb.sem_full.data_ptr(),
-                   tb.faces_uv_coord.data_ptr(), tb.n_faces, tex.data_ptr(), src_faces[i].data_ptr(), cond[i].data_ptr(),
-                   seg[i].data_ptr(), hr[i].data_ptr(), rend[i].data_ptr(), None if T is None else T[i].data_ptr(), st)
+            L.call('hoig_prep_lookup_batched', B, fim.data_ptr(), wim.data_ptr(), maps[0], maps[1], maps[2], nf, tex.data_ptr(),
+                   src_faces.data_ptr(), fstride, cond.data_ptr(), seg.data_ptr(), hr.data_ptr(), rend.data_ptr(),
+                   None if T is None else T.data_ptr(), st)
+    else:
+        occ = torch.empty(S * TEX_W, dtype=torch.uint8, device=dev)
+        tex = new(3, S, TEX_W)
+        for i in range(B):
+            tb = tables[i]
+            L.call('hoig_prep_texture', src_img[i].data_ptr(), src_faces[i].data_ptr(), src_fim[i].data_ptr(), tb.fim_uv.data_ptr(),
+                   tb.wim_uv.data_ptr(), tb.obj_tex_img.data_ptr(), occ.data_ptr(), tex.data_ptr(), st)
+            for fim, wim, cond, seg, hr, rend, T in ((src_fim, src_wim, cond_s, seg_s, hr_s, rend_s, None),
+                                                     (ref_fim, ref_wim, cond_r, seg_r, hr_r, rend_r, T_raw)):
+                L.call('hoig_prep_lookup', fim[i].data_ptr(), wim[i].data_ptr(), tb.map_fn.data_ptr(), tb.sem_full.data_ptr(),
+                       tb.faces_uv_coord.data_ptr(), tb.n_faces, tex.data_ptr(), src_faces[i].data_ptr(), cond[i].data_ptr(),
+                       seg[i].data_ptr(), hr[i].data_ptr(), rend[i].data_ptr(), None if T is None else T[i].data_ptr(), st)
     src_bg = new(B, 4, S, S)
     tsf_bg = new(B, 4, S, S) if bg_both else None
     hc = 12 if dexycb else 6

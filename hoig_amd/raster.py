@@ -81,6 +81,29 @@ def project_to_faces(cam, vertices, faces_idx, viewing_angle=30.0):
     return v[torch.arange(v.shape[0], device=v.device)[:, None, None], idx]           # vertices_to_faces
 
 
+def project_faces_batched(cam, vertices, face_lists, fmax, viewing_angle=30.0, pad_value=-1.0e6):
+    """project_to_faces for a batch whose samples hold DIFFERENT objects, as ONE launch (hoig_project_faces): cam (B,15|10), vertices
+    (B,V,3), face_lists: B int64 (F_b,3) device tensors over the sample's [hand | object] vertex buffer -> faces (B,fmax,3,3) with the
+    rows beyond a sample's own face count at `pad_value` (a point no pixel can see: the rasteriser's empty box)."""
+    import ctypes
+    if not vertices.is_cuda:
+        raise NotImplementedError('hoig_amd.raster runs on the HIP device only (no CPU path)')
+    B, V = int(vertices.shape[0]), int(vertices.shape[1])
+    cam, vertices = cam.float().contiguous(), vertices.float().contiguous()
+    if len(face_lists) != B or cam.shape[0] != B or cam.shape[1] not in (10, 15):
+        raise ValueError('one face list per sample; cam (B,15) or (B,10)')
+    for fl in face_lists:
+        if fl.dtype != torch.int64 or fl.dim() != 2 or fl.shape[1] != 3 or not fl.is_contiguous() or fl.shape[0] > fmax:
+            raise ValueError('face lists must be contiguous int64 (F,3) with F <= fmax')
+    out = torch.empty(B, int(fmax), 3, 3, dtype=torch.float32, device=vertices.device)
+    ptrs = ctypes.cast((ctypes.c_void_p * B)(*[fl.data_ptr() for fl in face_lists]), ctypes.c_void_p)
+    nf = ctypes.cast((ctypes.c_int * B)(*[int(fl.shape[0]) for fl in face_lists]), ctypes.c_void_p)
+    eye_z = -(1.0 / math.tan(math.radians(viewing_angle)) + 1.0)
+    L.call('hoig_project_faces', cam.data_ptr(), int(cam.shape[1]), vertices.data_ptr(), V, ptrs, nf, B, int(fmax), eye_z,
+           float(pad_value), out.data_ptr(), torch.cuda.current_stream().cuda_stream)
+    return out
+
+
 def render_fim_wim(cam, vertices, faces_idx, image_size=256, viewing_angle=30.0):
     """MANORenderer.render_fim_wim (nmr.py:496-513): returns (faces (B,F,3,3), fim, wim).  faces_idx (F,3) or (B,F,3) int."""
     faces = project_to_faces(cam, vertices, faces_idx, viewing_angle)

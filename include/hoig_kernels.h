@@ -452,6 +452,20 @@ int hoig_prep_texture(const float *src_img, const float *src_faces, const int32_
 int hoig_prep_lookup(const int32_t *fim, const float *wim, const float *map_fn, const float *sem_full,
                      const float *faces_uv_coord, int n_faces, const float *tex, const float *src_faces, float *cond,
                      float *seg, float *hand_region, float *rend, float *T, hoig_stream_t stream);
+/* The same two stages for a whole BATCH in one call each (round 6: two + one launches instead of B x (two + one); the chain of small
+ * launches is what the raw-batch stage costs a loader-fed step).  Tensors are the per-sample ones stacked over B; src_faces is
+ * [B][.][3][3] with face_stride floats between samples; the per-sample object buffers -- every sample may hold another object -- are
+ * passed as HOST arrays of B device pointers (n_faces: host array of B ints) and travel to the kernels by value, so B <=
+ * HOIG_PREP_MAX_BATCH (HOIG_EUNSUPPORTED beyond: the caller then loops over the per-sample entry points).  occ_ws: B * 256 * 640 bytes;
+ * tex [B,3,256,640]. */
+#define HOIG_PREP_MAX_BATCH 32
+int hoig_prep_texture_batched(int B, const float *src_img, const float *src_faces, int64_t face_stride, const int32_t *src_fim,
+                              const int32_t *const *fim_uv, const float *const *wim_uv, const float *const *obj_tex_img,
+                              unsigned char *occ_ws, float *tex, hoig_stream_t stream);
+int hoig_prep_lookup_batched(int B, const int32_t *fim, const float *wim, const float *const *map_fn, const float *const *sem_full,
+                             const float *const *faces_uv_coord, const int *n_faces, const float *tex, const float *src_faces,
+                             int64_t face_stride, float *cond, float *seg, float *hand_region, float *rend, float *T /*nullable*/,
+                             hoig_stream_t stream);
 /* batch: images [B,3,256,256]; the hoig_prep_lookup outputs of both views stacked over the batch; T_raw [B,256,256,2].
  * out: src_bg [B,4,..], tsf_bg (nullable: bg_both) [B,4,..], src_obj / tsf_obj [B,15,..], src_hand / ref_hand
  * [B,hand_channels,..] with hand_channels = 6 (HOv3) or 12 (DexYCB: + the six hand-part one-hots, HOIG_DexYCB/models/trainer.py:131,135),
@@ -469,6 +483,14 @@ int hoig_prep_assemble(int B, const float *src_img, const float *ref_img, const 
  *      faces [B,F,3,3] (vertices_to_faces output: x, y in [-1,1], y up, z depth); fim [B,S,S] int32 (-1 = no face),
  *      wim [B,S,S,3]; workspace: hoig_rasterize_workspace_bytes(B, F) bytes.  Tile-binned (16x16-pixel tiles). ---- */
 size_t hoig_rasterize_workspace_bytes(int B, int F);
+/* The vertex stage in front of it for a whole batch in ONE launch: MANORenderer's projection (orthographic_proj_withz_idrot,
+ * utils/nmr.py:109-140: cam_dim 15 = 3x3 camera matrix | 2x3 crop transform; HOIG_DexYCB/utils/nmr.py:146-163: cam_dim 10 = fx, fy, cx,
+ * cy | crop transform), the y flip (:506), nr.look_at with the renderer's eye (z - eye_z) and nr.vertices_to_faces (:508-511).
+ * verts [B][V][3]; face_lists: HOST array of B device pointers to [n_faces[b]][3] int64 vertex indices (a sample's object decides its
+ * list), n_faces: host array; faces_out [B][Fmax][3][3], rows >= n_faces[b] filled with pad_value (a point no pixel can see).
+ * B <= HOIG_PREP_MAX_BATCH. */
+int hoig_project_faces(const float *cam, int cam_dim, const float *verts, int V, const int64_t *const *face_lists, const int *n_faces,
+                       int B, int Fmax, float eye_z, float pad_value, float *faces_out, hoig_stream_t stream);
 int hoig_rasterize_fim_wim(const float *faces, int B, int F, int image_size, float near, float far, int32_t *fim,
                            float *wim, void *workspace, hoig_stream_t stream);
 

@@ -40,7 +40,7 @@ def _slice(inputs, lo, hi):
     return out
 
 
-def _run(rank, world, port, q):
+def _run(rank, world, port, q, mode=None, steps=STEPS):
     import torch.distributed as dist
     from common import product_trainer, SEEDS
     from hoig_amd import ops, synthetic
@@ -53,27 +53,31 @@ def _run(rank, world, port, q):
     ops.set_precision('bf16x3')
     batch = synthetic.make_inputs(2, SIDE, seed=SEEDS['inputs'])
     # the seeded weights of the parity tests (the oracle below starts from the same ones)
-    model = product_trainer('generator_spade_attn', 2, SIDE, use_ddp=ddp, inputs=_slice(batch, rank, rank + 1) if ddp else batch)
+    model = product_trainer('generator_spade_attn', 2, SIDE, use_ddp=ddp, inputs=_slice(batch, rank, rank + 1) if ddp else batch,
+                            **(dict(ddp_mode=mode) if mode else {}))
     model.set_train()
     g = model._G.module if ddp else model._G
     before = {k: g.state_dict()[k].cpu().numpy().copy() for k in PROBE}
-    for _ in range(STEPS):
+    early = []
+    for _ in range(steps):
         model.optimize_parameters()
+        if ddp:
+            early.append(model._G.sync.early_launches)
     torch.cuda.synchronize()
     sd = g.state_dict()
     mom = g.export_dict(model._optimizer_G.exp_avg)
     q.put((rank, {k: sd[k].cpu().numpy().copy() for k in PROBE}, before,
-           float(g.flat.double().sum().item()), {k: mom[k].cpu().numpy().copy() for k in PROBE}))
+           float(g.flat.double().sum().item()), {k: mom[k].cpu().numpy().copy() for k in PROBE}, early))
     if ddp:
         dist.barrier()
         dist.destroy_process_group()
 
 
-def _spawn(world):
+def _spawn(world, mode=None, steps=STEPS):
     ctx = mp.get_context('spawn')
     q = ctx.Queue()
     port = _free_port()
-    procs = [ctx.Process(target=_run, args=(r, world, port, q)) for r in range(world)]
+    procs = [ctx.Process(target=_run, args=(r, world, port, q, mode, steps)) for r in range(world)]
     for p in procs:
         p.start()
     res = sorted([q.get(timeout=600) for _ in range(world)], key=lambda t: t[0])
@@ -84,8 +88,8 @@ def _spawn(world):
 
 
 def test_trainer_ddp_world2_matches_single_process():
-    (_, w0, b0, s0, m0), (_, w1, b1, s1, m1) = _spawn(2)
-    (_, ws, bs, _, ms), = _spawn(1)
+    (_, w0, b0, s0, m0, _), (_, w1, b1, s1, m1, _) = _spawn(2)
+    (_, ws, bs, _, ms, _), = _spawn(1)
     # the ORACLE's gradient of the combined batch of 2 (what DDP's average over the two 1-sample ranks must equal:
     # mean-reduced losses, per-sample instance norm): models/trainer.py:425-434 on the CPU restatement
     from common import oracle_trainer
@@ -108,3 +112,20 @@ def test_trainer_ddp_world2_matches_single_process():
         print('                %-44s update sign agreement %.3f' % (k, agree))
         assert agree > 0.9, (k, agree)
     assert s0 == s1
+
+
+def test_bucket_mode_two_ranks_on_the_gpu_path():
+    """opt.ddp_mode = 'bucket' through the real Trainer with two ranks (gloo, one GPU): after the learning step the slices of G's
+    gradient are exchanged WHILE the backward is being issued -- from a communication stream ordered behind the chains that wrote each
+    slice -- and the two ranks must still end every step with bit-identical weights and Adam moments (they apply the same sums), equal
+    to the default mode's to the run-to-run floor of the weight gradients' fp32 atomics."""
+    (_, w0, _, s0, m0, e0), (_, w1, _, s1, m1, e1) = _spawn(2, 'bucket', 3)
+    (_, wa, _, _, ma, ea), _ = _spawn(2, 'after', 3)
+    print('early launches per step: rank 0 %s, rank 1 %s; mode after %s' % (e0, e1, ea))
+    assert e0 == e1 and e0[0] == 0 and e0[1] > 0 and e0[2] == e0[1] and ea == [0, 0, 0]
+    assert s0 == s1
+    for k in PROBE:
+        assert np.array_equal(w0[k], w1[k]) and np.array_equal(m0[k], m1[k]), k
+        assert np.isfinite(w0[k]).all() and np.linalg.norm(m0[k]) > 0
+        # three Adam steps of ~lr each: no weight further than that from the default mode's (rounding-level gradient elements may flip sign)
+        assert np.abs(w0[k] - wa[k]).max() <= 3 * 2.2 * 2e-4, k

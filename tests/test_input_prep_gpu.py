@@ -86,6 +86,26 @@ def test_hip_matches_reference_fixture():
                                        rtol=1e-6, atol=1e-2)
 
 
+def test_batched_launches_equal_the_per_sample_launches(monkeypatch):
+    """Round 6: prepare_inputs issues hoig_prep_texture_batched / hoig_prep_lookup_batched (five launches per batch) where it used to
+    loop over the samples (three launches each): the same arithmetic on the same tables, so every output is bit-identical; the
+    per-sample entry points stay the C ABI of one sample and the path of batches beyond HOIG_PREP_MAX_BATCH."""
+    from hoig_amd import input_prep as IP, synthetic
+    r = synthetic.make_raster(3, 12)
+    dev = torch.device('cuda', 0)
+    args = [r[k].to(dev) for k in ('src_img', 'ref_img', 'src_faces', 'src_fim', 'src_wim', 'ref_fim', 'ref_wim')]
+    tabs = [IP.ObjectTables(r['tables'][k], dev) for k in r['obj_ids']]
+    assert len({id(t) for t in tabs}) > 1 or len(tabs) == 1
+    a = IP.prepare_inputs(*args, tabs, bg_both=True)
+    monkeypatch.setattr(IP, 'MAX_BATCH', 0)
+    b = IP.prepare_inputs(*args, tabs, bg_both=True)
+    torch.cuda.synchronize()
+    for x, y in zip(a, b):
+        assert (x is None) == (y is None)
+        if x is not None:
+            assert torch.equal(x, y)
+
+
 def test_edge_cases_empty_and_full():
     r = synthetic.make_raster(1, 8)
     r['src_fim'] = -torch.ones_like(r['src_fim'])

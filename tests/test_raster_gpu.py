@@ -90,6 +90,31 @@ def test_vertex_stage_on_device_matches_reference_fixture_dexycb():
     np.testing.assert_allclose(faces.cpu().numpy(), g['faces'], rtol=0, atol=2e-5)
 
 
+@pytest.mark.parametrize('fixture', ['raster_vertex_stage.npz', 'raster_vertex_stage_dexycb.npz'])
+def test_one_launch_vertex_stage_matches_the_reference_fixture_and_the_torch_form(fixture):
+    """hoig_project_faces (round 6: projection + flip + look-at + vertices_to_faces for a batch whose samples hold different objects, one
+    launch) against the fixture made by the reference's own projection, and against raster.project_to_faces on a batch with two
+    face lists of different lengths and a padded tail."""
+    import os
+    from hoig_amd import raster
+    g = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), 'golden', fixture))
+    cam, verts = torch.from_numpy(g['cam']).cuda(), torch.from_numpy(g['vertices']).cuda()
+    idx = torch.from_numpy(g['faces_idx']).cuda().long().contiguous()
+    B = cam.shape[0]
+    lists = [idx if idx.dim() == 2 else idx[b].contiguous() for b in range(B)]
+    faces = raster.project_faces_batched(cam, verts, lists, lists[0].shape[0])
+    np.testing.assert_allclose(faces.cpu().numpy(), g['faces'], rtol=0, atol=2e-5)
+    # two different lists in one batch: sample 0 keeps the full list, the others a prefix; rows beyond a list are the far-away point
+    short = lists[0][: lists[0].shape[0] // 3].contiguous()
+    mixed = [lists[0]] + [short] * (B - 1)
+    got = raster.project_faces_batched(cam, verts, mixed, lists[0].shape[0], pad_value=-1.0e6)
+    full = raster.project_to_faces(cam, verts, lists[0])
+    np.testing.assert_allclose(got[0].cpu().numpy(), full[0].cpu().numpy(), rtol=0, atol=2e-5)
+    for b in range(1, B):
+        np.testing.assert_allclose(got[b, :short.shape[0]].cpu().numpy(), full[b, :short.shape[0]].cpu().numpy(), rtol=0, atol=2e-5)
+        assert bool((got[b, short.shape[0]:] == -1.0e6).all())
+
+
 def test_vertices_to_generator_inputs_end_to_end():
     """The whole HandRecoveryFlow.forward chain on the device -- render_fim_wim for the source and the reference pose, then
     the input preparation -- against the oracle chain (C rasteriser + torch restatement) on the same vertices."""

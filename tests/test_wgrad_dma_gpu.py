@@ -346,12 +346,12 @@ def test_grouped_backward_skips_the_weight_gradient_of_a_frozen_weight():
     prev = L.set_tuning('pair', 1)
     try:
         g = torch.Generator(device='cuda').manual_seed(23)
-        tree = hnn.ParamTree({'a.weight': (128, 64, 3, 3), 'b.weight': (128, 64, 3, 3)}, torch.device('cuda'), {}, {})
+        tree = hnn.ParamTree({'a.weight': (256, 64, 3, 3), 'b.weight': (256, 64, 3, 3)}, torch.device('cuda'), {}, {})
         with torch.no_grad():
             tree.flat.copy_(torch.randn(tree.flat.shape, device='cuda', generator=g) * 0.05)
         tree.version += 1
         xa0, xb0 = (torch.randn(8, 32, 32, 64, device='cuda', generator=g) for _ in range(2))
-        ga, gb = (torch.randn(8, 32, 32, 128, device='cuda', generator=g) for _ in range(2))
+        ga, gb = (torch.randn(8, 32, 32, 256, device='cuda', generator=g) for _ in range(2))
         wa, wb = tree.P['a.weight'], tree.P['b.weight']
         assert ops.pair_ok(xa0, xb0, wa, wb)
         res = []
@@ -366,7 +366,9 @@ def test_grouped_backward_skips_the_weight_gradient_of_a_frozen_weight():
             res.append((xa.grad.clone(), xb.grad.clone(), wa.grad.clone(), wb.grad.clone()))
         wb.requires_grad_(True)
         (dxa0, dxb0, dwa0, dwb0), (dxa1, dxb1, dwa1, dwb1) = res
-        assert torch.equal(dxa0, dxa1) and torch.equal(dxb0, dxb1)
+        # (64 output channels: the data gradient runs on a kernel whose atomic epilogue reorders fp32 sums from run to run)
+        assert (dxa0 - dxa1).abs().max().item() <= 4e-6 * dxa0.abs().max().item()
+        assert (dxb0 - dxb1).abs().max().item() <= 4e-6 * dxb0.abs().max().item()
         assert ((dwa0 - dwa1).norm() / dwa0.norm()).item() < 2e-5 and dwb0.abs().max().item() > 0
         assert dwb1.abs().max().item() == 0.0
     finally:
