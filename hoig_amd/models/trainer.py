@@ -364,7 +364,7 @@ class Trainer(BaseModel):
             # generator-only inference (eval.py:59-65; BASELINE.json configs[4]): no backward follows, so the forward may run on the
             # arithmetic that is bounded by north_star's output tolerance alone (opt.eval_precision, default 'f16f6'; 'same': the
             # training forward's)
-            with ops.inference_forward_precision(getattr(self._opt, 'eval_precision', 'f16f6')):
+            with ops.inference_forward_precision(getattr(self._opt, 'eval_precision', os.environ.get('HOIG_EVAL_PRECISION', 'f16f6'))):
                 return self._forward(keep_data_for_visuals)
         return self._forward(keep_data_for_visuals)
 

@@ -236,3 +236,12 @@ def test_bench_launcher_child_forwards_rank0_json_and_the_exit_code():
                         '--master-port', '29671', os.path.join(root, 'bench.py'), '--gpus', '3', '--dry-run-cpu'],
                        env=env, capture_output=True, text=True, timeout=300, cwd='/tmp')
     assert r.returncode != 0 and 'WORLD_SIZE=2' in r.stderr + r.stdout
+
+
+def test_batched_input_preparation_limit_matches_the_header():
+    """hoig_amd.input_prep loops over the per-sample entry points beyond the batched ones' limit: the Python constant must be the
+    header's HOIG_PREP_MAX_BATCH (the argument blocks carry that many per-sample pointers by value)."""
+    import re
+    from hoig_amd import _lib as L, input_prep as IP
+    m = re.search(r'#define\s+HOIG_PREP_MAX_BATCH\s+(\d+)', open(L.HEADER_PATH).read())
+    assert m and int(m.group(1)) == IP.MAX_BATCH

@@ -7,7 +7,9 @@ mkdir -p $O
 cd $GRAFT_REPO_ROOT
 python -c "from hoig_amd import _lib; _lib.lib" || { echo "library does not load: stale snapshot?"; exit 9; }
 if [ "${SKIP_TESTS:-0}" != "1" ]; then
-  timeout 3000 python -m pytest tests -m gpu -q 2>&1 | tail -15 > $O/${TAG}_pytest_gpu.log
+  ( time timeout 3000 python -m pytest tests -m gpu -q 2>&1 | tail -15 ) > $O/${TAG}_pytest_gpu.log 2>&1
+  # the opt-in duplicates too (the exact-fp32 gradient comparison at 128x128 lives there), once per round
+  ( time timeout 2400 python -m pytest tests -m gpu_slow -q 2>&1 | tail -8 ) > $O/${TAG}_pytest_gpu_slow.log 2>&1
 fi
 python bench.py > $O/${TAG}_bench.json 2> $O/${TAG}_bench.err
 export TMPDIR=/tmp
@@ -30,6 +32,11 @@ cd $GRAFT_REPO_ROOT
 python tools/pmc_summary.py conv_halo3_m16_kernel $O/${TAG}_pmc_dominant_conv.json fetch=$O/${TAG}_pmc_fetch_dominant_conv.csv write=$O/${TAG}_pmc_write_dominant_conv.csv sq=$O/${TAG}_pmc_sq_dominant_conv.csv > /dev/null
 python tools/pmc_summary.py ALL $O/${TAG}_pmc_genfwd_b32.json fetch=/tmp/pmcf_fetch.csv write=/tmp/pmcf_write.csv sq=/tmp/pmcf_sq.csv > /dev/null
 python tools/timeline.py /tmp/${TAG}_bench_trace.csv 2000 > $O/${TAG}_timeline_eager.txt 2>&1
+# the same step as a captured hipGraph: where its 2.7 ms go
+cd /tmp
+rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/p_graph -- python3 $GRAFT_REPO_ROOT/bench.py --graph --steps 3 --warmup 1 --no-cpu-baseline --no-gen-fwd --graph-steps 0 --host-samples 0 > /dev/null 2>&1
+cd $GRAFT_REPO_ROOT
+python tools/timeline.py $(find /tmp/p_graph -name "*kernel_trace.csv" | head -1) 2000 > $O/${TAG}_timeline_graph.txt 2>&1
 # the dominant SHAPE inside the multi-stream step and inside the one-stream step (the template serves several shapes)
 python tools/dominant_in_step.py /tmp/${TAG}_bench_trace.csv conv_halo3_m16_kernel 131072 > $O/${TAG}_dominant_in_step.txt 2>&1
 python tools/dominant_in_step.py $(find /tmp/p_serial -name "*kernel_trace.csv" | head -1) conv_halo3_m16_kernel 131072 >> $O/${TAG}_dominant_in_step.txt 2>&1
