@@ -138,6 +138,8 @@ _SIGS = {
     'hoig_prep_lookup': [_vp] * 5 + [_i] + [_vp] * 8,
     'hoig_prep_assemble': [_i] + [_vp] * 17 + [_i] + [_vp] * 6,
     'hoig_rasterize_fim_wim': [_vp, _i, _i, _i, _f, _f, _vp, _vp, _vp, _vp],
+    'hoig_pack_conv_weight_wino': [_vp, _i, _i, _vp, _vp, _vp],
+    'hoig_conv2d_fwd_wino': [ctypes.POINTER(ConvDesc), _vp, _vp, _vp, _vp, _vp, _vp],
     'hoig_project_faces': [_vp, _i, _vp, _i, _vp, _vp, _i, _i, _f, _f, _vp, _vp],
     'hoig_prep_texture_batched': [_i, _vp, _vp, _i64, _vp, _vp, _vp, _vp, _vp, _vp, _vp],
     'hoig_prep_lookup_batched': [_i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _vp, _vp, _vp, _vp, _vp, _vp],
@@ -161,6 +163,8 @@ def _load():
     lib.hoig_set_f6_min_tiles.restype = ctypes.c_int
     lib.hoig_f6_plane_bytes.argtypes = [_i, _i, _i]
     lib.hoig_f6_plane_bytes.restype = ctypes.c_int64
+    lib.hoig_wino_plane_halfs.argtypes = [_i, _i]
+    lib.hoig_wino_plane_halfs.restype = ctypes.c_int64
     lib.hoig_attn_index_ints.argtypes = [_i, _i, _i]
     lib.hoig_attn_index_ints.restype = ctypes.c_int64
     lib.hoig_rasterize_workspace_bytes.restype = ctypes.c_size_t

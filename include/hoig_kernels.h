@@ -91,6 +91,17 @@ int hoig_inorm_bwd_add_ld_split(const float *x, const float *mean, const float *
 int hoig_inorm_bwd_fused_add_split(const float *x, const float *mean, const float *rstd, int mode, const float *p0, const float *p1,
                                    int ld_p, const float *y, const float *dy, int act, float slope, const float *addend /*nullable*/,
                                    uint16_t *dx_split, float *dp0, float *dp1, int B, int HW, int C, hoig_stream_t stream);
+/* ---- Winograd F(2x2,3x3) forward for stride-1 "same" 3x3 layers (round 6; hoig_amd/csrc/conv_wino.hip): 16
+ *      element-wise products per 2 x 2 outputs instead of 36, on three fp16 terms like the direct forward (HOIG_PREC_BF16X3): U = G (2^8 w) G^T
+ *      is made once per weight version by hoig_pack_conv_weight_wino -- u_hi / u_lo: hoig_wino_plane_halfs(Co, Ci) = 16 Co Ci fp16 values
+ *      each, in MFMA A-fragment order [position][Co / 16][Ci / 32][64 lanes][8] -- V = B^T d B is made in the kernel from the fp32 input
+ *      and split after the transform, the accumulators are fp32, Y = A^T M A, then 2^-8, bias (nullable), activation.  Hi % 16 == 0,
+ *      Wi % 16 == 0, Ci % 32 == 0, Co % 64 == 0; HOIG_EUNSUPPORTED otherwise (the caller then uses hoig_conv2d_fwd_packed).  Replaces, for
+ *      these layers, the same F.conv2d calls as hoig_conv2d_fwd_packed (models/networks/generator.py:9-32,35-71, spade.py:18-22). ---- */
+int64_t hoig_wino_plane_halfs(int Co, int Ci);
+int hoig_pack_conv_weight_wino(const float *w /*[Co][3][3][Ci]*/, int Co, int Ci, uint16_t *u_hi, uint16_t *u_lo, hoig_stream_t stream);
+int hoig_conv2d_fwd_wino(const hoig_conv_desc *d, const float *x, const uint16_t *u_hi, const uint16_t *u_lo, const float *bias /*nullable*/,
+                         float *y, hoig_stream_t stream);
 /* ---- INFERENCE: the norm between two convolutions applied by the second one's loader (VERDICT r1-r4 "consumer half of the norm
  *      fusion"; the reference chains generator.py:16-22 (ResidualBlock: conv - IN - ReLU - conv) and :298-309 (decoder level: ConvTranspose
  *      - IN - ReLU - cat - conv)).  hoig_inorm_fold turns the statistics of the RAW tensor (hoig_inorm_stats / _stats_from_sums) and the
