@@ -65,6 +65,7 @@ _SIGS = {
     'hoig_conv2d_fwd_f6': [ctypes.POINTER(ConvDesc), _vp, _vp, _vp, _vp, _vp, _vp, _vp],
     'hoig_pack_conv_weights_f6_all': [_vp, _vp, _i, _i64, _vp, _vp, _vp],
     'hoig_conv2d_cat_fwd_f6': [ctypes.POINTER(ConvDesc), _vp, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp],
+    'hoig_conv2d_fwd_f6_ex': [ctypes.POINTER(ConvDesc), _vp, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _vp, _vp, _vp],
     'hoig_conv2d_cat_fwd_packed': [ctypes.POINTER(ConvDesc), _vp, _i, _vp, _vp, _vp, _vp, _vp, _vp],
     'hoig_conv2d_cat_bwd_data_packed': [ctypes.POINTER(ConvDesc), _vp, _vp, _vp, _vp, _i, _vp, _vp],
     'hoig_split_planes_bf16': [_vp, _vp, _i64, _i, _vp],

@@ -60,6 +60,11 @@ struct F6Args {
     int act;
     float slope;
     int nblk_n, nblk, tiles_x, tiles_y;
+    // NORMIN (inference chains, as conv_halo16.hip's): x * in_scale + in_shift per (image, gathered channel), ReLU on channel blocks
+    // >= in_relu_c0 (a multiple of 32), applied when the halo is converted; the zero padding stays zero
+    const float *in_scale, *in_shift;
+    int in_relu_c0;
+    float *stats;                             // nullable: per image [sum | sum of squares][N] of the stored values, atomically added
 };
 
 __device__ __forceinline__ size_t plane_index(int n, int k, int K) {
@@ -184,12 +189,15 @@ __device__ __forceinline__ i32x8 read_rec(const unsigned char *p) {
 }
 
 // BN = 64: the same tile with half the output channels (twice the workgroups: launches with too few 8x32 pixel tiles for BN = 128)
-template <int BN>
+constexpr int NORMIN_MAX_CG = 1024;                       // NORMIN keeps the image's scale | shift rows in LDS: 2 x 4 KB
+constexpr int NORMIN_BYTES = 2 * NORMIN_MAX_CG * 4;
+template <int BN, bool NORMIN = false>
 __global__ __launch_bounds__(NT) void conv_halo3_f6_kernel(const F6Args p) {
     constexpr int B_HI = BTile<BN>::HI, B_Q = BTile<BN>::Q, B_STAGE = BTile<BN>::STAGE, TN = BTile<BN>::TN;
     constexpr int QCHUNKS = B_Q / 16;                     // 16-B chunks of one fp6 record array
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     unsigned char *Ah = smem, *Aqh = smem + A_HI, *Aql = Aqh + A_Q, *Bbase = smem + A_BYTES;
+    const float4 *const Nsc = reinterpret_cast<const float4 *>(smem + BTile<BN>::SMEM);          // NORMIN: [scale: Cg][shift: Cg]
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int l31 = lane & 31, lh = lane >> 5;
@@ -209,19 +217,19 @@ __global__ __launch_bounds__(NT) void conv_halo3_f6_kernel(const F6Args p) {
     const bool bload = brow < BN;
     const unsigned short *wrow = p.Wh + plane_index(n0 + (bload ? brow : 0), bchunk * 8, p.K);
     const int boff = brow * 64 + ((bchunk ^ ((brow >> 2) & 3)) << 4);
+    const int qchunk = min(tid, QCHUNKS - 1);
     uint4 rbh0 = make_uint4(0, 0, 0, 0), rbh1 = rbh0, rbq0 = rbh0, rbq1 = rbh0;
+    // Every load of the loop is UNCONDITIONAL (idle threads re-read a valid address and skip the store): a load under a branch makes
+    // the compiler's wait-count pass merge the two paths, and the waits after it -- for OLDER loads -- degrade to vmcnt(0)
+    // (conv_wino.hip found the same; here it put a full L2 round trip of the weight loads in front of every halo prefetch).
     auto load_b = [&](int step) {
         const int cb = step / 9, tap = step - cb * 9;
         const size_t koff = (size_t)(tap * p.Cg + cb * 64) * 32;           // k-block index * 1024 elements
-        if (bload) {
-            rbh0 = *reinterpret_cast<const uint4 *>(wrow + koff);
-            rbh1 = *reinterpret_cast<const uint4 *>(wrow + koff + 1024);
-        }
+        rbh0 = *reinterpret_cast<const uint4 *>(wrow + koff);
+        rbh1 = *reinterpret_cast<const uint4 *>(wrow + koff + 1024);
         const size_t rec0 = ((size_t)(tap * ncb + cb) * p.N + n0) * REC;   // BN records (BN = 128: 7168 B = 448 chunks per plane)
-        if (tid < QCHUNKS) {
-            rbq0 = *reinterpret_cast<const uint4 *>(p.Qh + rec0 + (size_t)tid * 16);
-            rbq1 = *reinterpret_cast<const uint4 *>(p.Ql + rec0 + (size_t)tid * 16);
-        }
+        rbq0 = *reinterpret_cast<const uint4 *>(p.Qh + rec0 + (size_t)qchunk * 16);
+        rbq1 = *reinterpret_cast<const uint4 *>(p.Ql + rec0 + (size_t)qchunk * 16);
     };
     // The same stage by LDS-DMA: the fp16 planes are stored in HBM in exactly the LDS image (plane_index carries the XOR), so a
     // 32-row x 32-k block is 2 KB contiguous on both sides, and so are the record arrays: lane t moves bytes [16 t, 16 t + 16) of
@@ -261,27 +269,43 @@ __global__ __launch_bounds__(NT) void conv_halo3_f6_kernel(const F6Args p) {
     // ---- halo: task = (halo pixel, 32-channel block); 680 tasks over 512 threads
     float4 hreg0[8], hreg1[8];
     auto halo_load = [&](int cb, int slot, float4 (&hr)[8]) {
-        const int task = tid + slot * NT;
+        const int task = min(tid + slot * NT, HPIX * 2 - 1);
+        const int pix = task >> 1, kb = task & 1;
+        const int hy = pix / HW, hx = pix - hy * HW;
+        const int gy = min(max(y0 - 1 + hy, 0), p.H - 1), gx = min(max(x0 - 1 + hx, 0), p.W - 1);      // (clamped: the frame is zeroed at the store)
+        const int c0 = cb * 64 + kb * 32;
+        const bool second = p.A2 != nullptr && c0 >= p.cg1;
+        const int ld = p.A2 ? (second ? p.Cg - p.cg1 : p.cg1) : p.Cg;
+        const float *src = (second ? p.A2 : p.A) + (((size_t)b * p.H + gy) * p.W + gx) * ld + (second ? c0 - p.cg1 : c0);
 #pragma unroll
-        for (int k = 0; k < 8; ++k) hr[k] = make_float4(0.f, 0.f, 0.f, 0.f);
+        for (int k = 0; k < 8; ++k) hr[k] = *reinterpret_cast<const float4 *>(src + k * 4);
+    };
+    auto halo_store = [&](int cb, int slot, float4 (&hr)[8]) {
+        const int task = tid + slot * NT;
         if (task < HPIX * 2) {
             const int pix = task >> 1, kb = task & 1;
             const int hy = pix / HW, hx = pix - hy * HW;
             const int gy = y0 - 1 + hy, gx = x0 - 1 + hx;
-            if (gy >= 0 && gy < p.H && gx >= 0 && gx < p.W) {
-                const int c0 = cb * 64 + kb * 32;
-                const bool second = p.A2 != nullptr && c0 >= p.cg1;
-                const int ld = p.A2 ? (second ? p.Cg - p.cg1 : p.cg1) : p.Cg;
-                const float *src = (second ? p.A2 : p.A) + (((size_t)b * p.H + gy) * p.W + gx) * ld + (second ? c0 - p.cg1 : c0);
+            const bool inside = gy >= 0 && gy < p.H && gx >= 0 && gx < p.W;
+            if (!inside) {
 #pragma unroll
-                for (int k = 0; k < 8; ++k) hr[k] = *reinterpret_cast<const float4 *>(src + k * 4);
+                for (int k = 0; k < 8; ++k) hr[k] = make_float4(0.f, 0.f, 0.f, 0.f);
             }
-        }
-    };
-    auto halo_store = [&](int slot, const float4 (&hr)[8]) {
-        const int task = tid + slot * NT;
-        if (task < HPIX * 2) {
-            const int pix = task >> 1, kb = task & 1;
+            if constexpr (NORMIN) {
+                if (inside) {                                           // (the frame is padding of the NORMALISED tensor: zero)
+                    const int c0 = cb * 64 + kb * 32;
+                    const bool relu = c0 >= p.in_relu_c0;
+                    const float4 *sc = Nsc + (c0 >> 2), *sh = Nsc + ((p.Cg + c0) >> 2);
+#pragma unroll
+                    for (int k = 0; k < 8; ++k) {
+                        const float4 a = sc[k], c = sh[k];
+                        float4 v = hr[k];
+                        v.x = fmaf(v.x, a.x, c.x); v.y = fmaf(v.y, a.y, c.y); v.z = fmaf(v.z, a.z, c.z); v.w = fmaf(v.w, a.w, c.w);
+                        if (relu) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
+                        hr[k] = v;
+                    }
+                }
+            }
             const Split32 s = split32(hr, 1.f);
             uint4 *dh = reinterpret_cast<uint4 *>(Ah + pix * AROW + kb * 64);
 #pragma unroll
@@ -368,8 +392,15 @@ __global__ __launch_bounds__(NT) void conv_halo3_f6_kernel(const F6Args p) {
     halo_load(0, 1, hreg1);
     if (HOIG_F6_DMA) dma_b(0, 0);
     else load_b(0);
-    halo_store(0, hreg0);
-    halo_store(1, hreg1);
+    if constexpr (NORMIN) {                   // this image's scale | shift rows -> LDS, once
+        float4 *dst = reinterpret_cast<float4 *>(smem + BTile<BN>::SMEM);
+        const int q4 = p.Cg >> 2;
+        for (int i = tid; i < 2 * q4; i += NT)
+            dst[i] = *reinterpret_cast<const float4 *>((i < q4 ? p.in_scale : p.in_shift) + (size_t)b * p.Cg + (i < q4 ? i : i - q4) * 4);
+        __syncthreads();
+    }
+    halo_store(0, 0, hreg0);
+    halo_store(0, 1, hreg1);
     if (HOIG_F6_DMA) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     else {
         store_b(0);
@@ -384,19 +415,19 @@ __global__ __launch_bounds__(NT) void conv_halo3_f6_kernel(const F6Args p) {
         const bool boundary = more && tap == 8;
         if (HOIG_F6_DMA) {
             if (more && !(HOIG_F6_KO & 16)) dma_b(step + 1, bbuf ^ 1);          // stage s + 1: free since the previous barrier
-        } else {
-            if (more && !(HOIG_F6_KO & 16)) store_b(bbuf ^ 1);   // weights of step+1 (registers loaded during the previous step)
-            if (step + 2 < T && !(HOIG_F6_KO & 16)) load_b(step + 2);
+        } else if (!(HOIG_F6_KO & 16)) {
+            if (more) store_b(bbuf ^ 1);                  // weights of step+1 (registers loaded during the previous step)
+            load_b(min(step + 2, T - 1));                 // (the last two steps re-request the last stage: no branch around a load)
         }
-        if (!(HOIG_F6_KO & 8)) {
+        if (!(HOIG_F6_KO & 8)) {                          // (AFTER the weight prefetch: the next store_b's wait finds them a step old)
             if (tap == 7 && cb + 1 < ncb) halo_load(cb + 1, 0, hreg0);              // next block's halo: first half of the tasks ...
             if (boundary) halo_load(cb + 1, 1, hreg1);                               // ... second half
         }
         compute(tap, bbuf);
         if (boundary && !(HOIG_F6_KO & 1)) {
             __syncthreads();                              // every wave is done with the halo
-            halo_store(0, hreg0);
-            halo_store(1, hreg1);
+            halo_store(cb + 1, 0, hreg0);
+            halo_store(cb + 1, 1, hreg1);
         }
         if (HOIG_F6_DMA) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // stage s + 1 has landed (and this wave's halo loads)
         if (!(HOIG_F6_KO & 32)) __syncthreads();
@@ -411,6 +442,9 @@ __global__ __launch_bounds__(NT) void conv_halo3_f6_kernel(const F6Args p) {
         const int n = n0 + wn * (TN * 32) + j * 32 + l31;
         bias_r[j] = p.bias ? p.bias[n] : 0.f;
     }
+    float st1[TN], st2[TN];
+#pragma unroll
+    for (int j = 0; j < TN; ++j) st1[j] = st2[j] = 0.f;
 #pragma unroll
     for (int i = 0; i < TM; ++i) {
         const int oy = y0 + wm * TM + i;
@@ -421,9 +455,35 @@ __global__ __launch_bounds__(NT) void conv_halo3_f6_kernel(const F6Args p) {
 #pragma unroll
             for (int j = 0; j < TN; ++j) {
                 const int n = n0 + wn * (TN * 32) + j * 32 + l31;
-                float v = acc[i][j][r] * (1.f / W_SCALE) + bias_r[j];
-                p.C[pix * p.N + n] = fast_act(v, nslope, special, p.act, p.slope);
+                const float v = fast_act(acc[i][j][r] * (1.f / W_SCALE) + bias_r[j], nslope, special, p.act, p.slope);
+                p.C[pix * p.N + n] = v;
+                st1[j] += v;
+                st2[j] += v * v;
             }
+        }
+    }
+    if (p.stats) {                            // per-image channel sums for the instance norm that follows (hoig_inorm_stats_from_sums):
+        // lane = channel; its 2 x 16 pixels above, + the other half-wave's, + the four pixel-row waves' through LDS (free: the last
+        // step closed with a barrier), one atomic per (workgroup, channel, moment)
+        float *red = reinterpret_cast<float *>(smem);             // [WM][2][BN]
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+            st1[j] += __shfl_xor(st1[j], 32);
+            st2[j] += __shfl_xor(st2[j], 32);
+            if (lh == 0) {
+                const int cl = wn * (TN * 32) + j * 32 + l31;
+                red[(wm * 2 + 0) * BN + cl] = st1[j];
+                red[(wm * 2 + 1) * BN + cl] = st2[j];
+            }
+        }
+        __syncthreads();
+        float *stats_img = p.stats + (size_t)b * 2 * p.N;
+        for (int e = tid; e < 2 * BN; e += NT) {
+            const int mom = e / BN, cl = e - mom * BN;
+            float v = 0.f;
+#pragma unroll
+            for (int k = 0; k < WM; ++k) v += red[(k * 2 + mom) * BN + cl];
+            atomicAdd(&stats_img[(size_t)mom * p.N + n0 + cl], v);
         }
     }
 }
@@ -449,7 +509,8 @@ extern "C" int hoig_pack_conv_weight_f6(const float *w, int Co, int RS, int Ci, 
 // forward 3x3 stride-1 pad-1 convolution; HOIG_EUNSUPPORTED for every shape outside this kernel's tiling (the caller then uses
 // hoig_conv2d_fwd_packed with HOIG_PREC_BF16X3)
 static int launch_f6(const hoig_conv_desc *d, const float *x, const float *x2, int cg1, const uint16_t *w_hi, const uint8_t *q_hi,
-                     const uint8_t *q_lo, const float *bias, float *y, hipStream_t st) {
+                     const uint8_t *q_lo, const float *bias, float *y, hipStream_t st, const float *in_scale = nullptr,
+                     const float *in_shift = nullptr, int in_relu_c0 = 0, float *stats = nullptr) {
     if (d->transposed || d->stride != 1 || d->R != 3 || d->S != 3 || d->pad != 1 || d->Hi != d->Ho || d->Wi != d->Wo)
         return HOIG_EUNSUPPORTED;
     if ((d->Ci & 63) || (d->Co & 63) || (d->Hi & 7) || (d->Wi & 31)) return HOIG_EUNSUPPORTED;
@@ -458,6 +519,8 @@ static int launch_f6(const hoig_conv_desc *d, const float *x, const float *x2, i
     a.A = x; a.A2 = x2; a.cg1 = cg1; a.Wh = w_hi; a.Qh = q_hi; a.Ql = q_lo; a.bias = bias; a.C = y;
     a.Bn = d->B; a.H = d->Hi; a.W = d->Wi; a.Cg = d->Ci; a.N = d->Co; a.K = 9 * d->Ci;
     a.act = d->act; a.slope = d->slope;
+    a.in_scale = in_scale; a.in_shift = in_shift; a.in_relu_c0 = in_relu_c0; a.stats = stats;
+    if (in_scale && (a.Cg > NORMIN_MAX_CG || (in_relu_c0 & 31))) return HOIG_EUNSUPPORTED;
     a.tiles_x = a.W / TW; a.tiles_y = a.H / TH;
     const int ptiles = a.Bn * a.tiles_x * a.tiles_y;
     // 128-channel tiles when they fill the chip, 64-channel tiles (twice the workgroups) otherwise; launches that stay below
@@ -474,6 +537,21 @@ static int launch_f6(const hoig_conv_desc *d, const float *x, const float *x2, i
                                 BTile<64>::SMEM) != hipSuccess)
             return HOIG_ELAUNCH;
         once.set();
+    }
+    if (in_scale) {
+        static hoig_once once_n;
+        if (!once_n.done()) {
+            if (hipFuncSetAttribute(reinterpret_cast<const void *>(&conv_halo3_f6_kernel<128, true>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                    BTile<128>::SMEM + NORMIN_BYTES) != hipSuccess ||
+                hipFuncSetAttribute(reinterpret_cast<const void *>(&conv_halo3_f6_kernel<64, true>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                    BTile<64>::SMEM + NORMIN_BYTES) != hipSuccess)
+                return HOIG_ELAUNCH;
+            once_n.set();
+        }
+        if (n64) conv_halo3_f6_kernel<64, true><<<a.nblk, NT, BTile<64>::SMEM + NORMIN_BYTES, st>>>(a);
+        else conv_halo3_f6_kernel<128, true><<<a.nblk, NT, BTile<128>::SMEM + NORMIN_BYTES, st>>>(a);
+        HOIG_LAUNCH_CHECK();
+        return HOIG_OK;
     }
     if (n64) conv_halo3_f6_kernel<64><<<a.nblk, NT, BTile<64>::SMEM, st>>>(a);
     else conv_halo3_f6_kernel<128><<<a.nblk, NT, BTile<128>::SMEM, st>>>(a);
@@ -494,6 +572,16 @@ extern "C" int hoig_conv2d_cat_fwd_f6(const hoig_conv_desc *d, const float *x1, 
                                       hoig_stream_t stream) {
     if (!d || !x1 || !x2 || !w_hi || !q_hi || !q_lo || !y) return HOIG_EINVAL;
     return launch_f6(d, x1, x2, C1, w_hi, q_hi, q_lo, bias, y, (hipStream_t)stream);
+}
+
+// hoig_conv2d_fwd_f6 / hoig_conv2d_cat_fwd_f6 with the loader and epilogue options of the three-term path (include/hoig_kernels.h):
+// x2 (nullable) = the second tensor of a channel concatenation; in_scale / in_shift (nullable, together) = the instance norm + ReLU of
+// the gathered tensor applied in the loader; stats (nullable) = the per-image channel sums of y for the norm that follows
+extern "C" int hoig_conv2d_fwd_f6_ex(const hoig_conv_desc *d, const float *x, int C1, const float *x2, const uint16_t *w_hi,
+                                     const uint8_t *q_hi, const uint8_t *q_lo, const float *bias, const float *in_scale,
+                                     const float *in_shift, int in_relu_c0, float *y, float *stats, hoig_stream_t stream) {
+    if (!d || !x || !w_hi || !q_hi || !q_lo || !y || (in_scale == nullptr) != (in_shift == nullptr) || in_relu_c0 < 0) return HOIG_EINVAL;
+    return launch_f6(d, x, x2, x2 ? C1 : 0, w_hi, q_hi, q_lo, bias, y, (hipStream_t)stream, in_scale, in_shift, in_relu_c0, stats);
 }
 
 extern "C" int hoig_pack_conv_weights_f6_all(const float *flat, const int64_t *rows, int nrows, int64_t ntasks, uint8_t *q_hi,

@@ -883,12 +883,16 @@ class _ConvCat2(Function):
         y = torch.empty((B, H, W_, Co), dtype=x1.dtype, device=x1.device)
         hi, lo = _packed_planes(w, False, False)
         rc = L.EUNSUPPORTED
+        ws = _conv_stats_workspace(y) if norm_next else None
         if prec == L.PREC_F16F6 and (C1 + C2) % 64 == 0 and Co % 64 == 0 and H % 8 == 0:
             qh, ql = _f6_planes(w)
-            rc = L.lib.hoig_conv2d_cat_fwd_f6(ctypes.byref(d), _p(x1), C1, _p(x2), _p(hi), _p(qh), _p(ql), None, _p(y), _st())
+            rc = L.lib.hoig_conv2d_fwd_f6_ex(ctypes.byref(d), _p(x1), C1, _p(x2), _p(hi), _p(qh), _p(ql), None, None, None, 0, _p(y), _p(ws),
+                                             _st())
+            if rc != L.EUNSUPPORTED and ws is not None:
+                L.check(rc, 'hoig_conv2d_fwd_f6_ex')
+                _stats_offer(y)
         d = _x3(d)
-        ws = _conv_stats_workspace(y) if (rc == L.EUNSUPPORTED and norm_next) else None
-        if ws is not None:          # (see _conv_fwd_raw)
+        if ws is not None and rc == L.EUNSUPPORTED:          # (see _conv_fwd_raw)
             rc = L.lib.hoig_conv2d_cat_fwd_packed_stats(ctypes.byref(d), _p(x1), C1, _p(x2), _p(hi), _p(lo), None, _p(y), _p(ws), _st())
             if rc != L.EUNSUPPORTED:
                 L.check(rc, 'hoig_conv2d_cat_fwd_packed_stats')
@@ -952,7 +956,7 @@ def conv2d_after_norm(xraw, gamma, beta, w, b=None, first=None, norm_next=False,
     HW = H * W_
     C1 = first.shape[-1] if first is not None else 0
     Co = w.shape[0]
-    if (precision in (L.PREC_F32, L.PREC_F16F6) or tuple(w.shape[2:]) != (3, 3) or w.shape[1] != C1 + C or C % 32 or C1 % 32 or Co % 64
+    if (precision == L.PREC_F32 or tuple(w.shape[2:]) != (3, 3) or w.shape[1] != C1 + C or C % 32 or C1 % 32 or Co % 64
             or W_ % 32 or H % 8 or not xraw.is_contiguous() or (first is not None and (not first.is_contiguous() or first.shape[:3] != xraw.shape[:3]))
             or not L.lib.hoig_set_tuning(b'norm_in', -1)):
         _stats_drop(xraw)
@@ -977,8 +981,15 @@ def conv2d_after_norm(xraw, gamma, beta, w, b=None, first=None, norm_next=False,
     hi, lo = _packed_planes(w, False, False)
     sws = _conv_stats_workspace(y) if norm_next else None
     a, a2 = (first, xraw) if first is not None else (xraw, None)
-    rc = L.lib.hoig_conv2d_fwd_packed_normin(ctypes.byref(d), _p(a), C1, _p(a2), _p(hi), _p(lo), _p(b), fold.data_ptr(),
-                                             fold.data_ptr() + 4 * B * Cg, C1, _p(y), _p(sws), _st())
+    rc = L.EUNSUPPORTED
+    if precision == L.PREC_F16F6 and Cg % 64 == 0:          # eval.py's default arithmetic: the same two fusions on conv_f6.hip
+        qh, ql = _f6_planes(w)
+        rc = L.lib.hoig_conv2d_fwd_f6_ex(ctypes.byref(d), _p(a), C1, _p(a2), _p(hi), _p(qh), _p(ql), _p(b), fold.data_ptr(),
+                                         fold.data_ptr() + 4 * B * Cg, C1, _p(y), _p(sws), _st())
+    if rc == L.EUNSUPPORTED:
+        d = _x3(d)
+        rc = L.lib.hoig_conv2d_fwd_packed_normin(ctypes.byref(d), _p(a), C1, _p(a2), _p(hi), _p(lo), _p(b), fold.data_ptr(),
+                                                 fold.data_ptr() + 4 * B * Cg, C1, _p(y), _p(sws), _st())
     if rc == L.EUNSUPPORTED:
         return None
     L.check(rc, 'hoig_conv2d_fwd_packed_normin')
@@ -1004,7 +1015,9 @@ class _ConvHeads(Function):
         assert Co <= 16, 'the activation codes of the fused heads are 4 bits x 16 channels (hoig_conv2d_fwd_heads)'
         if Co > 16:
             raise ValueError('conv_heads: %d output channels, the per-channel activation codes hold 16' % Co)
-        d = ConvDesc(B, H, W_, Ci, H, W_, Co, R, S, 1, R // 2, 0, L.ACT_NONE, 0.0, prec)
+        # (f16f6 is an arithmetic of the 3x3 stride-1 layers; every other layer of such a forward runs on three fp16 terms -- without this
+        #  mapping the heads of an eval-mode forward missed the MFMA head kernel, which asks for BF16X3, and ran on the fp32 VALU one)
+        d = _x3(ConvDesc(B, H, W_, Ci, H, W_, Co, R, S, 1, R // 2, 0, L.ACT_NONE, 0.0, prec))
         codes, ch = 0, 0
         for n, a in zip(splits, acts):
             for _ in range(n):
@@ -1018,7 +1031,7 @@ class _ConvHeads(Function):
             _copy_channels(y, o, off, 0, n)
             outs.append(o)
             off += n
-        ctx.d_dg, ctx.d_wg = _bwd_descs(_x3(d))
+        ctx.d_dg, ctx.d_wg = _bwd_descs(d)
         ctx.cfg = (tuple(splits), tuple(acts))
         ctx.save_for_backward(x, w, *[o if a != L.ACT_NONE else None for o, a in zip(outs, acts)])
         return tuple(outs)
@@ -1112,26 +1125,31 @@ def _x3(d):
 def _conv_fwd_raw(d, x, w, b, y, transposed=False, norm_next=False):
     """y = conv(x, w) (+bias, activation) on the kernel the precision mode selects.  norm_next: y goes straight into an instance
     norm -- where the layer's kernel can, it also leaves the per-image channel sums of y in the stream's norm workspace
-    (hoig_conv2d_fwd_packed_stats) and says so (_stats_offer); the norm then skips its statistics pass."""
-    if norm_next and d.precision not in (L.PREC_F32, L.PREC_F16F6) and d.Ci % 32 == 0 and d.Co % 32 == 0 and d.Co > 32:
+    (hoig_conv2d_fwd_packed_stats; hoig_conv2d_fwd_f6_ex on the f16f6 arithmetic) and says so (_stats_offer); the norm then skips
+    its statistics pass."""
+    ws = None
+    if norm_next and d.precision != L.PREC_F32 and d.Ci % 32 == 0 and d.Co % 32 == 0 and d.Co > 32:
         ws = _conv_stats_workspace(y)
-        if ws is not None:
-            hi, lo = _packed_planes(w, transposed, False)
-            rc = L.lib.hoig_conv2d_fwd_packed_stats(ctypes.byref(d), _p(x), _p(hi), _p(lo), _p(b), _p(y), _p(ws), _st())
-            if rc != L.EUNSUPPORTED:
-                L.check(rc, 'hoig_conv2d_fwd_packed_stats')
-                _stats_offer(y)
-                return
     if d.precision == L.PREC_F16F6:
         if (not transposed and d.R == 3 and d.S == 3 and d.stride == 1 and d.pad == 1 and d.Ci % 64 == 0 and d.Co % 64 == 0
                 and d.Hi % 8 == 0 and d.Wi % 32 == 0):
             hi, _ = _packed_planes(w, False, False)
             qh, ql = _f6_planes(w)
-            rc = L.lib.hoig_conv2d_fwd_f6(ctypes.byref(d), _p(x), _p(hi), _p(qh), _p(ql), _p(b), _p(y), _st())
+            rc = L.lib.hoig_conv2d_fwd_f6_ex(ctypes.byref(d), _p(x), 0, None, _p(hi), _p(qh), _p(ql), _p(b), None, None, 0, _p(y), _p(ws),
+                                             _st())
             if rc != L.EUNSUPPORTED:
-                L.check(rc, 'hoig_conv2d_fwd_f6')
+                L.check(rc, 'hoig_conv2d_fwd_f6_ex')
+                if ws is not None:
+                    _stats_offer(y)
                 return
         d = _x3(d)
+    if ws is not None:
+        hi, lo = _packed_planes(w, transposed, False)
+        rc = L.lib.hoig_conv2d_fwd_packed_stats(ctypes.byref(d), _p(x), _p(hi), _p(lo), _p(b), _p(y), _p(ws), _st())
+        if rc != L.EUNSUPPORTED:
+            L.check(rc, 'hoig_conv2d_fwd_packed_stats')
+            _stats_offer(y)
+            return
     if d.precision != L.PREC_F32 and d.Ci % 32 == 0 and d.Co % 32 == 0 and d.Co > 32:
         hi, lo = _packed_planes(w, transposed, False)
         rc = L.lib.hoig_conv2d_fwd_packed(ctypes.byref(d), _p(x), _p(hi), _p(lo), _p(b), _p(y), _st())

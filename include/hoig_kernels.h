@@ -198,6 +198,17 @@ int hoig_conv2d_fwd_f6(const hoig_conv_desc *d, const float *x, const uint16_t *
 int hoig_conv2d_cat_fwd_f6(const hoig_conv_desc *d, const float *x1, int C1, const float *x2, const uint16_t *w_hi,
                            const uint8_t *q_hi, const uint8_t *q_lo, const float *bias /*nullable*/, float *y,
                            hoig_stream_t stream);
+/* The same kernel with the loader and epilogue options of the three-term path (round 6: eval.py's forward runs on this arithmetic
+ * by default, and the inference chain conv - IN - ReLU - conv, generator.py:16-22 / :298-309, keeps its two fusions):
+ *   x2 (nullable, C1 % 32 == 0) -- the second tensor of a channel concatenation, as hoig_conv2d_cat_fwd_f6;
+ *   in_scale / in_shift (nullable, together; B x Ci floats from hoig_inorm_fold) and in_relu_c0 (% 32 == 0) -- the gathered tensor is
+ *     RAW: x * in_scale + in_shift per (image, gathered channel) and ReLU on channels >= in_relu_c0 are applied when the halo is
+ *     converted, as hoig_conv2d_fwd_packed_normin does (Ci <= 1024: the image's two rows live in LDS);
+ *   stats (nullable) -- the accumulators of an instance-norm workspace, as hoig_conv2d_fwd_packed_stats.
+ * Same HOIG_EUNSUPPORTED conditions as hoig_conv2d_fwd_f6. */
+int hoig_conv2d_fwd_f6_ex(const hoig_conv_desc *d, const float *x, int C1, const float *x2 /*nullable*/, const uint16_t *w_hi,
+                          const uint8_t *q_hi, const uint8_t *q_lo, const float *bias /*nullable*/, const float *in_scale /*nullable*/,
+                          const float *in_shift /*nullable*/, int in_relu_c0, float *y, float *stats /*nullable*/, hoig_stream_t stream);
 /* all eligible weights of a flat parameter buffer in one launch: rows = int64[nrows][6] = (offset of the weight in `flat`, Co,
  * RS, Ci, byte offset of its records in q_hi / q_lo (a multiple of 4), index of its first task); a task = one (output channel,
  * tap, 32 input channels) half record: Co*RS*Ci/32 per weight */

@@ -2,6 +2,8 @@
 gradient, bias / activation / addend / statistics epilogues, the two-tensor input and the two-tensor output of the decoder's skip
 convolution.  Shapes are chosen so that the launcher picks the 8-row tilings (128- and 64-channel tiles).  (Until round 6 these tests
 also compared with the 32x32x16 instantiations the kernel replaced in round 4; those are deleted.)"""
+import ctypes
+
 import pytest
 import torch
 import torch.nn.functional as F
@@ -350,3 +352,75 @@ def test_inference_norm_applied_by_the_consumers_loader(case):
         assert (y1 - y2).abs().max().item() <= 2e-5 * y2.abs().max().item()
     finally:
         ops.set_precision('f32')
+
+
+@pytest.mark.parametrize('case', ['resblock_32', 'resblock_64', 'decoder_cat'])
+def test_inference_norm_applied_by_the_f6_loader_and_sums_left_by_its_epilogue(case):
+    """The same two fusions on eval.py's default arithmetic (f16f6, conv_f6.hip: hoig_conv2d_fwd_f6_ex): conv3x3(relu(IN(x) * gamma + beta))
+    with the norm applied when the fp32 halo is converted to fp16 | fp6 | fp6, against the same kernel fed the tensor a norm pass wrote
+    (1e-4 of the output's scale: the fold's association moves an input by an ulp, which can move a block's fp6 rounding), against torch
+    in fp64 (the arithmetic's 1e-3 bound), the zero frame -- and the channel sums the f6 kernel's epilogue leaves for the NEXT norm."""
+    from hoig_amd import _lib as L, ops
+    ops.set_precision('f16f6')
+    try:
+        g = torch.Generator(device='cuda').manual_seed(23)
+        if case == 'decoder_cat':
+            B, H, W, C1, C, Co = 8, 64, 64, 128, 128, 128
+        elif case == 'resblock_64':
+            B, H, W, C1, C, Co = 4, 64, 64, 0, 256, 256
+        else:
+            B, H, W, C1, C, Co = 16, 32, 32, 0, 128, 256
+        x = torch.randn(B, H, W, C, device='cuda', generator=g) * 2.0 + 0.7
+        first = torch.randn(B, H, W, C1, device='cuda', generator=g).relu() if C1 else None
+        gamma = torch.rand(C, device='cuda', generator=g) + 0.5
+        beta = torch.randn(C, device='cuda', generator=g) * 0.3
+        w = ops.pack_weight(torch.randn(Co, C1 + C, 3, 3, device='cuda', generator=g) * 0.05)
+        bias = torch.randn(Co, device='cuda', generator=g) if case != 'decoder_cat' else None
+        with torch.no_grad():
+            y = ops.conv2d_after_norm(x, gamma, beta, w, bias, first=first, norm_next=False)
+            assert y is not None
+            xn = ops.instance_norm(x, gamma, beta, act=L.ACT_RELU)
+            want = ops.conv2d_cat2(first, xn, w) if first is not None else ops.conv2d(xn, w, bias, 1, 1)
+        torch.cuda.synchronize()
+        scale = want.abs().max().item()
+        assert (y - want).abs().max().item() <= 1e-4 * scale, (y - want).abs().max().item() / scale
+        border = torch.ones(H, W, dtype=torch.bool, device='cuda')
+        border[1:-1, 1:-1] = False
+        assert (y[:, border] - want[:, border]).abs().max().item() <= 1e-4 * scale
+        xr = torch.nn.functional.instance_norm(x.permute(0, 3, 1, 2).double(), weight=gamma.double(), bias=beta.double(), eps=1e-5).relu()
+        if first is not None:
+            xr = torch.cat([first.permute(0, 3, 1, 2).double(), xr], 1)
+        ref = F.conv2d(xr, w.double(), bias.double() if bias is not None else None, padding=1).permute(0, 2, 3, 1)
+        assert rel_err(y.double(), ref) < 1e-3
+        # the kernel itself, not its three-term fallback: call the entry point and require HOIG_OK
+        d = L.ConvDesc(B, H, W, C1 + C, H, W, Co, 3, 3, 1, 1, 0, L.ACT_NONE, 0.0, L.PREC_F16F6)
+        hi, _ = ops._packed_planes(w, False, False)
+        qh, ql = ops._f6_planes(w)
+        st = torch.cuda.current_stream().cuda_stream
+        _p = lambda t: None if t is None else ctypes.c_void_p(t.data_ptr())
+        a, a2 = (first, xn) if first is not None else (xn, None)
+        y0 = torch.empty_like(y)
+        sums = torch.zeros(B, 2, Co, device='cuda')
+        assert L.lib.hoig_conv2d_fwd_f6_ex(ctypes.byref(d), _p(a), C1, _p(a2), _p(hi), _p(qh), _p(ql), _p(bias), None, None, 0, _p(y0), _p(sums),
+                                           st) == L.OK
+        torch.cuda.synchronize()
+        assert torch.equal(y0, want)
+        s1 = y0.double().sum((1, 2))
+        s2 = (y0.double() ** 2).sum((1, 2))
+        assert rel_err(sums[:, 0].double(), s1) < 1e-5 and rel_err(sums[:, 1].double(), s2) < 1e-5
+        # through ops: a producing f6 convolution offers its sums (maps of > 1024 pixels), the norm that follows takes them
+        if H * W > 1024:
+            with torch.no_grad():
+                src = torch.randn(B, H, W, 64, device='cuda', generator=g)
+                w0 = ops.pack_weight(torch.randn(C, 64, 3, 3, device='cuda', generator=g) * 0.1)
+                raw = ops.conv2d(src, w0, None, 1, 1, dead_bias=True)
+                n1 = ops.instance_norm(raw, gamma, beta, act=L.ACT_RELU)
+                n2 = ops.instance_norm(raw.clone(), gamma, beta, act=L.ACT_RELU)
+                raw = ops.conv2d(src, w0, None, 1, 1, dead_bias=True)
+                y1 = ops.conv2d_after_norm(raw, gamma, beta, w, bias, first=first)
+                y2 = ops.conv2d_after_norm(raw.clone(), gamma, beta, w, bias, first=first)
+            assert (n1 - n2).abs().max().item() <= 2e-5 * n2.abs().max().item()
+            assert (y1 - y2).abs().max().item() <= 1e-4 * y2.abs().max().item()
+    finally:
+        ops.set_precision('f32')
+
