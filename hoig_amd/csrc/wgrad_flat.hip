@@ -64,10 +64,7 @@ __global__ __launch_bounds__(NT) void wgrad_flat_kernel(const WFlatArgs p) {
                         v = *reinterpret_cast<const float4 *>(p.DY + ((size_t)(b * p.Ho + y) * p.Wo + x) * p.Co + c0 + c4 * 4);
                 }
             }
-            rp[i] = v;
-            if (do_bias) {                 // this thread always loads the same four channels (NT % 16 == 0)
-                bsum.x += v.x; bsum.y += v.y; bsum.z += v.z; bsum.w += v.w;
-            }
+            rp[i] = v;       // (the bias sum takes it in store_tiles: wgrad_igemm_bf16.hip, load_tiles)
         }
 #pragma unroll
         for (int i = 0; i < QSL; ++i) {
@@ -82,6 +79,9 @@ __global__ __launch_bounds__(NT) void wgrad_flat_kernel(const WFlatArgs p) {
 #pragma unroll
         for (int i = 0; i < PSL; ++i) {
             const int idx = tid + NT * i;
+            if (do_bias) {                 // this thread always holds the same four channels (NT % 16 == 0); idle slices hold zeros
+                bsum.x += rp[i].x; bsum.y += rp[i].y; bsum.z += rp[i].z; bsum.w += rp[i].w;
+            }
             if (idx < PTW * 16) {
                 uint2 hi, lo;
                 split4(rp[i], hi, lo);

@@ -330,10 +330,8 @@ __global__ __launch_bounds__(128 * KS * CM) void wgrad_halo_bf16_kernel(const WH
                 const int pp = idx / C4, c4 = idx % C4;    // pixel of the tile: row pp>>5, column pp&31
                 v = *reinterpret_cast<const float4 *>(dyb + ((size_t)(pp >> 5) * p.W + (pp & 31)) * p.Co + c4 * 4);
             }
-            rp[i] = v;
-            if (do_bias) {                 // this thread always loads the same four channels (NT % C4 == 0)
-                bsum.x += v.x; bsum.y += v.y; bsum.z += v.z; bsum.w += v.w;
-            }
+            rp[i] = v;       // (the bias sum takes it in store_tiles: summed HERE, hipcc turns the branch into a select and every
+                             //  workgroup waits for the loads it has just issued -- vmcnt(0) in front of the step's MFMAs)
         }
         const bool second = p.X2 != nullptr && ci0 >= p.ci1;
         const int ldx = p.X2 ? (second ? p.Ci - p.ci1 : p.ci1) : p.Ci;
@@ -356,6 +354,9 @@ __global__ __launch_bounds__(128 * KS * CM) void wgrad_halo_bf16_kernel(const WH
 #pragma unroll
         for (int i = 0; i < PSL; ++i) {
             const int idx = tid + NT * i;
+            if (do_bias) {                 // this thread always holds the same four channels (NT % C4 == 0); idle slices hold zeros
+                bsum.x += rp[i].x; bsum.y += rp[i].y; bsum.z += rp[i].z; bsum.w += rp[i].w;
+            }
             if (idx < TH * TW * C4) {
                 uint2 hi, lo;
                 if (HOIG_WG_KO & 1) {
