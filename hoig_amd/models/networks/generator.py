@@ -120,7 +120,8 @@ class Generator(ParamTree):
     def _resblock(self, x, name):                                          # generator.py:9-32
         if not torch.is_grad_enabled():
             # inference: the first norm + ReLU are applied by the second convolution's loader (ops.conv2d_after_norm)
-            h = self._conv(x, name + '.main.0', to_norm=True)
+            with ops.small_map_sums():             # (the loader norm below needs h's statistics: the convolution's epilogue leaves them)
+                h = self._conv(x, name + '.main.0', to_norm=True)
             y = ops.conv2d_after_norm(h, self.P[name + '.main.1.weight'], self.P[name + '.main.1.bias'], self.P[name + '.main.3.weight'],
                                       self.P.get(name + '.main.3.bias'), norm_next=True)
             if y is None:

@@ -35,11 +35,26 @@ def _norm_workspace(nfloats, device, take=None):
     return (ws, False) if take is not None else ws
 
 
+_small_sums = [False]
+
+
+@contextlib.contextmanager
+def small_map_sums():
+    """Inside: convolutions whose output feeds a norm leave their channel sums for maps of <= 1024 pixels too -- the caller knows the
+    reader is ops.conv2d_after_norm (inference: the norm is folded into the next convolution's loader and needs the statistics, not the
+    one-launch norm kernel's pass; round 6: 15 statistics launches per forward gone)."""
+    prev, _small_sums[0] = _small_sums[0], True
+    try:
+        yield
+    finally:
+        _small_sums[0] = prev
+
+
 def _conv_stats_workspace(y):
     """Accumulators for the statistics of `y` (a convolution output about to be written), or None when its instance norm would
-    not read them: maps of <= 1024 pixels take the one-launch norm kernel, which computes its own."""
+    not read them: maps of <= 1024 pixels take the one-launch norm kernel, which computes its own (but see small_map_sums)."""
     B, H, W_, C = y.shape
-    if H * W_ <= 1024 or C % 4 or B * 2 * C > (1 << 18):        # (1 << 18: the accumulator pool, norm.hip ACC_POOL)
+    if (H * W_ <= 1024 and not _small_sums[0]) or C % 4 or B * 2 * C > (1 << 18):        # (1 << 18: the accumulator pool, norm.hip ACC_POOL)
         return None
     return _norm_workspace(L.lib.hoig_inorm_workspace_bytes(B, H * W_, C) // 4, y.device)
 
