@@ -58,6 +58,7 @@ _SIGS = {
     'hoig_conv2d_fwd_packed': [ctypes.POINTER(ConvDesc), _vp, _vp, _vp, _vp, _vp, _vp],
     'hoig_conv2d_bwd_data_packed': [ctypes.POINTER(ConvDesc), _vp, _vp, _vp, _vp, _vp],
     'hoig_conv2d_fwd_packed_stats': [ctypes.POINTER(ConvDesc), _vp, _vp, _vp, _vp, _vp, _vp, _vp],
+    'hoig_conv2d_fwd_stats': [ctypes.POINTER(ConvDesc), _vp, _vp, _vp, _vp, _vp, _vp],
     'hoig_conv2d_cat_fwd_packed_stats': [ctypes.POINTER(ConvDesc), _vp, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp],
     'hoig_inorm_stats_from_sums': [_i, _i, _i, _f, _vp, _vp, _vp, _vp],
     'hoig_conv2d_bwd_data_packed_add': [ctypes.POINTER(ConvDesc), _vp, _vp, _vp, _vp, _vp, _vp],

@@ -589,7 +589,7 @@ int hoig_conv_small_fwd_acts(const hoig_conv_desc *d, const float *x, const floa
 int hoig_conv_head7_m16(const hoig_conv_desc *d, const float *x, const float *w, const float *bias, float *y, unsigned long long acts,
                         hipStream_t st);                  // conv_head16.hip
 // conv_thin.hip: stride-1 'same' convolutions with <= 8 (3x3: 16) channels on one side, taps in place of the missing channels
-int hoig_conv_thin_fwd(const hoig_conv_desc *d, const float *x, const float *w, const float *bias, float *y, hipStream_t st);
+int hoig_conv_thin_fwd(const hoig_conv_desc *d, const float *x, const float *w, const float *bias, float *y, hipStream_t st, float *stats = nullptr);
 int hoig_conv_thin_dgrad(const hoig_conv_desc *d, const float *dy, const float *w, float *dx, int accumulate, hipStream_t st);
 int hoig_conv_thin_wgrad(const hoig_conv_desc *d, const float *x, const float *dy, float *dw, hipStream_t st);
 int hoig_conv_thin_out(const hoig_conv_desc *d, const float *x, const float *w, const float *bias, float *y,
@@ -627,6 +627,18 @@ extern "C" int hoig_conv2d_fwd(const hoig_conv_desc *d, const float *x, const fl
     a.M = d->B * d->Ho * d->Wo; a.N = d->Co; a.K = d->R * d->S * d->Ci;
     a.act = d->act; a.slope = d->slope;
     return dispatch_igemm(a, false, st);
+}
+
+// hoig_conv2d_fwd + the per-image channel sums of y for the instance norm that follows (include/hoig_kernels.h), for the layers
+// hoig_conv2d_fwd_packed_stats does not reach: the thin-INPUT convolutions (the 7x7 stems: 3 / 8 -> 64 channels at full resolution,
+// where the statistics pass re-reads the largest tensor of the network).  HOIG_EUNSUPPORTED otherwise.
+extern "C" int hoig_conv2d_fwd_stats(const hoig_conv_desc *d, const float *x, const float *w, const float *bias, float *y, float *stats,
+                                     hoig_stream_t stream) {
+    int rc = check_desc(d);
+    if (rc) return rc;
+    if (!x || !w || !y || !stats) return HOIG_EINVAL;
+    if (!thin_enabled()) return HOIG_EUNSUPPORTED;
+    return hoig_conv_thin_fwd(d, x, w, bias, y, (hipStream_t)stream, stats);
 }
 
 // forward of a convolution with <= 16 output channels and a different activation per output channel (the generator's fused

@@ -44,6 +44,7 @@ struct ThinArgs {
     int K, KP, N, NP;        // K = KS*KS*F (gemm reduction, padded to 16) ; N = the same count as wgrad's columns (padded to 32)
     int tiles_x, tiles_y, ntiles, strip;
     int HR, CW;              // halo image: rows, row pitch (elements)
+    float *stats;            // gemm forward (nullable): per image [sum | sum of squares][CD] of the stored values, added atomically
 };
 
 template <bool FP16>
@@ -198,9 +199,31 @@ __global__ __launch_bounds__(NTHR) void thin_gemm_kernel(const ThinArgs p) {
         tile_coords(p, blockIdx.x * p.strip, b, y0, x0);
         halo_load(p, hmap, b, y0, x0, hreg);
     }
+    // channel sums for the instance norm that follows (the 7x7 stems: hoig_conv2d_fwd_stats): lane = channel, accumulated over the tiles of
+    // ONE image (a workgroup's strip rarely crosses an image) and added atomically when the image changes and at the end
+    float st1[2] = {0.f, 0.f}, st2[2] = {0.f, 0.f};
+    int sb = -1;
+    auto flush_stats = [&]() {
+        if (sb >= 0) {
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                const float s1 = st1[j] + __shfl_xor(st1[j], 32), s2 = st2[j] + __shfl_xor(st2[j], 32);
+                if (lh == 0) {
+                    float *dst = p.stats + (size_t)sb * 2 * p.CD + cbase + j * 32 + l31;
+                    atomicAdd(dst, s1);
+                    atomicAdd(dst + p.CD, s2);
+                }
+                st1[j] = st2[j] = 0.f;
+            }
+        }
+    };
     for (int t = blockIdx.x * p.strip; t < t_end; ++t) {
         int b, y0, x0;
         tile_coords(p, t, b, y0, x0);
+        if (p.stats && b != sb) {
+            flush_stats();
+            sb = b;
+        }
         __syncthreads();                                                 // the previous tile's reads (and the tables) are done
         halo_store<FP16, NT>(p, hmap, hreg, Tl);
         __syncthreads();
@@ -245,9 +268,12 @@ __global__ __launch_bounds__(NTHR) void thin_gemm_kernel(const ThinArgs p) {
                 v = fast_act(v, nslope, special, p.act, p.slope);
                 if (p.accumulate) v += dst[j * 32];
                 dst[j * 32] = v;
+                st1[j] += v;
+                st2[j] += v * v;
             }
         }
     }
+    if (p.stats) flush_stats();
 }
 
 // --------------------------------------------------------------------------------------------------------------- wgrad
@@ -641,7 +667,7 @@ void fill_common(ThinArgs &a, const hoig_conv_desc *d, int F, int CD) {
     a.ntiles = d->B * a.tiles_x * a.tiles_y;
     a.HR = TH + d->R - 1;
     a.CW = (TW + d->R - 1 + 8 + 1) & ~1;            // (+8: a fragment's eight-pixel run may start in the last columns)
-    a.bias = nullptr; a.act = HOIG_ACT_NONE; a.slope = 0.f; a.accumulate = 0; a.wscale = 1.f; a.strip = 1; a.Ws = nullptr;
+    a.bias = nullptr; a.act = HOIG_ACT_NONE; a.slope = 0.f; a.accumulate = 0; a.wscale = 1.f; a.strip = 1; a.Ws = nullptr; a.stats = nullptr;
 }
 
 template <bool FP16>
@@ -694,11 +720,11 @@ int launch_wgrad_t(const ThinArgs &a, int nt, int nd, dim3 grid, size_t smem, hi
 }  // namespace
 
 // forward of a thin-INPUT convolution (Ci <= 8, Co % 64 == 0); HOIG_EUNSUPPORTED otherwise
-int hoig_conv_thin_fwd(const hoig_conv_desc *d, const float *x, const float *w, const float *bias, float *y, hipStream_t st) {
+int hoig_conv_thin_fwd(const hoig_conv_desc *d, const float *x, const float *w, const float *bias, float *y, hipStream_t st, float *stats) {
     if (d->precision == HOIG_PREC_F32 || !thin_geometry(d) || d->Ci > (d->R <= 3 ? 12 : 8) || d->Ci < 1 || (d->Co % 64)) return HOIG_EUNSUPPORTED;
     ThinArgs a;
     fill_common(a, d, d->Ci, d->Co);
-    a.T = x; a.D = w; a.bias = bias; a.Out = y;
+    a.T = x; a.D = w; a.bias = bias; a.Out = y; a.stats = stats;
     a.flip = 0;
     a.sj = d->R * d->S * d->Ci; a.st = d->Ci; a.sf = 1;                  // w[co][tap][ci]
     a.act = d->act; a.slope = d->slope;

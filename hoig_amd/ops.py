@@ -1130,6 +1130,14 @@ def _conv_fwd_raw(d, x, w, b, y, transposed=False, norm_next=False):
     ws = None
     if norm_next and d.precision != L.PREC_F32 and d.Ci % 32 == 0 and d.Co % 32 == 0 and d.Co > 32:
         ws = _conv_stats_workspace(y)
+    elif norm_next and d.precision != L.PREC_F32 and not transposed and d.Ci <= 12 and d.Co % 64 == 0 and d.stride == 1:
+        ws0 = _conv_stats_workspace(y)              # the 7x7 stems (thin input): hoig_conv2d_fwd_stats
+        if ws0 is not None:
+            rc = L.lib.hoig_conv2d_fwd_stats(ctypes.byref(_x3(d)), _p(x), _p(w), _p(b), _p(y), _p(ws0), _st())
+            if rc != L.EUNSUPPORTED:
+                L.check(rc, 'hoig_conv2d_fwd_stats')
+                _stats_offer(y)
+                return
     if d.precision == L.PREC_F16F6:
         if (not transposed and d.R == 3 and d.S == 3 and d.stride == 1 and d.pad == 1 and d.Ci % 64 == 0 and d.Co % 64 == 0
                 and d.Hi % 8 == 0 and d.Wi % 32 == 0):

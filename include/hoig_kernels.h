@@ -178,6 +178,12 @@ int hoig_conv2d_fwd_packed_stats(const hoig_conv_desc *d, const float *x, const 
 int hoig_conv2d_cat_fwd_packed_stats(const hoig_conv_desc *d, const float *x1, int C1, const float *x2, const uint16_t *w_hi,
                                      const uint16_t *w_lo, const float *bias /*nullable*/, float *y, float *stats,
                                      hoig_stream_t stream);
+/* The same for the layers the packed kernels do not take: hoig_conv2d_fwd (unpacked weights) with the sums, HOIG_EUNSUPPORTED unless
+ * the layer is a thin-INPUT convolution on the MFMA path (Ci <= 8 (12 for 3x3), Co % 64 == 0, odd square stride-1 "same" kernel,
+ * Hi % 4 == 0, Wi % 32 == 0, a 16-bit precision): the generator's 7x7 stems (generator.py:100,262), whose output is the largest
+ * tensor an instance norm's statistics pass would re-read. */
+int hoig_conv2d_fwd_stats(const hoig_conv_desc *d, const float *x, const float *w, const float *bias /*nullable*/, float *y, float *stats,
+                          hoig_stream_t stream);
 /* dx = data gradient + addend (addend: the gradient that reaches the same tensor through its OTHER consumer, e.g. the skip path of
  * a residual block, generator.py:29-32 `x + self.main(x)`; torch's autograd engine sums the two in a separate pass).  Returns
  * HOIG_EUNSUPPORTED for layers whose kernel has no such epilogue (everything but stride-1 "same" 1x1/3x3/5x5 and stride-2 3x3 on the halo kernels): the

@@ -424,3 +424,41 @@ def test_inference_norm_applied_by_the_f6_loader_and_sums_left_by_its_epilogue(c
     finally:
         ops.set_precision('f32')
 
+
+@pytest.mark.parametrize('Ci,B', [(3, 2), (8, 3)])
+def test_stem_convolution_leaves_channel_sums_for_its_norm(Ci, B):
+    """hoig_conv2d_fwd_stats (conv_thin.hip): the 7x7 stems (3 / 8 -> 64 channels at full resolution, generator.py:100,262) accumulate
+    the per-image channel sums of their output in the epilogue, over a workgroup's strip of tiles; the instance norm that follows takes
+    them instead of re-reading the largest tensor of the network.  Against the entry point without sums (same kernel: equal bits),
+    against fp64 sums of the stored tensor, and through ops (conv2d(.., dead_bias=True) -> instance_norm)."""
+    from hoig_amd import _lib as L, ops
+    ops.set_precision('bf16x3:f16x2')
+    try:
+        g = torch.Generator(device='cuda').manual_seed(5 + Ci)
+        H = W = 128
+        x = torch.randn(B, H, W, Ci, device='cuda', generator=g)
+        w = ops.pack_weight(torch.randn(64, Ci, 7, 7, device='cuda', generator=g) * 0.1)
+        bias = torch.randn(64, device='cuda', generator=g)
+        d = L.ConvDesc(B, H, W, Ci, H, W, 64, 7, 7, 1, 3, 0, L.ACT_NONE, 0.0, L.PREC_BF16X3)
+        st = torch.cuda.current_stream().cuda_stream
+        _p = lambda t: None if t is None else ctypes.c_void_p(t.data_ptr())
+        y0, y1 = torch.empty(B, H, W, 64, device='cuda'), torch.empty(B, H, W, 64, device='cuda')
+        sums = torch.zeros(B, 2, 64, device='cuda')
+        L.call('hoig_conv2d_fwd', ctypes.byref(d), _p(x), _p(w), _p(bias), _p(y0), st)
+        assert L.lib.hoig_conv2d_fwd_stats(ctypes.byref(d), _p(x), _p(w), _p(bias), _p(y1), _p(sums), st) == L.OK
+        torch.cuda.synchronize()
+        assert torch.equal(y0, y1)
+        assert rel_err(sums[:, 0].double(), y1.double().sum((1, 2))) < 1e-5
+        assert rel_err(sums[:, 1].double(), (y1.double() ** 2).sum((1, 2))) < 1e-5
+        yr = F.conv2d(x.permute(0, 3, 1, 2), w, bias, padding=3).permute(0, 2, 3, 1)
+        assert rel_err(y1, yr) < 3e-4
+        gamma, beta = torch.rand(64, device='cuda', generator=g) + 0.5, torch.randn(64, device='cuda', generator=g)
+        with torch.no_grad():
+            raw = ops.conv2d(x, w, bias, 1, 3, dead_bias=True)
+            n1 = ops.instance_norm(raw, gamma, beta, act=L.ACT_RELU)            # (takes the sums the stem left)
+            n2 = ops.instance_norm(raw.clone(), gamma, beta, act=L.ACT_RELU)    # (a copy: its own statistics pass)
+        assert torch.equal(raw, y1)
+        assert (n1 - n2).abs().max().item() <= 2e-5 * n2.abs().max().item()
+    finally:
+        ops.set_precision('f32')
+
