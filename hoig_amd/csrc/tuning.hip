@@ -20,6 +20,7 @@ Entry g_table[HOIG_TUNE_COUNT] = {
     {"wdma16", 2},
     {"s2_pipe", 1},
     {"norm_in", 1},
+    {"wino8", 0},
 };
 }  // namespace
 

@@ -1113,6 +1113,30 @@ def _f6_planes(w):
     return qh, ql
 
 
+_wino_cache = {}
+
+
+def _wino_planes(w):
+    """Winograd-transformed fp16 hi / lo planes of a 3x3 conv weight (hoig_pack_conv_weight_wino), re-made when the owner's weights change."""
+    co, ci = w.shape[0], w.shape[1]
+    owner = getattr(w, '_hoig_owner', None)
+    ver = owner.version if owner is not None else None
+    key = (w.data_ptr(), tuple(w.shape))
+    hit = _wino_cache.get(key)
+    if hit is not None and ver is not None and hit[0] == ver:
+        return hit[1], hit[2]
+    if hit is not None:
+        uh, ul = hit[1], hit[2]
+    else:
+        n = L.lib.hoig_wino_plane_halfs(co, ci)
+        uh = torch.empty(n, dtype=torch.int16, device=w.device)
+        ul = torch.empty(n, dtype=torch.int16, device=w.device)
+    call('hoig_pack_conv_weight_wino', _p(w), co, ci, _p(uh), _p(ul), _st())
+    if ver is not None:
+        _wino_cache[key] = (ver, uh, ul)
+    return uh, ul
+
+
 def _x3(d):
     """The descriptor of a launch that the fp6 forward kernel does not cover: the same arithmetic on three fp16 terms."""
     if d.precision != L.PREC_F16F6:
@@ -1151,6 +1175,15 @@ def _conv_fwd_raw(d, x, w, b, y, transposed=False, norm_next=False):
                     _stats_offer(y)
                 return
         d = _x3(d)
+    if (ws is None and d.precision == L.PREC_BF16X3 and not transposed and d.R == 3 and d.S == 3 and d.stride == 1 and d.pad == 1
+            and d.Ci % 32 == 0 and d.Co % 64 == 0 and d.Hi % 16 == 0 and d.Wi % 16 == 0 and L.lib.hoig_set_tuning(b'wino8', -1) == 1
+            and d.B * (d.Hi // 16) * (d.Wi // 16) * (d.Co // 64) <= 256 and d.B * (d.Hi // 8) * ((d.Wi + 31) // 32) * ((d.Co + 127) // 128) <= 128):
+        # tuning key wino8 (off by default): half-chip launches of the direct kernel that ONE round of the Winograd kernel covers
+        uh, ul = _wino_planes(w)
+        rc = L.lib.hoig_conv2d_fwd_wino(ctypes.byref(d), _p(x), _p(uh), _p(ul), _p(b), _p(y), _st())
+        if rc != L.EUNSUPPORTED:
+            L.check(rc, 'hoig_conv2d_fwd_wino')
+            return
     if ws is not None:
         hi, lo = _packed_planes(w, transposed, False)
         rc = L.lib.hoig_conv2d_fwd_packed_stats(ctypes.byref(d), _p(x), _p(hi), _p(lo), _p(b), _p(y), _p(ws), _st())

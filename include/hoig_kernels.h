@@ -570,6 +570,11 @@ const char *hoig_version(void);
  *   "split_grads" 1  (read by the host side, hoig_amd/ops.py) the backward of a norm that follows an eligible 3x3 convolution writes its
  *                dx as bf16 hi | lo planes and that convolution's weight / data gradient read them without splitting ('PRE-SPLIT
  *                gradients' above); 0: fp32 gradients everywhere, split in every consuming workgroup
+ *   "wino8"    0  (read by the host side, hoig_amd/ops.py _conv_fwd_raw; round 6) 1: three-term FORWARD launches of 3x3 stride-1 layers that
+ *                the direct kernel would run on at most half the chip (<= 128 workgroups) and that ONE round of the Winograd F(2x2,3x3)
+ *                kernel covers (<= 256 workgroups: 8 images of 512 -> 512 at 32 x 32) go to hoig_conv2d_fwd_wino.  Alone such a launch
+ *                is 37 % faster; in the step they are the src / tsf twins, which already share the chip
+ *                (profiles/r06_winograd_ab.txt: the in-step A/B); off
  * Round 6 removed the keys whose losing side had lost two rounds running, and with them that side's code: "wgrad16" (the 3x3 weight
  * gradient on 16x16x32: 5-20 % slower, wgrad_halo16.hip deleted), "mfma16" (the 8-row 3x3 stride-1 tilings on 16x16x32: always; their
  * 32x32x16 instantiations are gone), "wgrad_ko" (knock-out instantiations of the LDS-DMA weight gradient:
