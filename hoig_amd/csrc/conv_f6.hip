@@ -30,11 +30,14 @@
 #ifndef HOIG_F6_KO
 #define HOIG_F6_KO 0
 #endif
-// 1: the weight stages go global -> LDS by LDS-DMA (global_load_lds_dwordx4; no staging registers, no ds_write); 0: through
-// registers, one step ahead.  Both are parity-tested; measured on the dominant launch 170.4 us (DMA) against 164.3 us (registers),
-// 117.5 against 113.6 us at 8 images (profiles/r02_f6_knockout.txt): the 28 us that staging costs are not the registers' doing.
+// 1 (default since round 6): the weight stages go global -> LDS by LDS-DMA (global_load_lds_dwordx4 from inline asm with M0 = the piece's
+// LDS address; no staging registers, no ds_write); 0: through registers, one step ahead.  Both are parity-tested.  Round 2 measured the
+// BUILTIN form of the copy 3.7 % slower than the registers (170.4 against 164.3 us on the dominant launch, profiles/r02_f6_knockout.txt):
+// hipcc guards the step's first ds_read with vmcnt(0) for it, so the copy landed in front of the MFMAs.  The asm form (conv_halo16.hip's
+// WDMA recipe) rides behind them: 137.0 -> 134.4 us at 16 images, 262.0 -> 256.5 at 32, 516.9 -> 505.6 at 64 (alternating libraries,
+// profiles/r06_f6_ab.txt), generator forward 2.21-2.22 -> 2.19-2.22 ms per image.
 #ifndef HOIG_F6_DMA
-#define HOIG_F6_DMA 0
+#define HOIG_F6_DMA 1
 #endif
 
 namespace {
@@ -239,18 +242,24 @@ __global__ __launch_bounds__(NT) void conv_halo3_f6_kernel(const F6Args p) {
         const int cb = step / 9, tap = step - cb * 9;
         const size_t koff = (size_t)(tap * p.Cg + cb * 64) * 32;
         const size_t rec0 = ((size_t)(tap * ncb + cb) * p.N + n0) * REC;
-        unsigned char *B = Bbase + buf * B_STAGE + wave * 1024;
-        typedef const __attribute__((address_space(1))) void *gptr;
-        typedef __attribute__((address_space(3))) void *lptr;
+        // (inline asm, M0 = the piece's LDS address: through the builtin hipcc guards the step's first ds_read with vmcnt(0) and the copy
+        //  lands BEFORE the MFMAs instead of behind them -- conv_halo16.hip's WDMA recipe)
+        const unsigned to0 = __builtin_amdgcn_readfirstlane(
+            (unsigned)(size_t)(__attribute__((address_space(3))) unsigned char *)(Bbase + buf * B_STAGE + wave * 1024));
+        auto dma16 = [&](const void *src, unsigned to) {
+            unsigned keep;
+            asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+                         : "=&s"(keep) : "v"(src), "s"(to) : "memory");
+        };
         if (wave * 16 < BN) {                                   // 16 rows of 64 B per wave-instruction
             const unsigned short *src = p.Wh + ((size_t)((n0 >> 5) + (tid >> 7)) * (p.K >> 5)) * 1024 + koff + (tid & 127) * 8;
-            __builtin_amdgcn_global_load_lds((gptr)src, (lptr)B, 16, 0, 0);
-            __builtin_amdgcn_global_load_lds((gptr)(src + 1024), (lptr)(B + BN * 64), 16, 0, 0);
+            dma16(src, to0);
+            dma16(src + 1024, to0 + BN * 64);
         }
         if (wave * 1024 < B_Q) {                                // 7168 B = 7 wave-instructions per record array (BN = 64: 3.5)
             if (tid < QCHUNKS) {
-                __builtin_amdgcn_global_load_lds((gptr)(p.Qh + rec0 + (size_t)tid * 16), (lptr)(B + B_HI), 16, 0, 0);
-                __builtin_amdgcn_global_load_lds((gptr)(p.Ql + rec0 + (size_t)tid * 16), (lptr)(B + B_HI + B_Q), 16, 0, 0);
+                dma16(p.Qh + rec0 + (size_t)tid * 16, to0 + B_HI);
+                dma16(p.Ql + rec0 + (size_t)tid * 16, to0 + B_HI + B_Q);
             }
         }
     };
