@@ -80,3 +80,38 @@ def test_wino_refuses_what_it_has_no_tiling_for():
     assert L.lib.hoig_conv2d_fwd_wino(ctypes.byref(d), _p(x), _p(uh), _p(uh), None, _p(y), 0) == L.EUNSUPPORTED       # H % 16
     d = L.ConvDesc(1, 16, 16, 32, 16, 16, 64, 3, 3, 1, 1, 0, 0, 0.0, L.PREC_F32)
     assert L.lib.hoig_conv2d_fwd_wino(ctypes.byref(d), _p(x), _p(uh), _p(uh), None, _p(y), 0) == L.EUNSUPPORTED       # arithmetic
+
+
+def test_tuning_key_wino8_routes_the_half_chip_forward_launches_and_leaves_the_backward_alone():
+    """hoig_set_tuning('wino8', 1): ops.conv2d sends a three-term 3x3 forward that the direct kernel would run on half the chip and one
+    Winograd round covers (8 images of 512 -> 512 at 32 x 32) to hoig_conv2d_fwd_wino -- same outputs to the arithmetic's floor, the
+    backward (direct kernels) unchanged; a launch outside that window (16 images) is not touched: equal bits with the key on or off."""
+    from hoig_amd import ops, _lib as L
+    ops.set_precision('bf16x3:f16x2')
+    prev = L.set_tuning('wino8', 0)
+    try:
+        g = torch.Generator(device='cuda').manual_seed(77)
+        w = ops.pack_weight(torch.randn(512, 512, 3, 3, device='cuda', generator=g) * 0.03).requires_grad_(True)
+        bias = torch.randn(512, device='cuda', generator=g).requires_grad_(True)
+        res = {}
+        for B in (8, 16):
+            x = torch.randn(B, 32, 32, 512, device='cuda', generator=g)
+            gy = torch.randn(B, 32, 32, 512, device='cuda', generator=g)
+            for key in (0, 1):
+                L.set_tuning('wino8', key)
+                xd = x.clone().requires_grad_(True)
+                w.grad = bias.grad = None
+                y = ops.conv2d(xd, w, bias, 1, 1)
+                y.backward(gy)
+                torch.cuda.synchronize()
+                res[B, key] = (y.detach().clone(), xd.grad.clone(), w.grad.clone(), bias.grad.clone())
+        y0, dx0, dw0, db0 = res[8, 0]
+        y1, dx1, dw1, db1 = res[8, 1]
+        assert not torch.equal(y0, y1), 'the key did not change the forward kernel'
+        assert rel_err(y1, y0) < 2e-5
+        assert rel_err(dx1, dx0) < 1e-5 and rel_err(dw1, dw0) < 1e-4 and rel_err(db1, db0) < 1e-4      # (fp32 atomics: summation order)
+        assert torch.equal(res[16, 0][0], res[16, 1][0])
+    finally:
+        L.set_tuning('wino8', prev)
+        ops.set_precision('f32')
+
