@@ -35,7 +35,7 @@
 // BUILTIN form of the copy 3.7 % slower than the registers (170.4 against 164.3 us on the dominant launch, profiles/r02_f6_knockout.txt):
 // hipcc guards the step's first ds_read with vmcnt(0) for it, so the copy landed in front of the MFMAs.  The asm form (conv_halo16.hip's
 // WDMA recipe) rides behind them: 137.0 -> 134.4 us at 16 images, 262.0 -> 256.5 at 32, 516.9 -> 505.6 at 64 (alternating libraries,
-// profiles/r06_f6_ab.txt), generator forward 2.21-2.22 -> 2.19-2.22 ms per image.
+// profiles/r06_f6_ab.txt), generator forward 2.21-2.22 -> 2.17-2.22 ms per image.
 #ifndef HOIG_F6_DMA
 #define HOIG_F6_DMA 1
 #endif
